@@ -1,0 +1,1124 @@
+// =====================================================================================
+// bmq_oracle.cpp -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// A structural + semantic restatement of apache/bifromq's topic-match arithmetic, used as
+// the checker for the MI355X engine.  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load this library; the product (bifromq_amd/) never does.
+//
+// Parity pinning: the reference is Java and cannot run in this image (no JDK), so this
+// restatement is pinned against the reference's own golden vectors / known-answer tests,
+// ported in tests/test_oracle_golden.py (see SURVEY.md section 8c for the list).
+//
+// Paths below are relative to the reference root; shorthands:
+//   TRIE/   = bifromq-dist/bifromq-dist-coproc-proto/src/main/java/org/apache/bifromq/dist/trie/
+//   TRIET/  = bifromq-dist/bifromq-dist-coproc-proto/src/test/java/org/apache/bifromq/dist/
+//   DW/     = bifromq-dist/bifromq-dist-worker/src/main/java/org/apache/bifromq/dist/worker/
+//   SCHEMA/ = bifromq-dist/bifromq-dist-worker-schema/src/main/java/org/apache/bifromq/dist/worker/schema/
+//   UTIL/   = bifromq-util/src/main/java/org/apache/bifromq/util/
+//   RS/     = bifromq-retain/bifromq-retain-store/src/main/java/org/apache/bifromq/retain/store/
+//
+// Documented deviation: Java compares level names with String.compareTo (UTF-16 code
+// units); this file compares UTF-8 bytes.  The two orders agree on the BMP minus
+// surrogates, which is all MQTT ingress admits (UTIL/UTF8Util.java:50), and the KV store
+// itself orders keys by UTF-8 bytes.
+// =====================================================================================
+#include <algorithm>
+#include <atomic>
+#include <cassert>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+using Levels = std::vector<std::string>;
+static const std::string NUL(1, '\0');          // UTIL/TopicConst.java:29
+static const std::string SINGLE_WILDCARD = "+"; // UTIL/TopicConst.java:32
+static const std::string MULTI_WILDCARD = "#";  // UTIL/TopicConst.java:33
+
+// ---- UTIL/TopicUtil.java:206-225 parse(): split on '/' (or NUL when escaped), keep empties
+static Levels parse(const std::string& topic, bool escaped) {
+    const char splitter = escaped ? '\0' : '/';
+    Levels out;
+    std::string tl;
+    for (char c : topic) {
+        if (c == splitter) {
+            out.push_back(tl);
+            tl.clear();
+        } else {
+            tl.push_back(c);
+        }
+    }
+    out.push_back(tl);
+    return out;
+}
+
+static std::string join(const Levels& l, char sep) {
+    std::string s;
+    for (size_t i = 0; i < l.size(); i++) {
+        if (i) s.push_back(sep);
+        s += l[i];
+    }
+    return s;
+}
+
+static bool starts_with_sys(const std::string& s) { return !s.empty() && s[0] == '$'; }
+
+// =====================================================================================
+// (A) semantic matcher -- TRIET/TopicMatcher.java:39-101 (the reference's own brute-force
+//     test matcher), restated line by line.
+// =====================================================================================
+static bool semantic_match(const Levels& topicLevels, const Levels& filterLevels) {
+    bool matched = false;
+    size_t hasMatched = 0;
+    size_t n = std::min(topicLevels.size(), filterLevels.size());
+    for (size_t i = 0; i < n; i++) {
+        const std::string& topicLevel = topicLevels[i];
+        const std::string& filterLevel = filterLevels[i];
+        if (filterLevel == MULTI_WILDCARD) {
+            if (i == 0 && starts_with_sys(topicLevel)) break;
+            hasMatched++;
+            matched = true;
+            break;
+        } else if (filterLevel == SINGLE_WILDCARD) {
+            if (i == 0 && starts_with_sys(topicLevel)) break;
+            hasMatched++;
+            if (hasMatched == topicLevels.size()) {
+                if (topicLevels.size() == filterLevels.size()) { matched = true; break; }
+                if (topicLevels.size() + 1 == filterLevels.size() && filterLevels[i + 1] == MULTI_WILDCARD) {
+                    matched = true;
+                    break;
+                }
+            }
+        } else {
+            if (topicLevel == filterLevel) {
+                hasMatched++;
+                if (hasMatched == topicLevels.size()) {
+                    if (topicLevels.size() == filterLevels.size()) { matched = true; break; }
+                    if (topicLevels.size() + 1 == filterLevels.size() && filterLevels[i + 1] == MULTI_WILDCARD) {
+                        matched = true;
+                        break;
+                    }
+                }
+            } else {
+                break;
+            }
+        }
+    }
+    return matched;
+}
+
+// ---- TRIET/TestUtil.java:184-201 toFilters(): the three candidates for one level, in order
+static std::vector<Levels> to_filters(const std::string& topicLevel) {
+    std::vector<Levels> f;
+    if (MULTI_WILDCARD.compare(topicLevel) > 0) {
+        f.push_back({topicLevel}); f.push_back({MULTI_WILDCARD}); f.push_back({SINGLE_WILDCARD});
+    } else if (SINGLE_WILDCARD.compare(topicLevel) > 0) {
+        f.push_back({MULTI_WILDCARD}); f.push_back({topicLevel}); f.push_back({SINGLE_WILDCARD});
+    } else {
+        f.push_back({MULTI_WILDCARD}); f.push_back({SINGLE_WILDCARD}); f.push_back({topicLevel});
+    }
+    return f;
+}
+
+// ---- TRIET/TestUtil.java:70-107 expand(): ordered expansion set of one (local) topic.
+// Known quirk kept on purpose: "x//#" style entries for a topic ending in an
+// empty level are omitted here but emitted by the iterator; iterator + Fixtures win.
+static std::vector<std::string> test_expand(const std::string& topic) {
+    Levels topicLevels = parse(topic, false);
+    std::vector<std::string> out;
+    std::vector<Levels> toVisit; // used as a deque with front at index 0
+    const std::string& rootLevel = topicLevels[0];
+    if (starts_with_sys(rootLevel)) toVisit.push_back({rootLevel});
+    else toVisit = to_filters(rootLevel);
+    while (!toVisit.empty()) {
+        Levels cur = toVisit.front();
+        toVisit.erase(toVisit.begin());
+        if (cur.back() == MULTI_WILDCARD) {
+            out.push_back(join(cur, '\0'));
+        } else if (cur.size() == topicLevels.size()) {
+            std::string tf = join(cur, '\0');
+            out.push_back(tf);
+            if (!cur.back().empty()) out.push_back(tf + NUL + MULTI_WILDCARD);
+        } else {
+            std::vector<Levels> nxt = to_filters(topicLevels[cur.size()]);
+            for (auto it = nxt.rbegin(); it != nxt.rend(); ++it) {
+                Levels f = cur;
+                f.insert(f.end(), it->begin(), it->end());
+                toVisit.insert(toVisit.begin(), f);
+            }
+        }
+    }
+    return out;
+}
+
+// =====================================================================================
+// (B) structural restatement: TopicTrieNode + TopicFilterIterator + N/S/M filter nodes
+// =====================================================================================
+
+// ---- TRIE/TopicTrieNode.java:37-163
+struct TopicTrieNode {
+    std::string levelName;
+    bool wildcardMatchable = false;
+    std::map<std::string, TopicTrieNode*> children; // TreeMap<String, TopicTrieNode>
+    std::set<int> values;                           // Set<V>; V = caller's topic index
+    Levels topic;
+    bool isUserTopic() const { return !values.empty(); }
+};
+
+struct TopicTrie {
+    bool isGlobal;
+    std::vector<std::unique_ptr<TopicTrieNode>> arena;
+    TopicTrieNode* root;
+    explicit TopicTrie(bool g) : isGlobal(g) {
+        arena.emplace_back(new TopicTrieNode());
+        root = arena.back().get();
+        root->levelName = NUL; // TopicTrieNode.java:48-50
+        root->wildcardMatchable = false;
+    }
+    // TopicTrieNode.java:135-161 Builder.addTopic/addChild
+    void addTopic(const Levels& topicLevels, int value) {
+        if (topicLevels.empty()) return;
+        TopicTrieNode* node = root;
+        for (size_t level = 0; level < topicLevels.size(); level++) {
+            const std::string& levelName = topicLevels[level];
+            bool wm = isGlobal ? (level > 1 || (level == 1 && !starts_with_sys(levelName)))
+                               : (level > 0 || !starts_with_sys(levelName));
+            auto it = node->children.find(levelName);
+            TopicTrieNode* child;
+            if (it == node->children.end()) {
+                arena.emplace_back(new TopicTrieNode());
+                child = arena.back().get();
+                child->levelName = levelName;
+                child->wildcardMatchable = wm;
+                node->children.emplace(levelName, child);
+            } else {
+                child = it->second;
+            }
+            if (level == topicLevels.size() - 1) {
+                child->topic = topicLevels;
+                child->values.insert(value);
+            }
+            node = child;
+        }
+    }
+};
+
+// ---- TRIE/NTopicFilterTrieNode.java:118-222, TRIE/STopicFilterTrieNode.java:117-217,
+//      TRIE/MTopicFilterTrieNode.java:105-135 (object pools dropped: they do not change results)
+struct FNode {
+    enum Kind { N, S, M } kind = N;
+    FNode* parent = nullptr;
+    std::string levelName_;
+    std::set<std::string> subLevelNames;                                // TreeSet<String>
+    std::map<std::string, std::set<TopicTrieNode*>> subTopicTrieNodes;  // TreeMap
+    std::set<TopicTrieNode*> subWildcardMatchable;
+    std::set<TopicTrieNode*> backingTopics;
+    bool hasSub = false; // subLevelName != null
+    std::string subLevelName;
+
+    const std::string& levelName() const { return levelName_; }
+
+    static void collectTopics(TopicTrieNode* node, std::set<TopicTrieNode*>& out) {
+        if (node->isUserTopic()) out.insert(node);
+        for (auto& kv : node->children) collectTopics(kv.second, out);
+    }
+
+    static FNode* makeNS(Kind k, FNode* parent, const std::string& levelName,
+                         const std::set<TopicTrieNode*>& siblings) {
+        FNode* n = new FNode();
+        n->kind = k;
+        n->parent = parent;
+        n->levelName_ = (k == S) ? SINGLE_WILDCARD : levelName;
+        for (TopicTrieNode* sibling : siblings) {
+            if (sibling->isUserTopic()) n->backingTopics.insert(sibling);
+            for (auto& e : sibling->children) {
+                TopicTrieNode* sub = e.second;
+                if (sub->wildcardMatchable) n->subWildcardMatchable.insert(sub);
+                n->subTopicTrieNodes[sub->levelName].insert(sub);
+                n->subLevelNames.insert(sub->levelName);
+            }
+        }
+        if (!n->backingTopics.empty()) n->subLevelNames.insert(MULTI_WILDCARD); // "# match parent"
+        if (!n->subWildcardMatchable.empty()) {
+            n->subLevelNames.insert(MULTI_WILDCARD);
+            n->subLevelNames.insert(SINGLE_WILDCARD);
+        }
+        n->seekChild("");
+        return n;
+    }
+    static FNode* makeM(FNode* parent, const std::set<TopicTrieNode*>& siblings) {
+        FNode* n = new FNode();
+        n->kind = M;
+        n->parent = parent;
+        n->levelName_ = MULTI_WILDCARD;
+        if (parent) n->backingTopics = parent->backingTopics;
+        for (TopicTrieNode* s : siblings) collectTopics(s, n->backingTopics);
+        return n;
+    }
+    void seekChild(const std::string& name) {
+        if (kind == M) return;
+        if (!subLevelNames.empty()) {
+            auto it = subLevelNames.lower_bound(name); // ceiling
+            hasSub = it != subLevelNames.end();
+            if (hasSub) subLevelName = *it;
+        }
+    }
+    bool atValidChild() const { return kind != M && hasSub; }
+    void nextChild() {
+        if (kind == M) return;
+        if (hasSub) {
+            auto it = subLevelNames.upper_bound(subLevelName); // higher
+            hasSub = it != subLevelNames.end();
+            if (hasSub) subLevelName = *it;
+        }
+    }
+    FNode* childNode() {
+        assert(atValidChild());
+        if (subLevelName == MULTI_WILDCARD) return makeM(this, subWildcardMatchable);
+        if (subLevelName == SINGLE_WILDCARD) return makeNS(S, this, "", subWildcardMatchable);
+        return makeNS(N, this, subLevelName, subTopicTrieNodes[subLevelName]);
+    }
+    // TRIE/TopicFilterTrieNode.java:68-78
+    Levels topicFilterPrefix() const {
+        if (!parent) return {};
+        Levels p = parent->topicFilterPrefix();
+        if (parent->levelName() != NUL) p.push_back(parent->levelName());
+        return p;
+    }
+};
+
+// ---- TRIE/TopicFilterIterator.java:38-311 (seek/next/key/value/isValid; seekPrev/prev are not
+//      on the matchAll path and are not restated)
+struct FilterIterator {
+    std::vector<FNode*> stack;
+    TopicTrieNode* root = nullptr;
+    uint64_t nodesPushed = 0;
+    ~FilterIterator() { clear(); }
+    void clear() {
+        for (FNode* n : stack) delete n;
+        stack.clear();
+    }
+    void pop() {
+        delete stack.back();
+        stack.pop_back();
+    }
+    void push(FNode* n) {
+        stack.push_back(n);
+        nodesPushed++;
+    }
+    void init(TopicTrieNode* r) {
+        root = r;
+        seek({});
+    }
+    void seek(const Levels& filterLevels) { // :61-122
+        clear();
+        push(FNode::makeNS(FNode::N, nullptr, root->levelName, std::set<TopicTrieNode*>{root}));
+        int i = -1;
+        const int n = (int)filterLevels.size();
+        bool out = false;
+        while (!out && !stack.empty() && i < n) {
+            const std::string& levelNameToSeek = (i == -1) ? NUL : filterLevels[i];
+            i++;
+            FNode* node = stack.back();
+            int cmp = levelNameToSeek.compare(node->levelName());
+            if (cmp < 0) {
+                break;
+            } else if (cmp == 0) {
+                if (i == n) break;
+                node->seekChild(filterLevels[i]);
+                if (node->atValidChild()) {
+                    push(node->childNode());
+                } else {
+                    pop();
+                    if (stack.empty()) break;
+                    while (!stack.empty()) {
+                        FNode* parent = stack.back();
+                        parent->nextChild();
+                        if (parent->atValidChild()) {
+                            push(parent->childNode());
+                            out = true;
+                            break;
+                        } else {
+                            pop();
+                        }
+                    }
+                }
+            } else {
+                clear();
+            }
+        }
+        while (!stack.empty()) {
+            FNode* node = stack.back();
+            if (node->backingTopics.empty()) {
+                assert(node->atValidChild());
+                push(node->childNode());
+            } else {
+                break;
+            }
+        }
+    }
+    bool isValid() const { return !stack.empty(); }
+    void next() { // :259-277
+        while (!stack.empty()) {
+            FNode* node = stack.back();
+            if (node->atValidChild()) {
+                FNode* sub = node->childNode();
+                push(sub);
+                if (!sub->backingTopics.empty()) break;
+            } else {
+                pop();
+                if (!stack.empty()) stack.back()->nextChild();
+            }
+        }
+    }
+    Levels key() const { // :279-288
+        FNode* f = stack.back();
+        Levels k = f->topicFilterPrefix();
+        k.push_back(f->levelName());
+        return k;
+    }
+    const std::set<TopicTrieNode*>& valueNodes() const { return stack.back()->backingTopics; } // :290-300
+};
+
+// =====================================================================================
+// route-key codec -- SCHEMA/KVSchemaUtil.java:91-130, SCHEMA/KVSchemaConstants.java:24-34,
+// SCHEMA/cache/RouteDetailCache.java:53-117, UTIL/BSUtil.java:27-70 (big-endian)
+// =====================================================================================
+
+// Java String.hashCode over UTF-16 code units of a UTF-8 string
+static int32_t java_string_hash(const std::string& s) {
+    uint32_t h = 0;
+    size_t i = 0, n = s.size();
+    auto add = [&](uint32_t unit) { h = 31u * h + unit; };
+    while (i < n) {
+        uint32_t c = (uint8_t)s[i];
+        uint32_t cp;
+        if (c < 0x80) { cp = c; i += 1; }
+        else if ((c >> 5) == 0x6 && i + 1 < n) { cp = ((c & 0x1F) << 6) | ((uint8_t)s[i + 1] & 0x3F); i += 2; }
+        else if ((c >> 4) == 0xE && i + 2 < n) {
+            cp = ((c & 0x0F) << 12) | (((uint8_t)s[i + 1] & 0x3F) << 6) | ((uint8_t)s[i + 2] & 0x3F);
+            i += 3;
+        } else if ((c >> 3) == 0x1E && i + 3 < n) {
+            cp = ((c & 0x07) << 18) | (((uint8_t)s[i + 1] & 0x3F) << 12) | (((uint8_t)s[i + 2] & 0x3F) << 6) |
+                 ((uint8_t)s[i + 3] & 0x3F);
+            i += 4;
+        } else { cp = 0xFFFD; i += 1; }
+        if (cp >= 0x10000) {
+            cp -= 0x10000;
+            add(0xD800 + (cp >> 10));
+            add(0xDC00 + (cp & 0x3FF));
+        } else {
+            add(cp);
+        }
+    }
+    return (int32_t)h;
+}
+// KVSchemaUtil.java:127-130
+static uint8_t bucket_of(const std::string& receiver) {
+    uint32_t hash = (uint32_t)java_string_hash(receiver);
+    return (uint8_t)((hash ^ (hash >> 16)) & 0xFF);
+}
+static void put_u16be(std::string& s, size_t v) {
+    s.push_back((char)((v >> 8) & 0xFF));
+    s.push_back((char)(v & 0xFF));
+}
+// KVSchemaUtil.java:91-94
+static std::string tenant_begin_key(const std::string& tenant) {
+    std::string k(1, '\0'); // SCHEMA_VER
+    put_u16be(k, tenant.size());
+    k += tenant;
+    return k;
+}
+// KVSchemaUtil.java:96-102
+static std::string tenant_route_start_key(const std::string& tenant, const Levels& filterLevels) {
+    std::string k = tenant_begin_key(tenant);
+    for (auto& l : filterLevels) { k += l; k.push_back('\0'); }
+    k.push_back('\0');
+    return k;
+}
+// KVSchemaUtil.java:108-125: flag 1 normal (receiver = receiverUrl), 2 unordered share, 3 ordered (receiver = group)
+static std::string route_key(const std::string& tenant, const Levels& filterLevels, uint8_t flag,
+                             const std::string& receiver) {
+    std::string k = tenant_route_start_key(tenant, filterLevels);
+    k.push_back((char)bucket_of(receiver));
+    k.push_back((char)flag);
+    k += receiver;
+    put_u16be(k, receiver.size());
+    return k;
+}
+// BoundaryUtil.java:299-339 upperBound
+static bool upper_bound_key(const std::string& key, std::string& out) {
+    int i = (int)key.size();
+    while (--i >= 0) {
+        if ((uint8_t)key[i] < 0xFF) break;
+    }
+    if (i < 0) return false;
+    out = key.substr(0, i + 1);
+    out[i] = (char)((uint8_t)out[i] + 1);
+    return true;
+}
+
+struct RouteDetail { // RouteDetailCache.java:53-109
+    std::string tenant;
+    std::string escapedFilter;
+    Levels filterLevels;
+    uint8_t flag = 0;
+    std::string receiver;        // receiverUrl (normal) or group name
+    std::string mqttTopicFilter; // incl. $share/<g>/ or $oshare/<g>/ prefix for groups
+    bool ok = false;
+};
+static RouteDetail parse_route_key(const std::string& k) {
+    RouteDetail d;
+    if (k.size() < 1 + 2 + 2 + 2 + 2) return d;
+    size_t tenantLen = ((uint8_t)k[1] << 8) | (uint8_t)k[2];
+    size_t tenantStart = 3;
+    size_t escStart = tenantStart + tenantLen;
+    size_t recvLen = ((uint8_t)k[k.size() - 2] << 8) | (uint8_t)k[k.size() - 1];
+    if (k.size() < escStart + 4 + recvLen + 2) return d;
+    size_t recvStart = k.size() - 2 - recvLen;
+    size_t flagIdx = recvStart - 1;
+    size_t sepIdx = flagIdx - 1 - 2;
+    if (sepIdx < escStart) return d;
+    d.tenant = k.substr(tenantStart, tenantLen);
+    d.escapedFilter = k.substr(escStart, sepIdx - escStart);
+    d.filterLevels = parse(d.escapedFilter, true);
+    d.flag = (uint8_t)k[flagIdx];
+    d.receiver = k.substr(recvStart, recvLen);
+    std::string unesc = d.escapedFilter;
+    std::replace(unesc.begin(), unesc.end(), '\0', '/');
+    if (d.flag == 1) d.mqttTopicFilter = unesc;
+    else if (d.flag == 2) d.mqttTopicFilter = "$share/" + d.receiver + "/" + unesc;
+    else if (d.flag == 3) d.mqttTopicFilter = "$oshare/" + d.receiver + "/" + unesc;
+    else return d;
+    d.ok = true;
+    return d;
+}
+
+// =====================================================================================
+// TenantRouteMatcher.matchAll + MatchedRoutes
+// =====================================================================================
+struct KV { // sorted (unsigned-lexicographic) key array: stand-in for TreeMapKVReader
+            // (DWT/cache/TenantRouteMatcherTest.java:344-531)
+    std::vector<std::string> keys; // sorted
+    std::vector<RouteDetail> details; // parsed lazily once (RouteDetailCache is also a cache)
+    bool sorted = true;
+    void finalize() {
+        if (!std::is_sorted(keys.begin(), keys.end())) std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        details.resize(keys.size());
+        for (size_t i = 0; i < keys.size(); i++) details[i] = parse_route_key(keys[i]);
+    }
+    size_t seek(const std::string& k) const {
+        return std::lower_bound(keys.begin(), keys.end(), k) - keys.begin();
+    }
+};
+
+struct ThrottleEvent {
+    int type; // 0 = PersistentFanoutThrottled, 1 = GroupFanoutThrottled
+    int topicIdx;
+    uint32_t route; // rank of the KV key whose route was rejected
+    int maxCount;
+};
+
+// DW/cache/MatchedRoutes.java:87-141
+struct MatchedRoutes {
+    std::vector<uint32_t> routes; // ranks in insertion (= KV) order
+    std::set<uint32_t> all;
+    std::set<std::string> groupFilters;
+    int persistentFanout = 0;
+    int maxPersistentFanout, maxGroupFanout;
+    void addNormal(uint32_t rank, const RouteDetail& d, int topicIdx, std::vector<ThrottleEvent>& ev) {
+        if (all.insert(rank).second) {
+            // subBrokerId = leading integer of receiverUrl "<brokerId>\0<receiverId>\0<delivererKey>"
+            bool persistent = d.receiver.size() >= 2 && d.receiver[0] == '1' && d.receiver[1] == '\0';
+            if (persistent) {
+                if (persistentFanout < maxPersistentFanout) {
+                    persistentFanout++;
+                    routes.push_back(rank);
+                } else {
+                    all.erase(rank);
+                    ev.push_back({0, topicIdx, rank, maxPersistentFanout});
+                }
+            } else {
+                routes.push_back(rank);
+            }
+        }
+    }
+    void putGroup(uint32_t rank, const RouteDetail& d, int topicIdx, std::vector<ThrottleEvent>& ev) {
+        bool isNew = groupFilters.insert(d.mqttTopicFilter).second;
+        if (isNew) {
+            if ((long)groupFilters.size() <= (long)maxGroupFanout) {
+                all.insert(rank);
+                routes.push_back(rank);
+            } else {
+                groupFilters.erase(d.mqttTopicFilter);
+                ev.push_back({1, topicIdx, rank, maxGroupFanout});
+            }
+        } // (a second key with the same mqttTopicFilter cannot occur: keys are unique)
+    }
+};
+
+struct MatchAllResult {
+    std::vector<uint32_t> rowPtr;
+    std::vector<uint32_t> routes;
+    std::vector<ThrottleEvent> events;
+    uint64_t seekCount = 0, nextCount = 0, filterNodes = 0;
+};
+
+// DW/cache/TenantRouteMatcher.java:67-161
+static void match_all(const KV& kv, const std::string& tenant, const std::vector<std::string>& topics,
+                      int maxPF, int maxGF, MatchAllResult& res) {
+    const size_t nT = topics.size();
+    std::vector<MatchedRoutes> matched(nT);
+    for (auto& m : matched) { m.maxPersistentFanout = maxPF; m.maxGroupFanout = maxGF; }
+    TopicTrie trie(false);
+    // topics is a Set<String> in the reference: identical strings share one MatchedRoutes.
+    std::map<std::string, int> firstIdx;
+    std::vector<int> canon(nT);
+    for (size_t i = 0; i < nT; i++) {
+        auto it = firstIdx.find(topics[i]);
+        if (it == firstIdx.end()) {
+            firstIdx.emplace(topics[i], (int)i);
+            canon[i] = (int)i;
+            trie.addTopic(parse(topics[i], false), (int)i);
+        } else {
+            canon[i] = it->second;
+        }
+    }
+    std::string startKey = tenant_begin_key(tenant);
+    std::string endKey;
+    bool hasEnd = upper_bound_key(startKey, endKey);
+    if (!kv.keys.empty()) {
+        FilterIterator itr;
+        itr.init(trie.root);
+        std::map<Levels, std::vector<int>> matchedTopicFilters;
+        size_t pos = kv.seek(startKey);
+        res.seekCount++;
+        int probe = 0;
+        while (pos < kv.keys.size() && (!hasEnd || kv.keys[pos] < endKey)) {
+            const RouteDetail& d = kv.details[pos];
+            auto mt = matchedTopicFilters.find(d.filterLevels);
+            if (mt == matchedTopicFilters.end()) {
+                itr.seek(d.filterLevels);
+                if (itr.isValid()) {
+                    Levels toMatch = itr.key();
+                    if (toMatch == d.filterLevels) {
+                        std::vector<int> backing;
+                        for (TopicTrieNode* tn : itr.valueNodes())
+                            for (int v : tn->values) {
+                                if (d.flag == 1) matched[v].addNormal((uint32_t)pos, d, v, res.events);
+                                else matched[v].putGroup((uint32_t)pos, d, v, res.events);
+                                backing.push_back(v);
+                            }
+                        matchedTopicFilters.emplace(d.filterLevels, backing);
+                        pos++;
+                        res.nextCount++;
+                        probe = 0;
+                    } else {
+                        if (probe++ < 20) {
+                            pos++;
+                            res.nextCount++;
+                        } else {
+                            pos = kv.seek(tenant_route_start_key(tenant, toMatch));
+                            res.seekCount++;
+                        }
+                    }
+                } else {
+                    break;
+                }
+            } else {
+                pos++;
+                res.nextCount++;
+                for (int v : mt->second) {
+                    if (d.flag == 1) matched[v].addNormal((uint32_t)pos - 1, d, v, res.events);
+                    else matched[v].putGroup((uint32_t)pos - 1, d, v, res.events);
+                }
+            }
+        }
+        res.filterNodes += itr.nodesPushed;
+    }
+    res.rowPtr.assign(nT + 1, 0);
+    for (size_t i = 0; i < nT; i++) {
+        const auto& r = matched[canon[i]].routes;
+        res.rowPtr[i + 1] = res.rowPtr[i] + (uint32_t)r.size();
+        res.routes.insert(res.routes.end(), r.begin(), r.end());
+    }
+}
+
+// =====================================================================================
+// retain direction: TopicLevelTrie.lookup with the two BranchSelectors
+//   UTIL/index/TopicLevelTrie.java:190-249 (lookup), :389-410 (BranchSelector/Action)
+//   DW/TopicIndex.java:40-117 (TopicMatcher, '$'-skip at level 0)
+//   RS/index/RetainTopicIndex.java:36-124 (RetainMatcher, '$'-skip at level 1; level 0 = tenant)
+// The Ctrie machinery (INode/CNode/TNode CAS, contraction) only affects concurrency, not
+// results, and is replaced by a plain ordered map per node.
+// =====================================================================================
+struct LNode;
+struct Branch {
+    std::set<int> values;
+    std::unique_ptr<LNode> iNode;
+};
+struct LNode {
+    std::map<std::string, Branch> branches;
+};
+enum Action { STOP, CONTINUE, MATCH_AND_CONTINUE, MATCH_AND_STOP };
+
+struct LevelTrie {
+    LNode root;
+    int sysLevel; // 0 for TopicIndex, 1 for RetainTopicIndex
+    uint64_t visits = 0;
+    explicit LevelTrie(int s) : sysLevel(s) {}
+    void add(const Levels& lv, int value) { // TopicLevelTrie.java:49-95 (result-equivalent)
+        LNode* n = &root;
+        for (size_t i = 0; i < lv.size(); i++) {
+            Branch& b = n->branches[lv[i]];
+            if (i == lv.size() - 1) {
+                b.values.insert(value);
+            } else {
+                if (!b.iNode) b.iNode.reset(new LNode());
+                n = b.iNode.get();
+            }
+        }
+    }
+    bool removeRec(LNode* n, const Levels& lv, size_t i, int value) { // :97-182 (result-equivalent)
+        auto it = n->branches.find(lv[i]);
+        if (it == n->branches.end()) return false;
+        Branch& b = it->second;
+        if (i == lv.size() - 1) {
+            b.values.erase(value);
+        } else if (b.iNode) {
+            if (removeRec(b.iNode.get(), lv, i + 1, value) && b.iNode->branches.empty()) b.iNode.reset();
+        }
+        if (b.values.empty() && !b.iNode) n->branches.erase(it);
+        return true;
+    }
+    void remove(const Levels& lv, int value) {
+        if (!lv.empty()) removeRec(&root, lv, 0, value);
+    }
+
+    // selectBranch of both selectors (they differ only in sysLevel and the isEmpty() findAll case)
+    void select(LNode* cn, const Levels& tl, int cur, std::vector<std::pair<Branch*, Action>>& out) {
+        const int n = (int)tl.size();
+        if (sysLevel == 1 && tl.empty()) { // RetainTopicIndex.java:41-48 findAll
+            for (auto& e : cn->branches) out.push_back({&e.second, MATCH_AND_CONTINUE});
+            return;
+        }
+        if (cur < n - 1) {
+            bool matchParent = (cur + 1 == n - 1) && tl[cur + 1] == MULTI_WILDCARD;
+            const std::string& l = tl[cur];
+            if (l == SINGLE_WILDCARD) {
+                for (auto& e : cn->branches) {
+                    if (cur == sysLevel && starts_with_sys(e.first)) continue;
+                    out.push_back({&e.second, matchParent ? MATCH_AND_CONTINUE : CONTINUE});
+                }
+            } else {
+                auto it = cn->branches.find(l);
+                if (it != cn->branches.end())
+                    out.push_back({&it->second, matchParent ? MATCH_AND_CONTINUE : CONTINUE});
+            }
+        } else if (cur == n - 1) {
+            const std::string& l = tl[cur];
+            if (l == SINGLE_WILDCARD) {
+                for (auto& e : cn->branches) {
+                    if (cur == sysLevel && starts_with_sys(e.first)) continue;
+                    out.push_back({&e.second, MATCH_AND_STOP});
+                }
+            } else if (l == MULTI_WILDCARD) {
+                for (auto& e : cn->branches) {
+                    if (cur == sysLevel && starts_with_sys(e.first)) continue;
+                    out.push_back({&e.second, MATCH_AND_CONTINUE});
+                }
+            } else {
+                auto it = cn->branches.find(l);
+                if (it != cn->branches.end()) out.push_back({&it->second, MATCH_AND_STOP});
+            }
+        } else {
+            for (auto& e : cn->branches) out.push_back({&e.second, MATCH_AND_CONTINUE});
+        }
+    }
+    void lookup(LNode* cn, const Levels& tl, int cur, std::set<int>& values) {
+        std::vector<std::pair<Branch*, Action>> sel;
+        select(cn, tl, cur, sel);
+        for (auto& ba : sel) {
+            visits++;
+            Branch* b = ba.first;
+            switch (ba.second) {
+                case MATCH_AND_CONTINUE:
+                case CONTINUE:
+                    if (ba.second == MATCH_AND_CONTINUE) values.insert(b->values.begin(), b->values.end());
+                    if (b->iNode) lookup(b->iNode.get(), tl, cur + 1, values);
+                    break;
+                case MATCH_AND_STOP:
+                    values.insert(b->values.begin(), b->values.end());
+                    break;
+                case STOP:
+                    break;
+            }
+        }
+    }
+};
+
+// =====================================================================================
+// roofline accounting: N_visit / N_match per topic, counted on the *data*:
+// N_visit(topic) = number of distinct stored-filter level-prefixes (wildcard levels '+'
+// included, '#' excluded, tenant root excluded) that match the topic's same-length prefix.
+// =====================================================================================
+struct VisitIndex {
+    std::unordered_set<std::string> prefixes; // "tenant \0 lvl \0 lvl \0 ..."
+    void addFilter(const std::string& tenant, const Levels& fl) {
+        std::string p = tenant;
+        p.push_back('\0');
+        for (auto& l : fl) {
+            if (l == MULTI_WILDCARD) break;
+            p += l;
+            p.push_back('\0');
+            prefixes.insert(p);
+        }
+    }
+    uint64_t visits(const std::string& tenant, const Levels& tl) const {
+        std::vector<std::string> frontier, next;
+        std::string r = tenant;
+        r.push_back('\0');
+        frontier.push_back(r);
+        uint64_t v = 0;
+        for (size_t d = 0; d < tl.size() && !frontier.empty(); d++) {
+            next.clear();
+            for (auto& p : frontier) {
+                std::string a = p + tl[d];
+                a.push_back('\0');
+                if (prefixes.count(a)) next.push_back(a);
+                if (!(d == 0 && starts_with_sys(tl[0]))) {
+                    std::string b = p + "+";
+                    b.push_back('\0');
+                    if (prefixes.count(b)) next.push_back(b);
+                }
+            }
+            v += next.size();
+            frontier.swap(next);
+        }
+        return v;
+    }
+};
+
+static std::vector<std::string> split_packed(const uint8_t* bytes, const uint32_t* off, uint32_t n) {
+    std::vector<std::string> v(n);
+    for (uint32_t i = 0; i < n; i++) v[i].assign((const char*)bytes + off[i], off[i + 1] - off[i]);
+    return v;
+}
+
+struct OutBuf {
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> off{0};
+    void push(const std::string& s) {
+        bytes.insert(bytes.end(), s.begin(), s.end());
+        off.push_back((uint32_t)bytes.size());
+    }
+    void clear() { bytes.clear(); off.assign(1, 0); }
+};
+
+} // namespace
+
+// =====================================================================================
+// C API (ctypes) -- handles are opaque
+// =====================================================================================
+extern "C" {
+
+int32_t orc_java_hash(const uint8_t* s, uint32_t n) { return java_string_hash(std::string((const char*)s, n)); }
+
+// route key encode: flag 1 => receiver = receiverUrl; 2/3 => receiver = group. filter = MQTT filter w/o $share prefix
+uint32_t orc_route_key(const uint8_t* tenant, uint32_t tl, const uint8_t* filter, uint32_t fl, uint8_t flag,
+                       const uint8_t* recv, uint32_t rl, uint8_t* out, uint32_t cap) {
+    std::string k = route_key(std::string((const char*)tenant, tl), parse(std::string((const char*)filter, fl), false),
+                              flag, std::string((const char*)recv, rl));
+    if (k.size() <= cap) memcpy(out, k.data(), k.size());
+    return (uint32_t)k.size();
+}
+uint32_t orc_tenant_route_start_key(const uint8_t* tenant, uint32_t tl, const uint8_t* filter, uint32_t fl,
+                                    uint8_t* out, uint32_t cap) {
+    std::string k = tenant_route_start_key(std::string((const char*)tenant, tl),
+                                           parse(std::string((const char*)filter, fl), false));
+    if (k.size() <= cap) memcpy(out, k.data(), k.size());
+    return (uint32_t)k.size();
+}
+// route key decode -> packed strings: tenant, mqttTopicFilter, receiver; returns flag or -1
+int orc_parse_route_key(const uint8_t* key, uint32_t kl, uint8_t* out, uint32_t cap, uint32_t* lens /*3*/) {
+    RouteDetail d = parse_route_key(std::string((const char*)key, kl));
+    if (!d.ok) return -1;
+    std::string all = d.tenant + d.mqttTopicFilter + d.receiver;
+    lens[0] = (uint32_t)d.tenant.size();
+    lens[1] = (uint32_t)d.mqttTopicFilter.size();
+    lens[2] = (uint32_t)d.receiver.size();
+    if (all.size() <= cap) memcpy(out, all.data(), all.size());
+    return d.flag;
+}
+
+// ---- semantic
+int orc_semantic_match(const uint8_t* topic, uint32_t tl, const uint8_t* filter, uint32_t fl) {
+    return semantic_match(parse(std::string((const char*)topic, tl), false),
+                          parse(std::string((const char*)filter, fl), false))
+               ? 1 : 0;
+}
+
+// ---- generic packed-string result holder
+void* orc_buf_new() { return new OutBuf(); }
+void orc_buf_free(void* b) { delete (OutBuf*)b; }
+uint32_t orc_buf_count(void* b) { return (uint32_t)((OutBuf*)b)->off.size() - 1; }
+const uint8_t* orc_buf_bytes(void* b) { return ((OutBuf*)b)->bytes.data(); }
+const uint32_t* orc_buf_off(void* b) { return ((OutBuf*)b)->off.data(); }
+
+// TestUtil.expand -> escaped ('\0'-joined) filters, in order
+void orc_test_expand(const uint8_t* topic, uint32_t tl, void* buf) {
+    OutBuf* ob = (OutBuf*)buf;
+    ob->clear();
+    for (auto& s : test_expand(std::string((const char*)topic, tl))) ob->push(s);
+}
+
+// ---- topic trie + expansion iterator
+void* orc_trie_new(int isGlobal) { return new TopicTrie(isGlobal != 0); }
+void orc_trie_free(void* t) { delete (TopicTrie*)t; }
+void orc_trie_add(void* t, const uint8_t* topic, uint32_t tl, int value) {
+    ((TopicTrie*)t)->addTopic(parse(std::string((const char*)topic, tl), false), value);
+}
+void* orc_iter_new(void* trie) {
+    FilterIterator* it = new FilterIterator();
+    it->init(((TopicTrie*)trie)->root);
+    return it;
+}
+void orc_iter_free(void* it) { delete (FilterIterator*)it; }
+// filter given as '/'-joined levels; n_levels==0 means the empty list (seek to first)
+void orc_iter_seek(void* it, const uint8_t* filter, uint32_t fl, int emptyList) {
+    if (emptyList) ((FilterIterator*)it)->seek({});
+    else ((FilterIterator*)it)->seek(parse(std::string((const char*)filter, fl), false));
+}
+void orc_iter_next(void* it) { ((FilterIterator*)it)->next(); }
+int orc_iter_valid(void* it) { return ((FilterIterator*)it)->isValid() ? 1 : 0; }
+// key as '/'-joined levels
+uint32_t orc_iter_key(void* it, uint8_t* out, uint32_t cap) {
+    std::string k = join(((FilterIterator*)it)->key(), '/');
+    if (k.size() <= cap) memcpy(out, k.data(), k.size());
+    return (uint32_t)k.size();
+}
+// values (union over backing topics), sorted
+uint32_t orc_iter_values(void* it, int* out, uint32_t cap) {
+    std::set<int> vals;
+    for (TopicTrieNode* n : ((FilterIterator*)it)->valueNodes()) vals.insert(n->values.begin(), n->values.end());
+    uint32_t i = 0;
+    for (int v : vals) {
+        if (i < cap) out[i] = v;
+        i++;
+    }
+    return i;
+}
+// backing topics ('/'-joined), into buf
+void orc_iter_value_topics(void* it, void* buf) {
+    OutBuf* ob = (OutBuf*)buf;
+    ob->clear();
+    std::set<std::string> ts;
+    for (TopicTrieNode* n : ((FilterIterator*)it)->valueNodes()) ts.insert(join(n->topic, '/'));
+    for (auto& s : ts) ob->push(s);
+}
+
+// ---- KV + matchAll
+void* orc_kv_new(const uint8_t* keys, const uint32_t* off, uint32_t n) {
+    KV* kv = new KV();
+    kv->keys = split_packed(keys, off, n);
+    kv->finalize();
+    return kv;
+}
+void orc_kv_free(void* kv) { delete (KV*)kv; }
+uint32_t orc_kv_size(void* kv) { return (uint32_t)((KV*)kv)->keys.size(); }
+// sorted key i (rank -> key), so callers can map ranks back to keys
+uint32_t orc_kv_key(void* kv, uint32_t i, uint8_t* out, uint32_t cap) {
+    const std::string& k = ((KV*)kv)->keys[i];
+    if (k.size() <= cap) memcpy(out, k.data(), k.size());
+    return (uint32_t)k.size();
+}
+
+void* orc_result_new() { return new MatchAllResult(); }
+void orc_result_free(void* r) { delete (MatchAllResult*)r; }
+const uint32_t* orc_result_rowptr(void* r) { return ((MatchAllResult*)r)->rowPtr.data(); }
+const uint32_t* orc_result_routes(void* r) { return ((MatchAllResult*)r)->routes.data(); }
+uint32_t orc_result_nroutes(void* r) { return (uint32_t)((MatchAllResult*)r)->routes.size(); }
+uint32_t orc_result_nevents(void* r) { return (uint32_t)((MatchAllResult*)r)->events.size(); }
+void orc_result_event(void* r, uint32_t i, int* out4) {
+    const ThrottleEvent& e = ((MatchAllResult*)r)->events[i];
+    out4[0] = e.type; out4[1] = e.topicIdx; out4[2] = (int)e.route; out4[3] = e.maxCount;
+}
+uint64_t orc_result_seeks(void* r) { return ((MatchAllResult*)r)->seekCount; }
+uint64_t orc_result_nexts(void* r) { return ((MatchAllResult*)r)->nextCount; }
+
+// one TenantRouteMatcher.matchAll(topics, maxPF, maxGF) call; routes per topic in KV order
+void orc_match_all(void* kv, const uint8_t* tenant, uint32_t tl, const uint8_t* topics, const uint32_t* off,
+                   uint32_t n, int maxPF, int maxGF, void* result) {
+    MatchAllResult* res = (MatchAllResult*)result;
+    *res = MatchAllResult();
+    match_all(*(KV*)kv, std::string((const char*)tenant, tl), split_packed(topics, off, n), maxPF, maxGF, *res);
+}
+
+// "production mode" (DW/cache/TenantRouteCache.java:180-193): one matchAll(singleton(topic)) per
+// topic, spread over `threads` host threads; per-topic results concatenated as CSR. Returns seconds.
+double orc_match_singletons(void* kvp, const uint8_t* tenants, const uint32_t* toff, const uint32_t* topicTenant,
+                            const uint8_t* topics, const uint32_t* off, uint32_t n, int threads, void* result) {
+    KV& kv = *(KV*)kvp;
+    std::vector<std::string> tn;
+    { // tenants packed: count = max(topicTenant)+1
+        uint32_t nt = 0;
+        for (uint32_t i = 0; i < n; i++) nt = std::max(nt, topicTenant[i] + 1);
+        tn = split_packed(tenants, toff, nt);
+    }
+    std::vector<std::string> tp = split_packed(topics, off, n);
+    std::vector<std::vector<uint32_t>> per(n);
+    if (threads < 1) threads = 1;
+    auto t0 = std::chrono::steady_clock::now();
+    std::atomic<uint32_t> cursor{0};
+    auto work = [&]() {
+        MatchAllResult r;
+        for (;;) {
+            uint32_t i = cursor.fetch_add(64);
+            if (i >= n) break;
+            for (uint32_t j = i; j < std::min(n, i + 64); j++) {
+                r = MatchAllResult();
+                match_all(kv, tn[topicTenant[j]], {tp[j]}, INT32_MAX, INT32_MAX, r);
+                per[j] = r.routes;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    MatchAllResult* res = (MatchAllResult*)result;
+    *res = MatchAllResult();
+    res->rowPtr.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        res->rowPtr[i + 1] = res->rowPtr[i] + (uint32_t)per[i].size();
+        res->routes.insert(res->routes.end(), per[i].begin(), per[i].end());
+    }
+    return sec;
+}
+
+// semantic brute force over the whole KV (authoritative oracle A): for each topic the ranks of all
+// keys of `tenant` whose filter matches. O(n_topics * n_keys_of_tenant); small cases only.
+void orc_match_bruteforce(void* kvp, const uint8_t* tenant, uint32_t tl, const uint8_t* topics, const uint32_t* off,
+                          uint32_t n, void* result) {
+    KV& kv = *(KV*)kvp;
+    std::string tn((const char*)tenant, tl);
+    std::vector<std::string> tp = split_packed(topics, off, n);
+    MatchAllResult* res = (MatchAllResult*)result;
+    *res = MatchAllResult();
+    res->rowPtr.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        Levels t = parse(tp[i], false);
+        for (size_t r = 0; r < kv.keys.size(); r++) {
+            const RouteDetail& d = kv.details[r];
+            if (d.ok && d.tenant == tn && semantic_match(t, d.filterLevels)) res->routes.push_back((uint32_t)r);
+        }
+        res->rowPtr[i + 1] = (uint32_t)res->routes.size();
+    }
+}
+
+// N_visit per topic (roofline accounting). visits_out[n].
+void orc_count_visits(void* kvp, const uint8_t* tenants, const uint32_t* toff, const uint32_t* topicTenant,
+                      const uint8_t* topics, const uint32_t* off, uint32_t n, uint32_t* visits_out) {
+    KV& kv = *(KV*)kvp;
+    VisitIndex vi;
+    for (auto& d : kv.details)
+        if (d.ok) vi.addFilter(d.tenant, d.filterLevels);
+    uint32_t nt = 0;
+    for (uint32_t i = 0; i < n; i++) nt = std::max(nt, topicTenant[i] + 1);
+    std::vector<std::string> tn = split_packed(tenants, toff, nt);
+    for (uint32_t i = 0; i < n; i++) {
+        std::string t((const char*)topics + off[i], off[i + 1] - off[i]);
+        visits_out[i] = (uint32_t)vi.visits(tn[topicTenant[i]], parse(t, false));
+    }
+}
+
+// ---- retain direction
+void* orc_ltrie_new(int sysLevel) { return new LevelTrie(sysLevel); }
+void orc_ltrie_free(void* t) { delete (LevelTrie*)t; }
+// levels: if tenant given (tl_>0 or useTenant) it becomes level 0 (TopicUtil.parse(tenantId, topic, false))
+static Levels lt_levels(const uint8_t* tenant, uint32_t tl, int useTenant, const uint8_t* topic, uint32_t pl) {
+    Levels lv;
+    if (useTenant) lv.push_back(std::string((const char*)tenant, tl));
+    Levels p = parse(std::string((const char*)topic, pl), false);
+    lv.insert(lv.end(), p.begin(), p.end());
+    return lv;
+}
+void orc_ltrie_add(void* t, const uint8_t* tenant, uint32_t tl, int useTenant, const uint8_t* topic, uint32_t pl,
+                   int value) {
+    ((LevelTrie*)t)->add(lt_levels(tenant, tl, useTenant, topic, pl), value);
+}
+void orc_ltrie_remove(void* t, const uint8_t* tenant, uint32_t tl, int useTenant, const uint8_t* topic, uint32_t pl,
+                      int value) {
+    ((LevelTrie*)t)->remove(lt_levels(tenant, tl, useTenant, topic, pl), value);
+}
+// match -> sorted value ids; returns count (writes up to cap). findAll!=0 => lookup(emptyList)
+uint32_t orc_ltrie_match(void* t, const uint8_t* tenant, uint32_t tl, int useTenant, const uint8_t* filter,
+                         uint32_t fl, int findAll, int* out, uint32_t cap) {
+    LevelTrie* lt = (LevelTrie*)t;
+    std::set<int> vals;
+    Levels lv = findAll ? Levels{} : lt_levels(tenant, tl, useTenant, filter, fl);
+    lt->lookup(&lt->root, lv, 0, vals);
+    uint32_t i = 0;
+    for (int v : vals) {
+        if (i < cap) out[i] = v;
+        i++;
+    }
+    return i;
+}
+uint64_t orc_ltrie_visits(void* t) { return ((LevelTrie*)t)->visits; }
+// batch: filters (one tenant each via filterTenant index) -> CSR of sorted value ids; returns seconds
+double orc_ltrie_match_batch(void* t, const uint8_t* tenants, const uint32_t* toff, const uint32_t* filterTenant,
+                             const uint8_t* filters, const uint32_t* off, uint32_t n, int threads, void* result) {
+    LevelTrie* lt = (LevelTrie*)t;
+    uint32_t nt = 0;
+    for (uint32_t i = 0; i < n; i++) nt = std::max(nt, filterTenant[i] + 1);
+    std::vector<std::string> tn = split_packed(tenants, toff, nt);
+    std::vector<std::vector<uint32_t>> per(n);
+    if (threads < 1) threads = 1;
+    auto t0 = std::chrono::steady_clock::now();
+    std::atomic<uint32_t> cursor{0};
+    std::atomic<uint64_t> visits{0};
+    auto work = [&]() {
+        LevelTrie view(lt->sysLevel); // per-thread visit counter; shares nodes read-only
+        for (;;) {
+            uint32_t i = cursor.fetch_add(16);
+            if (i >= n) break;
+            for (uint32_t j = i; j < std::min(n, i + 16); j++) {
+                std::set<int> vals;
+                const std::string& ten = tn[filterTenant[j]];
+                Levels lv = lt_levels((const uint8_t*)ten.data(), (uint32_t)ten.size(), lt->sysLevel == 1,
+                                      filters + off[j], off[j + 1] - off[j]);
+                view.lookup(&lt->root, lv, 0, vals);
+                per[j].assign(vals.begin(), vals.end());
+            }
+        }
+        visits += view.visits;
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < threads; k++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    lt->visits += visits.load();
+    MatchAllResult* res = (MatchAllResult*)result;
+    *res = MatchAllResult();
+    res->rowPtr.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        res->rowPtr[i + 1] = res->rowPtr[i] + (uint32_t)per[i].size();
+        res->routes.insert(res->routes.end(), per[i].begin(), per[i].end());
+    }
+    return sec;
+}
+
+} // extern "C"

@@ -1,0 +1,418 @@
+"""ctypes binding of the CPU oracle (oracle/bmq_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (bifromq_amd/) never does.  See bmq_oracle.cpp for the reference
+file:line each function follows.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbmq_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "bmq_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        u8p, u32p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_int)
+        vp = C.c_void_p
+        sig = {
+            "orc_java_hash": (C.c_int32, [C.c_char_p, C.c_uint32]),
+            "orc_route_key": (C.c_uint32, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint8, C.c_char_p,
+                                           C.c_uint32, C.c_char_p, C.c_uint32]),
+            "orc_tenant_route_start_key": (C.c_uint32, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p,
+                                                        C.c_uint32]),
+            "orc_parse_route_key": (C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, u32p]),
+            "orc_semantic_match": (C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]),
+            "orc_buf_new": (vp, []), "orc_buf_free": (None, [vp]), "orc_buf_count": (C.c_uint32, [vp]),
+            "orc_buf_bytes": (u8p, [vp]), "orc_buf_off": (u32p, [vp]),
+            "orc_test_expand": (None, [C.c_char_p, C.c_uint32, vp]),
+            "orc_trie_new": (vp, [C.c_int]), "orc_trie_free": (None, [vp]),
+            "orc_trie_add": (None, [vp, C.c_char_p, C.c_uint32, C.c_int]),
+            "orc_iter_new": (vp, [vp]), "orc_iter_free": (None, [vp]),
+            "orc_iter_seek": (None, [vp, C.c_char_p, C.c_uint32, C.c_int]),
+            "orc_iter_next": (None, [vp]), "orc_iter_valid": (C.c_int, [vp]),
+            "orc_iter_key": (C.c_uint32, [vp, C.c_char_p, C.c_uint32]),
+            "orc_iter_values": (C.c_uint32, [vp, i32p, C.c_uint32]),
+            "orc_iter_value_topics": (None, [vp, vp]),
+            "orc_kv_new": (vp, [vp, vp, C.c_uint32]), "orc_kv_free": (None, [vp]),
+            "orc_kv_size": (C.c_uint32, [vp]), "orc_kv_key": (C.c_uint32, [vp, C.c_uint32, C.c_char_p, C.c_uint32]),
+            "orc_result_new": (vp, []), "orc_result_free": (None, [vp]),
+            "orc_result_rowptr": (u32p, [vp]), "orc_result_routes": (u32p, [vp]),
+            "orc_result_nroutes": (C.c_uint32, [vp]), "orc_result_nevents": (C.c_uint32, [vp]),
+            "orc_result_event": (None, [vp, C.c_uint32, i32p]),
+            "orc_result_seeks": (C.c_uint64, [vp]), "orc_result_nexts": (C.c_uint64, [vp]),
+            "orc_match_all": (None, [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint32, C.c_int, C.c_int, vp]),
+            "orc_match_singletons": (C.c_double, [vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
+            "orc_match_bruteforce": (None, [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint32, vp]),
+            "orc_count_visits": (None, [vp, vp, vp, vp, vp, vp, C.c_uint32, vp]),
+            "orc_ltrie_new": (vp, [C.c_int]), "orc_ltrie_free": (None, [vp]),
+            "orc_ltrie_add": (None, [vp, C.c_char_p, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_int]),
+            "orc_ltrie_remove": (None, [vp, C.c_char_p, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_int]),
+            "orc_ltrie_match": (C.c_uint32, [vp, C.c_char_p, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_int,
+                                             i32p, C.c_uint32]),
+            "orc_ltrie_visits": (C.c_uint64, [vp]),
+            "orc_ltrie_match_batch": (C.c_double, [vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+INT_MAX = 2**31 - 1
+
+
+def _b(s) -> bytes:
+    return s if isinstance(s, (bytes, bytearray)) else s.encode("utf-8")
+
+
+def pack(strings: Sequence) -> Tuple[np.ndarray, np.ndarray]:
+    """list of str/bytes -> (uint8 bytes, uint32 offsets[n+1])"""
+    bs = [_b(s) for s in strings]
+    off = np.zeros(len(bs) + 1, dtype=np.uint32)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64).astype(np.uint32)
+    data = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
+    if data.size == 0:
+        data = np.zeros(1, dtype=np.uint8)  # keep a valid pointer
+    return data, off
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def java_hash(s) -> int:
+    b = _b(s)
+    return lib().orc_java_hash(b, len(b))
+
+
+# ---- route-key codec (SCHEMA/KVSchemaUtil.java:91-130) ---------------------------------------
+FLAG_NORMAL, FLAG_UNORDERED, FLAG_ORDERED = 1, 2, 3
+
+
+def receiver_url(sub_broker_id: int, receiver_id: str, deliverer_key: str) -> str:
+    """KVSchemaUtil.toReceiverUrl (SCHEMA/KVSchemaUtil.java:56-58)"""
+    return f"{sub_broker_id}\0{receiver_id}\0{deliverer_key}"
+
+
+def route_key(tenant, topic_filter, flag: int, receiver) -> bytes:
+    """topic_filter: MQTT filter without any $share prefix; receiver: receiverUrl (flag 1) or group (flag 2/3)."""
+    t, f, r = _b(tenant), _b(topic_filter), _b(receiver)
+    out = C.create_string_buffer(len(t) + len(f) + len(r) + 32)
+    n = lib().orc_route_key(t, len(t), f, len(f), flag, r, len(r), out, len(out))
+    return out.raw[:n]
+
+
+def route_key_from_mqtt(tenant, mqtt_topic_filter: str, receiver_url_: str = "") -> bytes:
+    """TopicUtil.from + toNormalRouteKey/toGroupRouteKey (UTIL/TopicUtil.java:252-272)."""
+    if mqtt_topic_filter.startswith("$share/") or mqtt_topic_filter.startswith("$oshare/"):
+        ordered = mqtt_topic_filter.startswith("$oshare/")
+        rest = mqtt_topic_filter[len("$oshare/" if ordered else "$share/"):]
+        i = rest.index("/")
+        return route_key(tenant, rest[i + 1:], FLAG_ORDERED if ordered else FLAG_UNORDERED, rest[:i])
+    return route_key(tenant, mqtt_topic_filter, FLAG_NORMAL, receiver_url_)
+
+
+def tenant_route_start_key(tenant, topic_filter) -> bytes:
+    t, f = _b(tenant), _b(topic_filter)
+    out = C.create_string_buffer(len(t) + len(f) + 16)
+    n = lib().orc_tenant_route_start_key(t, len(t), f, len(f), out, len(out))
+    return out.raw[:n]
+
+
+def parse_route_key(key: bytes):
+    """-> (flag, tenant, mqttTopicFilter, receiver) or None"""
+    out = C.create_string_buffer(len(key) + 64)
+    lens = (C.c_uint32 * 3)()
+    flag = lib().orc_parse_route_key(key, len(key), out, len(out), lens)
+    if flag < 0:
+        return None
+    a, b, c = lens[0], lens[1], lens[2]
+    raw = out.raw
+    return flag, raw[:a].decode(), raw[a:a + b].decode(), raw[a + b:a + b + c].decode()
+
+
+# ---- semantic matcher / expansion -----------------------------------------------------------
+def semantic_match(topic, topic_filter) -> bool:
+    t, f = _b(topic), _b(topic_filter)
+    return bool(lib().orc_semantic_match(t, len(t), f, len(f)))
+
+
+class _Buf:
+    def __init__(self):
+        self.h = lib().orc_buf_new()
+
+    def strings(self) -> List[bytes]:
+        L = lib()
+        n = L.orc_buf_count(self.h)
+        off = np.ctypeslib.as_array(L.orc_buf_off(self.h), shape=(n + 1,)).copy()
+        total = int(off[-1])
+        if total == 0:
+            return [b""] * n
+        data = bytes(np.ctypeslib.as_array(L.orc_buf_bytes(self.h), shape=(total,)))
+        return [data[off[i]:off[i + 1]] for i in range(n)]
+
+    def __del__(self):
+        if lib is not None and self.h:
+            lib().orc_buf_free(self.h)
+            self.h = None
+
+
+def test_expand(topic) -> List[str]:
+    """TRIET/TestUtil.java:70-107 -> '/'-joined filters in order"""
+    b = _Buf()
+    t = _b(topic)
+    lib().orc_test_expand(t, len(t), b.h)
+    return [s.replace(b"\0", b"/").decode() for s in b.strings()]
+
+
+test_expand.__test__ = False  # not a pytest test
+
+
+class TopicTrie:
+    """TRIE/TopicTrieNode.java builder"""
+
+    def __init__(self, is_global: bool = False):
+        self.h = lib().orc_trie_new(1 if is_global else 0)
+
+    def add_topic(self, topic, value: int):
+        t = _b(topic)
+        lib().orc_trie_add(self.h, t, len(t), value)
+        return self
+
+    def __del__(self):
+        if self.h:
+            lib().orc_trie_free(self.h)
+            self.h = None
+
+
+class TopicFilterIterator:
+    """TRIE/TopicFilterIterator.java (seek/next/key/value)"""
+
+    def __init__(self, trie: TopicTrie):
+        self._trie = trie
+        self.h = lib().orc_iter_new(trie.h)
+
+    def seek(self, topic_filter: Optional[str]):
+        """topic_filter None => seek(emptyList)"""
+        if topic_filter is None:
+            lib().orc_iter_seek(self.h, b"", 0, 1)
+        else:
+            f = _b(topic_filter)
+            lib().orc_iter_seek(self.h, f, len(f), 0)
+
+    def next(self):
+        lib().orc_iter_next(self.h)
+
+    def is_valid(self) -> bool:
+        return bool(lib().orc_iter_valid(self.h))
+
+    def key(self) -> str:
+        out = C.create_string_buffer(70000)
+        n = lib().orc_iter_key(self.h, out, len(out))
+        return out.raw[:n].decode()
+
+    def values(self) -> List[int]:
+        out = (C.c_int * 4096)()
+        n = lib().orc_iter_values(self.h, out, 4096)
+        return list(out[:n])
+
+    def value_topics(self) -> List[str]:
+        b = _Buf()
+        lib().orc_iter_value_topics(self.h, b.h)
+        return [s.decode() for s in b.strings()]
+
+    def all_keys(self) -> List[str]:
+        out = []
+        while self.is_valid():
+            out.append(self.key())
+            self.next()
+        return out
+
+    def __del__(self):
+        if self.h:
+            lib().orc_iter_free(self.h)
+            self.h = None
+
+
+# ---- KV + matchAll ----------------------------------------------------------------------------
+class MatchResult:
+    def __init__(self, n_topics: int):
+        self.h = lib().orc_result_new()
+        self.n = n_topics
+
+    @property
+    def row_ptr(self) -> np.ndarray:
+        return np.ctypeslib.as_array(lib().orc_result_rowptr(self.h), shape=(self.n + 1,)).copy()
+
+    @property
+    def routes(self) -> np.ndarray:
+        n = lib().orc_result_nroutes(self.h)
+        if n == 0:
+            return np.zeros(0, dtype=np.uint32)
+        return np.ctypeslib.as_array(lib().orc_result_routes(self.h), shape=(n,)).copy()
+
+    def per_topic(self) -> List[List[int]]:
+        rp, r = self.row_ptr, self.routes
+        return [r[rp[i]:rp[i + 1]].tolist() for i in range(self.n)]
+
+    @property
+    def events(self) -> List[Tuple[int, int, int, int]]:
+        """(type 0=PersistentFanoutThrottled 1=GroupFanoutThrottled, topic idx, route rank, maxCount)"""
+        out = []
+        buf = (C.c_int * 4)()
+        for i in range(lib().orc_result_nevents(self.h)):
+            lib().orc_result_event(self.h, i, buf)
+            out.append(tuple(buf))
+        return out
+
+    @property
+    def seek_count(self) -> int:
+        return lib().orc_result_seeks(self.h)
+
+    @property
+    def next_count(self) -> int:
+        return lib().orc_result_nexts(self.h)
+
+    def __del__(self):
+        if self.h:
+            lib().orc_result_free(self.h)
+            self.h = None
+
+
+class KV:
+    """Sorted route-key array: stand-in for the KV range (TreeMapKVReader of the reference's tests).
+    Route id == rank of the key in unsigned-byte order."""
+
+    def __init__(self, keys: Iterable[bytes] = (), packed: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+        if packed is None:
+            data, off = pack(list(keys))
+        else:
+            data, off = packed
+        self.h = lib().orc_kv_new(_ptr(data), _ptr(off), len(off) - 1)
+
+    def __len__(self):
+        return lib().orc_kv_size(self.h)
+
+    def key(self, rank: int) -> bytes:
+        out = C.create_string_buffer(70000)
+        n = lib().orc_kv_key(self.h, rank, out, len(out))
+        return out.raw[:n]
+
+    def match_all(self, tenant, topics: Sequence, max_persistent_fanout: int = INT_MAX,
+                  max_group_fanout: int = INT_MAX) -> MatchResult:
+        """One TenantRouteMatcher.matchAll call (DW/cache/TenantRouteMatcher.java:67-161)."""
+        t = _b(tenant)
+        data, off = pack(topics)
+        res = MatchResult(len(topics))
+        lib().orc_match_all(self.h, t, len(t), _ptr(data), _ptr(off), len(topics), max_persistent_fanout,
+                            max_group_fanout, res.h)
+        return res
+
+    def match_singletons(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed, threads: int = 1):
+        """Production call pattern: matchAll(singleton(topic)) per topic. -> (MatchResult, seconds)"""
+        tdata, toff = pack(tenants)
+        data, off = topics_packed
+        tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
+        n = len(off) - 1
+        res = MatchResult(n)
+        sec = lib().orc_match_singletons(self.h, _ptr(tdata), _ptr(toff), _ptr(tt), _ptr(data), _ptr(off), n,
+                                         threads, res.h)
+        return res, sec
+
+    def match_bruteforce(self, tenant, topics: Sequence) -> MatchResult:
+        """Semantic oracle (A): every key of the tenant tested against every topic."""
+        t = _b(tenant)
+        data, off = pack(topics)
+        res = MatchResult(len(topics))
+        lib().orc_match_bruteforce(self.h, t, len(t), _ptr(data), _ptr(off), len(topics), res.h)
+        return res
+
+    def count_visits(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed) -> np.ndarray:
+        tdata, toff = pack(tenants)
+        data, off = topics_packed
+        tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
+        n = len(off) - 1
+        out = np.zeros(n, dtype=np.uint32)
+        lib().orc_count_visits(self.h, _ptr(tdata), _ptr(toff), _ptr(tt), _ptr(data), _ptr(off), n, _ptr(out))
+        return out
+
+    def __del__(self):
+        if self.h:
+            lib().orc_kv_free(self.h)
+            self.h = None
+
+
+# ---- retain direction ---------------------------------------------------------------------------
+class LevelTrie:
+    """TopicLevelTrie + selector. sys_level=0: DW/TopicIndex.java (no tenant level);
+    sys_level=1: RS/index/RetainTopicIndex.java (level 0 = tenant)."""
+
+    def __init__(self, sys_level: int):
+        self.sys_level = sys_level
+        self.h = lib().orc_ltrie_new(sys_level)
+
+    def add(self, tenant, topic, value: int):
+        t, p = _b(tenant or ""), _b(topic)
+        lib().orc_ltrie_add(self.h, t, len(t), self.sys_level, p, len(p), value)
+
+    def remove(self, tenant, topic, value: int):
+        t, p = _b(tenant or ""), _b(topic)
+        lib().orc_ltrie_remove(self.h, t, len(t), self.sys_level, p, len(p), value)
+
+    def match(self, tenant, topic_filter) -> List[int]:
+        t, f = _b(tenant or ""), _b(topic_filter)
+        cap = 1 << 16
+        out = (C.c_int * cap)()
+        n = lib().orc_ltrie_match(self.h, t, len(t), self.sys_level, f, len(f), 0, out, cap)
+        if n > cap:
+            out = (C.c_int * n)()
+            n = lib().orc_ltrie_match(self.h, t, len(t), self.sys_level, f, len(f), 0, out, n)
+        return list(out[:n])
+
+    def find_all(self) -> List[int]:
+        cap = 1 << 16
+        out = (C.c_int * cap)()
+        n = lib().orc_ltrie_match(self.h, b"", 0, self.sys_level, b"", 0, 1, out, cap)
+        return list(out[:n])
+
+    def match_batch(self, tenants: Sequence, filter_tenant: np.ndarray, filters_packed, threads: int = 1):
+        tdata, toff = pack(tenants)
+        data, off = filters_packed
+        ft = np.ascontiguousarray(filter_tenant, dtype=np.uint32)
+        n = len(off) - 1
+        res = MatchResult(n)
+        sec = lib().orc_ltrie_match_batch(self.h, _ptr(tdata), _ptr(toff), _ptr(ft), _ptr(data), _ptr(off), n,
+                                          threads, res.h)
+        return res, sec
+
+    @property
+    def visits(self) -> int:
+        return lib().orc_ltrie_visits(self.h)
+
+    def __del__(self):
+        if self.h:
+            lib().orc_ltrie_free(self.h)
+            self.h = None
