@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- publish-topic matches/s of the MI355X engine on BASELINE.json's workload.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic publishes: tokenise + trie walk + CSR expand of
+--topics (default 1M) publish topics against this rank's shard of the filter index, inputs resident in HBM, results
+left in HBM (plus, for N > 1, the one exchange step of SURVEY.md 8e: an all-gather of every rank's CSR).
+Workload (config.workload):
+  c3 (default): 1000 tenants x 10k routes = 10M route keys (the index size BASELINE.json's metric is quoted at; it fits
+      one GPU), Zipf(1.0) tenant popularity, 1M publishes per batch.  N > 1: tenants are partitioned across ranks
+      (tenant-id blocks -- the synthetic stand-in for hash(tenantId) mod N), every rank matches its own 1M-publish
+      batch per step -> weak scaling in publishes, the 10M-route index is split N ways.
+  c2: 1 tenant x 1M routes, 1M publishes (configs[1]).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "small"])
+    ap.add_argument("--topics", type=int, default=1_000_000, help="publishes per batch per rank")
+    ap.add_argument("--batches", type=int, default=4, help="distinct pre-generated batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-tenants", type=int, default=16)
+    ap.add_argument("--cpu-sample-topics", type=int, default=200_000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import bifromq_amd as B
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload: this rank's shard ----------------------------------------------------------------------------------
+    if args.workload == "c3":
+        total_tenants, per_tenant, mode, seed = 1000, 10_000, 1, 0xB1F20003
+        name = "C3: 1000 tenants x 10k routes (10M route keys, +/# mix), Zipf publishes, %d-publish batches" % args.topics
+    elif args.workload == "c2":
+        total_tenants, per_tenant, mode, seed = 1, 1_000_000, 1, 0xB1F20002
+        name = "C2: 1 tenant x 1M routes (+/# mix), %d-publish batches" % args.topics
+    else:
+        total_tenants, per_tenant, mode, seed = 8, 5_000, 1, 0xB1F20009
+        name = "small: 8 tenants x 5k routes"
+    if total_tenants >= world:
+        t_lo = total_tenants * rank // world
+        t_hi = total_tenants * (rank + 1) // world
+    else:  # single-tenant config on several GPUs: replicas (documented in DESIGN.md)
+        t_lo, t_hi = 0, total_tenants
+    t0 = time.time()
+    w = B.Workload(seed, t_hi - t_lo, per_tenant, mode, tenant_base=t_lo)
+    t_gen = time.time() - t0
+    eng = B.Engine(device=local_rank)
+    t0 = time.time()
+    kb, ko = w.keys_packed()
+    eng.rebuild_raw(kb.ctypes.data, ko.ctypes.data, w.n_keys)
+    t_build = time.time() - t0
+    info = eng.info()
+
+    tdata, toff = w.tenants_packed()
+    d_tenants = torch.from_numpy(tdata.copy()).to(dev)
+    d_tenant_off = torch.from_numpy(toff.astype(np.int32)).to(dev)
+    n_tenants = w.n_tenants
+    n = args.topics
+    batches = []
+    for b in range(args.batches):
+        data, off, tt = w.topics(seed + 1000 * (rank + 1) + b, n)
+        batches.append((torch.from_numpy(data).to(dev), torch.from_numpy(off.astype(np.int32)).to(dev),
+                        torch.from_numpy(tt.astype(np.int32)).to(dev), (data, off, tt) if b == 0 else None))
+    cap = 16 * n
+    d_row = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def step(i):
+        nonlocal d_ids, cap
+        bt = batches[i % len(batches)]
+        while True:
+            eng.match_batch_device(d_tenants.data_ptr(), d_tenant_off.data_ptr(), n_tenants, bt[2].data_ptr(),
+                                   bt[0].data_ptr(), bt[1].data_ptr(), n, d_row.data_ptr(), d_ids.data_ptr(), cap,
+                                   d_total.data_ptr())
+            try:
+                total = eng.finish()  # stream sync + counters
+                break
+            except B.BmqError as ex:
+                if ex.code != -3:
+                    raise
+                cap = int(d_total.item()) * 2  # only during warm-up in practice
+                d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+        if world > 1:  # the one exchange step: every rank's CSR (row counts + ids) to every rank over RCCL/xGMI
+            cnt = torch.tensor([total], dtype=torch.int64, device=dev)
+            cnts = torch.empty(world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(cnts, cnt)
+            mx = int(cnts.max().item())
+            rows_all = torch.empty(world * (n + 1), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(rows_all, d_row)
+            ids_all = torch.empty(world * mx, dtype=torch.int32, device=dev)
+            if d_ids.numel() < mx:
+                d_ids = torch.cat([d_ids, torch.zeros(mx - d_ids.numel(), dtype=torch.int32, device=dev)])
+                cap = d_ids.numel()
+            dist.all_gather_into_tensor(ids_all, d_ids[:mx])
+            torch.cuda.synchronize()
+        return total
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    lat = []
+    walk_ms, expand_ms, total_ms = [], [], []
+    alg_bytes = []
+    n_match = n_visit = 0
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        step(i)
+        lat.append((time.perf_counter() - ts) * 1e3)
+        st = eng.stats()  # HIP-event times recorded on the engine's stream for this batch
+        walk_ms.append(st.ms_walk)
+        expand_ms.append(st.ms_expand)
+        total_ms.append(st.ms_total)
+        # ALGORITHMIC bytes: len(topic) + 8 + 32 * N_visit + 4 * N_match, summed over the batch
+        alg_bytes.append(st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit + 4 * st.n_match)
+        n_match += st.n_match
+        n_visit += st.n_visit
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    steps = args.steps
+    value = world * n * steps / elapsed
+    k_walk_ms = float(np.mean(walk_ms))
+    achieved = float(np.mean(alg_bytes)) / (k_walk_ms * 1e-3) / 1e9  # GB/s
+    out = {
+        "metric": "publish-topic matches/sec (whole node)",
+        "value": value,
+        "unit": "topics/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": name, "total_route_keys": total_tenants * per_tenant, "route_keys_this_rank": int(info.n_routes),
+                   "tenants_this_rank": int(info.n_tenants), "trie_nodes_this_rank": int(info.n_nodes),
+                   "index_bytes_this_rank": int(info.device_bytes), "publishes_per_batch_per_rank": n,
+                   "parallelism": "tenant-shard x%d" % world if world > 1 else "single GPU",
+                   "exchange": "RCCL all_gather of CSR (row_ptr + ids)" if world > 1 else "none"},
+        "p99_batch_ms": float(np.percentile(lat, 99)),
+        "p50_batch_ms": float(np.percentile(lat, 50)),
+        "routes_per_topic": n_match / (n * steps),
+        "visits_per_topic": n_visit / (n * steps),
+        "kernel_ms": {"k_walk": k_walk_ms, "k_expand": float(np.mean(expand_ms)), "all_kernels": float(np.mean(total_ms))},
+        "host_s": {"generate": t_gen, "rebuild": t_build},
+        "roofline": {"bound": "hbm", "kernel": "k_walk", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": float(np.mean(alg_bytes))},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(traffic_file):  # HBM bytes per k_walk launch from the committed rocprofv3 --pmc passes
+        try:
+            out["roofline"]["traffic"] = json.load(open(traffic_file)).get(args.workload)
+        except Exception:
+            pass
+
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, w, host_batch, n):
+    """The reference's algorithm (structural restatement of TenantRouteMatcher.matchAll, oracle/bmq_oracle.cpp) in the
+    reference's production call pattern -- one matchAll(singleton(topic)) per publish (TenantRouteCache.java:180-193) --
+    on all host cores, on a bounded sample: the first S tenants of rank 0's shard and the publishes of batch 0 that
+    address them."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    cores = os.cpu_count() or 1
+    S = min(args.cpu_sample_tenants, w.n_tenants)
+    first = w.tenant_first()
+    kb, ko = w.keys_packed()
+    hi = int(first[S])
+    sub_off = ko[:hi + 1].copy()
+    kv = O.KV(packed=(kb[:int(sub_off[-1]) + 1], sub_off))
+    data, off, tt = host_batch
+    sel = np.nonzero(tt < S)[0][:args.cpu_sample_topics]
+    raw = data.tobytes()
+    topics = [raw[off[i]:off[i + 1]] for i in sel]
+    packed = O.pack(topics)
+    res, sec = kv.match_singletons(w.tenants()[:S], tt[sel], packed, threads=cores)
+    return {"value": len(sel) / sec, "unit": "topics/s", "cores": cores, "kind": "port",
+            "sample": "%d publishes of batch 0 addressed to the first %d tenants (%d route keys) of rank 0's shard; one "
+                      "matchAll(singleton(topic)) per publish on %d threads; %.1f s" % (len(sel), S, hi, cores, sec),
+            "reference_livelocks_stepped_over": int(res.livelocks)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""ctypes loader of libbmq.so (the C-ABI engine, include/bmq.h) and libbmq_gen.so (workload generator).
+
+The libraries are built IN-TREE by `make -C bifromq_amd/csrc all` (hipcc --offload-arch=gfx950); see
+__graft_entry__.build().  Loading fails loudly if the HIP library is missing -- there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbmq.so")
+GEN_PATH = os.path.join(_HERE, "libbmq_gen.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/bmq.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_routes_apply",
+    "bmq_index_info_get", "bmq_route_key", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
+    "bmq_match_finish", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
+    "bmq_route_key_decode", "bmq_java_string_hash", "bmq_retain_rebuild", "bmq_retain_apply", "bmq_retain_topic",
+    "bmq_retain_match_batch", "bmq_retain_match_batch_dev",
+]
+
+
+def build(force: bool = False) -> None:
+    """(Re)build the in-tree shared libraries when sources are newer than the binaries."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", ".inc"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "bmq.h"))
+    newest = max(os.path.getmtime(s) for s in srcs)
+    stale = force or any(not os.path.exists(p) or os.path.getmtime(p) < newest for p in (LIB_PATH, GEN_PATH))
+    if stale:
+        cmd = ["make", "-C", CSRC, "all"] + (["-B"] if force else [])
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("wave_queue_cap", C.c_uint32),
+                ("wave_pair_cap", C.c_uint32), ("slow_scratch_mb", C.c_uint32), ("reserved", C.c_uint32 * 8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_topics", C.c_uint64), ("n_visit", C.c_uint64), ("n_match", C.c_uint64), ("n_ranges", C.c_uint64),
+                ("n_slow_topics", C.c_uint64), ("n_sorted_rows", C.c_uint64), ("topic_bytes", C.c_uint64),
+                ("ms_total", C.c_float), ("ms_walk", C.c_float), ("ms_expand", C.c_float), ("ms_reserved", C.c_float)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n_routes", C.c_uint64), ("n_tenants", C.c_uint64), ("n_nodes", C.c_uint64), ("n_tokens", C.c_uint64),
+                ("trie_slots", C.c_uint64), ("dict_slots", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("epoch", C.c_uint64)]
+
+
+_lib = None
+_gen = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+        P = C.POINTER
+        sig = {
+            "bmq_engine_create": (C.c_int, [P(Config), P(vp)]),
+            "bmq_engine_destroy": (None, [vp]),
+            "bmq_last_error": (C.c_char_p, [vp]),
+            "bmq_version": (C.c_char_p, []),
+            "bmq_rebuild": (C.c_int, [vp, vp, vp, u32]),
+            "bmq_routes_apply": (C.c_int, [vp, vp, vp, vp, u32]),
+            "bmq_index_info_get": (C.c_int, [vp, P(IndexInfo)]),
+            "bmq_route_key": (C.c_int, [vp, u32, C.c_char_p, u32, P(u32)]),
+            "bmq_index_find": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32, vp, u32, P(u32)]),
+            "bmq_match_batch": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, P(u64)]),
+            "bmq_match_batch_dev": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, vp]),
+            "bmq_match_finish": (C.c_int, [vp, P(u64)]),
+            "bmq_sync": (C.c_int, [vp]),
+            "bmq_stats_get": (C.c_int, [vp, P(Stats)]),
+            "bmq_stream": (vp, [vp]),
+            "bmq_match_all": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, i32, i32, vp, vp, u64, P(u64), vp, u32, P(u32)]),
+            "bmq_route_key_encode": (u32, [C.c_char_p, u32, C.c_char_p, u32, C.c_uint8, C.c_char_p, u32, C.c_char_p, u32]),
+            "bmq_route_key_decode": (C.c_int, [C.c_char_p, u32, P(u32)]),
+            "bmq_java_string_hash": (i32, [C.c_char_p, u32]),
+            "bmq_retain_rebuild": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32]),
+            "bmq_retain_apply": (C.c_int, [vp, C.c_char_p, u32, vp, vp, vp, u32]),
+            "bmq_retain_topic": (C.c_int, [vp, u32, C.c_char_p, u32, P(u32), P(u32)]),
+            "bmq_retain_match_batch": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, P(u64)]),
+            "bmq_retain_match_batch_dev": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, vp]),
+        }
+        assert sorted(sig) == sorted(ABI_SYMBOLS)
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)  # AttributeError here == symbol missing from the .so
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def gen() -> C.CDLL:
+    global _gen
+    if _gen is None:
+        if not os.path.exists(GEN_PATH):
+            raise RuntimeError(f"{GEN_PATH} is missing: run __graft_entry__.build()")
+        G = C.CDLL(GEN_PATH)
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        sig = {
+            "bmqgen_create": (vp, [u64, u32, u32, u32, C.c_int]), "bmqgen_destroy": (None, [vp]),
+            "bmqgen_n_keys": (u32, [vp]), "bmqgen_key_bytes": (vp, [vp]), "bmqgen_key_off": (vp, [vp]),
+            "bmqgen_n_tenants": (u32, [vp]), "bmqgen_tenant_bytes": (vp, [vp]), "bmqgen_tenant_off": (vp, [vp]),
+            "bmqgen_tenant_first": (vp, [vp]),
+            "bmqgen_topics": (u32, [vp, u64, u32, u32, u32, u32]),
+            "bmqgen_topic_bytes": (vp, [vp]), "bmqgen_topic_off": (vp, [vp]), "bmqgen_topic_tenant": (vp, [vp]),
+            "bmqgen_retain": (u32, [vp, u64, u32, C.c_int]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(G, name)
+            fn.restype = res
+            fn.argtypes = args
+        _gen = G
+    return _gen

@@ -1,0 +1,662 @@
+// bmq_dist_kernels.h -- gfx950 (wave64) kernels of the dist-direction match path.
+//
+// Replaces, for a whole batch at once, what TenantRouteMatcher.matchAll does per topic on a
+// matcher thread (DW/cache/TenantRouteMatcher.java:67-161): resolve every publish topic to the ids
+// of all routes whose filter matches it.  Semantics follow SURVEY.md 8a-0 (TRIE/TopicTrieNode.java:150-152
+// for the '$' rule, TRIE/NTopicFilterTrieNode.java:143-146 for '#' matching the parent level).
+//
+// Included only by bmq_engine.hip (hipcc --offload-arch=gfx950).  Work decomposition:
+//   k_resolve_tenants : one lane per distinct tenant of the batch -> root slot
+//   k_walk            : one wave per 64 topics.  Phase 1: every lane tokenises its own topic into LDS
+//                       (levels -> dictionary tokens, bytes verified).  Phase 2: the wave drains a shared LDS
+//                       work ring of (node, topic, level) items, one item per lane per round, one 32-byte
+//                       random HBM read per item; pushes and matches are compacted with ballot + mbcnt.
+//                       Phase 3: matched (begin,count) ranges are counting-sorted by topic and written out.
+//   k_walk_slow       : per-lane DFS with global scratch for topics the LDS path could not finish
+//                       (more than FAST_LEVELS levels, ring or range buffer overflow).
+//   k_scan_blocks     : exclusive scan of the per-wave id counts.
+//   k_expand          : per topic, order its ranges by first id and stream the ids into the CSR output.
+//   k_sort_rows       : bitonic fix-up of the (rare) rows whose ranges interleave (SURVEY.md 8c quirk ii).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bmq_layout.h"
+
+namespace bmq {
+
+// status bits raised by kernels, resolved by the host in bmq_match_finish()
+enum : uint32_t {
+    ST_NEED_PAIRS = 1u,    // matched-range buffer too small
+    ST_NEED_SLOW = 2u,     // slow-topic list too small
+    ST_NEED_SCRATCH = 4u,  // slow-path scratch too small
+    ST_NOSPACE = 8u,       // caller's id buffer too small
+    ST_RANGE = 16u,        // >= 2^32 ids
+    ST_NEED_SORTLIST = 32u // fix-up list too small
+};
+
+struct Counters { // one per batch, zeroed before launch
+    unsigned long long pair_alloc;
+    unsigned long long scratch_alloc; // in uint32 units
+    unsigned long long n_visit;
+    unsigned long long total_ids;
+    unsigned long long n_ranges;
+    unsigned long long topic_bytes;
+    uint32_t slow_count;
+    uint32_t sort_count;
+    uint32_t status;
+    uint32_t pad;
+};
+
+struct BatchArgs {
+    DistIndexView ix;
+    // inputs (device)
+    const uint8_t* tenants;
+    const uint32_t* tenant_off;
+    uint32_t n_tenants;
+    const uint32_t* topic_tenant;
+    const uint8_t* topics;
+    const uint32_t* topic_off;
+    uint32_t n_topics;
+    // per-batch scratch (device)
+    uint32_t* tenant_root; // [n_tenants]
+    uint32_t* pair_off;    // [n_topics]
+    uint32_t* pair_cnt;    // [n_topics]
+    uint32_t* route_cnt;   // [n_topics]
+    MatchRange* pairs;
+    unsigned long long pair_cap;
+    unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block; scanned in place to exclusive bases
+    uint32_t n_blocks;
+    uint32_t* slow_list;
+    uint32_t slow_cap;
+    uint32_t* scratch;
+    unsigned long long scratch_cap; // uint32 units
+    uint32_t* sort_list;
+    uint32_t sort_cap;
+    Counters* ctr;
+    // outputs (device)
+    uint32_t* out_row_ptr;
+    uint32_t* out_ids;
+    unsigned long long out_capacity;
+    unsigned long long* out_total;
+    // LDS geometry
+    uint32_t qcap; // pow2
+    uint32_t pcap;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ uint32_t rank_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t& total) {
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    total = __shfl(inc, 63);
+    return inc - v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ TrieSlot load_slot(const TrieSlot* trie, uint32_t idx) {
+    const uint4* p = reinterpret_cast<const uint4*>(trie + idx);
+    const uint4 a = p[0], b = p[1];
+    TrieSlot s;
+    s.parent = a.x; s.token = a.y; s.own_begin = a.z; s.own_count = a.w;
+    s.hash_begin = b.x; s.hash_count = b.y; s.plus_child = b.z; s.lit_bloom = b.w;
+    return s;
+}
+
+// (parent, token) -> child slot; NONE if absent.  On a hit `out` holds the child's header.
+__device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_t parent, uint32_t token, TrieSlot& out) {
+    uint32_t s = edge_hash(parent, token) & ix.trie_mask;
+    for (;;) {
+        const TrieSlot c = load_slot(ix.trie, s);
+        if (c.parent == parent && c.token == token) {
+            out = c;
+            return s;
+        }
+        if (c.parent == NONE) return NONE;
+        s = (s + 1) & ix.trie_mask;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// tokeniser: bytes -> levels -> dictionary tokens (exact: tag + length + bytes compared)
+// ------------------------------------------------------------------------------------------------------------
+struct ByteReader { // 8-byte chunked reads of a packed string buffer (base 8-byte aligned, padded to 8)
+    const uint8_t* base;
+    unsigned long long w;
+    uint32_t wbase;
+    __device__ __forceinline__ explicit ByteReader(const uint8_t* b) : base(b), w(0), wbase(0xFFFFFFFFu) {}
+    __device__ __forceinline__ uint32_t at(uint32_t i) {
+        const uint32_t a = i & ~7u;
+        if (a != wbase) {
+            w = *reinterpret_cast<const unsigned long long*>(base + a);
+            wbase = a;
+        }
+        return (uint32_t)(w >> ((i & 7u) * 8u)) & 0xFFu;
+    }
+};
+
+__device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const LevelHash& h, uint32_t len,
+                                                const uint32_t inl[4], ByteReader& rd, uint32_t start) {
+    const uint32_t tag = level_hash_tag(h);
+    uint32_t s = level_hash_slot(h, len) & ix.dict_mask;
+    for (;;) {
+        const uint4* p = reinterpret_cast<const uint4*>(ix.dict + s);
+        const uint4 a = p[0];
+        if (a.x == 0) return TOK_UNKNOWN;
+        if (a.x == tag && a.z == len) {
+            const uint4 b = p[1];
+            if (b.x == inl[0] && b.y == inl[1] && b.z == inl[2] && b.w == inl[3]) {
+                bool eq = true;
+                for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[a.w + i] == rd.at(start + i);
+                if (eq) return a.y;
+            }
+        }
+        s = (s + 1) & ix.dict_mask;
+    }
+}
+
+// Walks the bytes [beg,end) of one string.  split=true: levels separated by '/', empty levels kept
+// (UTIL/TopicUtil.java:206-225); split=false: the whole string is one level (tenant ids).
+// sink(level_index, token) is called for every level; returns the level count.
+template <class Sink>
+__device__ __forceinline__ uint32_t tokenise(const DistIndexView& ix, const uint8_t* base, uint32_t beg, uint32_t end,
+                                             bool split, uint32_t max_store, Sink&& sink) {
+    ByteReader rd(base);
+    LevelHash h = level_hash_init();
+    uint32_t inl[4] = {0, 0, 0, 0};
+    uint32_t len = 0, start = beg, level = 0;
+    for (uint32_t i = beg; i <= end; i++) {
+        const uint32_t c = (i < end) ? rd.at(i) : 0x100u;
+        if (c == 0x100u || (split && c == '/')) {
+            if (level < max_store) sink(level, dict_lookup(ix, h, len, inl, rd, start));
+            level++;
+            h = level_hash_init();
+            inl[0] = inl[1] = inl[2] = inl[3] = 0;
+            len = 0;
+            start = i + 1;
+        } else {
+            level_hash_step(h, c);
+            if (len < 16) inl[len >> 2] |= c << ((len & 3u) * 8u);
+            len++;
+        }
+    }
+    return level;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_resolve_tenants
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n_tenants) return;
+    uint32_t tok = TOK_UNKNOWN;
+    tokenise(a.ix, a.tenants, a.tenant_off[i], a.tenant_off[i + 1], false, 1, [&](uint32_t, uint32_t t) { tok = t; });
+    uint32_t root = NONE;
+    if (tok != TOK_UNKNOWN) {
+        TrieSlot s;
+        root = probe_child(a.ix, ROOT_PARENT, tok, s);
+    }
+    a.tenant_root[i] = root;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the per-item step shared by the LDS path and the slow path
+// ------------------------------------------------------------------------------------------------------------
+// item meta: bits 0-5 topic-local index, bits 6-21 level, bit 31 kind (0 = L: probe literal child of `node` with
+// the topic's token at `level`; 1 = H: `node` is already the discovered slot, arrived after `level` tokens)
+constexpr uint32_t KIND_H = 0x80000000u;
+__device__ __forceinline__ uint32_t make_meta(uint32_t tl, uint32_t level, uint32_t kind) { return tl | (level << 6) | kind; }
+
+struct StepOut {
+    bool found;       // a node was discovered
+    uint32_t idx;     // its slot
+    uint32_t dl;      // levels consumed on arrival
+    bool emit_own, emit_hash, push_l, push_h;
+    TrieSlot s;
+};
+
+// tok_at(level) returns the topic's token at that level; nlev = level count; sys = first level starts with '$'
+template <class TokAt>
+__device__ __forceinline__ void step_item(const DistIndexView& ix, uint32_t node, uint32_t level, bool kind_h,
+                                          uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
+    o.found = false;
+    o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
+    if (kind_h) {
+        o.s = load_slot(ix.trie, node);
+        o.idx = node;
+        o.dl = level;
+        o.found = true;
+    } else {
+        o.idx = probe_child(ix, node, tok_at(level), o.s);
+        o.dl = level + 1;
+        o.found = o.idx != NONE;
+    }
+    if (!o.found) return;
+    const bool root_sys = (o.dl == 0) && sys; // wildcards in filter position 0 never match a '$' topic
+    o.emit_own = (o.dl == nlev) && o.s.own_count != 0;
+    o.emit_hash = o.s.hash_count != 0 && !root_sys;
+    if (o.dl < nlev) {
+        const uint32_t t = tok_at(o.dl);
+        o.push_l = t != TOK_UNKNOWN && ((o.s.lit_bloom >> bloom_bit(t)) & 1u);
+        o.push_h = o.s.plus_child != NONE && !root_sys;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_walk -- one wave (= one 64-thread workgroup) per 64 topics
+// ------------------------------------------------------------------------------------------------------------
+// tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (overflow -> slow path), 10 active
+constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9, TM_ACTIVE = 1u << 10;
+
+__global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t* tokens = lds;                         // [FAST_LEVELS][64]
+    uint32_t* tmeta = tokens + FAST_LEVELS * 64;    // [64]
+    uint32_t* cnt_pairs = tmeta + 64;               // [64]
+    uint32_t* cnt_routes = cnt_pairs + 64;          // [64]
+    uint32_t* cursor = cnt_routes + 64;             // [64]
+    uint32_t* q_node = cursor + 64;                 // [qcap]
+    uint32_t* q_meta = q_node + a.qcap;             // [qcap]
+    uint32_t* p_begin = q_meta + a.qcap;            // [pcap]
+    uint32_t* p_count = p_begin + a.pcap;           // [pcap]
+    uint32_t* p_topic = p_count + a.pcap;           // [pcap]
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * 64 + lane;
+    const bool valid = t < a.n_topics;
+    const uint32_t qm = a.qcap - 1;
+
+    // ---- phase 1: tokenise own topic ------------------------------------------------------------------------------
+    uint32_t nlev = 0, root = NONE, tbytes = 0;
+    bool sys = false, deep = false;
+    if (valid) {
+        const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
+        tbytes = end - beg;
+        const uint32_t ti = a.topic_tenant[t];
+        root = ti < a.n_tenants ? a.tenant_root[ti] : NONE;
+        if (root != NONE) { // unknown tenant: no routes, nothing to tokenise
+            nlev = tokenise(a.ix, a.topics, beg, end, true, FAST_LEVELS,
+                            [&](uint32_t l, uint32_t tok) { tokens[l * 64 + lane] = tok; });
+            sys = end > beg && a.topics[beg] == '$';
+            deep = nlev > FAST_LEVELS;
+        }
+    }
+    const bool active = valid && root != NONE && !deep;
+    tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u) | (active ? TM_ACTIVE : 0u);
+    cnt_pairs[lane] = 0;
+    cnt_routes[lane] = 0;
+
+    // ---- phase 2: drain the work ring -----------------------------------------------------------------------------
+    uint32_t head = 0, tail = 0, pcount = 0, visits = 0;
+    {
+        const unsigned long long m = __ballot(active);
+        if (active) {
+            const uint32_t pos = rank_below(m);
+            q_node[pos & qm] = root;
+            q_meta[pos & qm] = make_meta(lane, 0, KIND_H);
+        }
+        tail = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    while (head != tail) {
+        const uint32_t n = tail - head;
+        const uint32_t take = n < 64 ? n : 64;
+        const bool act = lane < take;
+        uint32_t node = 0, meta = 0;
+        if (act) {
+            node = q_node[(head + lane) & qm];
+            meta = q_meta[(head + lane) & qm];
+        }
+        head += take;
+        const uint32_t tl = meta & 63u, level = (meta >> 6) & 0xFFFFu;
+        StepOut o;
+        o.found = o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
+        if (act) {
+            const uint32_t tm = tmeta[tl];
+            if (!(tm & TM_FLAG))
+                step_item(a.ix, node, level, (meta & KIND_H) != 0, tm & 0xFFu, (tm & TM_SYS) != 0,
+                          [&](uint32_t l) { return tokens[l * 64 + tl]; }, o);
+        }
+        if (o.found && o.dl) visits++;
+        // matched ranges -> LDS buffer
+        const unsigned long long m1 = __ballot(o.emit_own), m2 = __ballot(o.emit_hash);
+        if (m1 | m2) {
+            const uint32_t c1 = (uint32_t)__popcll(m1);
+            if (o.emit_own) {
+                const uint32_t pos = pcount + rank_below(m1);
+                if (pos < a.pcap) {
+                    p_begin[pos] = o.s.own_begin; p_count[pos] = o.s.own_count; p_topic[pos] = tl;
+                    atomicAdd(&cnt_pairs[tl], 1u);
+                    atomicAdd(&cnt_routes[tl], o.s.own_count);
+                } else atomicOr(&tmeta[tl], TM_FLAG);
+            }
+            if (o.emit_hash) {
+                const uint32_t pos = pcount + c1 + rank_below(m2);
+                if (pos < a.pcap) {
+                    p_begin[pos] = o.s.hash_begin; p_count[pos] = o.s.hash_count; p_topic[pos] = tl;
+                    atomicAdd(&cnt_pairs[tl], 1u);
+                    atomicAdd(&cnt_routes[tl], o.s.hash_count);
+                } else atomicOr(&tmeta[tl], TM_FLAG);
+            }
+            pcount += c1 + (uint32_t)__popcll(m2);
+        }
+        // children -> ring
+        const unsigned long long ml = __ballot(o.push_l), mh = __ballot(o.push_h);
+        if (ml | mh) {
+            const uint32_t cl = (uint32_t)__popcll(ml);
+            if (o.push_l) {
+                const uint32_t pos = tail + rank_below(ml);
+                if (pos - head < a.qcap) {
+                    q_node[pos & qm] = o.idx;
+                    q_meta[pos & qm] = make_meta(tl, o.dl, 0);
+                } else atomicOr(&tmeta[tl], TM_FLAG);
+            }
+            if (o.push_h) {
+                const uint32_t pos = tail + cl + rank_below(mh);
+                if (pos - head < a.qcap) {
+                    q_node[pos & qm] = o.s.plus_child;
+                    q_meta[pos & qm] = make_meta(tl, o.dl + 1, KIND_H);
+                } else atomicOr(&tmeta[tl], TM_FLAG);
+            }
+            uint32_t nt = tail + cl + (uint32_t)__popcll(mh);
+            if (nt - head > a.qcap) nt = head + a.qcap;
+            tail = nt;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 3: ranges grouped by topic -> global; per-topic bookkeeping --------------------------------------
+    const uint32_t tm = tmeta[lane];
+    const bool flagged = (tm & TM_FLAG) != 0;
+    const uint32_t np = flagged ? 0u : cnt_pairs[lane];
+    const uint32_t nr = flagged ? 0u : cnt_routes[lane];
+    uint32_t total_pairs;
+    const uint32_t excl = wave_excl_scan(np, lane, total_pairs);
+    unsigned long long base = 0;
+    if (lane == 0 && total_pairs) base = atomicAdd(&a.ctr->pair_alloc, (unsigned long long)total_pairs);
+    base = __shfl(base, 0);
+    const bool fits = base + total_pairs <= a.pair_cap;
+    if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_PAIRS);
+    cursor[lane] = excl;
+    __syncthreads();
+    if (fits) {
+        const uint32_t stored = pcount < a.pcap ? pcount : a.pcap;
+        for (uint32_t i = lane; i < stored; i += 64) {
+            const uint32_t tl = p_topic[i];
+            if (tmeta[tl] & TM_FLAG) continue;
+            const uint32_t dst = atomicAdd(&cursor[tl], 1u);
+            a.pairs[base + dst] = MatchRange{p_begin[i], p_count[i]};
+        }
+    }
+    if (valid) {
+        a.pair_off[t] = (uint32_t)(base + excl); // pair_cap < 2^32 is enforced by the host
+        a.pair_cnt[t] = np;
+        a.route_cnt[t] = nr;
+        if (flagged) {
+            const uint32_t sp = atomicAdd(&a.ctr->slow_count, 1u);
+            if (sp < a.slow_cap) a.slow_list[sp] = t;
+            else atomicOr(&a.ctr->status, ST_NEED_SLOW);
+        }
+    }
+    const unsigned long long wsum = wave_sum_u64(nr);
+    const unsigned long long wvis = wave_sum_u64(visits);
+    const unsigned long long wbytes = wave_sum_u64(tbytes);
+    if (lane == 0) {
+        a.wave_sums[blockIdx.x] = wsum;
+        if (wvis) atomicAdd(&a.ctr->n_visit, wvis);
+        if (total_pairs) atomicAdd(&a.ctr->n_ranges, (unsigned long long)total_pairs);
+        atomicAdd(&a.ctr->topic_bytes, wbytes);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_walk_slow -- per-lane depth-first walk, tokens + stack in global scratch, two passes (count, write)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
+    const uint32_t n_slow = a.ctr->slow_count < a.slow_cap ? a.ctr->slow_count : a.slow_cap;
+    for (uint32_t i = blockIdx.x * 64 + threadIdx.x; i < n_slow; i += gridDim.x * 64) {
+        const uint32_t t = a.slow_list[i];
+        const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
+        const uint32_t ti = a.topic_tenant[t];
+        const uint32_t root = ti < a.n_tenants ? a.tenant_root[ti] : NONE;
+        if (root == NONE) continue;
+        // level count first (cheap scan), then scratch: nlev tokens + (nlev + 2) stack entries of 2 words
+        uint32_t nlev = 1;
+        {
+            ByteReader rd(a.topics);
+            for (uint32_t j = beg; j < end; j++) nlev += rd.at(j) == '/';
+        }
+        const unsigned long long need = (unsigned long long)nlev + 2ull * (nlev + 2);
+        const unsigned long long so = atomicAdd(&a.ctr->scratch_alloc, need);
+        if (so + need > a.scratch_cap) {
+            atomicOr(&a.ctr->status, ST_NEED_SCRATCH);
+            continue;
+        }
+        uint32_t* toks = a.scratch + so;
+        uint32_t* stack = toks + nlev;
+        tokenise(a.ix, a.topics, beg, end, true, nlev, [&](uint32_t l, uint32_t tok) { toks[l] = tok; });
+        const bool sys = end > beg && a.topics[beg] == '$';
+        unsigned long long base = 0;
+        uint32_t np = 0, nr = 0, visits = 0;
+        bool ok = true;
+        for (int pass = 0; pass < 2 && ok; pass++) {
+            uint32_t sp = 0, wp = 0;
+            stack[0] = root;
+            stack[1] = make_meta(0, 0, KIND_H);
+            sp = 1;
+            while (sp) {
+                sp--;
+                const uint32_t node = stack[2 * sp], meta = stack[2 * sp + 1];
+                const uint32_t level = (meta >> 6) & 0x1FFFFFFu;
+                StepOut o;
+                step_item(a.ix, node, level, (meta & KIND_H) != 0, nlev, sys, [&](uint32_t l) { return toks[l]; }, o);
+                if (!o.found) continue;
+                if (pass == 0 && o.dl) visits++;
+                if (o.emit_own) {
+                    if (pass == 0) { np++; nr += o.s.own_count; }
+                    else a.pairs[base + wp++] = MatchRange{o.s.own_begin, o.s.own_count};
+                }
+                if (o.emit_hash) {
+                    if (pass == 0) { np++; nr += o.s.hash_count; }
+                    else a.pairs[base + wp++] = MatchRange{o.s.hash_begin, o.s.hash_count};
+                }
+                if (o.push_l) {
+                    stack[2 * sp] = o.idx;
+                    stack[2 * sp + 1] = o.dl << 6;
+                    sp++;
+                }
+                if (o.push_h) {
+                    stack[2 * sp] = o.s.plus_child;
+                    stack[2 * sp + 1] = ((o.dl + 1) << 6) | KIND_H;
+                    sp++;
+                }
+            }
+            if (pass == 0) {
+                base = np ? atomicAdd(&a.ctr->pair_alloc, (unsigned long long)np) : 0ull;
+                if (base + np > a.pair_cap) {
+                    atomicOr(&a.ctr->status, ST_NEED_PAIRS);
+                    ok = false;
+                }
+            }
+        }
+        if (!ok) continue;
+        a.pair_off[t] = (uint32_t)base;
+        a.pair_cnt[t] = np;
+        a.route_cnt[t] = nr;
+        if (nr) atomicAdd(&a.wave_sums[t >> 6], (unsigned long long)nr);
+        if (visits) atomicAdd(&a.ctr->n_visit, (unsigned long long)visits);
+        if (np) atomicAdd(&a.ctr->n_ranges, (unsigned long long)np);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_scan_blocks -- exclusive scan of wave_sums (one workgroup of 1024 threads), total -> counters / out_total
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (a.n_blocks + 1023) / 1024;
+    const uint32_t b0 = tid * per, b1 = min(b0 + per, a.n_blocks);
+    unsigned long long s = 0;
+    for (uint32_t i = b0; i < b1; i++) s += a.wave_sums[i];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        unsigned long long v = 0;
+        if (tid >= d) v = part[tid - d];
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[tid] - s;
+    for (uint32_t i = b0; i < b1; i++) {
+        const unsigned long long v = a.wave_sums[i];
+        a.wave_sums[i] = run;
+        run += v;
+    }
+    if (tid == 1023) {
+        const unsigned long long total = part[1023];
+        a.ctr->total_ids = total;
+        *a.out_total = total;
+        if (total > a.out_capacity) atomicOr(&a.ctr->status, ST_NOSPACE);
+        if (total >= 0xFFFFFFFFull) atomicOr(&a.ctr->status, ST_RANGE);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_expand -- CSR row pointers + ids.  One wave per 64 topics (same blocking as k_walk).
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t SMALL_ROW = 16;   // rows up to this many ids are copied by their own lane
+constexpr uint32_t SORT_PAIRS = 32;  // range lists up to this length are ordered in place (insertion sort)
+
+__global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * 64 + lane;
+    const bool valid = t < a.n_topics;
+    const uint32_t status = a.ctr->status;
+    const uint32_t nr = valid ? a.route_cnt[t] : 0u;
+    uint32_t wtotal;
+    const uint32_t excl = wave_excl_scan(nr, lane, wtotal);
+    const unsigned long long row = a.wave_sums[blockIdx.x] + excl;
+    const bool writable = !(status & (ST_NOSPACE | ST_RANGE | ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH));
+    if (valid && !(status & ST_RANGE)) {
+        a.out_row_ptr[t] = (uint32_t)row;
+        if (t == a.n_topics - 1) a.out_row_ptr[a.n_topics] = (uint32_t)(row + nr);
+    }
+    if (!writable) return;
+    const uint32_t po = valid ? a.pair_off[t] : 0u;
+    const uint32_t np = valid ? a.pair_cnt[t] : 0u;
+    // order this topic's ranges by first id (positions in route_pos are ordered by first id)
+    if (np > 1 && np <= SORT_PAIRS) {
+        MatchRange* pr = a.pairs + po;
+        for (uint32_t i = 1; i < np; i++) {
+            const MatchRange x = pr[i];
+            uint32_t j = i;
+            while (j > 0 && pr[j - 1].begin > x.begin) {
+                pr[j] = pr[j - 1];
+                j--;
+            }
+            pr[j] = x;
+        }
+    }
+    bool unsorted = np > SORT_PAIRS;
+    uint32_t* out = a.out_ids + row;
+    // small rows: own lane
+    if (nr && nr <= SMALL_ROW) {
+        uint32_t k = 0, prev = 0;
+        for (uint32_t p = 0; p < np; p++) {
+            const MatchRange r = a.pairs[po + p];
+            for (uint32_t j = 0; j < r.count; j++) {
+                const uint32_t id = a.ix.route_pos[r.begin + j];
+                if (k && id <= prev) unsorted = true;
+                prev = id;
+                out[k++] = id;
+            }
+        }
+    }
+    // big rows: the whole wave streams each of them
+    unsigned long long big = __ballot(nr > SMALL_ROW);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t b_po = __shfl(po, src), b_np = __shfl(np, src);
+        const unsigned long long b_row = __shfl(row, src);
+        uint32_t* bout = a.out_ids + b_row;
+        uint32_t done = 0, last = 0;
+        bool bad = false;
+        for (uint32_t p = 0; p < b_np; p++) {
+            const MatchRange r = a.pairs[b_po + p];
+            for (uint32_t j0 = 0; j0 < r.count; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                uint32_t id = 0;
+                const bool in = j < r.count;
+                if (in) {
+                    id = a.ix.route_pos[r.begin + j];
+                    bout[done + j] = id;
+                }
+                // order check: against the left neighbour, lane 0 against the last id of the previous chunk
+                uint32_t left = __shfl_up(id, 1);
+                if (lane == 0) left = last;
+                if (in && (done + j) > 0 && id <= left) bad = true;
+                const uint32_t cnt = min(64u, r.count - j0);
+                last = __shfl(id, cnt - 1);
+            }
+            done += r.count;
+        }
+        if (__ballot(bad) && (int)lane == src) unsorted = true;
+    }
+    if (unsorted && nr > 1) {
+        const uint32_t sp = atomicAdd(&a.ctr->sort_count, 1u);
+        if (sp < a.sort_cap) a.sort_list[sp] = t;
+        else atomicOr(&a.ctr->status, ST_NEED_SORTLIST);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_sort_rows -- one workgroup per flagged row, normalised bitonic network in global memory
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
+    const uint32_t n_rows = a.ctr->sort_count < a.sort_cap ? a.ctr->sort_count : a.sort_cap;
+    if (a.ctr->status & (ST_NOSPACE | ST_RANGE | ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH)) return;
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const uint32_t t = a.sort_list[r];
+        const uint32_t lo = a.out_row_ptr[t], n = a.out_row_ptr[t + 1] - lo;
+        uint32_t* v = a.out_ids + lo;
+        uint32_t np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (uint32_t k = 2; k <= np2; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < np2; i += blockDim.x) {
+                    const uint32_t p = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j); // first stage mirrors
+                    if (p > i && p < n) {
+                        const uint32_t x = v[i], y = v[p];
+                        if (x > y) {
+                            v[i] = y;
+                            v[p] = x;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
+    return sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 4 * 64 + 2 * (size_t)qcap + 3 * (size_t)pcap);
+}
+
+} // namespace bmq

@@ -1,0 +1,613 @@
+// bmq_engine.hip -- the engine behind include/bmq.h: owns the HBM-resident index, the per-batch scratch and the
+// HIP stream; launches the gfx950 kernels of bmq_dist_kernels.h / bmq_retain_kernels.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared (see __graft_entry__.build()).
+//
+// There is deliberately NO CPU implementation of the match path in this library: without a device every match
+// entry point returns BMQ_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bmq.h"
+#include "bmq_dist_kernels.h"
+#include "bmq_index.h"
+#include "bmq_retain.h"
+
+using namespace bmq;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // grow-only; contents are NOT preserved
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            want = bytes;
+            e = hipMalloc(&p, want);
+            if (e != hipSuccess) {
+                p = nullptr;
+                return e;
+            }
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct DistDevice { // one epoch of the dist index in HBM
+    DevBuf trie, dict, pool, route_pos;
+    DistIndexView view{};
+    uint64_t bytes = 0;
+};
+
+} // namespace
+
+struct bmq_engine {
+    bmq_config cfg{};
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8]{};
+    std::mutex mu;
+    std::string err;
+
+    // dist direction
+    KeySet keys;
+    DistIndexHost host;
+    std::unique_ptr<DistDevice> dist;
+    uint64_t epoch = 0;
+    bool built = false;
+
+    // per-batch scratch
+    DevBuf b_tenant_root, b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_wave_sums, b_slow_list, b_scratch, b_sort_list,
+        b_ctr, b_total;
+    uint64_t pair_cap = 0, scratch_cap = 0;
+    uint32_t slow_cap = 0, sort_cap = 0;
+    Counters* h_ctr = nullptr; // pinned
+    // staging for the host-buffer API
+    DevBuf s_tenants, s_tenant_off, s_topic_tenant, s_topics, s_topic_off, s_row_ptr, s_ids;
+
+    // last async batch (for bmq_match_finish)
+    bool pending = false;
+    int pending_kind = 0; // 0 dist, 1 retain
+    BatchArgs last{};
+    RetainBatchArgs rlast{};
+    bmq_stats stats{};
+
+    // retain direction
+    RetainIndexHost rhost;
+    RetainDevice rdev;
+    bool rbuilt = false;
+    DevBuf r_items, r_items2, r_cnt, r_blocksum;
+};
+
+namespace {
+
+#define HIPCHK(e, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _err = (expr);                                                                        \
+        if (_err != hipSuccess) {                                                                        \
+            (e)->err = std::string(#expr) + ": " + hipGetErrorString(_err);                              \
+            return BMQ_E_HIP;                                                                            \
+        }                                                                                                \
+    } while (0)
+
+int set_err(bmq_engine* e, int code, const std::string& msg) {
+    e->err = msg;
+    return code;
+}
+
+int upload(bmq_engine* e, DevBuf& b, const void* src, size_t bytes) {
+    HIPCHK(e, b.ensure(bytes ? bytes : 16));
+    if (bytes) HIPCHK(e, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, e->stream));
+    return BMQ_OK;
+}
+
+int upload_dist(bmq_engine* e) {
+    if (e->device < 0) return BMQ_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    auto d = std::make_unique<DistDevice>();
+    const DistIndexHost& h = e->host;
+    int rc;
+    if ((rc = upload(e, d->trie, h.trie.data(), h.trie.size() * sizeof(TrieSlot)))) return rc;
+    if ((rc = upload(e, d->dict, h.dict.data(), h.dict.size() * sizeof(DictSlot)))) return rc;
+    if ((rc = upload(e, d->pool, h.pool.data(), h.pool.size()))) return rc;
+    if ((rc = upload(e, d->route_pos, h.route_pos.data(), h.route_pos.size() * sizeof(uint32_t)))) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    d->view.trie = d->trie.as<TrieSlot>();
+    d->view.trie_mask = (uint32_t)h.trie.size() - 1;
+    d->view.dict = d->dict.as<DictSlot>();
+    d->view.dict_mask = (uint32_t)h.dict.size() - 1;
+    d->view.pool = d->pool.as<uint8_t>();
+    d->view.route_pos = d->route_pos.as<uint32_t>();
+    d->bytes = d->trie.cap + d->dict.cap + d->pool.cap + d->route_pos.cap;
+    e->dist = std::move(d); // previous epoch freed here (match calls are serialised by e->mu)
+    return BMQ_OK;
+}
+
+int rebuild_locked(bmq_engine* e) {
+    if (!e->host.build(e->keys)) return set_err(e, BMQ_E_INVAL, e->host.error);
+    int rc = upload_dist(e);
+    if (rc) return rc;
+    e->epoch++;
+    e->built = true;
+    return BMQ_OK;
+}
+
+// ---- dist batch ------------------------------------------------------------------------------------------------
+int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
+    const uint32_t n_blocks = (n_topics + 63) / 64;
+    if (e->pair_cap == 0) e->pair_cap = 1u << 16;
+    e->pair_cap = std::max<uint64_t>(e->pair_cap, (uint64_t)n_topics * 4);
+    if (e->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
+    if (e->slow_cap == 0) e->slow_cap = 1024;
+    e->slow_cap = std::max<uint32_t>(e->slow_cap, n_topics / 16);
+    if (e->sort_cap == 0) e->sort_cap = 1024;
+    e->sort_cap = std::max<uint32_t>(e->sort_cap, n_topics / 64);
+    if (e->scratch_cap == 0) e->scratch_cap = (uint64_t)(e->cfg.slow_scratch_mb ? e->cfg.slow_scratch_mb : 64) * (1u << 20) / 4;
+    HIPCHK(e, e->b_tenant_root.ensure(sizeof(uint32_t) * std::max(n_tenants, 1u)));
+    HIPCHK(e, e->b_pair_off.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, e->b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, e->b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, e->b_pairs.ensure(sizeof(MatchRange) * e->pair_cap));
+    HIPCHK(e, e->b_wave_sums.ensure(sizeof(unsigned long long) * std::max(n_blocks, 1u)));
+    HIPCHK(e, e->b_slow_list.ensure(sizeof(uint32_t) * e->slow_cap));
+    HIPCHK(e, e->b_sort_list.ensure(sizeof(uint32_t) * e->sort_cap));
+    HIPCHK(e, e->b_scratch.ensure(sizeof(uint32_t) * e->scratch_cap));
+    HIPCHK(e, e->b_ctr.ensure(sizeof(Counters)));
+    HIPCHK(e, e->b_total.ensure(sizeof(unsigned long long)));
+    return BMQ_OK;
+}
+
+int launch_dist(bmq_engine* e, BatchArgs& a) {
+    a.ix = e->dist->view;
+    a.n_blocks = (a.n_topics + 63) / 64;
+    a.tenant_root = e->b_tenant_root.as<uint32_t>();
+    a.pair_off = e->b_pair_off.as<uint32_t>();
+    a.pair_cnt = e->b_pair_cnt.as<uint32_t>();
+    a.route_cnt = e->b_route_cnt.as<uint32_t>();
+    a.pairs = e->b_pairs.as<MatchRange>();
+    a.pair_cap = e->pair_cap;
+    a.wave_sums = e->b_wave_sums.as<unsigned long long>();
+    a.slow_list = e->b_slow_list.as<uint32_t>();
+    a.slow_cap = e->slow_cap;
+    a.scratch = e->b_scratch.as<uint32_t>();
+    a.scratch_cap = e->scratch_cap;
+    a.sort_list = e->b_sort_list.as<uint32_t>();
+    a.sort_cap = e->sort_cap;
+    a.ctr = e->b_ctr.as<Counters>();
+    a.qcap = e->cfg.wave_queue_cap;
+    a.pcap = e->cfg.wave_pair_cap;
+    hipStream_t s = e->stream;
+    HIPCHK(e, hipMemsetAsync(a.ctr, 0, sizeof(Counters), s));
+    HIPCHK(e, hipEventRecord(e->ev[0], s));
+    if (a.n_tenants) hipLaunchKernelGGL(k_resolve_tenants, dim3((a.n_tenants + 63) / 64), dim3(64), 0, s, a);
+    HIPCHK(e, hipEventRecord(e->ev[1], s));
+    hipLaunchKernelGGL(k_walk, dim3(a.n_blocks), dim3(64), walk_lds_bytes(a.qcap, a.pcap), s, a);
+    HIPCHK(e, hipEventRecord(e->ev[2], s));
+    hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, a);
+    HIPCHK(e, hipEventRecord(e->ev[3], s));
+    hipLaunchKernelGGL(k_expand, dim3(a.n_blocks), dim3(64), 0, s, a);
+    HIPCHK(e, hipEventRecord(e->ev[4], s));
+    hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
+    HIPCHK(e, hipEventRecord(e->ev[5], s));
+    HIPCHK(e, hipMemcpyAsync(e->h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipGetLastError());
+    e->last = a;
+    e->pending = true;
+    e->pending_kind = 0;
+    return BMQ_OK;
+}
+
+// waits; grows internal buffers and re-runs when a kernel asked for it
+int finish_dist(bmq_engine* e, uint64_t* out_total) {
+    for (int attempt = 0; attempt < 8; attempt++) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        const Counters c = *e->h_ctr;
+        const uint32_t grow = c.status & (ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH | ST_NEED_SORTLIST);
+        if (grow) {
+            if (grow & ST_NEED_PAIRS) {
+                e->pair_cap = std::max<uint64_t>(e->pair_cap * 2, c.pair_alloc + c.pair_alloc / 8);
+                if (e->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
+                HIPCHK(e, e->b_pairs.ensure(sizeof(MatchRange) * e->pair_cap));
+            }
+            if (grow & ST_NEED_SLOW) {
+                e->slow_cap = std::max<uint32_t>(e->slow_cap * 2, c.slow_count);
+                HIPCHK(e, e->b_slow_list.ensure(sizeof(uint32_t) * e->slow_cap));
+            }
+            if (grow & ST_NEED_SCRATCH) {
+                e->scratch_cap = std::max<uint64_t>(e->scratch_cap * 2, c.scratch_alloc + c.scratch_alloc / 8);
+                HIPCHK(e, e->b_scratch.ensure(sizeof(uint32_t) * e->scratch_cap));
+            }
+            if (grow & ST_NEED_SORTLIST) {
+                e->sort_cap = std::max<uint32_t>(e->sort_cap * 2, c.sort_count);
+                HIPCHK(e, e->b_sort_list.ensure(sizeof(uint32_t) * e->sort_cap));
+            }
+            BatchArgs a = e->last;
+            int rc = launch_dist(e, a);
+            if (rc) return rc;
+            continue;
+        }
+        e->pending = false;
+        bmq_stats& st = e->stats;
+        st = bmq_stats{};
+        st.n_topics = e->last.n_topics;
+        st.n_visit = c.n_visit;
+        st.n_match = c.total_ids;
+        st.n_ranges = c.n_ranges;
+        st.n_slow_topics = c.slow_count;
+        st.n_sorted_rows = c.sort_count;
+        st.topic_bytes = c.topic_bytes;
+        (void)hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[5]);
+        (void)hipEventElapsedTime(&st.ms_walk, e->ev[1], e->ev[2]);
+        (void)hipEventElapsedTime(&st.ms_expand, e->ev[3], e->ev[4]);
+        if (out_total) *out_total = c.total_ids;
+        if (c.status & ST_RANGE) return set_err(e, BMQ_E_RANGE, "batch produced >= 2^32 route ids");
+        if (c.status & ST_NOSPACE) return set_err(e, BMQ_E_NOSPACE, "output buffer too small");
+        return BMQ_OK;
+    }
+    return set_err(e, BMQ_E_NOMEM, "scratch growth did not converge");
+}
+
+int check_dist_ready(bmq_engine* e) {
+    if (!e) return BMQ_E_INVAL;
+    if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only: matching requires a gfx950 device");
+    if (!e->built || !e->dist) return set_err(e, BMQ_E_STATE, "bmq_rebuild has not been called");
+    return BMQ_OK;
+}
+
+} // namespace
+
+// ====================================================================================================================
+// C ABI
+// ====================================================================================================================
+extern "C" {
+
+const char* bmq_version(void) { return "bifromq_amd 0.1 (gfx950)"; }
+
+int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
+    if (!out) return BMQ_E_INVAL;
+    *out = nullptr;
+    bmq_config c{};
+    c.device = 0;
+    if (cfg) {
+        if (cfg->struct_size < 8 || cfg->struct_size > sizeof(bmq_config)) return BMQ_E_INVAL;
+        memcpy(&c, cfg, cfg->struct_size);
+    }
+    if (c.wave_queue_cap == 0) c.wave_queue_cap = 512;
+    if (c.wave_pair_cap == 0) c.wave_pair_cap = 512;
+    if (c.wave_queue_cap < 128 || (c.wave_queue_cap & (c.wave_queue_cap - 1)) || c.wave_queue_cap > 8192) return BMQ_E_INVAL;
+    if (c.wave_pair_cap < 1 || c.wave_pair_cap > 8192) return BMQ_E_INVAL;
+    auto e = std::make_unique<bmq_engine>();
+    e->cfg = c;
+    e->device = c.device;
+    if (c.device >= 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || c.device >= n) return BMQ_E_NODEVICE;
+        if (hipSetDevice(c.device) != hipSuccess) return BMQ_E_NODEVICE;
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return BMQ_E_HIP;
+        for (auto& ev : e->ev)
+            if (hipEventCreate(&ev) != hipSuccess) return BMQ_E_HIP;
+        if (hipHostMalloc((void**)&e->h_ctr, sizeof(RetainCounters) > sizeof(Counters) ? sizeof(RetainCounters) : sizeof(Counters),
+                          hipHostMallocDefault) != hipSuccess)
+            return BMQ_E_NOMEM;
+        memset(e->h_ctr, 0, sizeof(Counters));
+    }
+    *out = e.release();
+    return BMQ_OK;
+}
+
+void bmq_engine_destroy(bmq_engine* e) {
+    if (!e) return;
+    if (e->device >= 0) {
+        (void)hipSetDevice(e->device);
+        if (e->stream) (void)hipStreamSynchronize(e->stream);
+        for (auto& ev : e->ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (e->h_ctr) (void)hipHostFree(e->h_ctr);
+        if (e->stream) (void)hipStreamDestroy(e->stream);
+    }
+    delete e;
+}
+
+const char* bmq_last_error(const bmq_engine* e) { return e ? e->err.c_str() : "null engine"; }
+void* bmq_stream(const bmq_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys) {
+    if (!e || (n_keys && (!keys || !key_off))) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    static const uint32_t zero_off[1] = {0};
+    e->keys.assign(keys, n_keys ? key_off : zero_off, n_keys);
+    return rebuild_locked(e);
+}
+
+int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+    if (!e || (n && (!keys || !key_off || !op))) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n == 0) return BMQ_OK;
+    for (uint32_t i = 0; i < n; i++) {
+        RouteKeyParts kp;
+        if (op[i] > 1) return set_err(e, BMQ_E_INVAL, "op must be 0 (put) or 1 (delete)");
+        if (!decode_route_key(std::string_view((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]), kp))
+            return set_err(e, BMQ_E_INVAL, "malformed route key in apply batch");
+    }
+    e->keys.apply(keys, key_off, op, n);
+    return rebuild_locked(e);
+}
+
+int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out) {
+    if (!e || !out) return BMQ_E_INVAL;
+    out->n_routes = e->host.n_routes;
+    out->n_tenants = e->host.n_tenants;
+    out->n_nodes = e->host.n_nodes;
+    out->n_tokens = e->host.n_tokens;
+    out->trie_slots = e->host.trie.size();
+    out->dict_slots = e->host.dict.size();
+    out->device_bytes = e->dist ? e->dist->bytes : 0;
+    out->epoch = e->epoch;
+    return BMQ_OK;
+}
+
+int bmq_route_key(const bmq_engine* e, uint32_t route_id, uint8_t* out, uint32_t cap, uint32_t* out_len) {
+    if (!e || !out_len) return BMQ_E_INVAL;
+    if (route_id >= e->keys.size()) return BMQ_E_INVAL;
+    const std::string_view k = e->keys.key(route_id);
+    *out_len = (uint32_t)k.size();
+    if (k.size() > cap) return BMQ_E_NOSPACE;
+    if (out && !k.empty()) memcpy(out, k.data(), k.size());
+    return BMQ_OK;
+}
+
+int bmq_index_find(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter,
+                   uint32_t filter_len, uint32_t* out_ids, uint32_t cap, uint32_t* out_n) {
+    if (!e || !out_n) return BMQ_E_INVAL;
+    *out_n = 0;
+    if (!e->built) return BMQ_E_STATE;
+    bool is_hash = false;
+    const uint32_t node = e->host.find_filter_node(std::string_view((const char*)tenant, tenant_len),
+                                                   std::string_view((const char*)filter, filter_len), is_hash);
+    if (node == NONE) return BMQ_OK;
+    const TrieSlot& s = e->host.trie[node];
+    const uint32_t b = is_hash ? s.hash_begin : s.own_begin, c = is_hash ? s.hash_count : s.own_count;
+    *out_n = c;
+    for (uint32_t i = 0; i < c && i < cap; i++) out_ids[i] = e->host.route_pos[b + i];
+    return BMQ_OK;
+}
+
+int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t* d_tenant_off, uint32_t n_tenants,
+                        const uint32_t* d_topic_tenant, const uint8_t* d_topics, const uint32_t* d_topic_off,
+                        uint32_t n_topics, uint32_t* d_out_row_ptr, uint32_t* d_out_route_ids, uint64_t out_capacity,
+                        uint64_t* d_out_total) {
+    int rc = check_dist_ready(e);
+    if (rc) return rc;
+    if (n_topics == 0 || !d_out_row_ptr || !d_topic_off || !d_topics || !d_topic_tenant || !d_out_total)
+        return set_err(e, BMQ_E_INVAL, "null pointer or empty batch");
+    if (((uintptr_t)d_topics & 7) || ((uintptr_t)d_tenants & 7)) return set_err(e, BMQ_E_INVAL, "string buffers must be 8-byte aligned");
+    std::lock_guard<std::mutex> g(e->mu);
+    HIPCHK(e, hipSetDevice(e->device));
+    if ((rc = ensure_batch_scratch(e, n_tenants, n_topics))) return rc;
+    BatchArgs a{};
+    a.tenants = d_tenants;
+    a.tenant_off = d_tenant_off;
+    a.n_tenants = n_tenants;
+    a.topic_tenant = d_topic_tenant;
+    a.topics = d_topics;
+    a.topic_off = d_topic_off;
+    a.n_topics = n_topics;
+    a.out_row_ptr = d_out_row_ptr;
+    a.out_ids = d_out_route_ids;
+    a.out_capacity = d_out_route_ids ? out_capacity : 0;
+    a.out_total = (unsigned long long*)d_out_total;
+    return launch_dist(e, a);
+}
+
+int bmq_match_finish(bmq_engine* e, uint64_t* out_total) {
+    if (!e) return BMQ_E_INVAL;
+    if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->pending) return set_err(e, BMQ_E_STATE, "no batch in flight");
+    HIPCHK(e, hipSetDevice(e->device));
+    return e->pending_kind == 0 ? finish_dist(e, out_total) : retain_finish(e, out_total);
+}
+
+int bmq_sync(bmq_engine* e) {
+    if (!e) return BMQ_E_INVAL;
+    if (e->device < 0) return BMQ_E_NODEVICE;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return BMQ_OK;
+}
+
+int bmq_stats_get(const bmq_engine* e, bmq_stats* out) {
+    if (!e || !out) return BMQ_E_INVAL;
+    *out = e->stats;
+    return BMQ_OK;
+}
+
+int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                    const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
+                    uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed) {
+    int rc = check_dist_ready(e);
+    if (rc) return rc;
+    if (!out_row_ptr || !out_needed) return set_err(e, BMQ_E_INVAL, "null output pointer");
+    *out_needed = 0;
+    if (n_topics == 0) {
+        out_row_ptr[0] = 0;
+        return BMQ_OK;
+    }
+    if (!topics || !topic_off || !topic_tenant || (n_tenants && (!tenants || !tenant_off)))
+        return set_err(e, BMQ_E_INVAL, "null input pointer");
+    uint64_t dev_cap;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        HIPCHK(e, hipSetDevice(e->device));
+        const size_t tb = n_tenants ? tenant_off[n_tenants] : 0, pb = topic_off[n_topics];
+        HIPCHK(e, e->s_tenants.ensure(tb + 16));
+        HIPCHK(e, e->s_topics.ensure(pb + 16));
+        if ((rc = upload(e, e->s_tenant_off, tenant_off, sizeof(uint32_t) * (n_tenants ? n_tenants + 1 : 0)))) return rc;
+        if (tb) HIPCHK(e, hipMemcpyAsync(e->s_tenants.p, tenants, tb, hipMemcpyHostToDevice, e->stream));
+        if ((rc = upload(e, e->s_topic_tenant, topic_tenant, sizeof(uint32_t) * n_topics))) return rc;
+        if (pb) HIPCHK(e, hipMemcpyAsync(e->s_topics.p, topics, pb, hipMemcpyHostToDevice, e->stream));
+        if ((rc = upload(e, e->s_topic_off, topic_off, sizeof(uint32_t) * (n_topics + 1)))) return rc;
+        HIPCHK(e, e->s_row_ptr.ensure(sizeof(uint32_t) * (n_topics + 1)));
+        dev_cap = std::max<uint64_t>(e->s_ids.cap / 4, std::max<uint64_t>((uint64_t)n_topics * 4, 1024));
+        HIPCHK(e, e->s_ids.ensure(dev_cap * 4));
+    }
+    for (int attempt = 0; attempt < 3; attempt++) {
+        rc = bmq_match_batch_dev(e, e->s_tenants.as<uint8_t>(), e->s_tenant_off.as<uint32_t>(), n_tenants,
+                                 e->s_topic_tenant.as<uint32_t>(), e->s_topics.as<uint8_t>(), e->s_topic_off.as<uint32_t>(),
+                                 n_topics, e->s_row_ptr.as<uint32_t>(), e->s_ids.as<uint32_t>(), dev_cap,
+                                 e->b_total.as<uint64_t>());
+        if (rc) return rc;
+        uint64_t total = 0;
+        rc = bmq_match_finish(e, &total);
+        *out_needed = total;
+        if (rc == BMQ_E_NOSPACE) {
+            if (total > out_capacity || !out_route_ids) return rc; // the caller's buffer is the problem
+            std::lock_guard<std::mutex> g(e->mu);
+            dev_cap = total;
+            HIPCHK(e, e->s_ids.ensure(dev_cap * 4));
+            continue;
+        }
+        if (rc) return rc;
+        std::lock_guard<std::mutex> g(e->mu);
+        HIPCHK(e, hipMemcpy(out_row_ptr, e->s_row_ptr.p, sizeof(uint32_t) * (n_topics + 1), hipMemcpyDeviceToHost));
+        if (total > out_capacity || (total && !out_route_ids)) return set_err(e, BMQ_E_NOSPACE, "output buffer too small");
+        if (total) HIPCHK(e, hipMemcpy(out_route_ids, e->s_ids.p, sizeof(uint32_t) * total, hipMemcpyDeviceToHost));
+        return BMQ_OK;
+    }
+    return set_err(e, BMQ_E_NOMEM, "device output buffer growth did not converge");
+}
+
+// ---- host-side mirror of MatchedRoutes (DW/cache/MatchedRoutes.java:87-141) -------------------------------------------
+int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics, const uint32_t* topic_off,
+                  uint32_t n_topics, int32_t max_pf, int32_t max_gf, uint32_t* out_row_ptr, uint32_t* out_route_ids,
+                  uint64_t out_capacity, uint64_t* out_needed, int32_t* out_events, uint32_t events_cap,
+                  uint32_t* out_n_events) {
+    int rc = check_dist_ready(e);
+    if (rc) return rc;
+    if (!out_row_ptr || !out_needed) return set_err(e, BMQ_E_INVAL, "null output pointer");
+    if (out_n_events) *out_n_events = 0;
+    *out_needed = 0;
+    if (n_topics == 0) {
+        out_row_ptr[0] = 0;
+        return BMQ_OK;
+    }
+    // matchAll takes a Set<String>: identical topics share one MatchedRoutes (TenantRouteMatcher.java:73-78)
+    std::map<std::string_view, uint32_t> first;
+    std::vector<uint32_t> canon(n_topics);
+    for (uint32_t i = 0; i < n_topics; i++) {
+        const std::string_view tp((const char*)topics + topic_off[i], topic_off[i + 1] - topic_off[i]);
+        canon[i] = first.emplace(tp, i).first->second;
+    }
+    const uint32_t toff[2] = {0, tenant_len};
+    std::vector<uint32_t> tt(n_topics, 0), rp(n_topics + 1);
+    std::vector<uint32_t> ids(std::max<uint64_t>(1024, (uint64_t)n_topics * 8));
+    uint64_t need = 0;
+    rc = bmq_match_batch(e, tenant, toff, 1, tt.data(), topics, topic_off, n_topics, rp.data(), ids.data(), ids.size(), &need);
+    if (rc == BMQ_E_NOSPACE) {
+        ids.resize(need);
+        rc = bmq_match_batch(e, tenant, toff, 1, tt.data(), topics, topic_off, n_topics, rp.data(), ids.data(), ids.size(), &need);
+    }
+    if (rc) return rc;
+    // apply the caps in id (= KV key) order
+    std::vector<std::vector<uint32_t>> kept(n_topics);
+    uint32_t n_ev = 0;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (uint32_t i = 0; i < n_topics; i++) {
+        if (canon[i] != i) continue;
+        int64_t persistent = 0, groups = 0;
+        for (uint32_t k = rp[i]; k < rp[i + 1]; k++) {
+            const uint32_t id = ids[k];
+            RouteKeyParts kp;
+            if (!decode_route_key(e->keys.key(id), kp)) return set_err(e, BMQ_E_INVAL, "corrupt key set");
+            int ev_type = -1;
+            if (kp.flag == 1) {
+                // subBrokerId = integer prefix of "<brokerId>\0<receiverId>\0<delivererKey>" (SCHEMA/KVSchemaUtil.java:56-58)
+                long broker = 0;
+                size_t p = 0;
+                while (p < kp.receiver.size() && kp.receiver[p] >= '0' && kp.receiver[p] <= '9') broker = broker * 10 + (kp.receiver[p++] - '0');
+                if (broker == 1 && p > 0) {
+                    if (persistent < (int64_t)max_pf) persistent++;
+                    else ev_type = 0;
+                }
+            } else {
+                if (groups + 1 <= (int64_t)max_gf) groups++;
+                else ev_type = 1;
+            }
+            if (ev_type < 0) kept[i].push_back(id);
+            else {
+                if (out_events && n_ev < events_cap) {
+                    int32_t* ev = out_events + 4 * (size_t)n_ev;
+                    ev[0] = ev_type; ev[1] = (int32_t)i; ev[2] = (int32_t)id; ev[3] = ev_type == 0 ? max_pf : max_gf;
+                }
+                n_ev++;
+            }
+        }
+    }
+    if (out_n_events) *out_n_events = n_ev;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_topics; i++) {
+        out_row_ptr[i] = (uint32_t)total;
+        total += kept[canon[i]].size();
+    }
+    out_row_ptr[n_topics] = (uint32_t)total;
+    *out_needed = total;
+    if (total > out_capacity || (total && !out_route_ids)) return set_err(e, BMQ_E_NOSPACE, "output buffer too small");
+    for (uint32_t i = 0; i < n_topics; i++) {
+        const auto& v = kept[canon[i]];
+        if (!v.empty()) memcpy(out_route_ids + out_row_ptr[i], v.data(), v.size() * 4);
+    }
+    return BMQ_OK;
+}
+
+// ---- codec ------------------------------------------------------------------------------------------------------------
+uint32_t bmq_route_key_encode(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len,
+                              uint8_t flag, const uint8_t* receiver, uint32_t receiver_len, uint8_t* out, uint32_t cap) {
+    const std::string k = encode_route_key(std::string_view((const char*)tenant, tenant_len),
+                                           std::string_view((const char*)filter, filter_len), flag,
+                                           std::string_view((const char*)receiver, receiver_len));
+    if (out && k.size() <= cap) memcpy(out, k.data(), k.size());
+    return (uint32_t)k.size();
+}
+
+int bmq_route_key_decode(const uint8_t* key, uint32_t key_len, uint32_t spans[6]) {
+    RouteKeyParts kp;
+    const std::string_view k((const char*)key, key_len);
+    if (!key || !spans || !decode_route_key(k, kp)) return BMQ_E_INVAL;
+    spans[0] = (uint32_t)(kp.tenant.data() - k.data());
+    spans[1] = (uint32_t)kp.tenant.size();
+    spans[2] = (uint32_t)(kp.esc_filter.data() - k.data());
+    spans[3] = (uint32_t)kp.esc_filter.size();
+    spans[4] = (uint32_t)(kp.receiver.data() - k.data());
+    spans[5] = (uint32_t)kp.receiver.size();
+    return kp.flag;
+}
+
+int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len) { return java_string_hash(std::string_view((const char*)utf8, len)); }
+
+} // extern "C"
+
+#include "bmq_retain_engine.inc"

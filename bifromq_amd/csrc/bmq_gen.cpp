@@ -1,0 +1,287 @@
+// bmq_gen.cpp -- deterministic synthetic workloads of SURVEY.md 8d / BASELINE.md section 3 (bench + test tooling,
+// not part of the match path).  PRNG = splitmix64.  Built into libbmq_gen.so.
+//
+//   vocabulary per level l: V = [8, 64, 512, 4096, 4096, 4096, 256, 64], token "l{l}_{rank}", rank ~ Zipf(1.1)
+//   depth uniform in [3, 8]; 1 % get a "$sys" first level; 0.5 % contain one empty level
+//   filters (mixed): 70 % literal, 15 % one '+', 5 % two '+', 8 % trailing '#', 2 % '+' ... '#'
+//   routes: one normal route per filter (receiverUrl "0\0inbox{i}\0d{i%64}"), 1 % of filters get 32 receivers,
+//           0.5 % are $share groups; a repeated filter string gets a fresh receiver (distinct key, same filter)
+//   publishes: 90 % instantiate a stored filter (wildcards filled from the vocabulary), 10 % fresh random;
+//              tenant of a publish ~ Zipf(1.0) over tenants
+//   retain direction: retained topics are literal topics as above; query filters 50 % one '+', 30 % trailing '#'
+//           (preceded by >= 2 non-'#' levels), 20 % both.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bmq_index.h"
+
+namespace {
+
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+};
+
+struct Zipf {
+    std::vector<double> cdf;
+    Zipf(uint32_t n, double s) : cdf(n) {
+        double acc = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            acc += 1.0 / std::pow((double)(i + 1), s);
+            cdf[i] = acc;
+        }
+        for (auto& c : cdf) c /= acc;
+    }
+    uint32_t draw(Rng& r) const {
+        const double u = r.uniform();
+        return (uint32_t)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+    }
+};
+
+const uint32_t VOCAB[8] = {8, 64, 512, 4096, 4096, 4096, 256, 64};
+
+struct Vocab {
+    std::vector<Zipf> z;
+    Vocab() {
+        for (int l = 0; l < 8; l++) z.emplace_back(VOCAB[l], 1.1);
+    }
+    std::string token(int level, Rng& r) const {
+        const int l = level < 8 ? level : 7;
+        return "l" + std::to_string(l) + "_" + std::to_string(z[l].draw(r));
+    }
+};
+
+using Levels = std::vector<std::string>;
+
+Levels random_topic_levels(const Vocab& v, Rng& r) {
+    const int depth = 3 + (int)r.below(6);
+    Levels lv(depth);
+    for (int i = 0; i < depth; i++) lv[i] = v.token(i, r);
+    if (r.below(100) == 0) lv[0] = "$sys";
+    if (r.below(200) == 0) lv[r.below((uint32_t)depth)] = "";
+    return lv;
+}
+
+// mode 0: literal only; 1: dist mix; 2: retain query mix
+Levels random_filter_levels(const Vocab& v, Rng& r, int mode) {
+    Levels lv = random_topic_levels(v, r);
+    if (mode == 0) return lv;
+    const uint32_t p = r.below(100);
+    auto plus = [&]() { lv[r.below((uint32_t)lv.size())] = "+"; };
+    if (mode == 1) {
+        if (p < 70) {
+        } else if (p < 85) plus();
+        else if (p < 90) { plus(); plus(); }
+        else if (p < 98) lv.back() = "#";
+        else { lv.back() = "#"; lv[r.below((uint32_t)lv.size() - 1)] = "+"; }
+    } else {
+        if (p < 50) plus();
+        else if (p < 80) lv.back() = "#"; // depth >= 3: at least 2 levels before '#'
+        else { lv.back() = "#"; lv[r.below((uint32_t)lv.size() - 1)] = "+"; }
+        if (lv.size() >= 2 && lv[0] == "+" && lv[1] == "#") lv[0] = v.token(0, r);
+        if (lv.size() == 3 && lv.back() == "#" && (lv[0] == "+" && lv[1] == "+")) lv[0] = v.token(0, r);
+    }
+    return lv;
+}
+
+std::string join(const Levels& lv) {
+    std::string s;
+    for (size_t i = 0; i < lv.size(); i++) {
+        if (i) s.push_back('/');
+        s += lv[i];
+    }
+    return s;
+}
+
+struct Packed {
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> off{0};
+    void push(const std::string& s) {
+        bytes.insert(bytes.end(), s.begin(), s.end());
+        off.push_back((uint32_t)bytes.size());
+    }
+    void pad() {
+        const size_t n = bytes.size();
+        bytes.resize(((n + 15) & ~(size_t)15) + 16, 0);
+        (void)n;
+    }
+};
+
+struct Gen {
+    uint64_t seed;
+    uint32_t tenant_base = 0;            // global index of this generator's first tenant (rank shards)
+    uint32_t n_tenants, per_tenant;
+    int mode;
+    Vocab vocab;
+    Packed tenants;                      // tenant ids "tenant%06u"
+    Packed keys;                         // all route keys, sorted
+    std::vector<uint32_t> tenant_first;  // first key rank per tenant (n_tenants + 1)
+    Packed out_topics;                   // last generated batch
+    std::vector<uint32_t> out_tenant;
+};
+
+std::string tenant_name(uint32_t t) {
+    char b[32];
+    snprintf(b, sizeof b, "tenant%06u", t);
+    return b;
+}
+
+void gen_tenant_keys(const Gen& g, uint32_t t_local, std::vector<std::string>& out) {
+    const uint32_t t = g.tenant_base + t_local;
+    Rng r(g.seed * 0x100000001B3ull + 0x517CC1B727220A95ull * (t + 1));
+    const std::string tn = tenant_name(t);
+    out.clear();
+    out.reserve(g.per_tenant + 32);
+    uint32_t rid = 0;
+    while (out.size() < g.per_tenant) {
+        const std::string f = join(random_filter_levels(g.vocab, r, g.mode));
+        const uint32_t p = r.below(1000);
+        if (p < 5) { // 0.5 %: shared subscription group
+            const std::string grp = "g" + std::to_string(r.below(64));
+            out.push_back(bmq::encode_route_key(tn, f, r.below(2) ? 2 : 3, grp));
+        } else {
+            const uint32_t n_recv = p < 15 ? 32u : 1u; // 1 %: 32 receivers on one filter
+            for (uint32_t k = 0; k < n_recv && out.size() < g.per_tenant; k++, rid++) {
+                std::string recv = "0";
+                recv.push_back('\0');
+                recv += "inbox" + std::to_string(rid);
+                recv.push_back('\0');
+                recv += "d" + std::to_string(rid % 64);
+                out.push_back(bmq::encode_route_key(tn, f, 1, recv));
+            }
+        }
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+} // namespace
+
+extern "C" {
+
+void* bmqgen_create(uint64_t seed, uint32_t tenant_base, uint32_t n_tenants, uint32_t routes_per_tenant, int mode) {
+    Gen* g = new Gen();
+    g->seed = seed;
+    g->tenant_base = tenant_base;
+    g->n_tenants = n_tenants;
+    g->per_tenant = routes_per_tenant;
+    g->mode = mode;
+    for (uint32_t t = 0; t < n_tenants; t++) g->tenants.push(tenant_name(tenant_base + t));
+    g->tenants.pad();
+    std::vector<std::vector<std::string>> per(n_tenants);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (!hw) hw = 1;
+    const unsigned nth = std::min<unsigned>(hw, n_tenants ? n_tenants : 1);
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nth; w++)
+        th.emplace_back([&, w] {
+            for (uint32_t t = w; t < n_tenants; t += nth) gen_tenant_keys(*g, t, per[t]);
+        });
+    for (auto& x : th) x.join();
+    g->tenant_first.assign(n_tenants + 1, 0);
+    uint64_t total_bytes = 0;
+    for (uint32_t t = 0; t < n_tenants; t++)
+        for (auto& k : per[t]) total_bytes += k.size();
+    if (total_bytes >= 0xFFFFFFF0ull) { // uint32 offsets of the ABI
+        delete g;
+        return nullptr;
+    }
+    g->keys.bytes.reserve(total_bytes + 32);
+    for (uint32_t t = 0; t < n_tenants; t++) { // fixed-width tenant ids: tenant order == key order
+        g->tenant_first[t] = (uint32_t)(g->keys.off.size() - 1);
+        for (auto& k : per[t]) g->keys.push(k);
+        std::vector<std::string>().swap(per[t]);
+    }
+    g->tenant_first[n_tenants] = (uint32_t)(g->keys.off.size() - 1);
+    return g;
+}
+
+void bmqgen_destroy(void* h) { delete (Gen*)h; }
+
+uint32_t bmqgen_n_keys(void* h) { return (uint32_t)((Gen*)h)->keys.off.size() - 1; }
+const uint8_t* bmqgen_key_bytes(void* h) { return ((Gen*)h)->keys.bytes.data(); }
+const uint32_t* bmqgen_key_off(void* h) { return ((Gen*)h)->keys.off.data(); }
+uint32_t bmqgen_n_tenants(void* h) { return ((Gen*)h)->n_tenants; }
+const uint8_t* bmqgen_tenant_bytes(void* h) { return ((Gen*)h)->tenants.bytes.data(); }
+const uint32_t* bmqgen_tenant_off(void* h) { return ((Gen*)h)->tenants.off.data(); }
+const uint32_t* bmqgen_tenant_first(void* h) { return ((Gen*)h)->tenant_first.data(); }
+
+// Generates a publish batch (kept inside the generator until the next call).  tenant_lo/hi restrict the tenants
+// publishes are drawn for (a rank's shard); hit_permille = share of topics instantiated from a stored filter.
+uint32_t bmqgen_topics(void* h, uint64_t seed, uint32_t n_topics, uint32_t tenant_lo, uint32_t tenant_hi, uint32_t hit_permille) {
+    Gen& g = *(Gen*)h;
+    Rng r(seed ^ 0xD1B54A32D192ED03ull);
+    if (tenant_hi > g.n_tenants) tenant_hi = g.n_tenants;
+    if (tenant_lo >= tenant_hi) return 0;
+    Zipf zt(tenant_hi - tenant_lo, 1.0);
+    g.out_topics = Packed();
+    g.out_tenant.clear();
+    g.out_tenant.reserve(n_topics);
+    g.out_topics.bytes.reserve((size_t)n_topics * 44);
+    for (uint32_t i = 0; i < n_topics; i++) {
+        const uint32_t t = tenant_lo + zt.draw(r);
+        const uint32_t k0 = g.tenant_first[t], k1 = g.tenant_first[t + 1];
+        Levels lv;
+        if (k1 > k0 && r.below(1000) < hit_permille) {
+            const uint32_t k = k0 + r.below(k1 - k0);
+            bmq::RouteKeyParts kp;
+            const std::string_view key((const char*)g.keys.bytes.data() + g.keys.off[k], g.keys.off[k + 1] - g.keys.off[k]);
+            bmq::decode_route_key(key, kp);
+            size_t s = 0;
+            const std::string_view f = kp.esc_filter;
+            for (size_t j = 0; j <= f.size(); j++)
+                if (j == f.size() || f[j] == '\0') {
+                    lv.emplace_back(f.substr(s, j - s));
+                    s = j + 1;
+                }
+            for (size_t j = 0; j < lv.size(); j++)
+                if (lv[j] == "+") lv[j] = g.vocab.token((int)j, r);
+            if (lv.back() == "#") {
+                lv.pop_back();
+                const uint32_t extra = r.below(3);
+                for (uint32_t e = 0; e < extra; e++) lv.push_back(g.vocab.token((int)lv.size(), r));
+                if (lv.empty()) lv.push_back(g.vocab.token(0, r));
+            }
+        } else {
+            lv = random_topic_levels(g.vocab, r);
+        }
+        g.out_topics.push(join(lv));
+        g.out_tenant.push_back(t);
+    }
+    g.out_topics.pad();
+    return n_topics;
+}
+const uint8_t* bmqgen_topic_bytes(void* h) { return ((Gen*)h)->out_topics.bytes.data(); }
+const uint32_t* bmqgen_topic_off(void* h) { return ((Gen*)h)->out_topics.off.data(); }
+const uint32_t* bmqgen_topic_tenant(void* h) { return ((Gen*)h)->out_tenant.data(); }
+
+// Retain direction: n retained literal topics (unique per tenant) or n query filters (mode 2) into the same out buffers.
+uint32_t bmqgen_retain(void* h, uint64_t seed, uint32_t n, int filters) {
+    Gen& g = *(Gen*)h;
+    Rng r(seed ^ 0xA24BAED4963EE407ull);
+    g.out_topics = Packed();
+    g.out_tenant.clear();
+    Zipf zt(g.n_tenants ? g.n_tenants : 1, 1.0);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t t = g.n_tenants > 1 ? zt.draw(r) : 0;
+        g.out_topics.push(join(filters ? random_filter_levels(g.vocab, r, 2) : random_topic_levels(g.vocab, r)));
+        g.out_tenant.push_back(t);
+    }
+    g.out_topics.pad();
+    return n;
+}
+
+} // extern "C"

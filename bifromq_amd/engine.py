@@ -1,0 +1,232 @@
+"""Python face of the C-ABI engine (include/bmq.h).  Thin: packs strings, calls libbmq.so, unpacks CSR.
+
+All matching happens in the HIP kernels behind the ABI (bifromq_amd/csrc).  Nothing here matches topics.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+INT_MAX = 2**31 - 1
+STATUS = {0: "OK", -1: "INVAL", -2: "NODEVICE", -3: "NOSPACE", -4: "NOMEM", -5: "HIP", -6: "RANGE", -7: "STATE"}
+
+
+class BmqError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"bmq error {STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _b(s) -> bytes:
+    return s if isinstance(s, (bytes, bytearray)) else s.encode("utf-8")
+
+
+def pack(strings: Sequence) -> Tuple[np.ndarray, np.ndarray]:
+    """list of str/bytes -> (uint8 bytes padded by >= 16 zero bytes, uint32 offsets[n+1])"""
+    bs = [_b(s) for s in strings]
+    off = np.zeros(len(bs) + 1, dtype=np.uint32)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64).astype(np.uint32)
+    raw = b"".join(bs)
+    data = np.zeros(((len(raw) + 15) & ~15) + 16, dtype=np.uint8)
+    if raw:
+        data[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+    return data, off
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- codec (SCHEMA/KVSchemaUtil.java:91-130) -----------------------------------------------------------
+def route_key(tenant, topic_filter, flag: int, receiver) -> bytes:
+    t, f, r = _b(tenant), _b(topic_filter), _b(receiver)
+    out = C.create_string_buffer(len(t) + len(f) + len(r) + 16)
+    n = _lib.lib().bmq_route_key_encode(t, len(t), f, len(f), flag, r, len(r), out, len(out))
+    return out.raw[:n]
+
+
+def route_key_from_mqtt(tenant, mqtt_topic_filter: str, receiver_url: str = "") -> bytes:
+    """TopicUtil.from + toNormalRouteKey / toGroupRouteKey (UTIL/TopicUtil.java:252-272)."""
+    for prefix, flag in (("$share/", 2), ("$oshare/", 3)):
+        if mqtt_topic_filter.startswith(prefix):
+            rest = mqtt_topic_filter[len(prefix):]
+            i = rest.index("/")
+            return route_key(tenant, rest[i + 1:], flag, rest[:i])
+    return route_key(tenant, mqtt_topic_filter, 1, receiver_url)
+
+
+def decode_route_key(key: bytes):
+    """-> (flag, tenant, mqttTopicFilter incl. $share prefix, receiver) or None (RouteDetailCache.java:53-109)."""
+    spans = (C.c_uint32 * 6)()
+    flag = _lib.lib().bmq_route_key_decode(key, len(key), spans)
+    if flag < 0:
+        return None
+    tenant = key[spans[0]:spans[0] + spans[1]].decode()
+    filt = key[spans[2]:spans[2] + spans[3]].replace(b"\0", b"/").decode()
+    recv = key[spans[4]:spans[4] + spans[5]].decode()
+    if flag == 2:
+        filt = f"$share/{recv}/{filt}"
+    elif flag == 3:
+        filt = f"$oshare/{recv}/{filt}"
+    return flag, tenant, filt, recv
+
+
+def java_string_hash(s) -> int:
+    b = _b(s)
+    return _lib.lib().bmq_java_string_hash(b, len(b))
+
+
+class Engine:
+    """One engine per KV range replica (cf. DistWorkerCoProc's SubscriptionCache)."""
+
+    def __init__(self, device: int = 0, wave_queue_cap: int = 0, wave_pair_cap: int = 0, slow_scratch_mb: int = 0):
+        L = _lib.lib()
+        cfg = _lib.Config()
+        cfg.struct_size = C.sizeof(_lib.Config)
+        cfg.device = device
+        cfg.wave_queue_cap = wave_queue_cap
+        cfg.wave_pair_cap = wave_pair_cap
+        cfg.slow_scratch_mb = slow_scratch_mb
+        h = C.c_void_p()
+        rc = L.bmq_engine_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise BmqError(rc, "bmq_engine_create failed (a gfx950 device is required for device >= 0)")
+        self.h = h
+        self.device = device
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().bmq_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise BmqError(rc, (_lib.lib().bmq_last_error(self.h) or b"").decode())
+
+    # ---- index ---------------------------------------------------------------------------------------
+    def rebuild(self, keys: Iterable[bytes] = (), packed: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+        data, off = pack(list(keys)) if packed is None else packed
+        self._check(_lib.lib().bmq_rebuild(self.h, _ptr(data), _ptr(off), len(off) - 1))
+        return self
+
+    def rebuild_raw(self, key_bytes_ptr: int, key_off_ptr: int, n: int):
+        self._check(_lib.lib().bmq_rebuild(self.h, key_bytes_ptr, key_off_ptr, n))
+        return self
+
+    def apply(self, ops: Sequence[Tuple[int, bytes]]):
+        """ops: (0 = put | 1 = delete, route key)"""
+        data, off = pack([k for _, k in ops])
+        op = np.array([o for o, _ in ops], dtype=np.uint8)
+        self._check(_lib.lib().bmq_routes_apply(self.h, _ptr(data), _ptr(off), _ptr(op), len(ops)))
+        return self
+
+    def info(self) -> _lib.IndexInfo:
+        out = _lib.IndexInfo()
+        self._check(_lib.lib().bmq_index_info_get(self.h, C.byref(out)))
+        return out
+
+    def route_key(self, route_id: int) -> bytes:
+        n = C.c_uint32()
+        buf = C.create_string_buffer(70000)
+        self._check(_lib.lib().bmq_route_key(self.h, route_id, buf, len(buf), C.byref(n)))
+        return buf.raw[:n.value]
+
+    def find(self, tenant, topic_filter) -> List[int]:
+        t, f = _b(tenant), _b(topic_filter)
+        n = C.c_uint32()
+        cap = 1024
+        while True:
+            out = np.zeros(cap, dtype=np.uint32)
+            self._check(_lib.lib().bmq_index_find(self.h, t, len(t), f, len(f), _ptr(out), cap, C.byref(n)))
+            if n.value <= cap:
+                return out[:n.value].tolist()
+            cap = n.value
+
+    # ---- match (host buffers) ---------------------------------------------------------------------------
+    def match_batch(self, tenants: Sequence, topic_tenant, topics: Sequence = (), packed_topics=None):
+        """-> (row_ptr[n+1], route_ids) numpy arrays; ids ascending per row."""
+        tdata, toff = pack(tenants)
+        pdata, poff = pack(topics) if packed_topics is None else packed_topics
+        n = len(poff) - 1
+        tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
+        assert tt.shape == (n,)
+        row = np.zeros(n + 1, dtype=np.uint32)
+        cap = max(1024, 8 * n)
+        need = C.c_uint64()
+        while True:
+            ids = np.zeros(cap, dtype=np.uint32)
+            rc = _lib.lib().bmq_match_batch(self.h, _ptr(tdata), _ptr(toff), len(toff) - 1, _ptr(tt), _ptr(pdata),
+                                            _ptr(poff), n, _ptr(row), _ptr(ids), cap, C.byref(need))
+            if rc == -3 and need.value > cap:
+                cap = need.value
+                continue
+            self._check(rc)
+            return row, ids[:need.value]
+
+    def match_tenant(self, tenant, topics: Sequence) -> List[List[int]]:
+        row, ids = self.match_batch([tenant], np.zeros(len(topics), dtype=np.uint32), topics)
+        return [ids[row[i]:row[i + 1]].tolist() for i in range(len(topics))]
+
+    def match_all(self, tenant, topics: Sequence, max_persistent_fanout: int = INT_MAX,
+                  max_group_fanout: int = INT_MAX):
+        """ITenantRouteMatcher.matchAll for one tenant incl. MatchedRoutes fan-out caps.
+        -> (per-topic id lists, events [(type, topic idx, route id, max)])"""
+        t = _b(tenant)
+        pdata, poff = pack(topics)
+        n = len(topics)
+        row = np.zeros(n + 1, dtype=np.uint32)
+        cap = max(1024, 8 * n)
+        need = C.c_uint64()
+        ev_cap = 4096
+        while True:
+            ids = np.zeros(cap, dtype=np.uint32)
+            ev = np.zeros(4 * ev_cap, dtype=np.int32)
+            nev = C.c_uint32()
+            rc = _lib.lib().bmq_match_all(self.h, t, len(t), _ptr(pdata), _ptr(poff), n, max_persistent_fanout,
+                                          max_group_fanout, _ptr(row), _ptr(ids), cap, C.byref(need), _ptr(ev), ev_cap,
+                                          C.byref(nev))
+            if rc == -3 and need.value > cap:
+                cap = need.value
+                continue
+            self._check(rc)
+            if nev.value > ev_cap:
+                ev_cap = nev.value
+                continue
+            events = [tuple(int(x) for x in ev[4 * i:4 * i + 4]) for i in range(nev.value)]
+            return [ids[row[i]:row[i + 1]].tolist() for i in range(n)], events
+
+    # ---- match (device-resident; torch tensors are only carriers of device pointers) ----------------------
+    def match_batch_device(self, d_tenants, d_tenant_off, n_tenants, d_topic_tenant, d_topics, d_topic_off, n_topics,
+                           d_row_ptr, d_ids, capacity, d_total):
+        """All d_* are device pointers (ints).  Asynchronous; call finish()."""
+        self._check(_lib.lib().bmq_match_batch_dev(self.h, d_tenants, d_tenant_off, n_tenants, d_topic_tenant, d_topics,
+                                                   d_topic_off, n_topics, d_row_ptr, d_ids, capacity, d_total))
+
+    def finish(self) -> int:
+        total = C.c_uint64()
+        self._check(_lib.lib().bmq_match_finish(self.h, C.byref(total)))
+        return total.value
+
+    def sync(self):
+        self._check(_lib.lib().bmq_sync(self.h))
+
+    def stats(self) -> _lib.Stats:
+        out = _lib.Stats()
+        self._check(_lib.lib().bmq_stats_get(self.h, C.byref(out)))
+        return out
+
+    @property
+    def stream(self) -> int:
+        return _lib.lib().bmq_stream(self.h) or 0

@@ -1,0 +1,185 @@
+/*
+ * bmq.h -- C ABI of the MI355X-native MQTT topic-match engine (libbmq.so).
+ *
+ * This is the drop-in boundary.  The reference (apache/bifromq, 100 % Java) has no FFI of its own;
+ * each entry point below names the Java seam it sits behind (paths relative to the reference root,
+ * DW = bifromq-dist/bifromq-dist-worker/src/main/java/org/apache/bifromq/dist/worker,
+ * RS = bifromq-retain/bifromq-retain-store/src/main/java/org/apache/bifromq/retain/store,
+ * SCHEMA = bifromq-dist/bifromq-dist-worker-schema/src/main/java/org/apache/bifromq/dist/worker/schema,
+ * KVAPI = base-kv/base-kv-store-coproc-api/src/main/java/org/apache/bifromq/basekv/store/api).
+ * INTEGRATION.md shows the JNI stub a maintainer would add on the Java side.
+ *
+ * Conventions
+ *   - every function returns BMQ_OK (0) or a negative bmq_status; nothing throws across the ABI;
+ *   - strings are packed: `bytes` + `off[n+1]` (uint32 byte offsets, off[0] == 0), UTF-8, not NUL-terminated;
+ *   - a route id is the RANK of the route's KV key in unsigned-byte order among the keys the engine
+ *     currently holds (== KV iteration order, the order MatchedRoutes applies fan-out caps in,
+ *     DW/cache/MatchedRoutes.java:87-141).  bmq_route_key() maps an id back to its key;
+ *   - match results are CSR: row_ptr[n+1] + ids, ids ascending inside each row;
+ *   - buffers are caller-owned; *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and
+ *     run asynchronously on the engine's HIP stream until bmq_sync();
+ *   - thread-safety: match calls on one engine are serialised internally; one writer (rebuild/apply)
+ *     may run concurrently with readers of the previous epoch.
+ *   - the engine REQUIRES a gfx950 device for every match call.  There is no CPU fallback: without a
+ *     device bmq_engine_create(device >= 0) fails with BMQ_E_NODEVICE.
+ */
+#ifndef BMQ_H
+#define BMQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum bmq_status {
+    BMQ_OK = 0,
+    BMQ_E_INVAL = -1,     /* bad argument / malformed route key                                   */
+    BMQ_E_NODEVICE = -2,  /* no HIP device (or engine created host-only) -- match is impossible    */
+    BMQ_E_NOSPACE = -3,   /* caller's output buffer too small; *out_needed tells the size          */
+    BMQ_E_NOMEM = -4,     /* host or device allocation failed                                      */
+    BMQ_E_HIP = -5,       /* a HIP runtime call failed; see bmq_last_error()                       */
+    BMQ_E_RANGE = -6,     /* a 32-bit size limit of the ABI exceeded (>= 2^32 ids in one batch...) */
+    BMQ_E_STATE = -7      /* call not valid in this state (e.g. match before rebuild)              */
+} bmq_status;
+
+typedef struct bmq_engine bmq_engine;
+
+/* Tunables.  Zero-initialise, set struct_size = sizeof(bmq_config), override what you need.
+ * The *_cap fields exist so tests can force the overflow (slow) paths; 0 = default. */
+typedef struct bmq_config {
+    uint32_t struct_size;
+    int32_t device;            /* HIP device ordinal; -1 = host-only engine (build/inspect, no match)      */
+    uint32_t wave_queue_cap;   /* per-wave LDS frontier ring, items (default 512, pow2, >= 128)            */
+    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 512)                 */
+    uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
+    uint32_t reserved[8];
+} bmq_config;
+
+/* Counters of the last completed match batch (for roofline accounting). */
+typedef struct bmq_stats {
+    uint64_t n_topics;
+    uint64_t n_visit;        /* filter-trie nodes discovered (root excluded), all topics                    */
+    uint64_t n_match;        /* route ids emitted                                                           */
+    uint64_t n_ranges;       /* matched (filter node) ranges                                                */
+    uint64_t n_slow_topics;  /* topics resolved by the slow path (deep topics / LDS overflow)               */
+    uint64_t n_sorted_rows;  /* rows that needed the element-level fix-up sort                              */
+    uint64_t topic_bytes;    /* sum of topic lengths                                                        */
+    float ms_total;          /* HIP-event time of the whole batch on the engine stream                      */
+    float ms_walk;           /* ... of the tokenise+walk kernel alone                                       */
+    float ms_expand;         /* ... of the expand kernel alone                                              */
+    float ms_reserved;
+} bmq_stats;
+
+typedef struct bmq_index_info {
+    uint64_t n_routes, n_tenants, n_nodes, n_tokens;
+    uint64_t trie_slots, dict_slots;      /* open-addressing table sizes (32-byte slots)                    */
+    uint64_t device_bytes;                /* HBM held by the index                                          */
+    uint64_t epoch;
+} bmq_index_info;
+
+/* ---- lifecycle -------------------------------------------------------------------------------------- */
+/* One engine per KV range replica, like DistWorkerCoProc's SubscriptionCache
+ * (DW/DistWorkerCoProcFactory.java:91-93). */
+int bmq_engine_create(const bmq_config* cfg, bmq_engine** out);
+void bmq_engine_destroy(bmq_engine* e);
+const char* bmq_last_error(const bmq_engine* e);
+const char* bmq_version(void);
+
+/* ---- dist direction: index maintenance -------------------------------------------------------------- */
+/* Full (re)load from a KV scan -- replaces IKVRangeCoProc.reset(Boundary) (KVAPI/IKVRangeCoProc.java:64,
+ * DW/DistWorkerCoProc.java:283-291).  keys = route keys in the layout of SCHEMA/KVSchemaUtil.java:91-130;
+ * any order (sorted + deduplicated internally; a KV iterator already yields them sorted). */
+int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys);
+
+/* Post-commit route mutations -- replaces ISubscriptionCache.refresh(AddRoutesTask/RemoveRoutesTask)
+ * (DW/DistWorkerCoProc.java:188-209, DW/cache/SubscriptionCache.java:127-134).  op[i]: 0 = put, 1 = delete.
+ * Applied in order; the new epoch becomes visible to the next match call. */
+int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
+
+int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out);
+/* id -> key (so the Java adapter can materialise Matching objects, SCHEMA/KVSchemaUtil.java:73-89). */
+int bmq_route_key(const bmq_engine* e, uint32_t route_id, uint8_t* out, uint32_t cap, uint32_t* out_len);
+/* exact lookup (no wildcard semantics): ids of the routes stored under (tenant, topicFilter); for tests
+ * and for RouteDetailCache-style inspection.  Writes up to cap ids, *out_n = total. */
+int bmq_index_find(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter,
+                   uint32_t filter_len, uint32_t* out_ids, uint32_t cap, uint32_t* out_n);
+
+/* ---- dist direction: match --------------------------------------------------------------------------- */
+/* Batch form of ITenantRouteMatcher.matchAll (DW/cache/ITenantRouteMatcher.java:37; implementation
+ * DW/cache/TenantRouteMatcher.java:67-161) across tenants, as DistWorkerCoProc.batchDist iterates
+ * DistPack(tenant) x TopicMessagePack(topic) (DW/DistWorkerCoProc.java:515-552).
+ *   tenants/tenant_off : the distinct tenant ids of the batch (n_tenants packed strings)
+ *   topic_tenant[i]    : index into that table for topic i
+ *   topics/topic_off   : n_topics packed topic strings
+ * Output: out_row_ptr[n_topics+1], out_route_ids[*out_needed] (ascending per row).  If out_capacity is too
+ * small nothing is written to out_route_ids, *out_needed is set and BMQ_E_NOSPACE returned. */
+int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                    const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off,
+                    uint32_t n_topics, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
+                    uint64_t* out_needed);
+
+/* Same, all seven data pointers are DEVICE pointers (inputs already resident in HBM; results stay in HBM).
+ * Asynchronous on the engine stream; d_out_total (device uint64) receives the id count.  Call bmq_sync()
+ * (or bmq_match_finish()) before reading results.  topics buffer must be readable up to
+ * topic_off[n_topics] rounded up to 8 bytes. */
+int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t* d_tenant_off, uint32_t n_tenants,
+                        const uint32_t* d_topic_tenant, const uint8_t* d_topics, const uint32_t* d_topic_off,
+                        uint32_t n_topics, uint32_t* d_out_row_ptr, uint32_t* d_out_route_ids,
+                        uint64_t out_capacity, uint64_t* d_out_total);
+/* Waits for the stream, resolves deferred conditions of the last *_dev batch (internal scratch growth ->
+ * transparent re-run; BMQ_E_NOSPACE if out_capacity was too small) and fills stats. */
+int bmq_match_finish(bmq_engine* e, uint64_t* out_total);
+int bmq_sync(bmq_engine* e);
+int bmq_stats_get(const bmq_engine* e, bmq_stats* out);
+/* The hipStream_t the engine launches on (as void*), so a harness can bracket it with HIP events. */
+void* bmq_stream(const bmq_engine* e);
+
+/* ---- host-side mirror of MatchedRoutes (fan-out caps in KV order) -------------------------------------- */
+/* One ITenantRouteMatcher.matchAll(topics, maxPersistentFanout, maxGroupFanout) call for one tenant,
+ * including DW/cache/MatchedRoutes.java:87-141: persistent (subBrokerId == 1) and group fan-out caps applied
+ * first-come in key order, throttle events reported.  events: 4 int32 each {type 0=PersistentFanoutThrottled
+ * 1=GroupFanoutThrottled, topic index, rejected route id, max count}. */
+int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics,
+                  const uint32_t* topic_off, uint32_t n_topics, int32_t max_persistent_fanout,
+                  int32_t max_group_fanout, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
+                  uint64_t* out_needed, int32_t* out_events, uint32_t events_cap, uint32_t* out_n_events);
+
+/* ---- route-key codec (SCHEMA/KVSchemaUtil.java:91-130, SCHEMA/cache/RouteDetailCache.java:53-117) ------- */
+/* flag: 1 normal (receiver = receiverUrl), 2 unordered share, 3 ordered share (receiver = group name).
+ * filter = MQTT topic filter WITHOUT a $share/$oshare prefix.  Returns key length (writes if <= cap). */
+uint32_t bmq_route_key_encode(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter,
+                              uint32_t filter_len, uint8_t flag, const uint8_t* receiver, uint32_t receiver_len,
+                              uint8_t* out, uint32_t cap);
+/* Decode: spans (offset,len) into `key` for tenant, escaped filter (levels joined by NUL), receiver.
+ * Returns flag (1..3) or BMQ_E_INVAL. */
+int bmq_route_key_decode(const uint8_t* key, uint32_t key_len, uint32_t spans[6]);
+int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len);
+
+/* ---- retain direction (RS/index/IRetainTopicIndex.java:27-35) -------------------------------------------- */
+/* Load the retained-topic index: (tenant, topic) pairs; topic id = rank of (tenant, levels) in byte order.
+ * Replaces the full-scan rebuild in RS/RetainStoreCoProc.java:134-137,279-296. */
+int bmq_retain_rebuild(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                       const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off,
+                       uint32_t n_topics);
+/* IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134). */
+int bmq_retain_apply(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics,
+                     const uint32_t* topic_off, const uint8_t* op, uint32_t n);
+int bmq_retain_topic(const bmq_engine* e, uint32_t topic_id, uint8_t* out, uint32_t cap, uint32_t* out_len,
+                     uint32_t* out_tenant_idx);
+/* Batch of IRetainTopicIndex.match(tenant, topicFilter) (RS/index/RetainTopicIndex.java:136-138; selector
+ * :36-124; walk UTIL/index/TopicLevelTrie.java:190-249).  Output CSR of topic ids (ascending per row). */
+int bmq_retain_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                           const uint32_t* filter_tenant, const uint8_t* filters, const uint32_t* filter_off,
+                           uint32_t n_filters, uint32_t* out_row_ptr, uint32_t* out_topic_ids,
+                           uint64_t out_capacity, uint64_t* out_needed);
+int bmq_retain_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t* d_tenant_off,
+                               uint32_t n_tenants, const uint32_t* d_filter_tenant, const uint8_t* d_filters,
+                               const uint32_t* d_filter_off, uint32_t n_filters, uint32_t* d_out_row_ptr,
+                               uint32_t* d_out_topic_ids, uint64_t out_capacity, uint64_t* d_out_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMQ_H */

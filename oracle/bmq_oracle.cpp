@@ -572,6 +572,9 @@ struct MatchAllResult {
     std::vector<uint32_t> routes;
     std::vector<ThrottleEvent> events;
     uint64_t seekCount = 0, nextCount = 0, filterNodes = 0;
+    // Times the probe-then-seek loop would NOT have advanced in the reference (it livelocks there; see the
+    // note at the seek below).  The restatement steps one entry forward instead so that it terminates.
+    uint64_t livelocks = 0;
 };
 
 // DW/cache/TenantRouteMatcher.java:67-161
@@ -628,8 +631,18 @@ static void match_all(const KV& kv, const std::string& tenant, const std::vector
                             pos++;
                             res.nextCount++;
                         } else {
-                            pos = kv.seek(tenant_route_start_key(tenant, toMatch));
+                            // REFERENCE DEFECT (DW/cache/TenantRouteMatcher.java:129-136): when toMatch is the
+                            // current filter plus a trailing EMPTY level ("x" -> "x/"), its start key
+                            // "x\0\0\0" sorts at or before the current key "x\0\0<bucket>..." and itr.seek()
+                            // re-positions on the SAME entry: the Java loop never terminates.  Reachable with a
+                            // publish topic ending in '/' once 20 probes have missed.  We count it and step on.
+                            size_t np = kv.seek(tenant_route_start_key(tenant, toMatch));
                             res.seekCount++;
+                            if (np <= pos) {
+                                res.livelocks++;
+                                np = pos + 1;
+                            }
+                            pos = np;
                         }
                     }
                 } else {
@@ -955,6 +968,7 @@ void orc_result_event(void* r, uint32_t i, int* out4) {
 }
 uint64_t orc_result_seeks(void* r) { return ((MatchAllResult*)r)->seekCount; }
 uint64_t orc_result_nexts(void* r) { return ((MatchAllResult*)r)->nextCount; }
+uint64_t orc_result_livelocks(void* r) { return ((MatchAllResult*)r)->livelocks; }
 
 // one TenantRouteMatcher.matchAll(topics, maxPF, maxGF) call; routes per topic in KV order
 void orc_match_all(void* kv, const uint8_t* tenant, uint32_t tl, const uint8_t* topics, const uint32_t* off,
@@ -980,6 +994,7 @@ double orc_match_singletons(void* kvp, const uint8_t* tenants, const uint32_t* t
     if (threads < 1) threads = 1;
     auto t0 = std::chrono::steady_clock::now();
     std::atomic<uint32_t> cursor{0};
+    std::atomic<uint64_t> livelocks{0};
     auto work = [&]() {
         MatchAllResult r;
         for (;;) {
@@ -989,6 +1004,7 @@ double orc_match_singletons(void* kvp, const uint8_t* tenants, const uint32_t* t
                 r = MatchAllResult();
                 match_all(kv, tn[topicTenant[j]], {tp[j]}, INT32_MAX, INT32_MAX, r);
                 per[j] = r.routes;
+                livelocks += r.livelocks;
             }
         }
     };
@@ -999,6 +1015,7 @@ double orc_match_singletons(void* kvp, const uint8_t* tenants, const uint32_t* t
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     MatchAllResult* res = (MatchAllResult*)result;
     *res = MatchAllResult();
+    res->livelocks = livelocks.load();
     res->rowPtr.assign(n + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
         res->rowPtr[i + 1] = res->rowPtr[i] + (uint32_t)per[i].size();

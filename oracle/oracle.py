@@ -60,6 +60,7 @@ def lib():
             "orc_result_nroutes": (C.c_uint32, [vp]), "orc_result_nevents": (C.c_uint32, [vp]),
             "orc_result_event": (None, [vp, C.c_uint32, i32p]),
             "orc_result_seeks": (C.c_uint64, [vp]), "orc_result_nexts": (C.c_uint64, [vp]),
+            "orc_result_livelocks": (C.c_uint64, [vp]),
             "orc_match_all": (None, [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint32, C.c_int, C.c_int, vp]),
             "orc_match_singletons": (C.c_double, [vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
             "orc_match_bruteforce": (None, [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint32, vp]),
@@ -295,6 +296,11 @@ class MatchResult:
     @property
     def next_count(self) -> int:
         return lib().orc_result_nexts(self.h)
+
+    @property
+    def livelocks(self) -> int:
+        """times the reference's probe-then-seek loop would have spun forever (see bmq_oracle.cpp)"""
+        return lib().orc_result_livelocks(self.h)
 
     def __del__(self):
         if self.h:

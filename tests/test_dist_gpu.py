@@ -1,0 +1,315 @@
+"""GPU parity tests of the dist-direction match path (HIP kernels behind the C ABI) against the CPU oracle.
+
+Bar: bit-exact -- for every (tenant, topic) the ascending list of route ids (= ranks of KV keys) equals the
+oracle's.  Known-answer tests are the reference's own (DWT/cache/TenantRouteMatcherTest.java:89-342,
+DWT/DistQoS0Test.java:95-150), re-run through the engine.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import bifromq_amd as B
+from bifromq_amd.workload import unpack
+from oracle import oracle as O
+from oracle import semantic as S
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+TENANT, OTHER = "tenantA", "tenantB"
+
+
+def _normal(tenant, tf, broker, recv, deliverer):
+    return B.route_key_from_mqtt(tenant, tf, O.receiver_url(broker, recv, deliverer))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = B.Engine(device=0)
+    yield e
+    e.close()
+
+
+def _keys_of(e, rows):
+    return [[e.route_key(r) for r in row] for row in rows]
+
+
+# ---- the reference's known-answer tests, through the engine ---------------------------------------------------
+def test_kat_no_tenant_data(eng):  # TenantRouteMatcherTest.java:89-110
+    eng.rebuild([_normal(OTHER, "sensors/+/temp", 1, "receiverX", "delivererX")])
+    m = B.TenantRouteMatcher(eng, TENANT).match_all(["sensors/device1/temp", "sensors/device1/humidity"], 10, 10)
+    assert set(m) == {"sensors/device1/temp", "sensors/device1/humidity"}
+    assert all(v.route_ids == [] for v in m.values())
+
+
+def test_kat_multiple_topics(eng):  # :112-146
+    temp = _normal(TENANT, "sensors/+/temp", 1, "receiverA", "delivererA")
+    hum = _normal(TENANT, "sensors/+/humidity", 1, "receiverB", "delivererB")
+    eng.rebuild([temp, hum])
+    rows, ev = eng.match_all(TENANT, ["sensors/device1/temp", "sensors/device1/humidity", "sensors/device2/temp"], 10, 10)
+    assert _keys_of(eng, rows) == [[temp], [hum], [temp]] and ev == []
+
+
+def test_kat_reuse_cached_filter_matches(eng):  # :148-176
+    a = _normal(TENANT, "devices/+/status", 1, "receiverA", "delivererA")
+    b = _normal(TENANT, "devices/+/status", 2, "receiverB", "delivererB")
+    eng.rebuild([a, b])
+    rows, ev = eng.match_all(TENANT, ["devices/a/status", "devices/b/status"], 5, 5)
+    assert _keys_of(eng, rows) == [sorted([a, b])] * 2 and ev == []
+
+
+def test_kat_shared_subscription(eng):  # :178-205
+    g = B.route_key_from_mqtt(TENANT, "$share/groupAlpha/alerts/+/+/temperature")
+    eng.rebuild([g])
+    m = B.TenantRouteMatcher(eng, TENANT).match_all(
+        ["alerts/site1/device1/temperature", "alerts/site1/device2/temperature"], 10, 10)
+    for v in m.values():
+        assert v.routes(eng) == [(2, TENANT, "$share/groupAlpha/alerts/+/+/temperature", "groupAlpha")]
+        assert v.group_fanout == 1 and v.persistent_fanout == 0
+
+
+def test_kat_probe_then_seek(eng):  # :207-237
+    keys = [_normal(TENANT, "invalid/%d" % i, 1, "noise%d" % i, "deliverer%d" % i) for i in range(21)]
+    valid = _normal(TENANT, "metrics/+/cpu", 1, "receiverA", "delivererA")
+    eng.rebuild(keys + [valid])
+    rows, ev = eng.match_all(TENANT, ["metrics/server1/cpu"], 10, 10)
+    assert _keys_of(eng, rows) == [[valid]] and ev == []
+
+
+def test_kat_tenant_isolation(eng):  # :239-270
+    a = _normal(TENANT, "devices/+/signal", 1, "receiverA", "delivererA")
+    b = _normal(OTHER, "devices/+/signal", 1, "receiverB", "delivererB")
+    eng.rebuild([a, b])
+    assert _keys_of(eng, eng.match_all(TENANT, ["devices/a/signal"], 10, 10)[0]) == [[a]]
+    assert _keys_of(eng, eng.match_all(OTHER, ["devices/a/signal"], 10, 10)[0]) == [[b]]
+    # both tenants in ONE batch
+    row, ids = eng.match_batch([TENANT, OTHER, "nobody"], [0, 1, 2, 1], ["devices/a/signal"] * 4)
+    assert _keys_of(eng, U.csr_rows(row, ids)) == [[a], [b], [], [b]]
+
+
+def test_kat_persistent_fanout_throttling(eng):  # :272-303
+    first = _normal(TENANT, "alarms/+/critical", 1, "receiverA", "delivererA")
+    second = _normal(TENANT, "alarms/+/critical", 1, "receiverB", "delivererB")
+    eng.rebuild([first, second])
+    kv = O.KV([first, second])
+    exp = kv.match_all(TENANT, ["alarms/device1/critical"], 1, 10)
+    rows, ev = eng.match_all(TENANT, ["alarms/device1/critical"], 1, 10)
+    assert rows == exp.per_topic() and ev == exp.events
+    assert len(rows[0]) == 1 and len(ev) == 1 and (ev[0][0], ev[0][1], ev[0][3]) == (0, 0, 1)
+    m = B.TenantRouteMatcher(eng, TENANT).match_all(["alarms/device1/critical"], 1, 10)["alarms/device1/critical"]
+    assert m.persistent_fanout == 1 and len(m.throttled) == 1
+
+
+def test_kat_group_fanout_throttling(eng):  # :305-342
+    first = B.route_key_from_mqtt(TENANT, "$share/groupA/jobs/+/progress")
+    second = B.route_key_from_mqtt(TENANT, "$share/groupB/jobs/+/progress")
+    eng.rebuild([first, second])
+    rows, ev = eng.match_all(TENANT, ["jobs/job1/progress"], 10, 1)
+    assert _keys_of(eng, rows) == [[second]]  # "second comes before first ... by bucketing key" (:339-340)
+    assert len(ev) == 1 and ev[0][0] == 1 and ev[0][3] == 1 and eng.route_key(ev[0][2]) == first
+
+
+def test_dist_qos0_vectors(eng):  # DWT/DistQoS0Test.java:95-150
+    keys = [_normal(TENANT, "/你好/hello/😄", 0, "inbox1", "batch1"), _normal(TENANT, "/#", 0, "inbox1", "batch1"),
+            _normal(TENANT, "/#", 0, "inbox2", "batch2"), _normal(TENANT, "#", 0, "inbox3", "batch3"),
+            _normal(TENANT, "$sys/#", 0, "inbox4", "b")]
+    eng.rebuild(keys)
+    rows = eng.match_tenant(TENANT, ["/你好/hello/😄", "$sys/bifromq/user/event/abc", "/", ""])
+    assert [len(r) for r in rows] == [4, 1, 3, 1]
+    assert _keys_of(eng, rows)[1] == [keys[4]]
+
+
+# ---- randomised parity: engine == structural oracle == semantic brute force -------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_parity_small(eng, seed):
+    rnd = random.Random(seed)
+    tenants = ["tA", "tB", "租户"]
+    keys = sorted({U.rand_route_key(rnd, rnd.choice(tenants), U.rand_filter(rnd, 5), i) for i in range(4000)})
+    eng.rebuild(keys)
+    kv = O.KV(keys)
+    topics = [U.rand_topic(rnd, 6) for _ in range(3000)] + ["", "/", "//", "a", "$sys", "$sys/a", "+", "#", "a/#"]
+    tt = [rnd.randrange(len(tenants) + 1) for _ in topics]  # index 3 = tenant without routes
+    tnames = tenants + ["ghost"]
+    row, ids = eng.match_batch(tnames, tt, topics)
+    got = U.csr_rows(row, ids)
+    assert got == U.semantic_rows(kv, tnames, tt, topics)
+    # the structural restatement of TenantRouteMatcher.matchAll (whole-batch mode) agrees, except where the
+    # reference loses routes to quirk (ii) -- this alphabet is rich in empty levels on purpose
+    U.assert_rows_equal_modulo_quirk_ii(keys, tnames, tt, U.oracle_rows(kv, tnames, tt, topics), got)
+    for i in range(0, len(topics), 7):  # semantic cross-check (independent python matcher)
+        exp = [r for r, k in enumerate(keys)
+               if (d := O.parse_route_key(k))[1] == tnames[tt[i]]
+               and S.matches(topics[i], d[2].split("/", 2)[2] if d[0] != 1 else d[2])]
+        assert got[i] == exp, (topics[i], tnames[tt[i]])
+    st = eng.stats()
+    assert st.n_topics == len(topics) and st.n_match == len(ids)
+    # roofline accounting: the engine's N_visit equals the oracle's count on the same data
+    packed = O.pack(topics)
+    assert st.n_visit == int(kv.count_visits(tnames, np.array(tt, dtype=np.uint32), packed).sum())
+
+
+def test_generated_workload_parity(eng):
+    """C1-shaped (literal) and C2/C3-shaped (wildcards, multi-tenant) workloads at oracle-friendly sizes."""
+    for seed, n_tenants, per, mode, n_topics in [(0xB1F20001, 1, 10000, 0, 20000), (0xB1F20002, 1, 20000, 1, 20000),
+                                                 (0xB1F20003, 20, 2000, 1, 30000)]:
+        w = B.Workload(seed, n_tenants, per, mode)
+        eng.rebuild(packed=w.keys_packed())
+        kv = O.KV(packed=w.keys_packed())
+        data, off, tt = w.topics(seed + 77, n_topics)
+        tn = w.tenants()
+        row, ids = eng.match_batch(tn, tt, packed_topics=(data, off))
+        topics = [t.decode() for t in unpack(data, off)]
+        got = U.csr_rows(row, ids)
+        assert eng.stats().n_visit == int(kv.count_visits(tn, tt, (data, off)).sum())
+        # (1) the reference's production call pattern -- one matchAll(singleton(topic)) per topic -- on EVERY topic;
+        # rows may differ only where the reference itself loses routes (quirk ii / the trailing-'/' livelock,
+        # see oracle/bmq_oracle.cpp); (2) whole-batch matchAll on a slice; (3) authoritative semantic rows on a sample
+        res, _ = kv.match_singletons(tn, tt, (data, off), threads=8)
+        n_diff = U.assert_rows_equal_modulo_quirk_ii(w.keys(), tn, tt, [sorted(r) for r in res.per_topic()], got)
+        assert n_diff <= n_topics // 100
+        m = 3000
+        U.assert_rows_equal_modulo_quirk_ii(w.keys(), tn, tt[:m], U.oracle_rows(kv, tn, tt[:m], topics[:m]), got[:m])
+        idx = list(range(0, n_topics, 40))
+        assert [got[i] for i in idx] == U.semantic_rows(kv, tn, [tt[i] for i in idx], [topics[i] for i in idx])
+
+
+# ---- the rare paths: LDS overflow -> per-lane DFS, deep topics, interleaved ranges -> fix-up sort ------------------
+def test_slow_path_equals_fast_path():
+    rnd = random.Random(5)
+    alphabet = ["a", "b", "c"]
+    keys = sorted({U.rand_route_key(rnd, "t", U.rand_filter(rnd, 6, alphabet), i) for i in range(6000)})
+    topics = [U.rand_topic(rnd, 6, alphabet) for _ in range(2000)]
+    topics += ["/".join(rnd.choice(alphabet) for _ in range(n)) for n in (16, 17, 18, 40, 300)]  # deep topics
+    deep = sorted({U.rand_route_key(rnd, "t", "/".join(["a"] * n + ["#"]), 900000 + n) for n in (15, 16, 17, 30)} |
+                  {U.rand_route_key(rnd, "t", "/".join(["+"] * 17), 800000), U.rand_route_key(rnd, "t", "/".join(["a"] * 40), 800001)})
+    topics += ["/".join(["a"] * n) for n in (15, 16, 17, 18, 30, 31, 40, 41)]
+    keys = sorted(set(keys) | set(deep))
+    kv = O.KV(keys)
+    exp = U.semantic_rows(kv, ["t"], [0] * len(topics), topics)
+    normal = B.Engine(device=0).rebuild(keys)
+    assert normal.match_tenant("t", topics) == exp
+    assert normal.stats().n_slow_topics >= 10  # the deep ones
+    tiny = B.Engine(device=0, wave_queue_cap=128, wave_pair_cap=8, slow_scratch_mb=1).rebuild(keys)
+    assert tiny.match_tenant("t", topics) == exp
+    assert tiny.stats().n_slow_topics > 100  # forced overflows went through the DFS path
+    assert tiny.stats().n_visit == normal.stats().n_visit
+
+
+def test_interleaved_ranges_are_sorted(eng):
+    # keys of filter "x" (bucket byte b) interleave with keys of "x/..." whose next level
+    # is empty -- id ranges of two matched filters overlap, the expand kernel must fall back to the row sort.
+    keys = [_normal("t", "x", 0, "r%d" % i, "d") for i in range(300)] + \
+           [_normal("t", "x/#", 0, "h%d" % i, "d") for i in range(50)] + \
+           [_normal("t", "x//#", 0, "e%d" % i, "d") for i in range(200)] + \
+           [_normal("t", "x//" + c + "/#", 0, "q%d" % i, "d") for i in range(40) for c in "aZ0"]
+    keys = sorted(set(keys))
+    eng.rebuild(keys)
+    kv = O.KV(keys)
+    topics = ["x", "x/", "x//a", "x//Z/k", "x/y"]
+    got = eng.match_tenant("t", topics)
+    exp = [kv.match_bruteforce("t", [t]).per_topic()[0] for t in topics]
+    assert got == exp
+    assert all(r == sorted(r) for r in got)
+    assert eng.stats().n_sorted_rows >= 1
+
+
+def test_big_fanout_and_many_ranges(eng):
+    # one topic matching > 32 distinct filters (range-list sort skipped -> row sort) and a 5000-receiver filter
+    keys = [_normal("t", "big/+", 0, "r%d" % i, "d%d" % (i % 5)) for i in range(5000)]
+    lv = ["a", "+"]
+    import itertools
+    for combo in itertools.product(lv, repeat=6):
+        keys.append(_normal("t", "/".join(combo), 0, "c", "d"))
+        keys.append(_normal("t", "/".join(combo[:5]) + "/#", 1, "h", "d"))
+    keys = sorted(set(keys))
+    eng.rebuild(keys)
+    kv = O.KV(keys)
+    topics = ["big/1", "a/a/a/a/a/a", "a/a/a/a/a/b", "big/2"] + ["a/a/a/a/a/a"] * 70
+    exp = [kv.match_bruteforce("t", [t]).per_topic()[0] for t in topics[:4]]
+    got = eng.match_tenant("t", topics)
+    assert got[:4] == exp and all(g == exp[1] for g in got[4:])
+    assert len(got[0]) == 5000 and len(got[1]) == 64 + 32
+
+
+def test_apply_then_match(eng):
+    w = B.Workload(42, 4, 1500, 1)
+    keys = w.keys()
+    eng.rebuild(keys)
+    rnd = random.Random(9)
+    live = set(keys)
+    tn = w.tenants()
+    data, off, tt = w.topics(5, 4000)
+    topics = [t.decode() for t in unpack(data, off)]
+    for step in range(3):
+        ops = []
+        for k in rnd.sample(sorted(live), 300):
+            ops.append((1, k))
+            live.discard(k)
+        for i in range(300):
+            k = U.rand_route_key(rnd, rnd.choice(tn), rnd.choice(topics).replace("l2_", "+/x")[:60] if i % 3 else "#", 10**6 + step * 1000 + i)
+            ops.append((0, k))
+            live.add(k)
+        eng.apply(ops)
+        kv = O.KV(sorted(live))
+        assert eng.info().n_routes == len(live)
+        row, ids = eng.match_batch(tn, tt, packed_topics=(data, off))
+        assert U.csr_rows(row, ids) == U.semantic_rows(kv, tn, tt, topics)
+
+
+def test_output_capacity_protocol(eng):
+    import ctypes as C
+    from bifromq_amd import _lib
+    keys = [_normal("t", "a/+", 0, "r%d" % i, "d") for i in range(100)]
+    eng.rebuild(keys)
+    tdata, toff = B.pack(["t"])
+    pdata, poff = B.pack(["a/b"] * 10)
+    tt = np.zeros(10, dtype=np.uint32)
+    row = np.zeros(11, dtype=np.uint32)
+    ids = np.zeros(10, dtype=np.uint32)
+    need = C.c_uint64()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = _lib.lib().bmq_match_batch(eng.h, p(tdata), p(toff), 1, p(tt), p(pdata), p(poff), 10, p(row), p(ids), 10, C.byref(need))
+    assert rc == -3 and need.value == 1000  # BMQ_E_NOSPACE, exact size reported
+    ids = np.zeros(1000, dtype=np.uint32)
+    rc = _lib.lib().bmq_match_batch(eng.h, p(tdata), p(toff), 1, p(tt), p(pdata), p(poff), 10, p(row), p(ids), 1000, C.byref(need))
+    assert rc == 0 and row.tolist() == list(range(0, 1001, 100)) and ids.tolist() == list(range(100)) * 10
+
+
+# ---- full BASELINE size: properties that do not need the oracle to finish the whole batch ---------------------------
+def test_full_size_config2_properties(eng):
+    """configs[1]: 1 tenant, 1M filters with +/# wildcards, 1M-publish batch.  Checked: CSR well-formed, rows strictly
+    ascending, a random sample of rows bit-exact vs the oracle (production call pattern), every emitted id of a second
+    sample semantically matches, duplicate topics get identical rows, idempotence across two runs."""
+    w = B.Workload(0xB1F20002, 1, 1_000_000, 1)
+    eng.rebuild(packed=w.keys_packed())
+    data, off, tt = w.topics(0xB1F20002 + 1, 1_000_000)
+    tn = w.tenants()
+    row, ids = eng.match_batch(tn, tt, packed_topics=(data, off))
+    assert row[0] == 0 and row[-1] == len(ids) and (np.diff(row.astype(np.int64)) >= 0).all()
+    d = np.diff(ids.astype(np.int64))
+    starts = row[1:-1][row[1:-1] < len(ids)]
+    d[(starts - 1)[starts > 0]] = 1  # ignore row boundaries
+    assert (d > 0).all()
+    assert ids.max() < w.n_keys
+    row2, ids2 = eng.match_batch(tn, tt, packed_topics=(data, off))
+    assert (row == row2).all() and (ids == ids2).all()
+    rnd = random.Random(3)
+    kv = O.KV(packed=w.keys_packed())
+    sample = sorted(rnd.sample(range(1_000_000), 3000))
+    raw = data.tobytes()
+    topics = [raw[off[i]:off[i + 1]] for i in sample]
+    res, _ = kv.match_singletons(tn, np.zeros(len(sample), dtype=np.uint32), O.pack(topics), threads=8)
+    got = [ids[row[i]:row[i + 1]].tolist() for i in sample]
+    U.assert_rows_equal_modulo_quirk_ii(w.keys(), tn, [0] * len(sample), [sorted(r) for r in res.per_topic()], got)
+    for j in range(0, len(sample), 100):  # authoritative semantic check on a sub-sample (O(keys) each)
+        assert got[j] == kv.match_bruteforce(tn[0], [topics[j]]).per_topic()[0]
+    # duplicates: same topic string -> same row
+    seen = {}
+    for i in range(0, 200000):
+        t = raw[off[i]:off[i + 1]]
+        if t in seen:
+            j = seen[t]
+            assert (ids[row[i]:row[i + 1]] == ids[row[j]:row[j + 1]]).all()
+        else:
+            seen[t] = i

@@ -1,0 +1,116 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, the product codec agrees
+with the oracle's, the host builder indexes every route exactly once, and matching refuses to run without a device."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import bifromq_amd as B
+from bifromq_amd import _lib
+from oracle import oracle as O
+from tests import util as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bmq.h")).read()
+    declared = set(re.findall(r"\b(bmq_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"bmq_engine", "bmq_config", "bmq_stats", "bmq_index_info", "bmq_status"}
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    L = C.CDLL(_lib.LIB_PATH)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert b"gfx950" in _lib.lib().bmq_version()
+
+
+def test_no_cpu_fallback():
+    e = B.Engine(device=-1)
+    e.rebuild([B.route_key("t", "a/b", 1, "0\0r\0d")])
+    with pytest.raises(B.BmqError) as ei:
+        e.match_tenant("t", ["a/b"])
+    assert ei.value.code == -2  # BMQ_E_NODEVICE
+
+
+def test_codec_matches_oracle():
+    rnd = random.Random(7)
+    for i in range(500):
+        tenant = rnd.choice(["t", "tenantA", "租户", ""])
+        f = U.rand_filter(rnd)
+        flag = rnd.choice([1, 2, 3])
+        recv = O.receiver_url(rnd.randint(0, 2), "inbox%d/😄" % i, "d%d" % i) if flag == 1 else "grp%d" % i
+        k = B.route_key(tenant, f, flag, recv)
+        assert k == O.route_key(tenant, f, flag, recv)
+        got = B.decode_route_key(k)
+        exp = O.parse_route_key(k)
+        assert got == exp
+    for s in ["", "a", "hello", "你好", "😄x", "0\0inbox\0d"]:
+        assert B.java_string_hash(s) == O.java_hash(s)
+    assert B.decode_route_key(b"\x01garbage") is None
+    assert B.decode_route_key(b"") is None
+
+
+def test_schema_vectors():
+    # SCHEMA KVSchemaUtilTest.java:88-145 round trips via the product codec
+    k = B.route_key_from_mqtt("tenantA", "/a/b/c", O.receiver_url(1, "inbox1", "deliverer1"))
+    assert B.decode_route_key(k) == (1, "tenantA", "/a/b/c", "1\0inbox1\0deliverer1")
+    g = B.route_key_from_mqtt("tenantA", "$share/group//a/b/c")
+    assert B.decode_route_key(g) == (2, "tenantA", "$share/group//a/b/c", "group")
+    og = B.route_key_from_mqtt("tenantA", "$oshare/group//a/b/c")
+    assert B.decode_route_key(og) == (3, "tenantA", "$oshare/group//a/b/c", "group")
+
+
+def test_builder_indexes_every_route_once():
+    rnd = random.Random(11)
+    tenants = ["tA", "tB", "t"]
+    keys = set()
+    for i in range(3000):
+        keys.add(U.rand_route_key(rnd, rnd.choice(tenants), U.rand_filter(rnd, 6), i))
+    keys = sorted(keys)
+    e = B.Engine(device=-1).rebuild(list(reversed(keys)))  # any input order
+    info = e.info()
+    assert info.n_routes == len(keys) and info.n_tenants == 3
+    assert [e.route_key(i) for i in range(0, len(keys), 97)] == keys[::97]
+    by_filter = {}
+    for rank, k in enumerate(keys):
+        flag, tenant, mqtt, recv = B.decode_route_key(k)
+        if flag != 1:
+            mqtt = mqtt.split("/", 2)[2]
+        by_filter.setdefault((tenant, mqtt), []).append(rank)
+    seen = 0
+    for (tenant, f), ranks in by_filter.items():
+        assert e.find(tenant, f) == ranks, (tenant, f)
+        seen += len(ranks)
+    assert seen == len(keys)
+    assert e.find("tA", "no/such/filter") == [] and e.find("nobody", "a") == []
+
+
+def test_apply_put_delete_host():
+    ks = [B.route_key("t", "a/%d" % i, 1, "0\0r%d\0d" % i) for i in range(50)]
+    e = B.Engine(device=-1).rebuild(ks)
+    e.apply([(1, ks[3]), (0, B.route_key("t", "z", 1, "0\0r\0d")), (1, ks[7]), (0, ks[7]), (1, b"\x00\x00\x01tq\x00\x00\x00\x01\x00\x00")])
+    exp = sorted((set(ks) - {ks[3]}) | {B.route_key("t", "z", 1, "0\0r\0d")})
+    assert e.info().n_routes == len(exp) and e.info().epoch == 2
+    assert [e.route_key(i) for i in range(len(exp))] == exp
+    with pytest.raises(B.BmqError):
+        e.apply([(0, b"not a key")])
+
+
+def test_workload_generator_is_deterministic_and_sorted():
+    w1, w2 = B.Workload(0xB1F20002, 3, 500), B.Workload(0xB1F20002, 3, 500)
+    k1 = w1.keys()
+    assert k1 == w2.keys() and k1 == sorted(set(k1))
+    assert all(B.decode_route_key(k) is not None for k in k1)
+    d1, o1, t1 = w1.topics(9, 200)
+    d2, o2, t2 = w2.topics(9, 200)
+    assert d1.tobytes() == d2.tobytes() and (o1 == o2).all() and (t1 == t2).all()
+    # 90 % of publishes are instantiated from a stored filter: most must have >= 1 semantic match
+    kv = O.KV(k1)
+    from bifromq_amd.workload import unpack
+    topics = [t.decode() for t in unpack(d1, o1)]
+    tn = w1.tenants()
+    hits = sum(1 for t, ti in zip(topics, t1) if kv.match_bruteforce(tn[ti], [t]).per_topic()[0])
+    assert hits >= 0.8 * len(topics)
