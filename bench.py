@@ -138,7 +138,7 @@ def main():
     lat = []
     walk_ms, expand_ms, total_ms = [], [], []
     alg_bytes = []
-    n_match = n_visit = 0
+    n_match = n_visit = n_slow = 0
     t_start = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()
@@ -152,6 +152,7 @@ def main():
         alg_bytes.append(st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit + 4 * st.n_match)
         n_match += st.n_match
         n_visit += st.n_visit
+        n_slow += st.n_slow_topics
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -190,6 +191,7 @@ def main():
         "p50_batch_ms": float(np.percentile(lat, 50)),
         "routes_per_topic": n_match / (n * steps),
         "visits_per_topic": n_visit / (n * steps),
+        "slow_path_topics_per_batch": n_slow / steps,
         "kernel_ms": {"k_walk": k_walk_ms, "k_expand": float(np.mean(expand_ms)), "all_kernels": float(np.mean(total_ms))},
         "host_s": {"generate": t_gen, "rebuild": t_build},
         "roofline": {"bound": "hbm", "kernel": "k_walk", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     uint32_t* tmeta = tokens + FAST_LEVELS * 64;    // [64]
     uint32_t* cnt_pairs = tmeta + 64;               // [64]
     uint32_t* cnt_routes = cnt_pairs + 64;          // [64]
-    uint32_t* cursor = cnt_routes + 64;             // [64]
+    uint32_t* cnt_visit = cnt_routes + 64;          // [64]
+    uint32_t* cursor = cnt_visit + 64;              // [64]
     uint32_t* q_node = cursor + 64;                 // [qcap]
     uint32_t* q_meta = q_node + a.qcap;             // [qcap]
     uint32_t* p_begin = q_meta + a.qcap;            // [pcap]
@@ -298,9 +299,10 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u) | (active ? TM_ACTIVE : 0u);
     cnt_pairs[lane] = 0;
     cnt_routes[lane] = 0;
+    cnt_visit[lane] = 0;
 
     // ---- phase 2: drain the work ring -----------------------------------------------------------------------------
-    uint32_t head = 0, tail = 0, pcount = 0, visits = 0;
+    uint32_t head = 0, tail = 0, pcount = 0;
     {
         const unsigned long long m = __ballot(active);
         if (active) {
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
                 step_item(a.ix, node, level, (meta & KIND_H) != 0, tm & 0xFFu, (tm & TM_SYS) != 0,
                           [&](uint32_t l) { return tokens[l * 64 + tl]; }, o);
         }
-        if (o.found && o.dl) visits++;
+        if (o.found && o.dl) atomicAdd(&cnt_visit[tl], 1u); // per topic: a flagged topic is recounted by the slow path
         // matched ranges -> LDS buffer
         const unsigned long long m1 = __ballot(o.emit_own), m2 = __ballot(o.emit_hash);
         if (m1 | m2) {
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     const bool flagged = (tm & TM_FLAG) != 0;
     const uint32_t np = flagged ? 0u : cnt_pairs[lane];
     const uint32_t nr = flagged ? 0u : cnt_routes[lane];
+    const uint32_t visits = flagged ? 0u : cnt_visit[lane];
     uint32_t total_pairs;
     const uint32_t excl = wave_excl_scan(np, lane, total_pairs);
     unsigned long long base = 0;
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
 }
 
 inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
-    return sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 4 * 64 + 2 * (size_t)qcap + 3 * (size_t)pcap);
+    return sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 5 * 64 + 2 * (size_t)qcap + 3 * (size_t)pcap);
 }
 
 } // namespace bmq

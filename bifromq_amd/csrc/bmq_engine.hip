@@ -472,6 +472,7 @@ int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenan
         if (pb) HIPCHK(e, hipMemcpyAsync(e->s_topics.p, topics, pb, hipMemcpyHostToDevice, e->stream));
         if ((rc = upload(e, e->s_topic_off, topic_off, sizeof(uint32_t) * (n_topics + 1)))) return rc;
         HIPCHK(e, e->s_row_ptr.ensure(sizeof(uint32_t) * (n_topics + 1)));
+        HIPCHK(e, e->b_total.ensure(sizeof(unsigned long long)));
         dev_cap = std::max<uint64_t>(e->s_ids.cap / 4, std::max<uint64_t>((uint64_t)n_topics * 4, 1024));
         HIPCHK(e, e->s_ids.ensure(dev_cap * 4));
     }

@@ -808,7 +808,9 @@ struct VisitIndex {
             for (auto& p : frontier) {
                 std::string a = p + tl[d];
                 a.push_back('\0');
-                if (prefixes.count(a)) next.push_back(a);
+                // a topic level that is literally "+" (illegal in a publish, tolerated here) must not count the
+                // wildcard node twice: filters cannot hold a literal "+", so prefix a IS the wildcard prefix b
+                if (tl[d] != SINGLE_WILDCARD && prefixes.count(a)) next.push_back(a);
                 if (!(d == 0 && starts_with_sys(tl[0]))) {
                     std::string b = p + "+";
                     b.push_back('\0');
