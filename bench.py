@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "small"])
     ap.add_argument("--topics", type=int, default=1_000_000, help="publishes per batch per rank")
     ap.add_argument("--batches", type=int, default=4, help="distinct pre-generated batches cycled through")
+    ap.add_argument("--ungrouped", action="store_true",
+                    help="publishes in random tenant order instead of one DistPack per tenant (BatchDistRequest shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tenants", type=int, default=16)
     ap.add_argument("--cpu-sample-topics", type=int, default=200_000)
@@ -87,7 +89,7 @@ def main():
     n = args.topics
     batches = []
     for b in range(args.batches):
-        data, off, tt = w.topics(seed + 1000 * (rank + 1) + b, n)
+        data, off, tt = w.topics(seed + 1000 * (rank + 1) + b, n, grouped=not args.ungrouped)
         batches.append((torch.from_numpy(data).to(dev), torch.from_numpy(off.astype(np.int32)).to(dev),
                         torch.from_numpy(tt.astype(np.int32)).to(dev), (data, off, tt) if b == 0 else None))
     cap = 16 * n
@@ -185,6 +187,7 @@ def main():
         "config": {"workload": name, "total_route_keys": total_tenants * per_tenant, "route_keys_this_rank": int(info.n_routes),
                    "tenants_this_rank": int(info.n_tenants), "trie_nodes_this_rank": int(info.n_nodes),
                    "index_bytes_this_rank": int(info.device_bytes), "publishes_per_batch_per_rank": n,
+                   "batch_order": "random" if args.ungrouped else "grouped by tenant (one DistPack per tenant)",
                    "parallelism": "tenant-shard x%d" % world if world > 1 else "single GPU",
                    "exchange": "RCCL all_gather of CSR (row_ptr + ids)" if world > 1 else "none"},
         "p99_batch_ms": float(np.percentile(lat, 99)),

@@ -112,7 +112,7 @@ def gen() -> C.CDLL:
             "bmqgen_n_keys": (u32, [vp]), "bmqgen_key_bytes": (vp, [vp]), "bmqgen_key_off": (vp, [vp]),
             "bmqgen_n_tenants": (u32, [vp]), "bmqgen_tenant_bytes": (vp, [vp]), "bmqgen_tenant_off": (vp, [vp]),
             "bmqgen_tenant_first": (vp, [vp]),
-            "bmqgen_topics": (u32, [vp, u64, u32, u32, u32, u32]),
+            "bmqgen_topics": (u32, [vp, u64, u32, u32, u32, u32, C.c_int]),
             "bmqgen_topic_bytes": (vp, [vp]), "bmqgen_topic_off": (vp, [vp]), "bmqgen_topic_tenant": (vp, [vp]),
             "bmqgen_retain": (u32, [vp, u64, u32, C.c_int]),
         }

@@ -58,7 +58,7 @@ struct BatchArgs {
     const uint32_t* topic_off;
     uint32_t n_topics;
     // per-batch scratch (device)
-    uint32_t* tenant_root; // [n_tenants]
+    TenantSlot* tenant_info; // [n_tenants] root/region of each batch tenant (root == NONE: unknown tenant)
     uint32_t* pair_off;    // [n_topics]
     uint32_t* pair_cnt;    // [n_topics]
     uint32_t* route_cnt;   // [n_topics]
@@ -81,6 +81,7 @@ struct BatchArgs {
     // LDS geometry
     uint32_t qcap; // pow2
     uint32_t pcap;
+    uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising, 2 = no XCD swizzle
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -116,9 +117,12 @@ __device__ __forceinline__ TrieSlot load_slot(const TrieSlot* trie, uint32_t idx
     return s;
 }
 
-// (parent, token) -> child slot; NONE if absent.  On a hit `out` holds the child's header.
-__device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_t parent, uint32_t token, TrieSlot& out) {
-    uint32_t s = edge_hash(parent, token) & ix.trie_mask;
+// (parent, token) -> child slot inside the tenant's region [base, base + size); NONE if absent.  On a hit `out`
+// holds the child's header.
+__device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_t base, uint32_t size, uint32_t parent,
+                                                uint32_t token, TrieSlot& out) {
+    const uint32_t end = base + size;
+    uint32_t s = base + edge_home(parent, token, size);
     for (;;) {
         const TrieSlot c = load_slot(ix.trie, s);
         if (c.parent == parent && c.token == token) {
@@ -126,7 +130,7 @@ __device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_
             return s;
         }
         if (c.parent == NONE) return NONE;
-        s = (s + 1) & ix.trie_mask;
+        s = (s + 1 == end) ? base : s + 1;
     }
 }
 
@@ -204,12 +208,20 @@ __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
     if (i >= a.n_tenants) return;
     uint32_t tok = TOK_UNKNOWN;
     tokenise(a.ix, a.tenants, a.tenant_off[i], a.tenant_off[i + 1], false, 1, [&](uint32_t, uint32_t t) { tok = t; });
-    uint32_t root = NONE;
+    TenantSlot info{tok, NONE, 0, 1};
     if (tok != TOK_UNKNOWN) {
-        TrieSlot s;
-        root = probe_child(a.ix, ROOT_PARENT, tok, s);
+        uint32_t d = tenant_hash(tok) & a.ix.tenant_mask;
+        for (;;) {
+            const TenantSlot t = a.ix.tenants[d];
+            if (t.token == tok) {
+                info = t;
+                break;
+            }
+            if (t.token == 0) break;
+            d = (d + 1) & a.ix.tenant_mask;
+        }
     }
-    a.tenant_root[i] = root;
+    a.tenant_info[i] = info;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -230,8 +242,9 @@ struct StepOut {
 
 // tok_at(level) returns the topic's token at that level; nlev = level count; sys = first level starts with '$'
 template <class TokAt>
-__device__ __forceinline__ void step_item(const DistIndexView& ix, uint32_t node, uint32_t level, bool kind_h,
-                                          uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
+__device__ __forceinline__ void step_item(const DistIndexView& ix, uint32_t rbase, uint32_t rsize, uint32_t node,
+                                          uint32_t level, bool kind_h, uint32_t nlev, bool sys, TokAt&& tok_at,
+                                          StepOut& o) {
     o.found = false;
     o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
     if (kind_h) {
@@ -240,7 +253,7 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, uint32_t node
         o.dl = level;
         o.found = true;
     } else {
-        o.idx = probe_child(ix, node, tok_at(level), o.s);
+        o.idx = probe_child(ix, rbase, rsize, node, tok_at(level), o.s);
         o.dl = level + 1;
         o.found = o.idx != NONE;
     }
@@ -269,14 +282,21 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     uint32_t* cnt_routes = cnt_pairs + 64;          // [64]
     uint32_t* cnt_visit = cnt_routes + 64;          // [64]
     uint32_t* cursor = cnt_visit + 64;              // [64]
-    uint32_t* q_node = cursor + 64;                 // [qcap]
+    uint32_t* t_base = cursor + 64;                 // [64] tenant region of each topic
+    uint32_t* t_size = t_base + 64;                 // [64]
+    uint32_t* q_node = t_size + 64;                 // [qcap]
     uint32_t* q_meta = q_node + a.qcap;             // [qcap]
     uint32_t* p_begin = q_meta + a.qcap;            // [pcap]
     uint32_t* p_count = p_begin + a.pcap;           // [pcap]
     uint32_t* p_topic = p_count + a.pcap;           // [pcap]
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t t = blockIdx.x * 64 + lane;
+    // XCD-aware block order: the dispatcher places workgroup b on XCD b % 8 (speed only, never correctness); give every
+    // XCD one contiguous run of topic blocks so that its private L2 caches the regions of "its" tenants only.
+    const uint32_t nb = gridDim.x, per_xcd = (nb + 7) / 8;
+    uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3); // host launches a multiple of 8 blocks
+    if (a.debug_flags & 2u) blk = blockIdx.x;
+    const uint32_t t = blk * 64 + lane;
     const bool valid = t < a.n_topics;
     const uint32_t qm = a.qcap - 1;
 
@@ -287,7 +307,11 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
         const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
         tbytes = end - beg;
         const uint32_t ti = a.topic_tenant[t];
-        root = ti < a.n_tenants ? a.tenant_root[ti] : NONE;
+        TenantSlot info{0, NONE, 0, 1};
+        if (ti < a.n_tenants) info = a.tenant_info[ti];
+        root = info.root;
+        t_base[lane] = info.base;
+        t_size[lane] = info.size;
         if (root != NONE) { // unknown tenant: no routes, nothing to tokenise
             nlev = tokenise(a.ix, a.topics, beg, end, true, FAST_LEVELS,
                             [&](uint32_t l, uint32_t tok) { tokens[l * 64 + lane] = tok; });
@@ -304,8 +328,8 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     // ---- phase 2: drain the work ring -----------------------------------------------------------------------------
     uint32_t head = 0, tail = 0, pcount = 0;
     {
-        const unsigned long long m = __ballot(active);
-        if (active) {
+        const unsigned long long m = __ballot(active && !(a.debug_flags & 1u));
+        if (active && !(a.debug_flags & 1u)) {
             const uint32_t pos = rank_below(m);
             q_node[pos & qm] = root;
             q_meta[pos & qm] = make_meta(lane, 0, KIND_H);
@@ -329,7 +353,7 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
         if (act) {
             const uint32_t tm = tmeta[tl];
             if (!(tm & TM_FLAG))
-                step_item(a.ix, node, level, (meta & KIND_H) != 0, tm & 0xFFu, (tm & TM_SYS) != 0,
+                step_item(a.ix, t_base[tl], t_size[tl], node, level, (meta & KIND_H) != 0, tm & 0xFFu, (tm & TM_SYS) != 0,
                           [&](uint32_t l) { return tokens[l * 64 + tl]; }, o);
         }
         if (o.found && o.dl) atomicAdd(&cnt_visit[tl], 1u); // per topic: a flagged topic is recounted by the slow path
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     const unsigned long long wvis = wave_sum_u64(visits);
     const unsigned long long wbytes = wave_sum_u64(tbytes);
     if (lane == 0) {
-        a.wave_sums[blockIdx.x] = wsum;
+        if (blk < a.n_blocks) a.wave_sums[blk] = wsum;
         if (wvis) atomicAdd(&a.ctr->n_visit, wvis);
         if (total_pairs) atomicAdd(&a.ctr->n_ranges, (unsigned long long)total_pairs);
         atomicAdd(&a.ctr->topic_bytes, wbytes);
@@ -434,7 +458,9 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         const uint32_t t = a.slow_list[i];
         const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
         const uint32_t ti = a.topic_tenant[t];
-        const uint32_t root = ti < a.n_tenants ? a.tenant_root[ti] : NONE;
+        if (ti >= a.n_tenants) continue;
+        const TenantSlot info = a.tenant_info[ti];
+        const uint32_t root = info.root;
         if (root == NONE) continue;
         // level count first (cheap scan), then scratch: nlev tokens + (nlev + 2) stack entries of 2 words
         uint32_t nlev = 1;
@@ -465,7 +491,8 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                 const uint32_t node = stack[2 * sp], meta = stack[2 * sp + 1];
                 const uint32_t level = (meta >> 6) & 0x1FFFFFFu;
                 StepOut o;
-                step_item(a.ix, node, level, (meta & KIND_H) != 0, nlev, sys, [&](uint32_t l) { return toks[l]; }, o);
+                step_item(a.ix, info.base, info.size, node, level, (meta & KIND_H) != 0, nlev, sys,
+                          [&](uint32_t l) { return toks[l]; }, o);
                 if (!o.found) continue;
                 if (pass == 0 && o.dl) visits++;
                 if (o.emit_own) {
@@ -659,7 +686,7 @@ __global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
 }
 
 inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
-    return sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 5 * 64 + 2 * (size_t)qcap + 3 * (size_t)pcap);
+    return sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 7 * 64 + 2 * (size_t)qcap + 3 * (size_t)pcap);
 }
 
 } // namespace bmq

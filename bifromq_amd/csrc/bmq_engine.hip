@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -58,7 +59,7 @@ struct DevBuf {
 };
 
 struct DistDevice { // one epoch of the dist index in HBM
-    DevBuf trie, dict, pool, route_pos;
+    DevBuf trie, tenants, dict, pool, route_pos;
     DistIndexView view{};
     uint64_t bytes = 0;
 };
@@ -132,17 +133,19 @@ int upload_dist(bmq_engine* e) {
     const DistIndexHost& h = e->host;
     int rc;
     if ((rc = upload(e, d->trie, h.trie.data(), h.trie.size() * sizeof(TrieSlot)))) return rc;
+    if ((rc = upload(e, d->tenants, h.tenants.data(), h.tenants.size() * sizeof(TenantSlot)))) return rc;
     if ((rc = upload(e, d->dict, h.dict.data(), h.dict.size() * sizeof(DictSlot)))) return rc;
     if ((rc = upload(e, d->pool, h.pool.data(), h.pool.size()))) return rc;
     if ((rc = upload(e, d->route_pos, h.route_pos.data(), h.route_pos.size() * sizeof(uint32_t)))) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     d->view.trie = d->trie.as<TrieSlot>();
-    d->view.trie_mask = (uint32_t)h.trie.size() - 1;
+    d->view.tenants = d->tenants.as<TenantSlot>();
+    d->view.tenant_mask = (uint32_t)h.tenants.size() - 1;
     d->view.dict = d->dict.as<DictSlot>();
     d->view.dict_mask = (uint32_t)h.dict.size() - 1;
     d->view.pool = d->pool.as<uint8_t>();
     d->view.route_pos = d->route_pos.as<uint32_t>();
-    d->bytes = d->trie.cap + d->dict.cap + d->pool.cap + d->route_pos.cap;
+    d->bytes = d->trie.cap + d->tenants.cap + d->dict.cap + d->pool.cap + d->route_pos.cap;
     e->dist = std::move(d); // previous epoch freed here (match calls are serialised by e->mu)
     return BMQ_OK;
 }
@@ -167,7 +170,7 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     if (e->sort_cap == 0) e->sort_cap = 1024;
     e->sort_cap = std::max<uint32_t>(e->sort_cap, n_topics / 64);
     if (e->scratch_cap == 0) e->scratch_cap = (uint64_t)(e->cfg.slow_scratch_mb ? e->cfg.slow_scratch_mb : 64) * (1u << 20) / 4;
-    HIPCHK(e, e->b_tenant_root.ensure(sizeof(uint32_t) * std::max(n_tenants, 1u)));
+    HIPCHK(e, e->b_tenant_root.ensure(sizeof(TenantSlot) * std::max(n_tenants, 1u)));
     HIPCHK(e, e->b_pair_off.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
@@ -184,7 +187,7 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
 int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.ix = e->dist->view;
     a.n_blocks = (a.n_topics + 63) / 64;
-    a.tenant_root = e->b_tenant_root.as<uint32_t>();
+    a.tenant_info = e->b_tenant_root.as<TenantSlot>();
     a.pair_off = e->b_pair_off.as<uint32_t>();
     a.pair_cnt = e->b_pair_cnt.as<uint32_t>();
     a.route_cnt = e->b_route_cnt.as<uint32_t>();
@@ -198,6 +201,10 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.sort_list = e->b_sort_list.as<uint32_t>();
     a.sort_cap = e->sort_cap;
     a.ctr = e->b_ctr.as<Counters>();
+    {
+        const char* dbg = getenv("BMQ_DEBUG");
+        a.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
+    }
     a.qcap = e->cfg.wave_queue_cap;
     a.pcap = e->cfg.wave_pair_cap;
     hipStream_t s = e->stream;
@@ -205,7 +212,7 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     HIPCHK(e, hipEventRecord(e->ev[0], s));
     if (a.n_tenants) hipLaunchKernelGGL(k_resolve_tenants, dim3((a.n_tenants + 63) / 64), dim3(64), 0, s, a);
     HIPCHK(e, hipEventRecord(e->ev[1], s));
-    hipLaunchKernelGGL(k_walk, dim3(a.n_blocks), dim3(64), walk_lds_bytes(a.qcap, a.pcap), s, a);
+    hipLaunchKernelGGL(k_walk, dim3((a.n_blocks + 7) & ~7u), dim3(64), walk_lds_bytes(a.qcap, a.pcap), s, a);
     HIPCHK(e, hipEventRecord(e->ev[2], s));
     hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, a);

@@ -221,7 +221,10 @@ const uint32_t* bmqgen_tenant_first(void* h) { return ((Gen*)h)->tenant_first.da
 
 // Generates a publish batch (kept inside the generator until the next call).  tenant_lo/hi restrict the tenants
 // publishes are drawn for (a rank's shard); hit_permille = share of topics instantiated from a stored filter.
-uint32_t bmqgen_topics(void* h, uint64_t seed, uint32_t n_topics, uint32_t tenant_lo, uint32_t tenant_hi, uint32_t hit_permille) {
+// grouped != 0: the batch is ordered by tenant (stable), the shape of a BatchDistRequest -- one DistPack per tenant
+// holding that tenant's topics (DW/DistWorkerCoProc.java:522-539).
+uint32_t bmqgen_topics(void* h, uint64_t seed, uint32_t n_topics, uint32_t tenant_lo, uint32_t tenant_hi, uint32_t hit_permille,
+                       int grouped) {
     Gen& g = *(Gen*)h;
     Rng r(seed ^ 0xD1B54A32D192ED03ull);
     if (tenant_hi > g.n_tenants) tenant_hi = g.n_tenants;
@@ -260,6 +263,23 @@ uint32_t bmqgen_topics(void* h, uint64_t seed, uint32_t n_topics, uint32_t tenan
         }
         g.out_topics.push(join(lv));
         g.out_tenant.push_back(t);
+    }
+    if (grouped) {
+        std::vector<uint32_t> order(n_topics);
+        for (uint32_t i = 0; i < n_topics; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g.out_tenant[a] < g.out_tenant[b]; });
+        Packed np;
+        np.bytes.reserve(g.out_topics.bytes.size() + 32);
+        std::vector<uint32_t> nt(n_topics);
+        for (uint32_t i = 0; i < n_topics; i++) {
+            const uint32_t j = order[i];
+            np.bytes.insert(np.bytes.end(), g.out_topics.bytes.begin() + g.out_topics.off[j],
+                            g.out_topics.bytes.begin() + g.out_topics.off[j + 1]);
+            np.off.push_back((uint32_t)np.bytes.size());
+            nt[i] = g.out_tenant[j];
+        }
+        g.out_topics = std::move(np);
+        g.out_tenant.swap(nt);
     }
     g.out_topics.pad();
     return n_topics;

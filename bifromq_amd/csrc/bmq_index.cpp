@@ -7,6 +7,7 @@
 #include "bmq_index.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -348,7 +349,7 @@ bool DistIndexHost::build(const KeySet& ks) {
     nodes.reserve(n + 16);
     std::vector<uint32_t> group_count;          // routes per group, groups in order of first route id
     std::vector<uint32_t> route_group(n ? n : 1);
-    uint64_t tenants = 0;
+    uint64_t tenant_count = 0;
 
     // path of the previous key, for prefix reuse (sorted keys share long prefixes)
     std::string_view prev_tenant;
@@ -390,7 +391,7 @@ bool DistIndexHost::build(const KeySet& ks) {
             if (created) {
                 v = (uint32_t)nodes.size();
                 nodes.push_back({NONE, ttok, NONE, NONE});
-                tenants++;
+                tenant_count++;
             }
             node = v;
             prev_root = node;
@@ -440,38 +441,58 @@ bool DistIndexHost::build(const KeySet& ks) {
     }
     std::vector<uint32_t>().swap(route_group);
 
-    // ---- place nodes into the open-addressing slot table (parents first: creation order) --------------------
-    const uint32_t slots = pow2_at_least((uint64_t)nodes.size() * 2);
-    if ((uint64_t)nodes.size() * 2 > 0x80000000ull) {
+    // ---- place nodes: one private region of the slot table per tenant (nodes of a tenant are contiguous in
+    // creation order because its keys are contiguous in key order); parents are created before children -----------
+    std::vector<uint32_t> root_nodes; // node index of every tenant root, ascending
+    for (size_t i = 0; i < nodes.size(); i++)
+        if (nodes[i].parent == NONE) root_nodes.push_back((uint32_t)i);
+    double region_factor = 2.0; // slots per node (load factor 1/2); BMQ_REGION_FACTOR overrides for experiments
+    if (const char* rf = getenv("BMQ_REGION_FACTOR")) region_factor = std::max(1.1, atof(rf));
+    std::vector<uint64_t> region_base(root_nodes.size() + 1, 0);
+    for (size_t t = 0; t < root_nodes.size(); t++) {
+        const uint64_t cnt = (t + 1 < root_nodes.size() ? root_nodes[t + 1] : nodes.size()) - root_nodes[t];
+        region_base[t + 1] = region_base[t] + std::max<uint64_t>(8, (uint64_t)(cnt * region_factor) + 1);
+    }
+    const uint64_t slots = std::max<uint64_t>(region_base.back(), 8);
+    if (slots >= 0xFFFFFFF0ull) {
         error = "trie too large";
         return false;
     }
-    const uint32_t tmask = slots - 1;
     TrieSlot empty_slot{NONE, 0, 0, 0, 0, 0, NONE, 0};
     trie.assign(slots, empty_slot);
+    const uint32_t tslots = pow2_at_least((uint64_t)root_nodes.size() * 2);
+    tenants.assign(tslots, TenantSlot{0, NONE, 0, 0});
     std::vector<uint32_t> slot_of(nodes.size());
-    for (size_t i = 0; i < nodes.size(); i++) {
-        const BuildNode& b = nodes[i];
-        const uint32_t pslot = b.parent == NONE ? ROOT_PARENT : slot_of[b.parent];
-        uint32_t s = edge_hash(pslot, b.token) & tmask;
-        while (trie[s].parent != NONE) s = (s + 1) & tmask;
-        TrieSlot& t = trie[s];
-        t.parent = pslot;
-        t.token = b.token;
-        if (b.own_group != NONE) {
-            t.own_begin = group_begin[b.own_group];
-            t.own_count = group_count[b.own_group];
+    for (size_t t = 0; t < root_nodes.size(); t++) {
+        const uint32_t base = (uint32_t)region_base[t], size = (uint32_t)(region_base[t + 1] - region_base[t]);
+        const size_t n_end = t + 1 < root_nodes.size() ? root_nodes[t + 1] : nodes.size();
+        for (size_t i = root_nodes[t]; i < n_end; i++) {
+            const BuildNode& b = nodes[i];
+            const uint32_t pslot = b.parent == NONE ? ROOT_PARENT : slot_of[b.parent];
+            uint32_t s = base + edge_home(pslot, b.token, size);
+            while (trie[s].parent != NONE) s = (s + 1 == base + size) ? base : s + 1;
+            TrieSlot& ts = trie[s];
+            ts.parent = pslot;
+            ts.token = b.token;
+            if (b.own_group != NONE) {
+                ts.own_begin = group_begin[b.own_group];
+                ts.own_count = group_count[b.own_group];
+            }
+            if (b.hash_group != NONE) {
+                ts.hash_begin = group_begin[b.hash_group];
+                ts.hash_count = group_count[b.hash_group];
+            }
+            slot_of[i] = s;
+            if (b.parent != NONE) {
+                TrieSlot& p = trie[pslot];
+                if (b.token == TOK_PLUS) p.plus_child = s;
+                else p.lit_bloom |= 1u << bloom_bit(b.token);
+            }
         }
-        if (b.hash_group != NONE) {
-            t.hash_begin = group_begin[b.hash_group];
-            t.hash_count = group_count[b.hash_group];
-        }
-        slot_of[i] = s;
-        if (b.parent != NONE) {
-            TrieSlot& p = trie[pslot];
-            if (b.token == TOK_PLUS) p.plus_child = s;
-            else p.lit_bloom |= 1u << bloom_bit(b.token);
-        }
+        const uint32_t ttok = nodes[root_nodes[t]].token;
+        uint32_t d = tenant_hash(ttok) & (tslots - 1);
+        while (tenants[d].token) d = (d + 1) & (tslots - 1);
+        tenants[d] = TenantSlot{ttok, slot_of[root_nodes[t]], base, size};
     }
 
     // ---- dictionary slots + pool -----------------------------------------------------------------------------------
@@ -496,7 +517,7 @@ bool DistIndexHost::build(const KeySet& ks) {
     while (pool.size() % 16 || pool.empty()) pool.push_back(0);
 
     n_routes = n;
-    n_tenants = tenants;
+    n_tenants = tenant_count;
     n_nodes = nodes.size();
     n_tokens = dict_h.entries.size();
     return true;
@@ -521,22 +542,31 @@ uint32_t DistIndexHost::find_token(std::string_view level) const {
     return TOK_UNKNOWN;
 }
 
-uint32_t DistIndexHost::find_child(uint32_t parent_slot, uint32_t token) const {
-    if (trie.empty()) return NONE;
-    const uint32_t mask = (uint32_t)trie.size() - 1;
-    uint32_t s = edge_hash(parent_slot, token) & mask;
+const TenantSlot* DistIndexHost::find_tenant(uint32_t token) const {
+    if (tenants.empty() || token == TOK_UNKNOWN) return nullptr;
+    const uint32_t mask = (uint32_t)tenants.size() - 1;
+    uint32_t d = tenant_hash(token) & mask;
+    while (tenants[d].token) {
+        if (tenants[d].token == token) return &tenants[d];
+        d = (d + 1) & mask;
+    }
+    return nullptr;
+}
+
+uint32_t DistIndexHost::find_child(const TenantSlot& r, uint32_t parent_slot, uint32_t token) const {
+    uint32_t s = r.base + edge_home(parent_slot, token, r.size);
     while (trie[s].parent != NONE) {
         if (trie[s].parent == parent_slot && trie[s].token == token) return s;
-        s = (s + 1) & mask;
+        s = (s + 1 == r.base + r.size) ? r.base : s + 1;
     }
     return NONE;
 }
 
 uint32_t DistIndexHost::find_filter_node(std::string_view tenant, std::string_view filter, bool& is_hash) const {
     is_hash = false;
-    const uint32_t tt = find_token(tenant);
-    if (tt == TOK_UNKNOWN) return NONE;
-    uint32_t node = find_child(ROOT_PARENT, tt);
+    const TenantSlot* r = find_tenant(find_token(tenant));
+    if (!r) return NONE;
+    uint32_t node = r->root;
     size_t s = 0;
     for (size_t i = 0; i <= filter.size() && node != NONE; i++)
         if (i == filter.size() || filter[i] == '/') {
@@ -548,7 +578,7 @@ uint32_t DistIndexHost::find_filter_node(std::string_view tenant, std::string_vi
             }
             const uint32_t tok = lv == "+" ? TOK_PLUS : find_token(lv);
             if (tok == TOK_UNKNOWN) return NONE;
-            node = find_child(node, tok);
+            node = find_child(*r, node, tok);
         }
     return node;
 }

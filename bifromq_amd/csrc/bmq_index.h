@@ -41,6 +41,7 @@ struct KeySet {
 // ---- flattened dist index (host copy of what is uploaded to HBM) -----------------------------------------------
 struct DistIndexHost {
     std::vector<TrieSlot> trie;
+    std::vector<TenantSlot> tenants;
     std::vector<DictSlot> dict;
     std::vector<uint8_t> pool;
     std::vector<uint32_t> route_pos;
@@ -52,7 +53,8 @@ struct DistIndexHost {
 
     // host-side exact helpers (inspection only -- never used for matching)
     uint32_t find_token(std::string_view level) const;                 // TOK_UNKNOWN if absent
-    uint32_t find_child(uint32_t parent_slot, uint32_t token) const;   // NONE if absent
+    const TenantSlot* find_tenant(uint32_t token) const;               // nullptr if absent
+    uint32_t find_child(const TenantSlot& region, uint32_t parent_slot, uint32_t token) const; // NONE if absent
     uint32_t find_filter_node(std::string_view tenant, std::string_view mqtt_filter, bool& is_hash) const;
 };
 

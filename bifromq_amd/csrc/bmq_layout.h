@@ -47,6 +47,17 @@ struct alignas(32) DictSlot {
 };
 static_assert(sizeof(DictSlot) == 32, "DictSlot must be 32 bytes");
 
+// Tenant directory: tenant token -> the tenant's root node and its private REGION of the slot table.  All nodes of a
+// tenant live in [base, base + size): a wave that works on one tenant's publishes touches only that region, which
+// for typical tenants (10^4 routes ~ 1.5 MiB) stays resident in the XCD's 4 MiB L2.
+struct alignas(16) TenantSlot {
+    uint32_t token; // dictionary token of the tenant id; 0 = empty slot
+    uint32_t root;  // slot index of the tenant's root node
+    uint32_t base;  // first slot of the region
+    uint32_t size;  // slots in the region (any value >= 1, not a power of two)
+};
+static_assert(sizeof(TenantSlot) == 16, "TenantSlot must be 16 bytes");
+
 // Incremental level hash: two 32-bit lanes (slot index, tag).  Same code on host and device.
 struct LevelHash {
     uint32_t h1, h2;
@@ -76,11 +87,20 @@ BMQ_HD uint32_t edge_hash(uint32_t parent, uint32_t token) {
     return x;
 }
 BMQ_HD uint32_t bloom_bit(uint32_t token) { return (token * 0x9E3779B1u) >> 27; }
+// home slot of edge (parent, token) inside a region of `size` slots (fastrange: no power-of-two needed)
+BMQ_HD uint32_t edge_home(uint32_t parent, uint32_t token, uint32_t size) {
+    return (uint32_t)(((uint64_t)edge_hash(parent, token) * size) >> 32);
+}
+BMQ_HD uint32_t tenant_hash(uint32_t token) {
+    uint32_t x = token * 0x9E3779B1u;
+    return x ^ (x >> 15);
+}
 
 // Everything a kernel needs to read the dist index.
 struct DistIndexView {
     const TrieSlot* trie;
-    uint32_t trie_mask;        // slots - 1
+    const TenantSlot* tenants;
+    uint32_t tenant_mask;      // tenant directory slots - 1
     const DictSlot* dict;
     uint32_t dict_mask;
     const uint8_t* pool;       // level strings longer than 16 bytes

@@ -60,10 +60,13 @@ class Workload:
     def tenant_first(self) -> np.ndarray:
         return _arr(_lib.gen().bmqgen_tenant_first(self.h), self.n_tenants + 1, np.uint32).copy()
 
-    def topics(self, seed: int, n_topics: int, tenant_lo: int = 0, tenant_hi: int = 2**32 - 1, hit_permille: int = 900):
-        """-> (topic bytes (padded), topic offsets, topic_tenant) as numpy COPIES"""
+    def topics(self, seed: int, n_topics: int, tenant_lo: int = 0, tenant_hi: int = 2**32 - 1, hit_permille: int = 900,
+               grouped: bool = False):
+        """-> (topic bytes (padded), topic offsets, topic_tenant) as numpy COPIES.  topic_tenant indexes THIS
+        workload's tenant table.  grouped: ordered by tenant, like the DistPacks of a BatchDistRequest."""
         G = _lib.gen()
-        n = G.bmqgen_topics(self.h, seed, n_topics, tenant_lo, min(tenant_hi, self.n_tenants), hit_permille)
+        n = G.bmqgen_topics(self.h, seed, n_topics, tenant_lo, min(tenant_hi, self.n_tenants), hit_permille,
+                            1 if grouped else 0)
         return self._out(n)
 
     def retain(self, seed: int, n: int, filters: bool):
