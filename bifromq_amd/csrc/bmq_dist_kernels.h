@@ -6,17 +6,21 @@
 // for the '$' rule, TRIE/NTopicFilterTrieNode.java:143-146 for '#' matching the parent level).
 //
 // Included only by bmq_engine.hip (hipcc --offload-arch=gfx950).  Work decomposition:
-//   k_resolve_tenants : one lane per distinct tenant of the batch -> root slot
-//   k_walk            : one wave per 64 topics.  Phase 1: every lane tokenises its own topic into LDS
-//                       (levels -> dictionary tokens, bytes verified).  Phase 2: the wave drains a shared LDS
-//                       work ring of (node, topic, level) items, one item per lane per round, one 32-byte
-//                       random HBM read per item; pushes and matches are compacted with ballot + mbcnt.
+//   k_resolve_tenants : one lane per distinct tenant of the batch -> region of the slot table
+//   k_walk            : one wave per 64 topics.
+//                       Phase 1: the wave stages its topics' bytes in LDS with coalesced 16-byte loads, then walks
+//                       them level by level: every lane scans its own next level (LDS only), then ALL lanes look
+//                       their level up in the dictionary together -- one memory latency per level, not per lane.
+//                       Phase 2: the wave drains a shared LDS work ring of (parent node, topic, level, kind) items,
+//                       one item per lane per round; an item reads one 64-byte bucket (literal child lookup, the
+//                       child's header comes with it) or one 32-byte slot ('+' child / tenant root by slot index).
+//                       Pushes and matches are compacted with ballot + mbcnt.
 //                       Phase 3: matched (begin,count) ranges are counting-sorted by topic and written out.
 //   k_walk_slow       : per-lane DFS with global scratch for topics the LDS path could not finish
-//                       (more than FAST_LEVELS levels, ring or range buffer overflow).
+//                       (more than FAST_LEVELS levels, ring overflow, too many range flushes).
 //   k_scan_blocks     : exclusive scan of the per-wave id counts.
 //   k_expand          : per topic, order its ranges by first id and stream the ids into the CSR output.
-//   k_sort_rows       : bitonic fix-up of the (rare) rows whose ranges interleave (SURVEY.md 8c quirk ii).
+//   k_sort_rows       : bitonic fix-up of rows whose range list was too long to order in k_expand.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,17 +30,20 @@ namespace bmq {
 
 // status bits raised by kernels, resolved by the host in bmq_match_finish()
 enum : uint32_t {
-    ST_NEED_PAIRS = 1u,    // matched-range buffer too small
-    ST_NEED_SLOW = 2u,     // slow-topic list too small
-    ST_NEED_SCRATCH = 4u,  // slow-path scratch too small
-    ST_NOSPACE = 8u,       // caller's id buffer too small
-    ST_RANGE = 16u,        // >= 2^32 ids
-    ST_NEED_SORTLIST = 32u // fix-up list too small
+    ST_NEED_PAIRS = 1u,     // matched-range buffer too small
+    ST_NEED_SLOW = 2u,      // slow-topic list too small
+    ST_NEED_SCRATCH = 4u,   // slow-path scratch too small
+    ST_NOSPACE = 8u,        // caller's id buffer too small
+    ST_RANGE = 16u,         // >= 2^32 ids
+    ST_NEED_SORTLIST = 32u, // fix-up list too small
+    ST_NEED_SPILL = 64u     // range spill buffer too small
 };
+constexpr uint32_t ST_RERUN = ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH | ST_NEED_SPILL;
 
 struct Counters { // one per batch, zeroed before launch
     unsigned long long pair_alloc;
     unsigned long long scratch_alloc; // in uint32 units
+    unsigned long long spill_alloc;   // in records
     unsigned long long n_visit;
     unsigned long long total_ids;
     unsigned long long n_ranges;
@@ -58,12 +65,14 @@ struct BatchArgs {
     const uint32_t* topic_off;
     uint32_t n_topics;
     // per-batch scratch (device)
-    TenantSlot* tenant_info; // [n_tenants] root/region of each batch tenant (root == NONE: unknown tenant)
-    uint32_t* pair_off;    // [n_topics]
-    uint32_t* pair_cnt;    // [n_topics]
-    uint32_t* route_cnt;   // [n_topics]
+    TenantSlot* tenant_info; // [n_tenants] region of each batch tenant (token == 0: unknown tenant)
+    uint32_t* pair_off;      // [n_topics]
+    uint32_t* pair_cnt;      // [n_topics]
+    uint32_t* route_cnt;     // [n_topics]
     MatchRange* pairs;
     unsigned long long pair_cap;
+    uint4* spill;            // LDS range buffer flushes: {begin, count, topic-local, 0}
+    unsigned long long spill_cap;
     unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block; scanned in place to exclusive bases
     uint32_t n_blocks;
     uint32_t* slow_list;
@@ -80,14 +89,13 @@ struct BatchArgs {
     unsigned long long* out_total;
     // LDS geometry
     uint32_t qcap; // pow2
-    uint32_t pcap;
-    uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising, 2 = no XCD swizzle
+    uint32_t pcap; // >= 128
+    uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising
 };
 
 // ------------------------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // number of set bits of `mask` strictly below this lane
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -108,96 +116,96 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-__device__ __forceinline__ TrieSlot load_slot(const TrieSlot* trie, uint32_t idx) {
-    const uint4* p = reinterpret_cast<const uint4*>(trie + idx);
-    const uint4 a = p[0], b = p[1];
+// ------------------------------------------------------------------------------------------------------------
+// trie access
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ TrieSlot unpack_slot(const uint4& a, const uint4& b) {
     TrieSlot s;
     s.parent = a.x; s.token = a.y; s.own_begin = a.z; s.own_count = a.w;
     s.hash_begin = b.x; s.hash_count = b.y; s.plus_child = b.z; s.lit_bloom = b.w;
     return s;
 }
-
-// (parent, token) -> child slot inside the tenant's region [base, base + size); NONE if absent.  On a hit `out`
-// holds the child's header.
-__device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_t base, uint32_t size, uint32_t parent,
+__device__ __forceinline__ TrieSlot load_slot(const TrieSlot* trie, uint32_t idx) {
+    const uint4* p = reinterpret_cast<const uint4*>(trie + idx);
+    const uint4 a = p[0], b = p[1];
+    return unpack_slot(a, b);
+}
+// (parent slot, token) -> child slot inside the tenant's region; NONE if absent.  Reads whole 64-byte buckets: the
+// home bucket answers unless it is full of other edges (rare at load factor 1/2).
+__device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_t base, uint32_t buckets, uint32_t parent,
                                                 uint32_t token, TrieSlot& out) {
-    const uint32_t end = base + size;
-    uint32_t s = base + edge_home(parent, token, size);
+    uint32_t bk = edge_bucket(parent, token, buckets);
     for (;;) {
-        const TrieSlot c = load_slot(ix.trie, s);
-        if (c.parent == parent && c.token == token) {
-            out = c;
-            return s;
+        const uint32_t s0 = base + 2 * bk;
+        const uint4* p = reinterpret_cast<const uint4*>(ix.trie + s0);
+        const uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+        if (a0.x == parent && a0.y == token) {
+            out = unpack_slot(a0, a1);
+            return s0;
         }
-        if (c.parent == NONE) return NONE;
-        s = (s + 1 == end) ? base : s + 1;
+        if (b0.x == parent && b0.y == token) {
+            out = unpack_slot(b0, b1);
+            return s0 + 1;
+        }
+        if (a0.x == NONE || b0.x == NONE) return NONE;
+        bk = (bk + 1 == buckets) ? 0 : bk + 1;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// tokeniser: bytes -> levels -> dictionary tokens (exact: tag + length + bytes compared)
+// dictionary lookup (exact: tag + length + bytes).  ONE latency: the whole 4-slot home group is requested together.
+// byte_at(i) returns byte i of the string buffer the level lives in (LDS-staged or global).
 // ------------------------------------------------------------------------------------------------------------
-struct ByteReader { // 8-byte chunked reads of a packed string buffer (base 8-byte aligned, padded to 8)
-    const uint8_t* base;
-    unsigned long long w;
-    uint32_t wbase;
-    __device__ __forceinline__ explicit ByteReader(const uint8_t* b) : base(b), w(0), wbase(0xFFFFFFFFu) {}
-    __device__ __forceinline__ uint32_t at(uint32_t i) {
-        const uint32_t a = i & ~7u;
-        if (a != wbase) {
-            w = *reinterpret_cast<const unsigned long long*>(base + a);
-            wbase = a;
-        }
-        return (uint32_t)(w >> ((i & 7u) * 8u)) & 0xFFu;
-    }
-};
-
+template <class ByteAt>
 __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const LevelHash& h, uint32_t len,
-                                                const uint32_t inl[4], ByteReader& rd, uint32_t start) {
+                                                const uint32_t inl[4], uint32_t start, ByteAt&& byte_at) {
     const uint32_t tag = level_hash_tag(h);
-    uint32_t s = level_hash_slot(h, len) & ix.dict_mask;
+    uint32_t g = level_hash_slot(h, len) & ix.dict_group_mask;
     for (;;) {
-        const uint4* p = reinterpret_cast<const uint4*>(ix.dict + s);
-        const uint4 a = p[0];
-        if (a.x == 0) return TOK_UNKNOWN;
-        if (a.x == tag && a.z == len) {
-            const uint4 b = p[1];
-            if (b.x == inl[0] && b.y == inl[1] && b.z == inl[2] && b.w == inl[3]) {
+        const uint4* p = reinterpret_cast<const uint4*>(ix.dict + 4 * (size_t)g);
+        uint4 hd[4], il[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            hd[j] = p[2 * j];
+            il[j] = p[2 * j + 1];
+        }
+        bool full = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (hd[j].x == 0) full = false;
+            else if (hd[j].x == tag && hd[j].z == len && il[j].x == inl[0] && il[j].y == inl[1] && il[j].z == inl[2] &&
+                     il[j].w == inl[3]) {
                 bool eq = true;
-                for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[a.w + i] == rd.at(start + i);
-                if (eq) return a.y;
+                for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[hd[j].w + i] == byte_at(start + i);
+                if (eq) return hd[j].y;
             }
         }
-        s = (s + 1) & ix.dict_mask;
+        if (!full) return TOK_UNKNOWN;
+        g = (g + 1) & ix.dict_group_mask;
     }
 }
 
-// Walks the bytes [beg,end) of one string.  split=true: levels separated by '/', empty levels kept
-// (UTIL/TopicUtil.java:206-225); split=false: the whole string is one level (tenant ids).
-// sink(level_index, token) is called for every level; returns the level count.
-template <class Sink>
-__device__ __forceinline__ uint32_t tokenise(const DistIndexView& ix, const uint8_t* base, uint32_t beg, uint32_t end,
-                                             bool split, uint32_t max_store, Sink&& sink) {
-    ByteReader rd(base);
-    LevelHash h = level_hash_init();
-    uint32_t inl[4] = {0, 0, 0, 0};
-    uint32_t len = 0, start = beg, level = 0;
-    for (uint32_t i = beg; i <= end; i++) {
-        const uint32_t c = (i < end) ? rd.at(i) : 0x100u;
-        if (c == 0x100u || (split && c == '/')) {
-            if (level < max_store) sink(level, dict_lookup(ix, h, len, inl, rd, start));
-            level++;
-            h = level_hash_init();
-            inl[0] = inl[1] = inl[2] = inl[3] = 0;
-            len = 0;
-            start = i + 1;
-        } else {
-            level_hash_step(h, c);
-            if (len < 16) inl[len >> 2] |= c << ((len & 3u) * 8u);
-            len++;
-        }
+// scans one level starting at pos: bytes up to the next '/' (split) or to `end`.  Returns through refs.
+template <class ByteAt>
+__device__ __forceinline__ void scan_level(uint32_t& pos, uint32_t end, bool split, ByteAt&& byte_at, LevelHash& h,
+                                           uint32_t inl[4], uint32_t& len, bool& last) {
+    h = level_hash_init();
+    inl[0] = inl[1] = inl[2] = inl[3] = 0;
+    len = 0;
+    while (pos < end) {
+        const uint32_t c = byte_at(pos);
+        if (split && c == '/') break;
+        level_hash_step(h, c);
+        if (len < 16) inl[len >> 2] |= c << ((len & 3u) * 8u);
+        len++;
+        pos++;
     }
-    return level;
+    if (pos < end) {
+        pos++; // skip the '/': another (possibly empty) level follows (UTIL/TopicUtil.java:206-225)
+        last = false;
+    } else {
+        last = true;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -206,9 +214,16 @@ __device__ __forceinline__ uint32_t tokenise(const DistIndexView& ix, const uint
 __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a.n_tenants) return;
-    uint32_t tok = TOK_UNKNOWN;
-    tokenise(a.ix, a.tenants, a.tenant_off[i], a.tenant_off[i + 1], false, 1, [&](uint32_t, uint32_t t) { tok = t; });
-    TenantSlot info{tok, NONE, 0, 1};
+    const uint8_t* base = a.tenants;
+    auto byte_at = [&](uint32_t k) -> uint32_t { return base[k]; };
+    uint32_t pos = a.tenant_off[i];
+    const uint32_t start = pos, end = a.tenant_off[i + 1];
+    LevelHash h;
+    uint32_t inl[4], len;
+    bool last;
+    scan_level(pos, end, false, byte_at, h, inl, len, last);
+    const uint32_t tok = dict_lookup(a.ix, h, len, inl, start, byte_at);
+    TenantSlot info{0, 0, 0, 1};
     if (tok != TOK_UNKNOWN) {
         uint32_t d = tenant_hash(tok) & a.ix.tenant_mask;
         for (;;) {
@@ -227,40 +242,40 @@ __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // the per-item step shared by the LDS path and the slow path
 // ------------------------------------------------------------------------------------------------------------
-// item meta: bits 0-5 topic-local index, bits 6-21 level, bit 31 kind (0 = L: probe literal child of `node` with
-// the topic's token at `level`; 1 = H: `node` is already the discovered slot, arrived after `level` tokens)
+// item = (node slot, meta); meta: bits 0-5 topic-local index, bits 6-29 level, bit 31 kind
+//   kind L (0): probe the literal child of `node` with the topic's token at `level`
+//   kind H (1): `node` is itself the slot to visit ('+' child or tenant root), reached after `level` tokens
 constexpr uint32_t KIND_H = 0x80000000u;
 __device__ __forceinline__ uint32_t make_meta(uint32_t tl, uint32_t level, uint32_t kind) { return tl | (level << 6) | kind; }
+__device__ __forceinline__ uint32_t meta_level(uint32_t m) { return (m >> 6) & 0xFFFFFFu; }
 
 struct StepOut {
-    bool found;       // a node was discovered
-    uint32_t idx;     // its slot
-    uint32_t dl;      // levels consumed on arrival
+    bool found;      // a node was discovered
     bool emit_own, emit_hash, push_l, push_h;
+    uint32_t idx;    // its slot
+    uint32_t dl;     // levels consumed on arrival
     TrieSlot s;
 };
 
-// tok_at(level) returns the topic's token at that level; nlev = level count; sys = first level starts with '$'
+// tok_at(level): the topic's token at that level; nlev: level count; sys: first level starts with '$'
 template <class TokAt>
-__device__ __forceinline__ void step_item(const DistIndexView& ix, uint32_t rbase, uint32_t rsize, uint32_t node,
-                                          uint32_t level, bool kind_h, uint32_t nlev, bool sys, TokAt&& tok_at,
-                                          StepOut& o) {
-    o.found = false;
-    o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
+__device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantSlot& rg, uint32_t node, uint32_t level,
+                                          bool kind_h, uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
+    o.found = o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
     if (kind_h) {
         o.s = load_slot(ix.trie, node);
         o.idx = node;
         o.dl = level;
         o.found = true;
     } else {
-        o.idx = probe_child(ix, rbase, rsize, node, tok_at(level), o.s);
+        o.idx = probe_child(ix, rg.base, rg.buckets, node, tok_at(level), o.s);
         o.dl = level + 1;
         o.found = o.idx != NONE;
     }
     if (!o.found) return;
     const bool root_sys = (o.dl == 0) && sys; // wildcards in filter position 0 never match a '$' topic
     o.emit_own = (o.dl == nlev) && o.s.own_count != 0;
-    o.emit_hash = o.s.hash_count != 0 && !root_sys;
+    o.emit_hash = o.s.hash_count != 0 && !root_sys; // "<path>/#" matches whatever follows, also nothing
     if (o.dl < nlev) {
         const uint32_t t = tok_at(o.dl);
         o.push_l = t != TOK_UNKNOWN && ((o.s.lit_bloom >> bloom_bit(t)) & 1u);
@@ -271,73 +286,126 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, uint32_t rbas
 // ------------------------------------------------------------------------------------------------------------
 // k_walk -- one wave (= one 64-thread workgroup) per 64 topics
 // ------------------------------------------------------------------------------------------------------------
-// tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (overflow -> slow path), 10 active
+// tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (-> slow path), 10 active
 constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9, TM_ACTIVE = 1u << 10;
+constexpr uint32_t MAX_FLUSH = 16; // range-buffer flushes per wave before topics are sent to the slow path
+
+__host__ __device__ inline size_t walk_union_words(uint32_t qcap, uint32_t pcap) { return 2 * (size_t)qcap + 3 * (size_t)pcap; }
+inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
+    return sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 7 * 64 + 2 * MAX_FLUSH + walk_union_words(qcap, pcap));
+}
 
 __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     extern __shared__ __align__(16) uint32_t lds[];
-    uint32_t* tokens = lds;                         // [FAST_LEVELS][64]
-    uint32_t* tmeta = tokens + FAST_LEVELS * 64;    // [64]
-    uint32_t* cnt_pairs = tmeta + 64;               // [64]
-    uint32_t* cnt_routes = cnt_pairs + 64;          // [64]
-    uint32_t* cnt_visit = cnt_routes + 64;          // [64]
-    uint32_t* cursor = cnt_visit + 64;              // [64]
-    uint32_t* t_base = cursor + 64;                 // [64] tenant region of each topic
-    uint32_t* t_size = t_base + 64;                 // [64]
-    uint32_t* q_node = t_size + 64;                 // [qcap]
-    uint32_t* q_meta = q_node + a.qcap;             // [qcap]
-    uint32_t* p_begin = q_meta + a.qcap;            // [pcap]
-    uint32_t* p_count = p_begin + a.pcap;           // [pcap]
-    uint32_t* p_topic = p_count + a.pcap;           // [pcap]
+    uint32_t* un = lds;                                       // union: staged topic bytes | work ring + range buffer
+    uint32_t* q_node = un;                                    // [qcap]
+    uint32_t* q_meta = q_node + a.qcap;                       // [qcap]
+    uint32_t* p_begin = q_meta + a.qcap;                      // [pcap]
+    uint32_t* p_count = p_begin + a.pcap;                     // [pcap]
+    uint32_t* p_topic = p_count + a.pcap;                     // [pcap]
+    uint32_t* tokens = un + walk_union_words(a.qcap, a.pcap); // [FAST_LEVELS][64]
+    uint32_t* tmeta = tokens + FAST_LEVELS * 64;              // [64]
+    uint32_t* cnt_pairs = tmeta + 64;                         // [64]
+    uint32_t* cnt_routes = cnt_pairs + 64;                    // [64]
+    uint32_t* cnt_visit = cnt_routes + 64;                    // [64]
+    uint32_t* cursor = cnt_visit + 64;                        // [64]
+    uint32_t* t_base = cursor + 64;                           // [64] tenant region of each topic
+    uint32_t* t_nb = t_base + 64;                             // [64]
+    uint32_t* f_base = t_nb + 64;                             // [MAX_FLUSH] spill record offset of each flush
+    uint32_t* f_len = f_base + MAX_FLUSH;                     // [MAX_FLUSH]
 
     const uint32_t lane = threadIdx.x;
-    // XCD-aware block order: the dispatcher places workgroup b on XCD b % 8 (speed only, never correctness); give every
-    // XCD one contiguous run of topic blocks so that its private L2 caches the regions of "its" tenants only.
-    const uint32_t nb = gridDim.x, per_xcd = (nb + 7) / 8;
-    uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3); // host launches a multiple of 8 blocks
-    if (a.debug_flags & 2u) blk = blockIdx.x;
+    const uint32_t blk = blockIdx.x;
     const uint32_t t = blk * 64 + lane;
     const bool valid = t < a.n_topics;
     const uint32_t qm = a.qcap - 1;
 
-    // ---- phase 1: tokenise own topic ------------------------------------------------------------------------------
-    uint32_t nlev = 0, root = NONE, tbytes = 0;
-    bool sys = false, deep = false;
+    // ---- phase 1: tokenise ---------------------------------------------------------------------------------------------
+    const uint32_t t_first = blk * 64, t_end = min(t_first + 64, a.n_topics);
+    const uint32_t s_beg = a.topic_off[t_first], s_end = a.topic_off[t_end]; // wave-uniform
+    const uint32_t a0 = s_beg & ~15u;
+    const bool staged = (s_end - a0) <= (uint32_t)(walk_union_words(a.qcap, a.pcap) * 4);
+    if (staged) { // coalesced 16-byte copies of the wave's contiguous topic bytes into LDS
+        uint4* dst = reinterpret_cast<uint4*>(un);
+        const uint4* src = reinterpret_cast<const uint4*>(a.topics + a0);
+        const uint32_t n16 = (s_end - a0 + 15) >> 4;
+        for (uint32_t o = lane; o < n16; o += 64) dst[o] = src[o];
+    }
+    __syncthreads();
+    const uint8_t* lbytes = reinterpret_cast<const uint8_t*>(un);
+    const uint8_t* gbytes = a.topics;
+    auto byte_at = [&](uint32_t i) -> uint32_t { return staged ? (uint32_t)lbytes[i - a0] : (uint32_t)gbytes[i]; };
+
+    uint32_t nlev = 0, tbytes = 0, pos = 0, end = 0;
+    bool sys = false, more = false;
+    TenantSlot rg{0, 0, 0, 1};
     if (valid) {
-        const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
-        tbytes = end - beg;
+        pos = a.topic_off[t];
+        end = a.topic_off[t + 1];
+        tbytes = end - pos;
         const uint32_t ti = a.topic_tenant[t];
-        TenantSlot info{0, NONE, 0, 1};
-        if (ti < a.n_tenants) info = a.tenant_info[ti];
-        root = info.root;
-        t_base[lane] = info.base;
-        t_size[lane] = info.size;
-        if (root != NONE) { // unknown tenant: no routes, nothing to tokenise
-            nlev = tokenise(a.ix, a.topics, beg, end, true, FAST_LEVELS,
-                            [&](uint32_t l, uint32_t tok) { tokens[l * 64 + lane] = tok; });
-            sys = end > beg && a.topics[beg] == '$';
-            deep = nlev > FAST_LEVELS;
+        if (ti < a.n_tenants) rg = a.tenant_info[ti];
+        more = rg.token != TOK_UNKNOWN; // unknown tenant: no routes, nothing to tokenise
+        sys = more && end > pos && byte_at(pos) == '$';
+    }
+    for (uint32_t l = 0; __any(more); l++) {
+        LevelHash h;
+        uint32_t inl[4], len = 0;
+        const uint32_t start = pos;
+        if (more) {
+            bool last;
+            scan_level(pos, end, true, byte_at, h, inl, len, last);
+            nlev++;
+            if (l < FAST_LEVELS) tokens[l * 64 + lane] = dict_lookup(a.ix, h, len, inl, start, byte_at);
+            more = !last;
         }
     }
-    const bool active = valid && root != NONE && !deep;
+    const bool known = valid && rg.token != TOK_UNKNOWN;
+    const bool deep = nlev > FAST_LEVELS;
+    const bool active = known && !deep;
+    __syncthreads(); // staged bytes are dead from here on: the union becomes ring + range buffer
     tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u) | (active ? TM_ACTIVE : 0u);
     cnt_pairs[lane] = 0;
     cnt_routes[lane] = 0;
     cnt_visit[lane] = 0;
+    t_base[lane] = rg.base;
+    t_nb[lane] = rg.buckets;
 
     // ---- phase 2: drain the work ring -----------------------------------------------------------------------------
-    uint32_t head = 0, tail = 0, pcount = 0;
+    uint32_t head = 0, tail = 0, pcount = 0, nflush = 0;
     {
-        const unsigned long long m = __ballot(active && !(a.debug_flags & 1u));
-        if (active && !(a.debug_flags & 1u)) {
-            const uint32_t pos = rank_below(m);
-            q_node[pos & qm] = root;
-            q_meta[pos & qm] = make_meta(lane, 0, KIND_H);
+        const bool go = active && !(a.debug_flags & 1u);
+        const unsigned long long m = __ballot(go);
+        if (go) {
+            const uint32_t p = rank_below(m);
+            q_node[p & qm] = rg.root;
+            q_meta[p & qm] = make_meta(lane, 0, KIND_H);
         }
         tail = (uint32_t)__popcll(m);
     }
     __syncthreads();
     while (head != tail) {
+        // make room for this round's matches (at most two per lane): flush the LDS range buffer to the spill area
+        if (pcount + 128 > a.pcap) {
+            unsigned long long sb = 0;
+            if (lane == 0) sb = atomicAdd(&a.ctr->spill_alloc, (unsigned long long)pcount);
+            sb = __shfl(sb, 0);
+            const bool fits = sb + pcount <= a.spill_cap && sb + pcount < 0xFFFFFFFFull;
+            if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_SPILL);
+            if (nflush < MAX_FLUSH) {
+                if (fits)
+                    for (uint32_t i = lane; i < pcount; i += 64) a.spill[sb + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
+                if (lane == 0) {
+                    f_base[nflush] = (uint32_t)sb;
+                    f_len[nflush] = fits ? pcount : 0u;
+                }
+                nflush++;
+            } else { // out of flush slots: the topics owning the buffered ranges go to the slow path
+                for (uint32_t i = lane; i < pcount; i += 64) atomicOr(&tmeta[p_topic[i]], TM_FLAG);
+            }
+            pcount = 0;
+            __syncthreads();
+        }
         const uint32_t n = tail - head;
         const uint32_t take = n < 64 ? n : 64;
         const bool act = lane < take;
@@ -347,14 +415,17 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
             meta = q_meta[(head + lane) & qm];
         }
         head += take;
-        const uint32_t tl = meta & 63u, level = (meta >> 6) & 0xFFFFu;
+        const uint32_t tl = meta & 63u;
         StepOut o;
         o.found = o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
+        o.dl = 0;
         if (act) {
             const uint32_t tm = tmeta[tl];
-            if (!(tm & TM_FLAG))
-                step_item(a.ix, t_base[tl], t_size[tl], node, level, (meta & KIND_H) != 0, tm & 0xFFu, (tm & TM_SYS) != 0,
+            if (!(tm & TM_FLAG)) {
+                const TenantSlot r{0, 0, t_base[tl], t_nb[tl]};
+                step_item(a.ix, r, node, meta_level(meta), (meta & KIND_H) != 0, tm & 0xFFu, (tm & TM_SYS) != 0,
                           [&](uint32_t l) { return tokens[l * 64 + tl]; }, o);
+            }
         }
         if (o.found && o.dl) atomicAdd(&cnt_visit[tl], 1u); // per topic: a flagged topic is recounted by the slow path
         // matched ranges -> LDS buffer
@@ -362,20 +433,20 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
         if (m1 | m2) {
             const uint32_t c1 = (uint32_t)__popcll(m1);
             if (o.emit_own) {
-                const uint32_t pos = pcount + rank_below(m1);
-                if (pos < a.pcap) {
-                    p_begin[pos] = o.s.own_begin; p_count[pos] = o.s.own_count; p_topic[pos] = tl;
-                    atomicAdd(&cnt_pairs[tl], 1u);
-                    atomicAdd(&cnt_routes[tl], o.s.own_count);
-                } else atomicOr(&tmeta[tl], TM_FLAG);
+                const uint32_t p = pcount + rank_below(m1);
+                p_begin[p] = o.s.own_begin;
+                p_count[p] = o.s.own_count;
+                p_topic[p] = tl;
+                atomicAdd(&cnt_pairs[tl], 1u);
+                atomicAdd(&cnt_routes[tl], o.s.own_count & ~RANGE_INDIRECT);
             }
             if (o.emit_hash) {
-                const uint32_t pos = pcount + c1 + rank_below(m2);
-                if (pos < a.pcap) {
-                    p_begin[pos] = o.s.hash_begin; p_count[pos] = o.s.hash_count; p_topic[pos] = tl;
-                    atomicAdd(&cnt_pairs[tl], 1u);
-                    atomicAdd(&cnt_routes[tl], o.s.hash_count);
-                } else atomicOr(&tmeta[tl], TM_FLAG);
+                const uint32_t p = pcount + c1 + rank_below(m2);
+                p_begin[p] = o.s.hash_begin;
+                p_count[p] = o.s.hash_count;
+                p_topic[p] = tl;
+                atomicAdd(&cnt_pairs[tl], 1u);
+                atomicAdd(&cnt_routes[tl], o.s.hash_count & ~RANGE_INDIRECT);
             }
             pcount += c1 + (uint32_t)__popcll(m2);
         }
@@ -384,17 +455,17 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
         if (ml | mh) {
             const uint32_t cl = (uint32_t)__popcll(ml);
             if (o.push_l) {
-                const uint32_t pos = tail + rank_below(ml);
-                if (pos - head < a.qcap) {
-                    q_node[pos & qm] = o.idx;
-                    q_meta[pos & qm] = make_meta(tl, o.dl, 0);
+                const uint32_t p = tail + rank_below(ml);
+                if (p - head < a.qcap) {
+                    q_node[p & qm] = o.idx;
+                    q_meta[p & qm] = make_meta(tl, o.dl, 0);
                 } else atomicOr(&tmeta[tl], TM_FLAG);
             }
             if (o.push_h) {
-                const uint32_t pos = tail + cl + rank_below(mh);
-                if (pos - head < a.qcap) {
-                    q_node[pos & qm] = o.s.plus_child;
-                    q_meta[pos & qm] = make_meta(tl, o.dl + 1, KIND_H);
+                const uint32_t p = tail + cl + rank_below(mh);
+                if (p - head < a.qcap) {
+                    q_node[p & qm] = o.s.plus_child;
+                    q_meta[p & qm] = make_meta(tl, o.dl + 1, KIND_H);
                 } else atomicOr(&tmeta[tl], TM_FLAG);
             }
             uint32_t nt = tail + cl + (uint32_t)__popcll(mh);
@@ -419,9 +490,17 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_PAIRS);
     cursor[lane] = excl;
     __syncthreads();
-    if (fits) {
-        const uint32_t stored = pcount < a.pcap ? pcount : a.pcap;
-        for (uint32_t i = lane; i < stored; i += 64) {
+    if (fits && total_pairs) {
+        for (uint32_t f = 0; f < nflush; f++) { // flushed chunks first (they are L2-hot), then what is still in LDS
+            const uint32_t fb = f_base[f], fl = f_len[f];
+            for (uint32_t i = lane; i < fl; i += 64) {
+                const uint4 r = a.spill[fb + i];
+                if (tmeta[r.z] & TM_FLAG) continue;
+                const uint32_t dst = atomicAdd(&cursor[r.z], 1u);
+                a.pairs[base + dst] = MatchRange{r.x, r.y};
+            }
+        }
+        for (uint32_t i = lane; i < pcount; i += 64) {
             const uint32_t tl = p_topic[i];
             if (tmeta[tl] & TM_FLAG) continue;
             const uint32_t dst = atomicAdd(&cursor[tl], 1u);
@@ -442,7 +521,7 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     const unsigned long long wvis = wave_sum_u64(visits);
     const unsigned long long wbytes = wave_sum_u64(tbytes);
     if (lane == 0) {
-        if (blk < a.n_blocks) a.wave_sums[blk] = wsum;
+        a.wave_sums[blk] = wsum;
         if (wvis) atomicAdd(&a.ctr->n_visit, wvis);
         if (total_pairs) atomicAdd(&a.ctr->n_ranges, (unsigned long long)total_pairs);
         atomicAdd(&a.ctr->topic_bytes, wbytes);
@@ -454,21 +533,20 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
     const uint32_t n_slow = a.ctr->slow_count < a.slow_cap ? a.ctr->slow_count : a.slow_cap;
+    const uint8_t* gbytes = a.topics;
+    auto byte_at = [&](uint32_t i) -> uint32_t { return gbytes[i]; };
     for (uint32_t i = blockIdx.x * 64 + threadIdx.x; i < n_slow; i += gridDim.x * 64) {
         const uint32_t t = a.slow_list[i];
         const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
         const uint32_t ti = a.topic_tenant[t];
         if (ti >= a.n_tenants) continue;
-        const TenantSlot info = a.tenant_info[ti];
-        const uint32_t root = info.root;
-        if (root == NONE) continue;
-        // level count first (cheap scan), then scratch: nlev tokens + (nlev + 2) stack entries of 2 words
+        const TenantSlot rg = a.tenant_info[ti];
+        if (rg.token == TOK_UNKNOWN) continue;
+        // level count first (cheap scan), then scratch: nlev tokens + stack of 2-word entries.  A DFS pop pushes at most
+        // two items one level deeper: <= 1 pending sibling per level + 2.
         uint32_t nlev = 1;
-        {
-            ByteReader rd(a.topics);
-            for (uint32_t j = beg; j < end; j++) nlev += rd.at(j) == '/';
-        }
-        const unsigned long long need = (unsigned long long)nlev + 2ull * (nlev + 2);
+        for (uint32_t j = beg; j < end; j++) nlev += byte_at(j) == '/';
+        const unsigned long long need = (unsigned long long)nlev + 2ull * (2ull * nlev + 8);
         const unsigned long long so = atomicAdd(&a.ctr->scratch_alloc, need);
         if (so + need > a.scratch_cap) {
             atomicOr(&a.ctr->status, ST_NEED_SCRATCH);
@@ -476,41 +554,52 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         }
         uint32_t* toks = a.scratch + so;
         uint32_t* stack = toks + nlev;
-        tokenise(a.ix, a.topics, beg, end, true, nlev, [&](uint32_t l, uint32_t tok) { toks[l] = tok; });
-        const bool sys = end > beg && a.topics[beg] == '$';
+        {
+            uint32_t pos = beg;
+            for (uint32_t l = 0; l < nlev; l++) {
+                LevelHash h;
+                uint32_t inl[4], len;
+                bool last;
+                const uint32_t start = pos;
+                scan_level(pos, end, true, byte_at, h, inl, len, last);
+                toks[l] = dict_lookup(a.ix, h, len, inl, start, byte_at);
+            }
+        }
+        const bool sys = end > beg && byte_at(beg) == '$';
         unsigned long long base = 0;
         uint32_t np = 0, nr = 0, visits = 0;
         bool ok = true;
         for (int pass = 0; pass < 2 && ok; pass++) {
-            uint32_t sp = 0, wp = 0;
-            stack[0] = root;
+            uint32_t sp = 1, wp = 0;
+            stack[0] = rg.root;
             stack[1] = make_meta(0, 0, KIND_H);
-            sp = 1;
             while (sp) {
                 sp--;
                 const uint32_t node = stack[2 * sp], meta = stack[2 * sp + 1];
-                const uint32_t level = (meta >> 6) & 0x1FFFFFFu;
                 StepOut o;
-                step_item(a.ix, info.base, info.size, node, level, (meta & KIND_H) != 0, nlev, sys,
-                          [&](uint32_t l) { return toks[l]; }, o);
+                step_item(a.ix, rg, node, meta_level(meta), (meta & KIND_H) != 0, nlev, sys, [&](uint32_t l) { return toks[l]; }, o);
                 if (!o.found) continue;
                 if (pass == 0 && o.dl) visits++;
                 if (o.emit_own) {
-                    if (pass == 0) { np++; nr += o.s.own_count; }
-                    else a.pairs[base + wp++] = MatchRange{o.s.own_begin, o.s.own_count};
+                    if (pass == 0) {
+                        np++;
+                        nr += o.s.own_count & ~RANGE_INDIRECT;
+                    } else a.pairs[base + wp++] = MatchRange{o.s.own_begin, o.s.own_count};
                 }
                 if (o.emit_hash) {
-                    if (pass == 0) { np++; nr += o.s.hash_count; }
-                    else a.pairs[base + wp++] = MatchRange{o.s.hash_begin, o.s.hash_count};
+                    if (pass == 0) {
+                        np++;
+                        nr += o.s.hash_count & ~RANGE_INDIRECT;
+                    } else a.pairs[base + wp++] = MatchRange{o.s.hash_begin, o.s.hash_count};
                 }
                 if (o.push_l) {
                     stack[2 * sp] = o.idx;
-                    stack[2 * sp + 1] = o.dl << 6;
+                    stack[2 * sp + 1] = make_meta(0, o.dl, 0);
                     sp++;
                 }
                 if (o.push_h) {
                     stack[2 * sp] = o.s.plus_child;
-                    stack[2 * sp + 1] = ((o.dl + 1) << 6) | KIND_H;
+                    stack[2 * sp + 1] = make_meta(0, o.dl + 1, KIND_H);
                     sp++;
                 }
             }
@@ -539,7 +628,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
     __shared__ unsigned long long part[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (a.n_blocks + 1023) / 1024;
-    const uint32_t b0 = tid * per, b1 = min(b0 + per, a.n_blocks);
+    const uint32_t b0 = min(tid * per, a.n_blocks), b1 = min(b0 + per, a.n_blocks);
     unsigned long long s = 0;
     for (uint32_t i = b0; i < b1; i++) s += a.wave_sums[i];
     part[tid] = s;
@@ -572,6 +661,13 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
 constexpr uint32_t SMALL_ROW = 16;   // rows up to this many ids are copied by their own lane
 constexpr uint32_t SORT_PAIRS = 32;  // range lists up to this length are ordered in place (insertion sort)
 
+__device__ __forceinline__ uint32_t range_first_id(const DistIndexView& ix, const MatchRange& r) {
+    return (r.count & RANGE_INDIRECT) ? ix.route_pos[r.begin] : r.begin;
+}
+__device__ __forceinline__ uint32_t range_id(const DistIndexView& ix, const MatchRange& r, uint32_t j) {
+    return (r.count & RANGE_INDIRECT) ? ix.route_pos[r.begin + j] : r.begin + j;
+}
+
 __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t t = blockIdx.x * 64 + lane;
@@ -581,7 +677,7 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
     uint32_t wtotal;
     const uint32_t excl = wave_excl_scan(nr, lane, wtotal);
     const unsigned long long row = a.wave_sums[blockIdx.x] + excl;
-    const bool writable = !(status & (ST_NOSPACE | ST_RANGE | ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH));
+    const bool writable = !(status & (ST_NOSPACE | ST_RANGE | ST_RERUN));
     if (valid && !(status & ST_RANGE)) {
         a.out_row_ptr[t] = (uint32_t)row;
         if (t == a.n_topics - 1) a.out_row_ptr[a.n_topics] = (uint32_t)(row + nr);
@@ -589,19 +685,21 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
     if (!writable) return;
     const uint32_t po = valid ? a.pair_off[t] : 0u;
     const uint32_t np = valid ? a.pair_cnt[t] : 0u;
-    // order this topic's ranges by first id (positions in route_pos are ordered by first id)
+    // order this topic's ranges by first id
     if (np > 1 && np <= SORT_PAIRS) {
         MatchRange* pr = a.pairs + po;
         for (uint32_t i = 1; i < np; i++) {
             const MatchRange x = pr[i];
+            const uint32_t kx = range_first_id(a.ix, x);
             uint32_t j = i;
-            while (j > 0 && pr[j - 1].begin > x.begin) {
+            while (j > 0 && range_first_id(a.ix, pr[j - 1]) > kx) {
                 pr[j] = pr[j - 1];
                 j--;
             }
             pr[j] = x;
         }
     }
+    __syncthreads(); // other lanes read this lane's ordered ranges below
     bool unsorted = np > SORT_PAIRS;
     uint32_t* out = a.out_ids + row;
     // small rows: own lane
@@ -609,8 +707,9 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
         uint32_t k = 0, prev = 0;
         for (uint32_t p = 0; p < np; p++) {
             const MatchRange r = a.pairs[po + p];
-            for (uint32_t j = 0; j < r.count; j++) {
-                const uint32_t id = a.ix.route_pos[r.begin + j];
+            const uint32_t c = r.count & ~RANGE_INDIRECT;
+            for (uint32_t j = 0; j < c; j++) {
+                const uint32_t id = range_id(a.ix, r, j);
                 if (k && id <= prev) unsorted = true;
                 prev = id;
                 out[k++] = id;
@@ -629,22 +728,23 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
         bool bad = false;
         for (uint32_t p = 0; p < b_np; p++) {
             const MatchRange r = a.pairs[b_po + p];
-            for (uint32_t j0 = 0; j0 < r.count; j0 += 64) {
+            const uint32_t c = r.count & ~RANGE_INDIRECT;
+            for (uint32_t j0 = 0; j0 < c; j0 += 64) {
                 const uint32_t j = j0 + lane;
                 uint32_t id = 0;
-                const bool in = j < r.count;
+                const bool in = j < c;
                 if (in) {
-                    id = a.ix.route_pos[r.begin + j];
+                    id = range_id(a.ix, r, j);
                     bout[done + j] = id;
                 }
                 // order check: against the left neighbour, lane 0 against the last id of the previous chunk
                 uint32_t left = __shfl_up(id, 1);
                 if (lane == 0) left = last;
                 if (in && (done + j) > 0 && id <= left) bad = true;
-                const uint32_t cnt = min(64u, r.count - j0);
+                const uint32_t cnt = min(64u, c - j0);
                 last = __shfl(id, cnt - 1);
             }
-            done += r.count;
+            done += c;
         }
         if (__ballot(bad) && (int)lane == src) unsorted = true;
     }
@@ -660,7 +760,7 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
     const uint32_t n_rows = a.ctr->sort_count < a.sort_cap ? a.ctr->sort_count : a.sort_cap;
-    if (a.ctr->status & (ST_NOSPACE | ST_RANGE | ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH)) return;
+    if (a.ctr->status & (ST_NOSPACE | ST_RANGE | ST_RERUN)) return;
     for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
         const uint32_t t = a.sort_list[r];
         const uint32_t lo = a.out_row_ptr[t], n = a.out_row_ptr[t + 1] - lo;
@@ -683,10 +783,6 @@ __global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
             }
         }
     }
-}
-
-inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
-    return sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 7 * 64 + 2 * (size_t)qcap + 3 * (size_t)pcap);
 }
 
 } // namespace bmq

@@ -82,9 +82,9 @@ struct bmq_engine {
     bool built = false;
 
     // per-batch scratch
-    DevBuf b_tenant_root, b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_wave_sums, b_slow_list, b_scratch, b_sort_list,
-        b_ctr, b_total;
-    uint64_t pair_cap = 0, scratch_cap = 0;
+    DevBuf b_tenant_root, b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch,
+        b_sort_list, b_ctr, b_total;
+    uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
     uint32_t slow_cap = 0, sort_cap = 0;
     Counters* h_ctr = nullptr; // pinned
     // staging for the host-buffer API
@@ -142,7 +142,7 @@ int upload_dist(bmq_engine* e) {
     d->view.tenants = d->tenants.as<TenantSlot>();
     d->view.tenant_mask = (uint32_t)h.tenants.size() - 1;
     d->view.dict = d->dict.as<DictSlot>();
-    d->view.dict_mask = (uint32_t)h.dict.size() - 1;
+    d->view.dict_group_mask = (uint32_t)h.dict.size() / 4 - 1;
     d->view.pool = d->pool.as<uint8_t>();
     d->view.route_pos = d->route_pos.as<uint32_t>();
     d->bytes = d->trie.cap + d->tenants.cap + d->dict.cap + d->pool.cap + d->route_pos.cap;
@@ -175,6 +175,9 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     HIPCHK(e, e->b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->b_pairs.ensure(sizeof(MatchRange) * e->pair_cap));
+    if (e->spill_cap == 0) e->spill_cap = 1u << 16;
+    e->spill_cap = std::max<uint64_t>(e->spill_cap, (uint64_t)n_topics * 2);
+    HIPCHK(e, e->b_spill.ensure(sizeof(uint4) * e->spill_cap));
     HIPCHK(e, e->b_wave_sums.ensure(sizeof(unsigned long long) * std::max(n_blocks, 1u)));
     HIPCHK(e, e->b_slow_list.ensure(sizeof(uint32_t) * e->slow_cap));
     HIPCHK(e, e->b_sort_list.ensure(sizeof(uint32_t) * e->sort_cap));
@@ -193,6 +196,8 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.route_cnt = e->b_route_cnt.as<uint32_t>();
     a.pairs = e->b_pairs.as<MatchRange>();
     a.pair_cap = e->pair_cap;
+    a.spill = e->b_spill.as<uint4>();
+    a.spill_cap = e->spill_cap;
     a.wave_sums = e->b_wave_sums.as<unsigned long long>();
     a.slow_list = e->b_slow_list.as<uint32_t>();
     a.slow_cap = e->slow_cap;
@@ -212,7 +217,7 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     HIPCHK(e, hipEventRecord(e->ev[0], s));
     if (a.n_tenants) hipLaunchKernelGGL(k_resolve_tenants, dim3((a.n_tenants + 63) / 64), dim3(64), 0, s, a);
     HIPCHK(e, hipEventRecord(e->ev[1], s));
-    hipLaunchKernelGGL(k_walk, dim3((a.n_blocks + 7) & ~7u), dim3(64), walk_lds_bytes(a.qcap, a.pcap), s, a);
+    hipLaunchKernelGGL(k_walk, dim3(a.n_blocks), dim3(64), walk_lds_bytes(a.qcap, a.pcap), s, a);
     HIPCHK(e, hipEventRecord(e->ev[2], s));
     hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, a);
@@ -234,12 +239,17 @@ int finish_dist(bmq_engine* e, uint64_t* out_total) {
     for (int attempt = 0; attempt < 8; attempt++) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         const Counters c = *e->h_ctr;
-        const uint32_t grow = c.status & (ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH | ST_NEED_SORTLIST);
+        const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST);
         if (grow) {
             if (grow & ST_NEED_PAIRS) {
                 e->pair_cap = std::max<uint64_t>(e->pair_cap * 2, c.pair_alloc + c.pair_alloc / 8);
                 if (e->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
                 HIPCHK(e, e->b_pairs.ensure(sizeof(MatchRange) * e->pair_cap));
+            }
+            if (grow & ST_NEED_SPILL) {
+                e->spill_cap = std::max<uint64_t>(e->spill_cap * 2, c.spill_alloc + c.spill_alloc / 8);
+                if (e->spill_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "range spill buffer exceeds 2^32 records");
+                HIPCHK(e, e->b_spill.ensure(sizeof(uint4) * e->spill_cap));
             }
             if (grow & ST_NEED_SLOW) {
                 e->slow_cap = std::max<uint32_t>(e->slow_cap * 2, c.slow_count);
@@ -305,9 +315,11 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         memcpy(&c, cfg, cfg->struct_size);
     }
     if (c.wave_queue_cap == 0) c.wave_queue_cap = 512;
-    if (c.wave_pair_cap == 0) c.wave_pair_cap = 512;
-    if (c.wave_queue_cap < 128 || (c.wave_queue_cap & (c.wave_queue_cap - 1)) || c.wave_queue_cap > 8192) return BMQ_E_INVAL;
-    if (c.wave_pair_cap < 1 || c.wave_pair_cap > 8192) return BMQ_E_INVAL;
+    if (c.wave_pair_cap == 0) c.wave_pair_cap = 256;
+    if (const char* v = getenv("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
+    if (const char* v = getenv("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
+    if (c.wave_queue_cap < 256 || (c.wave_queue_cap & (c.wave_queue_cap - 1)) || c.wave_queue_cap > 4096) return BMQ_E_INVAL;
+    if (c.wave_pair_cap < 128 || c.wave_pair_cap > 4096) return BMQ_E_INVAL;
     auto e = std::make_unique<bmq_engine>();
     e->cfg = c;
     e->device = c.device;
@@ -398,9 +410,10 @@ int bmq_index_find(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_l
                                                    std::string_view((const char*)filter, filter_len), is_hash);
     if (node == NONE) return BMQ_OK;
     const TrieSlot& s = e->host.trie[node];
-    const uint32_t b = is_hash ? s.hash_begin : s.own_begin, c = is_hash ? s.hash_count : s.own_count;
+    const uint32_t b = is_hash ? s.hash_begin : s.own_begin, cf = is_hash ? s.hash_count : s.own_count;
+    const uint32_t c = cf & ~RANGE_INDIRECT;
     *out_n = c;
-    for (uint32_t i = 0; i < c && i < cap; i++) out_ids[i] = e->host.route_pos[b + i];
+    for (uint32_t i = 0; i < c && i < cap; i++) out_ids[i] = (cf & RANGE_INDIRECT) ? e->host.route_pos[b + i] : b + i;
     return BMQ_OK;
 }
 
@@ -412,7 +425,7 @@ int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t*
     if (rc) return rc;
     if (n_topics == 0 || !d_out_row_ptr || !d_topic_off || !d_topics || !d_topic_tenant || !d_out_total)
         return set_err(e, BMQ_E_INVAL, "null pointer or empty batch");
-    if (((uintptr_t)d_topics & 7) || ((uintptr_t)d_tenants & 7)) return set_err(e, BMQ_E_INVAL, "string buffers must be 8-byte aligned");
+    if ((uintptr_t)d_topics & 15) return set_err(e, BMQ_E_INVAL, "the topic byte buffer must be 16-byte aligned");
     std::lock_guard<std::mutex> g(e->mu);
     HIPCHK(e, hipSetDevice(e->device));
     if ((rc = ensure_batch_scratch(e, n_tenants, n_topics))) return rc;

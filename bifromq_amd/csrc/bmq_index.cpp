@@ -7,6 +7,7 @@
 #include "bmq_index.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -331,7 +332,7 @@ struct ChildMap {
 struct BuildNode {
     uint32_t parent; // node id, NONE for tenant roots
     uint32_t token;
-    uint32_t own_group, hash_group;
+    uint32_t own_group, hash_group; // route groups of "<path>" and "<path>/#" (NONE: none)
 };
 
 } // namespace
@@ -339,7 +340,7 @@ struct BuildNode {
 bool DistIndexHost::build(const KeySet& ks) {
     error.clear();
     const size_t n = ks.size();
-    if (n >= 0xFFFFFFF0ull) {
+    if (n >= 0x7FFFFFF0ull) {
         error = "too many routes";
         return false;
     }
@@ -347,9 +348,9 @@ bool DistIndexHost::build(const KeySet& ks) {
     ChildMap children;
     std::vector<BuildNode> nodes;
     nodes.reserve(n + 16);
-    std::vector<uint32_t> group_count;          // routes per group, groups in order of first route id
+    std::vector<uint32_t> group_count, group_first, group_last; // per route group (one per filter with routes)
     std::vector<uint32_t> route_group(n ? n : 1);
-    uint64_t tenant_count = 0;
+    std::vector<uint32_t> root_nodes; // node index of every tenant root, ascending (tenants are contiguous in key order)
 
     // path of the previous key, for prefix reuse (sorted keys share long prefixes)
     std::string_view prev_tenant;
@@ -375,7 +376,6 @@ bool DistIndexHost::build(const KeySet& ks) {
                     s = i + 1;
                 }
         }
-        // tenant root
         uint32_t node;
         size_t reuse = 0;
         if (have_prev && kp.tenant == prev_tenant) {
@@ -388,11 +388,13 @@ bool DistIndexHost::build(const KeySet& ks) {
             const uint32_t ttok = dict_h.intern(kp.tenant);
             bool created;
             uint32_t& v = children.get(NONE, ttok, created);
-            if (created) {
-                v = (uint32_t)nodes.size();
-                nodes.push_back({NONE, ttok, NONE, NONE});
-                tenant_count++;
+            if (!created) {
+                error = "keys of one tenant are not contiguous (input not sorted?)";
+                return false;
             }
+            v = (uint32_t)nodes.size();
+            nodes.push_back({NONE, ttok, NONE, NONE});
+            root_nodes.push_back(v);
             node = v;
             prev_root = node;
             prev_tenant = kp.tenant;
@@ -405,7 +407,7 @@ bool DistIndexHost::build(const KeySet& ks) {
         bool is_hash = false;
         for (size_t li = reuse; li < levels.size(); li++) {
             const std::string_view lv = levels[li];
-            if (lv == "#" && li + 1 == levels.size()) { // '#' is legal only as the last level
+            if (lv == "#" && li + 1 == levels.size()) { // '#' is a wildcard only as the last level
                 is_hash = true;
                 prev_levels.push_back(lv);
                 prev_nodes.push_back(NONE); // not a node; never reused
@@ -426,84 +428,125 @@ bool DistIndexHost::build(const KeySet& ks) {
         if (g == NONE) {
             g = (uint32_t)group_count.size();
             group_count.push_back(0);
+            group_first.push_back((uint32_t)r);
+            group_last.push_back((uint32_t)r);
         }
         group_count[g]++;
+        group_last[g] = (uint32_t)r;
         route_group[r] = g;
     }
 
-    // ---- routes grouped per node, groups ordered by first route id -------------------------------------------
-    std::vector<uint32_t> group_begin(group_count.size() + 1, 0);
-    for (size_t g = 0; g < group_count.size(); g++) group_begin[g + 1] = group_begin[g] + group_count[g];
-    route_pos.assign(n ? n : 1, 0);
-    {
-        std::vector<uint32_t> cur(group_begin.begin(), group_begin.end() - 1);
-        for (size_t r = 0; r < n; r++) route_pos[cur[route_group[r]]++] = (uint32_t)r;
+    // ---- route groups: a group whose ids are one contiguous rank range is stored as that range (the overwhelmingly
+    // common case); otherwise (SURVEY.md 8c quirk ii: keys of "x" interleave with keys of "x//...") its ids go to
+    // route_pos[] and the range is flagged RANGE_INDIRECT ------------------------------------------------------------------
+    std::vector<uint32_t> group_begin(group_count.size());
+    uint64_t indirect_total = 0;
+    for (size_t g = 0; g < group_count.size(); g++) {
+        if (group_last[g] - group_first[g] + 1 == group_count[g]) {
+            group_begin[g] = group_first[g];
+        } else {
+            group_begin[g] = (uint32_t)indirect_total;
+            indirect_total += group_count[g];
+            group_count[g] |= RANGE_INDIRECT;
+        }
+    }
+    route_pos.assign(indirect_total ? indirect_total : 1, 0);
+    if (indirect_total) {
+        std::vector<uint32_t> cur(group_begin);
+        for (size_t r = 0; r < n; r++) {
+            const uint32_t g = route_group[r];
+            if (group_count[g] & RANGE_INDIRECT) route_pos[cur[g]++] = (uint32_t)r;
+        }
     }
     std::vector<uint32_t>().swap(route_group);
 
-    // ---- place nodes: one private region of the slot table per tenant (nodes of a tenant are contiguous in
-    // creation order because its keys are contiguous in key order); parents are created before children -----------
-    std::vector<uint32_t> root_nodes; // node index of every tenant root, ascending
-    for (size_t i = 0; i < nodes.size(); i++)
-        if (nodes[i].parent == NONE) root_nodes.push_back((uint32_t)i);
-    double region_factor = 2.0; // slots per node (load factor 1/2); BMQ_REGION_FACTOR overrides for experiments
-    if (const char* rf = getenv("BMQ_REGION_FACTOR")) region_factor = std::max(1.1, atof(rf));
-    std::vector<uint64_t> region_base(root_nodes.size() + 1, 0);
-    for (size_t t = 0; t < root_nodes.size(); t++) {
-        const uint64_t cnt = (t + 1 < root_nodes.size() ? root_nodes[t + 1] : nodes.size()) - root_nodes[t];
-        region_base[t + 1] = region_base[t] + std::max<uint64_t>(8, (uint64_t)(cnt * region_factor) + 1);
+    // ---- one region of the slot table per tenant; bucketised linear probing, load factor <= 1/2 ---------------------
+    double region_factor = 2.0; // slots per node; BMQ_REGION_FACTOR overrides for experiments
+    if (const char* rf = getenv("BMQ_REGION_FACTOR")) region_factor = std::max(1.25, atof(rf));
+    const size_t nt = root_nodes.size();
+    std::vector<uint64_t> region_base(nt + 1, 0); // in slots
+    std::vector<uint32_t> region_buckets(nt);
+    for (size_t t = 0; t < nt; t++) {
+        const uint64_t cnt = (t + 1 < nt ? root_nodes[t + 1] : nodes.size()) - root_nodes[t];
+        region_buckets[t] = (uint32_t)std::max<uint64_t>(2, (uint64_t)(cnt * region_factor / 2.0) + 1);
+        region_base[t + 1] = region_base[t] + 2ull * region_buckets[t];
     }
-    const uint64_t slots = std::max<uint64_t>(region_base.back(), 8);
+    const uint64_t slots = std::max<uint64_t>(region_base.back(), 2);
     if (slots >= 0xFFFFFFF0ull) {
         error = "trie too large";
         return false;
     }
     TrieSlot empty_slot{NONE, 0, 0, 0, 0, 0, NONE, 0};
     trie.assign(slots, empty_slot);
-    const uint32_t tslots = pow2_at_least((uint64_t)root_nodes.size() * 2);
-    tenants.assign(tslots, TenantSlot{0, NONE, 0, 0});
-    std::vector<uint32_t> slot_of(nodes.size());
-    for (size_t t = 0; t < root_nodes.size(); t++) {
-        const uint32_t base = (uint32_t)region_base[t], size = (uint32_t)(region_base[t + 1] - region_base[t]);
-        const size_t n_end = t + 1 < root_nodes.size() ? root_nodes[t + 1] : nodes.size();
-        for (size_t i = root_nodes[t]; i < n_end; i++) {
-            const BuildNode& b = nodes[i];
-            const uint32_t pslot = b.parent == NONE ? ROOT_PARENT : slot_of[b.parent];
-            uint32_t s = base + edge_home(pslot, b.token, size);
-            while (trie[s].parent != NONE) s = (s + 1 == base + size) ? base : s + 1;
-            TrieSlot& ts = trie[s];
-            ts.parent = pslot;
-            ts.token = b.token;
-            if (b.own_group != NONE) {
-                ts.own_begin = group_begin[b.own_group];
-                ts.own_count = group_count[b.own_group];
+    const uint32_t tslots = pow2_at_least((uint64_t)nt * 2);
+    tenants.assign(tslots, TenantSlot{0, NONE, 0, 1});
+    {
+        std::vector<uint32_t> slot_of(nodes.size());
+        std::atomic<size_t> next{0};
+        auto work = [&]() { // regions are independent: place them on all host cores (parents precede children)
+            for (;;) {
+                const size_t t = next.fetch_add(1);
+                if (t >= nt) break;
+                const size_t n0 = root_nodes[t], n1 = t + 1 < nt ? root_nodes[t + 1] : nodes.size();
+                const uint32_t base = (uint32_t)region_base[t], nb = region_buckets[t];
+                for (size_t i = n0; i < n1; i++) {
+                    const BuildNode& b = nodes[i];
+                    const uint32_t pslot = b.parent == NONE ? ROOT_PARENT : slot_of[b.parent];
+                    uint32_t bk = edge_bucket(pslot, b.token, nb), s;
+                    for (;;) {
+                        s = base + 2 * bk;
+                        if (trie[s].parent == NONE) break;
+                        if (trie[++s].parent == NONE) break;
+                        bk = (bk + 1 == nb) ? 0 : bk + 1;
+                    }
+                    TrieSlot& ts = trie[s];
+                    ts.parent = pslot;
+                    ts.token = b.token;
+                    if (b.own_group != NONE) {
+                        ts.own_begin = group_begin[b.own_group];
+                        ts.own_count = group_count[b.own_group];
+                    }
+                    if (b.hash_group != NONE) {
+                        ts.hash_begin = group_begin[b.hash_group];
+                        ts.hash_count = group_count[b.hash_group];
+                    }
+                    slot_of[i] = s;
+                    if (b.parent != NONE) {
+                        TrieSlot& pr = trie[pslot];
+                        if (b.token == TOK_PLUS) pr.plus_child = s;
+                        else pr.lit_bloom |= 1u << bloom_bit(b.token);
+                    }
+                }
             }
-            if (b.hash_group != NONE) {
-                ts.hash_begin = group_begin[b.hash_group];
-                ts.hash_count = group_count[b.hash_group];
-            }
-            slot_of[i] = s;
-            if (b.parent != NONE) {
-                TrieSlot& p = trie[pslot];
-                if (b.token == TOK_PLUS) p.plus_child = s;
-                else p.lit_bloom |= 1u << bloom_bit(b.token);
-            }
+        };
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nth = (unsigned)std::min<size_t>(hw ? hw : 1, std::max<size_t>(nt, 1));
+        std::vector<std::thread> th;
+        for (unsigned w = 1; w < nth; w++) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+        for (size_t t = 0; t < nt; t++) {
+            const uint32_t ttok = nodes[root_nodes[t]].token;
+            uint32_t d = tenant_hash(ttok) & (tslots - 1);
+            while (tenants[d].token) d = (d + 1) & (tslots - 1);
+            tenants[d] = TenantSlot{ttok, slot_of[root_nodes[t]], (uint32_t)region_base[t], region_buckets[t]};
         }
-        const uint32_t ttok = nodes[root_nodes[t]].token;
-        uint32_t d = tenant_hash(ttok) & (tslots - 1);
-        while (tenants[d].token) d = (d + 1) & (tslots - 1);
-        tenants[d] = TenantSlot{ttok, slot_of[root_nodes[t]], base, size};
     }
 
-    // ---- dictionary slots + pool -----------------------------------------------------------------------------------
-    const uint32_t dslots = pow2_at_least((uint64_t)dict_h.entries.size() * 2);
-    const uint32_t dmask = dslots - 1;
+    // ---- dictionary: groups of four slots, load factor <= 1/4 ------------------------------------------------------------
+    const uint32_t dslots = pow2_at_least(std::max<uint64_t>(8, (uint64_t)dict_h.entries.size() * 4));
+    const uint32_t gmask = dslots / 4 - 1;
     dict.assign(dslots, DictSlot{0, 0, 0, 0, {0, 0, 0, 0}});
     pool.clear();
     for (size_t t = 0; t < dict_h.entries.size(); t++) {
         const auto& e = dict_h.entries[t];
-        uint32_t s = e.slot_hash & dmask;
-        while (dict[s].tag) s = (s + 1) & dmask;
+        uint32_t g = e.slot_hash & gmask, s = NONE;
+        for (;;) {
+            for (uint32_t j = 0; j < 4 && s == NONE; j++)
+                if (!dict[4 * g + j].tag) s = 4 * g + j;
+            if (s != NONE) break;
+            g = (g + 1) & gmask;
+        }
         DictSlot& d = dict[s];
         d.tag = e.tag;
         d.token = (uint32_t)t + TOK_FIRST;
@@ -517,7 +560,7 @@ bool DistIndexHost::build(const KeySet& ks) {
     while (pool.size() % 16 || pool.empty()) pool.push_back(0);
 
     n_routes = n;
-    n_tenants = tenant_count;
+    n_tenants = nt;
     n_nodes = nodes.size();
     n_tokens = dict_h.entries.size();
     return true;
@@ -526,20 +569,27 @@ bool DistIndexHost::build(const KeySet& ks) {
 uint32_t DistIndexHost::find_token(std::string_view level) const {
     if (dict.empty()) return TOK_UNKNOWN;
     const LevelHash h = hash_level(level);
-    const uint32_t mask = (uint32_t)dict.size() - 1, tag = level_hash_tag(h);
-    uint32_t s = level_hash_slot(h, (uint32_t)level.size()) & mask;
-    while (dict[s].tag) {
-        const DictSlot& d = dict[s];
-        if (d.tag == tag && d.len == level.size()) {
-            bool eq = true;
-            for (size_t i = 0; i < level.size() && i < 16 && eq; i++)
-                eq = ((d.inl[i >> 2] >> (8 * (i & 3))) & 0xFF) == (uint8_t)level[i];
-            if (eq && level.size() > 16) eq = memcmp(pool.data() + d.pool_off, level.data(), level.size()) == 0;
-            if (eq) return d.token;
+    const uint32_t gmask = (uint32_t)dict.size() / 4 - 1, tag = level_hash_tag(h);
+    uint32_t g = level_hash_slot(h, (uint32_t)level.size()) & gmask;
+    for (;;) {
+        bool group_full = true;
+        for (uint32_t j = 0; j < 4; j++) {
+            const DictSlot& d = dict[4 * g + j];
+            if (!d.tag) {
+                group_full = false;
+                continue;
+            }
+            if (d.tag == tag && d.len == level.size()) {
+                bool eq = true;
+                for (size_t i = 0; i < level.size() && i < 16 && eq; i++)
+                    eq = ((d.inl[i >> 2] >> (8 * (i & 3))) & 0xFF) == (uint8_t)level[i];
+                if (eq && level.size() > 16) eq = memcmp(pool.data() + d.pool_off, level.data(), level.size()) == 0;
+                if (eq) return d.token;
+            }
         }
-        s = (s + 1) & mask;
+        if (!group_full) return TOK_UNKNOWN;
+        g = (g + 1) & gmask;
     }
-    return TOK_UNKNOWN;
 }
 
 const TenantSlot* DistIndexHost::find_tenant(uint32_t token) const {
@@ -554,21 +604,27 @@ const TenantSlot* DistIndexHost::find_tenant(uint32_t token) const {
 }
 
 uint32_t DistIndexHost::find_child(const TenantSlot& r, uint32_t parent_slot, uint32_t token) const {
-    uint32_t s = r.base + edge_home(parent_slot, token, r.size);
-    while (trie[s].parent != NONE) {
-        if (trie[s].parent == parent_slot && trie[s].token == token) return s;
-        s = (s + 1 == r.base + r.size) ? r.base : s + 1;
+    uint32_t bk = edge_bucket(parent_slot, token, r.buckets);
+    for (;;) {
+        bool full = true;
+        for (uint32_t j = 0; j < 2; j++) {
+            const TrieSlot& t = trie[r.base + 2 * bk + j];
+            if (t.parent == NONE) full = false;
+            else if (t.parent == parent_slot && t.token == token) return r.base + 2 * bk + j;
+        }
+        if (!full) return NONE;
+        bk = (bk + 1 == r.buckets) ? 0 : bk + 1;
     }
-    return NONE;
 }
 
+// slot of the node for (tenant, filter); for "x/#" the node of "x" with is_hash = true
 uint32_t DistIndexHost::find_filter_node(std::string_view tenant, std::string_view filter, bool& is_hash) const {
     is_hash = false;
     const TenantSlot* r = find_tenant(find_token(tenant));
     if (!r) return NONE;
-    uint32_t node = r->root;
+    uint32_t slot = r->root;
     size_t s = 0;
-    for (size_t i = 0; i <= filter.size() && node != NONE; i++)
+    for (size_t i = 0; i <= filter.size() && slot != NONE; i++)
         if (i == filter.size() || filter[i] == '/') {
             const std::string_view lv = filter.substr(s, i - s);
             s = i + 1;
@@ -578,9 +634,9 @@ uint32_t DistIndexHost::find_filter_node(std::string_view tenant, std::string_vi
             }
             const uint32_t tok = lv == "+" ? TOK_PLUS : find_token(lv);
             if (tok == TOK_UNKNOWN) return NONE;
-            node = find_child(*r, node, tok);
+            slot = find_child(*r, slot, tok);
         }
-    return node;
+    return slot;
 }
 
 } // namespace bmq

@@ -54,7 +54,7 @@ struct DistIndexHost {
     // host-side exact helpers (inspection only -- never used for matching)
     uint32_t find_token(std::string_view level) const;                 // TOK_UNKNOWN if absent
     const TenantSlot* find_tenant(uint32_t token) const;               // nullptr if absent
-    uint32_t find_child(const TenantSlot& region, uint32_t parent_slot, uint32_t token) const; // NONE if absent
+    uint32_t find_child(const TenantSlot& region, uint32_t parent_slot, uint32_t token) const; // slot or NONE
     uint32_t find_filter_node(std::string_view tenant, std::string_view mqtt_filter, bool& is_hash) const;
 };
 

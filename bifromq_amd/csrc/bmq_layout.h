@@ -1,10 +1,15 @@
 // bmq_layout.h -- HBM data layout shared by the host builder and the gfx950 kernels.
 //
 // Dist direction index ("filter trie", the inverse of the reference's per-call topic trie,
-// TRIE/TopicTrieNode.java:37-163): every node is ONE 32-byte slot of an open-addressing table keyed by
-// (parent slot, edge token).  A node's id IS its slot index, so a literal child lookup is a single
-// probe that returns the child's complete header; '+' children and tenant roots are reached by slot
-// index without probing.  '#' children are never nodes: their routes hang off the parent (hash_*).
+// TRIE/TopicTrieNode.java:37-163).  Every trie node is ONE 32-byte slot; a node's id IS its slot index.
+//   * all nodes of a tenant live in the tenant's private region of the slot table (TenantSlot);
+//   * inside a region, the edge (parent slot, token) hashes to a home BUCKET = two slots = one aligned 64-byte line;
+//     insertion fills the first free slot from the home bucket onwards (load factor <= 1/2), so a child lookup reads
+//     ONE line in ~92 % of the cases and gets the child's complete header with it.  Measured on MI355X the walk is
+//     bound by the rate of random 64-byte line fetches (~54 G lines/s from HBM, ~200 G/s from L2,
+//     tools/ubench_lines.hip), so lines per visited node is the figure of merit;
+//   * '+' children and tenant roots are reached by slot index (one 32-byte read, no probing);
+//   * '#' children are never nodes: the routes of "<path>/#" hang off the parent (hash_*).
 #pragma once
 #include <stdint.h>
 
@@ -22,22 +27,33 @@ constexpr uint32_t ROOT_PARENT = 0xFFFFFFFEu; // parent key of tenant roots
 constexpr uint32_t TOK_UNKNOWN = 0;           // level string not in the dictionary
 constexpr uint32_t TOK_PLUS = 1;              // the '+' edge
 constexpr uint32_t TOK_FIRST = 2;             // first dictionary token
-constexpr int FAST_LEVELS = 16;               // topics with more levels go to the slow path
+constexpr int FAST_LEVELS = 16;               // topics with more levels take the slow path
                                               // (Setting.MaxTopicLevels default, Setting.java:45)
+constexpr uint32_t RANGE_INDIRECT = 0x80000000u; // count flag: begin indexes route_pos[] instead of being the first id
 
 struct alignas(32) TrieSlot {
     uint32_t parent;      // slot index of the parent (NONE = empty slot, ROOT_PARENT = tenant root)
     uint32_t token;       // dictionary token of the edge label (TOK_PLUS for '+')
-    uint32_t own_begin;   // routes whose filter ends at this node: route_pos[own_begin .. +own_count)
-    uint32_t own_count;
-    uint32_t hash_begin;  // routes of "<this path>/#"
+    uint32_t own_begin;   // routes whose filter ends at this node: ids own_begin .. +count-1, or route_pos[own_begin ..]
+    uint32_t own_count;   //   when (own_count & RANGE_INDIRECT)
+    uint32_t hash_begin;  // routes of "<this path>/#", same encoding
     uint32_t hash_count;
     uint32_t plus_child;  // slot index of the '+' child or NONE
     uint32_t lit_bloom;   // 32-bit Bloom mask over the literal children's tokens; 0 = no literal child
 };
 static_assert(sizeof(TrieSlot) == 32, "TrieSlot must be 32 bytes");
 
-// Level dictionary: level string -> token, exact (bytes verified).  Strings <= 16 bytes live inline.
+// Tenant directory entry: the tenant's region of the slot table.  Bucket k of the region = slots base+2k, base+2k+1.
+struct alignas(16) TenantSlot {
+    uint32_t token;   // dictionary token of the tenant id; 0 = empty directory slot
+    uint32_t root;    // slot index of the tenant's root node
+    uint32_t base;    // first slot of the region (even)
+    uint32_t buckets; // number of 2-slot buckets (>= 1)
+};
+static_assert(sizeof(TenantSlot) == 16, "TenantSlot must be 16 bytes");
+
+// Level dictionary: level string -> token, exact (bytes verified).  Strings <= 16 bytes live inline.  Open addressing
+// over groups of four slots (one 128-byte line) at load factor <= 1/4: a lookup reads its home group in one go.
 struct alignas(32) DictSlot {
     uint32_t tag;       // second hash, forced non-zero; 0 = empty slot
     uint32_t token;
@@ -46,17 +62,6 @@ struct alignas(32) DictSlot {
     uint32_t inl[4];    // first 16 bytes, little-endian packed, zero padded
 };
 static_assert(sizeof(DictSlot) == 32, "DictSlot must be 32 bytes");
-
-// Tenant directory: tenant token -> the tenant's root node and its private REGION of the slot table.  All nodes of a
-// tenant live in [base, base + size): a wave that works on one tenant's publishes touches only that region, which
-// for typical tenants (10^4 routes ~ 1.5 MiB) stays resident in the XCD's 4 MiB L2.
-struct alignas(16) TenantSlot {
-    uint32_t token; // dictionary token of the tenant id; 0 = empty slot
-    uint32_t root;  // slot index of the tenant's root node
-    uint32_t base;  // first slot of the region
-    uint32_t size;  // slots in the region (any value >= 1, not a power of two)
-};
-static_assert(sizeof(TenantSlot) == 16, "TenantSlot must be 16 bytes");
 
 // Incremental level hash: two 32-bit lanes (slot index, tag).  Same code on host and device.
 struct LevelHash {
@@ -77,8 +82,7 @@ BMQ_HD uint32_t level_hash_slot(const LevelHash& h, uint32_t len) {
 }
 BMQ_HD uint32_t level_hash_tag(const LevelHash& h) { return h.h2 | 1u; }
 
-BMQ_HD uint32_t edge_hash(uint32_t parent, uint32_t token) {
-    uint32_t x = parent * 0x9E3779B1u + token * 0x85EBCA77u;
+BMQ_HD uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7FEB352Du;
     x ^= x >> 15;
@@ -86,11 +90,12 @@ BMQ_HD uint32_t edge_hash(uint32_t parent, uint32_t token) {
     x ^= x >> 16;
     return x;
 }
-BMQ_HD uint32_t bloom_bit(uint32_t token) { return (token * 0x9E3779B1u) >> 27; }
-// home slot of edge (parent, token) inside a region of `size` slots (fastrange: no power-of-two needed)
-BMQ_HD uint32_t edge_home(uint32_t parent, uint32_t token, uint32_t size) {
-    return (uint32_t)(((uint64_t)edge_hash(parent, token) * size) >> 32);
+// home bucket of edge (parent slot, token) in a region of `buckets` buckets (fastrange: any size)
+BMQ_HD uint32_t edge_bucket(uint32_t parent, uint32_t token, uint32_t buckets) {
+    const uint32_t h = mix32(parent * 0x9E3779B1u + token * 0x85EBCA77u);
+    return (uint32_t)(((uint64_t)h * buckets) >> 32);
 }
+BMQ_HD uint32_t bloom_bit(uint32_t token) { return (token * 0x9E3779B1u) >> 27; }
 BMQ_HD uint32_t tenant_hash(uint32_t token) {
     uint32_t x = token * 0x9E3779B1u;
     return x ^ (x >> 15);
@@ -102,12 +107,12 @@ struct DistIndexView {
     const TenantSlot* tenants;
     uint32_t tenant_mask;      // tenant directory slots - 1
     const DictSlot* dict;
-    uint32_t dict_mask;
+    uint32_t dict_group_mask;  // (dictionary slots / 4) - 1
     const uint8_t* pool;       // level strings longer than 16 bytes
-    const uint32_t* route_pos; // route ids grouped per node, groups ordered by first id
+    const uint32_t* route_pos; // ids of the (rare) nodes whose route ids are not one contiguous rank range
 };
 
-// A matched range: routes route_pos[begin .. begin+count) belong to one filter node.
+// A matched range of one filter node: ids begin .. begin+count-1, or route_pos[begin ..] if count has RANGE_INDIRECT.
 struct MatchRange {
     uint32_t begin, count;
 };

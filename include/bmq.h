@@ -51,8 +51,8 @@ typedef struct bmq_engine bmq_engine;
 typedef struct bmq_config {
     uint32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = host-only engine (build/inspect, no match)      */
-    uint32_t wave_queue_cap;   /* per-wave LDS frontier ring, items (default 512, pow2, >= 128)            */
-    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 512)                 */
+    uint32_t wave_queue_cap;   /* per-wave LDS work ring, items (default 512; pow2 in 256..4096)           */
+    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 256; 128..4096)      */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t reserved[8];
 } bmq_config;
@@ -122,8 +122,8 @@ int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenan
 
 /* Same, all seven data pointers are DEVICE pointers (inputs already resident in HBM; results stay in HBM).
  * Asynchronous on the engine stream; d_out_total (device uint64) receives the id count.  Call bmq_sync()
- * (or bmq_match_finish()) before reading results.  topics buffer must be readable up to
- * topic_off[n_topics] rounded up to 8 bytes. */
+ * (or bmq_match_finish()) before reading results.  d_topics must be 16-byte aligned and readable up to
+ * topic_off[n_topics] rounded up to the next multiple of 16 bytes. */
 int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t* d_tenant_off, uint32_t n_tenants,
                         const uint32_t* d_topic_tenant, const uint8_t* d_topics, const uint32_t* d_topic_off,
                         uint32_t n_topics, uint32_t* d_out_row_ptr, uint32_t* d_out_route_ids,
