@@ -20,6 +20,7 @@
 #include "bmq_dist_kernels.h"
 #include "bmq_index.h"
 #include "bmq_retain.h"
+#include "bmq_retain_kernels.h"
 
 using namespace bmq;
 
@@ -58,6 +59,11 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+struct RetainDevice { // the retained-topic index in HBM
+    DevBuf nodes, edges, tenants, dict, pool;
+    RetainIndexView view{};
+};
+
 struct DistDevice { // one epoch of the dist index in HBM
     DevBuf trie, tenants, dict, pool, route_pos;
     DistIndexView view{};
@@ -94,15 +100,18 @@ struct bmq_engine {
     bool pending = false;
     int pending_kind = 0; // 0 dist, 1 retain
     BatchArgs last{};
-    RetainBatchArgs rlast{};
+    RetainArgs rlast{};
     bmq_stats stats{};
 
     // retain direction
     RetainIndexHost rhost;
     RetainDevice rdev;
     bool rbuilt = false;
-    DevBuf r_items, r_items2, r_cnt, r_blocksum;
+    DevBuf r_scratch;
+    uint32_t rgcap = 0;
 };
+
+static int retain_finish(bmq_engine* e, uint64_t* out_total);
 
 namespace {
 
@@ -314,8 +323,8 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (cfg->struct_size < 8 || cfg->struct_size > sizeof(bmq_config)) return BMQ_E_INVAL;
         memcpy(&c, cfg, cfg->struct_size);
     }
-    if (c.wave_queue_cap == 0) c.wave_queue_cap = 512;
-    if (c.wave_pair_cap == 0) c.wave_pair_cap = 256;
+    if (c.wave_queue_cap == 0) c.wave_queue_cap = 1024;
+    if (c.wave_pair_cap == 0) c.wave_pair_cap = 512;
     if (const char* v = getenv("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
     if (const char* v = getenv("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
     if (c.wave_queue_cap < 256 || (c.wave_queue_cap & (c.wave_queue_cap - 1)) || c.wave_queue_cap > 4096) return BMQ_E_INVAL;
@@ -330,8 +339,7 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return BMQ_E_HIP;
         for (auto& ev : e->ev)
             if (hipEventCreate(&ev) != hipSuccess) return BMQ_E_HIP;
-        if (hipHostMalloc((void**)&e->h_ctr, sizeof(RetainCounters) > sizeof(Counters) ? sizeof(RetainCounters) : sizeof(Counters),
-                          hipHostMallocDefault) != hipSuccess)
+        if (hipHostMalloc((void**)&e->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess)
             return BMQ_E_NOMEM;
         memset(e->h_ctr, 0, sizeof(Counters));
     }

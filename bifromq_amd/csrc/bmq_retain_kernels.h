@@ -1,0 +1,358 @@
+// bmq_retain_kernels.h -- gfx950 kernel of the retain-direction match: wildcard FILTERS against the index of
+// retained TOPICS (bmq_retain.h).  Semantics: RetainMatcher (RS/index/RetainTopicIndex.java:36-124) driven by
+// TopicLevelTrie.lookup (UTIL/index/TopicLevelTrie.java:190-249); '$' children are skipped by a wildcard in the first
+// topic level (currentLevel == 1 there, because level 0 is the tenant).
+//
+// k_retain_walk: persistent waves, one filter per wave at a time (grid-stride).  The frontier is a list of NODE RANGES
+// in LDS (overflowing into a per-wave global scratch).  '+' maps a range to the range of its children with two node
+// reads; a literal level looks every node of the frontier up in the edge hash (one 64-byte line each, lanes in
+// parallel); '#' and end-of-filter emit topic-id RANGES.  Two passes per filter (count, then write) keep the output of a
+// filter contiguous without any per-filter capacity.  The CSR is then produced by the dist direction's k_scan_blocks /
+// k_expand / k_sort_rows (same MatchRange plumbing).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bmq_dist_kernels.h"
+#include "bmq_retain.h"
+
+namespace bmq {
+
+constexpr uint32_t R_MAXL = 64;        // filter levels supported by the kernel
+constexpr uint32_t R_FRONT = 1024;     // frontier ranges kept in LDS (per buffer)
+constexpr uint32_t RT_PLUS = 0xFFFFFFFDu, RT_HASH = 0xFFFFFFFCu; // level kinds next to dictionary tokens
+constexpr uint32_t ST_RETAIN_DEEP = 128u, ST_RETAIN_FRONT = 256u;
+
+struct RetainArgs {
+    RetainIndexView ix;
+    const uint8_t* tenants;
+    const uint32_t* tenant_off;
+    uint32_t n_tenants;
+    const uint32_t* filter_tenant;
+    const uint8_t* filters;
+    const uint32_t* filter_off;
+    uint32_t n_filters;
+    uint2* gscratch;       // per wave: 2 * gcap ranges
+    uint32_t gcap;
+};
+
+struct Frontier {
+    uint32_t* lb;
+    uint32_t* lc;
+    uint2* g;
+    __device__ __forceinline__ uint2 get(uint32_t i) const { return i < R_FRONT ? make_uint2(lb[i], lc[i]) : g[i - R_FRONT]; }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t b, uint32_t c) const {
+        if (i < R_FRONT) {
+            lb[i] = b;
+            lc[i] = c;
+        } else g[i - R_FRONT] = make_uint2(b, c);
+    }
+};
+
+__device__ __forceinline__ uint32_t redge_lookup(const RetainIndexView& ix, uint32_t parent, uint32_t token) {
+    uint32_t bk = redge_bucket(parent, token, ix.edge_bucket_mask);
+    for (;;) {
+        const uint4* p = reinterpret_cast<const uint4*>(ix.edges + 4 * (size_t)bk);
+        const uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+        if (e0.x == parent && e0.y == token) return e0.z;
+        if (e1.x == parent && e1.y == token) return e1.z;
+        if (e2.x == parent && e2.y == token) return e2.z;
+        if (e3.x == parent && e3.y == token) return e3.z;
+        if (e0.x == NONE || e1.x == NONE || e2.x == NONE || e3.x == NONE) return NONE;
+        bk = (bk + 1) & ix.edge_bucket_mask;
+    }
+}
+__device__ __forceinline__ RNode load_rnode(const RetainIndexView& ix, uint32_t i) {
+    const uint4 v = *reinterpret_cast<const uint4*>(ix.nodes + i);
+    return RNode{v.x, v.y, v.z, v.w};
+}
+
+__global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
+    __shared__ uint32_t lev_start[R_MAXL + 1], lev_end[R_MAXL + 1], ftok[R_MAXL + 1];
+    __shared__ uint32_t fb0[R_FRONT], fc0[R_FRONT], fb1[R_FRONT], fc1[R_FRONT];
+    __shared__ uint32_t sh[8];
+    const uint32_t lane = threadIdx.x;
+    uint2* gs = r.gscratch + (size_t)blockIdx.x * 2 * r.gcap;
+    const uint32_t cap = R_FRONT + r.gcap;
+    unsigned long long visits = 0;
+
+    for (uint32_t f = blockIdx.x; f < r.n_filters; f += gridDim.x) {
+        // ---- tokenise the filter: '/' positions by ballot, then one lane per level for hash + dictionary ----------------
+        const uint32_t beg = r.filter_off[f], end = r.filter_off[f + 1];
+        uint32_t nsep = 0;
+        if (lane == 0) lev_start[0] = beg;
+        bool deep = false;
+        for (uint32_t cb = beg; cb < end; cb += 64) {
+            const uint32_t i = cb + lane;
+            const bool sep = i < end && r.filters[i] == '/';
+            const unsigned long long m = __ballot(sep);
+            if (sep) {
+                const uint32_t k = nsep + rank_below(m);
+                if (k < R_MAXL) {
+                    lev_end[k] = i;
+                    lev_start[k + 1] = i + 1;
+                }
+            }
+            nsep += (uint32_t)__popcll(m);
+        }
+        const uint32_t nlev = nsep + 1;
+        if (nlev > R_MAXL) deep = true;
+        if (lane == 0 && !deep) lev_end[nlev - 1] = end;
+        __syncthreads();
+        RTenantSlot ten{0, 0, 0, 0, 0, 0, {0, 0}};
+        if (!deep) {
+            const uint8_t* fbytes = r.filters;
+            auto fbyte = [&](uint32_t k) -> uint32_t { return fbytes[k]; };
+            if (lane < nlev) {
+                uint32_t pos = lev_start[lane];
+                const uint32_t start = pos, e = lev_end[lane];
+                LevelHash h;
+                uint32_t inl[4], len;
+                bool last;
+                scan_level(pos, e, false, fbyte, h, inl, len, last);
+                uint32_t tok;
+                if (len == 1 && inl[0] == '+') tok = RT_PLUS;
+                else if (len == 1 && inl[0] == '#' && lane == nlev - 1) tok = RT_HASH;
+                else {
+                    DistIndexView dv{};
+                    dv.dict = r.ix.dict;
+                    dv.dict_group_mask = r.ix.dict_group_mask;
+                    dv.pool = r.ix.pool;
+                    tok = dict_lookup(dv, h, len, inl, start, fbyte);
+                }
+                ftok[lane] = tok;
+            }
+            if (lane == 63) { // tenant -> root
+                const uint32_t ti = r.filter_tenant[f];
+                uint32_t tok = TOK_UNKNOWN;
+                if (ti < r.n_tenants) {
+                    const uint8_t* tb = r.tenants;
+                    auto tbyte = [&](uint32_t k) -> uint32_t { return tb[k]; };
+                    uint32_t pos = r.tenant_off[ti];
+                    const uint32_t start = pos, e = r.tenant_off[ti + 1];
+                    LevelHash h;
+                    uint32_t inl[4], len;
+                    bool last;
+                    scan_level(pos, e, false, tbyte, h, inl, len, last);
+                    DistIndexView dv{};
+                    dv.dict = r.ix.dict;
+                    dv.dict_group_mask = r.ix.dict_group_mask;
+                    dv.pool = r.ix.pool;
+                    tok = dict_lookup(dv, h, len, inl, start, tbyte);
+                }
+                uint32_t root = NONE;
+                if (tok != TOK_UNKNOWN) {
+                    uint32_t d = tenant_hash(tok) & r.ix.tenant_mask;
+                    for (;;) {
+                        const uint4* p = reinterpret_cast<const uint4*>(r.ix.tenants + d);
+                        const uint4 t0 = p[0];
+                        if (t0.x == tok) {
+                            const uint4 t1 = p[1];
+                            sh[1] = t0.z; sh[2] = t0.w; sh[3] = t1.x; sh[4] = t1.y;
+                            root = t0.y;
+                            break;
+                        }
+                        if (t0.x == 0) break;
+                        d = (d + 1) & r.ix.tenant_mask;
+                    }
+                }
+                sh[0] = root;
+            }
+        }
+        __syncthreads();
+        const uint32_t root = deep ? NONE : sh[0];
+        ten.sys_node_lo = sh[1]; ten.sys_node_hi = sh[2]; ten.sys_id_lo = sh[3]; ten.sys_id_hi = sh[4];
+        if (deep && lane == 0) atomicOr(&a.ctr->status, ST_RETAIN_DEEP);
+
+        // ---- two passes: count, then write -------------------------------------------------------------------------------------
+        unsigned long long base = 0;
+        uint32_t np_total = 0, nr_total = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            uint32_t wp = 0, nr = 0; // ranges / ids emitted so far (wave-uniform)
+            const uint32_t vinc = pass == 0 ? 1u : 0u; // nodes touched are counted once, in the counting pass
+            auto emit = [&](bool pred, uint32_t b, uint32_t c) {
+                const unsigned long long m = __ballot(pred);
+                if (pred && pass == 1) a.pairs[base + wp + rank_below(m)] = MatchRange{b, c};
+                wp += (uint32_t)__popcll(m);
+                unsigned long long s = pred ? c : 0u;
+                nr += (uint32_t)wave_sum_u64(s);
+            };
+            Frontier cur{fb0, fc0, gs}, nxt{fb1, fc1, gs + r.gcap};
+            uint32_t ncur = 0;
+            bool overflow = false;
+            if (root != NONE) {
+                if (lane == 0) cur.put(0, root, 1);
+                ncur = 1;
+            }
+            __syncthreads();
+            bool done = false;
+            for (uint32_t l = 0; l < nlev && ncur && !done; l++) {
+                const uint32_t kind = ftok[l];
+                uint32_t nn = 0;
+                if (kind == RT_HASH) { // last level: whole subtrees (the parent level matches too)
+                    for (uint32_t i0 = 0; i0 < ncur; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        uint2 rg = make_uint2(0, 0);
+                        if (i < ncur) rg = cur.get(i);
+                        // singletons in parallel
+                        {
+                            const bool one = i < ncur && rg.y == 1;
+                            RNode n{0, 0, 0, 0};
+                            if (one) n = load_rnode(r.ix, rg.x);
+                            if (l == 0) { // filter "#": everything of the tenant except what lies below '$' children
+                                emit(one && ten.sys_id_lo > n.sub_begin && ten.sys_id_hi > ten.sys_id_lo, n.sub_begin, ten.sys_id_lo - n.sub_begin);
+                                const uint32_t lo2 = ten.sys_id_hi > ten.sys_id_lo ? ten.sys_id_hi : n.sub_begin;
+                                emit(one && n.sub_end > lo2, lo2, n.sub_end - lo2);
+                            } else {
+                                emit(one && n.sub_end > n.sub_begin, n.sub_begin, n.sub_end - n.sub_begin);
+                            }
+                            if (one) visits += vinc;
+                        }
+                        // ranges of several nodes: the wave streams each of them
+                        unsigned long long big = __ballot(i < ncur && rg.y > 1);
+                        while (big) {
+                            const int src = __ffsll((long long)big) - 1;
+                            big &= big - 1;
+                            const uint32_t b = __shfl(rg.x, src), c = __shfl(rg.y, src);
+                            for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+                                const uint32_t j = j0 + lane;
+                                RNode n{0, 0, 0, 0};
+                                if (j < c) {
+                                    n = load_rnode(r.ix, b + j);
+                                    visits += vinc;
+                                }
+                                emit(j < c && n.sub_end > n.sub_begin, n.sub_begin, n.sub_end - n.sub_begin);
+                            }
+                        }
+                    }
+                    done = true;
+                    break;
+                }
+                if (kind == RT_PLUS) { // every child of every frontier node: a node range maps to ONE node range
+                    for (uint32_t i0 = 0; i0 < ncur; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        uint32_t b1 = 0, c1 = 0, b2 = 0, c2 = 0;
+                        if (i < ncur) {
+                            const uint2 rg = cur.get(i);
+                            const RNode first = load_rnode(r.ix, rg.x);
+                            const RNode last = rg.y > 1 ? load_rnode(r.ix, rg.x + rg.y - 1) : first;
+                            visits += 2 * vinc;
+                            const uint32_t cb = first.child_begin, ce = last.child_begin + (last.child_count & ~RN_TERM);
+                            if (l == 0 && ten.sys_node_hi > ten.sys_node_lo) { // skip the '$' children of the tenant root
+                                b1 = cb; c1 = ten.sys_node_lo > cb ? ten.sys_node_lo - cb : 0;
+                                b2 = ten.sys_node_hi; c2 = ce > ten.sys_node_hi ? ce - ten.sys_node_hi : 0;
+                            } else {
+                                b1 = cb; c1 = ce - cb;
+                            }
+                        }
+                        const unsigned long long m1 = __ballot(c1 != 0), m2 = __ballot(c2 != 0);
+                        const uint32_t p1 = nn + rank_below(m1), p2 = nn + (uint32_t)__popcll(m1) + rank_below(m2);
+                        if (c1) { if (p1 < cap) nxt.put(p1, b1, c1); else overflow = true; }
+                        if (c2) { if (p2 < cap) nxt.put(p2, b2, c2); else overflow = true; }
+                        nn += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+                    }
+                } else { // literal level: look every frontier node up in the edge hash
+                    for (uint32_t i0 = 0; i0 < ncur && kind != TOK_UNKNOWN; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        uint2 rg = make_uint2(0, 0);
+                        if (i < ncur) rg = cur.get(i);
+                        {
+                            uint32_t child = NONE;
+                            if (i < ncur && rg.y == 1) {
+                                child = redge_lookup(r.ix, rg.x, kind);
+                                visits += vinc;
+                            }
+                            const unsigned long long m = __ballot(child != NONE);
+                            const uint32_t p = nn + rank_below(m);
+                            if (child != NONE) { if (p < cap) nxt.put(p, child, 1); else overflow = true; }
+                            nn += (uint32_t)__popcll(m);
+                        }
+                        unsigned long long big = __ballot(i < ncur && rg.y > 1);
+                        while (big) {
+                            const int src = __ffsll((long long)big) - 1;
+                            big &= big - 1;
+                            const uint32_t b = __shfl(rg.x, src), c = __shfl(rg.y, src);
+                            for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+                                const uint32_t j = j0 + lane;
+                                uint32_t child = NONE;
+                                if (j < c) {
+                                    child = redge_lookup(r.ix, b + j, kind);
+                                    visits += vinc;
+                                }
+                                const unsigned long long m = __ballot(child != NONE);
+                                const uint32_t p = nn + rank_below(m);
+                                if (child != NONE) { if (p < cap) nxt.put(p, child, 1); else overflow = true; }
+                                nn += (uint32_t)__popcll(m);
+                            }
+                        }
+                    }
+                }
+                if (__any(overflow)) {
+                    if (lane == 0) atomicOr(&a.ctr->status, ST_RETAIN_FRONT);
+                    nn = 0;
+                    done = true;
+                }
+                __syncthreads();
+                const Frontier t = cur;
+                cur = nxt;
+                nxt = t;
+                ncur = nn;
+            }
+            if (!done) { // the filter ended without '#': topics that end exactly at a frontier node
+                for (uint32_t i0 = 0; i0 < ncur; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    uint2 rg = make_uint2(0, 0);
+                    if (i < ncur) rg = cur.get(i);
+                    {
+                        const bool one = i < ncur && rg.y == 1;
+                        RNode n{0, 0, 0, 0};
+                        if (one) {
+                            n = load_rnode(r.ix, rg.x);
+                            visits += vinc;
+                        }
+                        emit(one && (n.child_count & RN_TERM), n.sub_begin, 1);
+                    }
+                    unsigned long long big = __ballot(i < ncur && rg.y > 1);
+                    while (big) {
+                        const int src = __ffsll((long long)big) - 1;
+                        big &= big - 1;
+                        const uint32_t b = __shfl(rg.x, src), c = __shfl(rg.y, src);
+                        for (uint32_t j0 = 0; j0 < c; j0 += 64) {
+                            const uint32_t j = j0 + lane;
+                            RNode n{0, 0, 0, 0};
+                            if (j < c) {
+                                n = load_rnode(r.ix, b + j);
+                                visits += vinc;
+                            }
+                            emit(j < c && (n.child_count & RN_TERM), n.sub_begin, 1);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                np_total = wp;
+                nr_total = nr;
+                if (lane == 0 && wp) base = atomicAdd(&a.ctr->pair_alloc, (unsigned long long)wp);
+                base = __shfl(base, 0);
+                if (base + wp > a.pair_cap) {
+                    if (lane == 0) atomicOr(&a.ctr->status, ST_NEED_PAIRS);
+                    break;
+                }
+                if (wp == 0) break;
+            }
+        }
+        if (lane == 0) {
+            a.pair_off[f] = (uint32_t)base;
+            a.pair_cnt[f] = np_total;
+            a.route_cnt[f] = nr_total;
+            if (nr_total) atomicAdd(&a.wave_sums[f >> 6], (unsigned long long)nr_total);
+            if (np_total) atomicAdd(&a.ctr->n_ranges, (unsigned long long)np_total);
+            atomicAdd(&a.ctr->topic_bytes, (unsigned long long)(end - beg));
+        }
+        __syncthreads();
+    }
+    const unsigned long long wv = wave_sum_u64(visits);
+    if (lane == 0 && wv) atomicAdd(&a.ctr->n_visit, wv);
+}
+
+} // namespace bmq

@@ -227,6 +227,60 @@ class Engine:
         self._check(_lib.lib().bmq_stats_get(self.h, C.byref(out)))
         return out
 
+    # ---- retain direction (IRetainTopicIndex, RS/index/IRetainTopicIndex.java:27-35) --------------------------------
+    def retain_rebuild(self, tenants: Sequence, topic_tenant, topics: Sequence = (), packed_topics=None):
+        """Load the retained-topic index; topic id = rank of (tenant, level list)."""
+        tdata, toff = pack(tenants)
+        pdata, poff = pack(topics) if packed_topics is None else packed_topics
+        tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
+        self._check(_lib.lib().bmq_retain_rebuild(self.h, _ptr(tdata), _ptr(toff), len(toff) - 1, _ptr(tt), _ptr(pdata),
+                                                  _ptr(poff), len(poff) - 1))
+        return self
+
+    def retain_apply(self, tenant, ops: Sequence[Tuple[int, str]]):
+        """ops: (0 = add | 1 = remove, topic) -- IRetainTopicIndex.add / remove"""
+        t = _b(tenant)
+        data, off = pack([tp for _, tp in ops])
+        op = np.array([o for o, _ in ops], dtype=np.uint8)
+        self._check(_lib.lib().bmq_retain_apply(self.h, t, len(t), _ptr(data), _ptr(off), _ptr(op), len(ops)))
+        return self
+
+    def retain_topic(self, topic_id: int) -> Tuple[str, str]:
+        buf = C.create_string_buffer(140000)
+        n, tl = C.c_uint32(), C.c_uint32()
+        self._check(_lib.lib().bmq_retain_topic(self.h, topic_id, buf, len(buf), C.byref(n), C.byref(tl)))
+        raw = buf.raw[:n.value]
+        return raw[:tl.value].decode(), raw[tl.value:].decode()
+
+    def retain_match_batch(self, tenants: Sequence, filter_tenant, filters: Sequence = (), packed_filters=None):
+        """Batch of IRetainTopicIndex.match(tenant, topicFilter) -> (row_ptr[n+1], topic ids ascending per row)."""
+        tdata, toff = pack(tenants)
+        pdata, poff = pack(filters) if packed_filters is None else packed_filters
+        n = len(poff) - 1
+        ft = np.ascontiguousarray(filter_tenant, dtype=np.uint32)
+        row = np.zeros(n + 1, dtype=np.uint32)
+        cap = max(1024, 16 * n)
+        need = C.c_uint64()
+        while True:
+            ids = np.zeros(cap, dtype=np.uint32)
+            rc = _lib.lib().bmq_retain_match_batch(self.h, _ptr(tdata), _ptr(toff), len(toff) - 1, _ptr(ft), _ptr(pdata),
+                                                   _ptr(poff), n, _ptr(row), _ptr(ids), cap, C.byref(need))
+            if rc == -3 and need.value > cap:
+                cap = need.value
+                continue
+            self._check(rc)
+            return row, ids[:need.value]
+
+    def retain_match(self, tenant, topic_filter) -> List[int]:
+        row, ids = self.retain_match_batch([tenant], [0], [topic_filter])
+        return ids.tolist()
+
+    def retain_match_batch_device(self, d_tenants, d_tenant_off, n_tenants, d_filter_tenant, d_filters, d_filter_off,
+                                  n_filters, d_row_ptr, d_ids, capacity, d_total):
+        self._check(_lib.lib().bmq_retain_match_batch_dev(self.h, d_tenants, d_tenant_off, n_tenants, d_filter_tenant,
+                                                          d_filters, d_filter_off, n_filters, d_row_ptr, d_ids, capacity,
+                                                          d_total))
+
     @property
     def stream(self) -> int:
         return _lib.lib().bmq_stream(self.h) or 0

@@ -51,8 +51,8 @@ typedef struct bmq_engine bmq_engine;
 typedef struct bmq_config {
     uint32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = host-only engine (build/inspect, no match)      */
-    uint32_t wave_queue_cap;   /* per-wave LDS work ring, items (default 512; pow2 in 256..4096)           */
-    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 256; 128..4096)      */
+    uint32_t wave_queue_cap;   /* per-wave LDS work ring, items (default 1024; pow2 in 256..4096)          */
+    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 512; 128..4096)      */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t reserved[8];
 } bmq_config;
@@ -166,8 +166,10 @@ int bmq_retain_rebuild(bmq_engine* e, const uint8_t* tenants, const uint32_t* te
 /* IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134). */
 int bmq_retain_apply(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics,
                      const uint32_t* topic_off, const uint8_t* op, uint32_t n);
+/* id -> retained topic: out receives the tenant id followed by the topic (no separator), *out_tenant_len bytes of
+ * tenant, *out_len bytes in total. */
 int bmq_retain_topic(const bmq_engine* e, uint32_t topic_id, uint8_t* out, uint32_t cap, uint32_t* out_len,
-                     uint32_t* out_tenant_idx);
+                     uint32_t* out_tenant_len);
 /* Batch of IRetainTopicIndex.match(tenant, topicFilter) (RS/index/RetainTopicIndex.java:136-138; selector
  * :36-124; walk UTIL/index/TopicLevelTrie.java:190-249).  Output CSR of topic ids (ascending per row). */
 int bmq_retain_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,

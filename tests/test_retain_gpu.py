@@ -1,0 +1,104 @@
+"""GPU parity tests of the retain direction (wildcard filters against the retained-topic index) vs the oracle's
+restatement of TopicLevelTrie.lookup + RetainMatcher.  Golden tables: RST/index/RetainTopicIndexTest.java:42-76."""
+import random
+
+import numpy as np
+import pytest
+
+import bifromq_amd as B
+from bifromq_amd.workload import unpack
+from oracle import oracle as O
+from oracle import semantic as S
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_oracle_golden import INDEX_ROWS, RETAIN_TOPICS, TOPIC_INDEX_EXTRA_ROWS
+
+TOPICS = RETAIN_TOPICS
+# RST/index/RetainTopicIndexTest.java:42-76,113-117 (filter -> matched topics), as ported for the oracle
+TABLE = dict(INDEX_ROWS + TOPIC_INDEX_EXTRA_ROWS + [("+/b", ["/b", "a/b"]), ("nope/#", []), ("a/b/c/d", [])])
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = B.Engine(device=0)
+    yield e
+    e.close()
+
+
+def test_golden_table(eng):
+    eng.retain_rebuild(["tenantA", "tenantB"], [0] * len(TOPICS) + [1], TOPICS + ["a"])
+    ids = {eng.retain_topic(i): i for i in range(len(TOPICS) + 1)}
+    assert len(ids) == len(TOPICS) + 1
+    lt = O.LevelTrie(1)
+    for (tenant, topic), i in ids.items():
+        lt.add(tenant, topic, i)
+    for f, exp in TABLE.items():
+        got = eng.retain_match("tenantA", f)
+        assert sorted(eng.retain_topic(i)[1] for i in got) == sorted(exp), f
+        assert got == sorted(lt.match("tenantA", f)), f
+        assert got == sorted(got)
+    assert [eng.retain_topic(i) for i in eng.retain_match("tenantB", "#")] == [("tenantB", "a")]
+    assert eng.retain_match("ghost", "#") == []
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_parity(eng, seed):
+    rnd = random.Random(seed)
+    tenants = ["tA", "tB"]
+    topics = sorted({(rnd.randrange(2), U.rand_topic(rnd, 5)) for _ in range(5000)})
+    eng.retain_rebuild(tenants, [t for t, _ in topics], [p for _, p in topics])
+    lt = O.LevelTrie(1)
+    n = len(topics)
+    for i in range(n):
+        tn, tp = eng.retain_topic(i)
+        lt.add(tn, tp, i)
+    filters = [U.rand_filter(rnd, 6) for _ in range(3000)] + ["#", "+", "+/#", "+/+", "/", "", "$sys/#", "$sys/+", "a/+/#"]
+    ft = [rnd.randrange(3) for _ in filters]
+    tnames = tenants + ["ghost"]
+    row, ids = eng.retain_match_batch(tnames, ft, filters)
+    got = U.csr_rows(row, ids)
+    for i, f in enumerate(filters):
+        exp = sorted(lt.match(tnames[ft[i]], f))
+        assert got[i] == exp, (f, tnames[ft[i]])
+    # independent semantic check on a sample: retained topic matches iff the MQTT rule says so
+    for i in range(0, len(filters), 11):
+        if filters[i].count("#") > 1 or ("#" in filters[i][:-1]):
+            continue
+        exp = [k for k in range(n) if eng.retain_topic(k)[0] == tnames[ft[i]] and S.matches(eng.retain_topic(k)[1], filters[i])]
+        assert got[i] == exp, filters[i]
+
+
+def test_generated_workload_parity(eng):
+    """config 4 shape at an oracle-friendly size: literal retained topics, wildcard query filters."""
+    w = B.Workload(0xB1F20004, 4, 1, 0)
+    data, off, tt = w.retain(0xB1F20004, 60000, filters=False)
+    tn = w.tenants()
+    eng.retain_rebuild(tn, tt, packed_topics=(data, off))
+    lt = O.LevelTrie(1)
+    seen = set()
+    i = 0
+    while True:
+        try:
+            tenant, topic = eng.retain_topic(i)
+        except B.BmqError:
+            break
+        assert (tenant, topic) not in seen
+        seen.add((tenant, topic))
+        lt.add(tenant, topic, i)
+        i += 1
+    assert i == len({(int(t), p) for t, p in zip(tt, unpack(data, off))})
+    fdata, foff, ft = w.retain(0xB1F20004 + 1, 20000, filters=True)
+    row, ids = eng.retain_match_batch(tn, ft, packed_filters=(fdata, foff))
+    res, _ = lt.match_batch(tn, ft, (fdata, foff), threads=8)
+    assert U.csr_rows(row, ids) == [sorted(r) for r in res.per_topic()]
+    assert (np.diff(row.astype(np.int64)) >= 0).all()
+
+
+def test_apply_add_remove(eng):
+    eng.retain_rebuild(["t"], [0, 0, 0], ["a/b", "a/c", "x"])
+    assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "a/+")] == ["a/b", "a/c"]
+    eng.retain_apply("t", [(1, "a/b"), (0, "a/d"), (0, "a/c"), (1, "zzz")])
+    assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "a/+")] == ["a/c", "a/d"]
+    assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "#")] == ["a/c", "a/d", "x"]
