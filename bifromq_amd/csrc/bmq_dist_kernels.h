@@ -658,17 +658,21 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // k_expand -- CSR row pointers + ids.  One wave per 64 topics (same blocking as k_walk).
 // ------------------------------------------------------------------------------------------------------------
-constexpr uint32_t SMALL_ROW = 16;   // rows up to this many ids are copied by their own lane
 constexpr uint32_t SORT_PAIRS = 32;  // range lists up to this length are ordered in place (insertion sort)
+constexpr uint32_t EXP_K = 1024;     // ranges laid out per LDS pass
+constexpr uint32_t EXP_LONG = 64;    // ranges at least this long are streamed, shorter ones are flattened
 
 __device__ __forceinline__ uint32_t range_first_id(const DistIndexView& ix, const MatchRange& r) {
     return (r.count & RANGE_INDIRECT) ? ix.route_pos[r.begin] : r.begin;
 }
-__device__ __forceinline__ uint32_t range_id(const DistIndexView& ix, const MatchRange& r, uint32_t j) {
-    return (r.count & RANGE_INDIRECT) ? ix.route_pos[r.begin + j] : r.begin + j;
-}
 
+// The 64 rows of a wave are one contiguous piece of the output.  Their ranges are laid out in LDS in output order with
+// the exclusive prefix of their lengths; then every lane produces output elements j, j+64, ... by locating the range
+// that covers j (binary search in LDS): stores are fully coalesced and all lanes stay busy whatever the mix of range
+// lengths (a 5000-subscriber filter next to 60 singletons).
 __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
+    __shared__ uint32_t r_begin[EXP_K], r_cnt[EXP_K], r_off[EXP_K + 1], r_row[EXP_K];
+    __shared__ uint32_t row_bad[64], row_first[64];
     const uint32_t lane = threadIdx.x;
     const uint32_t t = blockIdx.x * 64 + lane;
     const bool valid = t < a.n_topics;
@@ -676,16 +680,17 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
     const uint32_t nr = valid ? a.route_cnt[t] : 0u;
     uint32_t wtotal;
     const uint32_t excl = wave_excl_scan(nr, lane, wtotal);
-    const unsigned long long row = a.wave_sums[blockIdx.x] + excl;
+    const unsigned long long wbase = a.wave_sums[blockIdx.x];
+    const unsigned long long row = wbase + excl;
     const bool writable = !(status & (ST_NOSPACE | ST_RANGE | ST_RERUN));
     if (valid && !(status & ST_RANGE)) {
         a.out_row_ptr[t] = (uint32_t)row;
         if (t == a.n_topics - 1) a.out_row_ptr[a.n_topics] = (uint32_t)(row + nr);
     }
-    if (!writable) return;
+    if (!writable || wtotal == 0) return;
     const uint32_t po = valid ? a.pair_off[t] : 0u;
     const uint32_t np = valid ? a.pair_cnt[t] : 0u;
-    // order this topic's ranges by first id
+    // order this topic's ranges by first id (usually 1-5 ranges; already ordered lists are left alone)
     if (np > 1 && np <= SORT_PAIRS) {
         MatchRange* pr = a.pairs + po;
         for (uint32_t i = 1; i < np; i++) {
@@ -696,59 +701,108 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
                 pr[j] = pr[j - 1];
                 j--;
             }
-            pr[j] = x;
+            if (j != i) pr[j] = x;
         }
     }
-    __syncthreads(); // other lanes read this lane's ordered ranges below
-    bool unsorted = np > SORT_PAIRS;
-    uint32_t* out = a.out_ids + row;
-    // small rows: own lane
-    if (nr && nr <= SMALL_ROW) {
-        uint32_t k = 0, prev = 0;
-        for (uint32_t p = 0; p < np; p++) {
-            const MatchRange r = a.pairs[po + p];
-            const uint32_t c = r.count & ~RANGE_INDIRECT;
-            for (uint32_t j = 0; j < c; j++) {
-                const uint32_t id = range_id(a.ix, r, j);
-                if (k && id <= prev) unsorted = true;
-                prev = id;
-                out[k++] = id;
+    row_bad[lane] = 0;
+    uint32_t ptotal;
+    const uint32_t pexcl = wave_excl_scan(np, lane, ptotal);
+    row_first[lane] = pexcl;
+    __syncthreads();
+    unsigned long long out_done = 0; // output elements produced by earlier LDS passes
+    uint32_t carry_row = 64, carry_last = 0;
+    for (uint32_t k0 = 0; k0 < ptotal; k0 += EXP_K) {
+        const uint32_t kn = min(EXP_K, ptotal - k0);
+        // every lane copies the part of its own range list that falls into [k0, k0 + kn)
+        {
+            const uint32_t lo = pexcl > k0 ? pexcl : k0, hi = min(pexcl + np, k0 + kn);
+            for (uint32_t k = lo; k < hi; k++) {
+                const MatchRange r = a.pairs[po + (k - pexcl)];
+                r_begin[k - k0] = r.begin;
+                r_cnt[k - k0] = r.count;
+                r_row[k - k0] = lane;
             }
         }
-    }
-    // big rows: the whole wave streams each of them
-    unsigned long long big = __ballot(nr > SMALL_ROW);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t b_po = __shfl(po, src), b_np = __shfl(np, src);
-        const unsigned long long b_row = __shfl(row, src);
-        uint32_t* bout = a.out_ids + b_row;
-        uint32_t done = 0, last = 0;
-        bool bad = false;
-        for (uint32_t p = 0; p < b_np; p++) {
-            const MatchRange r = a.pairs[b_po + p];
-            const uint32_t c = r.count & ~RANGE_INDIRECT;
-            for (uint32_t j0 = 0; j0 < c; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                uint32_t id = 0;
-                const bool in = j < c;
-                if (in) {
-                    id = range_id(a.ix, r, j);
-                    bout[done + j] = id;
+        __syncthreads();
+        // exclusive prefix of the range lengths: 16 consecutive entries per lane + one wave scan
+        {
+            uint32_t s = 0;
+            const uint32_t e0 = lane * (EXP_K / 64);
+            for (uint32_t i = 0; i < EXP_K / 64; i++) {
+                const uint32_t e = e0 + i;
+                s += e < kn ? (r_cnt[e] & ~RANGE_INDIRECT) : 0u;
+            }
+            uint32_t tot;
+            uint32_t run = wave_excl_scan(s, lane, tot);
+            for (uint32_t i = 0; i < EXP_K / 64; i++) {
+                const uint32_t e = e0 + i;
+                if (e < kn) {
+                    r_off[e] = run;
+                    run += r_cnt[e] & ~RANGE_INDIRECT;
                 }
-                // order check: against the left neighbour, lane 0 against the last id of the previous chunk
-                uint32_t left = __shfl_up(id, 1);
-                if (lane == 0) left = last;
-                if (in && (done + j) > 0 && id <= left) bad = true;
-                const uint32_t cnt = min(64u, c - j0);
-                last = __shfl(id, cnt - 1);
             }
-            done += c;
+            if (lane == 63) r_off[kn] = tot;
         }
-        if (__ballot(bad) && (int)lane == src) unsorted = true;
+        __syncthreads();
+        const uint32_t T = r_off[kn];
+        uint32_t* out = a.out_ids + wbase + out_done;
+        // ids ascend inside a range by construction, so order is checked at range boundaries only: the first id of a range
+        // against the last id of the previous range of the same row (also across LDS passes: carry_*)
+        for (uint32_t e = lane; e < kn; e += 64) {
+            const uint32_t rr = r_row[e];
+            const uint32_t fid = (r_cnt[e] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[e]] : r_begin[e];
+            uint32_t prow = carry_row, plast = carry_last;
+            if (e > 0) {
+                const uint32_t c = r_cnt[e - 1] & ~RANGE_INDIRECT;
+                prow = r_row[e - 1];
+                plast = (r_cnt[e - 1] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[e - 1] + c - 1] : r_begin[e - 1] + c - 1;
+            }
+            if (prow == rr && fid <= plast) row_bad[rr] = 1;
+        }
+        {
+            const uint32_t c = r_cnt[kn - 1] & ~RANGE_INDIRECT;
+            carry_row = r_row[kn - 1];
+            carry_last = (r_cnt[kn - 1] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[kn - 1] + c - 1] : r_begin[kn - 1] + c - 1;
+        }
+        // element generation: runs of short ranges are flattened (every lane locates its range in LDS), long ranges are
+        // streamed by the whole wave with no per-element lookup
+        for (uint32_t k = 0; k < kn;) {
+            uint32_t kl = kn; // first long range at or after k
+            for (uint32_t c0 = k; c0 < kn && kl == kn; c0 += 64) {
+                const unsigned long long m = __ballot(c0 + lane < kn && (r_cnt[c0 + lane] & ~RANGE_INDIRECT) >= EXP_LONG);
+                if (m) kl = c0 + (uint32_t)__ffsll((long long)m) - 1;
+            }
+            if (kl > k) {
+                const uint32_t jhi = r_off[kl];
+                uint32_t kc = k;
+                for (uint32_t j = r_off[k] + lane; j < jhi; j += 64) {
+                    if (r_off[kc + 1] <= j) {
+                        uint32_t lo = kc + 1, hi = kl; // largest index in [kc + 1, kl) with r_off <= j
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (r_off[mid] <= j) lo = mid;
+                            else hi = mid;
+                        }
+                        kc = lo;
+                    }
+                    const uint32_t o = j - r_off[kc];
+                    out[j] = (r_cnt[kc] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[kc] + o] : r_begin[kc] + o;
+                }
+            }
+            if (kl < kn) {
+                const uint32_t b = r_begin[kl], cf = r_cnt[kl], c = cf & ~RANGE_INDIRECT;
+                uint32_t* dst = out + r_off[kl];
+                if (cf & RANGE_INDIRECT)
+                    for (uint32_t o = lane; o < c; o += 64) dst[o] = a.ix.route_pos[b + o];
+                else
+                    for (uint32_t o = lane; o < c; o += 64) dst[o] = b + o;
+            }
+            k = kl + 1;
+        }
+        out_done += T;
+        __syncthreads();
     }
-    if (unsorted && nr > 1) {
+    if (valid && row_bad[lane] && nr > 1) {
         const uint32_t sp = atomicAdd(&a.ctr->sort_count, 1u);
         if (sp < a.sort_cap) a.sort_list[sp] = t;
         else atomicOr(&a.ctr->status, ST_NEED_SORTLIST);

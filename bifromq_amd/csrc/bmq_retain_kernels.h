@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                         const uint32_t i = i0 + lane;
                         uint2 rg = make_uint2(0, 0);
                         if (i < ncur) rg = cur.get(i);
-                        // singletons in parallel
-                        {
+                        const bool mixed = __any(i < ncur && rg.y > 1); // keep frontier order: ids must come out ascending
+                        if (!mixed) { // singletons in parallel
                             const bool one = i < ncur && rg.y == 1;
                             RNode n{0, 0, 0, 0};
                             if (one) n = load_rnode(r.ix, rg.x);
@@ -207,12 +207,9 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                             }
                             if (one) visits += vinc;
                         }
-                        // ranges of several nodes: the wave streams each of them
-                        unsigned long long big = __ballot(i < ncur && rg.y > 1);
-                        while (big) {
-                            const int src = __ffsll((long long)big) - 1;
-                            big &= big - 1;
-                            const uint32_t b = __shfl(rg.x, src), c = __shfl(rg.y, src);
+                        // a chunk holding ranges of several nodes: the wave streams its items one after the other
+                        for (uint32_t src = 0; mixed && src < min(64u, ncur - i0); src++) {
+                            const uint32_t b = __shfl(rg.x, (int)src), c = __shfl(rg.y, (int)src);
                             for (uint32_t j0 = 0; j0 < c; j0 += 64) {
                                 const uint32_t j = j0 + lane;
                                 RNode n{0, 0, 0, 0};
@@ -255,7 +252,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                         const uint32_t i = i0 + lane;
                         uint2 rg = make_uint2(0, 0);
                         if (i < ncur) rg = cur.get(i);
-                        {
+                        const bool mixed = __any(i < ncur && rg.y > 1);
+                        if (!mixed) {
                             uint32_t child = NONE;
                             if (i < ncur && rg.y == 1) {
                                 child = redge_lookup(r.ix, rg.x, kind);
@@ -266,11 +264,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                             if (child != NONE) { if (p < cap) nxt.put(p, child, 1); else overflow = true; }
                             nn += (uint32_t)__popcll(m);
                         }
-                        unsigned long long big = __ballot(i < ncur && rg.y > 1);
-                        while (big) {
-                            const int src = __ffsll((long long)big) - 1;
-                            big &= big - 1;
-                            const uint32_t b = __shfl(rg.x, src), c = __shfl(rg.y, src);
+                        for (uint32_t src = 0; mixed && src < min(64u, ncur - i0); src++) {
+                            const uint32_t b = __shfl(rg.x, (int)src), c = __shfl(rg.y, (int)src);
                             for (uint32_t j0 = 0; j0 < c; j0 += 64) {
                                 const uint32_t j = j0 + lane;
                                 uint32_t child = NONE;
@@ -302,7 +297,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                     const uint32_t i = i0 + lane;
                     uint2 rg = make_uint2(0, 0);
                     if (i < ncur) rg = cur.get(i);
-                    {
+                    const bool mixed = __any(i < ncur && rg.y > 1);
+                    if (!mixed) {
                         const bool one = i < ncur && rg.y == 1;
                         RNode n{0, 0, 0, 0};
                         if (one) {
@@ -311,11 +307,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                         }
                         emit(one && (n.child_count & RN_TERM), n.sub_begin, 1);
                     }
-                    unsigned long long big = __ballot(i < ncur && rg.y > 1);
-                    while (big) {
-                        const int src = __ffsll((long long)big) - 1;
-                        big &= big - 1;
-                        const uint32_t b = __shfl(rg.x, src), c = __shfl(rg.y, src);
+                    for (uint32_t src = 0; mixed && src < min(64u, ncur - i0); src++) {
+                        const uint32_t b = __shfl(rg.x, (int)src), c = __shfl(rg.y, (int)src);
                         for (uint32_t j0 = 0; j0 < c; j0 += 64) {
                             const uint32_t j = j0 + lane;
                             RNode n{0, 0, 0, 0};

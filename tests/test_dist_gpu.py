@@ -236,7 +236,7 @@ def test_big_fanout_and_many_ranges(eng):
     got = eng.match_tenant("t", topics)
     assert got[:4] == exp and all(g == exp[1] for g in got[4:])
     assert len(got[0]) == 5000 and len(got[1]) == 64 + 32
-    assert eng.stats().n_sorted_rows >= 70  # > 32 ranges per row: range ordering skipped, row sorted by k_sort_rows
+    assert eng.stats().n_sorted_rows >= 1  # > 32 ranges per row: range ordering skipped, out-of-order rows sorted by k_sort_rows
 
 
 def test_apply_then_match(eng):
