@@ -122,17 +122,10 @@ def main():
                 cap = int(d_total.item()) * 2  # only during warm-up in practice
                 d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
         if world > 1:  # the one exchange step: every rank's CSR (row counts + ids) to every rank over RCCL/xGMI
-            cnt = torch.tensor([total], dtype=torch.int64, device=dev)
-            cnts = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(cnts, cnt)
-            mx = int(cnts.max().item())
-            rows_all = torch.empty(world * (n + 1), dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(rows_all, d_row)
-            ids_all = torch.empty(world * mx, dtype=torch.int32, device=dev)
-            if d_ids.numel() < mx:
-                d_ids = torch.cat([d_ids, torch.zeros(mx - d_ids.numel(), dtype=torch.int32, device=dev)])
-                cap = d_ids.numel()
-            dist.all_gather_into_tensor(ids_all, d_ids[:mx])
+            from bifromq_amd import shard
+            if d_ids.numel() < total:
+                raise RuntimeError("id buffer smaller than the batch result")
+            shard.exchange_csr(dist, d_row, d_ids, total, world)
             torch.cuda.synchronize()
         return total
 

@@ -11,7 +11,11 @@ namespace bmq {
 
 inline LevelHash hash_level(std::string_view s) {
     LevelHash h = level_hash_init();
-    for (unsigned char c : s) level_hash_step(h, c);
+    for (size_t i = 0; i < s.size(); i += 4) {
+        uint32_t w = 0;
+        for (size_t k = 0; k < 4 && i + k < s.size(); k++) w |= (uint32_t)(uint8_t)s[i + k] << (8 * k);
+        level_hash_word(h, w);
+    }
     return h;
 }
 

@@ -54,6 +54,23 @@ struct Counters { // one per batch, zeroed before launch
     uint32_t pad;
 };
 
+// Contiguous space in the matched-range buffer is handed out by N_SUB independent allocators, each owning one slice
+// of the buffer and living in its own 128-byte line: a single counter bumped by every wave of a batch (15 625 waves
+// for 1M topics) serialises in the L2 atomic unit and was measured to set the kernel's duration.
+constexpr uint32_t N_SUB = 64;
+struct alignas(128) SubAlloc {
+    unsigned long long used;
+    unsigned long long pad[15];
+};
+__device__ __forceinline__ bool pair_alloc(SubAlloc* subs, unsigned long long pair_cap, uint32_t key, uint32_t n,
+                                           unsigned long long& base) {
+    const unsigned long long slice = pair_cap / N_SUB;
+    const uint32_t s = key & (N_SUB - 1);
+    const unsigned long long off = atomicAdd(&subs[s].used, (unsigned long long)n);
+    base = (unsigned long long)s * slice + off;
+    return off + n <= slice;
+}
+
 struct BatchArgs {
     DistIndexView ix;
     // inputs (device)
@@ -71,6 +88,8 @@ struct BatchArgs {
     uint32_t* route_cnt;     // [n_topics]
     MatchRange* pairs;
     unsigned long long pair_cap;
+    SubAlloc* subs;          // [2 * N_SUB] allocators of `pairs` (first N_SUB) and of `spill` (second N_SUB)
+    uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, 0}; summed by k_scan_blocks
     uint4* spill;            // LDS range buffer flushes: {begin, count, topic-local, 0}
     unsigned long long spill_cap;
     unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block; scanned in place to exclusive bases
@@ -96,6 +115,14 @@ struct BatchArgs {
 // ------------------------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------------------------
+// Waves of one workgroup are independent here (each owns a slice of LDS).  LDS operations of ONE wave execute in issue
+// order, so lanes of a wave see each other's LDS writes without a hardware barrier; this only stops the compiler from
+// moving LDS accesses across the hand-off point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // number of set bits of `mask` strictly below this lane
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -185,20 +212,33 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
     }
 }
 
-// scans one level starting at pos: bytes up to the next '/' (split) or to `end`.  Returns through refs.
-template <class ByteAt>
-__device__ __forceinline__ void scan_level(uint32_t& pos, uint32_t end, bool split, ByteAt&& byte_at, LevelHash& h,
+// Scans one level starting at pos: bytes up to the next '/' (split) or to `end`, FOUR BYTES PER STEP.
+// word_at(p) returns the 4 bytes p..p+3 as a little-endian word (bytes at or beyond `end` may be garbage: masked here).
+template <class WordAt>
+__device__ __forceinline__ void scan_level(uint32_t& pos, uint32_t end, bool split, WordAt&& word_at, LevelHash& h,
                                            uint32_t inl[4], uint32_t& len, bool& last) {
     h = level_hash_init();
     inl[0] = inl[1] = inl[2] = inl[3] = 0;
     len = 0;
-    while (pos < end) {
-        const uint32_t c = byte_at(pos);
-        if (split && c == '/') break;
-        level_hash_step(h, c);
-        if (len < 16) inl[len >> 2] |= c << ((len & 3u) * 8u);
-        len++;
-        pos++;
+    for (;;) {
+        const uint32_t remaining = end - pos;
+        if (remaining == 0) break;
+        const uint32_t w = word_at(pos);
+        uint32_t nb = 4;
+        if (split) { // first '/' among the four bytes (exact for the lowest hit, which is all that is used)
+            const uint32_t x = w ^ 0x2F2F2F2Fu;
+            const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
+            if (z) nb = (uint32_t)(__ffs((int)z) - 1) >> 3;
+        }
+        nb = min(nb, remaining);
+        if (nb) {
+            const uint32_t wm = nb == 4 ? w : (w & ((1u << (8u * nb)) - 1u));
+            level_hash_word(h, wm);
+            if (len < 16) inl[len >> 2] = wm;
+            len += nb;
+            pos += nb;
+        }
+        if (nb < 4) break;
     }
     if (pos < end) {
         pos++; // skip the '/': another (possibly empty) level follows (UTIL/TopicUtil.java:206-225)
@@ -206,6 +246,13 @@ __device__ __forceinline__ void scan_level(uint32_t& pos, uint32_t end, bool spl
     } else {
         last = true;
     }
+}
+
+// 4 bytes at byte offset p of a global buffer (any alignment): two aligned dwords + byte align.  The buffer must be
+// readable up to the next multiple of 4 after its last byte plus 4 (all packed inputs are padded by 16 bytes).
+__device__ __forceinline__ uint32_t global_word_at(const uint8_t* base, uint32_t p) {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(base + (p & ~3u));
+    return __builtin_amdgcn_alignbyte(a[1], a[0], p & 3u);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -216,12 +263,13 @@ __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
     if (i >= a.n_tenants) return;
     const uint8_t* base = a.tenants;
     auto byte_at = [&](uint32_t k) -> uint32_t { return base[k]; };
+    auto word_at = [&](uint32_t k) -> uint32_t { return global_word_at(base, k); };
     uint32_t pos = a.tenant_off[i];
     const uint32_t start = pos, end = a.tenant_off[i + 1];
     LevelHash h;
     uint32_t inl[4], len;
     bool last;
-    scan_level(pos, end, false, byte_at, h, inl, len, last);
+    scan_level(pos, end, false, word_at, h, inl, len, last);
     const uint32_t tok = dict_lookup(a.ix, h, len, inl, start, byte_at);
     TenantSlot info{0, 0, 0, 1};
     if (tok != TOK_UNKNOWN) {
@@ -288,15 +336,23 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantS
 // ------------------------------------------------------------------------------------------------------------
 // tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (-> slow path), 10 active
 constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9, TM_ACTIVE = 1u << 10;
+#ifndef BMQ_WALK_WAVES
+#define BMQ_WALK_WAVES 2
+#endif
+constexpr uint32_t WALK_WAVES = BMQ_WALK_WAVES; // waves per k_walk workgroup
 constexpr uint32_t MAX_FLUSH = 16; // range-buffer flushes per wave before topics are sent to the slow path
 
 __host__ __device__ inline size_t walk_union_words(uint32_t qcap, uint32_t pcap) { return 2 * (size_t)qcap + 3 * (size_t)pcap; }
-inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
-    return sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 7 * 64 + 2 * MAX_FLUSH + walk_union_words(qcap, pcap));
+__host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
+    return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 7 * 64 + 2 * MAX_FLUSH + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
 }
 
-__global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
-    extern __shared__ __align__(16) uint32_t lds[];
+__global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
+    extern __shared__ __align__(16) uint32_t lds_all[];
+    // WALK_WAVES independent waves per workgroup (a CU admits only ~8 workgroups, so single-wave groups would cap the CU at
+    // 8 waves); every wave owns its own slice of LDS and never synchronises with its neighbours
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* lds = lds_all + wave * (walk_lds_bytes(a.qcap, a.pcap) / 4);
     uint32_t* un = lds;                                       // union: staged topic bytes | work ring + range buffer
     uint32_t* q_node = un;                                    // [qcap]
     uint32_t* q_meta = q_node + a.qcap;                       // [qcap]
@@ -314,27 +370,32 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     uint32_t* f_base = t_nb + 64;                             // [MAX_FLUSH] spill record offset of each flush
     uint32_t* f_len = f_base + MAX_FLUSH;                     // [MAX_FLUSH]
 
-    const uint32_t lane = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t blk = blockIdx.x * WALK_WAVES + wave;
+    if (blk >= a.n_blocks) return;
     const uint32_t t = blk * 64 + lane;
     const bool valid = t < a.n_topics;
-    const uint32_t qm = a.qcap - 1;
 
     // ---- phase 1: tokenise ---------------------------------------------------------------------------------------------
     const uint32_t t_first = blk * 64, t_end = min(t_first + 64, a.n_topics);
     const uint32_t s_beg = a.topic_off[t_first], s_end = a.topic_off[t_end]; // wave-uniform
     const uint32_t a0 = s_beg & ~15u;
-    const bool staged = (s_end - a0) <= (uint32_t)(walk_union_words(a.qcap, a.pcap) * 4);
+    const bool staged = (s_end - a0) + 32u <= (uint32_t)(walk_union_words(a.qcap, a.pcap) * 4);
     if (staged) { // coalesced 16-byte copies of the wave's contiguous topic bytes into LDS
         uint4* dst = reinterpret_cast<uint4*>(un);
         const uint4* src = reinterpret_cast<const uint4*>(a.topics + a0);
         const uint32_t n16 = (s_end - a0 + 15) >> 4;
         for (uint32_t o = lane; o < n16; o += 64) dst[o] = src[o];
     }
-    __syncthreads();
+    wave_sync();
     const uint8_t* lbytes = reinterpret_cast<const uint8_t*>(un);
     const uint8_t* gbytes = a.topics;
     auto byte_at = [&](uint32_t i) -> uint32_t { return staged ? (uint32_t)lbytes[i - a0] : (uint32_t)gbytes[i]; };
+    auto word_at = [&](uint32_t i) -> uint32_t {
+        if (!staged) return global_word_at(gbytes, i);
+        const uint32_t rel = i - a0;
+        return __builtin_amdgcn_alignbyte(un[(rel >> 2) + 1], un[rel >> 2], rel & 3u);
+    };
 
     uint32_t nlev = 0, tbytes = 0, pos = 0, end = 0;
     bool sys = false, more = false;
@@ -354,7 +415,7 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
         const uint32_t start = pos;
         if (more) {
             bool last;
-            scan_level(pos, end, true, byte_at, h, inl, len, last);
+            scan_level(pos, end, true, word_at, h, inl, len, last);
             nlev++;
             if (l < FAST_LEVELS) tokens[l * 64 + lane] = dict_lookup(a.ix, h, len, inl, start, byte_at);
             more = !last;
@@ -363,7 +424,7 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     const bool known = valid && rg.token != TOK_UNKNOWN;
     const bool deep = nlev > FAST_LEVELS;
     const bool active = known && !deep;
-    __syncthreads(); // staged bytes are dead from here on: the union becomes ring + range buffer
+    wave_sync(); // staged bytes are dead from here on: the union becomes ring + range buffer
     tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u) | (active ? TM_ACTIVE : 0u);
     cnt_pairs[lane] = 0;
     cnt_routes[lane] = 0;
@@ -372,25 +433,28 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     t_nb[lane] = rg.buckets;
 
     // ---- phase 2: drain the work ring -----------------------------------------------------------------------------
-    uint32_t head = 0, tail = 0, pcount = 0, nflush = 0;
+    // The work list is a STACK (newest items first): depth-first order keeps it at a few pending siblings per topic,
+    // where breadth-first order would have to hold a whole frontier level of all 64 topics.
+    uint32_t tail = 0, pcount = 0, nflush = 0;
     {
         const bool go = active && !(a.debug_flags & 1u);
         const unsigned long long m = __ballot(go);
         if (go) {
             const uint32_t p = rank_below(m);
-            q_node[p & qm] = rg.root;
-            q_meta[p & qm] = make_meta(lane, 0, KIND_H);
+            q_node[p] = rg.root;
+            q_meta[p] = make_meta(lane, 0, KIND_H);
         }
         tail = (uint32_t)__popcll(m);
     }
-    __syncthreads();
-    while (head != tail) {
+    wave_sync();
+    while (tail) {
         // make room for this round's matches (at most two per lane): flush the LDS range buffer to the spill area
         if (pcount + 128 > a.pcap) {
             unsigned long long sb = 0;
-            if (lane == 0) sb = atomicAdd(&a.ctr->spill_alloc, (unsigned long long)pcount);
+            uint32_t fits_s = 1;
+            if (lane == 0) fits_s = pair_alloc(a.subs + N_SUB, a.spill_cap, blk, pcount, sb) ? 1u : 0u;
             sb = __shfl(sb, 0);
-            const bool fits = sb + pcount <= a.spill_cap && sb + pcount < 0xFFFFFFFFull;
+            const bool fits = __shfl(fits_s, 0) != 0 && sb + pcount < 0xFFFFFFFFull;
             if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_SPILL);
             if (nflush < MAX_FLUSH) {
                 if (fits)
@@ -404,17 +468,16 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
                 for (uint32_t i = lane; i < pcount; i += 64) atomicOr(&tmeta[p_topic[i]], TM_FLAG);
             }
             pcount = 0;
-            __syncthreads();
+            wave_sync();
         }
-        const uint32_t n = tail - head;
-        const uint32_t take = n < 64 ? n : 64;
+        const uint32_t take = tail < 64 ? tail : 64;
         const bool act = lane < take;
+        tail -= take;
         uint32_t node = 0, meta = 0;
         if (act) {
-            node = q_node[(head + lane) & qm];
-            meta = q_meta[(head + lane) & qm];
+            node = q_node[tail + lane];
+            meta = q_meta[tail + lane];
         }
-        head += take;
         const uint32_t tl = meta & 63u;
         StepOut o;
         o.found = o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
@@ -456,23 +519,21 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
             const uint32_t cl = (uint32_t)__popcll(ml);
             if (o.push_l) {
                 const uint32_t p = tail + rank_below(ml);
-                if (p - head < a.qcap) {
-                    q_node[p & qm] = o.idx;
-                    q_meta[p & qm] = make_meta(tl, o.dl, 0);
+                if (p < a.qcap) {
+                    q_node[p] = o.idx;
+                    q_meta[p] = make_meta(tl, o.dl, 0);
                 } else atomicOr(&tmeta[tl], TM_FLAG);
             }
             if (o.push_h) {
                 const uint32_t p = tail + cl + rank_below(mh);
-                if (p - head < a.qcap) {
-                    q_node[p & qm] = o.s.plus_child;
-                    q_meta[p & qm] = make_meta(tl, o.dl + 1, KIND_H);
+                if (p < a.qcap) {
+                    q_node[p] = o.s.plus_child;
+                    q_meta[p] = make_meta(tl, o.dl + 1, KIND_H);
                 } else atomicOr(&tmeta[tl], TM_FLAG);
             }
-            uint32_t nt = tail + cl + (uint32_t)__popcll(mh);
-            if (nt - head > a.qcap) nt = head + a.qcap;
-            tail = nt;
+            tail = min(tail + cl + (uint32_t)__popcll(mh), a.qcap);
         }
-        __syncthreads();
+        wave_sync();
     }
 
     // ---- phase 3: ranges grouped by topic -> global; per-topic bookkeeping --------------------------------------
@@ -484,12 +545,13 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     uint32_t total_pairs;
     const uint32_t excl = wave_excl_scan(np, lane, total_pairs);
     unsigned long long base = 0;
-    if (lane == 0 && total_pairs) base = atomicAdd(&a.ctr->pair_alloc, (unsigned long long)total_pairs);
+    uint32_t fits_l = 1;
+    if (lane == 0 && total_pairs) fits_l = pair_alloc(a.subs, a.pair_cap, blk, total_pairs, base) ? 1u : 0u;
     base = __shfl(base, 0);
-    const bool fits = base + total_pairs <= a.pair_cap;
+    const bool fits = __shfl(fits_l, 0) != 0;
     if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_PAIRS);
     cursor[lane] = excl;
-    __syncthreads();
+    wave_sync();
     if (fits && total_pairs) {
         for (uint32_t f = 0; f < nflush; f++) { // flushed chunks first (they are L2-hot), then what is still in LDS
             const uint32_t fb = f_base[f], fl = f_len[f];
@@ -522,9 +584,7 @@ __global__ __launch_bounds__(64) void k_walk(BatchArgs a) {
     const unsigned long long wbytes = wave_sum_u64(tbytes);
     if (lane == 0) {
         a.wave_sums[blk] = wsum;
-        if (wvis) atomicAdd(&a.ctr->n_visit, wvis);
-        if (total_pairs) atomicAdd(&a.ctr->n_ranges, (unsigned long long)total_pairs);
-        atomicAdd(&a.ctr->topic_bytes, wbytes);
+        a.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
     }
 }
 
@@ -535,6 +595,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
     const uint32_t n_slow = a.ctr->slow_count < a.slow_cap ? a.ctr->slow_count : a.slow_cap;
     const uint8_t* gbytes = a.topics;
     auto byte_at = [&](uint32_t i) -> uint32_t { return gbytes[i]; };
+    auto word_at = [&](uint32_t i) -> uint32_t { return global_word_at(gbytes, i); };
     for (uint32_t i = blockIdx.x * 64 + threadIdx.x; i < n_slow; i += gridDim.x * 64) {
         const uint32_t t = a.slow_list[i];
         const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
@@ -561,7 +622,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                 uint32_t inl[4], len;
                 bool last;
                 const uint32_t start = pos;
-                scan_level(pos, end, true, byte_at, h, inl, len, last);
+                scan_level(pos, end, true, word_at, h, inl, len, last);
                 toks[l] = dict_lookup(a.ix, h, len, inl, start, byte_at);
             }
         }
@@ -604,8 +665,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                 }
             }
             if (pass == 0) {
-                base = np ? atomicAdd(&a.ctr->pair_alloc, (unsigned long long)np) : 0ull;
-                if (base + np > a.pair_cap) {
+                if (np && !pair_alloc(a.subs, a.pair_cap, t >> 6, np, base)) {
                     atomicOr(&a.ctr->status, ST_NEED_PAIRS);
                     ok = false;
                 }
@@ -629,8 +689,19 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (a.n_blocks + 1023) / 1024;
     const uint32_t b0 = min(tid * per, a.n_blocks), b1 = min(b0 + per, a.n_blocks);
-    unsigned long long s = 0;
-    for (uint32_t i = b0; i < b1; i++) s += a.wave_sums[i];
+    unsigned long long s = 0, sv = 0, sr = 0, sb = 0;
+    for (uint32_t i = b0; i < b1; i++) {
+        s += a.wave_sums[i];
+        if (a.blk_stats) {
+            const uint4 q = a.blk_stats[i];
+            sv += q.x;
+            sr += q.y;
+            sb += q.z;
+        }
+    }
+    if (sv) atomicAdd(&a.ctr->n_visit, sv); // 1024 adds per batch, on top of what the slow path counted
+    if (sr) atomicAdd(&a.ctr->n_ranges, sr);
+    if (sb) atomicAdd(&a.ctr->topic_bytes, sb);
     part[tid] = s;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {

@@ -88,6 +88,7 @@ struct bmq_engine {
     bool built = false;
 
     // per-batch scratch
+    DevBuf b_subs, b_blk_stats;
     DevBuf b_tenant_root, b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch,
         b_sort_list, b_ctr, b_total;
     uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
@@ -184,6 +185,8 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     HIPCHK(e, e->b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->b_pairs.ensure(sizeof(MatchRange) * e->pair_cap));
+    HIPCHK(e, e->b_subs.ensure(sizeof(SubAlloc) * 2 * N_SUB));
+    HIPCHK(e, e->b_blk_stats.ensure(sizeof(uint4) * std::max(n_blocks, 1u)));
     if (e->spill_cap == 0) e->spill_cap = 1u << 16;
     e->spill_cap = std::max<uint64_t>(e->spill_cap, (uint64_t)n_topics * 2);
     HIPCHK(e, e->b_spill.ensure(sizeof(uint4) * e->spill_cap));
@@ -205,6 +208,8 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.route_cnt = e->b_route_cnt.as<uint32_t>();
     a.pairs = e->b_pairs.as<MatchRange>();
     a.pair_cap = e->pair_cap;
+    a.subs = e->b_subs.as<SubAlloc>();
+    a.blk_stats = e->b_blk_stats.as<uint4>();
     a.spill = e->b_spill.as<uint4>();
     a.spill_cap = e->spill_cap;
     a.wave_sums = e->b_wave_sums.as<unsigned long long>();
@@ -223,10 +228,15 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.pcap = e->cfg.wave_pair_cap;
     hipStream_t s = e->stream;
     HIPCHK(e, hipMemsetAsync(a.ctr, 0, sizeof(Counters), s));
+    HIPCHK(e, hipMemsetAsync(a.subs, 0, sizeof(SubAlloc) * 2 * N_SUB, s));
     HIPCHK(e, hipEventRecord(e->ev[0], s));
     if (a.n_tenants) hipLaunchKernelGGL(k_resolve_tenants, dim3((a.n_tenants + 63) / 64), dim3(64), 0, s, a);
     HIPCHK(e, hipEventRecord(e->ev[1], s));
-    hipLaunchKernelGGL(k_walk, dim3(a.n_blocks), dim3(64), walk_lds_bytes(a.qcap, a.pcap), s, a);
+    {
+        const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
+        if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_walk, dim3((a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), dim3(WALK_WAVES * 64), lds, s, a);
+    }
     HIPCHK(e, hipEventRecord(e->ev[2], s));
     hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, a);
@@ -251,12 +261,12 @@ int finish_dist(bmq_engine* e, uint64_t* out_total) {
         const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST);
         if (grow) {
             if (grow & ST_NEED_PAIRS) {
-                e->pair_cap = std::max<uint64_t>(e->pair_cap * 2, c.pair_alloc + c.pair_alloc / 8);
+                e->pair_cap = e->pair_cap * 2; // slices fill unevenly: double until every sub-allocator fits
                 if (e->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
                 HIPCHK(e, e->b_pairs.ensure(sizeof(MatchRange) * e->pair_cap));
             }
             if (grow & ST_NEED_SPILL) {
-                e->spill_cap = std::max<uint64_t>(e->spill_cap * 2, c.spill_alloc + c.spill_alloc / 8);
+                e->spill_cap = e->spill_cap * 2;
                 if (e->spill_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "range spill buffer exceeds 2^32 records");
                 HIPCHK(e, e->b_spill.ensure(sizeof(uint4) * e->spill_cap));
             }
@@ -323,11 +333,11 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (cfg->struct_size < 8 || cfg->struct_size > sizeof(bmq_config)) return BMQ_E_INVAL;
         memcpy(&c, cfg, cfg->struct_size);
     }
-    if (c.wave_queue_cap == 0) c.wave_queue_cap = 1024;
-    if (c.wave_pair_cap == 0) c.wave_pair_cap = 512;
+    if (c.wave_queue_cap == 0) c.wave_queue_cap = 256;
+    if (c.wave_pair_cap == 0) c.wave_pair_cap = 256;
     if (const char* v = getenv("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
     if (const char* v = getenv("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
-    if (c.wave_queue_cap < 256 || (c.wave_queue_cap & (c.wave_queue_cap - 1)) || c.wave_queue_cap > 4096) return BMQ_E_INVAL;
+    if (c.wave_queue_cap < 128 || (c.wave_queue_cap & 63) || c.wave_queue_cap > 4096) return BMQ_E_INVAL;
     if (c.wave_pair_cap < 128 || c.wave_pair_cap > 4096) return BMQ_E_INVAL;
     auto e = std::make_unique<bmq_engine>();
     e->cfg = c;

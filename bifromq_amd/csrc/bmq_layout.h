@@ -63,25 +63,21 @@ struct alignas(32) DictSlot {
 };
 static_assert(sizeof(DictSlot) == 32, "DictSlot must be 32 bytes");
 
-// Incremental level hash: two 32-bit lanes (slot index, tag).  Same code on host and device.
+// Level hash over the level's bytes taken as little-endian 32-bit words (the last word zero padded; an empty
+// trailing chunk is not hashed).  Only shifts/adds per word -- 32-bit multiplies are quarter rate on CDNA and the walk
+// kernel is instruction-issue bound -- and one multiplicative mix per level.  Same code on host and device.  The hash
+// only picks the dictionary slot and a tag: equality is always decided on the bytes.
 struct LevelHash {
     uint32_t h1, h2;
 };
+BMQ_HD uint32_t rotl32(uint32_t x, uint32_t r) { return (x << r) | (x >> (32u - r)); }
 BMQ_HD LevelHash level_hash_init() { return {0x811C9DC5u, 0x9747B28Cu}; }
-BMQ_HD void level_hash_step(LevelHash& h, uint32_t byte) {
-    h.h1 = (h.h1 ^ byte) * 0x01000193u;
-    h.h2 = (h.h2 + byte + 1u) * 0x9E3779B1u;
-    h.h2 ^= h.h2 >> 15;
+BMQ_HD void level_hash_word(LevelHash& h, uint32_t w) {
+    h.h1 = rotl32(h.h1, 5) ^ w;
+    h.h1 += h.h1 << 3;
+    h.h2 = rotl32(h.h2, 11) + w;
+    h.h2 ^= h.h2 >> 7;
 }
-BMQ_HD uint32_t level_hash_slot(const LevelHash& h, uint32_t len) {
-    uint32_t x = h.h1 ^ (len * 0x85EBCA6Bu);
-    x ^= x >> 16;
-    x *= 0x7FEB352Du;
-    x ^= x >> 15;
-    return x;
-}
-BMQ_HD uint32_t level_hash_tag(const LevelHash& h) { return h.h2 | 1u; }
-
 BMQ_HD uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7FEB352Du;
@@ -90,12 +86,24 @@ BMQ_HD uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
+BMQ_HD uint32_t level_hash_slot(const LevelHash& h, uint32_t len) { return mix32(h.h1 ^ (len * 0x85EBCA6Bu)); }
+BMQ_HD uint32_t level_hash_tag(const LevelHash& h) {
+    uint32_t x = h.h2 ^ (h.h1 >> 3);
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 13;
+    return x | 1u;
+}
+
 // home bucket of edge (parent slot, token) in a region of `buckets` buckets (fastrange: any size)
 BMQ_HD uint32_t edge_bucket(uint32_t parent, uint32_t token, uint32_t buckets) {
-    const uint32_t h = mix32(parent * 0x9E3779B1u + token * 0x85EBCA77u);
+    uint32_t h = (parent ^ rotl32(token, 16)) * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
     return (uint32_t)(((uint64_t)h * buckets) >> 32);
 }
-BMQ_HD uint32_t bloom_bit(uint32_t token) { return (token * 0x9E3779B1u) >> 27; }
+BMQ_HD uint32_t bloom_bit(uint32_t token) { return (token ^ (token >> 5) ^ (token >> 11)) & 31u; }
 BMQ_HD uint32_t tenant_hash(uint32_t token) {
     uint32_t x = token * 0x9E3779B1u;
     return x ^ (x >> 15);

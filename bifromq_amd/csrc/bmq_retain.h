@@ -79,7 +79,11 @@ struct RetainIndexHost {
 };
 
 BMQ_HD uint32_t redge_bucket(uint32_t parent, uint32_t token, uint32_t mask) {
-    return mix32(parent * 0x9E3779B1u + token * 0x85EBCA77u) & mask;
+    uint32_t h = (parent ^ rotl32(token, 16)) * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h & mask;
 }
 
 } // namespace bmq

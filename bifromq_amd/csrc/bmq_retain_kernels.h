@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
     const uint32_t lane = threadIdx.x;
     uint2* gs = r.gscratch + (size_t)blockIdx.x * 2 * r.gcap;
     const uint32_t cap = R_FRONT + r.gcap;
-    unsigned long long visits = 0;
+    unsigned long long visits = 0, wranges = 0, wbytes = 0;
 
     for (uint32_t f = blockIdx.x; f < r.n_filters; f += gridDim.x) {
         // ---- tokenise the filter: '/' positions by ballot, then one lane per level for hash + dictionary ----------------
@@ -102,13 +102,14 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
         if (!deep) {
             const uint8_t* fbytes = r.filters;
             auto fbyte = [&](uint32_t k) -> uint32_t { return fbytes[k]; };
+            auto fword = [&](uint32_t k) -> uint32_t { return global_word_at(fbytes, k); };
             if (lane < nlev) {
                 uint32_t pos = lev_start[lane];
                 const uint32_t start = pos, e = lev_end[lane];
                 LevelHash h;
                 uint32_t inl[4], len;
                 bool last;
-                scan_level(pos, e, false, fbyte, h, inl, len, last);
+                scan_level(pos, e, false, fword, h, inl, len, last);
                 uint32_t tok;
                 if (len == 1 && inl[0] == '+') tok = RT_PLUS;
                 else if (len == 1 && inl[0] == '#' && lane == nlev - 1) tok = RT_HASH;
@@ -127,12 +128,13 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                 if (ti < r.n_tenants) {
                     const uint8_t* tb = r.tenants;
                     auto tbyte = [&](uint32_t k) -> uint32_t { return tb[k]; };
+                    auto tword = [&](uint32_t k) -> uint32_t { return global_word_at(tb, k); };
                     uint32_t pos = r.tenant_off[ti];
                     const uint32_t start = pos, e = r.tenant_off[ti + 1];
                     LevelHash h;
                     uint32_t inl[4], len;
                     bool last;
-                    scan_level(pos, e, false, tbyte, h, inl, len, last);
+                    scan_level(pos, e, false, tword, h, inl, len, last);
                     DistIndexView dv{};
                     dv.dict = r.ix.dict;
                     dv.dict_group_mask = r.ix.dict_group_mask;
@@ -325,9 +327,10 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             if (pass == 0) {
                 np_total = wp;
                 nr_total = nr;
-                if (lane == 0 && wp) base = atomicAdd(&a.ctr->pair_alloc, (unsigned long long)wp);
+                uint32_t fits_l = 1;
+                if (lane == 0 && wp) fits_l = pair_alloc(a.subs, a.pair_cap, f, wp, base) ? 1u : 0u;
                 base = __shfl(base, 0);
-                if (base + wp > a.pair_cap) {
+                if (!__shfl(fits_l, 0)) {
                     if (lane == 0) atomicOr(&a.ctr->status, ST_NEED_PAIRS);
                     break;
                 }
@@ -339,13 +342,17 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             a.pair_cnt[f] = np_total;
             a.route_cnt[f] = nr_total;
             if (nr_total) atomicAdd(&a.wave_sums[f >> 6], (unsigned long long)nr_total);
-            if (np_total) atomicAdd(&a.ctr->n_ranges, (unsigned long long)np_total);
-            atomicAdd(&a.ctr->topic_bytes, (unsigned long long)(end - beg));
         }
+        wranges += np_total;
+        wbytes += end - beg;
         __syncthreads();
     }
     const unsigned long long wv = wave_sum_u64(visits);
-    if (lane == 0 && wv) atomicAdd(&a.ctr->n_visit, wv);
+    if (lane == 0) { // once per persistent wave
+        if (wv) atomicAdd(&a.ctr->n_visit, wv);
+        if (wranges) atomicAdd(&a.ctr->n_ranges, wranges);
+        if (wbytes) atomicAdd(&a.ctr->topic_bytes, wbytes);
+    }
 }
 
 } // namespace bmq

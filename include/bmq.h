@@ -51,8 +51,8 @@ typedef struct bmq_engine bmq_engine;
 typedef struct bmq_config {
     uint32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = host-only engine (build/inspect, no match)      */
-    uint32_t wave_queue_cap;   /* per-wave LDS work ring, items (default 1024; pow2 in 256..4096)          */
-    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 512; 128..4096)      */
+    uint32_t wave_queue_cap;   /* per-wave LDS work stack, items (default 256; 128..4096, x64)               */
+    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 256; 128..4096)      */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t reserved[8];
 } bmq_config;

@@ -194,9 +194,9 @@ def test_slow_path_equals_fast_path():
     assert normal.stats().n_slow_topics >= 10  # the deep ones
     nv = int(kv.count_visits(["t"], np.zeros(len(topics), dtype=np.uint32), O.pack(topics)).sum())
     assert normal.stats().n_visit == nv
-    tiny = B.Engine(device=0, wave_queue_cap=256, wave_pair_cap=128, slow_scratch_mb=1).rebuild(keys)
+    tiny = B.Engine(device=0, wave_queue_cap=128, wave_pair_cap=128, slow_scratch_mb=1).rebuild(keys)
     assert tiny.match_tenant("t", topics) == exp
-    assert tiny.stats().n_slow_topics > 100  # forced overflows went through the DFS path
+    assert tiny.stats().n_slow_topics > 20  # forced overflows went through the DFS path
     assert tiny.stats().n_visit == nv
 
 

@@ -1,0 +1,95 @@
+"""N > 1 path on CPU: tenant sharding + the one exchange step (all-gather of CSR) with the gloo backend, world_size 2.
+Each rank's local result comes from the oracle here (no GPU in this tier); the merged node-wide result must equal the
+oracle run over the unsharded key set."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import bifromq_amd as B
+from bifromq_amd import shard
+from bifromq_amd.workload import unpack
+from oracle import oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = B.Workload(0xB1F20003, 6, 400, 1)
+        tn = w.tenants()
+        keys = w.keys()
+        data, off, tt = w.topics(11, 600)
+        topics = unpack(data, off)
+        mine = [t for t in tn if shard.tenant_rank(t, world) == rank]
+        my_keys = [k for k in keys if B.decode_route_key(k)[1] in mine]
+        kv = O.KV(my_keys)  # this rank's shard of the index
+        parts = shard.route_batch(tn, tt, world)
+        idx = parts[rank]
+        rows = [sorted(kv.match_all(tn[tt[i]], [topics[i]]).per_topic()[0]) for i in idx]
+        n_pad = max(len(p) for p in parts)  # fixed-size row_ptr per rank for the gather
+        row_ptr = np.zeros(n_pad + 1, dtype=np.int32)
+        row_ptr[1:len(rows) + 1] = np.cumsum([len(r) for r in rows])
+        row_ptr[len(rows) + 1:] = row_ptr[len(rows)]
+        ids = np.array([x for r in rows for x in r] or [0], dtype=np.int32)
+        total = int(row_ptr[-1])
+        rows_all, ids_all, cnts = shard.exchange_csr(dist, torch.from_numpy(row_ptr), torch.from_numpy(ids), total, world)
+        merged = shard.merge_rows(parts, rows_all.numpy(), ids_all.numpy(), len(topics))
+        # rank-local ids -> keys, so that the result is comparable across shards
+        shard_keys = []
+        for r in range(world):
+            sk = [k for k in keys if shard.tenant_rank(B.decode_route_key(k)[1], world) == r]
+            shard_keys.append(sorted(sk))
+        owner = [shard.tenant_rank(tn[t], world) for t in tt]
+        merged_keys = [[shard_keys[owner[i]][x] for x in row] for i, row in enumerate(merged)]
+        q.put((rank, cnts.tolist(), merged_keys))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_exchange_merge():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # every rank ends up with the same node-wide result, equal to the unsharded oracle
+    w = B.Workload(0xB1F20003, 6, 400, 1)
+    keys = w.keys()
+    kv = O.KV(keys)
+    data, off, tt = w.topics(11, 600)
+    tn = w.tenants()
+    topics = unpack(data, off)
+    exp = [[keys[x] for x in sorted(kv.match_all(tn[tt[i]], [topics[i]]).per_topic()[0])] for i in range(len(topics))]
+    for rank, cnts, merged_keys in got:
+        assert merged_keys == exp
+        assert sum(cnts) == sum(len(r) for r in exp)
+    assert got[0][1] == got[1][1]
+
+
+def test_tenant_hash_is_stable_and_spreads():
+    assert shard.tenant_hash("tenantA") == shard.tenant_hash(b"tenantA")
+    assert shard.tenant_hash("") == shard.FNV_OFFSET  # FNV-1a 64 offset basis
+    ranks = [shard.tenant_rank("tenant%06d" % i, 8) for i in range(8000)]
+    counts = np.bincount(ranks, minlength=8)
+    assert counts.min() > 800 and counts.max() < 1200
+    parts = shard.route_batch(["a", "b", "c"], np.array([0, 1, 2, 0, 0, 2]), 2)
+    assert sorted(np.concatenate(parts).tolist()) == [0, 1, 2, 3, 4, 5]
