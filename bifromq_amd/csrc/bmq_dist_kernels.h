@@ -699,9 +699,14 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
             sb += q.z;
         }
     }
-    if (sv) atomicAdd(&a.ctr->n_visit, sv); // 1024 adds per batch, on top of what the slow path counted
-    if (sr) atomicAdd(&a.ctr->n_ranges, sr);
-    if (sb) atomicAdd(&a.ctr->topic_bytes, sb);
+    { // block-reduce the statistics: one add per wave, on top of what the slow path counted
+        const unsigned long long wv = wave_sum_u64(sv), wr = wave_sum_u64(sr), wb = wave_sum_u64(sb);
+        if ((tid & 63u) == 0) {
+            if (wv) atomicAdd(&a.ctr->n_visit, wv);
+            if (wr) atomicAdd(&a.ctr->n_ranges, wr);
+            if (wb) atomicAdd(&a.ctr->topic_bytes, wb);
+        }
+    }
     part[tid] = s;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -730,7 +735,8 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
 // k_expand -- CSR row pointers + ids.  One wave per 64 topics (same blocking as k_walk).
 // ------------------------------------------------------------------------------------------------------------
 constexpr uint32_t SORT_PAIRS = 32;  // range lists up to this length are ordered in place (insertion sort)
-constexpr uint32_t EXP_K = 1024;     // ranges laid out per LDS pass
+constexpr uint32_t EXP_K = 512;      // ranges laid out per LDS pass
+constexpr uint32_t EXP_WAVES = 4;    // independent waves per k_expand workgroup
 constexpr uint32_t EXP_LONG = 64;    // ranges at least this long are streamed, shorter ones are flattened
 
 __device__ __forceinline__ uint32_t range_first_id(const DistIndexView& ix, const MatchRange& r) {
@@ -741,17 +747,25 @@ __device__ __forceinline__ uint32_t range_first_id(const DistIndexView& ix, cons
 // the exclusive prefix of their lengths; then every lane produces output elements j, j+64, ... by locating the range
 // that covers j (binary search in LDS): stores are fully coalesced and all lanes stay busy whatever the mix of range
 // lengths (a 5000-subscriber filter next to 60 singletons).
-__global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
-    __shared__ uint32_t r_begin[EXP_K], r_cnt[EXP_K], r_off[EXP_K + 1], r_row[EXP_K];
-    __shared__ uint32_t row_bad[64], row_first[64];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t t = blockIdx.x * 64 + lane;
+__global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
+    __shared__ uint32_t s_begin[EXP_WAVES][EXP_K], s_cnt[EXP_WAVES][EXP_K], s_off[EXP_WAVES][EXP_K + 8], s_row[EXP_WAVES][EXP_K];
+    __shared__ uint32_t s_bad[EXP_WAVES][64], s_first[EXP_WAVES][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t blk = blockIdx.x * EXP_WAVES + wave; // every wave owns one 64-row block and its own LDS slice
+    if (blk >= a.n_blocks) return;
+    uint32_t* r_begin = s_begin[wave];
+    uint32_t* r_cnt = s_cnt[wave];
+    uint32_t* r_off = s_off[wave];
+    uint32_t* r_row = s_row[wave];
+    uint32_t* row_bad = s_bad[wave];
+    uint32_t* row_first = s_first[wave];
+    const uint32_t t = blk * 64 + lane;
     const bool valid = t < a.n_topics;
     const uint32_t status = a.ctr->status;
     const uint32_t nr = valid ? a.route_cnt[t] : 0u;
     uint32_t wtotal;
     const uint32_t excl = wave_excl_scan(nr, lane, wtotal);
-    const unsigned long long wbase = a.wave_sums[blockIdx.x];
+    const unsigned long long wbase = a.wave_sums[blk];
     const unsigned long long row = wbase + excl;
     const bool writable = !(status & (ST_NOSPACE | ST_RANGE | ST_RERUN));
     if (valid && !(status & ST_RANGE)) {
@@ -779,7 +793,7 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
     uint32_t ptotal;
     const uint32_t pexcl = wave_excl_scan(np, lane, ptotal);
     row_first[lane] = pexcl;
-    __syncthreads();
+    wave_sync();
     unsigned long long out_done = 0; // output elements produced by earlier LDS passes
     uint32_t carry_row = 64, carry_last = 0;
     for (uint32_t k0 = 0; k0 < ptotal; k0 += EXP_K) {
@@ -794,7 +808,7 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
                 r_row[k - k0] = lane;
             }
         }
-        __syncthreads();
+        wave_sync();
         // exclusive prefix of the range lengths: 16 consecutive entries per lane + one wave scan
         {
             uint32_t s = 0;
@@ -814,7 +828,7 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
             }
             if (lane == 63) r_off[kn] = tot;
         }
-        __syncthreads();
+        wave_sync();
         const uint32_t T = r_off[kn];
         uint32_t* out = a.out_ids + wbase + out_done;
         // ids ascend inside a range by construction, so order is checked at range boundaries only: the first id of a range
@@ -871,7 +885,7 @@ __global__ __launch_bounds__(64) void k_expand(BatchArgs a) {
             k = kl + 1;
         }
         out_done += T;
-        __syncthreads();
+        wave_sync();
     }
     if (valid && row_bad[lane] && nr > 1) {
         const uint32_t sp = atomicAdd(&a.ctr->sort_count, 1u);

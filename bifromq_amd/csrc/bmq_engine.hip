@@ -241,7 +241,7 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, a);
     HIPCHK(e, hipEventRecord(e->ev[3], s));
-    hipLaunchKernelGGL(k_expand, dim3(a.n_blocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
     HIPCHK(e, hipEventRecord(e->ev[4], s));
     hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
     HIPCHK(e, hipEventRecord(e->ev[5], s));
