@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="distinct pre-generated batches cycled through")
     ap.add_argument("--ungrouped", action="store_true",
                     help="publishes in random tenant order instead of one DistPack per tenant (BatchDistRequest shape)")
+    ap.add_argument("--churn", type=int, default=0,
+                    help="configs[4]: apply this many route mutations (50%% subscribe / 50%% unsubscribe) between batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tenants", type=int, default=16)
     ap.add_argument("--cpu-sample-topics", type=int, default=200_000)
@@ -129,6 +131,33 @@ def main():
             torch.cuda.synchronize()
         return total
 
+    churn_ms = []
+    churn_state = {"rng": np.random.default_rng(1234 + rank), "seq": 0}
+
+    def churn():
+        """configs[4]: N/2 unsubscribes of existing routes + N/2 subscribes of new filters (bmq_routes_apply)."""
+        if not args.churn:
+            return
+        rng = churn_state["rng"]
+        nk = int(eng.info().n_routes)
+        tenants_l = w.tenants()
+        ops = []
+        for rid in rng.integers(0, nk, size=args.churn // 2):
+            ops.append((1, eng.route_key(int(rid))))
+        for _ in range(args.churn - args.churn // 2):
+            churn_state["seq"] += 1
+            q = churn_state["seq"]
+            t = tenants_l[int(rng.integers(0, len(tenants_l)))]
+            ops.append((0, B.route_key(t, "churn/l1_%d/+/l3_%d" % (q % 64, q % 4096), 1, "0\0c%d\0d%d" % (q, q % 64))))
+        from bifromq_amd.engine import pack, _ptr
+        data, off = pack([k for _, k in ops])
+        opb = np.array([o for o, _ in ops], dtype=np.uint8)
+        t0c = time.perf_counter()  # the C-ABI call alone: host index update + upload
+        rc = B._lib.lib().bmq_routes_apply(eng.h, _ptr(data), _ptr(off), _ptr(opb), len(ops))
+        churn_ms.append((time.perf_counter() - t0c) * 1e3)
+        if rc:
+            raise RuntimeError("bmq_routes_apply failed: %d" % rc)
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -144,6 +173,7 @@ def main():
     n_match = n_visit = n_slow = 0
     t_start = time.perf_counter()
     for i in range(args.steps):
+        churn()  # inside the timed region when --churn is given
         ts = time.perf_counter()
         step(i)
         lat.append((time.perf_counter() - ts) * 1e3)
@@ -198,6 +228,9 @@ def main():
         "routes_per_topic": n_match / (n * steps),
         "visits_per_topic": n_visit / (n * steps),
         "slow_path_topics_per_batch": n_slow / steps,
+        "churn": {"ops_per_batch": args.churn, "apply_ms_mean": float(np.mean(churn_ms)) if churn_ms else None,
+                  "note": "bmq_routes_apply: per-tenant region rebuild on host cores + upload of the touched regions; "
+                          "time of the C-ABI call alone"},
         "kernel_ms": {"k_walk": k_walk_ms, "k_expand": float(np.mean(expand_ms)), "all_kernels": float(np.mean(total_ms))},
         "host_s": {"generate": t_gen, "rebuild": t_build},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -46,6 +46,17 @@ struct HostDict {
         table.swap(nt);
         mask = nm;
     }
+    uint32_t find(std::string_view s) const { // read-only: safe from several threads while nobody interns
+        const LevelHash h = hash_level(s);
+        const uint32_t sh = level_hash_slot(h, (uint32_t)s.size()), tag = level_hash_tag(h);
+        uint32_t i = sh & mask;
+        while (table[i]) {
+            const Entry& e = entries[table[i] - TOK_FIRST];
+            if (e.tag == tag && e.s == s) return table[i];
+            i = (i + 1) & mask;
+        }
+        return TOK_UNKNOWN;
+    }
     uint32_t intern(std::string_view s) {
         const LevelHash h = hash_level(s);
         const uint32_t sh = level_hash_slot(h, (uint32_t)s.size()), tag = level_hash_tag(h);

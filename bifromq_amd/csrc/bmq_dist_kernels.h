@@ -157,14 +157,14 @@ __device__ __forceinline__ TrieSlot load_slot(const TrieSlot* trie, uint32_t idx
     const uint4 a = p[0], b = p[1];
     return unpack_slot(a, b);
 }
-// (parent slot, token) -> child slot inside the tenant's region; NONE if absent.  Reads whole 64-byte buckets: the
-// home bucket answers unless it is full of other edges (rare at load factor 1/2).
+// (parent slot, token) -> child slot inside the tenant's region (slots are region-relative); NONE if absent.  Reads
+// whole 64-byte buckets: the home bucket answers unless it is full of other edges (rare at load factor 1/2).
 __device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_t base, uint32_t buckets, uint32_t parent,
                                                 uint32_t token, TrieSlot& out) {
     uint32_t bk = edge_bucket(parent, token, buckets);
     for (;;) {
-        const uint32_t s0 = base + 2 * bk;
-        const uint4* p = reinterpret_cast<const uint4*>(ix.trie + s0);
+        const uint32_t s0 = 2 * bk;
+        const uint4* p = reinterpret_cast<const uint4*>(ix.trie + base + s0);
         const uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
         if (a0.x == parent && a0.y == token) {
             out = unpack_slot(a0, a1);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
     bool last;
     scan_level(pos, end, false, word_at, h, inl, len, last);
     const uint32_t tok = dict_lookup(a.ix, h, len, inl, start, byte_at);
-    TenantSlot info{0, 0, 0, 1};
+    TenantSlot info{0, 0, 0, 1, 0, 0, {0, 0}};
     if (tok != TOK_UNKNOWN) {
         uint32_t d = tenant_hash(tok) & a.ix.tenant_mask;
         for (;;) {
@@ -311,7 +311,7 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantS
                                           bool kind_h, uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
     o.found = o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
     if (kind_h) {
-        o.s = load_slot(ix.trie, node);
+        o.s = load_slot(ix.trie, rg.base + node);
         o.idx = node;
         o.dl = level;
         o.found = true;
@@ -344,7 +344,7 @@ constexpr uint32_t MAX_FLUSH = 16; // range-buffer flushes per wave before topic
 
 __host__ __device__ inline size_t walk_union_words(uint32_t qcap, uint32_t pcap) { return 2 * (size_t)qcap + 3 * (size_t)pcap; }
 __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
-    return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 7 * 64 + 2 * MAX_FLUSH + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
+    return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 9 * 64 + 2 * MAX_FLUSH + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
 }
 
 __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
@@ -367,7 +367,9 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     uint32_t* cursor = cnt_visit + 64;                        // [64]
     uint32_t* t_base = cursor + 64;                           // [64] tenant region of each topic
     uint32_t* t_nb = t_base + 64;                             // [64]
-    uint32_t* f_base = t_nb + 64;                             // [MAX_FLUSH] spill record offset of each flush
+    uint32_t* t_rank = t_nb + 64;                             // [64] id base of the tenant
+    uint32_t* t_rp = t_rank + 64;                             // [64] route_pos base of the tenant
+    uint32_t* f_base = t_rp + 64;                             // [MAX_FLUSH] spill record offset of each flush
     uint32_t* f_len = f_base + MAX_FLUSH;                     // [MAX_FLUSH]
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
 
     uint32_t nlev = 0, tbytes = 0, pos = 0, end = 0;
     bool sys = false, more = false;
-    TenantSlot rg{0, 0, 0, 1};
+    TenantSlot rg{0, 0, 0, 1, 0, 0, {0, 0}};
     if (valid) {
         pos = a.topic_off[t];
         end = a.topic_off[t + 1];
@@ -431,6 +433,8 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     cnt_visit[lane] = 0;
     t_base[lane] = rg.base;
     t_nb[lane] = rg.buckets;
+    t_rank[lane] = rg.rank_base;
+    t_rp[lane] = rg.rp_base;
 
     // ---- phase 2: drain the work ring -----------------------------------------------------------------------------
     // The work list is a STACK (newest items first): depth-first order keeps it at a few pending siblings per topic,
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
         if (act) {
             const uint32_t tm = tmeta[tl];
             if (!(tm & TM_FLAG)) {
-                const TenantSlot r{0, 0, t_base[tl], t_nb[tl]};
+                const TenantSlot r{0, 0, t_base[tl], t_nb[tl], 0, 0, {0, 0}};
                 step_item(a.ix, r, node, meta_level(meta), (meta & KIND_H) != 0, tm & 0xFFu, (tm & TM_SYS) != 0,
                           [&](uint32_t l) { return tokens[l * 64 + tl]; }, o);
             }
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
             const uint32_t c1 = (uint32_t)__popcll(m1);
             if (o.emit_own) {
                 const uint32_t p = pcount + rank_below(m1);
-                p_begin[p] = o.s.own_begin;
+                p_begin[p] = o.s.own_begin + ((o.s.own_count & RANGE_INDIRECT) ? t_rp[tl] : t_rank[tl]);
                 p_count[p] = o.s.own_count;
                 p_topic[p] = tl;
                 atomicAdd(&cnt_pairs[tl], 1u);
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
             }
             if (o.emit_hash) {
                 const uint32_t p = pcount + c1 + rank_below(m2);
-                p_begin[p] = o.s.hash_begin;
+                p_begin[p] = o.s.hash_begin + ((o.s.hash_count & RANGE_INDIRECT) ? t_rp[tl] : t_rank[tl]);
                 p_count[p] = o.s.hash_count;
                 p_topic[p] = tl;
                 atomicAdd(&cnt_pairs[tl], 1u);
@@ -645,13 +649,13 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                     if (pass == 0) {
                         np++;
                         nr += o.s.own_count & ~RANGE_INDIRECT;
-                    } else a.pairs[base + wp++] = MatchRange{o.s.own_begin, o.s.own_count};
+                    } else a.pairs[base + wp++] = MatchRange{o.s.own_begin + ((o.s.own_count & RANGE_INDIRECT) ? rg.rp_base : rg.rank_base), o.s.own_count};
                 }
                 if (o.emit_hash) {
                     if (pass == 0) {
                         np++;
                         nr += o.s.hash_count & ~RANGE_INDIRECT;
-                    } else a.pairs[base + wp++] = MatchRange{o.s.hash_begin, o.s.hash_count};
+                    } else a.pairs[base + wp++] = MatchRange{o.s.hash_begin + ((o.s.hash_count & RANGE_INDIRECT) ? rg.rp_base : rg.rank_base), o.s.hash_count};
                 }
                 if (o.push_l) {
                     stack[2 * sp] = o.idx;

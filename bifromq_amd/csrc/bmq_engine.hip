@@ -81,8 +81,8 @@ struct bmq_engine {
     std::string err;
 
     // dist direction
-    KeySet keys;
     DistIndexHost host;
+    void* pinned_trie = nullptr; // host.trie memory currently registered with HIP
     std::unique_ptr<DistDevice> dist;
     uint64_t epoch = 0;
     bool built = false;
@@ -139,29 +139,49 @@ int upload(bmq_engine* e, DevBuf& b, const void* src, size_t bytes) {
 int upload_dist(bmq_engine* e) {
     if (e->device < 0) return BMQ_OK;
     HIPCHK(e, hipSetDevice(e->device));
-    auto d = std::make_unique<DistDevice>();
-    const DistIndexHost& h = e->host;
+    DistIndexHost& h = e->host;
+    if (!e->dist) {
+        e->dist = std::make_unique<DistDevice>();
+        h.full_upload = true;
+    }
+    DistDevice& d = *e->dist;
     int rc;
-    if ((rc = upload(e, d->trie, h.trie.data(), h.trie.size() * sizeof(TrieSlot)))) return rc;
-    if ((rc = upload(e, d->tenants, h.tenants.data(), h.tenants.size() * sizeof(TenantSlot)))) return rc;
-    if ((rc = upload(e, d->dict, h.dict.data(), h.dict.size() * sizeof(DictSlot)))) return rc;
-    if ((rc = upload(e, d->pool, h.pool.data(), h.pool.size()))) return rc;
-    if ((rc = upload(e, d->route_pos, h.route_pos.data(), h.route_pos.size() * sizeof(uint32_t)))) return rc;
+    const size_t trie_bytes = h.trie.size() * sizeof(TrieSlot);
+    if (e->pinned_trie != (void*)h.trie.data()) { // pin the host image: region re-uploads then run at PCIe speed
+        if (e->pinned_trie) (void)hipHostUnregister(e->pinned_trie);
+        e->pinned_trie = nullptr;
+        if (hipHostRegister((void*)h.trie.data(), trie_bytes, hipHostRegisterDefault) == hipSuccess) e->pinned_trie = (void*)h.trie.data();
+        else (void)hipGetLastError(); // not fatal: copies fall back to pageable memory
+    }
+    if (h.full_upload || d.trie.cap < trie_bytes) {
+        if ((rc = upload(e, d.trie, h.trie.data(), trie_bytes))) return rc;
+    } else { // only the regions of the tenants this batch of mutations touched
+        for (auto& r : h.dirty)
+            HIPCHK(e, hipMemcpyAsync(d.trie.as<TrieSlot>() + r.first, h.trie.data() + r.first, (size_t)r.second * sizeof(TrieSlot),
+                                     hipMemcpyHostToDevice, e->stream));
+    }
+    if ((rc = upload(e, d.tenants, h.tenants.data(), h.tenants.size() * sizeof(TenantSlot)))) return rc;
+    if (h.dict_changed || h.full_upload) {
+        if ((rc = upload(e, d.dict, h.dict.data(), h.dict.size() * sizeof(DictSlot)))) return rc;
+        if ((rc = upload(e, d.pool, h.pool.data(), h.pool.size()))) return rc;
+    }
+    if ((rc = upload(e, d.route_pos, h.route_pos.data(), h.route_pos.size() * sizeof(uint32_t)))) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    d->view.trie = d->trie.as<TrieSlot>();
-    d->view.tenants = d->tenants.as<TenantSlot>();
-    d->view.tenant_mask = (uint32_t)h.tenants.size() - 1;
-    d->view.dict = d->dict.as<DictSlot>();
-    d->view.dict_group_mask = (uint32_t)h.dict.size() / 4 - 1;
-    d->view.pool = d->pool.as<uint8_t>();
-    d->view.route_pos = d->route_pos.as<uint32_t>();
-    d->bytes = d->trie.cap + d->tenants.cap + d->dict.cap + d->pool.cap + d->route_pos.cap;
-    e->dist = std::move(d); // previous epoch freed here (match calls are serialised by e->mu)
+    h.full_upload = false;
+    h.dict_changed = false;
+    h.dirty.clear();
+    d.view.trie = d.trie.as<TrieSlot>();
+    d.view.tenants = d.tenants.as<TenantSlot>();
+    d.view.tenant_mask = (uint32_t)h.tenants.size() - 1;
+    d.view.dict = d.dict.as<DictSlot>();
+    d.view.dict_group_mask = (uint32_t)h.dict.size() / 4 - 1;
+    d.view.pool = d.pool.as<uint8_t>();
+    d.view.route_pos = d.route_pos.as<uint32_t>();
+    d.bytes = d.trie.cap + d.tenants.cap + d.dict.cap + d.pool.cap + d.route_pos.cap;
     return BMQ_OK;
 }
 
-int rebuild_locked(bmq_engine* e) {
-    if (!e->host.build(e->keys)) return set_err(e, BMQ_E_INVAL, e->host.error);
+int publish_epoch(bmq_engine* e) {
     int rc = upload_dist(e);
     if (rc) return rc;
     e->epoch++;
@@ -365,6 +385,7 @@ void bmq_engine_destroy(bmq_engine* e) {
         for (auto& ev : e->ev)
             if (ev) (void)hipEventDestroy(ev);
         if (e->h_ctr) (void)hipHostFree(e->h_ctr);
+        if (e->pinned_trie) (void)hipHostUnregister(e->pinned_trie);
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
     delete e;
@@ -377,30 +398,24 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
     if (!e || (n_keys && (!keys || !key_off))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
     static const uint32_t zero_off[1] = {0};
-    e->keys.assign(keys, n_keys ? key_off : zero_off, n_keys);
-    return rebuild_locked(e);
+    if (!e->host.rebuild(keys, n_keys ? key_off : zero_off, n_keys)) return set_err(e, BMQ_E_INVAL, e->host.error);
+    return publish_epoch(e);
 }
 
 int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
     if (!e || (n && (!keys || !key_off || !op))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (n == 0) return BMQ_OK;
-    for (uint32_t i = 0; i < n; i++) {
-        RouteKeyParts kp;
-        if (op[i] > 1) return set_err(e, BMQ_E_INVAL, "op must be 0 (put) or 1 (delete)");
-        if (!decode_route_key(std::string_view((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]), kp))
-            return set_err(e, BMQ_E_INVAL, "malformed route key in apply batch");
-    }
-    e->keys.apply(keys, key_off, op, n);
-    return rebuild_locked(e);
+    if (!e->host.apply(keys, key_off, op, n)) return set_err(e, BMQ_E_INVAL, e->host.error);
+    return publish_epoch(e);
 }
 
 int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out) {
     if (!e || !out) return BMQ_E_INVAL;
     out->n_routes = e->host.n_routes;
-    out->n_tenants = e->host.n_tenants;
+    out->n_tenants = e->host.n_tenants();
     out->n_nodes = e->host.n_nodes;
-    out->n_tokens = e->host.n_tokens;
+    out->n_tokens = e->host.n_tokens();
     out->trie_slots = e->host.trie.size();
     out->dict_slots = e->host.dict.size();
     out->device_bytes = e->dist ? e->dist->bytes : 0;
@@ -410,8 +425,8 @@ int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out) {
 
 int bmq_route_key(const bmq_engine* e, uint32_t route_id, uint8_t* out, uint32_t cap, uint32_t* out_len) {
     if (!e || !out_len) return BMQ_E_INVAL;
-    if (route_id >= e->keys.size()) return BMQ_E_INVAL;
-    const std::string_view k = e->keys.key(route_id);
+    if (route_id >= e->host.n_routes) return BMQ_E_INVAL;
+    const std::string_view k = e->host.route_key(route_id);
     *out_len = (uint32_t)k.size();
     if (k.size() > cap) return BMQ_E_NOSPACE;
     if (out && !k.empty()) memcpy(out, k.data(), k.size());
@@ -423,15 +438,10 @@ int bmq_index_find(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_l
     if (!e || !out_n) return BMQ_E_INVAL;
     *out_n = 0;
     if (!e->built) return BMQ_E_STATE;
-    bool is_hash = false;
-    const uint32_t node = e->host.find_filter_node(std::string_view((const char*)tenant, tenant_len),
-                                                   std::string_view((const char*)filter, filter_len), is_hash);
-    if (node == NONE) return BMQ_OK;
-    const TrieSlot& s = e->host.trie[node];
-    const uint32_t b = is_hash ? s.hash_begin : s.own_begin, cf = is_hash ? s.hash_count : s.own_count;
-    const uint32_t c = cf & ~RANGE_INDIRECT;
-    *out_n = c;
-    for (uint32_t i = 0; i < c && i < cap; i++) out_ids[i] = (cf & RANGE_INDIRECT) ? e->host.route_pos[b + i] : b + i;
+    const std::vector<uint32_t> ids = e->host.find_filter(std::string_view((const char*)tenant, tenant_len),
+                                                          std::string_view((const char*)filter, filter_len));
+    *out_n = (uint32_t)ids.size();
+    for (uint32_t i = 0; i < ids.size() && i < cap; i++) out_ids[i] = ids[i];
     return BMQ_OK;
 }
 
@@ -581,7 +591,7 @@ int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, con
         for (uint32_t k = rp[i]; k < rp[i + 1]; k++) {
             const uint32_t id = ids[k];
             RouteKeyParts kp;
-            if (!decode_route_key(e->keys.key(id), kp)) return set_err(e, BMQ_E_INVAL, "corrupt key set");
+            if (!decode_route_key(e->host.route_key(id), kp)) return set_err(e, BMQ_E_INVAL, "corrupt key set");
             int ev_type = -1;
             if (kp.flag == 1) {
                 // subBrokerId = integer prefix of "<brokerId>\0<receiverId>\0<delivererKey>" (SCHEMA/KVSchemaUtil.java:56-58)

@@ -1,18 +1,17 @@
-// bmq_index.cpp -- host-side builder: route keys -> dictionary + filter trie -> 32-byte slot tables.
+// bmq_index.cpp -- host-side dist index: route keys per tenant -> dictionary + per-tenant filter-trie regions.
 //
-// What it indexes is what the reference scans: the route keys of a KV range
-// (SCHEMA/KVSchemaUtil.java:91-130).  The reference joins those keys against the expansion set of the
-// publish topics (DW/cache/TenantRouteMatcher.java:88-156); this builder turns the same keys into the
-// inverse structure (a trie of filters) once per rebuild so that the GPU can walk it per topic.
+// What it indexes is what the reference scans: the route keys of a KV range (SCHEMA/KVSchemaUtil.java:91-130).  The
+// reference joins those keys against the expansion set of the publish topics on every call
+// (DW/cache/TenantRouteMatcher.java:88-156); here the same keys become the inverse structure (a trie of filters) once,
+// and a batch of route mutations rebuilds only the regions of the tenants it touches, on all host cores.
 #include "bmq_index.h"
-
-#include "bmq_dict.h"
 
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
-#include <numeric>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 
 namespace bmq {
@@ -103,123 +102,76 @@ bool decode_route_key(std::string_view k, RouteKeyParts& out) {
 // KeySet
 // ------------------------------------------------------------------------------------------------------------
 namespace {
-struct KeyRef {
-    const uint8_t* p;
-    uint32_t n;
-};
-inline bool key_less(const KeyRef& a, const KeyRef& b) {
-    const uint32_t m = a.n < b.n ? a.n : b.n;
-    const int c = m ? memcmp(a.p, b.p, m) : 0;
-    return c < 0 || (c == 0 && a.n < b.n);
-}
-inline bool key_eq(const KeyRef& a, const KeyRef& b) { return a.n == b.n && (a.n == 0 || memcmp(a.p, b.p, a.n) == 0); }
-
-void parallel_sort(std::vector<KeyRef>& v) {
-    const size_t n = v.size();
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t parts = 1;
-    while (parts * 2 <= (hw ? hw : 1) && parts < 16) parts *= 2;
-    if (n < (1u << 16) || parts == 1) {
-        std::sort(v.begin(), v.end(), key_less);
-        return;
-    }
-    std::vector<size_t> cut(parts + 1);
-    for (size_t i = 0; i <= parts; i++) cut[i] = n * i / parts;
-    {
-        std::vector<std::thread> th;
-        for (size_t i = 0; i < parts; i++)
-            th.emplace_back([&, i] { std::sort(v.begin() + cut[i], v.begin() + cut[i + 1], key_less); });
-        for (auto& t : th) t.join();
-    }
-    for (size_t w = 1; w < parts; w *= 2) {
-        std::vector<std::thread> th;
-        for (size_t i = 0; i + w < parts; i += 2 * w)
-            th.emplace_back([&, i, w] {
-                std::inplace_merge(v.begin() + cut[i], v.begin() + cut[i + w], v.begin() + cut[std::min(i + 2 * w, parts)],
-                                   key_less);
-            });
-        for (auto& t : th) t.join();
-    }
+inline bool sv_less(std::string_view a, std::string_view b) {
+    const size_t m = a.size() < b.size() ? a.size() : b.size();
+    const int c = m ? memcmp(a.data(), b.data(), m) : 0;
+    return c < 0 || (c == 0 && a.size() < b.size());
 }
 } // namespace
 
-void KeySet::assign(const uint8_t* keys, const uint32_t* key_off, uint32_t n) {
-    std::vector<KeyRef> refs(n);
-    bool sorted = true;
-    for (uint32_t i = 0; i < n; i++) {
-        refs[i] = {keys + key_off[i], key_off[i + 1] - key_off[i]};
-        if (i && !key_less(refs[i - 1], refs[i])) sorted = false; // strict: also catches duplicates
-    }
-    if (!sorted) {
-        parallel_sort(refs);
-        refs.erase(std::unique(refs.begin(), refs.end(), key_eq), refs.end());
-    }
+void KeySet::assign(std::vector<std::string_view>& keys) {
+    if (!std::is_sorted(keys.begin(), keys.end(), sv_less)) std::sort(keys.begin(), keys.end(), sv_less);
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     uint64_t total = 0;
-    for (auto& r : refs) total += r.n;
+    for (auto& k : keys) total += k.size();
     std::vector<uint8_t> nb(total ? total : 1);
-    std::vector<uint64_t> no(refs.size() + 1);
+    std::vector<uint64_t> no(keys.size() + 1);
     uint64_t o = 0;
-    for (size_t i = 0; i < refs.size(); i++) {
+    for (size_t i = 0; i < keys.size(); i++) {
         no[i] = o;
-        if (refs[i].n) memcpy(nb.data() + o, refs[i].p, refs[i].n);
-        o += refs[i].n;
+        if (!keys[i].empty()) memcpy(nb.data() + o, keys[i].data(), keys[i].size());
+        o += keys[i].size();
     }
-    no[refs.size()] = o;
+    no[keys.size()] = o;
     bytes.swap(nb);
     off.swap(no);
 }
 
 int64_t KeySet::find(std::string_view k) const {
     size_t lo = 0, hi = size();
-    const KeyRef kr{(const uint8_t*)k.data(), (uint32_t)k.size()};
     while (lo < hi) {
         const size_t mid = (lo + hi) / 2;
-        const std::string_view m = key(mid);
-        if (key_less(KeyRef{(const uint8_t*)m.data(), (uint32_t)m.size()}, kr)) lo = mid + 1;
+        if (sv_less(key(mid), k)) lo = mid + 1;
         else hi = mid;
     }
-    if (lo < size() && key(lo) == k) return (int64_t)lo;
-    return -1;
+    return (lo < size() && key(lo) == k) ? (int64_t)lo : -1;
 }
 
-void KeySet::apply(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+void KeySet::apply(std::vector<std::pair<std::string_view, uint8_t>>& ops) {
     // last op per key wins (ops are applied in order); then one merge pass over the sorted set
-    std::vector<std::pair<KeyRef, uint32_t>> ops(n);
-    for (uint32_t i = 0; i < n; i++) ops[i] = {KeyRef{keys + key_off[i], key_off[i + 1] - key_off[i]}, i};
-    std::stable_sort(ops.begin(), ops.end(),
-                     [](const auto& a, const auto& b) { return key_less(a.first, b.first); });
+    std::vector<uint32_t> idx(ops.size());
+    for (uint32_t i = 0; i < ops.size(); i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return sv_less(ops[a].first, ops[b].first); });
     std::vector<uint8_t> nb;
-    nb.reserve(bytes.size() + (n ? key_off[n] : 0));
+    nb.reserve(bytes.size() + 64 * ops.size());
     std::vector<uint64_t> no;
-    no.reserve(off.size() + n);
+    no.reserve(off.size() + ops.size());
     no.push_back(0);
-    auto emit = [&](const uint8_t* p, uint32_t len) {
-        nb.insert(nb.end(), p, p + len);
+    auto emit = [&](std::string_view k) {
+        nb.insert(nb.end(), k.begin(), k.end());
         no.push_back(nb.size());
     };
     size_t i = 0, j = 0;
     const size_t m = size();
-    while (i < m || j < ops.size()) {
-        if (j == ops.size()) {
-            const auto k = key(i++);
-            emit((const uint8_t*)k.data(), (uint32_t)k.size());
+    while (i < m || j < idx.size()) {
+        if (j == idx.size()) {
+            emit(key(i++));
             continue;
         }
         size_t j2 = j; // run of ops on the same key; the last one decides
-        while (j2 + 1 < ops.size() && key_eq(ops[j2 + 1].first, ops[j].first)) j2++;
-        const KeyRef& ok = ops[j2].first;
-        const bool is_put = op[ops[j2].second] == 0;
+        while (j2 + 1 < idx.size() && ops[idx[j2 + 1]].first == ops[idx[j]].first) j2++;
+        const std::string_view ok = ops[idx[j2]].first;
+        const bool is_put = ops[idx[j2]].second == 0;
         if (i < m) {
-            const auto k = key(i);
-            const KeyRef kr{(const uint8_t*)k.data(), (uint32_t)k.size()};
-            if (key_less(kr, ok)) {
-                emit(kr.p, kr.n);
+            const std::string_view k = key(i);
+            if (sv_less(k, ok)) {
+                emit(k);
                 i++;
                 continue;
             }
-            if (key_eq(kr, ok)) i++; // replaced or deleted
+            if (k == ok) i++; // replaced or deleted
         }
-        if (is_put) emit(ok.p, ok.n);
+        if (is_put) emit(ok);
         j = j2 + 1;
     }
     if (nb.empty()) nb.push_back(0);
@@ -228,7 +180,7 @@ void KeySet::apply(const uint8_t* keys, const uint32_t* key_off, const uint8_t* 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// builder
+// per-tenant trie construction
 // ------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -282,41 +234,40 @@ struct ChildMap {
 };
 
 struct BuildNode {
-    uint32_t parent; // node id, NONE for tenant roots
-    uint32_t token;
-    uint32_t own_group, hash_group; // route groups of "<path>" and "<path>/#" (NONE: none)
+    uint32_t parent; // node index, NONE for the root
+    uint32_t token;  // LOCAL token while building, global after translation
+    uint32_t own_group, hash_group;
 };
 
-} // namespace
+// result of phase 1 for one tenant (everything tenant-local)
+struct TenantBuild {
+    TenantState* st = nullptr;
+    std::vector<BuildNode> nodes;               // creation order: parents first
+    std::vector<std::string_view> local_strings; // local token - TOK_FIRST -> level string (views into st->keys)
+    std::vector<uint32_t> l2g;                   // local token index -> global token
+    std::vector<uint32_t> group_begin, group_count;
+    std::vector<uint32_t> indirect;
+    std::string error;
+};
 
-bool DistIndexHost::build(const KeySet& ks) {
-    error.clear();
+// Phase 1: keys -> trie nodes (local tokens), route groups.  Keys are sorted: consecutive keys share long prefixes.
+void build_tenant_trie(TenantBuild& b) {
+    const KeySet& ks = b.st->keys;
     const size_t n = ks.size();
-    if (n >= 0x7FFFFFF0ull) {
-        error = "too many routes";
-        return false;
-    }
-    HostDict dict_h;
+    HostDict local;
     ChildMap children;
-    std::vector<BuildNode> nodes;
-    nodes.reserve(n + 16);
-    std::vector<uint32_t> group_count, group_first, group_last; // per route group (one per filter with routes)
+    b.nodes.clear();
+    b.nodes.reserve(n + 8);
+    b.nodes.push_back({NONE, 0, NONE, NONE}); // root; its token (the tenant id) is filled in globally
+    std::vector<uint32_t> group_first, group_last;
     std::vector<uint32_t> route_group(n ? n : 1);
-    std::vector<uint32_t> root_nodes; // node index of every tenant root, ascending (tenants are contiguous in key order)
-
-    // path of the previous key, for prefix reuse (sorted keys share long prefixes)
-    std::string_view prev_tenant;
-    bool have_prev = false;
-    uint32_t prev_root = NONE;
-    std::vector<std::string_view> prev_levels;
-    std::vector<uint32_t> prev_nodes; // node reached after consuming prev_levels[0..i]
-
-    std::vector<std::string_view> levels;
+    std::vector<std::string_view> prev_levels, levels;
+    std::vector<uint32_t> prev_nodes;
     for (size_t r = 0; r < n; r++) {
         RouteKeyParts kp;
         if (!decode_route_key(ks.key(r), kp)) {
-            error = "malformed route key at rank " + std::to_string(r);
-            return false;
+            b.error = "malformed route key";
+            return;
         }
         levels.clear();
         { // split escaped filter on NUL, keeping empty levels (TopicUtil.parse(escaped = true))
@@ -328,32 +279,11 @@ bool DistIndexHost::build(const KeySet& ks) {
                     s = i + 1;
                 }
         }
-        uint32_t node;
+        uint32_t node = 0;
         size_t reuse = 0;
-        if (have_prev && kp.tenant == prev_tenant) {
-            node = prev_root;
-            while (reuse < levels.size() && reuse < prev_levels.size() && levels[reuse] == prev_levels[reuse] &&
-                   prev_nodes[reuse] != NONE)
-                reuse++;
-            if (reuse) node = prev_nodes[reuse - 1];
-        } else {
-            const uint32_t ttok = dict_h.intern(kp.tenant);
-            bool created;
-            uint32_t& v = children.get(NONE, ttok, created);
-            if (!created) {
-                error = "keys of one tenant are not contiguous (input not sorted?)";
-                return false;
-            }
-            v = (uint32_t)nodes.size();
-            nodes.push_back({NONE, ttok, NONE, NONE});
-            root_nodes.push_back(v);
-            node = v;
-            prev_root = node;
-            prev_tenant = kp.tenant;
-            have_prev = true;
-            prev_levels.clear();
-            prev_nodes.clear();
-        }
+        while (reuse < levels.size() && reuse < prev_levels.size() && levels[reuse] == prev_levels[reuse] && prev_nodes[reuse] != NONE)
+            reuse++;
+        if (reuse) node = prev_nodes[reuse - 1];
         prev_levels.resize(reuse);
         prev_nodes.resize(reuse);
         bool is_hash = false;
@@ -365,168 +295,337 @@ bool DistIndexHost::build(const KeySet& ks) {
                 prev_nodes.push_back(NONE); // not a node; never reused
                 break;
             }
-            const uint32_t tok = (lv == "+") ? TOK_PLUS : dict_h.intern(lv);
+            const uint32_t tok = (lv == "+") ? TOK_PLUS : local.intern(lv);
             bool created;
             uint32_t& v = children.get(node, tok, created);
             if (created) {
-                v = (uint32_t)nodes.size();
-                nodes.push_back({node, tok, NONE, NONE});
+                v = (uint32_t)b.nodes.size();
+                b.nodes.push_back({node, tok, NONE, NONE});
             }
             node = v;
             prev_levels.push_back(lv);
             prev_nodes.push_back(node);
         }
-        uint32_t& g = is_hash ? nodes[node].hash_group : nodes[node].own_group;
+        uint32_t& g = is_hash ? b.nodes[node].hash_group : b.nodes[node].own_group;
         if (g == NONE) {
-            g = (uint32_t)group_count.size();
-            group_count.push_back(0);
+            g = (uint32_t)b.group_count.size();
+            b.group_count.push_back(0);
             group_first.push_back((uint32_t)r);
             group_last.push_back((uint32_t)r);
         }
-        group_count[g]++;
+        b.group_count[g]++;
         group_last[g] = (uint32_t)r;
         route_group[r] = g;
     }
-
-    // ---- route groups: a group whose ids are one contiguous rank range is stored as that range (the overwhelmingly
-    // common case); otherwise (SURVEY.md 8c quirk ii: keys of "x" interleave with keys of "x//...") its ids go to
-    // route_pos[] and the range is flagged RANGE_INDIRECT ------------------------------------------------------------------
-    std::vector<uint32_t> group_begin(group_count.size());
-    uint64_t indirect_total = 0;
-    for (size_t g = 0; g < group_count.size(); g++) {
-        if (group_last[g] - group_first[g] + 1 == group_count[g]) {
-            group_begin[g] = group_first[g];
-        } else {
-            group_begin[g] = (uint32_t)indirect_total;
-            indirect_total += group_count[g];
-            group_count[g] |= RANGE_INDIRECT;
+    // a group whose ids are one contiguous rank range is stored as that range (the overwhelmingly common case);
+    // otherwise (SURVEY.md 8c quirk ii: keys of "x" interleave with keys of "x//...") its ids go to the indirect list
+    b.group_begin.resize(b.group_count.size());
+    uint32_t ind = 0;
+    for (size_t g = 0; g < b.group_count.size(); g++) {
+        if (group_last[g] - group_first[g] + 1 == b.group_count[g]) b.group_begin[g] = group_first[g];
+        else {
+            b.group_begin[g] = ind;
+            ind += b.group_count[g];
+            b.group_count[g] |= RANGE_INDIRECT;
         }
     }
-    route_pos.assign(indirect_total ? indirect_total : 1, 0);
-    if (indirect_total) {
-        std::vector<uint32_t> cur(group_begin);
+    b.indirect.assign(ind, 0);
+    if (ind) {
+        std::vector<uint32_t> cur(b.group_begin);
         for (size_t r = 0; r < n; r++) {
             const uint32_t g = route_group[r];
-            if (group_count[g] & RANGE_INDIRECT) route_pos[cur[g]++] = (uint32_t)r;
+            if (b.group_count[g] & RANGE_INDIRECT) b.indirect[cur[g]++] = (uint32_t)r;
         }
     }
-    std::vector<uint32_t>().swap(route_group);
+    b.local_strings.resize(local.entries.size());
+    for (size_t i = 0; i < local.entries.size(); i++) b.local_strings[i] = local.entries[i].s;
+}
 
-    // ---- one region of the slot table per tenant; bucketised linear probing, load factor <= 1/2 ---------------------
-    double region_factor = 2.0; // slots per node; BMQ_REGION_FACTOR overrides for experiments
-    if (const char* rf = getenv("BMQ_REGION_FACTOR")) region_factor = std::max(1.25, atof(rf));
-    const size_t nt = root_nodes.size();
-    std::vector<uint64_t> region_base(nt + 1, 0); // in slots
-    std::vector<uint32_t> region_buckets(nt);
-    for (size_t t = 0; t < nt; t++) {
-        const uint64_t cnt = (t + 1 < nt ? root_nodes[t + 1] : nodes.size()) - root_nodes[t];
-        region_buckets[t] = (uint32_t)std::max<uint64_t>(2, (uint64_t)(cnt * region_factor / 2.0) + 1);
-        region_base[t + 1] = region_base[t] + 2ull * region_buckets[t];
+// Phase 3: place the nodes (global tokens) into the tenant's region: bucketised first-free probing, parents first.
+void place_tenant(const TenantBuild& b, SlotBuf& trie) {
+    TenantState& t = *b.st;
+    const TrieSlot empty_slot{NONE, 0, 0, 0, 0, 0, NONE, 0};
+    for (uint32_t s = 0; s < t.cap_slots; s++) trie[t.base + s] = empty_slot;
+    std::vector<uint32_t> slot_of(b.nodes.size());
+    const uint32_t nb = t.buckets;
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+        const BuildNode& bn = b.nodes[i];
+        const uint32_t pslot = bn.parent == NONE ? ROOT_PARENT : slot_of[bn.parent];
+        const uint32_t tok = bn.parent == NONE ? t.token : (bn.token == TOK_PLUS ? TOK_PLUS : b.l2g[bn.token - TOK_FIRST]);
+        uint32_t bk = edge_bucket(pslot, tok, nb), s;
+        for (;;) {
+            s = 2 * bk;
+            if (trie[t.base + s].parent == NONE) break;
+            if (trie[t.base + ++s].parent == NONE) break;
+            bk = (bk + 1 == nb) ? 0 : bk + 1;
+        }
+        TrieSlot& ts = trie[t.base + s];
+        ts.parent = pslot;
+        ts.token = tok;
+        if (bn.own_group != NONE) {
+            ts.own_begin = b.group_begin[bn.own_group];
+            ts.own_count = b.group_count[bn.own_group];
+        }
+        if (bn.hash_group != NONE) {
+            ts.hash_begin = b.group_begin[bn.hash_group];
+            ts.hash_count = b.group_count[bn.hash_group];
+        }
+        slot_of[i] = s;
+        if (bn.parent != NONE) {
+            TrieSlot& pr = trie[t.base + pslot];
+            if (tok == TOK_PLUS) pr.plus_child = s;
+            else pr.lit_bloom |= 1u << bloom_bit(tok);
+        }
     }
-    const uint64_t slots = std::max<uint64_t>(region_base.back(), 2);
-    if (slots >= 0xFFFFFFF0ull) {
-        error = "trie too large";
+    t.root_rel = slot_of[0];
+    t.n_nodes = (uint32_t)b.nodes.size();
+}
+
+struct PhaseTimer { // BMQ_TIMING=1 prints host build phases to stderr
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = getenv("BMQ_TIMING") != nullptr;
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bmq build] %-28s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+template <class F> void parallel_for(size_t n, F&& f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nth = (unsigned)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 64), std::max<size_t>(n, 1));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) break;
+            f(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < nth; w++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// DistIndexHost
+// ------------------------------------------------------------------------------------------------------------
+bool DistIndexHost::rebuild(const uint8_t* keys, const uint32_t* key_off, uint32_t n) {
+    error.clear();
+    by_name.clear();
+    order.clear();
+    trie.clear();
+    next_free = 0;
+    dict_h = HostDict();
+    strings.clear();
+    full_upload = true;
+    dict_changed = true;
+    dirty.clear();
+    PhaseTimer pt;
+    // split by tenant
+    std::map<std::string_view, std::vector<std::string_view>> per;
+    for (uint32_t i = 0; i < n; i++) {
+        const std::string_view k((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
+        RouteKeyParts kp;
+        if (!decode_route_key(k, kp)) {
+            error = "malformed route key at position " + std::to_string(i);
+            return false;
+        }
+        per[kp.tenant].push_back(k);
+    }
+    std::vector<TenantState*> touched;
+    std::vector<std::vector<std::string_view>*> lists;
+    for (auto& e : per) {
+        auto st = std::make_unique<TenantState>();
+        st->name = std::string(e.first);
+        touched.push_back(st.get());
+        lists.push_back(&e.second);
+        by_name.emplace(st->name, std::move(st));
+    }
+    pt.lap("split keys by tenant");
+    parallel_for(touched.size(), [&](size_t i) { touched[i]->keys.assign(*lists[i]); });
+    pt.lap("per-tenant key sets");
+    return refresh(touched);
+}
+
+bool DistIndexHost::apply(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+    error.clear();
+    std::map<std::string_view, std::vector<std::pair<std::string_view, uint8_t>>> per;
+    for (uint32_t i = 0; i < n; i++) {
+        const std::string_view k((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
+        RouteKeyParts kp;
+        if (op[i] > 1 || !decode_route_key(k, kp)) {
+            error = "malformed route key or op in apply batch";
+            return false;
+        }
+        per[kp.tenant].push_back({k, op[i]});
+    }
+    std::vector<TenantState*> touched;
+    std::vector<std::vector<std::pair<std::string_view, uint8_t>>*> lists;
+    for (auto& e : per) {
+        auto it = by_name.find(std::string(e.first));
+        if (it == by_name.end()) {
+            auto st = std::make_unique<TenantState>();
+            st->name = std::string(e.first);
+            it = by_name.emplace(st->name, std::move(st)).first;
+        }
+        touched.push_back(it->second.get());
+        lists.push_back(&e.second);
+    }
+    parallel_for(touched.size(), [&](size_t i) { touched[i]->keys.apply(*lists[i]); });
+    return refresh(touched);
+}
+
+// Rebuilds the regions of the touched tenants, then the (small) global pieces: directory, id bases, route_pos, dictionary.
+bool DistIndexHost::refresh(std::vector<TenantState*>& touched) {
+    PhaseTimer pt;
+    // tenants that lost their last route disappear
+    std::vector<TenantState*> live;
+    for (TenantState* t : touched) {
+        if (t->keys.size() == 0) {
+            const std::string name = t->name;
+            by_name.erase(name); // its region becomes garbage until the next full rebuild
+        } else live.push_back(t);
+    }
+    // phase 1 (parallel): tries with tenant-local tokens
+    std::vector<TenantBuild> builds(live.size());
+    for (size_t i = 0; i < live.size(); i++) builds[i].st = live[i];
+    parallel_for(builds.size(), [&](size_t i) { build_tenant_trie(builds[i]); });
+    for (auto& b : builds)
+        if (!b.error.empty()) {
+            error = b.error;
+            return false;
+        }
+    pt.lap("phase 1: tries (parallel)");
+    // phase 2 (sequential): global dictionary, region allocation
+    double region_factor = 2.0; // slots per node (load factor 1/2); BMQ_REGION_FACTOR overrides for experiments
+    if (const char* rf = getenv("BMQ_REGION_FACTOR")) region_factor = std::max(1.25, atof(rf));
+    const size_t tokens_before = dict_h.entries.size();
+    auto intern_owned = [&](std::string_view s) -> uint32_t {
+        const size_t before = dict_h.entries.size();
+        const uint32_t tok = dict_h.intern(s);
+        if (dict_h.entries.size() != before) { // new: give the entry storage that outlives the key bytes
+            strings.emplace_back(s);
+            dict_h.entries.back().s = strings.back();
+        }
+        return tok;
+    };
+    // most level strings of a touched tenant are already in the dictionary: resolve those in parallel (read-only), then
+    // intern only the new ones sequentially
+    parallel_for(builds.size(), [&](size_t bi) {
+        TenantBuild& b = builds[bi];
+        b.l2g.resize(b.local_strings.size());
+        for (size_t i = 0; i < b.local_strings.size(); i++) b.l2g[i] = dict_h.find(b.local_strings[i]);
+    });
+    for (auto& b : builds) {
+        TenantState& t = *b.st;
+        t.token = intern_owned(t.name);
+        for (size_t i = 0; i < b.local_strings.size(); i++)
+            if (b.l2g[i] == TOK_UNKNOWN) b.l2g[i] = intern_owned(b.local_strings[i]);
+        const uint32_t buckets = (uint32_t)std::max<uint64_t>(2, (uint64_t)(b.nodes.size() * region_factor / 2.0) + 1);
+        if (2ull * buckets > t.cap_slots) { // (re)allocate the region at the end of the table, with room to grow
+            const uint64_t cap = 2ull * buckets + (t.cap_slots ? buckets / 2 : 0);
+            if ((uint64_t)next_free + cap >= 0xFFFFFFF0ull) {
+                error = "trie too large";
+                return false;
+            }
+            t.base = next_free;
+            t.cap_slots = (uint32_t)(cap + (cap & 1));
+            next_free += t.cap_slots;
+        } else if (!full_upload) {
+            dirty.push_back({t.base, t.cap_slots});
+        }
+        t.buckets = buckets;
+    }
+    if (dict_h.entries.size() != tokens_before) dict_changed = true;
+    pt.lap("  intern + allocate");
+    if (next_free > trie.size()) { // the device table must grow: everything is re-uploaded (slots outside the regions
+        // are never read, so plain zero fill is enough; place_tenant initialises every region it owns)
+        const size_t keep = full_upload ? 0 : trie.size(); // a from-scratch build rewrites every region anyway
+        if (!trie.grow(std::max<size_t>((size_t)next_free + next_free / 4, 64), keep)) {
+            error = "out of host memory";
+            return false;
+        }
+        full_upload = true;
+        dirty.clear();
+    }
+    pt.lap("phase 2: dictionary, regions");
+    // phase 3 (parallel): placement
+    parallel_for(builds.size(), [&](size_t i) {
+        place_tenant(builds[i], trie);
+        builds[i].st->indirect.swap(builds[i].indirect);
+    });
+    pt.lap("phase 3: placement (parallel)");
+    // global pieces
+    order.clear();
+    uint64_t rank = 0, rp = 0, nodes_total = 0;
+    for (auto& e : by_name) {
+        TenantState& t = *e.second;
+        t.rank_base = (uint32_t)rank;
+        t.rp_base = (uint32_t)rp;
+        rank += t.keys.size();
+        rp += t.indirect.size();
+        nodes_total += t.n_nodes;
+        order.push_back(&t);
+    }
+    if (rank >= 0x7FFFFFF0ull) {
+        error = "too many routes";
         return false;
     }
-    TrieSlot empty_slot{NONE, 0, 0, 0, 0, 0, NONE, 0};
-    trie.assign(slots, empty_slot);
-    const uint32_t tslots = pow2_at_least((uint64_t)nt * 2);
-    tenants.assign(tslots, TenantSlot{0, NONE, 0, 1});
-    {
-        std::vector<uint32_t> slot_of(nodes.size());
-        std::atomic<size_t> next{0};
-        auto work = [&]() { // regions are independent: place them on all host cores (parents precede children)
-            for (;;) {
-                const size_t t = next.fetch_add(1);
-                if (t >= nt) break;
-                const size_t n0 = root_nodes[t], n1 = t + 1 < nt ? root_nodes[t + 1] : nodes.size();
-                const uint32_t base = (uint32_t)region_base[t], nb = region_buckets[t];
-                for (size_t i = n0; i < n1; i++) {
-                    const BuildNode& b = nodes[i];
-                    const uint32_t pslot = b.parent == NONE ? ROOT_PARENT : slot_of[b.parent];
-                    uint32_t bk = edge_bucket(pslot, b.token, nb), s;
-                    for (;;) {
-                        s = base + 2 * bk;
-                        if (trie[s].parent == NONE) break;
-                        if (trie[++s].parent == NONE) break;
-                        bk = (bk + 1 == nb) ? 0 : bk + 1;
-                    }
-                    TrieSlot& ts = trie[s];
-                    ts.parent = pslot;
-                    ts.token = b.token;
-                    if (b.own_group != NONE) {
-                        ts.own_begin = group_begin[b.own_group];
-                        ts.own_count = group_count[b.own_group];
-                    }
-                    if (b.hash_group != NONE) {
-                        ts.hash_begin = group_begin[b.hash_group];
-                        ts.hash_count = group_count[b.hash_group];
-                    }
-                    slot_of[i] = s;
-                    if (b.parent != NONE) {
-                        TrieSlot& pr = trie[pslot];
-                        if (b.token == TOK_PLUS) pr.plus_child = s;
-                        else pr.lit_bloom |= 1u << bloom_bit(b.token);
-                    }
-                }
-            }
-        };
-        unsigned hw = std::thread::hardware_concurrency();
-        const unsigned nth = (unsigned)std::min<size_t>(hw ? hw : 1, std::max<size_t>(nt, 1));
-        std::vector<std::thread> th;
-        for (unsigned w = 1; w < nth; w++) th.emplace_back(work);
-        work();
-        for (auto& x : th) x.join();
-        for (size_t t = 0; t < nt; t++) {
-            const uint32_t ttok = nodes[root_nodes[t]].token;
-            uint32_t d = tenant_hash(ttok) & (tslots - 1);
-            while (tenants[d].token) d = (d + 1) & (tslots - 1);
-            tenants[d] = TenantSlot{ttok, slot_of[root_nodes[t]], (uint32_t)region_base[t], region_buckets[t]};
-        }
+    n_routes = rank;
+    n_nodes = nodes_total;
+    route_pos.assign(rp ? rp : 1, 0);
+    for (TenantState* t : order)
+        for (size_t i = 0; i < t->indirect.size(); i++) route_pos[t->rp_base + i] = t->rank_base + t->indirect[i];
+    const uint32_t tslots = pow2_at_least((uint64_t)order.size() * 2);
+    tenants.assign(tslots, TenantSlot{0, 0, 0, 1, 0, 0, {0, 0}});
+    for (TenantState* t : order) {
+        uint32_t d = tenant_hash(t->token) & (tslots - 1);
+        while (tenants[d].token) d = (d + 1) & (tslots - 1);
+        tenants[d] = TenantSlot{t->token, t->root_rel, t->base, t->buckets, t->rank_base, t->rp_base, {0, 0}};
     }
-
-    flatten_dict(dict_h, dict, pool);
-
-    n_routes = n;
-    n_tenants = nt;
-    n_nodes = nodes.size();
-    n_tokens = dict_h.entries.size();
+    if (dict_changed) flatten_dict(dict_h, dict, pool);
+    if (trie.empty()) trie.grow(64, 0);
+    pt.lap("directory, ids, dictionary");
     return true;
 }
 
-uint32_t DistIndexHost::find_token(std::string_view level) const { return dict_find(dict, pool, level); }
-
-const TenantSlot* DistIndexHost::find_tenant(uint32_t token) const {
-    if (tenants.empty() || token == TOK_UNKNOWN) return nullptr;
-    const uint32_t mask = (uint32_t)tenants.size() - 1;
-    uint32_t d = tenant_hash(token) & mask;
-    while (tenants[d].token) {
-        if (tenants[d].token == token) return &tenants[d];
-        d = (d + 1) & mask;
+std::string_view DistIndexHost::route_key(uint32_t id) const {
+    if (id >= n_routes || order.empty()) return {};
+    size_t lo = 0, hi = order.size(); // last tenant with rank_base <= id
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) / 2;
+        if (order[mid]->rank_base <= id) lo = mid;
+        else hi = mid;
     }
-    return nullptr;
+    return order[lo]->keys.key(id - order[lo]->rank_base);
 }
 
-uint32_t DistIndexHost::find_child(const TenantSlot& r, uint32_t parent_slot, uint32_t token) const {
-    uint32_t bk = edge_bucket(parent_slot, token, r.buckets);
+uint32_t DistIndexHost::find_child(const TenantState& t, uint32_t parent_rel, uint32_t token) const {
+    uint32_t bk = edge_bucket(parent_rel, token, t.buckets);
     for (;;) {
         bool full = true;
         for (uint32_t j = 0; j < 2; j++) {
-            const TrieSlot& t = trie[r.base + 2 * bk + j];
-            if (t.parent == NONE) full = false;
-            else if (t.parent == parent_slot && t.token == token) return r.base + 2 * bk + j;
+            const TrieSlot& s = trie[t.base + 2 * bk + j];
+            if (s.parent == NONE) full = false;
+            else if (s.parent == parent_rel && s.token == token) return 2 * bk + j;
         }
         if (!full) return NONE;
-        bk = (bk + 1 == r.buckets) ? 0 : bk + 1;
+        bk = (bk + 1 == t.buckets) ? 0 : bk + 1;
     }
 }
 
-// slot of the node for (tenant, filter); for "x/#" the node of "x" with is_hash = true
-uint32_t DistIndexHost::find_filter_node(std::string_view tenant, std::string_view filter, bool& is_hash) const {
-    is_hash = false;
-    const TenantSlot* r = find_tenant(find_token(tenant));
-    if (!r) return NONE;
-    uint32_t slot = r->root;
+std::vector<uint32_t> DistIndexHost::find_filter(std::string_view tenant, std::string_view filter) const {
+    std::vector<uint32_t> out;
+    auto it = by_name.find(std::string(tenant));
+    if (it == by_name.end()) return out;
+    const TenantState& t = *it->second;
+    uint32_t slot = t.root_rel;
+    bool is_hash = false;
     size_t s = 0;
     for (size_t i = 0; i <= filter.size() && slot != NONE; i++)
         if (i == filter.size() || filter[i] == '/') {
@@ -536,11 +635,16 @@ uint32_t DistIndexHost::find_filter_node(std::string_view tenant, std::string_vi
                 is_hash = true;
                 break;
             }
-            const uint32_t tok = lv == "+" ? TOK_PLUS : find_token(lv);
-            if (tok == TOK_UNKNOWN) return NONE;
-            slot = find_child(*r, slot, tok);
+            const uint32_t tok = lv == "+" ? TOK_PLUS : dict_find(dict, pool, lv);
+            if (tok == TOK_UNKNOWN) return out;
+            slot = find_child(t, slot, tok);
         }
-    return slot;
+    if (slot == NONE) return out;
+    const TrieSlot& n = trie[t.base + slot];
+    const uint32_t b = is_hash ? n.hash_begin : n.own_begin, cf = is_hash ? n.hash_count : n.own_count;
+    const uint32_t c = cf & ~RANGE_INDIRECT;
+    for (uint32_t i = 0; i < c; i++) out.push_back((cf & RANGE_INDIRECT) ? route_pos[t.rp_base + b + i] : t.rank_base + b + i);
+    return out;
 }
 
 } // namespace bmq

@@ -32,25 +32,30 @@ constexpr int FAST_LEVELS = 16;               // topics with more levels take th
 constexpr uint32_t RANGE_INDIRECT = 0x80000000u; // count flag: begin indexes route_pos[] instead of being the first id
 
 struct alignas(32) TrieSlot {
-    uint32_t parent;      // slot index of the parent (NONE = empty slot, ROOT_PARENT = tenant root)
+    uint32_t parent;      // region-relative slot of the parent (NONE = empty slot, ROOT_PARENT = tenant root)
     uint32_t token;       // dictionary token of the edge label (TOK_PLUS for '+')
-    uint32_t own_begin;   // routes whose filter ends at this node: ids own_begin .. +count-1, or route_pos[own_begin ..]
-    uint32_t own_count;   //   when (own_count & RANGE_INDIRECT)
+    uint32_t own_begin;   // routes whose filter ends at this node: ids rank_base + own_begin .. +count-1, or
+    uint32_t own_count;   //   route_pos[rp_base + own_begin ..] when (own_count & RANGE_INDIRECT)
     uint32_t hash_begin;  // routes of "<this path>/#", same encoding
     uint32_t hash_count;
-    uint32_t plus_child;  // slot index of the '+' child or NONE
+    uint32_t plus_child;  // region-relative slot of the '+' child or NONE
     uint32_t lit_bloom;   // 32-bit Bloom mask over the literal children's tokens; 0 = no literal child
 };
 static_assert(sizeof(TrieSlot) == 32, "TrieSlot must be 32 bytes");
 
 // Tenant directory entry: the tenant's region of the slot table.  Bucket k of the region = slots base+2k, base+2k+1.
-struct alignas(16) TenantSlot {
-    uint32_t token;   // dictionary token of the tenant id; 0 = empty directory slot
-    uint32_t root;    // slot index of the tenant's root node
-    uint32_t base;    // first slot of the region (even)
-    uint32_t buckets; // number of 2-slot buckets (>= 1)
+// Slot indices stored INSIDE a region (TrieSlot.parent, plus_child, the root) are relative to `base`, and route ids
+// inside a region are relative to `rank_base`: a region can be rebuilt, moved or re-based without touching the others.
+struct alignas(32) TenantSlot {
+    uint32_t token;     // dictionary token of the tenant id; 0 = empty directory slot
+    uint32_t root;      // slot of the tenant's root node, relative to base
+    uint32_t base;      // first slot of the region (even)
+    uint32_t buckets;   // number of 2-slot buckets (>= 1)
+    uint32_t rank_base; // global route id of the tenant's first route (ids are ranks in KV key order)
+    uint32_t rp_base;   // first entry of the tenant in route_pos[]
+    uint32_t pad[2];
 };
-static_assert(sizeof(TenantSlot) == 16, "TenantSlot must be 16 bytes");
+static_assert(sizeof(TenantSlot) == 32, "TenantSlot must be 32 bytes");
 
 // Level dictionary: level string -> token, exact (bytes verified).  Strings <= 16 bytes live inline.  Open addressing
 // over groups of four slots (one 128-byte line) at load factor <= 1/4: a lookup reads its home group in one go.

@@ -139,8 +139,12 @@ class Engine:
 
     def route_key(self, route_id: int) -> bytes:
         n = C.c_uint32()
-        buf = C.create_string_buffer(70000)
-        self._check(_lib.lib().bmq_route_key(self.h, route_id, buf, len(buf), C.byref(n)))
+        buf = C.create_string_buffer(512)
+        rc = _lib.lib().bmq_route_key(self.h, route_id, buf, len(buf), C.byref(n))
+        if rc == -3:  # BMQ_E_NOSPACE: n holds the length
+            buf = C.create_string_buffer(n.value)
+            rc = _lib.lib().bmq_route_key(self.h, route_id, buf, len(buf), C.byref(n))
+        self._check(rc)
         return buf.raw[:n.value]
 
     def find(self, tenant, topic_filter) -> List[int]:
