@@ -147,9 +147,15 @@ int upload_dist(bmq_engine* e) {
     DistDevice& d = *e->dist;
     int rc;
     const size_t trie_bytes = h.trie.size() * sizeof(TrieSlot);
-    if (e->pinned_trie != (void*)h.trie.data()) { // pin the host image: region re-uploads then run at PCIe speed
-        if (e->pinned_trie) (void)hipHostUnregister(e->pinned_trie);
-        e->pinned_trie = nullptr;
+    if (!e->pinned_trie && trie_bytes >= (64u << 20)) { // pin a large host image: region re-uploads then run at PCIe
+        h.trie.on_release = [](void* ctx, void* p) {      // speed; the index un-pins through this hook before freeing
+            bmq_engine* eng = (bmq_engine*)ctx;
+            if (eng->pinned_trie == p) {
+                (void)hipHostUnregister(p);
+                eng->pinned_trie = nullptr;
+            }
+        };
+        h.trie.release_ctx = e;
         if (hipHostRegister((void*)h.trie.data(), trie_bytes, hipHostRegisterDefault) == hipSuccess) e->pinned_trie = (void*)h.trie.data();
         else (void)hipGetLastError(); // not fatal: copies fall back to pageable memory
     }
@@ -386,6 +392,8 @@ void bmq_engine_destroy(bmq_engine* e) {
             if (ev) (void)hipEventDestroy(ev);
         if (e->h_ctr) (void)hipHostFree(e->h_ctr);
         if (e->pinned_trie) (void)hipHostUnregister(e->pinned_trie);
+        e->pinned_trie = nullptr;
+        e->host.trie.on_release = nullptr;
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
     delete e;

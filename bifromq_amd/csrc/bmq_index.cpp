@@ -536,9 +536,8 @@ bool DistIndexHost::refresh(std::vector<TenantState*>& touched) {
             t.base = next_free;
             t.cap_slots = (uint32_t)(cap + (cap & 1));
             next_free += t.cap_slots;
-        } else if (!full_upload) {
-            dirty.push_back({t.base, t.cap_slots});
         }
+        if (!full_upload) dirty.push_back({t.base, t.cap_slots}); // rewritten in place or freshly allocated
         t.buckets = buckets;
     }
     if (dict_h.entries.size() != tokens_before) dict_changed = true;

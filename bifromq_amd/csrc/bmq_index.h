@@ -69,26 +69,30 @@ struct TenantOrder { // tenants in KV key order: u16be(len) then bytes (SCHEMA/K
 struct SlotBuf {
     TrieSlot* p = nullptr;
     size_t n = 0;
+    void (*on_release)(void* ctx, void* p) = nullptr; // called before the memory goes away (the engine un-pins it)
+    void* release_ctx = nullptr;
     SlotBuf() = default;
     SlotBuf(const SlotBuf&) = delete;
     SlotBuf& operator=(const SlotBuf&) = delete;
-    ~SlotBuf() { free(p); }
+    ~SlotBuf() { release(); }
+    void release() {
+        if (p && on_release) on_release(release_ctx, p);
+        free(p);
+        p = nullptr;
+        n = 0;
+    }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
     TrieSlot* data() { return p; }
     const TrieSlot* data() const { return p; }
     TrieSlot& operator[](size_t i) { return p[i]; }
     const TrieSlot& operator[](size_t i) const { return p[i]; }
-    void clear() {
-        free(p);
-        p = nullptr;
-        n = 0;
-    }
+    void clear() { release(); }
     bool grow(size_t m, size_t keep) { // contents of [0, keep) survive
         TrieSlot* q = (TrieSlot*)aligned_alloc_zero(m);
         if (!q) return false;
         if (keep) memcpy(q, p, keep * sizeof(TrieSlot));
-        free(p);
+        release();
         p = q;
         n = m;
         return true;

@@ -264,6 +264,36 @@ def test_apply_then_match(eng):
         assert U.csr_rows(row, ids) == U.semantic_rows(kv, tn, tt, topics)
 
 
+def test_apply_creates_and_removes_tenants(eng):
+    """bmq_routes_apply touching a subset of tenants: in-place region rewrite, region relocation (growth), a tenant
+    appearing through apply and a tenant losing its last route; ids stay ranks of the whole key set."""
+    t1 = [_normal("t1", "a/%d" % i, 0, "r%d" % i, "d") for i in range(50)]
+    t2 = [_normal("t2", "b/+", 0, "r%d" % i, "d") for i in range(5)]
+    eng.rebuild(t1 + t2)
+    live = set(t1 + t2)
+    steps = [
+        [(0, _normal("t1", "a/%d/x" % i, 0, "n%d" % i, "d")) for i in range(3)],                    # small, in place
+        [(0, _normal("t0", "a/#", 0, "z", "d")), (0, _normal("t3", "+/1", 1, "p", "d"))],           # new tenants (before and after)
+        [(1, k) for k in t2],                                                                       # t2 disappears
+        [(0, _normal("t1", "g/%d/+/#" % i, 0, "g%d" % i, "d")) for i in range(400)],                # t1 outgrows its region
+        [(1, _normal("t1", "a/7", 0, "r7", "d")), (0, _normal("t2", "b/#", 0, "back", "d"))],       # delete + tenant returns
+    ]
+    topics = ["a/1", "a/7", "a/1/x", "b/q", "g/3/k/m", "zzz/1"]
+    for ops in steps:
+        eng.apply(ops)
+        for o, k in ops:
+            (live.discard if o else live.add)(k)
+        keys = sorted(live)
+        assert eng.info().n_routes == len(keys)
+        assert [eng.route_key(i) for i in range(0, len(keys), 17)] == keys[::17]
+        kv = O.KV(keys)
+        tn = ["t0", "t1", "t2", "t3", "ghost"]
+        tt = [i % 5 for i in range(len(topics) * 5)]
+        tp = [topics[i // 5] for i in range(len(topics) * 5)]
+        row, ids = eng.match_batch(tn, tt, tp)
+        assert U.csr_rows(row, ids) == U.semantic_rows(kv, tn, tt, tp)
+
+
 def test_output_capacity_protocol(eng):
     import ctypes as C
     from bifromq_amd import _lib

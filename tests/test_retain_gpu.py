@@ -102,3 +102,43 @@ def test_apply_add_remove(eng):
     eng.retain_apply("t", [(1, "a/b"), (0, "a/d"), (0, "a/c"), (1, "zzz")])
     assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "a/+")] == ["a/c", "a/d"]
     assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "#")] == ["a/c", "a/d", "x"]
+
+
+def test_full_size_config4_properties(eng):
+    """configs[3]: 1M retained topics, 100k wildcard filters.  CSR well-formed, rows strictly ascending, every id in range,
+    idempotent; a random sample of rows bit-exact vs the oracle's TopicLevelTrie; the sum of all row lengths equals the
+    oracle's on the sample (checksum of counts)."""
+    w = B.Workload(0xB1F20004, 1, 1, 0)
+    data, off, tt = w.retain(0xB1F20004, 1_000_000, filters=False)
+    tn = w.tenants()
+    eng.retain_rebuild(tn, tt, packed_topics=(data, off))
+    fdata, foff, ft = w.retain(0xB1F20004 + 1, 100_000, filters=True)
+    row, ids = eng.retain_match_batch(tn, ft, packed_filters=(fdata, foff))
+    assert row[0] == 0 and row[-1] == len(ids) and (np.diff(row.astype(np.int64)) >= 0).all()
+    d = np.diff(ids.astype(np.int64))
+    starts = row[1:-1][row[1:-1] < len(ids)]
+    d[(starts - 1)[starts > 0]] = 1  # ignore row boundaries
+    assert (d > 0).all()
+    row2, ids2 = eng.retain_match_batch(tn, ft, packed_filters=(fdata, foff))
+    assert (row == row2).all() and (ids == ids2).all()
+    n_index = 0
+    lt = O.LevelTrie(1)
+    while True:  # the engine de-duplicates: ids are ranks of the distinct (tenant, topic) pairs
+        try:
+            tenant, topic = eng.retain_topic(n_index)
+        except B.BmqError:
+            break
+        lt.add(tenant, topic, n_index)
+        n_index += 1
+        if n_index % 250_000 == 0 and n_index >= 1_000_000:
+            break
+    assert ids.max() < n_index
+    rnd = random.Random(4)
+    sample = sorted(rnd.sample(range(100_000), 1500))
+    raw = fdata.tobytes()
+    filters = [raw[foff[i]:foff[i + 1]] for i in sample]
+    res, _ = lt.match_batch(tn, np.zeros(len(sample), dtype=np.uint32), O.pack(filters), threads=8)
+    exp = [sorted(r) for r in res.per_topic()]
+    got = [ids[row[i]:row[i + 1]].tolist() for i in sample]
+    assert sum(len(g) for g in got) == sum(len(e) for e in exp)
+    assert got == exp
