@@ -689,12 +689,13 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
 // k_scan_blocks -- exclusive scan of wave_sums (one workgroup of 1024 threads), total -> counters / out_total
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
-    __shared__ unsigned long long part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (a.n_blocks + 1023) / 1024;
-    const uint32_t b0 = min(tid * per, a.n_blocks), b1 = min(b0 + per, a.n_blocks);
+    __shared__ unsigned long long wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    // every wave owns one contiguous segment; all accesses are lane-strided (coalesced, independent loads)
+    const uint32_t seg = ((a.n_blocks + 15) / 16 + 63) & ~63u;
+    const uint32_t s0 = min(wv * seg, a.n_blocks), s1 = min(s0 + seg, a.n_blocks);
     unsigned long long s = 0, sv = 0, sr = 0, sb = 0;
-    for (uint32_t i = b0; i < b1; i++) {
+    for (uint32_t i = s0 + lane; i < s1; i += 64) {
         s += a.wave_sums[i];
         if (a.blk_stats) {
             const uint4 q = a.blk_stats[i];
@@ -703,31 +704,38 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
             sb += q.z;
         }
     }
-    { // block-reduce the statistics: one add per wave, on top of what the slow path counted
-        const unsigned long long wv = wave_sum_u64(sv), wr = wave_sum_u64(sr), wb = wave_sum_u64(sb);
-        if ((tid & 63u) == 0) {
-            if (wv) atomicAdd(&a.ctr->n_visit, wv);
+    const unsigned long long wsum = wave_sum_u64(s);
+    { // statistics: one add per wave, on top of what the slow path counted
+        const unsigned long long wvv = wave_sum_u64(sv), wr = wave_sum_u64(sr), wb = wave_sum_u64(sb);
+        if (lane == 0) {
+            if (wvv) atomicAdd(&a.ctr->n_visit, wvv);
             if (wr) atomicAdd(&a.ctr->n_ranges, wr);
             if (wb) atomicAdd(&a.ctr->topic_bytes, wb);
         }
     }
-    part[tid] = s;
+    if (lane == 0) wave_tot[wv] = wsum;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        unsigned long long v = 0;
-        if (tid >= d) v = part[tid - d];
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    unsigned long long carry = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+        const unsigned long long t = wave_tot[w];
+        if (w < wv) carry += t;
+        total += t;
     }
-    unsigned long long run = part[tid] - s;
-    for (uint32_t i = b0; i < b1; i++) {
-        const unsigned long long v = a.wave_sums[i];
-        a.wave_sums[i] = run;
-        run += v;
+    // exclusive scan of the segment, 64 elements per step, carry in a register
+    for (uint32_t i0 = s0; i0 < s1; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const unsigned long long v = i < s1 ? a.wave_sums[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += o;
+        }
+        if (i < s1) a.wave_sums[i] = carry + inc - v;
+        carry += __shfl(inc, 63);
     }
-    if (tid == 1023) {
-        const unsigned long long total = part[1023];
+    if (tid == 0) {
         a.ctr->total_ids = total;
         *a.out_total = total;
         if (total > a.out_capacity) atomicOr(&a.ctr->status, ST_NOSPACE);
