@@ -460,6 +460,10 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
             sb = __shfl(sb, 0);
             const bool fits = __shfl(fits_s, 0) != 0 && sb + pcount < 0xFFFFFFFFull;
             if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_SPILL);
+            for (uint32_t i = lane; i < pcount; i += 64) { // per-topic range / id counts of what leaves the buffer
+                atomicAdd(&cnt_pairs[p_topic[i]], 1u);
+                atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
+            }
             if (nflush < MAX_FLUSH) {
                 if (fits)
                     for (uint32_t i = lane; i < pcount; i += 64) a.spill[sb + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
@@ -504,16 +508,12 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
                 p_begin[p] = o.s.own_begin + ((o.s.own_count & RANGE_INDIRECT) ? t_rp[tl] : t_rank[tl]);
                 p_count[p] = o.s.own_count;
                 p_topic[p] = tl;
-                atomicAdd(&cnt_pairs[tl], 1u);
-                atomicAdd(&cnt_routes[tl], o.s.own_count & ~RANGE_INDIRECT);
             }
             if (o.emit_hash) {
                 const uint32_t p = pcount + c1 + rank_below(m2);
                 p_begin[p] = o.s.hash_begin + ((o.s.hash_count & RANGE_INDIRECT) ? t_rp[tl] : t_rank[tl]);
                 p_count[p] = o.s.hash_count;
                 p_topic[p] = tl;
-                atomicAdd(&cnt_pairs[tl], 1u);
-                atomicAdd(&cnt_routes[tl], o.s.hash_count & ~RANGE_INDIRECT);
             }
             pcount += c1 + (uint32_t)__popcll(m2);
         }
@@ -541,6 +541,11 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     }
 
     // ---- phase 3: ranges grouped by topic -> global; per-topic bookkeeping --------------------------------------
+    for (uint32_t i = lane; i < pcount; i += 64) { // counted here, once per range, instead of two LDS atomics per match
+        atomicAdd(&cnt_pairs[p_topic[i]], 1u);
+        atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
+    }
+    wave_sync();
     const uint32_t tm = tmeta[lane];
     const bool flagged = (tm & TM_FLAG) != 0;
     const uint32_t np = flagged ? 0u : cnt_pairs[lane];

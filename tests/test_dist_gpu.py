@@ -294,6 +294,27 @@ def test_apply_creates_and_removes_tenants(eng):
         assert U.csr_rows(row, ids) == U.semantic_rows(kv, tn, tt, tp)
 
 
+def test_edge_shapes(eng):
+    """maximum-size and degenerate inputs: a 65535-byte topic of 32768 empty levels, a 60000-byte single level, batches of
+    one topic, only-slash topics, levels longer than the 16-byte inline prefix that differ only in their tail."""
+    long_a, long_b = "p" * 40 + "A", "p" * 40 + "B"  # same first 16 bytes, same length: the pool compare must decide
+    keys = [_normal("t", "#", 0, "all", "d"), _normal("t", "/#", 0, "slash", "d"), _normal("t", long_a + "/+", 0, "la", "d"),
+            _normal("t", long_b + "/+", 0, "lb", "d"), _normal("t", "x" * 60000, 0, "huge", "d"),
+            _normal("t", "/".join(["+"] * 9), 0, "nine", "d"), _normal("t", "////", 0, "four", "d")]
+    keys = sorted(keys)
+    eng.rebuild(keys)
+    kv = O.KV(keys)
+    topics = ["/" * 65535, "x" * 60000, "x" * 59999, long_a + "/1", long_b + "/1", "p" * 40 + "C/1", "////", "///", "/////",
+              "a/b/c/d/e/f/g/h/i", "a"]
+    exp = [kv.match_bruteforce("t", [t]).per_topic()[0] for t in topics]
+    assert eng.match_tenant("t", topics) == exp
+    assert eng.stats().n_slow_topics >= 1  # the 32768-level topic
+    for i, t in enumerate(topics):  # batches of one
+        assert eng.match_tenant("t", [t]) == [exp[i]]
+    row, ids = eng.match_batch([], [0, 0], ["a", "b"])  # no tenant table at all: every row empty
+    assert row.tolist() == [0, 0, 0] and len(ids) == 0
+
+
 def test_output_capacity_protocol(eng):
     import ctypes as C
     from bifromq_amd import _lib

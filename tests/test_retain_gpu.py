@@ -96,6 +96,20 @@ def test_generated_workload_parity(eng):
     assert (np.diff(row.astype(np.int64)) >= 0).all()
 
 
+def test_edge_shapes(eng):
+    deep = "/".join(["a"] * 40)
+    eng.retain_rebuild(["t"], [0, 0, 0, 0], [deep, "a", "/", "x" * 5000 + "/y"])
+    assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "/".join(["a"] * 39) + "/+")] == [deep]
+    assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "/".join(["+"] * 40))] == [deep]
+    assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "x" * 5000 + "/#")] == ["x" * 5000 + "/y"]
+    assert eng.retain_match("t", "x" * 4999 + "/#") == []
+    assert len(eng.retain_match("t", "#")) == 4
+    with pytest.raises(B.BmqError) as ei:  # documented limit of the kernel: 64 filter levels
+        eng.retain_match("t", "/".join(["+"] * 65))
+    assert ei.value.code == -6
+    assert len(eng.retain_match("t", "#")) == 4  # the engine stays usable after the error
+
+
 def test_apply_add_remove(eng):
     eng.retain_rebuild(["t"], [0, 0, 0], ["a/b", "a/c", "x"])
     assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "a/+")] == ["a/b", "a/c"]
