@@ -41,8 +41,8 @@ def main():
     ap.add_argument("--churn", type=int, default=0,
                     help="configs[4]: apply this many route mutations (50%% subscribe / 50%% unsubscribe) between batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-tenants", type=int, default=16)
-    ap.add_argument("--cpu-sample-topics", type=int, default=200_000)
+    ap.add_argument("--cpu-sample-tenants", type=int, default=128)
+    ap.add_argument("--cpu-sample-topics", type=int, default=1_000_000)
     args = ap.parse_args()
 
     import numpy
