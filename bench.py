@@ -40,6 +40,8 @@ def main():
                     help="publishes in random tenant order instead of one DistPack per tenant (BatchDistRequest shape)")
     ap.add_argument("--churn", type=int, default=0,
                     help="configs[4]: apply this many route mutations (50%% subscribe / 50%% unsubscribe) between batches")
+    ap.add_argument("--exchange-selftest", action="store_true",
+                    help="run the N>1 exchange step (RCCL all-gather of the CSR) also at world size 1, to exercise that code path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tenants", type=int, default=128)
     ap.add_argument("--cpu-sample-topics", type=int, default=1_000_000)
@@ -60,9 +62,14 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.exchange_selftest:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.workload == "c4":
         return bench_retain(args, rank, world, local_rank, dev, dist)
@@ -123,7 +130,7 @@ def main():
                     raise
                 cap = int(d_total.item()) * 2  # only during warm-up in practice
                 d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
-        if world > 1:  # the one exchange step: every rank's CSR (row counts + ids) to every rank over RCCL/xGMI
+        if dist is not None:  # the one exchange step: every rank's CSR (row counts + ids) to every rank over RCCL/xGMI
             from bifromq_amd import shard
             if d_ids.numel() < total:
                 raise RuntimeError("id buffer smaller than the batch result")
@@ -160,7 +167,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -188,14 +195,13 @@ def main():
         n_slow += st.n_slow_topics
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     steps = args.steps
@@ -222,7 +228,7 @@ def main():
                    "index_bytes_this_rank": int(info.device_bytes), "publishes_per_batch_per_rank": n,
                    "batch_order": "random" if args.ungrouped else "grouped by tenant (one DistPack per tenant)",
                    "parallelism": "tenant-shard x%d" % world if world > 1 else "single GPU",
-                   "exchange": "RCCL all_gather of CSR (row_ptr + ids)" if world > 1 else "none"},
+                   "exchange": "RCCL all_gather of CSR (row_ptr + ids)" if dist is not None else "none"},
         "p99_batch_ms": float(np.percentile(lat, 99)),
         "p50_batch_ms": float(np.percentile(lat, 50)),
         "routes_per_topic": n_match / (n * steps),
@@ -246,9 +252,21 @@ def main():
 
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n)
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    emit_json(out)
+    if dist is not None:
         dist.destroy_process_group()
+
+
+def emit_json(out):
+    """ONE JSON line, and the last thing on stdout: flush the C runtime's buffer first (RCCL prints its version banner
+    through it) so that nothing lands after the line."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 def bench_retain(args, rank, world, local_rank, dev, dist):
@@ -354,7 +372,7 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
         out["cpu_baseline"] = {"value": m / sec, "unit": "filters/s", "cores": cores, "kind": "port",
                                "sample": "first %d filters of batch 0 against the full 1M-topic TopicLevelTrie restatement on "
                                          "%d threads; %.1f s" % (m, cores, sec)}
-    print(json.dumps(out), flush=True)
+    emit_json(out)
     if world > 1:
         dist.destroy_process_group()
 

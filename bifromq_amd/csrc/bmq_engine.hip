@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -188,8 +189,16 @@ int upload_dist(bmq_engine* e) {
 }
 
 int publish_epoch(bmq_engine* e) {
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t dirty_slots = 0;
+    for (auto& r : e->host.dirty) dirty_slots += r.second;
+    const bool full = e->host.full_upload;
     int rc = upload_dist(e);
     if (rc) return rc;
+    if (getenv("BMQ_TIMING"))
+        fprintf(stderr, "[bmq build] %-28s %.3f s (%s, %.1f MB of regions)\n", "upload to HBM",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), full ? "full" : "touched regions",
+                full ? e->host.trie.size() * 32 / 1e6 : dirty_slots * 32 / 1e6);
     e->epoch++;
     e->built = true;
     return BMQ_OK;
@@ -405,6 +414,7 @@ void* bmq_stream(const bmq_engine* e) { return e ? (void*)e->stream : nullptr; }
 int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys) {
     if (!e || (n_keys && (!keys || !key_off))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     static const uint32_t zero_off[1] = {0};
     if (!e->host.rebuild(keys, n_keys ? key_off : zero_off, n_keys)) return set_err(e, BMQ_E_INVAL, e->host.error);
     return publish_epoch(e);
@@ -414,6 +424,7 @@ int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off
     if (!e || (n && (!keys || !key_off || !op))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (n == 0) return BMQ_OK;
+    if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (!e->host.apply(keys, key_off, op, n)) return set_err(e, BMQ_E_INVAL, e->host.error);
     return publish_epoch(e);
 }
@@ -463,6 +474,7 @@ int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t*
         return set_err(e, BMQ_E_INVAL, "null pointer or empty batch");
     if ((uintptr_t)d_topics & 15) return set_err(e, BMQ_E_INVAL, "the topic byte buffer must be 16-byte aligned");
     std::lock_guard<std::mutex> g(e->mu);
+    if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     HIPCHK(e, hipSetDevice(e->device));
     if ((rc = ensure_batch_scratch(e, n_tenants, n_topics))) return rc;
     BatchArgs a{};

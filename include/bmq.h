@@ -18,8 +18,10 @@
  *   - match results are CSR: row_ptr[n+1] + ids, ids ascending inside each row;
  *   - buffers are caller-owned; *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and
  *     run asynchronously on the engine's HIP stream until bmq_sync();
- *   - thread-safety: match calls on one engine are serialised internally; one writer (rebuild/apply)
- *     may run concurrently with readers of the previous epoch.
+ *   - thread-safety: every call on one engine is serialised internally (matcher threads of the reference's
+ *     ForkJoinPool, DW/DistWorkerCoProcFactory.java:74-88, may all call into it); ONE device batch may be in flight
+ *     per engine: bmq_match_batch_dev / bmq_retain_match_batch_dev must be followed by bmq_match_finish before the next
+ *     batch, rebuild or apply.  Use one engine per stream of work (e.g. per KV range replica).
  *   - the engine REQUIRES a gfx950 device for every match call.  There is no CPU fallback: without a
  *     device bmq_engine_create(device >= 0) fails with BMQ_E_NODEVICE.
  */
