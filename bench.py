@@ -252,9 +252,9 @@ def main():
 
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n)
-    emit_json(out)
     if dist is not None:
         dist.destroy_process_group()
+    emit_json(out)
 
 
 def emit_json(out):
@@ -372,9 +372,9 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
         out["cpu_baseline"] = {"value": m / sec, "unit": "filters/s", "cores": cores, "kind": "port",
                                "sample": "first %d filters of batch 0 against the full 1M-topic TopicLevelTrie restatement on "
                                          "%d threads; %.1f s" % (m, cores, sec)}
-    emit_json(out)
     if world > 1:
         dist.destroy_process_group()
+    emit_json(out)
 
 
 def cpu_baseline(args, w, host_batch, n):
