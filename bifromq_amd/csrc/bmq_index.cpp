@@ -454,6 +454,7 @@ bool DistIndexHost::rebuild(const uint8_t* keys, const uint32_t* key_off, uint32
 
 bool DistIndexHost::apply(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
     error.clear();
+    PhaseTimer pt;
     std::map<std::string_view, std::vector<std::pair<std::string_view, uint8_t>>> per;
     for (uint32_t i = 0; i < n; i++) {
         const std::string_view k((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
@@ -476,7 +477,9 @@ bool DistIndexHost::apply(const uint8_t* keys, const uint32_t* key_off, const ui
         touched.push_back(it->second.get());
         lists.push_back(&e.second);
     }
+    pt.lap("group ops by tenant");
     parallel_for(touched.size(), [&](size_t i) { touched[i]->keys.apply(*lists[i]); });
+    pt.lap("merge into key sets");
     return refresh(touched);
 }
 
@@ -528,7 +531,7 @@ bool DistIndexHost::refresh(std::vector<TenantState*>& touched) {
             if (b.l2g[i] == TOK_UNKNOWN) b.l2g[i] = intern_owned(b.local_strings[i]);
         const uint32_t buckets = (uint32_t)std::max<uint64_t>(2, (uint64_t)(b.nodes.size() * region_factor / 2.0) + 1);
         if (2ull * buckets > t.cap_slots) { // (re)allocate the region at the end of the table, with room to grow
-            const uint64_t cap = 2ull * buckets + (t.cap_slots ? buckets / 2 : 0);
+            const uint64_t cap = 2ull * buckets + (t.cap_slots ? buckets / 2 : buckets / 4); // head-room: growth stays in place
             if ((uint64_t)next_free + cap >= 0xFFFFFFF0ull) {
                 error = "trie too large";
                 return false;

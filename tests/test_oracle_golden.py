@@ -448,3 +448,15 @@ def test_match_all_equals_bruteforce_random():
             exp = [r for r in range(len(kv)) if (lambda p: p[1] == TENANT and S.matches(
                 t, p[2] if p[0] == 1 else p[2].split("/", 2)[2]))(O.parse_route_key(kv.key(r)))]
             assert a[ti] == exp
+
+
+def test_golden_files_match_the_inline_tables():
+    """tests/golden/*.json are exports of the hand-ported tables above; keep them in sync."""
+    import json
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rows = json.load(open(os.path.join(g, "retain_rows.json"), encoding="utf-8"))
+    assert rows["topics"] == RETAIN_TOPICS
+    assert [tuple(r) for r in rows["rows"]] == [(f, t) for f, t in INDEX_ROWS + TOPIC_INDEX_EXTRA_ROWS]
+    fx = json.load(open(os.path.join(g, "expansion_fixtures.json"), encoding="utf-8"))
+    assert fx["global"] == GLOBAL_TOPIC_TO_FILTERS and fx["local"] == LOCAL_TOPIC_TO_FILTERS
