@@ -75,18 +75,18 @@ struct HostDict {
 };
 
 
-// device layout: groups of four slots (one 128-byte line), load factor <= 1/4
+// device layout: groups of DICT_GROUP slots (one 64-byte line), load factor <= 1/4
 inline void flatten_dict(const HostDict& dict_h, std::vector<DictSlot>& dict, std::vector<uint8_t>& pool) {
     const uint32_t dslots = pow2_at_least(std::max<uint64_t>(8, (uint64_t)dict_h.entries.size() * 4));
-    const uint32_t gmask = dslots / 4 - 1;
+    const uint32_t gmask = dslots / DICT_GROUP - 1;
     dict.assign(dslots, DictSlot{0, 0, 0, 0, {0, 0, 0, 0}});
     pool.clear();
     for (size_t t = 0; t < dict_h.entries.size(); t++) {
         const auto& e = dict_h.entries[t];
         uint32_t g = e.slot_hash & gmask, s = NONE;
         for (;;) {
-            for (uint32_t j = 0; j < 4 && s == NONE; j++)
-                if (!dict[4 * g + j].tag) s = 4 * g + j;
+            for (uint32_t j = 0; j < DICT_GROUP && s == NONE; j++)
+                if (!dict[DICT_GROUP * g + j].tag) s = DICT_GROUP * g + j;
             if (s != NONE) break;
             g = (g + 1) & gmask;
         }
@@ -106,12 +106,12 @@ inline void flatten_dict(const HostDict& dict_h, std::vector<DictSlot>& dict, st
 inline uint32_t dict_find(const std::vector<DictSlot>& dict, const std::vector<uint8_t>& pool, std::string_view level) {
     if (dict.empty()) return TOK_UNKNOWN;
     const LevelHash h = hash_level(level);
-    const uint32_t gmask = (uint32_t)dict.size() / 4 - 1, tag = level_hash_tag(h);
+    const uint32_t gmask = (uint32_t)dict.size() / DICT_GROUP - 1, tag = level_hash_tag(h);
     uint32_t g = level_hash_slot(h, (uint32_t)level.size()) & gmask;
     for (;;) {
         bool group_full = true;
-        for (uint32_t j = 0; j < 4; j++) {
-            const DictSlot& d = dict[4 * g + j];
+        for (uint32_t j = 0; j < DICT_GROUP; j++) {
+            const DictSlot& d = dict[DICT_GROUP * g + j];
             if (!d.tag) {
                 group_full = false;
                 continue;

@@ -180,7 +180,7 @@ __device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// dictionary lookup (exact: tag + length + bytes).  ONE latency: the whole 4-slot home group is requested together.
+// dictionary lookup (exact: tag + length + bytes).  ONE latency: the whole home group (one 64-byte line) is requested together.
 // byte_at(i) returns byte i of the string buffer the level lives in (LDS-staged or global).
 // ------------------------------------------------------------------------------------------------------------
 template <class ByteAt>
@@ -189,16 +189,16 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
     const uint32_t tag = level_hash_tag(h);
     uint32_t g = level_hash_slot(h, len) & ix.dict_group_mask;
     for (;;) {
-        const uint4* p = reinterpret_cast<const uint4*>(ix.dict + 4 * (size_t)g);
-        uint4 hd[4], il[4];
+        const uint4* p = reinterpret_cast<const uint4*>(ix.dict + DICT_GROUP * (size_t)g);
+        uint4 hd[DICT_GROUP], il[DICT_GROUP];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < (int)DICT_GROUP; j++) {
             hd[j] = p[2 * j];
             il[j] = p[2 * j + 1];
         }
         bool full = true;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < (int)DICT_GROUP; j++) {
             if (hd[j].x == 0) full = false;
             else if (hd[j].x == tag && hd[j].z == len && il[j].x == inl[0] && il[j].y == inl[1] && il[j].z == inl[2] &&
                      il[j].w == inl[3]) {
@@ -792,8 +792,11 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
     if (!writable || wtotal == 0) return;
     const uint32_t po = valid ? a.pair_off[t] : 0u;
     const uint32_t np = valid ? a.pair_cnt[t] : 0u;
+    uint32_t ptotal;
+    const uint32_t pexcl = wave_excl_scan(np, lane, ptotal);
+    const bool one_pass = ptotal <= EXP_K; // all ranges of the wave fit one LDS layout: they are ordered there, in LDS
     // order this topic's ranges by first id (usually 1-5 ranges; already ordered lists are left alone)
-    if (np > 1 && np <= SORT_PAIRS) {
+    if (!one_pass && np > 1 && np <= SORT_PAIRS) {
         MatchRange* pr = a.pairs + po;
         for (uint32_t i = 1; i < np; i++) {
             const MatchRange x = pr[i];
@@ -807,8 +810,6 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
         }
     }
     row_bad[lane] = 0;
-    uint32_t ptotal;
-    const uint32_t pexcl = wave_excl_scan(np, lane, ptotal);
     row_first[lane] = pexcl;
     wave_sync();
     unsigned long long out_done = 0; // output elements produced by earlier LDS passes
@@ -823,6 +824,24 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
                 r_begin[k - k0] = r.begin;
                 r_cnt[k - k0] = r.count;
                 r_row[k - k0] = lane;
+            }
+            if (one_pass && np > 1 && np <= SORT_PAIRS) { // insertion sort of this lane's own segment, in LDS
+                for (uint32_t i = pexcl + 1; i < pexcl + np; i++) {
+                    const uint32_t xb = r_begin[i], xc = r_cnt[i];
+                    const uint32_t kx = (xc & RANGE_INDIRECT) ? a.ix.route_pos[xb] : xb;
+                    uint32_t j = i;
+                    while (j > pexcl) {
+                        const uint32_t yb = r_begin[j - 1], yc = r_cnt[j - 1];
+                        if (((yc & RANGE_INDIRECT) ? a.ix.route_pos[yb] : yb) <= kx) break;
+                        r_begin[j] = yb;
+                        r_cnt[j] = yc;
+                        j--;
+                    }
+                    if (j != i) {
+                        r_begin[j] = xb;
+                        r_cnt[j] = xc;
+                    }
+                }
             }
         }
         wave_sync();

@@ -181,7 +181,7 @@ int upload_dist(bmq_engine* e) {
     d.view.tenants = d.tenants.as<TenantSlot>();
     d.view.tenant_mask = (uint32_t)h.tenants.size() - 1;
     d.view.dict = d.dict.as<DictSlot>();
-    d.view.dict_group_mask = (uint32_t)h.dict.size() / 4 - 1;
+    d.view.dict_group_mask = (uint32_t)h.dict.size() / DICT_GROUP - 1;
     d.view.pool = d.pool.as<uint8_t>();
     d.view.route_pos = d.route_pos.as<uint32_t>();
     d.bytes = d.trie.cap + d.tenants.cap + d.dict.cap + d.pool.cap + d.route_pos.cap;

@@ -58,7 +58,8 @@ struct alignas(32) TenantSlot {
 static_assert(sizeof(TenantSlot) == 32, "TenantSlot must be 32 bytes");
 
 // Level dictionary: level string -> token, exact (bytes verified).  Strings <= 16 bytes live inline.  Open addressing
-// over groups of four slots (one 128-byte line) at load factor <= 1/4: a lookup reads its home group in one go.
+// over groups of DICT_GROUP slots (one 64-byte line) at load factor <= 1/4: a lookup reads its home group in one go.
+constexpr uint32_t DICT_GROUP = 2;
 struct alignas(32) DictSlot {
     uint32_t tag;       // second hash, forced non-zero; 0 = empty slot
     uint32_t token;
@@ -120,7 +121,7 @@ struct DistIndexView {
     const TenantSlot* tenants;
     uint32_t tenant_mask;      // tenant directory slots - 1
     const DictSlot* dict;
-    uint32_t dict_group_mask;  // (dictionary slots / 4) - 1
+    uint32_t dict_group_mask;  // (dictionary slots / DICT_GROUP) - 1
     const uint8_t* pool;       // level strings longer than 16 bytes
     const uint32_t* route_pos; // ids of the (rare) nodes whose route ids are not one contiguous rank range
 };
