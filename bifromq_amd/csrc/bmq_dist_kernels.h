@@ -7,19 +7,20 @@
 //
 // Included only by bmq_engine.hip (hipcc --offload-arch=gfx950).  Work decomposition:
 //   k_resolve_tenants : one lane per distinct tenant of the batch -> region of the slot table
-//   k_walk            : one wave per 64 topics.
+//   k_walk            : one wave per 64 topics, WALK_WAVES independent waves per workgroup (own LDS slice each).
 //                       Phase 1: the wave stages its topics' bytes in LDS with coalesced 16-byte loads, then walks
 //                       them level by level: every lane scans its own next level (LDS only), then ALL lanes look
 //                       their level up in the dictionary together -- one memory latency per level, not per lane.
-//                       Phase 2: the wave drains a shared LDS work ring of (parent node, topic, level, kind) items,
+//                       Phase 2: the wave drains a depth-first LDS work stack of (node, topic, level, kind) items,
 //                       one item per lane per round; an item reads one 64-byte bucket (literal child lookup, the
 //                       child's header comes with it) or one 32-byte slot ('+' child / tenant root by slot index).
 //                       Pushes and matches are compacted with ballot + mbcnt.
 //                       Phase 3: matched (begin,count) ranges are counting-sorted by topic and written out.
 //   k_walk_slow       : per-lane DFS with global scratch for topics the LDS path could not finish
-//                       (more than FAST_LEVELS levels, ring overflow, too many range flushes).
+//                       (more than FAST_LEVELS levels, stack overflow, too many range flushes).
 //   k_scan_blocks     : exclusive scan of the per-wave id counts.
-//   k_expand          : per topic, order its ranges by first id and stream the ids into the CSR output.
+//   k_expand          : per 64 rows: order each row's ranges by first id in LDS, lay them out in output order and fill the
+//                       CSR ids with fully coalesced stores (short ranges flattened, long ranges streamed).
 //   k_sort_rows       : bitonic fix-up of rows whose range list was too long to order in k_expand.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     // 8 waves); every wave owns its own slice of LDS and never synchronises with its neighbours
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t* lds = lds_all + wave * (walk_lds_bytes(a.qcap, a.pcap) / 4);
-    uint32_t* un = lds;                                       // union: staged topic bytes | work ring + range buffer
+    uint32_t* un = lds;                                       // union: staged topic bytes | work stack + range buffer
     uint32_t* q_node = un;                                    // [qcap]
     uint32_t* q_meta = q_node + a.qcap;                       // [qcap]
     uint32_t* p_begin = q_meta + a.qcap;                      // [pcap]
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     const bool known = valid && rg.token != TOK_UNKNOWN;
     const bool deep = nlev > FAST_LEVELS;
     const bool active = known && !deep;
-    wave_sync(); // staged bytes are dead from here on: the union becomes ring + range buffer
+    wave_sync(); // staged bytes are dead from here on: the union becomes stack + range buffer
     tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u) | (active ? TM_ACTIVE : 0u);
     cnt_pairs[lane] = 0;
     cnt_routes[lane] = 0;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     t_rank[lane] = rg.rank_base;
     t_rp[lane] = rg.rp_base;
 
-    // ---- phase 2: drain the work ring -----------------------------------------------------------------------------
+    // ---- phase 2: drain the work stack ----------------------------------------------------------------------------
     // The work list is a STACK (newest items first): depth-first order keeps it at a few pending siblings per topic,
     // where breadth-first order would have to hold a whole frontier level of all 64 topics.
     uint32_t tail = 0, pcount = 0, nflush = 0;
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
             }
             pcount += c1 + (uint32_t)__popcll(m2);
         }
-        // children -> ring
+        // children -> stack
         const unsigned long long ml = __ballot(o.push_l), mh = __ballot(o.push_h);
         if (ml | mh) {
             const uint32_t cl = (uint32_t)__popcll(ml);

@@ -76,7 +76,7 @@ typedef struct bmq_stats {
 
 typedef struct bmq_index_info {
     uint64_t n_routes, n_tenants, n_nodes, n_tokens;
-    uint64_t trie_slots, dict_slots;      /* open-addressing table sizes (32-byte slots)                    */
+    uint64_t trie_slots, dict_slots;      /* table sizes in 32-byte slots (trie: sum of the tenant regions)  */
     uint64_t device_bytes;                /* HBM held by the index                                          */
     uint64_t epoch;
 } bmq_index_info;
