@@ -78,7 +78,8 @@ struct bmq_engine {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8]{};
-    std::mutex mu;
+    std::mutex mu;             // protects engine state inside one entry point
+    mutable std::recursive_mutex api;  // held for the whole duration of the host-buffer entry points (they are multi-step)
     std::string err;
 
     // dist direction
@@ -412,6 +413,8 @@ const char* bmq_last_error(const bmq_engine* e) { return e ? e->err.c_str() : "n
 void* bmq_stream(const bmq_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys) {
+    std::unique_lock<std::recursive_mutex> api_lock;
+    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || (n_keys && (!keys || !key_off))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
@@ -421,6 +424,8 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
 }
 
 int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+    std::unique_lock<std::recursive_mutex> api_lock;
+    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || (n && (!keys || !key_off || !op))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (n == 0) return BMQ_OK;
@@ -430,6 +435,8 @@ int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off
 }
 
 int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out) {
+    std::unique_lock<std::recursive_mutex> api_lock;
+    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || !out) return BMQ_E_INVAL;
     out->n_routes = e->host.n_routes;
     out->n_tenants = e->host.n_tenants();
@@ -443,6 +450,8 @@ int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out) {
 }
 
 int bmq_route_key(const bmq_engine* e, uint32_t route_id, uint8_t* out, uint32_t cap, uint32_t* out_len) {
+    std::unique_lock<std::recursive_mutex> api_lock;
+    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || !out_len) return BMQ_E_INVAL;
     if (route_id >= e->host.n_routes) return BMQ_E_INVAL;
     const std::string_view k = e->host.route_key(route_id);
@@ -454,6 +463,8 @@ int bmq_route_key(const bmq_engine* e, uint32_t route_id, uint8_t* out, uint32_t
 
 int bmq_index_find(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter,
                    uint32_t filter_len, uint32_t* out_ids, uint32_t cap, uint32_t* out_n) {
+    std::unique_lock<std::recursive_mutex> api_lock;
+    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || !out_n) return BMQ_E_INVAL;
     *out_n = 0;
     if (!e->built) return BMQ_E_STATE;
@@ -517,6 +528,8 @@ int bmq_stats_get(const bmq_engine* e, bmq_stats* out) {
 int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
                     const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
                     uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed) {
+    std::unique_lock<std::recursive_mutex> api_lock;
+    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     int rc = check_dist_ready(e);
     if (rc) return rc;
     if (!out_row_ptr || !out_needed) return set_err(e, BMQ_E_INVAL, "null output pointer");
@@ -575,6 +588,8 @@ int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, con
                   uint32_t n_topics, int32_t max_pf, int32_t max_gf, uint32_t* out_row_ptr, uint32_t* out_route_ids,
                   uint64_t out_capacity, uint64_t* out_needed, int32_t* out_events, uint32_t events_cap,
                   uint32_t* out_n_events) {
+    std::unique_lock<std::recursive_mutex> api_lock;
+    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     int rc = check_dist_ready(e);
     if (rc) return rc;
     if (!out_row_ptr || !out_needed) return set_err(e, BMQ_E_INVAL, "null output pointer");

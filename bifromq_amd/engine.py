@@ -141,8 +141,8 @@ class Engine:
         n = C.c_uint32()
         buf = C.create_string_buffer(512)
         rc = _lib.lib().bmq_route_key(self.h, route_id, buf, len(buf), C.byref(n))
-        if rc == -3:  # BMQ_E_NOSPACE: n holds the length
-            buf = C.create_string_buffer(n.value)
+        while rc == -3:  # BMQ_E_NOSPACE: n holds the length (ids may move under concurrent apply: retry)
+            buf = C.create_string_buffer(max(n.value, 2 * len(buf)))
             rc = _lib.lib().bmq_route_key(self.h, route_id, buf, len(buf), C.byref(n))
         self._check(rc)
         return buf.raw[:n.value]

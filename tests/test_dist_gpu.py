@@ -315,6 +315,50 @@ def test_edge_shapes(eng):
     assert row.tolist() == [0, 0, 0] and len(ids) == 0
 
 
+def test_concurrent_callers(eng):
+    """The reference calls matchAll from a ForkJoinPool (DW/DistWorkerCoProcFactory.java:74-88) while the apply thread
+    mutates routes: concurrent host-buffer calls on one engine are serialised inside the library (ctypes drops the GIL)."""
+    import threading
+    w = B.Workload(7, 3, 800, 1)
+    keys = w.keys()
+    eng.rebuild(keys)
+    tn = w.tenants()
+    data, off, tt = w.topics(3, 600)
+    topics = [t.decode() for t in unpack(data, off)]
+    kv = O.KV(keys)
+    exp = U.semantic_rows(kv, tn, tt, topics)
+    extra = [_normal(tn[0], "zz/%d" % i, 0, "x%d" % i, "d") for i in range(40)]  # never match the topics above
+    errors = []
+
+    def matcher():
+        try:
+            for _ in range(15):
+                row, ids = eng.match_batch(tn, tt, topics)
+                got = U.csr_rows(row, ids)
+                assert [len(g) for g in got] == [len(x) for x in exp]  # ids shift while routes come and go; counts do not
+                n_now = eng.info().n_routes
+                assert all(eng.route_key(min(r, n_now - 41)) for r in got[0][:3])
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    def mutator():
+        try:
+            for i in range(10):
+                eng.apply([(0, k) for k in extra[i * 4:(i + 1) * 4]])
+                eng.apply([(1, k) for k in extra[i * 4:(i + 1) * 4]])
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    th = [threading.Thread(target=matcher) for _ in range(4)] + [threading.Thread(target=mutator)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    row, ids = eng.match_batch(tn, tt, topics)
+    assert U.csr_rows(row, ids) == exp
+
+
 def test_output_capacity_protocol(eng):
     import ctypes as C
     from bifromq_amd import _lib
