@@ -6,8 +6,8 @@
 // k_retain_walk: persistent waves, one filter per wave at a time (grid-stride).  The frontier is a list of NODE RANGES
 // in LDS (overflowing into a per-wave global scratch).  '+' maps a range to the range of its children with two node
 // reads; a literal level looks every node of the frontier up in the edge hash (one 64-byte line each, lanes in
-// parallel); '#' and end-of-filter emit topic-id RANGES.  Two passes per filter (count, then write) keep the output of a
-// filter contiguous without any per-filter capacity.  The CSR is then produced by the dist direction's k_scan_blocks /
+// parallel); '#' and end-of-filter emit topic-id RANGES.  The ranges of a filter are buffered in LDS and copied out once
+// their number is known; only a filter with more than R_OUT ranges is walked a second time (count, then write).  The CSR is then produced by the dist direction's k_scan_blocks /
 // k_expand / k_sort_rows (same MatchRange plumbing).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,7 +18,8 @@
 namespace bmq {
 
 constexpr uint32_t R_MAXL = 64;        // filter levels supported by the kernel
-constexpr uint32_t R_FRONT = 1024;     // frontier ranges kept in LDS (per buffer)
+constexpr uint32_t R_FRONT = 768;      // frontier ranges kept in LDS (per buffer)
+constexpr uint32_t R_OUT = 512;        // matched ranges of one filter buffered in LDS (more: a second, writing walk)
 constexpr uint32_t RT_PLUS = 0xFFFFFFFDu, RT_HASH = 0xFFFFFFFCu; // level kinds next to dictionary tokens
 constexpr uint32_t ST_RETAIN_DEEP = 128u, ST_RETAIN_FRONT = 256u;
 
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
     __shared__ uint32_t lev_start[R_MAXL + 1], lev_end[R_MAXL + 1], ftok[R_MAXL + 1];
     __shared__ uint32_t fb0[R_FRONT], fc0[R_FRONT], fb1[R_FRONT], fc1[R_FRONT];
     __shared__ uint32_t sh[8];
+    __shared__ uint32_t ob[R_OUT], oc[R_OUT];
     const uint32_t lane = threadIdx.x;
     uint2* gs = r.gscratch + (size_t)blockIdx.x * 2 * r.gcap;
     const uint32_t cap = R_FRONT + r.gcap;
@@ -173,7 +175,14 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             const uint32_t vinc = pass == 0 ? 1u : 0u; // nodes touched are counted once, in the counting pass
             auto emit = [&](bool pred, uint32_t b, uint32_t c) {
                 const unsigned long long m = __ballot(pred);
-                if (pred && pass == 1) a.pairs[base + wp + rank_below(m)] = MatchRange{b, c};
+                if (pred) {
+                    const uint32_t p = wp + rank_below(m);
+                    if (pass == 1) a.pairs[base + p] = MatchRange{b, c};
+                    else if (p < R_OUT) { // first walk: keep the ranges in LDS, most filters never need the second walk
+                        ob[p] = b;
+                        oc[p] = c;
+                    }
+                }
                 wp += (uint32_t)__popcll(m);
                 unsigned long long s = pred ? c : 0u;
                 nr += (uint32_t)wave_sum_u64(s);
@@ -335,6 +344,10 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                     break;
                 }
                 if (wp == 0) break;
+                if (wp <= R_OUT) { // everything is in LDS: copy it out, no second walk
+                    for (uint32_t i = lane; i < wp; i += 64) a.pairs[base + i] = MatchRange{ob[i], oc[i]};
+                    break;
+                }
             }
         }
         if (lane == 0) {
