@@ -916,8 +916,17 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
                 uint32_t* dst = out + r_off[kl];
                 if (cf & RANGE_INDIRECT)
                     for (uint32_t o = lane; o < c; o += 64) dst[o] = a.ix.route_pos[b + o];
-                else
-                    for (uint32_t o = lane; o < c; o += 64) dst[o] = b + o;
+                else { // consecutive ids: 16-byte stores (four ids per lane) between an aligning head and a tail
+                    const uint32_t head = min((uint32_t)(((16u - ((uintptr_t)dst & 15u)) & 15u) >> 2), c);
+                    if (lane < head) dst[lane] = b + lane;
+                    uint4* d4 = reinterpret_cast<uint4*>(dst + head);
+                    const uint32_t n4 = (c - head) >> 2;
+                    for (uint32_t q = lane; q < n4; q += 64) {
+                        const uint32_t v = b + head + 4 * q;
+                        d4[q] = make_uint4(v, v + 1, v + 2, v + 3);
+                    }
+                    for (uint32_t o = head + 4 * n4 + lane; o < c; o += 64) dst[o] = b + o;
+                }
             }
             k = kl + 1;
         }
