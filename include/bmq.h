@@ -17,7 +17,9 @@
  *     DW/cache/MatchedRoutes.java:87-141).  bmq_route_key() maps an id back to its key;
  *   - match results are CSR: row_ptr[n+1] + ids, ids ascending inside each row;
  *   - buffers are caller-owned; *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and
- *     run asynchronously on the engine's HIP stream until bmq_sync();
+ *     run asynchronously on the engine's HIP stream until bmq_match_finish().  Device string buffers (tenants,
+ *     topics, filters) must be 16-byte aligned and readable 16 bytes past their last byte (the kernels read them in
+ *     aligned words); the host-buffer variants stage and pad internally, so host callers have no such duty;
  *   - thread-safety: every call on one engine is serialised internally (matcher threads of the reference's
  *     ForkJoinPool, DW/DistWorkerCoProcFactory.java:74-88, may all call into it); ONE device batch may be in flight
  *     per engine: bmq_match_batch_dev / bmq_retain_match_batch_dev must be followed by bmq_match_finish before the next
