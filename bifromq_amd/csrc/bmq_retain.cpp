@@ -1,16 +1,16 @@
-// bmq_retain.cpp -- host builder of the retained-topic index (see bmq_retain.h).
+// bmq_retain.cpp -- host builder of the retained-topic index (see bmq_retain.h): one trie per tenant.
 #include "bmq_retain.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
-
-#include "bmq_dict.h"
+#include <thread>
 
 namespace bmq {
 
 namespace {
-// order of (tenant, level list): compare tenants bytewise, then topics with '/' ranking below every other byte
-// (== comparing the level lists level by level, a shorter list first) -- the order that makes subtrees contiguous
+// order of level lists: compare topics with '/' ranking below every other byte (== comparing level by level, a shorter
+// list first) -- the order that makes subtrees contiguous id ranges
 inline int cmp_topic(std::string_view a, std::string_view b) {
     const size_t n = std::min(a.size(), b.size());
     for (size_t i = 0; i < n; i++) {
@@ -19,56 +19,33 @@ inline int cmp_topic(std::string_view a, std::string_view b) {
     }
     return a.size() < b.size() ? -1 : (a.size() > b.size() ? 1 : 0);
 }
-} // namespace
+inline bool topic_less(const std::string& a, const std::string& b) { return cmp_topic(a, b) < 0; }
 
-void RetainIndexHost::assign(std::vector<std::pair<std::string, std::string>>&& items) {
-    std::sort(items.begin(), items.end(), [](const auto& x, const auto& y) {
-        if (x.first != y.first) return x.first < y.first;
-        return cmp_topic(x.second, y.second) < 0;
-    });
-    items.erase(std::unique(items.begin(), items.end()), items.end());
-    bytes.clear();
-    off.assign(1, 0);
-    tenant_len.clear();
-    for (auto& it : items) {
-        bytes.insert(bytes.end(), it.first.begin(), it.first.end());
-        bytes.push_back(0);
-        bytes.insert(bytes.end(), it.second.begin(), it.second.end());
-        off.push_back(bytes.size());
-        tenant_len.push_back((uint32_t)it.first.size());
-    }
-    if (bytes.empty()) bytes.push_back(0);
-}
-
-std::vector<std::pair<std::string, std::string>> RetainIndexHost::items() const {
-    std::vector<std::pair<std::string, std::string>> v;
-    v.reserve(size());
-    for (size_t i = 0; i < size(); i++) v.emplace_back(std::string(tenant_of(i)), std::string(topic_of(i)));
-    return v;
-}
-
-bool RetainIndexHost::build() {
-    error.clear();
-    const size_t n = size();
-    if (n >= 0x7FFFFFF0ull) {
-        error = "too many retained topics";
-        return false;
-    }
-    struct PNode { // preorder construction
+struct LocalBuild { // phase 1 result: a tenant's trie with tenant-local tokens
+    RTenantState* st = nullptr;
+    struct PNode {
         uint32_t parent, token, first_child, n_children, term, sub_begin, sub_end, bfs;
         bool sys;
     };
-    std::vector<PNode> pn;
-    pn.reserve(n * 2 + 16);
-    HostDict dict_h;
-    std::vector<uint32_t> roots;
-    std::vector<uint32_t> stack; // node per depth of the previous topic (stack[0] = tenant root)
-    std::vector<std::string_view> prev_levels;
-    std::string_view prev_tenant;
-    bool have_prev = false;
-    std::vector<std::string_view> levels;
+    std::vector<PNode> pn;          // preorder
+    std::vector<uint32_t> order;    // bfs index -> preorder id
+    std::vector<uint32_t> next_after;
+    std::vector<std::string_view> local_strings;
+    std::vector<uint32_t> l2g;
+};
+
+void build_local(LocalBuild& b) {
+    RTenantState& t = *b.st;
+    const size_t n = t.topics.size();
+    HostDict local;
+    auto& pn = b.pn;
+    pn.clear();
+    pn.reserve(n * 2 + 4);
+    pn.push_back({NONE, 0, NONE, 0, 0, 0, 0, 0, false}); // root (label = tenant id, filled in globally)
+    std::vector<uint32_t> stack{0};
+    std::vector<std::string_view> prev_levels, levels;
     for (size_t i = 0; i < n; i++) {
-        const std::string_view tenant = tenant_of(i), topic = topic_of(i);
+        const std::string_view topic = t.topics[i];
         levels.clear();
         for (size_t s = 0, k = 0; k <= topic.size(); k++)
             if (k == topic.size() || topic[k] == '/') {
@@ -76,23 +53,13 @@ bool RetainIndexHost::build() {
                 s = k + 1;
             }
         size_t reuse = 0;
-        if (!have_prev || tenant != prev_tenant) {
-            roots.push_back((uint32_t)pn.size());
-            pn.push_back({NONE, dict_h.intern(tenant), NONE, 0, 0, (uint32_t)i, 0, 0, false});
-            stack.assign(1, (uint32_t)pn.size() - 1);
-            prev_levels.clear();
-            prev_tenant = tenant;
-            have_prev = true;
-        } else {
-            while (reuse < levels.size() && reuse < prev_levels.size() && levels[reuse] == prev_levels[reuse]) reuse++;
-        }
+        while (reuse < levels.size() && reuse < prev_levels.size() && levels[reuse] == prev_levels[reuse]) reuse++;
         stack.resize(reuse + 1);
         prev_levels.resize(reuse);
         for (size_t l = reuse; l < levels.size(); l++) {
             const uint32_t parent = stack.back();
             const uint32_t id = (uint32_t)pn.size();
-            pn.push_back({parent, dict_h.intern(levels[l]), NONE, 0, 0, (uint32_t)i, 0, 0,
-                          !levels[l].empty() && levels[l][0] == '$'});
+            pn.push_back({parent, local.intern(levels[l]), NONE, 0, 0, (uint32_t)i, 0, 0, !levels[l].empty() && levels[l][0] == '$'});
             if (pn[parent].first_child == NONE) pn[parent].first_child = id;
             pn[parent].n_children++;
             stack.push_back(id);
@@ -100,13 +67,14 @@ bool RetainIndexHost::build() {
         }
         pn[stack.back()].term = 1; // sorted unique input: each topic ends at a distinct node
     }
-    // subtree id ranges: preorder means a node's subtree is the node index range up to the next node that is not a
-    // descendant; sub_begin was set to the first topic at/below the node, sub_end follows from the parent chain
+    // subtree id ranges + "next node after the subtree" (= next sibling), one stack pass over the preorder
+    b.next_after.assign(pn.size(), (uint32_t)pn.size());
     {
         std::vector<uint32_t> st;
         for (uint32_t v = 0; v < pn.size(); v++) {
             while (!st.empty() && st.back() != pn[v].parent) {
                 pn[st.back()].sub_end = pn[v].sub_begin;
+                b.next_after[st.back()] = v;
                 st.pop_back();
             }
             st.push_back(v);
@@ -116,83 +84,238 @@ bool RetainIndexHost::build() {
             st.pop_back();
         }
     }
-    // breadth-first numbering: roots first, then level by level; children of a node keep their (sorted) order.  The
-    // children of node v in preorder: first_child, then repeatedly "the next node after that child's subtree".
-    std::vector<uint32_t> order; // bfs index -> preorder id
-    order.reserve(pn.size());
-    for (uint32_t r : roots) order.push_back(r);
-    // next sibling in preorder = first node after the subtree; subtree node-extent via a second stack pass
-    std::vector<uint32_t> next_after(pn.size(), (uint32_t)pn.size());
-    {
-        std::vector<uint32_t> st;
-        for (uint32_t v = 0; v < pn.size(); v++) {
-            while (!st.empty() && st.back() != pn[v].parent) {
-                next_after[st.back()] = v;
-                st.pop_back();
-            }
-            st.push_back(v);
-        }
-    }
-    for (size_t q = 0; q < order.size(); q++) {
-        const uint32_t v = order[q];
+    // breadth-first numbering; children of a node keep their (sorted) order
+    b.order.clear();
+    b.order.reserve(pn.size());
+    b.order.push_back(0);
+    for (size_t q = 0; q < b.order.size(); q++) {
+        const uint32_t v = b.order[q];
         uint32_t c = pn[v].first_child;
         for (uint32_t k = 0; k < pn[v].n_children; k++) {
-            order.push_back(c);
-            c = next_after[c];
+            b.order.push_back(c);
+            c = b.next_after[c];
         }
     }
-    for (uint32_t b = 0; b < order.size(); b++) pn[order[b]].bfs = b;
-    nodes.assign(std::max<size_t>(order.size(), 1), RNode{0, 0, 0, 0});
-    const uint32_t eslots = pow2_at_least(std::max<uint64_t>(8, (uint64_t)order.size() * 2));
+    for (uint32_t i = 0; i < b.order.size(); i++) pn[b.order[i]].bfs = i;
+    b.local_strings.resize(local.entries.size());
+    for (size_t i = 0; i < local.entries.size(); i++) b.local_strings[i] = local.entries[i].s;
+}
+
+void place_local(LocalBuild& b) { // phase 3: nodes + edge hash with global tokens
+    RTenantState& t = *b.st;
+    auto& pn = b.pn;
+    const size_t nn = b.order.size();
+    t.nodes.assign(nn, RNode{0, 0, 0, 0});
+    const uint32_t eslots = pow2_at_least(std::max<uint64_t>(8, (uint64_t)nn * 2));
     const uint32_t bmask = eslots / 4 - 1;
-    edges.assign(eslots, REdge{NONE, 0, 0, 0});
-    uint32_t running = (uint32_t)roots.size(); // child_begin is monotone also over childless nodes, so that the children
-    for (uint32_t b = 0; b < order.size(); b++) { // of the node range [a, b) are [child_begin(a), child_begin(b-1) + count(b-1))
-        const PNode& p = pn[order[b]];
-        RNode& r = nodes[b];
+    t.edges.assign(eslots, REdge{NONE, 0, 0, 0});
+    uint32_t running = 1; // child_begin is monotone also over childless nodes: the children of the node range [a, b)
+    for (uint32_t i = 0; i < nn; i++) { // are [child_begin(a), child_begin(b-1) + count(b-1))
+        const auto& p = pn[b.order[i]];
+        RNode& r = t.nodes[i];
         r.child_begin = running;
         running += p.n_children;
         r.child_count = p.n_children | (p.term ? RN_TERM : 0u);
         r.sub_begin = p.sub_begin;
         r.sub_end = p.sub_end;
         if (p.parent != NONE) {
-            const uint32_t pb = pn[p.parent].bfs;
-            uint32_t bk = redge_bucket(pb, p.token, bmask), s = NONE;
+            const uint32_t pb = pn[p.parent].bfs, tok = b.l2g[p.token - TOK_FIRST];
+            uint32_t bk = redge_bucket(pb, tok, bmask), s = NONE;
             for (;;) {
                 for (uint32_t j = 0; j < 4 && s == NONE; j++)
-                    if (edges[4 * bk + j].parent == NONE) s = 4 * bk + j;
+                    if (t.edges[4 * bk + j].parent == NONE) s = 4 * bk + j;
                 if (s != NONE) break;
                 bk = (bk + 1) & bmask;
             }
-            edges[s] = REdge{pb, p.token, b, 0};
+            t.edges[s] = REdge{pb, tok, i, 0};
         }
     }
-    const uint32_t tslots = pow2_at_least((uint64_t)roots.size() * 2);
-    tenants.assign(tslots, RTenantSlot{0, 0, 0, 0, 0, 0, {0, 0}});
-    for (uint32_t r : roots) {
-        RTenantSlot t{pn[r].token, pn[r].bfs, 0, 0, 0, 0, {0, 0}};
-        // the '$' children of the root form one contiguous run (children are sorted by label bytes)
-        uint32_t c = pn[r].first_child;
-        bool in_run = false;
-        for (uint32_t k = 0; k < pn[r].n_children; k++) {
-            if (pn[c].sys) {
-                if (!in_run) {
-                    t.sys_node_lo = pn[c].bfs;
-                    t.sys_id_lo = pn[c].sub_begin;
-                    in_run = true;
-                }
-                t.sys_node_hi = pn[c].bfs + 1;
-                t.sys_id_hi = pn[c].sub_end;
+    // the '$' children of the root form one contiguous run (children are sorted by label bytes)
+    t.sys_node_lo = t.sys_node_hi = t.sys_id_lo = t.sys_id_hi = 0;
+    uint32_t c = pn[0].first_child;
+    bool in_run = false;
+    for (uint32_t k = 0; k < pn[0].n_children; k++) {
+        if (pn[c].sys) {
+            if (!in_run) {
+                t.sys_node_lo = pn[c].bfs;
+                t.sys_id_lo = pn[c].sub_begin;
+                in_run = true;
             }
-            c = next_after[c];
+            t.sys_node_hi = pn[c].bfs + 1;
+            t.sys_id_hi = pn[c].sub_end;
         }
-        uint32_t d = tenant_hash(t.token) & (tslots - 1);
-        while (tenants[d].token) d = (d + 1) & (tslots - 1);
-        tenants[d] = t;
+        c = b.next_after[c];
     }
-    flatten_dict(dict_h, dict, pool);
-    n_topics = n;
-    n_tenants = roots.size();
+}
+
+template <class F> void parallel_for(size_t n, F&& f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nth = (unsigned)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 64), std::max<size_t>(n, 1));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) break;
+            f(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < nth; w++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+} // namespace
+
+bool RetainIndexHost::rebuild(std::vector<std::pair<std::string, std::string>>&& items) {
+    error.clear();
+    by_name.clear();
+    order.clear();
+    nodes.clear();
+    edges.clear();
+    dict_h = HostDict();
+    strings.clear();
+    node_free = edge_free = 0;
+    full_upload = dict_changed = true;
+    dirty.clear();
+    std::vector<RTenantState*> touched;
+    for (auto& it : items) {
+        auto f = by_name.find(it.first);
+        if (f == by_name.end()) {
+            auto st = std::make_unique<RTenantState>();
+            st->name = it.first;
+            f = by_name.emplace(it.first, std::move(st)).first;
+            touched.push_back(f->second.get());
+        }
+        f->second->topics.push_back(std::move(it.second));
+    }
+    parallel_for(touched.size(), [&](size_t i) {
+        auto& tp = touched[i]->topics;
+        std::sort(tp.begin(), tp.end(), topic_less);
+        tp.erase(std::unique(tp.begin(), tp.end()), tp.end());
+    });
+    return refresh(touched);
+}
+
+bool RetainIndexHost::apply(const std::string& tenant, std::vector<std::pair<std::string, uint8_t>>&& ops) {
+    error.clear();
+    auto f = by_name.find(tenant);
+    if (f == by_name.end()) {
+        auto st = std::make_unique<RTenantState>();
+        st->name = tenant;
+        f = by_name.emplace(tenant, std::move(st)).first;
+    }
+    RTenantState& t = *f->second;
+    for (auto& op : ops) { // in order: IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134)
+        auto it = std::lower_bound(t.topics.begin(), t.topics.end(), op.first, topic_less);
+        const bool present = it != t.topics.end() && *it == op.first;
+        if (op.second == 0) {
+            if (!present) t.topics.insert(it, std::move(op.first));
+        } else if (op.second == 1) {
+            if (present) t.topics.erase(it);
+        } else {
+            error = "op must be 0 (add) or 1 (remove)";
+            return false;
+        }
+    }
+    std::vector<RTenantState*> touched{&t};
+    return refresh(touched);
+}
+
+bool RetainIndexHost::refresh(std::vector<RTenantState*>& touched) {
+    std::vector<RTenantState*> live;
+    for (RTenantState* t : touched) {
+        if (t->topics.empty()) {
+            const std::string name = t->name;
+            by_name.erase(name);
+        } else live.push_back(t);
+    }
+    std::vector<LocalBuild> builds(live.size());
+    for (size_t i = 0; i < live.size(); i++) builds[i].st = live[i];
+    parallel_for(builds.size(), [&](size_t i) { build_local(builds[i]); });
+    const size_t tokens_before = dict_h.entries.size();
+    auto intern_owned = [&](std::string_view s) -> uint32_t {
+        const size_t before = dict_h.entries.size();
+        const uint32_t tok = dict_h.intern(s);
+        if (dict_h.entries.size() != before) {
+            strings.emplace_back(s);
+            dict_h.entries.back().s = strings.back();
+        }
+        return tok;
+    };
+    parallel_for(builds.size(), [&](size_t bi) {
+        LocalBuild& b = builds[bi];
+        b.l2g.resize(b.local_strings.size());
+        for (size_t i = 0; i < b.local_strings.size(); i++) b.l2g[i] = dict_h.find(b.local_strings[i]);
+    });
+    for (auto& b : builds) {
+        b.st->token = intern_owned(b.st->name);
+        for (size_t i = 0; i < b.local_strings.size(); i++)
+            if (b.l2g[i] == TOK_UNKNOWN) b.l2g[i] = intern_owned(b.local_strings[i]);
+    }
+    if (dict_h.entries.size() != tokens_before) dict_changed = true;
+    parallel_for(builds.size(), [&](size_t i) { place_local(builds[i]); });
+    // segment allocation in the global arrays (with head-room; a tenant that outgrows its segment moves to the end)
+    for (auto& b : builds) {
+        RTenantState& t = *b.st;
+        if (t.nodes.size() > t.node_cap) {
+            t.node_base = node_free;
+            t.node_cap = (uint32_t)(t.nodes.size() + t.nodes.size() / 4 + 4);
+            node_free += t.node_cap;
+        }
+        if (t.edges.size() > t.edge_cap) {
+            t.edge_base = edge_free;
+            t.edge_cap = (uint32_t)t.edges.size();
+            edge_free += t.edge_cap;
+        }
+    }
+    if (node_free > nodes.size() || edge_free > edges.size()) {
+        nodes.resize(std::max<size_t>((size_t)node_free + node_free / 4, 16));
+        edges.resize(std::max<size_t>((size_t)edge_free + edge_free / 4, 16), REdge{NONE, 0, 0, 0});
+        full_upload = true;
+        dirty.clear();
+    }
+    for (auto& b : builds) {
+        RTenantState& t = *b.st;
+        std::copy(t.nodes.begin(), t.nodes.end(), nodes.begin() + t.node_base);
+        std::copy(t.edges.begin(), t.edges.end(), edges.begin() + t.edge_base);
+        if (!full_upload) dirty.push_back(&t);
+    }
+    order.clear();
+    uint64_t id = 0;
+    for (auto& e : by_name) {
+        e.second->id_base = (uint32_t)id;
+        id += e.second->topics.size();
+        order.push_back(e.second.get());
+    }
+    if (id >= 0x7FFFFFF0ull) {
+        error = "too many retained topics";
+        return false;
+    }
+    n_topics = id;
+    const uint32_t tslots = pow2_at_least((uint64_t)order.size() * 2);
+    tenants.assign(tslots, RTenantSlot{0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}});
+    for (RTenantState* t : order) {
+        uint32_t d = tenant_hash(t->token) & (tslots - 1);
+        while (tenants[d].token) d = (d + 1) & (tslots - 1);
+        tenants[d] = RTenantSlot{t->token, t->node_base, t->edge_base, (uint32_t)t->edges.size() / 4 - 1, t->id_base,
+                                 t->sys_node_lo, t->sys_node_hi, t->sys_id_lo, t->sys_id_hi, {0, 0, 0, 0, 0, 0, 0}};
+    }
+    if (dict_changed) flatten_dict(dict_h, dict, pool);
+    if (nodes.empty()) nodes.resize(16);
+    if (edges.empty()) edges.resize(16, REdge{NONE, 0, 0, 0});
+    return true;
+}
+
+bool RetainIndexHost::topic(uint32_t id, std::string_view& tenant, std::string_view& topic) const {
+    if (id >= n_topics || order.empty()) return false;
+    size_t lo = 0, hi = order.size();
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) / 2;
+        if (order[mid]->id_base <= id) lo = mid;
+        else hi = mid;
+    }
+    tenant = order[lo]->name;
+    topic = order[lo]->topics[id - order[lo]->id_base];
     return true;
 }
 

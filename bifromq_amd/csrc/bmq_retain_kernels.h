@@ -49,17 +49,19 @@ struct Frontier {
     }
 };
 
-__device__ __forceinline__ uint32_t redge_lookup(const RetainIndexView& ix, uint32_t parent, uint32_t token) {
-    uint32_t bk = redge_bucket(parent, token, ix.edge_bucket_mask);
+// (parent, token) -> child inside the tenant's edge region (all ids tenant-local); NONE if absent
+__device__ __forceinline__ uint32_t redge_lookup(const RetainIndexView& ix, uint32_t edge_base, uint32_t mask, uint32_t parent,
+                                                 uint32_t token) {
+    uint32_t bk = redge_bucket(parent, token, mask);
     for (;;) {
-        const uint4* p = reinterpret_cast<const uint4*>(ix.edges + 4 * (size_t)bk);
+        const uint4* p = reinterpret_cast<const uint4*>(ix.edges + edge_base + 4 * (size_t)bk);
         const uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
         if (e0.x == parent && e0.y == token) return e0.z;
         if (e1.x == parent && e1.y == token) return e1.z;
         if (e2.x == parent && e2.y == token) return e2.z;
         if (e3.x == parent && e3.y == token) return e3.z;
         if (e0.x == NONE || e1.x == NONE || e2.x == NONE || e3.x == NONE) return NONE;
-        bk = (bk + 1) & ix.edge_bucket_mask;
+        bk = (bk + 1) & mask;
     }
 }
 __device__ __forceinline__ RNode load_rnode(const RetainIndexView& ix, uint32_t i) {
@@ -70,7 +72,7 @@ __device__ __forceinline__ RNode load_rnode(const RetainIndexView& ix, uint32_t 
 __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
     __shared__ uint32_t lev_start[R_MAXL + 1], lev_end[R_MAXL + 1], ftok[R_MAXL + 1];
     __shared__ uint32_t fb0[R_FRONT], fc0[R_FRONT], fb1[R_FRONT], fc1[R_FRONT];
-    __shared__ uint32_t sh[8];
+    __shared__ uint32_t sh[12];
     __shared__ uint32_t ob[R_OUT], oc[R_OUT];
     const uint32_t lane = threadIdx.x;
     uint2* gs = r.gscratch + (size_t)blockIdx.x * 2 * r.gcap;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
         if (nlev > R_MAXL) deep = true;
         if (lane == 0 && !deep) lev_end[nlev - 1] = end;
         __syncthreads();
-        RTenantSlot ten{0, 0, 0, 0, 0, 0, {0, 0}};
+        RTenantSlot ten{0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
         if (!deep) {
             const uint8_t* fbytes = r.filters;
             auto fbyte = [&](uint32_t k) -> uint32_t { return fbytes[k]; };
@@ -151,8 +153,11 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                         const uint4 t0 = p[0];
                         if (t0.x == tok) {
                             const uint4 t1 = p[1];
-                            sh[1] = t0.z; sh[2] = t0.w; sh[3] = t1.x; sh[4] = t1.y;
-                            root = t0.y;
+                            const uint4 t2 = p[2];
+                            sh[1] = t0.y; sh[2] = t0.z; sh[3] = t0.w;                   // node_base, edge_base, edge mask
+                            sh[4] = t1.x; sh[5] = t1.y; sh[6] = t1.z; sh[7] = t1.w;     // id_base, sys nodes lo/hi, sys id lo
+                            sh[8] = t2.x;                                               // sys id hi
+                            root = 0; // tenant-local id of the root
                             break;
                         }
                         if (t0.x == 0) break;
@@ -164,7 +169,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
         }
         __syncthreads();
         const uint32_t root = deep ? NONE : sh[0];
-        ten.sys_node_lo = sh[1]; ten.sys_node_hi = sh[2]; ten.sys_id_lo = sh[3]; ten.sys_id_hi = sh[4];
+        ten.node_base = sh[1]; ten.edge_base = sh[2]; ten.edge_bucket_mask = sh[3]; ten.id_base = sh[4];
+        ten.sys_node_lo = sh[5]; ten.sys_node_hi = sh[6]; ten.sys_id_lo = sh[7]; ten.sys_id_hi = sh[8];
         if (deep && lane == 0) atomicOr(&a.ctr->status, ST_RETAIN_DEEP);
 
         // ---- two passes: count, then write -------------------------------------------------------------------------------------
@@ -175,11 +181,11 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             const uint32_t vinc = pass == 0 ? 1u : 0u; // nodes touched are counted once, in the counting pass
             auto emit = [&](bool pred, uint32_t b, uint32_t c) {
                 const unsigned long long m = __ballot(pred);
-                if (pred) {
+                if (pred) { // b is a tenant-local topic rank: ids are global
                     const uint32_t p = wp + rank_below(m);
-                    if (pass == 1) a.pairs[base + p] = MatchRange{b, c};
+                    if (pass == 1) a.pairs[base + p] = MatchRange{ten.id_base + b, c};
                     else if (p < R_OUT) { // first walk: keep the ranges in LDS, most filters never need the second walk
-                        ob[p] = b;
+                        ob[p] = ten.id_base + b;
                         oc[p] = c;
                     }
                 }
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                         if (!mixed) { // singletons in parallel
                             const bool one = i < ncur && rg.y == 1;
                             RNode n{0, 0, 0, 0};
-                            if (one) n = load_rnode(r.ix, rg.x);
+                            if (one) n = load_rnode(r.ix, ten.node_base + rg.x);
                             if (l == 0) { // filter "#": everything of the tenant except what lies below '$' children
                                 emit(one && ten.sys_id_lo > n.sub_begin && ten.sys_id_hi > ten.sys_id_lo, n.sub_begin, ten.sys_id_lo - n.sub_begin);
                                 const uint32_t lo2 = ten.sys_id_hi > ten.sys_id_lo ? ten.sys_id_hi : n.sub_begin;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                                 const uint32_t j = j0 + lane;
                                 RNode n{0, 0, 0, 0};
                                 if (j < c) {
-                                    n = load_rnode(r.ix, b + j);
+                                    n = load_rnode(r.ix, ten.node_base + b + j);
                                     visits += vinc;
                                 }
                                 emit(j < c && n.sub_end > n.sub_begin, n.sub_begin, n.sub_end - n.sub_begin);
@@ -241,8 +247,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                         uint32_t b1 = 0, c1 = 0, b2 = 0, c2 = 0;
                         if (i < ncur) {
                             const uint2 rg = cur.get(i);
-                            const RNode first = load_rnode(r.ix, rg.x);
-                            const RNode last = rg.y > 1 ? load_rnode(r.ix, rg.x + rg.y - 1) : first;
+                            const RNode first = load_rnode(r.ix, ten.node_base + rg.x);
+                            const RNode last = rg.y > 1 ? load_rnode(r.ix, ten.node_base + rg.x + rg.y - 1) : first;
                             visits += 2 * vinc;
                             const uint32_t cb = first.child_begin, ce = last.child_begin + (last.child_count & ~RN_TERM);
                             if (l == 0 && ten.sys_node_hi > ten.sys_node_lo) { // skip the '$' children of the tenant root
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                         if (!mixed) {
                             uint32_t child = NONE;
                             if (i < ncur && rg.y == 1) {
-                                child = redge_lookup(r.ix, rg.x, kind);
+                                child = redge_lookup(r.ix, ten.edge_base, ten.edge_bucket_mask, rg.x, kind);
                                 visits += vinc;
                             }
                             const unsigned long long m = __ballot(child != NONE);
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                                 const uint32_t j = j0 + lane;
                                 uint32_t child = NONE;
                                 if (j < c) {
-                                    child = redge_lookup(r.ix, b + j, kind);
+                                    child = redge_lookup(r.ix, ten.edge_base, ten.edge_bucket_mask, b + j, kind);
                                     visits += vinc;
                                 }
                                 const unsigned long long m = __ballot(child != NONE);
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                         const bool one = i < ncur && rg.y == 1;
                         RNode n{0, 0, 0, 0};
                         if (one) {
-                            n = load_rnode(r.ix, rg.x);
+                            n = load_rnode(r.ix, ten.node_base + rg.x);
                             visits += vinc;
                         }
                         emit(one && (n.child_count & RN_TERM), n.sub_begin, 1);
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                             const uint32_t j = j0 + lane;
                             RNode n{0, 0, 0, 0};
                             if (j < c) {
-                                n = load_rnode(r.ix, b + j);
+                                n = load_rnode(r.ix, ten.node_base + b + j);
                                 visits += vinc;
                             }
                             emit(j < c && (n.child_count & RN_TERM), n.sub_begin, 1);

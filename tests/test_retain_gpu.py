@@ -110,6 +110,46 @@ def test_edge_shapes(eng):
     assert len(eng.retain_match("t", "#")) == 4  # the engine stays usable after the error
 
 
+def test_apply_is_per_tenant(eng):
+    """add/remove touch one tenant: its segment is rebuilt (and moved when it outgrows its room), other tenants keep
+    their nodes; ids stay ranks over all tenants."""
+    rnd = random.Random(8)
+    state = {"tA": {"a/b", "a/c", "x"}, "tB": {"a/b"}, "tD": {"$sys/1", "q/r/s"}}
+    items = [(t, p) for t, ps in state.items() for p in ps]
+    tn = sorted(state)
+    eng.retain_rebuild(tn, [tn.index(t) for t, _ in items], [p for _, p in items])
+
+    def check():
+        lt = O.LevelTrie(1)
+        n = sum(len(v) for v in state.values())
+        for i in range(n):
+            tenant, topic = eng.retain_topic(i)
+            assert topic in state[tenant]
+            lt.add(tenant, topic, i)
+        names = sorted(state) + ["ghost"]
+        filters = ["#", "+/#", "a/+", "a/#", "+/+/+", "$sys/#", "new/+/3", "q/r/+"]
+        ft = [i % len(names) for i in range(len(filters) * len(names))]
+        fl = [filters[i // len(names)] for i in range(len(filters) * len(names))]
+        row, ids = eng.retain_match_batch(names, ft, fl)
+        got = U.csr_rows(row, ids)
+        for i in range(len(fl)):
+            assert got[i] == sorted(lt.match(names[ft[i]], fl[i])), (names[ft[i]], fl[i])
+
+    check()
+    steps = [("tA", [(0, "a/d"), (1, "x")]), ("tC", [(0, "new/1/3"), (0, "new/2/3")]),         # a tenant appears
+             ("tB", [(1, "a/b")]),                                                             # a tenant disappears
+             ("tA", [(0, "g/%d/%d" % (i, i % 7)) for i in range(500)]),                        # outgrows its segment
+             ("tD", [(1, "$sys/1"), (0, "$sys/2"), (0, "a")]), ("tB", [(0, "a/z")])]           # ... and returns
+    for tenant, ops in steps:
+        eng.retain_apply(tenant, ops)
+        for o, tp in ops:
+            s_ = state.setdefault(tenant, set())
+            (s_.discard if o else s_.add)(tp)
+        for k in [k for k, v in state.items() if not v]:
+            del state[k]
+        check()
+
+
 def test_apply_add_remove(eng):
     eng.retain_rebuild(["t"], [0, 0, 0], ["a/b", "a/c", "x"])
     assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "a/+")] == ["a/b", "a/c"]
