@@ -374,8 +374,11 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     uint32_t* f_len = f_base + MAX_FLUSH;                     // [MAX_FLUSH]
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t blk = blockIdx.x * WALK_WAVES + wave;
+    uint32_t blk = blockIdx.x * WALK_WAVES + wave;
     if (blk >= a.n_blocks) return;
+    // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
+    // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
+    blk = a.n_blocks - 1 - blk;
     const uint32_t t = blk * 64 + lane;
     const bool valid = t < a.n_topics;
 
