@@ -8,9 +8,9 @@ A "step" is one pass of the hot path over one batch of synthetic publishes: toke
 left in HBM (plus, for N > 1, the one exchange step of SURVEY.md 8e: an all-gather of every rank's CSR).
 Workload (config.workload):
   c3 (default): 1000 tenants x 10k routes = 10M route keys (the index size BASELINE.json's metric is quoted at; it fits
-      one GPU), Zipf(1.0) tenant popularity, 1M publishes per batch.  N > 1: tenants are partitioned across ranks
-      (tenant-id blocks -- the synthetic stand-in for hash(tenantId) mod N), every rank matches its own 1M-publish
-      batch per step -> weak scaling in publishes, the 10M-route index is split N ways.
+      one GPU), Zipf(1.0) tenant popularity, 1M publishes per batch.  N > 1: tenants are partitioned across ranks by
+      hash(tenantId) mod N (bifromq_amd/shard.py), every rank matches its own 1M-publish batch per step -> weak scaling
+      in publishes, the 10M-route index is split N ways.
   c2: 1 tenant x 1M routes, 1M publishes (configs[1]).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -84,13 +84,14 @@ def main():
     else:
         total_tenants, per_tenant, mode, seed = 8, 5_000, 1, 0xB1F20009
         name = "small: 8 tenants x 5k routes"
-    if total_tenants >= world:
-        t_lo = total_tenants * rank // world
-        t_hi = total_tenants * (rank + 1) // world
-    else:  # single-tenant config on several GPUs: replicas (documented in DESIGN.md)
-        t_lo, t_hi = 0, total_tenants
     t0 = time.time()
-    w = B.Workload(seed, t_hi - t_lo, per_tenant, mode, tenant_base=t_lo)
+    if total_tenants >= world and world > 1:
+        # the index shards by hash(tenantId) mod N (bifromq_amd/shard.py); publishes follow their tenant
+        from bifromq_amd import shard
+        mine = [t for t in range(total_tenants) if shard.tenant_rank("tenant%06d" % t, world) == rank]
+        w = B.Workload(seed, len(mine), per_tenant, mode, tenant_ids=mine)
+    else:  # one GPU, or a single-tenant config on several GPUs: replicas (documented in DESIGN.md)
+        w = B.Workload(seed, total_tenants, per_tenant, mode)
     t_gen = time.time() - t0
     eng = B.Engine(device=local_rank)
     t0 = time.time()

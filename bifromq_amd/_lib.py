@@ -109,6 +109,7 @@ def gen() -> C.CDLL:
         vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
         sig = {
             "bmqgen_create": (vp, [u64, u32, u32, u32, C.c_int]), "bmqgen_destroy": (None, [vp]),
+            "bmqgen_create_list": (vp, [u64, vp, u32, u32, C.c_int]),
             "bmqgen_n_keys": (u32, [vp]), "bmqgen_key_bytes": (vp, [vp]), "bmqgen_key_off": (vp, [vp]),
             "bmqgen_n_tenants": (u32, [vp]), "bmqgen_tenant_bytes": (vp, [vp]), "bmqgen_tenant_off": (vp, [vp]),
             "bmqgen_tenant_first": (vp, [vp]),

@@ -122,7 +122,8 @@ struct Packed {
 
 struct Gen {
     uint64_t seed;
-    uint32_t tenant_base = 0;            // global index of this generator's first tenant (rank shards)
+    uint32_t tenant_base = 0;            // global index of this generator's first tenant (contiguous shard), or
+    std::vector<uint32_t> tenant_ids;    // ... the explicit global tenant indices of a hash shard (ascending)
     uint32_t n_tenants, per_tenant;
     int mode;
     Vocab vocab;
@@ -140,7 +141,7 @@ std::string tenant_name(uint32_t t) {
 }
 
 void gen_tenant_keys(const Gen& g, uint32_t t_local, std::vector<std::string>& out) {
-    const uint32_t t = g.tenant_base + t_local;
+    const uint32_t t = g.tenant_ids.empty() ? g.tenant_base + t_local : g.tenant_ids[t_local];
     Rng r(g.seed * 0x100000001B3ull + 0x517CC1B727220A95ull * (t + 1));
     const std::string tn = tenant_name(t);
     out.clear();
@@ -172,6 +173,9 @@ void gen_tenant_keys(const Gen& g, uint32_t t_local, std::vector<std::string>& o
 
 extern "C" {
 
+static void* gen_build(Gen* g);
+
+// tenants tenant_base .. tenant_base + n_tenants - 1
 void* bmqgen_create(uint64_t seed, uint32_t tenant_base, uint32_t n_tenants, uint32_t routes_per_tenant, int mode) {
     Gen* g = new Gen();
     g->seed = seed;
@@ -179,7 +183,23 @@ void* bmqgen_create(uint64_t seed, uint32_t tenant_base, uint32_t n_tenants, uin
     g->n_tenants = n_tenants;
     g->per_tenant = routes_per_tenant;
     g->mode = mode;
-    for (uint32_t t = 0; t < n_tenants; t++) g->tenants.push(tenant_name(tenant_base + t));
+    return gen_build(g);
+}
+
+// an explicit, ascending list of global tenant indices (the tenants hash(tenantId) mod N assigns to one rank)
+void* bmqgen_create_list(uint64_t seed, const uint32_t* tenant_ids, uint32_t n_tenants, uint32_t routes_per_tenant, int mode) {
+    Gen* g = new Gen();
+    g->seed = seed;
+    g->tenant_ids.assign(tenant_ids, tenant_ids + n_tenants);
+    g->n_tenants = n_tenants;
+    g->per_tenant = routes_per_tenant;
+    g->mode = mode;
+    return gen_build(g);
+}
+
+static void* gen_build(Gen* g) {
+    const uint32_t n_tenants = g->n_tenants;
+    for (uint32_t t = 0; t < n_tenants; t++) g->tenants.push(tenant_name(g->tenant_ids.empty() ? g->tenant_base + t : g->tenant_ids[t]));
     g->tenants.pad();
     std::vector<std::vector<std::string>> per(n_tenants);
     unsigned hw = std::thread::hardware_concurrency();

@@ -22,10 +22,18 @@ def _arr(ptr, n, dtype):
 class Workload:
     """Route keys for n_tenants x routes_per_tenant (sorted), plus publish batches drawn from them."""
 
-    def __init__(self, seed: int, n_tenants: int, routes_per_tenant: int, mode: int = MODE_MIXED, tenant_base: int = 0):
-        """tenant_base: global index of the first tenant (a rank's shard of a larger tenant population)"""
+    def __init__(self, seed: int, n_tenants: int, routes_per_tenant: int, mode: int = MODE_MIXED, tenant_base: int = 0,
+                 tenant_ids=None):
+        """tenant_base: global index of the first tenant of a contiguous block; tenant_ids: explicit ascending list of
+        global tenant indices instead (the shard hash(tenantId) mod N gives one rank).  A tenant's routes depend only on
+        (seed, global tenant index), so shards of one population are consistent with the unsharded workload."""
         G = _lib.gen()
-        self.h = G.bmqgen_create(seed, tenant_base, n_tenants, routes_per_tenant, mode)
+        if tenant_ids is not None:
+            ids = np.ascontiguousarray(sorted(int(i) for i in tenant_ids), dtype=np.uint32)
+            n_tenants = len(ids)
+            self.h = G.bmqgen_create_list(seed, ids.ctypes.data_as(C.c_void_p), n_tenants, routes_per_tenant, mode)
+        else:
+            self.h = G.bmqgen_create(seed, tenant_base, n_tenants, routes_per_tenant, mode)
         if not self.h:
             raise MemoryError("workload exceeds the 4 GiB key buffer of the ABI")
         self.n_tenants = n_tenants

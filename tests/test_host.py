@@ -114,3 +114,21 @@ def test_workload_generator_is_deterministic_and_sorted():
     tn = w1.tenants()
     hits = sum(1 for t, ti in zip(topics, t1) if kv.match_bruteforce(tn[ti], [t]).per_topic()[0])
     assert hits >= 0.8 * len(topics)
+
+
+def test_hash_sharded_workloads_partition_the_population():
+    """bench.py --gpus N gives every rank the tenants hash(tenantId) mod N assigns to it: the shards' key sets are a
+    partition of the unsharded workload's key set (a tenant's routes depend only on seed and global tenant index)."""
+    from bifromq_amd import shard
+    full = set(B.Workload(5, 16, 40, 1).keys())
+    union, total = set(), 0
+    for r in range(4):
+        mine = [t for t in range(16) if shard.tenant_rank("tenant%06d" % t, 4) == r]
+        w = B.Workload(5, len(mine), 40, 1, tenant_ids=mine)
+        assert w.tenants() == ["tenant%06d" % t for t in mine]
+        ks = w.keys()
+        total += len(ks)
+        union |= set(ks)
+        _, _, tt = w.topics(3, 50)
+        assert len(mine) == 0 or tt.max() < len(mine)
+    assert union == full and total == len(full)
