@@ -110,7 +110,8 @@ struct BatchArgs {
     // LDS geometry
     uint32_t qcap; // pow2
     uint32_t pcap; // >= 128
-    uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising
+    uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising, 2 = fill dbg_wave
+    uint4* dbg_wave;      // [n_blocks] {phase 1, phase 2, phase 3 shader clocks, rounds} of every k_walk wave, or null
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -158,26 +159,36 @@ __device__ __forceinline__ TrieSlot load_slot(const TrieSlot* trie, uint32_t idx
     const uint4 a = p[0], b = p[1];
     return unpack_slot(a, b);
 }
-// (parent slot, token) -> child slot inside the tenant's region (slots are region-relative); NONE if absent.  Reads
-// whole 64-byte buckets: the home bucket answers unless it is full of other edges (rare at load factor 1/2).
-__device__ __forceinline__ uint32_t probe_child(const DistIndexView& ix, uint32_t base, uint32_t buckets, uint32_t parent,
-                                                uint32_t token, TrieSlot& out) {
-    uint32_t bk = edge_bucket(parent, token, buckets);
-    for (;;) {
-        const uint32_t s0 = 2 * bk;
-        const uint4* p = reinterpret_cast<const uint4*>(ix.trie + base + s0);
-        const uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-        if (a0.x == parent && a0.y == token) {
-            out = unpack_slot(a0, a1);
-            return s0;
-        }
-        if (b0.x == parent && b0.y == token) {
-            out = unpack_slot(b0, b1);
-            return s0 + 1;
-        }
-        if (a0.x == NONE || b0.x == NONE) return NONE;
-        bk = (bk + 1 == buckets) ? 0 : bk + 1;
-    }
+// One aligned 64-byte line = one trie bucket (two TrieSlots) or one dictionary group (two DictSlots), requested with
+// four 16-byte loads issued back to back and ONE wait.  Written as asm because the compiler otherwise splits the
+// line into dependent pieces (first the 8 key bytes of slot 0, wait, then those of slot 1, wait, then the payload):
+// three serial cache round trips per visited node instead of one.  The index is never written while a batch runs.
+struct Line64 {
+    uint4 a0, a1, b0, b1;
+};
+static_assert(DICT_GROUP == 2, "a dictionary group is one Line64");
+__device__ __forceinline__ void load_line64(const void* p, Line64& r) {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:48\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1)
+                 : "v"(p));
+}
+// two independent lines in flight per lane, one wait
+__device__ __forceinline__ void load_line64x2(const void* p, const void* q, Line64& r, Line64& t) {
+    asm volatile("global_load_dwordx4 %0, %8, off\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %8, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %9, off\n\t"
+                 "global_load_dwordx4 %5, %9, off offset:16\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:32\n\t"
+                 "global_load_dwordx4 %7, %9, off offset:48\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1), "=&v"(t.a0), "=&v"(t.a1), "=&v"(t.b0), "=&v"(t.b1)
+                 : "v"(p), "v"(q));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -189,26 +200,21 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
                                                 const uint32_t inl[4], uint32_t start, ByteAt&& byte_at) {
     const uint32_t tag = level_hash_tag(h);
     uint32_t g = level_hash_slot(h, len) & ix.dict_group_mask;
+    auto tail_eq = [&](uint32_t pool_off) { // bytes beyond the 16 inline ones (rare: levels are short)
+        bool eq = true;
+        for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[pool_off + i] == byte_at(start + i);
+        return eq;
+    };
     for (;;) {
-        const uint4* p = reinterpret_cast<const uint4*>(ix.dict + DICT_GROUP * (size_t)g);
-        uint4 hd[DICT_GROUP], il[DICT_GROUP];
-#pragma unroll
-        for (int j = 0; j < (int)DICT_GROUP; j++) {
-            hd[j] = p[2 * j];
-            il[j] = p[2 * j + 1];
-        }
-        bool full = true;
-#pragma unroll
-        for (int j = 0; j < (int)DICT_GROUP; j++) {
-            if (hd[j].x == 0) full = false;
-            else if (hd[j].x == tag && hd[j].z == len && il[j].x == inl[0] && il[j].y == inl[1] && il[j].z == inl[2] &&
-                     il[j].w == inl[3]) {
-                bool eq = true;
-                for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[hd[j].w + i] == byte_at(start + i);
-                if (eq) return hd[j].y;
-            }
-        }
-        if (!full) return TOK_UNKNOWN;
+        Line64 ln;
+        load_line64(ix.dict + DICT_GROUP * (size_t)g, ln);
+        const bool h0 = ln.a0.x == tag && ln.a0.z == len && ln.a1.x == inl[0] && ln.a1.y == inl[1] && ln.a1.z == inl[2] &&
+                        ln.a1.w == inl[3];
+        const bool h1 = ln.b0.x == tag && ln.b0.z == len && ln.b1.x == inl[0] && ln.b1.y == inl[1] && ln.b1.z == inl[2] &&
+                        ln.b1.w == inl[3];
+        if (h0 && (len <= 16 || tail_eq(ln.a0.w))) return ln.a0.y;
+        if (h1 && (len <= 16 || tail_eq(ln.b0.w))) return ln.b0.y;
+        if (ln.a0.x == 0 || ln.b0.x == 0) return TOK_UNKNOWN;
         g = (g + 1) & ix.dict_group_mask;
     }
 }
@@ -306,30 +312,50 @@ struct StepOut {
     TrieSlot s;
 };
 
+// Both item kinds read ONE bucket line: kind L the home bucket of edge (node, token) -- which holds the child's complete
+// slot --, kind H the bucket that contains slot `node`.  Slots are region-relative; regions start on a bucket boundary.
+__device__ __forceinline__ uint32_t item_bucket(bool kind_h, uint32_t node, uint32_t tok, uint32_t buckets) {
+    return kind_h ? (node >> 1) : edge_bucket(node, tok, buckets);
+}
+// ln = bucket `bk` of the item (already loaded).  tok = the topic's token at `level` (kind L only).
 // tok_at(level): the topic's token at that level; nlev: level count; sys: first level starts with '$'
 template <class TokAt>
-__device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantSlot& rg, uint32_t node, uint32_t level,
-                                          bool kind_h, uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
-    o.found = o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
-    if (kind_h) {
-        o.s = load_slot(ix.trie, rg.base + node);
-        o.idx = node;
-        o.dl = level;
-        o.found = true;
-    } else {
-        o.idx = probe_child(ix, rg.base, rg.buckets, node, tok_at(level), o.s);
-        o.dl = level + 1;
-        o.found = o.idx != NONE;
+__device__ __forceinline__ void resolve_item(const DistIndexView& ix, Line64 ln, bool live, bool kind_h, uint32_t node,
+                                             uint32_t tok, uint32_t bk, uint32_t rbase, uint32_t rbuckets, uint32_t level,
+                                             uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
+    bool m0 = kind_h ? ((node & 1u) == 0) : (ln.a0.x == node && ln.a0.y == tok);
+    bool m1 = kind_h ? ((node & 1u) != 0) : (ln.b0.x == node && ln.b0.y == tok);
+    bool more = live && !m0 && !m1 && ln.a0.x != NONE && ln.b0.x != NONE;
+    while (more) { // home bucket full of other edges (rare at load factor 1/2): first-free probing continues
+        bk = (bk + 1 == rbuckets) ? 0 : bk + 1;
+        load_line64(ix.trie + rbase + 2 * bk, ln);
+        m0 = ln.a0.x == node && ln.a0.y == tok;
+        m1 = ln.b0.x == node && ln.b0.y == tok;
+        more = !m0 && !m1 && ln.a0.x != NONE && ln.b0.x != NONE;
     }
-    if (!o.found) return;
+    o.found = live && (m0 || m1);
+    o.s = m1 ? unpack_slot(ln.b0, ln.b1) : unpack_slot(ln.a0, ln.a1);
+    o.idx = kind_h ? node : 2 * bk + (m1 ? 1u : 0u);
+    o.dl = kind_h ? level : level + 1;
     const bool root_sys = (o.dl == 0) && sys; // wildcards in filter position 0 never match a '$' topic
-    o.emit_own = (o.dl == nlev) && o.s.own_count != 0;
-    o.emit_hash = o.s.hash_count != 0 && !root_sys; // "<path>/#" matches whatever follows, also nothing
-    if (o.dl < nlev) {
+    o.emit_own = o.found && (o.dl == nlev) && o.s.own_count != 0;
+    o.emit_hash = o.found && o.s.hash_count != 0 && !root_sys; // "<path>/#" matches whatever follows, also nothing
+    o.push_l = o.push_h = false;
+    if (o.found && o.dl < nlev) {
         const uint32_t t = tok_at(o.dl);
         o.push_l = t != TOK_UNKNOWN && ((o.s.lit_bloom >> bloom_bit(t)) & 1u);
         o.push_h = o.s.plus_child != NONE && !root_sys;
     }
+}
+
+template <class TokAt>
+__device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantSlot& rg, uint32_t node, uint32_t level,
+                                          bool kind_h, uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
+    const uint32_t tok = kind_h ? 0u : tok_at(level);
+    const uint32_t bk = item_bucket(kind_h, node, tok, rg.buckets);
+    Line64 ln;
+    load_line64(ix.trie + rg.base + 2 * bk, ln);
+    resolve_item(ix, ln, true, kind_h, node, tok, bk, rg.base, rg.buckets, level, nlev, sys, tok_at, o);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -344,34 +370,36 @@ constexpr uint32_t WALK_WAVES = BMQ_WALK_WAVES; // waves per k_walk workgroup
 constexpr uint32_t MAX_FLUSH = 16; // range-buffer flushes per wave before topics are sent to the slow path
 
 __host__ __device__ inline size_t walk_union_words(uint32_t qcap, uint32_t pcap) { return 2 * (size_t)qcap + 3 * (size_t)pcap; }
+constexpr uint32_t WALK_TOPIC_WORDS = 9 * 64 + 2 * MAX_FLUSH; // per-topic arrays + flush records, behind the union
 __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
-    return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + 9 * 64 + 2 * MAX_FLUSH + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
+    return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + WALK_TOPIC_WORDS + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
 }
 
+// ILP = work items per lane per round (1 or 2): ILP bucket lines in flight per lane, one wait per round.
+template <int ILP>
 __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     extern __shared__ __align__(16) uint32_t lds_all[];
     // WALK_WAVES independent waves per workgroup (a CU admits only ~8 workgroups, so single-wave groups would cap the CU at
     // 8 waves); every wave owns its own slice of LDS and never synchronises with its neighbours
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t* lds = lds_all + wave * (walk_lds_bytes(a.qcap, a.pcap) / 4);
-    uint32_t* un = lds;                                       // union: staged topic bytes | work stack + range buffer
-    uint32_t* q_node = un;                                    // [qcap]
+    uint32_t* tokens = lds;                                   // [FAST_LEVELS][64]
+    uint32_t* un = tokens + FAST_LEVELS * 64;                 // staged topic bytes (phase 1) | everything below (phases 2, 3)
+    uint32_t* q_node = un;                                    // [qcap] work stack
     uint32_t* q_meta = q_node + a.qcap;                       // [qcap]
-    uint32_t* p_begin = q_meta + a.qcap;                      // [pcap]
+    uint32_t* p_begin = q_meta + a.qcap;                      // [pcap] range buffer
     uint32_t* p_count = p_begin + a.pcap;                     // [pcap]
     uint32_t* p_topic = p_count + a.pcap;                     // [pcap]
-    uint32_t* tokens = un + walk_union_words(a.qcap, a.pcap); // [FAST_LEVELS][64]
-    uint32_t* tmeta = tokens + FAST_LEVELS * 64;              // [64]
+    uint32_t* tmeta = un + walk_union_words(a.qcap, a.pcap);  // [64]
     uint32_t* cnt_pairs = tmeta + 64;                         // [64]
     uint32_t* cnt_routes = cnt_pairs + 64;                    // [64]
     uint32_t* cnt_visit = cnt_routes + 64;                    // [64]
     uint32_t* cursor = cnt_visit + 64;                        // [64]
-    uint32_t* t_base = cursor + 64;                           // [64] tenant region of each topic
-    uint32_t* t_nb = t_base + 64;                             // [64]
-    uint32_t* t_rank = t_nb + 64;                             // [64] id base of the tenant
-    uint32_t* t_rp = t_rank + 64;                             // [64] route_pos base of the tenant
-    uint32_t* f_base = t_rp + 64;                             // [MAX_FLUSH] spill record offset of each flush
+    uint2* t_region = reinterpret_cast<uint2*>(cursor + 64);  // [64] (region base, buckets) of each topic's tenant
+    uint2* t_ids = t_region + 64;                             // [64] (route id base, route_pos base)
+    uint32_t* f_base = reinterpret_cast<uint32_t*>(t_ids + 64); // [MAX_FLUSH] spill record offset of each flush
     uint32_t* f_len = f_base + MAX_FLUSH;                     // [MAX_FLUSH]
+    const uint32_t stage_bytes = (uint32_t)(walk_union_words(a.qcap, a.pcap) + WALK_TOPIC_WORDS) * 4u;
 
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t blk = blockIdx.x * WALK_WAVES + wave;
@@ -381,12 +409,13 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     blk = a.n_blocks - 1 - blk;
     const uint32_t t = blk * 64 + lane;
     const bool valid = t < a.n_topics;
+    const unsigned long long clk0 = a.dbg_wave ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- phase 1: tokenise ---------------------------------------------------------------------------------------------
     const uint32_t t_first = blk * 64, t_end = min(t_first + 64, a.n_topics);
     const uint32_t s_beg = a.topic_off[t_first], s_end = a.topic_off[t_end]; // wave-uniform
     const uint32_t a0 = s_beg & ~15u;
-    const bool staged = (s_end - a0) + 32u <= (uint32_t)(walk_union_words(a.qcap, a.pcap) * 4);
+    const bool staged = (s_end - a0) + 32u <= stage_bytes;
     if (staged) { // coalesced 16-byte copies of the wave's contiguous topic bytes into LDS
         uint4* dst = reinterpret_cast<uint4*>(un);
         const uint4* src = reinterpret_cast<const uint4*>(a.topics + a0);
@@ -430,20 +459,19 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     const bool known = valid && rg.token != TOK_UNKNOWN;
     const bool deep = nlev > FAST_LEVELS;
     const bool active = known && !deep;
-    wave_sync(); // staged bytes are dead from here on: the union becomes stack + range buffer
+    wave_sync(); // staged bytes are dead from here on: the area becomes stack + range buffer + per-topic arrays
     tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u) | (active ? TM_ACTIVE : 0u);
     cnt_pairs[lane] = 0;
     cnt_routes[lane] = 0;
     cnt_visit[lane] = 0;
-    t_base[lane] = rg.base;
-    t_nb[lane] = rg.buckets;
-    t_rank[lane] = rg.rank_base;
-    t_rp[lane] = rg.rp_base;
+    t_region[lane] = make_uint2(rg.base, rg.buckets);
+    t_ids[lane] = make_uint2(rg.rank_base, rg.rp_base);
 
     // ---- phase 2: drain the work stack ----------------------------------------------------------------------------
     // The work list is a STACK (newest items first): depth-first order keeps it at a few pending siblings per topic,
     // where breadth-first order would have to hold a whole frontier level of all 64 topics.
-    uint32_t tail = 0, pcount = 0, nflush = 0;
+    uint32_t tail = 0, pcount = 0, nflush = 0, rounds = 0;
+    const unsigned long long clk1 = a.dbg_wave ? __builtin_amdgcn_s_memtime() : 0ull;
     {
         const bool go = active && !(a.debug_flags & 1u);
         const unsigned long long m = __ballot(go);
@@ -456,95 +484,130 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     }
     wave_sync();
     while (tail) {
-        // make room for this round's matches (at most two per lane): flush the LDS range buffer to the spill area
-        if (pcount + 128 > a.pcap) {
-            unsigned long long sb = 0;
-            uint32_t fits_s = 1;
-            if (lane == 0) fits_s = pair_alloc(a.subs + N_SUB, a.spill_cap, blk, pcount, sb) ? 1u : 0u;
-            sb = __shfl(sb, 0);
-            const bool fits = __shfl(fits_s, 0) != 0 && sb + pcount < 0xFFFFFFFFull;
-            if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_SPILL);
-            for (uint32_t i = lane; i < pcount; i += 64) { // per-topic range / id counts of what leaves the buffer
-                atomicAdd(&cnt_pairs[p_topic[i]], 1u);
-                atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
-            }
-            if (nflush < MAX_FLUSH) {
-                if (fits)
-                    for (uint32_t i = lane; i < pcount; i += 64) a.spill[sb + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
-                if (lane == 0) {
-                    f_base[nflush] = (uint32_t)sb;
-                    f_len[nflush] = fits ? pcount : 0u;
-                }
-                nflush++;
-            } else { // out of flush slots: the topics owning the buffered ranges go to the slow path
-                for (uint32_t i = lane; i < pcount; i += 64) atomicOr(&tmeta[p_topic[i]], TM_FLAG);
-            }
-            pcount = 0;
-            wave_sync();
-        }
-        const uint32_t take = tail < 64 ? tail : 64;
-        const bool act = lane < take;
+        const uint32_t take = tail < 64u * ILP ? tail : 64u * ILP;
         tail -= take;
-        uint32_t node = 0, meta = 0;
-        if (act) {
-            node = q_node[tail + lane];
-            meta = q_meta[tail + lane];
+        rounds++;
+        // pop ILP items per lane, request their bucket lines together
+        uint32_t node[ILP], meta[ILP], tl[ILP], tok[ILP], bk[ILP], tmv[ILP];
+        uint2 reg[ILP];
+        bool live[ILP];
+        const TrieSlot* addr[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; k++) {
+            const uint32_t j = lane + 64u * k;
+            node[k] = meta[k] = 0;
+            tmv[k] = TM_FLAG;
+            if (j < take) {
+                node[k] = q_node[tail + j];
+                meta[k] = q_meta[tail + j];
+                tmv[k] = tmeta[meta[k] & 63u];
+            }
+            tl[k] = meta[k] & 63u;
+            live[k] = !(tmv[k] & TM_FLAG);
+            const bool kh = (meta[k] & KIND_H) != 0;
+            reg[k] = make_uint2(0u, 1u);
+            tok[k] = 0;
+            if (live[k]) {
+                reg[k] = t_region[tl[k]];
+                if (!kh) tok[k] = tokens[meta_level(meta[k]) * 64 + tl[k]];
+            }
+            bk[k] = item_bucket(kh, node[k], tok[k], reg[k].y);
+            addr[k] = a.ix.trie + (live[k] ? reg[k].x + 2 * bk[k] : 0u);
         }
-        const uint32_t tl = meta & 63u;
-        StepOut o;
-        o.found = o.emit_own = o.emit_hash = o.push_l = o.push_h = false;
-        o.dl = 0;
-        if (act) {
-            const uint32_t tm = tmeta[tl];
-            if (!(tm & TM_FLAG)) {
-                const TenantSlot r{0, 0, t_base[tl], t_nb[tl], 0, 0, {0, 0}};
-                step_item(a.ix, r, node, meta_level(meta), (meta & KIND_H) != 0, tm & 0xFFu, (tm & TM_SYS) != 0,
-                          [&](uint32_t l) { return tokens[l * 64 + tl]; }, o);
-            }
+        Line64 ln[ILP];
+        if constexpr (ILP == 1) load_line64(addr[0], ln[0]);
+        else load_line64x2(addr[0], addr[1], ln[0], ln[1]);
+        StepOut o[ILP];
+        unsigned long long m_own[ILP], m_hash[ILP], m_l[ILP], m_h[ILP];
+        uint32_t n_emit = 0, n_push = 0;
+#pragma unroll
+        for (int k = 0; k < ILP; k++) {
+            const uint32_t tlk = tl[k];
+            resolve_item(a.ix, ln[k], live[k], (meta[k] & KIND_H) != 0, node[k], tok[k], bk[k], reg[k].x, reg[k].y,
+                         meta_level(meta[k]), tmv[k] & 0xFFu, (tmv[k] & TM_SYS) != 0,
+                         [&](uint32_t l) { return tokens[l * 64 + tlk]; }, o[k]);
+            if (o[k].found && o[k].dl) atomicAdd(&cnt_visit[tlk], 1u); // per topic: a flagged topic is recounted by the slow path
+            m_own[k] = __ballot(o[k].emit_own);
+            m_hash[k] = __ballot(o[k].emit_hash);
+            m_l[k] = __ballot(o[k].push_l);
+            m_h[k] = __ballot(o[k].push_h);
+            n_emit += (uint32_t)__popcll(m_own[k]) + (uint32_t)__popcll(m_hash[k]);
+            n_push += (uint32_t)__popcll(m_l[k]) + (uint32_t)__popcll(m_h[k]);
         }
-        if (o.found && o.dl) atomicAdd(&cnt_visit[tl], 1u); // per topic: a flagged topic is recounted by the slow path
-        // matched ranges -> LDS buffer
-        const unsigned long long m1 = __ballot(o.emit_own), m2 = __ballot(o.emit_hash);
-        if (m1 | m2) {
-            const uint32_t c1 = (uint32_t)__popcll(m1);
-            if (o.emit_own) {
-                const uint32_t p = pcount + rank_below(m1);
-                p_begin[p] = o.s.own_begin + ((o.s.own_count & RANGE_INDIRECT) ? t_rp[tl] : t_rank[tl]);
-                p_count[p] = o.s.own_count;
-                p_topic[p] = tl;
+        // matched ranges -> LDS buffer; when this round's matches do not fit, the buffer is flushed to the spill area first
+        if (n_emit) {
+            if (pcount + n_emit > a.pcap) {
+                unsigned long long sb = 0;
+                uint32_t fits_s = 1;
+                if (lane == 0) fits_s = pair_alloc(a.subs + N_SUB, a.spill_cap, blk, pcount, sb) ? 1u : 0u;
+                sb = __shfl(sb, 0);
+                const bool fits = __shfl(fits_s, 0) != 0 && sb + pcount < 0xFFFFFFFFull;
+                if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_SPILL);
+                for (uint32_t i = lane; i < pcount; i += 64) { // per-topic range / id counts of what leaves the buffer
+                    atomicAdd(&cnt_pairs[p_topic[i]], 1u);
+                    atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
+                }
+                if (nflush < MAX_FLUSH) {
+                    if (fits)
+                        for (uint32_t i = lane; i < pcount; i += 64) a.spill[sb + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
+                    if (lane == 0) {
+                        f_base[nflush] = (uint32_t)sb;
+                        f_len[nflush] = fits ? pcount : 0u;
+                    }
+                    nflush++;
+                } else { // out of flush slots: the topics owning the buffered ranges go to the slow path
+                    for (uint32_t i = lane; i < pcount; i += 64) atomicOr(&tmeta[p_topic[i]], TM_FLAG);
+                }
+                pcount = 0;
+                wave_sync();
             }
-            if (o.emit_hash) {
-                const uint32_t p = pcount + c1 + rank_below(m2);
-                p_begin[p] = o.s.hash_begin + ((o.s.hash_count & RANGE_INDIRECT) ? t_rp[tl] : t_rank[tl]);
-                p_count[p] = o.s.hash_count;
-                p_topic[p] = tl;
+#pragma unroll
+            for (int k = 0; k < ILP; k++) {
+                const uint2 ids = t_ids[tl[k]];
+                if (o[k].emit_own) {
+                    const uint32_t p = pcount + rank_below(m_own[k]);
+                    p_begin[p] = o[k].s.own_begin + ((o[k].s.own_count & RANGE_INDIRECT) ? ids.y : ids.x);
+                    p_count[p] = o[k].s.own_count;
+                    p_topic[p] = tl[k];
+                }
+                pcount += (uint32_t)__popcll(m_own[k]);
+                if (o[k].emit_hash) {
+                    const uint32_t p = pcount + rank_below(m_hash[k]);
+                    p_begin[p] = o[k].s.hash_begin + ((o[k].s.hash_count & RANGE_INDIRECT) ? ids.y : ids.x);
+                    p_count[p] = o[k].s.hash_count;
+                    p_topic[p] = tl[k];
+                }
+                pcount += (uint32_t)__popcll(m_hash[k]);
             }
-            pcount += c1 + (uint32_t)__popcll(m2);
         }
         // children -> stack
-        const unsigned long long ml = __ballot(o.push_l), mh = __ballot(o.push_h);
-        if (ml | mh) {
-            const uint32_t cl = (uint32_t)__popcll(ml);
-            if (o.push_l) {
-                const uint32_t p = tail + rank_below(ml);
-                if (p < a.qcap) {
-                    q_node[p] = o.idx;
-                    q_meta[p] = make_meta(tl, o.dl, 0);
-                } else atomicOr(&tmeta[tl], TM_FLAG);
+        if (n_push) {
+#pragma unroll
+            for (int k = 0; k < ILP; k++) {
+                if (o[k].push_l) {
+                    const uint32_t p = tail + rank_below(m_l[k]);
+                    if (p < a.qcap) {
+                        q_node[p] = o[k].idx;
+                        q_meta[p] = make_meta(tl[k], o[k].dl, 0);
+                    } else atomicOr(&tmeta[tl[k]], TM_FLAG);
+                }
+                tail += (uint32_t)__popcll(m_l[k]);
+                if (o[k].push_h) {
+                    const uint32_t p = tail + rank_below(m_h[k]);
+                    if (p < a.qcap) {
+                        q_node[p] = o[k].s.plus_child;
+                        q_meta[p] = make_meta(tl[k], o[k].dl + 1, KIND_H);
+                    } else atomicOr(&tmeta[tl[k]], TM_FLAG);
+                }
+                tail += (uint32_t)__popcll(m_h[k]);
             }
-            if (o.push_h) {
-                const uint32_t p = tail + cl + rank_below(mh);
-                if (p < a.qcap) {
-                    q_node[p] = o.s.plus_child;
-                    q_meta[p] = make_meta(tl, o.dl + 1, KIND_H);
-                } else atomicOr(&tmeta[tl], TM_FLAG);
-            }
-            tail = min(tail + cl + (uint32_t)__popcll(mh), a.qcap);
+            tail = min(tail, a.qcap);
         }
         wave_sync();
     }
 
     // ---- phase 3: ranges grouped by topic -> global; per-topic bookkeeping --------------------------------------
+    const unsigned long long clk2 = a.dbg_wave ? __builtin_amdgcn_s_memtime() : 0ull;
     for (uint32_t i = lane; i < pcount; i += 64) { // counted here, once per range, instead of two LDS atomics per match
         atomicAdd(&cnt_pairs[p_topic[i]], 1u);
         atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
@@ -598,6 +661,10 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     if (lane == 0) {
         a.wave_sums[blk] = wsum;
         a.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
+        if (a.dbg_wave) {
+            const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
+            a.dbg_wave[blk] = make_uint4((uint32_t)(clk1 - clk0), (uint32_t)(clk2 - clk1), (uint32_t)(clk3 - clk2), rounds);
+        }
     }
 }
 

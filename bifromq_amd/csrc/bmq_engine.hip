@@ -75,6 +75,7 @@ struct DistDevice { // one epoch of the dist index in HBM
 
 struct bmq_engine {
     bmq_config cfg{};
+    uint32_t walk_ilp = 1; // work items per lane per k_walk round
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8]{};
@@ -90,7 +91,7 @@ struct bmq_engine {
     bool built = false;
 
     // per-batch scratch
-    DevBuf b_subs, b_blk_stats;
+    DevBuf b_subs, b_blk_stats, b_dbg_wave;
     DevBuf b_tenant_root, b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch,
         b_sort_list, b_ctr, b_total;
     uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
@@ -259,6 +260,11 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     {
         const char* dbg = getenv("BMQ_DEBUG");
         a.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
+        a.dbg_wave = nullptr;
+        if (a.debug_flags & 2u) {
+            HIPCHK(e, e->b_dbg_wave.ensure(sizeof(uint4) * std::max(a.n_blocks, 1u)));
+            a.dbg_wave = e->b_dbg_wave.as<uint4>();
+        }
     }
     a.qcap = e->cfg.wave_queue_cap;
     a.pcap = e->cfg.wave_pair_cap;
@@ -270,8 +276,14 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     HIPCHK(e, hipEventRecord(e->ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
-        if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_walk, dim3((a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), dim3(WALK_WAVES * 64), lds, s, a);
+        const dim3 grid((a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
+        if (e->walk_ilp == 2) {
+            if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_walk<2>, grid, block, lds, s, a);
+        } else {
+            if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_walk<1>, grid, block, lds, s, a);
+        }
     }
     HIPCHK(e, hipEventRecord(e->ev[2], s));
     hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
@@ -290,9 +302,30 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
 }
 
 // waits; grows internal buffers and re-runs when a kernel asked for it
+// BMQ_DEBUG=2: per-wave phase clocks of the last k_walk launch (profiling experiments only)
+static void print_wave_debug(bmq_engine* e) {
+    const BatchArgs& a = e->last;
+    if (!a.dbg_wave || !a.n_blocks) return;
+    std::vector<uint4> h(a.n_blocks);
+    if (hipMemcpy(h.data(), a.dbg_wave, sizeof(uint4) * a.n_blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
+    double s1 = 0, s2 = 0, s3 = 0, sr = 0;
+    std::vector<uint32_t> r(a.n_blocks), c2(a.n_blocks);
+    for (uint32_t i = 0; i < a.n_blocks; i++) {
+        s1 += h[i].x, s2 += h[i].y, s3 += h[i].z, sr += h[i].w;
+        r[i] = h[i].w, c2[i] = h[i].y;
+    }
+    std::sort(r.begin(), r.end());
+    std::sort(c2.begin(), c2.end());
+    const double n = a.n_blocks;
+    fprintf(stderr, "[bmq] k_walk waves=%u clocks/wave: tokenise %.0f walk %.0f (p50 %u p99 %u) write %.0f | rounds mean %.1f p50 %u p99 %u max %u\n",
+            a.n_blocks, s1 / n, s2 / n, c2[a.n_blocks / 2], c2[(size_t)(a.n_blocks * 0.99)], s3 / n, sr / n, r[a.n_blocks / 2],
+            r[(size_t)(a.n_blocks * 0.99)], r.back());
+}
+
 int finish_dist(bmq_engine* e, uint64_t* out_total) {
     for (int attempt = 0; attempt < 8; attempt++) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->last.debug_flags & 2u) print_wave_debug(e);
         const Counters c = *e->h_ctr;
         const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST);
         if (grow) {
@@ -374,9 +407,13 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     if (const char* v = getenv("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
     if (const char* v = getenv("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
     if (c.wave_queue_cap < 128 || (c.wave_queue_cap & 63) || c.wave_queue_cap > 4096) return BMQ_E_INVAL;
-    if (c.wave_pair_cap < 128 || c.wave_pair_cap > 4096) return BMQ_E_INVAL;
+    uint32_t walk_ilp = 1;
+    if (const char* v = getenv("BMQ_WALK_ILP")) walk_ilp = atoi(v) == 2 ? 2u : 1u;
+    // the range buffer must take one round's matches (two per work item) after a flush
+    if (c.wave_pair_cap < 128 * walk_ilp || (c.wave_pair_cap & 3) || c.wave_pair_cap > 4096) return BMQ_E_INVAL;
     auto e = std::make_unique<bmq_engine>();
     e->cfg = c;
+    e->walk_ilp = walk_ilp;
     e->device = c.device;
     if (c.device >= 0) {
         int n = 0;
