@@ -111,7 +111,7 @@ struct BatchArgs {
     uint32_t qcap; // pow2
     uint32_t pcap; // >= 128
     uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising, 2 = fill dbg_wave
-    uint4* dbg_wave;      // [n_blocks] {phase 1, phase 2, phase 3 shader clocks, rounds} of every k_walk wave, or null
+    uint4* dbg_wave;      // [n_blocks] {phase 1, phase 2, phase 3 shader clocks, rounds | items << 8} of every k_walk wave, or null
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -176,21 +176,6 @@ __device__ __forceinline__ void load_line64(const void* p, Line64& r) {
                  : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1)
                  : "v"(p));
 }
-// two independent lines in flight per lane, one wait
-__device__ __forceinline__ void load_line64x2(const void* p, const void* q, Line64& r, Line64& t) {
-    asm volatile("global_load_dwordx4 %0, %8, off\n\t"
-                 "global_load_dwordx4 %1, %8, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %8, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %8, off offset:48\n\t"
-                 "global_load_dwordx4 %4, %9, off\n\t"
-                 "global_load_dwordx4 %5, %9, off offset:16\n\t"
-                 "global_load_dwordx4 %6, %9, off offset:32\n\t"
-                 "global_load_dwordx4 %7, %9, off offset:48\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1), "=&v"(t.a0), "=&v"(t.a1), "=&v"(t.b0), "=&v"(t.b1)
-                 : "v"(p), "v"(q));
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // dictionary lookup (exact: tag + length + bytes).  ONE latency: the whole home group (one 64-byte line) is requested together.
 // byte_at(i) returns byte i of the string buffer the level lives in (LDS-staged or global).
@@ -278,7 +263,7 @@ __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
     bool last;
     scan_level(pos, end, false, word_at, h, inl, len, last);
     const uint32_t tok = dict_lookup(a.ix, h, len, inl, start, byte_at);
-    TenantSlot info{0, 0, 0, 1, 0, 0, {0, 0}};
+    TenantSlot info = EMPTY_TENANT;
     if (tok != TOK_UNKNOWN) {
         uint32_t d = tenant_hash(tok) & a.ix.tenant_mask;
         for (;;) {
@@ -367,16 +352,13 @@ constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9, TM_ACTIVE = 1u << 10;
 #define BMQ_WALK_WAVES 2
 #endif
 constexpr uint32_t WALK_WAVES = BMQ_WALK_WAVES; // waves per k_walk workgroup
-constexpr uint32_t MAX_FLUSH = 16; // range-buffer flushes per wave before topics are sent to the slow path
 
 __host__ __device__ inline size_t walk_union_words(uint32_t qcap, uint32_t pcap) { return 2 * (size_t)qcap + 3 * (size_t)pcap; }
-constexpr uint32_t WALK_TOPIC_WORDS = 9 * 64 + 2 * MAX_FLUSH; // per-topic arrays + flush records, behind the union
+constexpr uint32_t WALK_TOPIC_WORDS = 9 * 64; // per-topic arrays, behind the union
 __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
     return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + WALK_TOPIC_WORDS + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
 }
 
-// ILP = work items per lane per round (1 or 2): ILP bucket lines in flight per lane, one wait per round.
-template <int ILP>
 __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     extern __shared__ __align__(16) uint32_t lds_all[];
     // WALK_WAVES independent waves per workgroup (a CU admits only ~8 workgroups, so single-wave groups would cap the CU at
@@ -397,8 +379,6 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     uint32_t* cursor = cnt_visit + 64;                        // [64]
     uint2* t_region = reinterpret_cast<uint2*>(cursor + 64);  // [64] (region base, buckets) of each topic's tenant
     uint2* t_ids = t_region + 64;                             // [64] (route id base, route_pos base)
-    uint32_t* f_base = reinterpret_cast<uint32_t*>(t_ids + 64); // [MAX_FLUSH] spill record offset of each flush
-    uint32_t* f_len = f_base + MAX_FLUSH;                     // [MAX_FLUSH]
     const uint32_t stage_bytes = (uint32_t)(walk_union_words(a.qcap, a.pcap) + WALK_TOPIC_WORDS) * 4u;
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -434,7 +414,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
 
     uint32_t nlev = 0, tbytes = 0, pos = 0, end = 0;
     bool sys = false, more = false;
-    TenantSlot rg{0, 0, 0, 1, 0, 0, {0, 0}};
+    TenantSlot rg = EMPTY_TENANT;
     if (valid) {
         pos = a.topic_off[t];
         end = a.topic_off[t + 1];
@@ -470,138 +450,139 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     // ---- phase 2: drain the work stack ----------------------------------------------------------------------------
     // The work list is a STACK (newest items first): depth-first order keeps it at a few pending siblings per topic,
     // where breadth-first order would have to hold a whole frontier level of all 64 topics.
-    uint32_t tail = 0, pcount = 0, nflush = 0, rounds = 0;
+    // Neither LDS list bounds the walk: a full range buffer is flushed to, and a full stack parked in, the global spill
+    // area, as chunks {header record, payload records}; the header links to the wave's previous chunk of the same kind
+    // (base, length; length 0 ends the chain), so the bookkeeping is two wave-uniform registers per chain.
+    uint32_t tail = 0, pcount = 0, rounds = 0, items = 0;
+    uint32_t fl_base = 0, fl_len = 0; // last flushed range chunk
+    uint32_t qs_base = 0, qs_len = 0; // last parked stack chunk (LIFO)
+    auto spill_alloc = [&](uint32_t n, uint32_t& base) -> bool { // wave-uniform; n payload records + header
+        unsigned long long sb = 0;
+        uint32_t ok = 1;
+        if (lane == 0) ok = pair_alloc(a.subs + N_SUB, a.spill_cap, blk, n + 1, sb) ? 1u : 0u;
+        sb = __shfl(sb, 0);
+        const bool fits = __shfl(ok, 0) != 0 && sb + n + 1 < 0xFFFFFFFFull;
+        if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_SPILL); // the batch is re-run with a larger area
+        base = (uint32_t)sb;
+        return fits;
+    };
     const unsigned long long clk1 = a.dbg_wave ? __builtin_amdgcn_s_memtime() : 0ull;
-    {
-        const bool go = active && !(a.debug_flags & 1u);
-        const unsigned long long m = __ballot(go);
-        if (go) {
-            const uint32_t p = rank_below(m);
-            q_node[p] = rg.root;
-            q_meta[p] = make_meta(lane, 0, KIND_H);
-        }
-        tail = (uint32_t)__popcll(m);
-    }
-    wave_sync();
-    while (tail) {
-        const uint32_t take = tail < 64u * ILP ? tail : 64u * ILP;
-        tail -= take;
-        rounds++;
-        // pop ILP items per lane, request their bucket lines together
-        uint32_t node[ILP], meta[ILP], tl[ILP], tok[ILP], bk[ILP], tmv[ILP];
-        uint2 reg[ILP];
-        bool live[ILP];
-        const TrieSlot* addr[ILP];
-#pragma unroll
-        for (int k = 0; k < ILP; k++) {
-            const uint32_t j = lane + 64u * k;
-            node[k] = meta[k] = 0;
-            tmv[k] = TM_FLAG;
-            if (j < take) {
-                node[k] = q_node[tail + j];
-                meta[k] = q_meta[tail + j];
-                tmv[k] = tmeta[meta[k] & 63u];
+    // Round 0 visits the tenant roots: their slot payload came with the directory entry, so no line is fetched.
+    bool boot = !(a.debug_flags & 1u);
+    while (boot || tail || qs_len) {
+        if (!boot && tail == 0) { // the stack ran dry: take the most recently parked chunk back
+            const uint4 hd = a.spill[qs_base];
+            for (uint32_t i = lane; i < qs_len; i += 64) {
+                const uint4 r = a.spill[qs_base + 1 + i];
+                q_node[i] = r.x;
+                q_meta[i] = r.y;
             }
-            tl[k] = meta[k] & 63u;
-            live[k] = !(tmv[k] & TM_FLAG);
-            const bool kh = (meta[k] & KIND_H) != 0;
-            reg[k] = make_uint2(0u, 1u);
-            tok[k] = 0;
-            if (live[k]) {
-                reg[k] = t_region[tl[k]];
-                if (!kh) tok[k] = tokens[meta_level(meta[k]) * 64 + tl[k]];
+            tail = qs_len;
+            qs_base = hd.x;
+            qs_len = hd.y;
+            wave_sync();
+        }
+        StepOut o;
+        uint32_t tl = lane;
+        if (boot) {
+            boot = false;
+            o.found = active;
+            o.idx = rg.root;
+            o.dl = 0;
+            o.s = TrieSlot{ROOT_PARENT, 0, 0, 0, rg.root_hash_begin, rg.root_hash_count, rg.root_plus_child, rg.root_lit_bloom};
+            o.emit_own = false; // a topic has at least one level
+            o.emit_hash = active && rg.root_hash_count != 0 && !sys; // the filter "#"; never for '$' topics
+            const uint32_t t0 = active ? tokens[lane] : TOK_UNKNOWN;
+            o.push_l = active && t0 != TOK_UNKNOWN && ((rg.root_lit_bloom >> bloom_bit(t0)) & 1u);
+            o.push_h = active && rg.root_plus_child != NONE && !sys;
+        } else {
+            const uint32_t take = tail < 64u ? tail : 64u;
+            tail -= take;
+            rounds++;
+            items += take;
+            uint32_t node = 0, meta = 0, tmv = TM_FLAG;
+            if (lane < take) {
+                node = q_node[tail + lane];
+                meta = q_meta[tail + lane];
+                tmv = tmeta[meta & 63u];
             }
-            bk[k] = item_bucket(kh, node[k], tok[k], reg[k].y);
-            addr[k] = a.ix.trie + (live[k] ? reg[k].x + 2 * bk[k] : 0u);
+            tl = meta & 63u;
+            const bool live = !(tmv & TM_FLAG);
+            const bool kh = (meta & KIND_H) != 0;
+            uint2 reg = make_uint2(0u, 1u);
+            uint32_t tok = 0;
+            if (live) {
+                reg = t_region[tl];
+                if (!kh) tok = tokens[meta_level(meta) * 64 + tl];
+            }
+            const uint32_t bk = item_bucket(kh, node, tok, reg.y);
+            Line64 ln;
+            load_line64(a.ix.trie + (live ? reg.x + 2 * bk : 0u), ln);
+            const uint32_t tlc = tl;
+            resolve_item(a.ix, ln, live, kh, node, tok, bk, reg.x, reg.y, meta_level(meta), tmv & 0xFFu, (tmv & TM_SYS) != 0,
+                         [&](uint32_t l) { return tokens[l * 64 + tlc]; }, o);
+            if (o.found) atomicAdd(&cnt_visit[tl], 1u); // per topic: a flagged topic is recounted by the slow path
         }
-        Line64 ln[ILP];
-        if constexpr (ILP == 1) load_line64(addr[0], ln[0]);
-        else load_line64x2(addr[0], addr[1], ln[0], ln[1]);
-        StepOut o[ILP];
-        unsigned long long m_own[ILP], m_hash[ILP], m_l[ILP], m_h[ILP];
-        uint32_t n_emit = 0, n_push = 0;
-#pragma unroll
-        for (int k = 0; k < ILP; k++) {
-            const uint32_t tlk = tl[k];
-            resolve_item(a.ix, ln[k], live[k], (meta[k] & KIND_H) != 0, node[k], tok[k], bk[k], reg[k].x, reg[k].y,
-                         meta_level(meta[k]), tmv[k] & 0xFFu, (tmv[k] & TM_SYS) != 0,
-                         [&](uint32_t l) { return tokens[l * 64 + tlk]; }, o[k]);
-            if (o[k].found && o[k].dl) atomicAdd(&cnt_visit[tlk], 1u); // per topic: a flagged topic is recounted by the slow path
-            m_own[k] = __ballot(o[k].emit_own);
-            m_hash[k] = __ballot(o[k].emit_hash);
-            m_l[k] = __ballot(o[k].push_l);
-            m_h[k] = __ballot(o[k].push_h);
-            n_emit += (uint32_t)__popcll(m_own[k]) + (uint32_t)__popcll(m_hash[k]);
-            n_push += (uint32_t)__popcll(m_l[k]) + (uint32_t)__popcll(m_h[k]);
-        }
+        const unsigned long long m_own = __ballot(o.emit_own), m_hash = __ballot(o.emit_hash);
+        const unsigned long long m_l = __ballot(o.push_l), m_h = __ballot(o.push_h);
+        const uint32_t n_own = (uint32_t)__popcll(m_own), n_emit = n_own + (uint32_t)__popcll(m_hash);
         // matched ranges -> LDS buffer; when this round's matches do not fit, the buffer is flushed to the spill area first
         if (n_emit) {
             if (pcount + n_emit > a.pcap) {
-                unsigned long long sb = 0;
-                uint32_t fits_s = 1;
-                if (lane == 0) fits_s = pair_alloc(a.subs + N_SUB, a.spill_cap, blk, pcount, sb) ? 1u : 0u;
-                sb = __shfl(sb, 0);
-                const bool fits = __shfl(fits_s, 0) != 0 && sb + pcount < 0xFFFFFFFFull;
-                if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_SPILL);
                 for (uint32_t i = lane; i < pcount; i += 64) { // per-topic range / id counts of what leaves the buffer
                     atomicAdd(&cnt_pairs[p_topic[i]], 1u);
                     atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
                 }
-                if (nflush < MAX_FLUSH) {
-                    if (fits)
-                        for (uint32_t i = lane; i < pcount; i += 64) a.spill[sb + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
-                    if (lane == 0) {
-                        f_base[nflush] = (uint32_t)sb;
-                        f_len[nflush] = fits ? pcount : 0u;
-                    }
-                    nflush++;
-                } else { // out of flush slots: the topics owning the buffered ranges go to the slow path
-                    for (uint32_t i = lane; i < pcount; i += 64) atomicOr(&tmeta[p_topic[i]], TM_FLAG);
+                uint32_t cb;
+                if (spill_alloc(pcount, cb)) {
+                    if (lane == 0) a.spill[cb] = make_uint4(fl_base, fl_len, 0u, 0u);
+                    for (uint32_t i = lane; i < pcount; i += 64) a.spill[cb + 1 + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
+                    fl_base = cb;
+                    fl_len = pcount;
                 }
                 pcount = 0;
                 wave_sync();
             }
-#pragma unroll
-            for (int k = 0; k < ILP; k++) {
-                const uint2 ids = t_ids[tl[k]];
-                if (o[k].emit_own) {
-                    const uint32_t p = pcount + rank_below(m_own[k]);
-                    p_begin[p] = o[k].s.own_begin + ((o[k].s.own_count & RANGE_INDIRECT) ? ids.y : ids.x);
-                    p_count[p] = o[k].s.own_count;
-                    p_topic[p] = tl[k];
-                }
-                pcount += (uint32_t)__popcll(m_own[k]);
-                if (o[k].emit_hash) {
-                    const uint32_t p = pcount + rank_below(m_hash[k]);
-                    p_begin[p] = o[k].s.hash_begin + ((o[k].s.hash_count & RANGE_INDIRECT) ? ids.y : ids.x);
-                    p_count[p] = o[k].s.hash_count;
-                    p_topic[p] = tl[k];
-                }
-                pcount += (uint32_t)__popcll(m_hash[k]);
+            const uint2 ids = t_ids[tl];
+            if (o.emit_own) {
+                const uint32_t p = pcount + rank_below(m_own);
+                p_begin[p] = o.s.own_begin + ((o.s.own_count & RANGE_INDIRECT) ? ids.y : ids.x);
+                p_count[p] = o.s.own_count;
+                p_topic[p] = tl;
             }
+            if (o.emit_hash) {
+                const uint32_t p = pcount + n_own + rank_below(m_hash);
+                p_begin[p] = o.s.hash_begin + ((o.s.hash_count & RANGE_INDIRECT) ? ids.y : ids.x);
+                p_count[p] = o.s.hash_count;
+                p_topic[p] = tl;
+            }
+            pcount += n_emit;
         }
-        // children -> stack
-        if (n_push) {
-#pragma unroll
-            for (int k = 0; k < ILP; k++) {
-                if (o[k].push_l) {
-                    const uint32_t p = tail + rank_below(m_l[k]);
-                    if (p < a.qcap) {
-                        q_node[p] = o[k].idx;
-                        q_meta[p] = make_meta(tl[k], o[k].dl, 0);
-                    } else atomicOr(&tmeta[tl[k]], TM_FLAG);
+        // children -> stack; if they do not fit, the pending (older) items are parked and the walk goes on with the children
+        if (m_l | m_h) {
+            const uint32_t n_l = (uint32_t)__popcll(m_l), n_push = n_l + (uint32_t)__popcll(m_h);
+            if (tail + n_push > a.qcap) {
+                uint32_t cb;
+                if (spill_alloc(tail, cb)) {
+                    if (lane == 0) a.spill[cb] = make_uint4(qs_base, qs_len, 0u, 0u);
+                    for (uint32_t i = lane; i < tail; i += 64) a.spill[cb + 1 + i] = make_uint4(q_node[i], q_meta[i], 0u, 0u);
+                    qs_base = cb;
+                    qs_len = tail;
                 }
-                tail += (uint32_t)__popcll(m_l[k]);
-                if (o[k].push_h) {
-                    const uint32_t p = tail + rank_below(m_h[k]);
-                    if (p < a.qcap) {
-                        q_node[p] = o[k].s.plus_child;
-                        q_meta[p] = make_meta(tl[k], o[k].dl + 1, KIND_H);
-                    } else atomicOr(&tmeta[tl[k]], TM_FLAG);
-                }
-                tail += (uint32_t)__popcll(m_h[k]);
+                tail = 0;
+                wave_sync();
             }
-            tail = min(tail, a.qcap);
+            if (o.push_l) {
+                const uint32_t p = tail + rank_below(m_l);
+                q_node[p] = o.idx;
+                q_meta[p] = make_meta(tl, o.dl, 0);
+            }
+            if (o.push_h) {
+                const uint32_t p = tail + n_l + rank_below(m_h);
+                q_node[p] = o.s.plus_child;
+                q_meta[p] = make_meta(tl, o.dl + 1, KIND_H);
+            }
+            tail += n_push;
         }
         wave_sync();
     }
@@ -629,14 +610,16 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     cursor[lane] = excl;
     wave_sync();
     if (fits && total_pairs) {
-        for (uint32_t f = 0; f < nflush; f++) { // flushed chunks first (they are L2-hot), then what is still in LDS
-            const uint32_t fb = f_base[f], fl = f_len[f];
-            for (uint32_t i = lane; i < fl; i += 64) {
-                const uint4 r = a.spill[fb + i];
+        for (uint32_t cb = fl_base, cl = fl_len; cl;) { // flushed chunks first (they are L2-hot), then what is still in LDS
+            const uint4 hd = a.spill[cb];
+            for (uint32_t i = lane; i < cl; i += 64) {
+                const uint4 r = a.spill[cb + 1 + i];
                 if (tmeta[r.z] & TM_FLAG) continue;
                 const uint32_t dst = atomicAdd(&cursor[r.z], 1u);
                 a.pairs[base + dst] = MatchRange{r.x, r.y};
             }
+            cb = hd.x;
+            cl = hd.y;
         }
         for (uint32_t i = lane; i < pcount; i += 64) {
             const uint32_t tl = p_topic[i];
@@ -663,7 +646,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
         a.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
         if (a.dbg_wave) {
             const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
-            a.dbg_wave[blk] = make_uint4((uint32_t)(clk1 - clk0), (uint32_t)(clk2 - clk1), (uint32_t)(clk3 - clk2), rounds);
+            a.dbg_wave[blk] = make_uint4((uint32_t)(clk1 - clk0), (uint32_t)(clk2 - clk1), (uint32_t)(clk3 - clk2), rounds | (items << 8));
         }
     }
 }

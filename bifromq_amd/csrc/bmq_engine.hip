@@ -75,7 +75,6 @@ struct DistDevice { // one epoch of the dist index in HBM
 
 struct bmq_engine {
     bmq_config cfg{};
-    uint32_t walk_ilp = 1; // work items per lane per k_walk round
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8]{};
@@ -277,13 +276,8 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
         const dim3 grid((a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
-        if (e->walk_ilp == 2) {
-            if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_walk<2>, grid, block, lds, s, a);
-        } else {
-            if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_walk<1>, grid, block, lds, s, a);
-        }
+        if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_walk, grid, block, lds, s, a);
     }
     HIPCHK(e, hipEventRecord(e->ev[2], s));
     hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
@@ -308,18 +302,18 @@ static void print_wave_debug(bmq_engine* e) {
     if (!a.dbg_wave || !a.n_blocks) return;
     std::vector<uint4> h(a.n_blocks);
     if (hipMemcpy(h.data(), a.dbg_wave, sizeof(uint4) * a.n_blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
-    double s1 = 0, s2 = 0, s3 = 0, sr = 0;
+    double s1 = 0, s2 = 0, s3 = 0, sr = 0, si = 0;
     std::vector<uint32_t> r(a.n_blocks), c2(a.n_blocks);
     for (uint32_t i = 0; i < a.n_blocks; i++) {
-        s1 += h[i].x, s2 += h[i].y, s3 += h[i].z, sr += h[i].w;
-        r[i] = h[i].w, c2[i] = h[i].y;
+        s1 += h[i].x, s2 += h[i].y, s3 += h[i].z, sr += h[i].w & 255u, si += h[i].w >> 8;
+        r[i] = h[i].w & 255u, c2[i] = h[i].y;
     }
     std::sort(r.begin(), r.end());
     std::sort(c2.begin(), c2.end());
     const double n = a.n_blocks;
-    fprintf(stderr, "[bmq] k_walk waves=%u clocks/wave: tokenise %.0f walk %.0f (p50 %u p99 %u) write %.0f | rounds mean %.1f p50 %u p99 %u max %u\n",
+    fprintf(stderr, "[bmq] k_walk waves=%u clocks/wave: tokenise %.0f walk %.0f (p50 %u p99 %u) write %.0f | rounds mean %.1f p50 %u p99 %u max %u | items/wave %.0f\n",
             a.n_blocks, s1 / n, s2 / n, c2[a.n_blocks / 2], c2[(size_t)(a.n_blocks * 0.99)], s3 / n, sr / n, r[a.n_blocks / 2],
-            r[(size_t)(a.n_blocks * 0.99)], r.back());
+            r[(size_t)(a.n_blocks * 0.99)], r.back(), si / n);
 }
 
 int finish_dist(bmq_engine* e, uint64_t* out_total) {
@@ -402,18 +396,16 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (cfg->struct_size < 8 || cfg->struct_size > sizeof(bmq_config)) return BMQ_E_INVAL;
         memcpy(&c, cfg, cfg->struct_size);
     }
-    if (c.wave_queue_cap == 0) c.wave_queue_cap = 256;
-    if (c.wave_pair_cap == 0) c.wave_pair_cap = 256;
+    // defaults: 9.6 KB of LDS per wave -> 8 two-wave workgroups = 16 waves per CU (measured best on C3, profiles/r01)
+    if (c.wave_queue_cap == 0) c.wave_queue_cap = 192;
+    if (c.wave_pair_cap == 0) c.wave_pair_cap = 160;
     if (const char* v = getenv("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
     if (const char* v = getenv("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
     if (c.wave_queue_cap < 128 || (c.wave_queue_cap & 63) || c.wave_queue_cap > 4096) return BMQ_E_INVAL;
-    uint32_t walk_ilp = 1;
-    if (const char* v = getenv("BMQ_WALK_ILP")) walk_ilp = atoi(v) == 2 ? 2u : 1u;
     // the range buffer must take one round's matches (two per work item) after a flush
-    if (c.wave_pair_cap < 128 * walk_ilp || (c.wave_pair_cap & 3) || c.wave_pair_cap > 4096) return BMQ_E_INVAL;
+    if (c.wave_pair_cap < 128 || (c.wave_pair_cap & 3) || c.wave_pair_cap > 4096) return BMQ_E_INVAL;
     auto e = std::make_unique<bmq_engine>();
     e->cfg = c;
-    e->walk_ilp = walk_ilp;
     e->device = c.device;
     if (c.device >= 0) {
         int n = 0;

@@ -584,11 +584,13 @@ bool DistIndexHost::refresh(std::vector<TenantState*>& touched) {
     for (TenantState* t : order)
         for (size_t i = 0; i < t->indirect.size(); i++) route_pos[t->rp_base + i] = t->rank_base + t->indirect[i];
     const uint32_t tslots = pow2_at_least((uint64_t)order.size() * 2);
-    tenants.assign(tslots, TenantSlot{0, 0, 0, 1, 0, 0, {0, 0}});
+    tenants.assign(tslots, EMPTY_TENANT);
     for (TenantState* t : order) {
         uint32_t d = tenant_hash(t->token) & (tslots - 1);
         while (tenants[d].token) d = (d + 1) & (tslots - 1);
-        tenants[d] = TenantSlot{t->token, t->root_rel, t->base, t->buckets, t->rank_base, t->rp_base, {0, 0}};
+        const TrieSlot& root = trie[t->base + t->root_rel];
+        tenants[d] = TenantSlot{t->token, t->root_rel, t->base, t->buckets, t->rank_base, t->rp_base, root.hash_begin, root.hash_count,
+                                root.plus_child, root.lit_bloom, {0, 0, 0, 0, 0, 0}};
     }
     if (dict_changed) flatten_dict(dict_h, dict, pool);
     if (trie.empty()) trie.grow(64, 0);

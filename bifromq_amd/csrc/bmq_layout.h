@@ -46,16 +46,21 @@ static_assert(sizeof(TrieSlot) == 32, "TrieSlot must be 32 bytes");
 // Tenant directory entry: the tenant's region of the slot table.  Bucket k of the region = slots base+2k, base+2k+1.
 // Slot indices stored INSIDE a region (TrieSlot.parent, plus_child, the root) are relative to `base`, and route ids
 // inside a region are relative to `rank_base`: a region can be rebuilt, moved or re-based without touching the others.
-struct alignas(32) TenantSlot {
+struct alignas(64) TenantSlot {
     uint32_t token;     // dictionary token of the tenant id; 0 = empty directory slot
     uint32_t root;      // slot of the tenant's root node, relative to base
     uint32_t base;      // first slot of the region (even)
     uint32_t buckets;   // number of 2-slot buckets (>= 1)
     uint32_t rank_base; // global route id of the tenant's first route (ids are ranks in KV key order)
     uint32_t rp_base;   // first entry of the tenant in route_pos[]
-    uint32_t pad[2];
+    // copy of the root slot's payload: every topic of the tenant starts at the root, so the walk takes it from the
+    // directory entry it reads anyway instead of spending a line fetch and a round on it
+    uint32_t root_hash_begin, root_hash_count; // routes of the filter "#"
+    uint32_t root_plus_child, root_lit_bloom;
+    uint32_t pad[6];
 };
-static_assert(sizeof(TenantSlot) == 32, "TenantSlot must be 32 bytes");
+static_assert(sizeof(TenantSlot) == 64, "TenantSlot must be 64 bytes");
+constexpr TenantSlot EMPTY_TENANT{0, 0, 0, 1, 0, 0, 0, 0, NONE, 0, {0, 0, 0, 0, 0, 0}};
 
 // Level dictionary: level string -> token, exact (bytes verified).  Strings <= 16 bytes live inline.  Open addressing
 // over groups of DICT_GROUP slots (one 64-byte line) at load factor <= 1/4: a lookup reads its home group in one go.

@@ -54,8 +54,9 @@ __device__ __forceinline__ uint32_t redge_lookup(const RetainIndexView& ix, uint
                                                  uint32_t token) {
     uint32_t bk = redge_bucket(parent, token, mask);
     for (;;) {
-        const uint4* p = reinterpret_cast<const uint4*>(ix.edges + edge_base + 4 * (size_t)bk);
-        const uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+        Line64 ln; // the whole bucket in one request (see load_line64)
+        load_line64(ix.edges + edge_base + 4 * (size_t)bk, ln);
+        const uint4 e0 = ln.a0, e1 = ln.a1, e2 = ln.b0, e3 = ln.b1;
         if (e0.x == parent && e0.y == token) return e0.z;
         if (e1.x == parent && e1.y == token) return e1.z;
         if (e2.x == parent && e2.y == token) return e2.z;

@@ -51,12 +51,13 @@ typedef enum bmq_status {
 typedef struct bmq_engine bmq_engine;
 
 /* Tunables.  Zero-initialise, set struct_size = sizeof(bmq_config), override what you need.
- * The *_cap fields exist so tests can force the overflow (slow) paths; 0 = default. */
+ * The *_cap fields exist so tests can force the LDS overflow (global spill) paths; 0 = default. */
 typedef struct bmq_config {
     uint32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = host-only engine (build/inspect, no match)      */
-    uint32_t wave_queue_cap;   /* per-wave LDS work stack, items (default 256; 128..4096, x64)               */
-    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 256; 128..4096)      */
+    uint32_t wave_queue_cap;   /* per-wave LDS work stack, items (default 192; 128..4096, x64); overflow is   */
+                               /* parked in global memory, never an error                                    */
+    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 160; 128..4096, x4)  */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t reserved[8];
 } bmq_config;
@@ -67,7 +68,7 @@ typedef struct bmq_stats {
     uint64_t n_visit;        /* filter-trie nodes discovered (root excluded), all topics                    */
     uint64_t n_match;        /* route ids emitted                                                           */
     uint64_t n_ranges;       /* matched (filter node) ranges                                                */
-    uint64_t n_slow_topics;  /* topics resolved by the slow path (deep topics / LDS overflow)               */
+    uint64_t n_slow_topics;  /* topics resolved by the slow path (more than 16 levels)                     */
     uint64_t n_sorted_rows;  /* rows that needed the element-level fix-up sort                              */
     uint64_t topic_bytes;    /* sum of topic lengths                                                        */
     float ms_total;          /* HIP-event time of the whole batch on the engine stream                      */
