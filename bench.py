@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--exchange-selftest", action="store_true",
                     help="run the N>1 exchange step (RCCL all-gather of the CSR) also at world size 1, to exercise that code path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batcher-threads", type=int, default=0,
+                    help="also measure the batching front (bmq_batcher_*, SURVEY 8f-1): N native threads issue single-topic calls")
+    ap.add_argument("--batcher-topics", type=int, default=200_000)
     ap.add_argument("--cpu-sample-tenants", type=int, default=128)
     ap.add_argument("--cpu-sample-topics", type=int, default=1_000_000)
     args = ap.parse_args()
@@ -251,6 +254,18 @@ def main():
         except Exception:
             pass
 
+    if args.batcher_threads:  # the production call pattern (one topic per call, many threads) through the collector
+        hdata, hoff, htt = batches[0][3]
+        m = min(args.batcher_topics, n)
+        sub = (hdata, hoff[:m + 1].copy())
+        bt = eng.batcher()
+        cnt, hsh, sec = bt.drive_singletons(w.tenants(), htt[:m], sub, args.batcher_threads)
+        bs = bt.stats()
+        out["batching_front"] = {"threads": args.batcher_threads, "single_topic_calls": m, "calls_per_s": m / sec,
+                                 "launches": int(bs.n_batches), "mean_topics_per_launch": bs.n_topics / max(1, bs.n_batches),
+                                 "max_topics_per_launch": int(bs.max_batch_topics), "ids_returned": int(cnt.sum()),
+                                 "note": "bmq_batcher_match_all, blocking callers: a launch holds at most one topic per thread"}
+        bt.close()
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n)
     if dist is not None:

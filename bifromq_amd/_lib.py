@@ -20,7 +20,8 @@ ABI_SYMBOLS = [
     "bmq_index_info_get", "bmq_route_key", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
     "bmq_match_finish", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_retain_rebuild", "bmq_retain_apply", "bmq_retain_topic",
-    "bmq_retain_match_batch", "bmq_retain_match_batch_dev",
+    "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_batcher_create", "bmq_batcher_destroy",
+    "bmq_batcher_match_all", "bmq_batcher_stats_get",
 ]
 
 
@@ -50,6 +51,15 @@ class IndexInfo(C.Structure):
     _fields_ = [("n_routes", C.c_uint64), ("n_tenants", C.c_uint64), ("n_nodes", C.c_uint64), ("n_tokens", C.c_uint64),
                 ("trie_slots", C.c_uint64), ("dict_slots", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("epoch", C.c_uint64)]
+
+
+class BatcherConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("max_batch_topics", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+
+
+class BatcherStats(C.Structure):
+    _fields_ = [("n_requests", C.c_uint64), ("n_topics", C.c_uint64), ("n_batches", C.c_uint64),
+                ("max_batch_topics", C.c_uint64)]
 
 
 _lib = None
@@ -90,6 +100,10 @@ def lib() -> C.CDLL:
             "bmq_retain_topic": (C.c_int, [vp, u32, C.c_char_p, u32, P(u32), P(u32)]),
             "bmq_retain_match_batch": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, P(u64)]),
             "bmq_retain_match_batch_dev": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, vp]),
+            "bmq_batcher_create": (C.c_int, [vp, P(BatcherConfig), P(vp)]),
+            "bmq_batcher_destroy": (None, [vp]),
+            "bmq_batcher_match_all": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, vp, vp, u64, P(u64), P(u64)]),
+            "bmq_batcher_stats_get": (C.c_int, [vp, P(BatcherStats)]),
         }
         assert sorted(sig) == sorted(ABI_SYMBOLS)
         for name, (res, args) in sig.items():
@@ -116,6 +130,8 @@ def gen() -> C.CDLL:
             "bmqgen_topics": (u32, [vp, u64, u32, u32, u32, u32, C.c_int]),
             "bmqgen_topic_bytes": (vp, [vp]), "bmqgen_topic_off": (vp, [vp]), "bmqgen_topic_tenant": (vp, [vp]),
             "bmqgen_retain": (u32, [vp, u64, u32, C.c_int]),
+            "bmqgen_drive_singletons": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, vp, vp, C.POINTER(C.c_double)]),
+            "bmqgen_row_hash": (u64, [vp, u64]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(G, name)

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "../../include/bmq.h"
@@ -724,3 +726,4 @@ int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len) { return java_st
 } // extern "C"
 
 #include "bmq_retain_engine.inc"
+#include "bmq_batcher.inc"

@@ -17,6 +17,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
+#include <atomic>
 
 #include "bmq_index.h"
 
@@ -322,6 +324,60 @@ uint32_t bmqgen_retain(void* h, uint64_t seed, uint32_t n, int filters) {
     }
     g.out_topics.pad();
     return n;
+}
+
+// ---- load driver for the batching front (include/bmq.h, bmq_batcher_match_all): n_threads threads issue ONE-topic calls, the
+// production call pattern of TenantRouteCache (DW/cache/TenantRouteCache.java:180-193).  `fn` is the address of
+// bmq_batcher_match_all (passed in so that this library does not link against libbmq.so).  Per topic: the number of ids
+// and an order-sensitive hash of the row, for the caller to compare with a direct bmq_match_batch over the same topics.
+typedef int (*match_all_fn)(void*, const uint8_t*, uint32_t, const uint8_t*, const uint32_t*, uint32_t, uint32_t*, uint32_t*,
+                            uint64_t, uint64_t*, uint64_t*);
+uint64_t bmqgen_row_hash(const uint32_t* ids, uint64_t n) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (uint64_t i = 0; i < n; i++) h = (h ^ ids[i]) * 0x100000001B3ull;
+    return h;
+}
+int bmqgen_drive_singletons(void* fn, void* batcher, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                            const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
+                            uint32_t n_threads, uint32_t* out_count, uint64_t* out_hash, double* out_seconds) {
+    if (!fn || !batcher || !n_threads) return -1;
+    const match_all_fn match = (match_all_fn)fn;
+    std::atomic<uint32_t> next{0};
+    std::atomic<int> err{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (uint32_t w = 0; w < n_threads; w++)
+        th.emplace_back([&] {
+            std::vector<uint32_t> ids(1024);
+            for (;;) {
+                const uint32_t i = next.fetch_add(1);
+                if (i >= n_topics || err.load()) break;
+                const uint32_t ti = topic_tenant[i];
+                if (ti >= n_tenants) {
+                    err = -1;
+                    break;
+                }
+                const uint32_t off[2] = {0, topic_off[i + 1] - topic_off[i]};
+                uint32_t row_ptr[2];
+                uint64_t need = 0, epoch = 0;
+                int rc = match(batcher, tenants + tenant_off[ti], tenant_off[ti + 1] - tenant_off[ti], topics + topic_off[i], off, 1,
+                               row_ptr, ids.data(), ids.size(), &need, &epoch);
+                if (rc == -3) { // BMQ_E_NOSPACE: grow and ask again
+                    ids.resize(need + 64);
+                    rc = match(batcher, tenants + tenant_off[ti], tenant_off[ti + 1] - tenant_off[ti], topics + topic_off[i], off, 1,
+                               row_ptr, ids.data(), ids.size(), &need, &epoch);
+                }
+                if (rc) {
+                    err = rc;
+                    break;
+                }
+                out_count[i] = (uint32_t)need;
+                out_hash[i] = bmqgen_row_hash(ids.data(), need);
+            }
+        });
+    for (auto& t : th) t.join();
+    if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return err.load();
 }
 
 } // extern "C"

@@ -179,6 +179,10 @@ class Engine:
             self._check(rc)
             return row, ids[:need.value]
 
+    def batcher(self, max_batch_topics: int = 0) -> "Batcher":
+        """The batching front of SURVEY.md 8f-1 over this engine (close it before the engine)."""
+        return Batcher(self, max_batch_topics)
+
     def match_tenant(self, tenant, topics: Sequence) -> List[List[int]]:
         row, ids = self.match_batch([tenant], np.zeros(len(topics), dtype=np.uint32), topics)
         return [ids[row[i]:row[i + 1]].tolist() for i in range(len(topics))]
@@ -288,3 +292,74 @@ class Engine:
     @property
     def stream(self) -> int:
         return _lib.lib().bmq_stream(self.h) or 0
+
+
+class Batcher:
+    """bmq_batcher_*: collects the single-topic matchAll calls of many threads (TenantRouteCache.java:180-193) into one
+    GPU batch.  match_all blocks; call it from as many threads as there are callers (ctypes drops the GIL)."""
+
+    def __init__(self, engine: Engine, max_batch_topics: int = 0):
+        cfg = _lib.BatcherConfig()
+        cfg.struct_size = C.sizeof(_lib.BatcherConfig)
+        cfg.max_batch_topics = max_batch_topics
+        h = C.c_void_p()
+        rc = _lib.lib().bmq_batcher_create(engine.h, C.byref(cfg), C.byref(h))
+        if rc:
+            raise BmqError(rc, "bmq_batcher_create failed")
+        self.h = h
+        self.engine = engine  # keeps the engine alive
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().bmq_batcher_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def match_all(self, tenant, topics: Sequence) -> Tuple[List[List[int]], int]:
+        """-> (per-topic ascending route id lists, epoch the ids belong to)"""
+        t = _b(tenant)
+        pdata, poff = pack(topics)
+        n = len(topics)
+        row = np.zeros(n + 1, dtype=np.uint32)
+        cap = max(256, 16 * n)
+        need, epoch = C.c_uint64(), C.c_uint64()
+        while True:
+            ids = np.zeros(cap, dtype=np.uint32)
+            rc = _lib.lib().bmq_batcher_match_all(self.h, t, len(t), _ptr(pdata), _ptr(poff), n, _ptr(row), _ptr(ids), cap,
+                                                  C.byref(need), C.byref(epoch))
+            if rc == -3 and need.value > cap:
+                cap = int(need.value)
+                continue
+            if rc:
+                raise BmqError(rc, (_lib.lib().bmq_last_error(self.engine.h) or b"").decode())
+            return [ids[row[i]:row[i + 1]].tolist() for i in range(n)], int(epoch.value)
+
+    def stats(self) -> "_lib.BatcherStats":
+        st = _lib.BatcherStats()
+        rc = _lib.lib().bmq_batcher_stats_get(self.h, C.byref(st))
+        if rc:
+            raise BmqError(rc, "bmq_batcher_stats_get")
+        return st
+
+    def drive_singletons(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed: Tuple[np.ndarray, np.ndarray],
+                         n_threads: int):
+        """n_threads native threads issue one single-topic call per topic (the production call pattern).
+        -> (ids per topic, row hash per topic, seconds)"""
+        tdata, toff = pack(tenants)
+        pdata, poff = topics_packed
+        n = len(poff) - 1
+        cnt = np.zeros(n, dtype=np.uint32)
+        hsh = np.zeros(n, dtype=np.uint64)
+        sec = C.c_double()
+        fn = C.cast(_lib.lib().bmq_batcher_match_all, C.c_void_p)
+        tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
+        rc = _lib.gen().bmqgen_drive_singletons(fn, self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(tt), _ptr(pdata), _ptr(poff),
+                                                n, n_threads, _ptr(cnt), _ptr(hsh), C.byref(sec))
+        if rc:
+            raise BmqError(rc, "bmqgen_drive_singletons")
+        return cnt, hsh, sec.value

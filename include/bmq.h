@@ -141,6 +141,34 @@ int bmq_stats_get(const bmq_engine* e, bmq_stats* out);
 /* The hipStream_t the engine launches on (as void*), so a harness can bracket it with HIP events. */
 void* bmq_stream(const bmq_engine* e);
 
+/* ---- batching front ------------------------------------------------------------------- */
+/* Production asks for one topic per call: TenantRouteCache issues matchAll(singleton(topic)) per cache miss from
+ * the matchExecutor pool (DW/cache/TenantRouteCache.java:180-193, DW/DistWorkerCoProcFactory.java:74-88).  A batcher
+ * collects the calls of all threads that are waiting right now into ONE bmq_match_batch (leader/follower: no timer,
+ * no extra thread; the batch is whatever piled up while the previous one was on the GPU) and hands every caller
+ * its rows.  Any number of threads may call bmq_batcher_match_all concurrently; the call blocks until the batch
+ * that contains the request has been matched.  bmq_rebuild / bmq_routes_apply may run concurrently (they serialise
+ * with the batches on the engine lock); *out_epoch tells which epoch the returned route ids are ranks of. */
+typedef struct bmq_batcher bmq_batcher;
+typedef struct bmq_batcher_config {
+    uint32_t struct_size;
+    uint32_t max_batch_topics; /* upper bound of one launch (default 2^20); a single larger request still runs alone */
+    uint32_t reserved[6];
+} bmq_batcher_config;
+typedef struct bmq_batcher_stats {
+    uint64_t n_requests, n_topics, n_batches, max_batch_topics;
+} bmq_batcher_stats;
+int bmq_batcher_create(bmq_engine* e, const bmq_batcher_config* cfg /* may be NULL */, bmq_batcher** out);
+/* Waits for the calls in flight; calls arriving afterwards fail with BMQ_E_STATE.  Destroy before the engine. */
+void bmq_batcher_destroy(bmq_batcher* b);
+/* ITenantRouteMatcher.matchAll(topics) for ONE tenant, caps not applied (INT_MAX), through the collector.
+ * out_row_ptr[n_topics + 1] is relative to this request; BMQ_E_NOSPACE + *out_needed if out_capacity is too small
+ * (row pointers are still written). */
+int bmq_batcher_match_all(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics,
+                          const uint32_t* topic_off, uint32_t n_topics, uint32_t* out_row_ptr,
+                          uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed, uint64_t* out_epoch);
+int bmq_batcher_stats_get(bmq_batcher* b, bmq_batcher_stats* out);
+
 /* ---- host-side mirror of MatchedRoutes (fan-out caps in KV order) -------------------------------------- */
 /* One ITenantRouteMatcher.matchAll(topics, maxPersistentFanout, maxGroupFanout) call for one tenant,
  * including DW/cache/MatchedRoutes.java:87-141: persistent (subBrokerId == 1) and group fan-out caps applied

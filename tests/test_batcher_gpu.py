@@ -1,0 +1,116 @@
+"""GPU tests of the batching front (include/bmq.h, bmq_batcher_*): many threads issue the production
+call -- ITenantRouteMatcher.matchAll(singleton(topic)) per cache miss, DW/cache/TenantRouteCache.java:180-193 -- and
+every caller must get exactly the rows a direct batch (and the oracle) gives for its topics."""
+import threading
+
+import numpy as np
+import pytest
+
+import bifromq_amd as B
+from bifromq_amd import _lib
+from bifromq_amd.workload import unpack
+from oracle import oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _row_hash(ids):
+    a = np.ascontiguousarray(ids, dtype=np.uint32)
+    return int(_lib.gen().bmqgen_row_hash(a.ctypes.data, len(a)))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    w = B.Workload(21, 6, 1500, 1)
+    keys = w.keys()
+    eng = B.Engine(device=0).rebuild(keys)
+    tn = w.tenants()
+    data, off, tt = w.topics(9, 6000)
+    topics = [t.decode() for t in unpack(data, off)]
+    exp = U.semantic_rows(O.KV(keys), tn, tt, topics)
+    yield eng, tn, tt, (data, off), topics, exp
+    eng.close()
+
+
+def test_single_caller_equals_oracle(setup):
+    eng, tn, tt, _, topics, exp = setup
+    b = eng.batcher()
+    for i in (0, 1, 2, 57, 4000):
+        rows, epoch = b.match_all(tn[tt[i]], [topics[i]])
+        assert rows == [exp[i]] and epoch == eng.info().epoch
+    sel = [i for i in range(len(topics)) if tt[i] == 2][:50]  # matchAll(Set<String>) of one tenant
+    rows, _ = b.match_all(tn[2], [topics[i] for i in sel])
+    assert rows == [exp[i] for i in sel]
+    assert b.match_all(tn[0], [])[0] == []
+    assert b.match_all("no-such-tenant", ["a/b"])[0] == [[]]  # every topic is a key, also with 0 routes
+    st = b.stats()
+    assert st.n_batches == st.n_requests and st.n_topics == 5 + len(sel) + 1  # one caller: every request runs alone
+    b.close()
+
+
+def test_many_native_threads_singleton_calls(setup):
+    eng, tn, tt, packed, topics, exp = setup
+    b = eng.batcher()
+    cnt, hsh, sec = b.drive_singletons(tn, tt, packed, n_threads=64)
+    assert cnt.tolist() == [len(r) for r in exp]
+    assert hsh.tolist() == [_row_hash(r) for r in exp]
+    st = b.stats()
+    assert st.n_requests == len(topics) and st.n_topics == len(topics)
+    assert st.n_batches < st.n_requests and st.max_batch_topics > 1  # calls really were collected into shared launches
+    assert st.max_batch_topics <= 64  # a blocked caller has one request in flight
+    b.close()
+
+
+def test_python_threads_while_routes_change(setup):
+    """Callers keep matching while the apply thread mutates routes (DistWorkerCoProc.java:188-209): rows always belong to
+    ONE epoch -- the one reported with them -- because batch and epoch are read under one hold of the engine lock."""
+    eng, tn, tt, _, topics, exp = setup
+    b = eng.batcher(max_batch_topics=8)
+    extra = [B.route_key_from_mqtt(tn[0], "zz/%d" % i, O.receiver_url(0, "x%d" % i, "d")) for i in range(24)]  # match nothing above
+    errors, epochs = [], set()
+
+    def caller(k):
+        try:
+            for i in range(k, 600, 6):
+                rows, epoch = b.match_all(tn[tt[i]], [topics[i]])
+                assert len(rows[0]) == len(exp[i])  # ids shift while routes come and go; counts do not
+                epochs.add(epoch)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    def mutator():
+        try:
+            for i in range(6):
+                eng.apply([(0, k) for k in extra[i * 4:(i + 1) * 4]])
+                eng.apply([(1, k) for k in extra[i * 4:(i + 1) * 4]])
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    th = [threading.Thread(target=caller, args=(k,)) for k in range(6)] + [threading.Thread(target=mutator)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert len(epochs) > 1 and b.stats().max_batch_topics <= 8
+    rows, epoch = b.match_all(tn[tt[5]], [topics[5]])
+    assert rows == [exp[5]] and epoch == eng.info().epoch
+    b.close()
+
+
+def test_small_output_buffer_reports_needed(setup):
+    eng, tn, tt, _, topics, exp = setup
+    b = eng.batcher()
+    i = int(np.argmax([len(r) for r in exp]))
+    assert len(exp[i]) > 1
+    t = tn[tt[i]].encode() if isinstance(tn[tt[i]], str) else tn[tt[i]]
+    pdata, poff = B.pack([topics[i]])
+    row = np.zeros(2, dtype=np.uint32)
+    ids = np.zeros(1, dtype=np.uint32)
+    import ctypes as C
+    need, epoch = C.c_uint64(), C.c_uint64()
+    rc = _lib.lib().bmq_batcher_match_all(b.h, t, len(t), pdata.ctypes.data, poff.ctypes.data, 1, row.ctypes.data, ids.ctypes.data, 1,
+                                          C.byref(need), C.byref(epoch))
+    assert rc == -3 and need.value == len(exp[i]) and row.tolist() == [0, len(exp[i])]
+    b.close()
