@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "bmq_index_info_get", "bmq_route_key", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
     "bmq_match_finish", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_retain_rebuild", "bmq_retain_apply", "bmq_retain_topic",
-    "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_batcher_create", "bmq_batcher_destroy",
+    "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
     "bmq_batcher_match_all", "bmq_batcher_stats_get",
 ]
 
@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
             "bmq_retain_topic": (C.c_int, [vp, u32, C.c_char_p, u32, P(u32), P(u32)]),
             "bmq_retain_match_batch": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, P(u64)]),
             "bmq_retain_match_batch_dev": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, vp]),
+            "bmq_retain_match_limited": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, vp, u64, P(u64), vp]),
             "bmq_batcher_create": (C.c_int, [vp, P(BatcherConfig), P(vp)]),
             "bmq_batcher_destroy": (None, [vp]),
             "bmq_batcher_match_all": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, vp, vp, u64, P(u64), P(u64)]),

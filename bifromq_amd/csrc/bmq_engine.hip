@@ -99,7 +99,7 @@ struct bmq_engine {
     uint32_t slow_cap = 0, sort_cap = 0;
     Counters* h_ctr = nullptr; // pinned
     // staging for the host-buffer API
-    DevBuf s_tenants, s_tenant_off, s_topic_tenant, s_topics, s_topic_off, s_row_ptr, s_ids;
+    DevBuf s_tenants, s_tenant_off, s_topic_tenant, s_topics, s_topic_off, s_row_ptr, s_ids, s_lim, s_lim_ids;
 
     // last async batch (for bmq_match_finish)
     bool pending = false;

@@ -375,4 +375,47 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// RetainStoreCoProc.match `limit` (RS/RetainStoreCoProc.java:167-190): keep the first limit[i] ids of every row of a
+// finished CSR (rows are ascending, so these are the smallest topic ids) and report the exact row lengths.
+// ------------------------------------------------------------------------------------------------------------
+// one workgroup: new_row_ptr = exclusive scan of min(row length, limit); counts = row lengths
+__global__ __launch_bounds__(1024) void k_limit_scan(const uint32_t* row_ptr, const uint32_t* limit, uint32_t n, uint32_t* new_row_ptr,
+                                                     uint32_t* counts, unsigned long long* new_total) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023) / 1024, lo = min(n, tid * per), hi = min(n, lo + per);
+    unsigned long long s = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t c = row_ptr[i + 1] - row_ptr[i];
+        counts[i] = c;
+        s += min(c, limit[i]);
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan of the per-thread sums
+        const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[tid] - s;
+    for (uint32_t i = lo; i < hi; i++) {
+        new_row_ptr[i] = (uint32_t)run; // <= the untruncated total, which is < 2^32
+        run += min(counts[i], limit[i]);
+    }
+    if (tid == 1023) {
+        new_row_ptr[n] = (uint32_t)part[1023];
+        *new_total = part[1023];
+    }
+}
+// one lane per row: rows are short after truncation (the reference's default limit is 10, Setting.java:77)
+__global__ __launch_bounds__(256) void k_limit_copy(const uint32_t* row_ptr, const uint32_t* new_row_ptr, const uint32_t* ids, uint32_t n,
+                                                    uint32_t* out_ids) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = row_ptr[i], dst = new_row_ptr[i], c = new_row_ptr[i + 1] - dst;
+    for (uint32_t k = 0; k < c; k++) out_ids[dst + k] = ids[src + k];
+}
+
 } // namespace bmq

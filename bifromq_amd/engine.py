@@ -279,6 +279,29 @@ class Engine:
             self._check(rc)
             return row, ids[:need.value]
 
+    def retain_match_limited(self, tenants: Sequence, filter_tenant, filters: Sequence, limits):
+        """RetainStoreCoProc.match with per-filter limits -> (row_ptr[n+1], kept topic ids, exact match count per filter):
+        row i holds the min(limit, count) smallest matching topic ids."""
+        tdata, toff = pack(tenants)
+        pdata, poff = pack(filters)
+        n = len(poff) - 1
+        ft = np.ascontiguousarray(filter_tenant, dtype=np.uint32)
+        lim = np.ascontiguousarray(limits, dtype=np.uint32)
+        assert len(lim) == n and len(ft) == n
+        row = np.zeros(n + 1, dtype=np.uint32)
+        counts = np.zeros(n, dtype=np.uint32)
+        cap = int(min(int(lim.astype(np.uint64).sum()), 1 << 28)) + 1
+        need = C.c_uint64()
+        while True:
+            ids = np.zeros(cap, dtype=np.uint32)
+            rc = _lib.lib().bmq_retain_match_limited(self.h, _ptr(tdata), _ptr(toff), len(toff) - 1, _ptr(ft), _ptr(pdata), _ptr(poff),
+                                                     n, _ptr(lim), _ptr(row), _ptr(ids), cap, C.byref(need), _ptr(counts))
+            if rc == -3 and need.value > cap:
+                cap = need.value
+                continue
+            self._check(rc)
+            return row, ids[:need.value], counts
+
     def retain_match(self, tenant, topic_filter) -> List[int]:
         row, ids = self.retain_match_batch([tenant], [0], [topic_filter])
         return ids.tolist()

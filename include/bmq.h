@@ -209,6 +209,15 @@ int bmq_retain_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t
                            const uint32_t* filter_tenant, const uint8_t* filters, const uint32_t* filter_off,
                            uint32_t n_filters, uint32_t* out_row_ptr, uint32_t* out_topic_ids,
                            uint64_t out_capacity, uint64_t* out_needed);
+/* RetainStoreCoProc.match with its per-filter `limit` (RS/RetainStoreCoProc.java:167-190, limit from
+ * RetainStoreCoProc.proto:63, tenant default RetainMessageMatchLimit = 10, Setting.java:77): the reference computes the
+ * FULL match set and then keeps an unspecified `limit` of it (HashSet iteration order, UTIL/index/StrategySet.java:31).
+ * Here: out_match_count[i] = the exact number of retained topics matching filter i (may be NULL), and row i holds the
+ * min(limit[i], count) SMALLEST topic ids.  Same buffer protocol as bmq_retain_match_batch. */
+int bmq_retain_match_limited(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                             const uint32_t* filter_tenant, const uint8_t* filters, const uint32_t* filter_off,
+                             uint32_t n_filters, const uint32_t* limit, uint32_t* out_row_ptr, uint32_t* out_topic_ids,
+                             uint64_t out_capacity, uint64_t* out_needed, uint32_t* out_match_count);
 int bmq_retain_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t* d_tenant_off,
                                uint32_t n_tenants, const uint32_t* d_filter_tenant, const uint8_t* d_filters,
                                const uint32_t* d_filter_off, uint32_t n_filters, uint32_t* d_out_row_ptr,

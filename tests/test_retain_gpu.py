@@ -96,6 +96,31 @@ def test_generated_workload_parity(eng):
     assert (np.diff(row.astype(np.int64)) >= 0).all()
 
 
+def test_match_limited_keeps_smallest_ids_and_exact_counts(eng):
+    """RetainStoreCoProc.match (RS/RetainStoreCoProc.java:167-190) computes the full match set and keeps `limit` of it:
+    here the exact count and the `limit` smallest topic ids, i.e. the prefix of the unlimited (ascending) row."""
+    w = B.Workload(0xB1F20004, 3, 1, 0)
+    data, off, tt = w.retain(77, 30000, filters=False)
+    tn = w.tenants()
+    eng.retain_rebuild(tn, tt, packed_topics=(data, off))
+    fdata, foff, ft = w.retain(78, 5000, filters=True)
+    filters = [f.decode() for f in unpack(fdata, foff)]
+    row, ids = eng.retain_match_batch(tn, ft, filters)
+    full = U.csr_rows(row, ids)
+    rnd = random.Random(3)
+    limits = [rnd.choice([0, 1, 2, 10, 10, 10, 100, 0xFFFFFFFF]) for _ in filters]  # 10 = RetainMessageMatchLimit default
+    lrow, lids, counts = eng.retain_match_limited(tn, ft, filters, limits)
+    assert counts.tolist() == [len(r) for r in full]
+    assert U.csr_rows(lrow, lids) == [r[:min(l, len(r))] for r, l in zip(full, limits)]
+    assert any(len(r) > 10 for r in full) and any(0 < len(r) <= 10 for r in full)  # both regimes were exercised
+    # a single filter, unknown tenant, empty batch
+    lrow, lids, counts = eng.retain_match_limited(tn + ["nobody"], [3], ["#"], [5])
+    assert lrow.tolist() == [0, 0] and counts.tolist() == [0]
+    lrow, lids, counts = eng.retain_match_limited(tn, [0], ["#"], [7])
+    everything = eng.retain_match(tn[0], "#")
+    assert counts[0] == len(everything) > 7 and lids.tolist() == everything[:7]
+
+
 def test_edge_shapes(eng):
     deep = "/".join(["a"] * 40)
     eng.retain_rebuild(["t"], [0, 0, 0, 0], [deep, "a", "/", "x" * 5000 + "/y"])
