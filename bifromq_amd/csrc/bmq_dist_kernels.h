@@ -610,16 +610,32 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     cursor[lane] = excl;
     wave_sync();
     if (fits && total_pairs) {
-        for (uint32_t cb = fl_base, cl = fl_len; cl;) { // flushed chunks first (they are L2-hot), then what is still in LDS
-            const uint4 hd = a.spill[cb];
+        // flushed chunks first, OLDEST first (the chain runs newest to oldest: it is laid out in the dead stack area and
+        // replayed backwards), then what is still in LDS: every topic's ranges stay in discovery order, which is close to
+        // ascending id order and keeps the ordering work of k_expand small
+        auto copy_chunk = [&](uint32_t cb, uint32_t cl) {
             for (uint32_t i = lane; i < cl; i += 64) {
                 const uint4 r = a.spill[cb + 1 + i];
                 if (tmeta[r.z] & TM_FLAG) continue;
                 const uint32_t dst = atomicAdd(&cursor[r.z], 1u);
                 a.pairs[base + dst] = MatchRange{r.x, r.y};
             }
+        };
+        uint32_t n_ch = 0;
+        for (uint32_t cb = fl_base, cl = fl_len; cl;) {
+            const uint4 hd = a.spill[cb];
+            if (n_ch < a.qcap) {
+                q_node[n_ch] = cb; // all lanes store the same values
+                q_meta[n_ch] = cl;
+                n_ch++;
+            } else copy_chunk(cb, cl); // a chain longer than the stack area: order is only a matter of speed
             cb = hd.x;
             cl = hd.y;
+        }
+        wave_sync();
+        while (n_ch) {
+            n_ch--;
+            copy_chunk(q_node[n_ch], q_meta[n_ch]);
         }
         for (uint32_t i = lane; i < pcount; i += 64) {
             const uint32_t tl = p_topic[i];
