@@ -8,7 +8,8 @@
 //     ONE line in ~92 % of the cases and gets the child's complete header with it.  Measured on MI355X the walk is
 //     bound by the rate of random 64-byte line fetches (~54 G lines/s from HBM, ~200 G/s from L2,
 //     tools/ubench_lines.hip), so lines per visited node is the figure of merit;
-//   * '+' children and tenant roots are reached by slot index (one 32-byte read, no probing);
+//   * '+' children are reached by slot index: the walk reads the bucket line that contains the slot, so both kinds of
+//     work item cost the same single line; tenant roots travel in the directory entry (TenantSlot) and cost nothing;
 //   * '#' children are never nodes: the routes of "<path>/#" hang off the parent (hash_*).
 #pragma once
 #include <stdint.h>

@@ -43,4 +43,22 @@ if rows:
             json.dump({"c3": traffic, "_note": "HBM bytes per k_walk launch = FETCH_SIZE*1024*0.992 (calibrated on random 64-byte line "
                        "fetches, tools/ubench_lines.hip) + WRITE_SIZE*1024 (uncalibrated); profiles/%s/c3_pmc_hbm.csv" % R}, f)
         print("k_walk traffic per launch: %.1f MB" % (traffic / 1e6))
+ex = os.path.join(src, "extras")
+if os.path.isdir(ex):  # tools/measure_extras.sh
+    os.makedirs(os.path.join(dst, "extras"), exist_ok=True)
+    for f in sorted(glob.glob(os.path.join(ex, "*.json")) + glob.glob(os.path.join(ex, "*.txt"))):
+        shutil.copy(f, os.path.join(dst, "extras", os.path.basename(f)))
+    rows = []
+    for n in (1000, 10000, 100000, 1000000, 4000000):
+        f = os.path.join(ex, "sweep_%d.json" % n) if n != 1000000 else os.path.join(src, "bench_c3.json")
+        if os.path.exists(f):
+            d = json.loads(open(f).read().strip().splitlines()[-1])
+            k = d["kernel_ms"]
+            rows.append("%-11d %-12.1f %-14.3f %-14.3f %-11.3f %-13.3f %.3f" % (n, d["value"] / 1e6, d["p50_batch_ms"], d["p99_batch_ms"],
+                                                                           k["k_walk"], k["k_expand"], k["all_kernels"]))
+    if rows:
+        with open(os.path.join(dst, "batch_size_sweep.txt"), "w") as f:
+            f.write("# python bench.py --topics N --steps 30 --warmup 5 --no-cpu-baseline   (C3 index: 10M route keys, 1 x MI355X)\n")
+            f.write("# N         M topics/s   p50 batch ms   p99 batch ms   k_walk ms   k_expand ms   all kernels ms\n")
+            f.write("\n".join(rows) + "\n")
 print("collected into", dst)
