@@ -254,7 +254,7 @@ def main():
         except Exception:
             pass
 
-    if args.batcher_threads:  # the production call pattern (one topic per call, many threads) through the collector
+    if args.batcher_threads and world == 1:  # the production call pattern (one topic per call, many threads) through the collector
         hdata, hoff, htt = batches[0][3]
         m = min(args.batcher_topics, n)
         sub = (hdata, hoff[:m + 1].copy())
@@ -266,7 +266,7 @@ def main():
                                  "max_topics_per_launch": int(bs.max_batch_topics), "ids_returned": int(cnt.sum()),
                                  "note": "bmq_batcher_match_all, blocking callers: a launch holds at most one topic per thread"}
         bt.close()
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n)
     if dist is not None:
         dist.destroy_process_group()
@@ -374,7 +374,7 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
            "roofline": {"bound": "hbm", "kernel": "k_retain_walk+k_expand", "achieved": achieved, "peak": 8000.0,
                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                         "algorithmic_bytes_per_launch": float(np.mean(alg))}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
         lt = O.LevelTrie(1)
         raw = data.tobytes()

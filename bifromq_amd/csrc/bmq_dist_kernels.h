@@ -346,7 +346,7 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantS
 // ------------------------------------------------------------------------------------------------------------
 // k_walk -- one wave (= one 64-thread workgroup) per 64 topics
 // ------------------------------------------------------------------------------------------------------------
-// tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (-> slow path), 10 active
+// tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (more than FAST_LEVELS levels -> slow path), 10 active
 constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9, TM_ACTIVE = 1u << 10;
 #ifndef BMQ_WALK_WAVES
 #define BMQ_WALK_WAVES 2
@@ -354,7 +354,7 @@ constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9, TM_ACTIVE = 1u << 10;
 constexpr uint32_t WALK_WAVES = BMQ_WALK_WAVES; // waves per k_walk workgroup
 
 __host__ __device__ inline size_t walk_union_words(uint32_t qcap, uint32_t pcap) { return 2 * (size_t)qcap + 3 * (size_t)pcap; }
-constexpr uint32_t WALK_TOPIC_WORDS = 9 * 64; // per-topic arrays, behind the union
+constexpr uint32_t WALK_TOPIC_WORDS = 8 * 64; // per-topic arrays, behind the union
 __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
     return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + WALK_TOPIC_WORDS + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
 }
@@ -375,8 +375,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     uint32_t* tmeta = un + walk_union_words(a.qcap, a.pcap);  // [64]
     uint32_t* cnt_pairs = tmeta + 64;                         // [64]
     uint32_t* cnt_routes = cnt_pairs + 64;                    // [64]
-    uint32_t* cnt_visit = cnt_routes + 64;                    // [64]
-    uint32_t* cursor = cnt_visit + 64;                        // [64]
+    uint32_t* cursor = cnt_routes + 64;                       // [64]
     uint2* t_region = reinterpret_cast<uint2*>(cursor + 64);  // [64] (region base, buckets) of each topic's tenant
     uint2* t_ids = t_region + 64;                             // [64] (route id base, route_pos base)
     const uint32_t stage_bytes = (uint32_t)(walk_union_words(a.qcap, a.pcap) + WALK_TOPIC_WORDS) * 4u;
@@ -443,7 +442,6 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u) | (active ? TM_ACTIVE : 0u);
     cnt_pairs[lane] = 0;
     cnt_routes[lane] = 0;
-    cnt_visit[lane] = 0;
     t_region[lane] = make_uint2(rg.base, rg.buckets);
     t_ids[lane] = make_uint2(rg.rank_base, rg.rp_base);
 
@@ -453,7 +451,9 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     // Neither LDS list bounds the walk: a full range buffer is flushed to, and a full stack parked in, the global spill
     // area, as chunks {header record, payload records}; the header links to the wave's previous chunk of the same kind
     // (base, length; length 0 ends the chain), so the bookkeeping is two wave-uniform registers per chain.
-    uint32_t tail = 0, pcount = 0, rounds = 0, items = 0;
+    // Only topics with more than FAST_LEVELS levels are flagged (TM_FLAG, set above) and they never enter the stack: every
+    // item popped below belongs to a live topic, and a lane may count the nodes it discovers in a register.
+    uint32_t tail = 0, pcount = 0, rounds = 0, items = 0, my_visits = 0;
     uint32_t fl_base = 0, fl_len = 0; // last flushed range chunk
     uint32_t qs_base = 0, qs_len = 0; // last parked stack chunk (LIFO)
     auto spill_alloc = [&](uint32_t n, uint32_t& base) -> bool { // wave-uniform; n payload records + header
@@ -500,14 +500,14 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
             tail -= take;
             rounds++;
             items += take;
-            uint32_t node = 0, meta = 0, tmv = TM_FLAG;
-            if (lane < take) {
+            const bool live = lane < take;
+            uint32_t node = 0, meta = 0, tmv = 0;
+            if (live) {
                 node = q_node[tail + lane];
                 meta = q_meta[tail + lane];
                 tmv = tmeta[meta & 63u];
             }
             tl = meta & 63u;
-            const bool live = !(tmv & TM_FLAG);
             const bool kh = (meta & KIND_H) != 0;
             uint2 reg = make_uint2(0u, 1u);
             uint32_t tok = 0;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
             const uint32_t tlc = tl;
             resolve_item(a.ix, ln, live, kh, node, tok, bk, reg.x, reg.y, meta_level(meta), tmv & 0xFFu, (tmv & TM_SYS) != 0,
                          [&](uint32_t l) { return tokens[l * 64 + tlc]; }, o);
-            if (o.found) atomicAdd(&cnt_visit[tl], 1u); // per topic: a flagged topic is recounted by the slow path
+            my_visits += o.found ? 1u : 0u;
         }
         const unsigned long long m_own = __ballot(o.emit_own), m_hash = __ballot(o.emit_hash);
         const unsigned long long m_l = __ballot(o.push_l), m_h = __ballot(o.push_h);
@@ -598,7 +598,6 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     const bool flagged = (tm & TM_FLAG) != 0;
     const uint32_t np = flagged ? 0u : cnt_pairs[lane];
     const uint32_t nr = flagged ? 0u : cnt_routes[lane];
-    const uint32_t visits = flagged ? 0u : cnt_visit[lane];
     uint32_t total_pairs;
     const uint32_t excl = wave_excl_scan(np, lane, total_pairs);
     unsigned long long base = 0;
@@ -616,7 +615,6 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
         auto copy_chunk = [&](uint32_t cb, uint32_t cl) {
             for (uint32_t i = lane; i < cl; i += 64) {
                 const uint4 r = a.spill[cb + 1 + i];
-                if (tmeta[r.z] & TM_FLAG) continue;
                 const uint32_t dst = atomicAdd(&cursor[r.z], 1u);
                 a.pairs[base + dst] = MatchRange{r.x, r.y};
             }
@@ -639,7 +637,6 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
         }
         for (uint32_t i = lane; i < pcount; i += 64) {
             const uint32_t tl = p_topic[i];
-            if (tmeta[tl] & TM_FLAG) continue;
             const uint32_t dst = atomicAdd(&cursor[tl], 1u);
             a.pairs[base + dst] = MatchRange{p_begin[i], p_count[i]};
         }
@@ -655,7 +652,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
         }
     }
     const unsigned long long wsum = wave_sum_u64(nr);
-    const unsigned long long wvis = wave_sum_u64(visits);
+    const unsigned long long wvis = wave_sum_u64(my_visits);
     const unsigned long long wbytes = wave_sum_u64(tbytes);
     if (lane == 0) {
         a.wave_sums[blk] = wsum;
