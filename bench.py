@@ -266,6 +266,14 @@ def main():
                                  "max_topics_per_launch": int(bs.max_batch_topics), "ids_returned": int(cnt.sum()),
                                  "note": "bmq_batcher_match_all, blocking callers: a launch holds at most one topic per thread"}
         bt.close()
+        bt = eng.batcher()  # asynchronous side: 4 submitting threads, nobody blocks on the GPU
+        cnt2, hsh2, sec2 = bt.drive_singletons(w.tenants(), htt[:m], sub, 4, asynchronous=True)
+        bs = bt.stats()
+        out["batching_front"]["async_submit"] = {"threads": 4, "calls_per_s": m / sec2, "launches": int(bs.n_batches),
+                                                 "mean_topics_per_launch": bs.n_topics / max(1, bs.n_batches),
+                                                 "max_topics_per_launch": int(bs.max_batch_topics),
+                                                 "rows_equal_blocking_path": bool((cnt2 == cnt).all() and (hsh2 == hsh).all())}
+        bt.close()
     if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n)
     if dist is not None:

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "bmq_match_finish", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_retain_rebuild", "bmq_retain_apply", "bmq_retain_topic",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
-    "bmq_batcher_match_all", "bmq_batcher_stats_get",
+    "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get",
 ]
 
 
@@ -104,6 +104,7 @@ def lib() -> C.CDLL:
             "bmq_batcher_create": (C.c_int, [vp, P(BatcherConfig), P(vp)]),
             "bmq_batcher_destroy": (None, [vp]),
             "bmq_batcher_match_all": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, vp, vp, u64, P(u64), P(u64)]),
+            "bmq_batcher_submit": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32, vp, vp]),
             "bmq_batcher_stats_get": (C.c_int, [vp, P(BatcherStats)]),
         }
         assert sorted(sig) == sorted(ABI_SYMBOLS)
@@ -133,6 +134,7 @@ def gen() -> C.CDLL:
             "bmqgen_retain": (u32, [vp, u64, u32, C.c_int]),
             "bmqgen_drive_singletons": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, vp, vp, C.POINTER(C.c_double)]),
             "bmqgen_row_hash": (u64, [vp, u64]),
+            "bmqgen_drive_async": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, vp, vp, C.POINTER(C.c_double)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(G, name)

@@ -380,4 +380,60 @@ int bmqgen_drive_singletons(void* fn, void* batcher, const uint8_t* tenants, con
     return err.load();
 }
 
+// ---- the same for the asynchronous side (bmq_batcher_submit): n_threads threads submit every topic once, as fast as the batcher
+// takes them; the callback records count + row hash; returns when every callback has run.
+typedef void (*batcher_cb)(void*, int, const uint32_t*, uint32_t, uint64_t);
+typedef int (*submit_fn)(void*, const uint8_t*, uint32_t, const uint8_t*, uint32_t, batcher_cb, void*);
+struct AsyncCtx {
+    uint32_t* out_count;
+    uint64_t* out_hash;
+    std::atomic<uint32_t> done{0};
+    std::atomic<int> err{0};
+};
+struct AsyncReq {
+    AsyncCtx* ctx;
+    uint32_t i;
+};
+static void drive_cb(void* user, int status, const uint32_t* ids, uint32_t n, uint64_t) {
+    AsyncReq* r = (AsyncReq*)user;
+    if (status) r->ctx->err = status;
+    else {
+        r->ctx->out_count[r->i] = n;
+        r->ctx->out_hash[r->i] = bmqgen_row_hash(ids, n);
+    }
+    r->ctx->done.fetch_add(1);
+}
+int bmqgen_drive_async(void* fn, void* batcher, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                       const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
+                       uint32_t n_threads, uint32_t* out_count, uint64_t* out_hash, double* out_seconds) {
+    if (!fn || !batcher || !n_threads) return -1;
+    const submit_fn submit = (submit_fn)fn;
+    AsyncCtx ctx;
+    ctx.out_count = out_count;
+    ctx.out_hash = out_hash;
+    std::vector<AsyncReq> reqs(n_topics);
+    std::atomic<uint32_t> submitted{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (uint32_t w = 0; w < n_threads; w++)
+        th.emplace_back([&, w] {
+            for (uint32_t i = w; i < n_topics && !ctx.err.load(); i += n_threads) {
+                const uint32_t ti = topic_tenant[i];
+                reqs[i] = AsyncReq{&ctx, i};
+                const int rc = ti < n_tenants ? submit(batcher, tenants + tenant_off[ti], tenant_off[ti + 1] - tenant_off[ti],
+                                                        topics + topic_off[i], topic_off[i + 1] - topic_off[i], drive_cb, &reqs[i])
+                                              : -1;
+                if (rc) {
+                    ctx.err = rc;
+                    break;
+                }
+                submitted.fetch_add(1);
+            }
+        });
+    for (auto& t : th) t.join();
+    while (ctx.done.load() < submitted.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return ctx.err.load();
+}
+
 } // extern "C"

@@ -369,9 +369,33 @@ class Batcher:
             raise BmqError(rc, "bmq_batcher_stats_get")
         return st
 
+    CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64)
+
+    def submit(self, tenant, topic, on_done):
+        """bmq_batcher_submit: returns at once; on_done(status, ids list, epoch) runs on the batcher's dispatcher thread."""
+        t, p = _b(tenant), _b(topic)
+        if not hasattr(self, "_live"):
+            self._live, self._seq = {}, 0
+        self._seq += 1
+        key = self._seq
+
+        def tramp(_user, status, ids, n, epoch):
+            try:
+                on_done(status, [ids[i] for i in range(n)], epoch)
+            finally:
+                self._live.pop(key, None)
+
+        cb = Batcher.CALLBACK(tramp)
+        self._live[key] = cb  # keeps the trampoline alive until it has run
+        rc = _lib.lib().bmq_batcher_submit(self.h, t, len(t), p, len(p), C.cast(cb, C.c_void_p), None)
+        if rc:
+            self._live.pop(key, None)
+            raise BmqError(rc, "bmq_batcher_submit")
+
     def drive_singletons(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed: Tuple[np.ndarray, np.ndarray],
-                         n_threads: int):
-        """n_threads native threads issue one single-topic call per topic (the production call pattern).
+                         n_threads: int, asynchronous: bool = False):
+        """n_threads native threads issue one single-topic call per topic (the production call pattern), blocking
+        (bmq_batcher_match_all) or asynchronous (bmq_batcher_submit + callback).
         -> (ids per topic, row hash per topic, seconds)"""
         tdata, toff = pack(tenants)
         pdata, poff = topics_packed
@@ -379,9 +403,10 @@ class Batcher:
         cnt = np.zeros(n, dtype=np.uint32)
         hsh = np.zeros(n, dtype=np.uint64)
         sec = C.c_double()
-        fn = C.cast(_lib.lib().bmq_batcher_match_all, C.c_void_p)
+        fn = C.cast(_lib.lib().bmq_batcher_submit if asynchronous else _lib.lib().bmq_batcher_match_all, C.c_void_p)
         tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
-        rc = _lib.gen().bmqgen_drive_singletons(fn, self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(tt), _ptr(pdata), _ptr(poff),
+        drive = _lib.gen().bmqgen_drive_async if asynchronous else _lib.gen().bmqgen_drive_singletons
+        rc = drive(fn, self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(tt), _ptr(pdata), _ptr(poff),
                                                 n, n_threads, _ptr(cnt), _ptr(hsh), C.byref(sec))
         if rc:
             raise BmqError(rc, "bmqgen_drive_singletons")

@@ -167,6 +167,15 @@ void bmq_batcher_destroy(bmq_batcher* b);
 int bmq_batcher_match_all(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics,
                           const uint32_t* topic_off, uint32_t n_topics, uint32_t* out_row_ptr,
                           uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed, uint64_t* out_epoch);
+/* Asynchronous form for loaders that return a future (Caffeine's AsyncCache in TenantRouteCache.java:116-139): the topic is
+ * copied and packed into the batch being collected and the call returns at once; a dispatcher thread owned by the batcher
+ * (started by the first submit) matches whatever has been collected whenever the engine is free and then calls
+ * cb(user, status, ids, n_ids, epoch) once per request, on the dispatcher thread, in submission order.  `ids` is only
+ * valid during the callback.  A submitter blocks only while max_batch_topics requests are already waiting.
+ * bmq_batcher_destroy matches and calls back everything submitted before it. */
+typedef void (*bmq_batcher_cb)(void* user, int status, const uint32_t* route_ids, uint32_t n_ids, uint64_t epoch);
+int bmq_batcher_submit(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len,
+                       bmq_batcher_cb cb, void* user);
 int bmq_batcher_stats_get(bmq_batcher* b, bmq_batcher_stats* out);
 
 /* ---- host-side mirror of MatchedRoutes (fan-out caps in KV order) -------------------------------------- */

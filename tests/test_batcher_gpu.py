@@ -62,6 +62,43 @@ def test_many_native_threads_singleton_calls(setup):
     b.close()
 
 
+def test_async_submit_native_threads(setup):
+    """bmq_batcher_submit: nobody blocks on the GPU, a dispatcher thread matches whatever has been collected; every
+    callback must deliver exactly the oracle's row, and batches are far larger than the number of submitting threads."""
+    eng, tn, tt, packed, topics, exp = setup
+    b = eng.batcher()
+    cnt, hsh, sec = b.drive_singletons(tn, tt, packed, n_threads=4, asynchronous=True)
+    assert cnt.tolist() == [len(r) for r in exp]
+    assert hsh.tolist() == [_row_hash(r) for r in exp]
+    st = b.stats()
+    assert st.n_requests == len(topics) and st.n_batches < len(topics) // 8 and st.max_batch_topics > 4
+    b.close()
+
+
+def test_async_submit_python_callbacks_and_drain_on_close(setup):
+    eng, tn, tt, _, topics, exp = setup
+    b = eng.batcher(max_batch_topics=16)  # small batches: submitters feel the back-pressure
+    got = {}
+    done = threading.Event()
+    n = 300
+
+    def on_done_for(i):
+        def f(status, ids, epoch):
+            got[i] = (status, ids, epoch)
+            if len(got) == n:
+                done.set()
+        return f
+
+    for i in range(n):
+        b.submit(tn[tt[i]], topics[i], on_done_for(i))
+    b.close()  # matches and calls back everything submitted before it
+    assert done.is_set() and len(got) == n
+    ep = eng.info().epoch
+    assert all(got[i] == (0, exp[i], ep) for i in range(n))
+    with pytest.raises(Exception):
+        b.submit(tn[0], "a", lambda *a: None)
+
+
 def test_python_threads_while_routes_change(setup):
     """Callers keep matching while the apply thread mutates routes (DistWorkerCoProc.java:188-209): rows always belong to
     ONE epoch -- the one reported with them -- because batch and epoch are read under one hold of the engine lock."""
