@@ -190,7 +190,7 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
         for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[pool_off + i] == byte_at(start + i);
         return eq;
     };
-    for (;;) {
+    for (uint32_t probes = 0; probes <= ix.dict_group_mask; probes++) { // bounded: a damaged table must not hang the GPU
         Line64 ln;
         load_line64(ix.dict + DICT_GROUP * (size_t)g, ln);
         const bool h0 = ln.a0.x == tag && ln.a0.z == len && ln.a1.x == inl[0] && ln.a1.y == inl[1] && ln.a1.z == inl[2] &&
@@ -202,6 +202,7 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
         if (ln.a0.x == 0 || ln.b0.x == 0) return TOK_UNKNOWN;
         g = (g + 1) & ix.dict_group_mask;
     }
+    return TOK_UNKNOWN;
 }
 
 // Scans one level starting at pos: bytes up to the next '/' (split) or to `end`, FOUR BYTES PER STEP.
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
     TenantSlot info = EMPTY_TENANT;
     if (tok != TOK_UNKNOWN) {
         uint32_t d = tenant_hash(tok) & a.ix.tenant_mask;
-        for (;;) {
+        for (uint32_t probes = 0; probes <= a.ix.tenant_mask; probes++) {
             const TenantSlot t = a.ix.tenants[d];
             if (t.token == tok) {
                 info = t;
@@ -311,7 +312,9 @@ __device__ __forceinline__ void resolve_item(const DistIndexView& ix, Line64 ln,
     bool m0 = kind_h ? ((node & 1u) == 0) : (ln.a0.x == node && ln.a0.y == tok);
     bool m1 = kind_h ? ((node & 1u) != 0) : (ln.b0.x == node && ln.b0.y == tok);
     bool more = live && !m0 && !m1 && ln.a0.x != NONE && ln.b0.x != NONE;
-    while (more) { // home bucket full of other edges (rare at load factor 1/2): first-free probing continues
+    // home bucket full of other edges (rare at load factor 1/2): first-free probing continues.  Bounded by the region size so
+    // that not even a damaged image can hang the GPU.
+    for (uint32_t probes = 1; more && probes < rbuckets; probes++) {
         bk = (bk + 1 == rbuckets) ? 0 : bk + 1;
         load_line64(ix.trie + rbase + 2 * bk, ln);
         m0 = ln.a0.x == node && ln.a0.y == tok;

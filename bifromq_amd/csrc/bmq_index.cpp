@@ -547,7 +547,9 @@ bool DistIndexHost::refresh(std::vector<TenantState*>& touched) {
     pt.lap("  intern + allocate");
     if (next_free > trie.size()) { // the device table must grow: everything is re-uploaded (slots outside the regions
         // are never read, so plain zero fill is enough; place_tenant initialises every region it owns)
-        const size_t keep = full_upload ? 0 : trie.size(); // a from-scratch build rewrites every region anyway
+        // the regions of the tenants this call does not touch must survive (after rebuild() the table is empty: nothing to
+        // copy).  Not tied to full_upload: that flag is only reset by an upload, which a host-only engine never does.
+        const size_t keep = trie.size();
         if (!trie.grow(std::max<size_t>((size_t)next_free + next_free / 4, 64), keep)) {
             error = "out of host memory";
             return false;
@@ -611,7 +613,7 @@ std::string_view DistIndexHost::route_key(uint32_t id) const {
 
 uint32_t DistIndexHost::find_child(const TenantState& t, uint32_t parent_rel, uint32_t token) const {
     uint32_t bk = edge_bucket(parent_rel, token, t.buckets);
-    for (;;) {
+    for (uint32_t probes = 0; probes < t.buckets; probes++) {
         bool full = true;
         for (uint32_t j = 0; j < 2; j++) {
             const TrieSlot& s = trie[t.base + 2 * bk + j];
@@ -621,6 +623,7 @@ uint32_t DistIndexHost::find_child(const TenantState& t, uint32_t parent_rel, ui
         if (!full) return NONE;
         bk = (bk + 1 == t.buckets) ? 0 : bk + 1;
     }
+    return NONE;
 }
 
 std::vector<uint32_t> DistIndexHost::find_filter(std::string_view tenant, std::string_view filter) const {

@@ -53,7 +53,7 @@ struct Frontier {
 __device__ __forceinline__ uint32_t redge_lookup(const RetainIndexView& ix, uint32_t edge_base, uint32_t mask, uint32_t parent,
                                                  uint32_t token) {
     uint32_t bk = redge_bucket(parent, token, mask);
-    for (;;) {
+    for (uint32_t probes = 0; probes <= mask; probes++) { // bounded: a damaged table must not hang the GPU
         Line64 ln; // the whole bucket in one request (see load_line64)
         load_line64(ix.edges + edge_base + 4 * (size_t)bk, ln);
         const uint4 e0 = ln.a0, e1 = ln.a1, e2 = ln.b0, e3 = ln.b1;
@@ -64,6 +64,7 @@ __device__ __forceinline__ uint32_t redge_lookup(const RetainIndexView& ix, uint
         if (e0.x == NONE || e1.x == NONE || e2.x == NONE || e3.x == NONE) return NONE;
         bk = (bk + 1) & mask;
     }
+    return NONE;
 }
 __device__ __forceinline__ RNode load_rnode(const RetainIndexView& ix, uint32_t i) {
     const uint4 v = *reinterpret_cast<const uint4*>(ix.nodes + i);
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                 uint32_t root = NONE;
                 if (tok != TOK_UNKNOWN) {
                     uint32_t d = tenant_hash(tok) & r.ix.tenant_mask;
-                    for (;;) {
+                    for (uint32_t probes = 0; probes <= r.ix.tenant_mask; probes++) {
                         const uint4* p = reinterpret_cast<const uint4*>(r.ix.tenants + d);
                         const uint4 t0 = p[0];
                         if (t0.x == tok) {

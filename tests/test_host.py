@@ -132,3 +132,17 @@ def test_hash_sharded_workloads_partition_the_population():
         _, _, tt = w.topics(3, 50)
         assert len(mine) == 0 or tt.max() < len(mine)
     assert union == full and total == len(full)
+
+
+def test_host_index_fuzz_under_sanitizers():
+    """tools/host_fuzz.cpp: random rebuild / incremental-apply sequences on the host index, built with ASan + UBSan; after every
+    step ids must be the ranks of a std::set model and a CPU walk over the HBM image (directory, regions, dictionary, exactly
+    the probes k_walk does) must give the brute-force result of the matching rule for random topics.  Seed 9 is the sequence
+    that exposed the loss of untouched regions when the table grew during an apply on an engine that never uploads."""
+    import subprocess
+    csrc = os.path.join(ROOT, "bifromq_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "fuzz"], check=True, capture_output=True, timeout=600)
+    exe = os.path.join(ROOT, "tools", "host_fuzz")
+    for seed, rounds in ((1, 15), (9, 58)):
+        r = subprocess.run([exe, str(seed), str(rounds)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "host_fuzz ok" in r.stdout, r.stdout + r.stderr
