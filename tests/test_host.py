@@ -146,3 +146,8 @@ def test_host_index_fuzz_under_sanitizers():
     for seed, rounds in ((1, 15), (9, 58)):
         r = subprocess.run([exe, str(seed), str(rounds)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "host_fuzz ok" in r.stdout, r.stdout + r.stderr
+    # the retain direction's host index (tools/retain_fuzz.cpp): per-tenant add/remove, segment growth, '$' runs
+    exe = os.path.join(ROOT, "tools", "retain_fuzz")
+    for seed, rounds in ((1, 25), (7, 25)):
+        r = subprocess.run([exe, str(seed), str(rounds)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "retain_fuzz ok" in r.stdout, r.stdout + r.stderr
