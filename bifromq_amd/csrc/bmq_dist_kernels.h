@@ -154,11 +154,6 @@ __device__ __forceinline__ TrieSlot unpack_slot(const uint4& a, const uint4& b) 
     s.hash_begin = b.x; s.hash_count = b.y; s.plus_child = b.z; s.lit_bloom = b.w;
     return s;
 }
-__device__ __forceinline__ TrieSlot load_slot(const TrieSlot* trie, uint32_t idx) {
-    const uint4* p = reinterpret_cast<const uint4*>(trie + idx);
-    const uint4 a = p[0], b = p[1];
-    return unpack_slot(a, b);
-}
 // One aligned 64-byte line = one trie bucket (two TrieSlots) or one dictionary group (two DictSlots), requested with
 // four 16-byte loads issued back to back and ONE wait.  Written as asm because the compiler otherwise splits the
 // line into dependent pieces (first the 8 key bytes of slot 0, wait, then those of slot 1, wait, then the payload):
@@ -349,8 +344,8 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantS
 // ------------------------------------------------------------------------------------------------------------
 // k_walk -- one wave (= one 64-thread workgroup) per 64 topics
 // ------------------------------------------------------------------------------------------------------------
-// tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (more than FAST_LEVELS levels -> slow path), 10 active
-constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9, TM_ACTIVE = 1u << 10;
+// tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (more than FAST_LEVELS levels -> slow path)
+constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9;
 #ifndef BMQ_WALK_WAVES
 #define BMQ_WALK_WAVES 2
 #endif
@@ -442,7 +437,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     const bool deep = nlev > FAST_LEVELS;
     const bool active = known && !deep;
     wave_sync(); // staged bytes are dead from here on: the area becomes stack + range buffer + per-topic arrays
-    tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u) | (active ? TM_ACTIVE : 0u);
+    tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u);
     cnt_pairs[lane] = 0;
     cnt_routes[lane] = 0;
     t_region[lane] = make_uint2(rg.base, rg.buckets);
@@ -836,7 +831,7 @@ __device__ __forceinline__ uint32_t range_first_id(const DistIndexView& ix, cons
 // lengths (a 5000-subscriber filter next to 60 singletons).
 __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
     __shared__ uint32_t s_begin[EXP_WAVES][EXP_K], s_cnt[EXP_WAVES][EXP_K], s_off[EXP_WAVES][EXP_K + 8], s_row[EXP_WAVES][EXP_K];
-    __shared__ uint32_t s_bad[EXP_WAVES][64], s_first[EXP_WAVES][64];
+    __shared__ uint32_t s_bad[EXP_WAVES][64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blk = blockIdx.x * EXP_WAVES + wave; // every wave owns one 64-row block and its own LDS slice
     if (blk >= a.n_blocks) return;
@@ -845,7 +840,6 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
     uint32_t* r_off = s_off[wave];
     uint32_t* r_row = s_row[wave];
     uint32_t* row_bad = s_bad[wave];
-    uint32_t* row_first = s_first[wave];
     const uint32_t t = blk * 64 + lane;
     const bool valid = t < a.n_topics;
     const uint32_t status = a.ctr->status;
@@ -880,7 +874,6 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
         }
     }
     row_bad[lane] = 0;
-    row_first[lane] = pexcl;
     wave_sync();
     unsigned long long out_done = 0; // output elements produced by earlier LDS passes
     uint32_t carry_row = 64, carry_last = 0;

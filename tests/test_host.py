@@ -151,3 +151,16 @@ def test_host_index_fuzz_under_sanitizers():
     for seed, rounds in ((1, 25), (7, 25)):
         r = subprocess.run([exe, str(seed), str(rounds)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "retain_fuzz ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_header_is_plain_c_and_usable_from_c(tmp_path):
+    """include/bmq.h is what a JNI/cgo binding compiles against: it must be valid C99 (-pedantic) and the host-side entry
+    points must work from a C program linked against libbmq.so (tests/c/abi_smoke.c; no GPU: host-only engine)."""
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "bifromq_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-L", libdir, "-lbmq", "-Wl,-rpath," + libdir],
+                   check=True, capture_output=True, timeout=120)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
