@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbmq.so")
+LIB_PATH = os.environ.get("BMQ_LIB") or os.path.join(_HERE, "libbmq.so")  # BMQ_LIB: build-variant experiments only
 GEN_PATH = os.path.join(_HERE, "libbmq_gen.so")
 CSRC = os.path.join(_HERE, "csrc")
 

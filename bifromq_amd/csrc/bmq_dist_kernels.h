@@ -347,7 +347,7 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantS
 // tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (more than FAST_LEVELS levels -> slow path)
 constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9;
 #ifndef BMQ_WALK_WAVES
-#define BMQ_WALK_WAVES 2
+#define BMQ_WALK_WAVES 1
 #endif
 constexpr uint32_t WALK_WAVES = BMQ_WALK_WAVES; // waves per k_walk workgroup
 
@@ -359,8 +359,9 @@ __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
 
 __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     extern __shared__ __align__(16) uint32_t lds_all[];
-    // WALK_WAVES independent waves per workgroup (a CU admits only ~8 workgroups, so single-wave groups would cap the CU at
-    // 8 waves); every wave owns its own slice of LDS and never synchronises with its neighbours
+    // WALK_WAVES independent waves per workgroup: every wave owns its own slice of LDS and never synchronises with its
+    // neighbours.  Measured on C3 (profiles/r01): 1 wave per workgroup 0.308 ms, 2 waves 0.317 ms, 4 waves 0.320 ms -- 16 waves
+    // per CU in all three (9.6 KB of LDS per wave), single-wave groups retire and refill a little faster.
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t* lds = lds_all + wave * (walk_lds_bytes(a.qcap, a.pcap) / 4);
     uint32_t* tokens = lds;                                   // [FAST_LEVELS][64]
@@ -817,8 +818,14 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
 // k_expand -- CSR row pointers + ids.  One wave per 64 topics (same blocking as k_walk).
 // ------------------------------------------------------------------------------------------------------------
 constexpr uint32_t SORT_PAIRS = 32;  // range lists up to this length are ordered in place (insertion sort)
-constexpr uint32_t EXP_K = 512;      // ranges laid out per LDS pass
-constexpr uint32_t EXP_WAVES = 4;    // independent waves per k_expand workgroup
+#ifndef BMQ_EXP_K
+#define BMQ_EXP_K 256 // measured: 256 -> k_expand 0.112 ms on C3, 512 -> 0.123 ms; C2 unchanged, C4 +5 %
+#endif
+#ifndef BMQ_EXP_WAVES
+#define BMQ_EXP_WAVES 4
+#endif
+constexpr uint32_t EXP_K = BMQ_EXP_K;         // ranges laid out per LDS pass
+constexpr uint32_t EXP_WAVES = BMQ_EXP_WAVES; // independent waves per k_expand workgroup
 constexpr uint32_t EXP_LONG = 64;    // ranges at least this long are streamed, shorter ones are flattened
 
 __device__ __forceinline__ uint32_t range_first_id(const DistIndexView& ix, const MatchRange& r) {
