@@ -426,19 +426,45 @@ bool DistIndexHost::rebuild(const uint8_t* keys, const uint32_t* key_off, uint32
     dict_changed = true;
     dirty.clear();
     PhaseTimer pt;
-    // split by tenant
-    std::map<std::string_view, std::vector<std::string_view>> per;
-    for (uint32_t i = 0; i < n; i++) {
-        const std::string_view k((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
-        RouteKeyParts kp;
-        if (!decode_route_key(k, kp)) {
-            error = "malformed route key at position " + std::to_string(i);
+    // split by tenant: decode in parallel chunks (each thread fills its own per-tenant lists), then concatenate per tenant;
+    // KeySet::assign sorts anyway, so the order inside a tenant's list does not matter
+    struct Chunk {
+        std::map<std::string_view, std::vector<std::string_view>> per;
+        uint32_t bad = 0xFFFFFFFFu;
+    };
+    uint32_t per_chunk = 4096; // BMQ_SPLIT_CHUNK: test knob (tools/host_fuzz runs with tiny chunks)
+    if (const char* v = getenv("BMQ_SPLIT_CHUNK")) per_chunk = (uint32_t)std::max(1, atoi(v));
+    const uint32_t n_chunks = std::max(1u, std::min(256u, n / per_chunk));
+    std::vector<Chunk> chunks(n_chunks);
+    parallel_for(n_chunks, [&](size_t c) {
+        Chunk& ch = chunks[c];
+        const uint32_t lo = (uint32_t)((uint64_t)n * c / n_chunks), hi = (uint32_t)((uint64_t)n * (c + 1) / n_chunks);
+        std::string_view last_tenant;
+        std::vector<std::string_view>* last_list = nullptr;
+        for (uint32_t i = lo; i < hi; i++) {
+            const std::string_view k((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
+            RouteKeyParts kp;
+            if (!decode_route_key(k, kp)) {
+                ch.bad = i;
+                return;
+            }
+            if (!last_list || kp.tenant != last_tenant) { // sorted input: long runs of one tenant
+                last_list = &ch.per[kp.tenant];
+                last_tenant = kp.tenant;
+            }
+            last_list->push_back(k);
+        }
+    });
+    std::map<std::string_view, std::vector<std::vector<std::string_view>*>> per; // tenant -> its lists in the chunks
+    for (auto& ch : chunks) {
+        if (ch.bad != 0xFFFFFFFFu) {
+            error = "malformed route key at position " + std::to_string(ch.bad);
             return false;
         }
-        per[kp.tenant].push_back(k);
+        for (auto& e : ch.per) per[e.first].push_back(&e.second);
     }
     std::vector<TenantState*> touched;
-    std::vector<std::vector<std::string_view>*> lists;
+    std::vector<std::vector<std::vector<std::string_view>*>*> lists;
     for (auto& e : per) {
         auto st = std::make_unique<TenantState>();
         st->name = std::string(e.first);
@@ -447,7 +473,18 @@ bool DistIndexHost::rebuild(const uint8_t* keys, const uint32_t* key_off, uint32
         by_name.emplace(st->name, std::move(st));
     }
     pt.lap("split keys by tenant");
-    parallel_for(touched.size(), [&](size_t i) { touched[i]->keys.assign(*lists[i]); });
+    parallel_for(touched.size(), [&](size_t i) {
+        std::vector<std::vector<std::string_view>*>& parts = *lists[i];
+        if (parts.size() == 1) touched[i]->keys.assign(*parts[0]);
+        else {
+            std::vector<std::string_view> all;
+            size_t total = 0;
+            for (auto* p : parts) total += p->size();
+            all.reserve(total);
+            for (auto* p : parts) all.insert(all.end(), p->begin(), p->end());
+            touched[i]->keys.assign(all);
+        }
+    });
     pt.lap("per-tenant key sets");
     return refresh(touched);
 }
