@@ -167,3 +167,16 @@ def test_header_is_plain_c_and_usable_from_c(tmp_path):
                    check=True, capture_output=True, timeout=120)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_batching_front_under_thread_sanitizer():
+    """tools/batcher_tsan.cpp: the batching front (bmq_batcher.inc) built with -fsanitize=thread against a stand-in engine whose
+    match is a pure function of (tenant, topic): 24 blocking callers, 4 submitting threads, an epoch-bumping mutator, three
+    max_batch settings, destroy while requests wait -- every caller must get exactly its own rows and TSan must stay silent."""
+    import subprocess
+    csrc = os.path.join(ROOT, "bifromq_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "tsan"], check=True, capture_output=True, timeout=600)
+    exe = os.path.join(ROOT, "tools", "batcher_tsan")
+    for _ in range(3):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "batcher_tsan ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr

@@ -1,0 +1,179 @@
+// batcher_tsan.cpp -- test tool, not product: the concurrency of the batching front (bifromq_amd/csrc/bmq_batcher.inc) under
+// ThreadSanitizer, without a GPU.  The engine is replaced by a stand-in whose "match" is a pure function of (tenant, topic), so
+// every caller can check that it received exactly its own rows, whatever batch they travelled in:
+//   * many threads in bmq_batcher_match_all (single topics and small sets, some with too small output buffers),
+//   * threads in bmq_batcher_submit with callbacks, back-pressure (tiny max_batch_topics),
+//   * an "apply" thread bumping the epoch under the engine lock, as bmq_routes_apply does,
+//   * bmq_batcher_destroy while submitted requests are still waiting (they must all be called back).
+// Build + run: make -C bifromq_amd/csrc tsan   (tests/test_host.py runs it)
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <vector>
+
+#include "../include/bmq.h"
+
+struct bmq_engine { // the members the batching front touches
+    std::recursive_mutex api;
+    uint64_t epoch = 1;
+    int device = 0;
+};
+
+static uint32_t fake_count(std::string_view tenant, std::string_view topic) { return (uint32_t)((tenant.size() * 7 + topic.size() * 3) % 6); }
+static uint32_t fake_id(std::string_view tenant, std::string_view topic, uint32_t k) {
+    uint32_t h = 2166136261u;
+    for (char c : tenant) h = (h ^ (uint8_t)c) * 16777619u;
+    for (char c : topic) h = (h ^ (uint8_t)c) * 16777619u;
+    return h % 1000003u + k;
+}
+static std::atomic<uint64_t> g_batches{0};
+
+extern "C" int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                               const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
+                               uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed) {
+    std::unique_lock<std::recursive_mutex> lk(e->api);
+    g_batches++;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_topics; i++) {
+        if (topic_tenant[i] >= n_tenants) return BMQ_E_INVAL;
+        const std::string_view tn((const char*)tenants + tenant_off[topic_tenant[i]], tenant_off[topic_tenant[i] + 1] - tenant_off[topic_tenant[i]]);
+        const std::string_view tp((const char*)topics + topic_off[i], topic_off[i + 1] - topic_off[i]);
+        out_row_ptr[i] = (uint32_t)total;
+        total += fake_count(tn, tp);
+    }
+    out_row_ptr[n_topics] = (uint32_t)total;
+    *out_needed = total;
+    if (total > out_capacity) return BMQ_E_NOSPACE;
+    std::this_thread::sleep_for(std::chrono::microseconds(30)); // a launch takes a while: requests pile up meanwhile
+    for (uint32_t i = 0; i < n_topics; i++) {
+        const std::string_view tn((const char*)tenants + tenant_off[topic_tenant[i]], tenant_off[topic_tenant[i] + 1] - tenant_off[topic_tenant[i]]);
+        const std::string_view tp((const char*)topics + topic_off[i], topic_off[i + 1] - topic_off[i]);
+        for (uint32_t k = 0; k < out_row_ptr[i + 1] - out_row_ptr[i]; k++) out_route_ids[out_row_ptr[i] + k] = fake_id(tn, tp, k);
+    }
+    return BMQ_OK;
+}
+
+#include "../bifromq_amd/csrc/bmq_batcher.inc"
+
+static std::atomic<int> g_fail{0};
+#define EXPECT(c)                                                     \
+    do {                                                              \
+        if (!(c)) {                                                   \
+            fprintf(stderr, "batcher_tsan: %s (line %d)\n", #c, __LINE__); \
+            g_fail++;                                                 \
+        }                                                             \
+    } while (0)
+
+struct CbCtx {
+    std::string tenant, topic;
+    std::atomic<int>* done;
+};
+static void on_done(void* user, int status, const uint32_t* ids, uint32_t n, uint64_t epoch) {
+    CbCtx* c = (CbCtx*)user;
+    EXPECT(status == BMQ_OK && epoch >= 1);
+    EXPECT(n == fake_count(c->tenant, c->topic));
+    for (uint32_t k = 0; k < n && status == BMQ_OK; k++) EXPECT(ids[k] == fake_id(c->tenant, c->topic, k));
+    c->done->fetch_add(1);
+}
+
+int main() {
+    bmq_engine eng;
+    const char* tenants[] = {"t", "tenantB", "x-long-tenant"};
+    for (int pass = 0; pass < 3; pass++) {
+        bmq_batcher_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.struct_size = sizeof cfg;
+        cfg.max_batch_topics = pass == 0 ? 0 : (pass == 1 ? 5 : 64);
+        bmq_batcher* b = nullptr;
+        EXPECT(bmq_batcher_create(&eng, &cfg, &b) == BMQ_OK && b);
+        std::atomic<bool> stop{false};
+        std::thread mutator([&] { // bmq_routes_apply: takes the engine lock, bumps the epoch
+            while (!stop.load()) {
+                {
+                    std::unique_lock<std::recursive_mutex> lk(eng.api);
+                    eng.epoch++;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        });
+        std::vector<std::thread> th;
+        for (int w = 0; w < 24; w++)
+            th.emplace_back([&, w] {
+                std::mt19937 rng(1000 * pass + w);
+                for (int it = 0; it < 150; it++) {
+                    const std::string tn = tenants[rng() % 3];
+                    const uint32_t nt = 1 + (rng() % 8 == 0 ? rng() % 6 : 0);
+                    std::string bytes;
+                    std::vector<uint32_t> off{0};
+                    std::vector<std::string> tps;
+                    for (uint32_t i = 0; i < nt; i++) {
+                        std::string tp = "a/" + std::to_string(rng() % 50) + std::string(rng() % 7, 'z');
+                        bytes += tp;
+                        off.push_back((uint32_t)bytes.size());
+                        tps.push_back(tp);
+                    }
+                    std::vector<uint32_t> row(nt + 1), ids(rng() % 5 == 0 ? 1 : 64);
+                    uint64_t need = 0, epoch = 0;
+                    int rc = bmq_batcher_match_all(b, (const uint8_t*)tn.data(), (uint32_t)tn.size(), (const uint8_t*)bytes.data(), off.data(), nt, row.data(),
+                                                   ids.data(), ids.size(), &need, &epoch);
+                    uint64_t want = 0;
+                    for (auto& tp : tps) want += fake_count(tn, tp);
+                    EXPECT(need == want && epoch >= 1);
+                    if (want > ids.size()) EXPECT(rc == BMQ_E_NOSPACE);
+                    else {
+                        EXPECT(rc == BMQ_OK);
+                        for (uint32_t i = 0; i < nt && rc == BMQ_OK; i++) {
+                            EXPECT(row[i + 1] - row[i] == fake_count(tn, tps[i]));
+                            for (uint32_t k = 0; k < row[i + 1] - row[i]; k++) EXPECT(ids[row[i] + k] == fake_id(tn, tps[i], k));
+                        }
+                    }
+                }
+            });
+        std::atomic<int> done{0};
+        std::vector<std::unique_ptr<CbCtx>> ctxs;
+        std::mutex cm;
+        std::atomic<int> submitted{0};
+        for (int w = 0; w < 4; w++)
+            th.emplace_back([&, w] {
+                std::mt19937 rng(77 * pass + w);
+                for (int it = 0; it < 400; it++) {
+                    auto c = std::make_unique<CbCtx>();
+                    c->tenant = tenants[rng() % 3];
+                    c->topic = "s/" + std::to_string(rng() % 1000);
+                    c->done = &done;
+                    CbCtx* raw = c.get();
+                    {
+                        std::lock_guard<std::mutex> g(cm);
+                        ctxs.push_back(std::move(c));
+                    }
+                    EXPECT(bmq_batcher_submit(b, (const uint8_t*)raw->tenant.data(), (uint32_t)raw->tenant.size(), (const uint8_t*)raw->topic.data(),
+                                              (uint32_t)raw->topic.size(), on_done, raw) == BMQ_OK);
+                    submitted++;
+                }
+            });
+        for (auto& t : th) t.join();
+        stop = true;
+        mutator.join();
+        bmq_batcher_stats st;
+        EXPECT(bmq_batcher_stats_get(b, &st) == BMQ_OK && st.n_requests >= 24 * 150);
+        if (cfg.max_batch_topics) EXPECT(st.max_batch_topics <= std::max<uint64_t>(cfg.max_batch_topics, 6));
+        bmq_batcher_destroy(b); // drains the asynchronous side: every submitted request has been called back when it returns
+        EXPECT(done.load() == submitted.load() && submitted.load() == 1600);
+    }
+    if (g_fail.load()) {
+        fprintf(stderr, "batcher_tsan: %d failures\n", g_fail.load());
+        return 1;
+    }
+    printf("batcher_tsan ok: %llu fake launches\n", (unsigned long long)g_batches.load());
+    return 0;
+}
