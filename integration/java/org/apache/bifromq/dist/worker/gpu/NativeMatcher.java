@@ -1,0 +1,64 @@
+/*
+ * Java face of libbmq.so (include/bmq.h) through integration/jni/bmq_jni.c.
+ * NOT compiled in this repository (its build image has no JDK); it is the file a bifromq maintainer adds next to
+ * bifromq-dist-worker's cache package.  All buffers are DIRECT and in native byte order.
+ */
+package org.apache.bifromq.dist.worker.gpu;
+
+import java.nio.ByteBuffer;
+import java.nio.IntBuffer;
+
+final class NativeMatcher {
+    static {
+        System.loadLibrary("bmq_jni"); // links against libbmq.so
+    }
+
+    private NativeMatcher() {
+    }
+
+    // ---- engine ----
+    static native long create(int device);
+
+    static native void destroy(long engine);
+
+    /** IKVRangeCoProc.reset(): all route keys of the range, in any order (ids become the ranks in KV key order). */
+    static native void rebuild(long engine, ByteBuffer keys, IntBuffer keyOff, int n);
+
+    /** Post-commit AddRoutesTask / RemoveRoutesTask: ops[i] 0 = put, 1 = delete; applied in order. */
+    static native void routesApply(long engine, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n);
+
+    static native long epoch(long engine);
+
+    /** @return key length, or -(needed) when out is too small */
+    static native int routeKey(long engine, int routeId, ByteBuffer out);
+
+    // ---- dist direction ----
+    /** @return number of ids, or -(needed) when outIds is too small */
+    static native long matchBatch(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant,
+                                  ByteBuffer topics, IntBuffer topicOff, int nTopics, IntBuffer outRowPtr, IntBuffer outIds);
+
+    static native long matchAll(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, int nTopics,
+                                int maxPersistentFanout, int maxGroupFanout, IntBuffer outRowPtr, IntBuffer outIds,
+                                IntBuffer outEvents, long[] nEventsOut);
+
+    // ---- batching front ----
+    static native long batcherCreate(long engine, int maxBatchTopics);
+
+    static native void batcherDestroy(long batcher);
+
+    /** Blocks until the launch that carries these topics has finished; epochOut[0] = epoch the ids are ranks of. */
+    static native long batcherMatchAll(long batcher, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, int nTopics,
+                                       IntBuffer outRowPtr, IntBuffer outIds, long[] epochOut);
+
+    // ---- retain direction ----
+    static native void retainRebuild(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant,
+                                     ByteBuffer topics, IntBuffer topicOff, int nTopics);
+
+    static native void retainApply(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, ByteBuffer ops, int n);
+
+    static native long retainMatchLimited(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants,
+                                          IntBuffer filterTenant, ByteBuffer filters, IntBuffer filterOff, int nFilters,
+                                          IntBuffer limits, IntBuffer outRowPtr, IntBuffer outTopicIds, IntBuffer outCounts);
+
+    static native int retainTopic(long engine, int topicId, ByteBuffer out, long[] tenantLenOut);
+}

@@ -1,0 +1,213 @@
+/* bmq_jni.c -- the JNI binding a bifromq maintainer adds to put libbmq.so behind the dist worker's match path
+ * (INTEGRATION.md).  Java side: integration/java/org/apache/bifromq/dist/worker/gpu/NativeMatcher.java.
+ *
+ * Conventions: every buffer is a DIRECT ByteBuffer / IntBuffer in native byte order (zero copy, GetDirectBufferAddress);
+ * tenant ids travel as byte[] (short, copied).  A method returning "long" gives the number of ids written, or -(needed) when
+ * the output buffer is too small (the caller grows it and calls again); any other failure throws IllegalStateException with
+ * bmq_last_error().  No JDK exists in this repository's build image: the file is compile-checked against jni_min.h. */
+#ifdef BMQ_REAL_JNI
+#include <jni.h>
+#else
+#include "jni_min.h"
+#endif
+#include <stdint.h>
+#include <stdio.h>
+
+#include "bmq.h"
+
+#define ENGINE(h) ((bmq_engine*)(intptr_t)(h))
+#define BATCHER(h) ((bmq_batcher*)(intptr_t)(h))
+#define ADDR(o) ((o) ? (*env)->GetDirectBufferAddress(env, (o)) : NULL)
+#define CAP(o) ((o) ? (uint64_t)(*env)->GetDirectBufferCapacity(env, (o)) : 0u)
+#define NM(name) Java_org_apache_bifromq_dist_worker_gpu_NativeMatcher_##name
+
+static void throw_state(JNIEnv* env, bmq_engine* e, const char* what, int rc) {
+    char msg[512];
+    snprintf(msg, sizeof msg, "%s failed: %d %s", what, rc, e ? bmq_last_error(e) : "");
+    jclass cls = (*env)->FindClass(env, "java/lang/IllegalStateException");
+    if (cls) (*env)->ThrowNew(env, cls, msg);
+}
+/* NOSPACE -> -(needed); other errors -> exception, 0 */
+static jlong result_of(JNIEnv* env, bmq_engine* e, const char* what, int rc, uint64_t need) {
+    if (rc == BMQ_E_NOSPACE) return -(jlong)need;
+    if (rc != BMQ_OK) {
+        throw_state(env, e, what, rc);
+        return 0;
+    }
+    return (jlong)need;
+}
+
+/* long create(int device) */
+JNIEXPORT jlong JNICALL NM(create)(JNIEnv* env, jclass c, jint device) {
+    (void)c;
+    bmq_config cfg = {0};
+    cfg.struct_size = sizeof cfg;
+    cfg.device = device;
+    bmq_engine* e = NULL;
+    const int rc = bmq_engine_create(&cfg, &e);
+    if (rc != BMQ_OK) {
+        throw_state(env, NULL, "bmq_engine_create (a gfx950 device is required)", rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)e;
+}
+/* void destroy(long engine) */
+JNIEXPORT void JNICALL NM(destroy)(JNIEnv* env, jclass c, jlong h) {
+    (void)env, (void)c;
+    bmq_engine_destroy(ENGINE(h));
+}
+
+/* void rebuild(long engine, ByteBuffer keys, IntBuffer keyOff, int n)      <- IKVRangeCoProc.reset(): reader.iterator() keys */
+JNIEXPORT void JNICALL NM(rebuild)(JNIEnv* env, jclass c, jlong h, jobject keys, jobject keyOff, jint n) {
+    (void)c;
+    const int rc = bmq_rebuild(ENGINE(h), (const uint8_t*)ADDR(keys), (const uint32_t*)ADDR(keyOff), (uint32_t)n);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_rebuild", rc);
+}
+/* void routesApply(long engine, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n)   <- post-commit Add/RemoveRoutesTask */
+JNIEXPORT void JNICALL NM(routesApply)(JNIEnv* env, jclass c, jlong h, jobject keys, jobject keyOff, jobject ops, jint n) {
+    (void)c;
+    const int rc = bmq_routes_apply(ENGINE(h), (const uint8_t*)ADDR(keys), (const uint32_t*)ADDR(keyOff), (const uint8_t*)ADDR(ops), (uint32_t)n);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_routes_apply", rc);
+}
+/* long epoch(long engine) */
+JNIEXPORT jlong JNICALL NM(epoch)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    bmq_index_info info;
+    const int rc = bmq_index_info_get(ENGINE(h), &info);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_index_info_get", rc);
+        return 0;
+    }
+    return (jlong)info.epoch;
+}
+/* int routeKey(long engine, int routeId, ByteBuffer out)    -> key length; the adapter turns it into a Matching
+ *                                                              (KVSchemaUtil.buildMatchRoute(routeKey, value)) */
+JNIEXPORT jint JNICALL NM(routeKey)(JNIEnv* env, jclass c, jlong h, jint id, jobject out) {
+    (void)c;
+    uint32_t len = 0;
+    const int rc = bmq_route_key(ENGINE(h), (uint32_t)id, (uint8_t*)ADDR(out), (uint32_t)CAP(out), &len);
+    if (rc == BMQ_E_NOSPACE) return -(jint)len;
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_route_key", rc);
+        return 0;
+    }
+    return (jint)len;
+}
+
+/* long matchBatch(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant,
+ *                 ByteBuffer topics, IntBuffer topicOff, int nTopics, IntBuffer outRowPtr, IntBuffer outIds)
+ * one call per BatchDistRequest: all DistPacks (tenants) x all cache-missing topics */
+JNIEXPORT jlong JNICALL NM(matchBatch)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants,
+                                       jobject topicTenant, jobject topics, jobject topicOff, jint nTopics, jobject outRowPtr,
+                                       jobject outIds) {
+    (void)c;
+    uint64_t need = 0;
+    const int rc = bmq_match_batch(ENGINE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
+                                   (const uint32_t*)ADDR(topicTenant), (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                   (uint32_t)nTopics, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds) / 4, &need);
+    return result_of(env, ENGINE(h), "bmq_match_batch", rc, need);
+}
+
+/* long matchAll(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, int nTopics, int maxPersistentFanout,
+ *               int maxGroupFanout, IntBuffer outRowPtr, IntBuffer outIds, IntBuffer outEvents (4 ints each), long[] nEventsOut)
+ * ITenantRouteMatcher.matchAll with the MatchedRoutes caps applied natively; events: see bmq_match_all */
+JNIEXPORT jlong JNICALL NM(matchAll)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jobject topics, jobject topicOff, jint nTopics,
+                                     jint maxPF, jint maxGF, jobject outRowPtr, jobject outIds, jobject outEvents, jlongArray nEventsOut) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    uint64_t need = 0;
+    uint32_t n_events = 0;
+    const int rc = bmq_match_all(ENGINE(h), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                 (uint32_t)nTopics, maxPF, maxGF, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds) / 4, &need,
+                                 (int32_t*)ADDR(outEvents), (uint32_t)(CAP(outEvents) / 16), &n_events);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    const jlong ne = (jlong)n_events;
+    (*env)->SetLongArrayRegion(env, nEventsOut, 0, 1, &ne);
+    return result_of(env, ENGINE(h), "bmq_match_all", rc, need);
+}
+
+/* ---- batching front: the call shape TenantRouteCache already has (one matchAll per cache miss, many threads) ---- */
+/* long batcherCreate(long engine, int maxBatchTopics) */
+JNIEXPORT jlong JNICALL NM(batcherCreate)(JNIEnv* env, jclass c, jlong h, jint maxBatchTopics) {
+    (void)c;
+    bmq_batcher_config cfg = {0};
+    cfg.struct_size = sizeof cfg;
+    cfg.max_batch_topics = (uint32_t)maxBatchTopics;
+    bmq_batcher* b = NULL;
+    const int rc = bmq_batcher_create(ENGINE(h), &cfg, &b);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_batcher_create", rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)b;
+}
+/* void batcherDestroy(long batcher) */
+JNIEXPORT void JNICALL NM(batcherDestroy)(JNIEnv* env, jclass c, jlong b) {
+    (void)env, (void)c;
+    bmq_batcher_destroy(BATCHER(b));
+}
+/* long batcherMatchAll(long batcher, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, int nTopics, IntBuffer outRowPtr,
+ *                      IntBuffer outIds, long[] epochOut)      blocks until the launch carrying these topics has finished */
+JNIEXPORT jlong JNICALL NM(batcherMatchAll)(JNIEnv* env, jclass c, jlong b, jbyteArray tenant, jobject topics, jobject topicOff, jint nTopics,
+                                            jobject outRowPtr, jobject outIds, jlongArray epochOut) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    uint64_t need = 0, epoch = 0;
+    const int rc = bmq_batcher_match_all(BATCHER(b), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                         (uint32_t)nTopics, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds) / 4, &need, &epoch);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    const jlong ep = (jlong)epoch;
+    (*env)->SetLongArrayRegion(env, epochOut, 0, 1, &ep);
+    return result_of(env, NULL, "bmq_batcher_match_all", rc, need);
+}
+
+/* ---- retain direction (IRetainTopicIndex) ---- */
+/* void retainRebuild(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant, ByteBuffer topics,
+ *                    IntBuffer topicOff, int nTopics) */
+JNIEXPORT void JNICALL NM(retainRebuild)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants, jobject topicTenant,
+                                         jobject topics, jobject topicOff, jint nTopics) {
+    (void)c;
+    const int rc = bmq_retain_rebuild(ENGINE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
+                                      (const uint32_t*)ADDR(topicTenant), (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff), (uint32_t)nTopics);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_rebuild", rc);
+}
+/* void retainApply(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, ByteBuffer ops, int n)   add = 0 / remove = 1 */
+JNIEXPORT void JNICALL NM(retainApply)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jobject topics, jobject topicOff, jobject ops, jint n) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    const int rc = bmq_retain_apply(ENGINE(h), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                    (const uint8_t*)ADDR(ops), (uint32_t)n);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_apply", rc);
+}
+/* long retainMatchLimited(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer filterTenant, ByteBuffer filters,
+ *                         IntBuffer filterOff, int nFilters, IntBuffer limits, IntBuffer outRowPtr, IntBuffer outTopicIds, IntBuffer outCounts)
+ * RetainStoreCoProc.match for one BatchMatchRequest: exact match counts + the `limit` smallest topic ids per filter */
+JNIEXPORT jlong JNICALL NM(retainMatchLimited)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants, jobject filterTenant,
+                                               jobject filters, jobject filterOff, jint nFilters, jobject limits, jobject outRowPtr,
+                                               jobject outTopicIds, jobject outCounts) {
+    (void)c;
+    uint64_t need = 0;
+    const int rc = bmq_retain_match_limited(ENGINE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
+                                            (const uint32_t*)ADDR(filterTenant), (const uint8_t*)ADDR(filters), (const uint32_t*)ADDR(filterOff),
+                                            (uint32_t)nFilters, (const uint32_t*)ADDR(limits), (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outTopicIds),
+                                            CAP(outTopicIds) / 4, &need, (uint32_t*)ADDR(outCounts));
+    return result_of(env, ENGINE(h), "bmq_retain_match_limited", rc, need);
+}
+/* int retainTopic(long engine, int topicId, ByteBuffer out, long[] tenantLenOut)   -> total length (tenant bytes then topic bytes) */
+JNIEXPORT jint JNICALL NM(retainTopic)(JNIEnv* env, jclass c, jlong h, jint id, jobject out, jlongArray tenantLenOut) {
+    (void)c;
+    uint32_t len = 0, tl = 0;
+    const int rc = bmq_retain_topic(ENGINE(h), (uint32_t)id, (uint8_t*)ADDR(out), (uint32_t)CAP(out), &len, &tl);
+    const jlong t = (jlong)tl;
+    (*env)->SetLongArrayRegion(env, tenantLenOut, 0, 1, &t);
+    if (rc == BMQ_E_NOSPACE) return -(jint)len;
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_retain_topic", rc);
+        return 0;
+    }
+    return (jint)len;
+}

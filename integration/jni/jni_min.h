@@ -1,0 +1,36 @@
+/* jni_min.h -- NOT the JDK's jni.h.  A minimal stand-in that declares, with the JNI specification's signatures, exactly the
+ * pieces bmq_jni.c uses, so that the binding can be compile-checked in an image that has no JDK (tests/test_host.py).  A real
+ * build includes $JAVA_HOME/include/jni.h instead (cc -DBMQ_REAL_JNI -I$JAVA_HOME/include -I$JAVA_HOME/include/linux ...). */
+#ifndef BMQ_JNI_MIN_H
+#define BMQ_JNI_MIN_H
+#include <stdint.h>
+
+typedef int32_t jint;
+typedef int64_t jlong;
+typedef int8_t jbyte;
+typedef uint8_t jboolean;
+typedef jint jsize;
+struct _jobject;
+typedef struct _jobject* jobject;
+typedef jobject jclass;
+typedef jobject jthrowable;
+typedef jobject jarray;
+typedef jarray jbyteArray;
+typedef jarray jlongArray;
+#define JNIEXPORT __attribute__((visibility("default")))
+#define JNICALL
+#define JNI_ABORT 2
+
+struct JNINativeInterface_;
+typedef const struct JNINativeInterface_* JNIEnv;
+struct JNINativeInterface_ { /* only the members used by bmq_jni.c; the real table has 230 entries */
+    jclass (*FindClass)(JNIEnv* env, const char* name);
+    jint (*ThrowNew)(JNIEnv* env, jclass clazz, const char* msg);
+    void* (*GetDirectBufferAddress)(JNIEnv* env, jobject buf);
+    jlong (*GetDirectBufferCapacity)(JNIEnv* env, jobject buf);
+    jsize (*GetArrayLength)(JNIEnv* env, jarray array);
+    jbyte* (*GetByteArrayElements)(JNIEnv* env, jbyteArray array, jboolean* isCopy);
+    void (*ReleaseByteArrayElements)(JNIEnv* env, jbyteArray array, jbyte* elems, jint mode);
+    void (*SetLongArrayRegion)(JNIEnv* env, jlongArray array, jsize start, jsize len, const jlong* buf);
+};
+#endif

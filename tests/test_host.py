@@ -180,3 +180,20 @@ def test_batching_front_under_thread_sanitizer():
     for _ in range(3):
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "batcher_tsan ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
+
+
+def test_jni_binding_compiles_against_the_header(tmp_path):
+    """integration/jni/bmq_jni.c -- the binding INTEGRATION.md describes -- compiles (C99, -Werror) against include/bmq.h and links
+    against libbmq.so, and exports one Java_..._NativeMatcher_<name> symbol per native method NativeMatcher.java declares.
+    (No JDK in this image: jni_min.h stands in for jni.h; the Java sources are not compiled.)"""
+    import subprocess
+    so = str(tmp_path / "libbmq_jni.so")
+    libdir = os.path.join(ROOT, "bifromq_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-I",
+                    os.path.join(ROOT, "integration", "jni"), "-o", so, os.path.join(ROOT, "integration", "jni", "bmq_jni.c"), "-L", libdir,
+                    "-lbmq"], check=True, capture_output=True, timeout=120)
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"Java_org_apache_bifromq_dist_worker_gpu_NativeMatcher_(\w+)", syms))
+    java = open(os.path.join(ROOT, "integration", "java", "org", "apache", "bifromq", "dist", "worker", "gpu", "NativeMatcher.java")).read()
+    declared = set(re.findall(r"static native \w+ (\w+)\(", java))
+    assert declared and exported == declared, (sorted(declared - exported), sorted(exported - declared))
