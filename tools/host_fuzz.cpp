@@ -100,6 +100,7 @@ static std::vector<uint32_t> image_match(const DistIndexHost& h, std::string_vie
 int main(int argc, char** argv) {
     const uint64_t seed = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
     const int rounds = argc > 2 ? atoi(argv[2]) : 30;
+    const size_t max_keys = argc > 3 ? (size_t)atoll(argv[3]) : 3000; // keys of a rebuild round
     std::mt19937_64 rng(seed);
     const std::vector<std::string> tenants = {"t", "tenantB", "x", "a-much-longer-tenant-identifier"};
     const std::vector<std::string> alpha = {"a", "b", "c", "", "$sys", "+", "a-level-longer-than-sixteen-bytes", "\xE4\xBD\xA0\xE5\xA5\xBD", "0"};
@@ -140,7 +141,7 @@ int main(int argc, char** argv) {
         const bool full = round == 0 || rnd(8) == 0;
         if (full) {
             model.clear();
-            const size_t n = rnd(3) == 0 ? 0 : 1 + rnd(3000);
+            const size_t n = rnd(3) == 0 ? 0 : 1 + rnd(max_keys);
             for (size_t i = 0; i < n; i++) model.insert(rand_key());
             keys.assign(model.begin(), model.end());
             std::shuffle(keys.begin(), keys.end(), rng);
