@@ -1,0 +1,52 @@
+"""The committed evidence under profiles/ must be self-consistent: the bench line of the default workload and the rocprofv3
+kernel trace of the same command agree on the dominant kernel's duration, the roofline object is what bench.py computes from the
+counters, and the PMC traffic file is the one the bench line quotes."""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.join(ROOT, "profiles", "r01")
+
+
+def _bench(name):
+    return json.loads(open(os.path.join(R, name)).read().strip().splitlines()[-1])
+
+
+def test_bench_line_has_the_contract_fields():
+    d = _bench("bench_c3.json")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert abs(d["value"] - d["config"]["publishes_per_batch_per_rank"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+
+
+def test_rocprof_trace_agrees_with_the_bench_line():
+    d = _bench("bench_c3.json")
+    with open(os.path.join(R, "c3_kernel_stats.csv")) as f:
+        rows = {r["Name"].split("(")[0]: float(r["AverageNs"]) for r in csv.DictReader(f)}
+    walk_us = rows["bmq::k_walk"] / 1e3
+    assert abs(walk_us - d["kernel_ms"]["k_walk"] * 1e3) / walk_us < 0.05  # HIP events on the engine stream vs rocprofv3
+    # achieved = algorithmic bytes per launch / duration of the dominant kernel
+    rf = d["roofline"]
+    assert rf["kernel"] == "k_walk"
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (d["kernel_ms"]["k_walk"] * 1e-3) / 1e9) / rf["achieved"] < 0.01
+
+
+def test_traffic_comes_from_the_pmc_passes():
+    d = _bench("bench_c3.json")
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))["c3"]
+    assert abs(d["roofline"]["traffic"] - t) / t < 1e-6
+    per = {}
+    with open(os.path.join(R, "c3_pmc_hbm.csv")) as f:
+        for line in f:
+            if line.startswith("bmq::k_walk,"):
+                _, counter, _, kib = line.strip().split(",")
+                per[counter] = float(kib)
+    assert abs(per["FETCH_SIZE"] * 1024 * 0.992 + per["WRITE_SIZE"] * 1024 - t) / t < 1e-3
+    assert t < d["roofline"]["algorithmic_bytes_per_launch"]  # L2 / MALL hits: less HBM traffic than algorithmic bytes
