@@ -137,7 +137,8 @@ int64_t KeySet::find(std::string_view k) const {
     return (lo < size() && key(lo) == k) ? (int64_t)lo : -1;
 }
 
-void KeySet::apply(std::vector<std::pair<std::string_view, uint8_t>>& ops) {
+void KeySet::apply(std::vector<std::pair<std::string_view, uint8_t>>& ops, std::vector<int64_t>* src) {
+    if (src) src->clear();
     // last op per key wins (ops are applied in order); then one merge pass over the sorted set
     std::vector<uint32_t> idx(ops.size());
     for (uint32_t i = 0; i < ops.size(); i++) idx[i] = i;
@@ -147,15 +148,17 @@ void KeySet::apply(std::vector<std::pair<std::string_view, uint8_t>>& ops) {
     std::vector<uint64_t> no;
     no.reserve(off.size() + ops.size());
     no.push_back(0);
-    auto emit = [&](std::string_view k) {
+    auto emit = [&](std::string_view k, int64_t from) {
         nb.insert(nb.end(), k.begin(), k.end());
         no.push_back(nb.size());
+        if (src) src->push_back(from);
     };
     size_t i = 0, j = 0;
     const size_t m = size();
     while (i < m || j < idx.size()) {
         if (j == idx.size()) {
-            emit(key(i++));
+            emit(key(i), (int64_t)i);
+            i++;
             continue;
         }
         size_t j2 = j; // run of ops on the same key; the last one decides
@@ -165,13 +168,13 @@ void KeySet::apply(std::vector<std::pair<std::string_view, uint8_t>>& ops) {
         if (i < m) {
             const std::string_view k = key(i);
             if (sv_less(k, ok)) {
-                emit(k);
+                emit(k, (int64_t)i);
                 i++;
                 continue;
             }
             if (k == ok) i++; // replaced or deleted
         }
-        if (is_put) emit(ok);
+        if (is_put) emit(ok, -(int64_t)idx[j2] - 1);
         j = j2 + 1;
     }
     if (nb.empty()) nb.push_back(0);
@@ -248,7 +251,128 @@ struct TenantBuild {
     std::vector<uint32_t> group_begin, group_count;
     std::vector<uint32_t> indirect;
     std::string error;
+    std::shared_ptr<void> hold; // keeps a persistent trie alive whose strings local_strings points into
 };
+
+// ---- EXPERIMENTAL (BMQ_INCREMENTAL=1): the tenant's trie kept between applies ---------------------------------------
+// Local tokens, the child map and the nodes persist; every key remembers the node it hangs off.  A batch of mutations then
+// walks / extends the trie for the keys it puts only, and the id ranges of all nodes are recomputed from key_node[] in one
+// pass over the (merged) key set -- no key of the tenant is parsed again.  Nodes that lose their last route stay in the
+// persistent trie (they may come back) but are left out of the image; when they pile up the state is dropped and the next
+// refresh parses the keys from scratch.
+constexpr uint32_t KEY_HASH = 0x80000000u; // key_node flag: the key is a route of "<node path>/#"
+struct TenantInc {
+    HostDict local;
+    std::deque<std::string> local_store; // owned level strings (key bytes move when the key set is merged)
+    ChildMap children;
+    std::vector<BuildNode> nodes;        // creation order: parents first; own_group / hash_group unused here
+    std::vector<uint32_t> key_node;      // per key, in rank order: node | KEY_HASH
+    uint32_t intern(std::string_view s) {
+        const size_t before = local.entries.size();
+        const uint32_t tok = local.intern(s);
+        if (local.entries.size() != before) {
+            local_store.emplace_back(s);
+            local.entries.back().s = local_store.back();
+        }
+        return tok;
+    }
+    // node of a route key (creating the path if needed); false: malformed key
+    bool locate(std::string_view key, uint32_t& out) {
+        RouteKeyParts kp;
+        if (!decode_route_key(key, kp)) return false;
+        const std::string_view f = kp.esc_filter;
+        uint32_t node = 0;
+        size_t s0 = 0;
+        for (size_t i = 0; i <= f.size(); i++)
+            if (i == f.size() || f[i] == '\0') {
+                const std::string_view lv = f.substr(s0, i - s0);
+                s0 = i + 1;
+                if (lv == "#" && i == f.size()) {
+                    out = node | KEY_HASH;
+                    return true;
+                }
+                const uint32_t tok = (lv == "+") ? TOK_PLUS : intern(lv);
+                bool created;
+                uint32_t& v = children.get(node, tok, created);
+                if (created) {
+                    v = (uint32_t)nodes.size();
+                    nodes.push_back({node, tok, NONE, NONE});
+                }
+                node = v;
+            }
+        out = node;
+        return true;
+    }
+};
+
+static bool incremental_enabled() {
+    static const bool on = [] {
+        const char* v = getenv("BMQ_INCREMENTAL");
+        return v && atoi(v) != 0;
+    }();
+    return on;
+}
+
+// TenantBuild from the persistent trie + key_node[] (no key is parsed)
+void build_from_inc(TenantBuild& b, TenantInc& inc) {
+    const size_t n = inc.key_node.size(), nn = inc.nodes.size();
+    // per (node, kind): count / first rank / last rank
+    std::vector<uint32_t> cnt(2 * nn, 0), first(2 * nn, 0), last(2 * nn, 0);
+    for (size_t r = 0; r < n; r++) {
+        const uint32_t kn = inc.key_node[r], g = 2 * (kn & ~KEY_HASH) + (kn >> 31);
+        if (cnt[g]++ == 0) first[g] = (uint32_t)r;
+        last[g] = (uint32_t)r;
+    }
+    // liveness: a node is part of the image if it or a descendant has routes (children have larger indices than parents)
+    std::vector<uint8_t> alive(nn, 0);
+    alive[0] = 1;
+    for (size_t i = nn; i-- > 0;) {
+        if (cnt[2 * i] || cnt[2 * i + 1]) alive[i] = 1;
+        if (alive[i] && inc.nodes[i].parent != NONE) alive[inc.nodes[i].parent] = 1;
+    }
+    std::vector<uint32_t> remap(nn, NONE);
+    b.nodes.clear();
+    b.group_begin.clear();
+    b.group_count.clear();
+    std::vector<uint32_t> group_of(2 * nn, NONE);
+    uint32_t ind = 0;
+    for (size_t i = 0; i < nn; i++) {
+        if (!alive[i]) continue;
+        remap[i] = (uint32_t)b.nodes.size();
+        BuildNode bn = inc.nodes[i];
+        bn.parent = bn.parent == NONE ? NONE : remap[bn.parent];
+        bn.own_group = bn.hash_group = NONE;
+        for (uint32_t kind = 0; kind < 2; kind++) {
+            const size_t g = 2 * i + kind;
+            if (!cnt[g]) continue;
+            group_of[g] = (uint32_t)b.group_count.size();
+            (kind ? bn.hash_group : bn.own_group) = group_of[g];
+            if (last[g] - first[g] + 1 == cnt[g]) {
+                b.group_begin.push_back(first[g]);
+                b.group_count.push_back(cnt[g]);
+            } else { // ids are not one contiguous rank range (SURVEY.md 8c quirk ii): listed in the indirect array
+                b.group_begin.push_back(ind);
+                b.group_count.push_back(cnt[g] | RANGE_INDIRECT);
+                ind += cnt[g];
+            }
+        }
+        b.nodes.push_back(bn);
+    }
+    b.indirect.assign(ind, 0);
+    if (ind) {
+        std::vector<uint32_t> cur(b.group_begin);
+        for (size_t r = 0; r < n; r++) {
+            const uint32_t kn = inc.key_node[r], g = group_of[2 * (kn & ~KEY_HASH) + (kn >> 31)];
+            if (b.group_count[g] & RANGE_INDIRECT) b.indirect[cur[g]++] = (uint32_t)r;
+        }
+    }
+    b.local_strings.resize(inc.local.entries.size());
+    for (size_t i = 0; i < inc.local.entries.size(); i++) b.local_strings[i] = inc.local.entries[i].s;
+    if (nn > 2 * b.nodes.size() + 64) { // mostly dead nodes: drop the state, the next refresh parses the keys again
+        b.hold = b.st->inc;
+        b.st->inc.reset();
+    }
+}
 
 // Phase 1: keys -> trie nodes (local tokens), route groups.  Keys are sorted: consecutive keys share long prefixes.
 void build_tenant_trie(TenantBuild& b) {
@@ -263,6 +387,11 @@ void build_tenant_trie(TenantBuild& b) {
     std::vector<uint32_t> route_group(n ? n : 1);
     std::vector<std::string_view> prev_levels, levels;
     std::vector<uint32_t> prev_nodes;
+    std::shared_ptr<TenantInc> keep; // BMQ_INCREMENTAL=1: the trie outlives this call
+    if (incremental_enabled()) {
+        keep = std::make_shared<TenantInc>();
+        keep->key_node.assign(n, 0);
+    }
     for (size_t r = 0; r < n; r++) {
         RouteKeyParts kp;
         if (!decode_route_key(ks.key(r), kp)) {
@@ -306,6 +435,7 @@ void build_tenant_trie(TenantBuild& b) {
             prev_levels.push_back(lv);
             prev_nodes.push_back(node);
         }
+        if (keep) keep->key_node[r] = node | (is_hash ? KEY_HASH : 0u);
         uint32_t& g = is_hash ? b.nodes[node].hash_group : b.nodes[node].own_group;
         if (g == NONE) {
             g = (uint32_t)b.group_count.size();
@@ -339,6 +469,16 @@ void build_tenant_trie(TenantBuild& b) {
     }
     b.local_strings.resize(local.entries.size());
     for (size_t i = 0; i < local.entries.size(); i++) b.local_strings[i] = local.entries[i].s;
+    if (keep) { // hand the trie over (level strings become owned: the key bytes they point into move on the next merge)
+        for (auto& e : local.entries) {
+            keep->local_store.emplace_back(e.s);
+            e.s = keep->local_store.back();
+        }
+        keep->local = std::move(local);
+        keep->children = std::move(children);
+        keep->nodes = b.nodes;
+        b.st->inc = keep;
+    } else b.st->inc.reset();
 }
 
 // Phase 3: place the nodes (global tokens) into the tenant's region: bucketised first-free probing, parents first.
@@ -515,7 +655,26 @@ bool DistIndexHost::apply(const uint8_t* keys, const uint32_t* key_off, const ui
         lists.push_back(&e.second);
     }
     pt.lap("group ops by tenant");
-    parallel_for(touched.size(), [&](size_t i) { touched[i]->keys.apply(*lists[i]); });
+    parallel_for(touched.size(), [&](size_t i) {
+        TenantState& t = *touched[i];
+        TenantInc* inc = incremental_enabled() ? (TenantInc*)t.inc.get() : nullptr;
+        if (!inc) {
+            t.keys.apply(*lists[i]);
+            t.inc.reset();
+            return;
+        }
+        // EXPERIMENTAL incremental path: merge the keys, carry every surviving key's node along, walk the trie for the new keys only
+        std::vector<int64_t> src;
+        t.keys.apply(*lists[i], &src);
+        std::vector<uint32_t> kn(src.size());
+        bool ok = true;
+        for (size_t r = 0; r < src.size() && ok; r++) {
+            if (src[r] >= 0) kn[r] = inc->key_node[(size_t)src[r]];
+            else ok = inc->locate((*lists[i])[(size_t)(-src[r] - 1)].first, kn[r]);
+        }
+        if (ok) inc->key_node.swap(kn);
+        else t.inc.reset(); // cannot happen (keys were decoded above); the full parse reports it
+    });
     pt.lap("merge into key sets");
     return refresh(touched);
 }
@@ -534,7 +693,11 @@ bool DistIndexHost::refresh(std::vector<TenantState*>& touched) {
     // phase 1 (parallel): tries with tenant-local tokens
     std::vector<TenantBuild> builds(live.size());
     for (size_t i = 0; i < live.size(); i++) builds[i].st = live[i];
-    parallel_for(builds.size(), [&](size_t i) { build_tenant_trie(builds[i]); });
+    parallel_for(builds.size(), [&](size_t i) {
+        TenantBuild& b = builds[i];
+        if (incremental_enabled() && b.st->inc) build_from_inc(b, *(TenantInc*)b.st->inc.get()); // kept in sync by apply()
+        else build_tenant_trie(b);
+    });
     for (auto& b : builds)
         if (!b.error.empty()) {
             error = b.error;

@@ -40,7 +40,9 @@ struct KeySet {
         return std::string_view((const char*)bytes.data() + off[i], (size_t)(off[i + 1] - off[i]));
     }
     void assign(std::vector<std::string_view>& keys);                       // any order; sorts + uniques
-    void apply(std::vector<std::pair<std::string_view, uint8_t>>& ops);     // in order; op 0 put, 1 delete
+    // in order; op 0 put, 1 delete.  src (optional): for every rank of the result, the rank the key had before (>= 0) or
+    // -(index into ops) - 1 for a key the batch put
+    void apply(std::vector<std::pair<std::string_view, uint8_t>>& ops, std::vector<int64_t>* src = nullptr);
     int64_t find(std::string_view k) const;                                 // rank or -1
 };
 
@@ -56,6 +58,9 @@ struct TenantState {
     uint32_t rank_base = 0;  // global id of the tenant's first route
     uint32_t rp_base = 0;    // first entry of the tenant in route_pos
     std::vector<uint32_t> indirect; // tenant-relative ids of nodes whose ids are not one contiguous range
+    // EXPERIMENTAL, off unless BMQ_INCREMENTAL=1: the tenant's trie kept between applies (opaque, see bmq_index.cpp), so that a
+    // batch of mutations costs O(ops * depth + nodes) on the host instead of a re-parse of all the tenant's keys
+    std::shared_ptr<void> inc;
 };
 
 struct TenantOrder { // tenants in KV key order: u16be(len) then bytes (SCHEMA/KVSchemaUtil.java:91-94)

@@ -149,6 +149,10 @@ def test_host_index_fuzz_under_sanitizers():
     # rebuild() splits the keys by tenant in parallel chunks: force many tiny chunks
     r = subprocess.run([exe, "5", "40"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BMQ_SPLIT_CHUNK="7"))
     assert r.returncode == 0 and "host_fuzz ok" in r.stdout, r.stdout + r.stderr
+    # the experimental incremental apply path (BMQ_INCREMENTAL=1: persistent per-tenant trie, no key is parsed twice)
+    for seed in ("2", "11"):
+        r = subprocess.run([exe, seed, "50"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BMQ_INCREMENTAL="1"))
+        assert r.returncode == 0 and "host_fuzz ok" in r.stdout, r.stdout + r.stderr
     # the retain direction's host index (tools/retain_fuzz.cpp): per-tenant add/remove, segment growth, '$' runs
     exe = os.path.join(ROOT, "tools", "retain_fuzz")
     for seed, rounds in ((1, 25), (7, 25)):
