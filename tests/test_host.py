@@ -201,3 +201,26 @@ def test_jni_binding_compiles_against_the_header(tmp_path):
     java = open(os.path.join(ROOT, "integration", "java", "org", "apache", "bifromq", "dist", "worker", "gpu", "NativeMatcher.java")).read()
     declared = set(re.findall(r"static native \w+ (\w+)\(", java))
     assert declared and exported == declared, (sorted(declared - exported), sorted(exported - declared))
+
+
+def test_churn_case_helper_on_host_only_engine():
+    """tests/util.py::churn_case is the body of the full-size configs[4] GPU test; here it runs small, on a host-only engine
+    (rebuild / apply / info / route_key are host code) with the match taken from the semantic oracle over the updated key set,
+    so that the helper's bookkeeping (new id ranges, sub-KV of the first tenants, sampling) is verified without a GPU."""
+    eng = B.Engine(device=-1)
+    state = {}
+
+    def oracle_match(tn, tt, packed):
+        data, off = packed
+        raw = data.tobytes()
+        topics = [raw[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
+        keys = [eng.route_key(i) for i in range(int(eng.info().n_routes))]
+        rows = U.semantic_rows(O.KV(keys), tn, tt, topics)
+        row = np.zeros(len(rows) + 1, dtype=np.uint32)
+        row[1:] = np.cumsum([len(r) for r in rows])
+        state["rows"] = len(rows)
+        return row, np.array([x for r in rows for x in r], dtype=np.uint32)
+
+    n = U.churn_case(eng, oracle_match, n_tenants=12, per_tenant=400, n_ops=1200, n_topics=1500, sample_tenants=5, n_sample=300)
+    assert state["rows"] == 1500 and n == eng.info().n_routes
+    eng.close()
