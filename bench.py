@@ -162,11 +162,12 @@ def main():
         if not args.churn:
             return
         rng = churn_state["rng"]
-        nk = int(eng.info().n_routes)
+        nk = int(eng.info().next_route_id)
         tenants_l = w.tenants()
         ops = []
-        for rid in rng.integers(0, nk, size=args.churn // 2):
-            ops.append((1, eng.route_key(int(rid))))
+        for k in eng.route_keys(rng.integers(0, nk, size=args.churn // 2)):  # ids are stable handles; a dead one gives b""
+            if k:
+                ops.append((1, k))
         for _ in range(args.churn - args.churn // 2):
             churn_state["seq"] += 1
             q = churn_state["seq"]

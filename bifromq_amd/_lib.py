@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # every symbol include/bmq.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_routes_apply",
-    "bmq_index_info_get", "bmq_route_key", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
+    "bmq_index_info_get", "bmq_route_key", "bmq_route_keys", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
     "bmq_match_finish", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_retain_rebuild", "bmq_retain_apply", "bmq_retain_topic",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
@@ -50,7 +50,8 @@ class Stats(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("n_routes", C.c_uint64), ("n_tenants", C.c_uint64), ("n_nodes", C.c_uint64), ("n_tokens", C.c_uint64),
                 ("trie_slots", C.c_uint64), ("dict_slots", C.c_uint64), ("device_bytes", C.c_uint64),
-                ("epoch", C.c_uint64)]
+                ("epoch", C.c_uint64), ("generation", C.c_uint64), ("next_route_id", C.c_uint64),
+                ("garbage_bytes", C.c_uint64)]
 
 
 class BatcherConfig(C.Structure):
@@ -84,6 +85,7 @@ def lib() -> C.CDLL:
             "bmq_routes_apply": (C.c_int, [vp, vp, vp, vp, u32]),
             "bmq_index_info_get": (C.c_int, [vp, P(IndexInfo)]),
             "bmq_route_key": (C.c_int, [vp, u32, C.c_char_p, u32, P(u32)]),
+            "bmq_route_keys": (C.c_int, [vp, vp, u32, vp, u64, vp]),
             "bmq_index_find": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32, vp, u32, P(u32)]),
             "bmq_match_batch": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, P(u64)]),
             "bmq_match_batch_dev": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, vp]),

@@ -1,0 +1,772 @@
+// bmq_dist_index.h -- owner of the dist index: the arrays of bmq_layout.h in "exec memory" (HBM under DevExec, host memory
+// under HostExec) and the host-side control of the builder pipeline of bmq_build_core.h.  The host side only moves bytes,
+// sizes buffers and reads back counters; every key is parsed, every node inserted and every id set edited by the builder
+// functions on the exec side.
+//
+//   rebuild(keys)  <- IKVRangeCoProc.reset(Boundary)           (KVAPI/IKVRangeCoProc.java:64, DW/DistWorkerCoProc.java:283-291)
+//   apply(ops)     <- ISubscriptionCache.refresh(add/remove)   (DW/DistWorkerCoProc.java:188-209, DW/cache/SubscriptionCache.java:127-134)
+//   route_key(id)  -> key bytes, so the Java side can materialise Matching objects (SCHEMA/KVSchemaUtil.java:73-89)
+//
+// Exec concept (bmq_exec_host.h: HostExec; bmq_engine.hip: DevExec):
+//   void* alloc(size_t); void release(void*);
+//   bool copy_in(dst, src, n)  [blocking]   bool copy_in_async(dst, src, n) [src valid until sync()]
+//   bool copy_out(dst, src, n) [blocking, after everything queued before]   bool copy(dst, src, n)   bool zero(p, n)   bool sync()
+//   bool fill_slots(TrieSlot*, n), iota(uint32_t*, n)
+//   bool prepare(ix, ob), prepare_check(ix, ob, n_dir), bulk_prepare(ix, ob), scan_flags(in, out, n), bulk_tenants(ix, ob, scan),
+//        locate(ix, ob), sort_targets(ob), group(ix, ob), rehash(ix, old_base, old_slots, new_base, new_buckets),
+//        dict_rehash(old, old_slots, ix), find(ix, query, tenant_len, filter_len, out, cap), gather_refs(ix, ids, n, out_refs),
+//        gather_bytes(ix, refs, offs, n, out)
+//   std::string err;
+#pragma once
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "bmq_build_core.h"
+
+namespace bmq {
+
+struct DistIndexStats {
+    uint64_t n_routes = 0, n_tenants = 0, n_nodes = 0, n_tokens = 0;
+    uint64_t trie_slots = 0, dict_slots = 0, bytes = 0;
+    uint64_t id_list_words = 0, id_list_garbage = 0, trie_garbage_slots = 0, key_bytes = 0;
+    uint32_t next_id = 0;
+};
+struct ApplyResult {
+    uint32_t added = 0, removed = 0, dups = 0;
+};
+
+template <class Exec> class DistIndex {
+public:
+    explicit DistIndex(Exec& exec) : x(exec) {}
+    ~DistIndex() { drop(); }
+    DistIndex(const DistIndex&) = delete;
+    DistIndex& operator=(const DistIndex&) = delete;
+
+    Exec& x;
+    std::string error;
+    bool built = false, broken = false;
+    uint64_t generation = 0; // bumped by every rebuild: ids of different generations are unrelated
+    bool tiny = false;       // test knob (tools/host_fuzz.cpp): minimal initial capacities, so that every growth path runs all the time
+
+    // ---- arrays in exec memory ----
+    TrieSlot* trie = nullptr;
+    uint64_t trie_cap = 0, trie_used = 0;
+    TenantSlot* dir = nullptr;
+    uint32_t dir_slots = 0;
+    uint8_t* names = nullptr;
+    uint32_t names_cap = 0, names_used = 0;
+    DictSlot* dict = nullptr;
+    uint32_t dict_slots = 0;
+    uint8_t* dpool = nullptr;
+    uint32_t dpool_cap = 0;
+    uint32_t* route_pos = nullptr;
+    uint64_t rp_cap = 0;
+    unsigned long long* kref = nullptr;
+    uint32_t* khash = nullptr;
+    uint32_t id_cap = 0, next_id = 0;
+    uint8_t* kpool = nullptr;
+    uint64_t kpool_cap = 0, kpool_used = 0;
+    BuildCounters* bc = nullptr;
+    BuildCounters hbc{}; // last read-back
+
+    // ---- host bookkeeping ----
+    std::unordered_map<std::string, uint32_t> tenant_slot; // tenant id -> directory slot
+    std::vector<std::pair<uint64_t, uint64_t>> free_regions; // (base, slots) abandoned by region growth
+    uint64_t trie_garbage = 0;
+
+    DistIndexView view() const {
+        DistIndexView v{};
+        v.trie = trie;
+        v.tenants = dir;
+        v.tenant_mask = dir_slots - 1;
+        v.tenant_names = names;
+        v.dict = dict;
+        v.dict_group_mask = dict_slots / DICT_GROUP - 1;
+        v.pool = dpool;
+        v.route_pos = route_pos;
+        return v;
+    }
+    DistIndexMut mut() const {
+        DistIndexMut m{};
+        m.trie = trie;
+        m.tenants = dir;
+        m.tenant_mask = dir_slots - 1;
+        m.tenant_names = names;
+        m.dict = dict;
+        m.dict_group_mask = dict_slots / DICT_GROUP - 1;
+        m.dpool = dpool;
+        m.dpool_cap = dpool_cap;
+        m.route_pos = route_pos;
+        m.rp_cap = rp_cap;
+        m.kref = kref;
+        m.khash = khash;
+        m.id_cap = id_cap;
+        m.kpool = kpool;
+        m.bc = bc;
+        return m;
+    }
+
+    // ---- full (re)load.  keys: packed route keys, any order (a KV scan yields them sorted: that is the fast path) ----
+    bool rebuild(const uint8_t* keys, const uint32_t* key_off, uint32_t n) {
+        error.clear();
+        std::vector<uint8_t> sorted_bytes; // only used when the input was not strictly ascending
+        std::vector<uint32_t> sorted_off;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            uint32_t err = 0;
+            if (!rebuild_sorted(keys, key_off, n, err)) {
+                if (err & ERR_BAD_KEY) return false;
+                if ((err & ERR_UNSORTED) && attempt == 0) { // not a KV scan: order + de-duplicate on the host, once
+                    sort_unique(keys, key_off, n, sorted_bytes, sorted_off);
+                    keys = sorted_bytes.data();
+                    key_off = sorted_off.data();
+                    n = (uint32_t)sorted_off.size() - 1;
+                    continue;
+                }
+                return false;
+            }
+            built = true;
+            broken = false;
+            generation++;
+            return true;
+        }
+        return fail("rebuild: input could not be ordered");
+    }
+
+    // ---- post-commit mutations, applied in order.  op[i]: 0 = put, 1 = delete ----
+    bool apply(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n, ApplyResult* res = nullptr) {
+        error.clear();
+        if (n == 0) return true;
+        if (broken) return fail("the index is inconsistent after a failed batch: bmq_rebuild is required");
+        if (!built && !reset_empty()) return false;
+        const uint64_t kb = key_off[n];
+        std::vector<uint32_t> put_rank(n);
+        uint32_t n_put = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            put_rank[i] = n_put;
+            n_put += op[i] == 0;
+        }
+        if ((uint64_t)next_id + n_put >= 0xFFFFFFF0ull) return fail("route id space exhausted: bmq_rebuild re-numbers the routes");
+        if (!ensure_keys(kb) || !ensure_ids(next_id + n_put) || !ensure_scratch(n, true)) return false;
+        OpBatch ob = batch(n);
+        ob.key_base = kpool_used;
+        ob.id_base = next_id;
+        ob.put_rank = s_put_rank;
+        ob.op = s_op;
+        ob.bulk = 0;
+        if (!x.copy_in_async(kpool + kpool_used, keys, kb) || !x.copy_in_async(s_key_off, key_off, sizeof(uint32_t) * ((size_t)n + 1)) ||
+            !x.copy_in_async(s_op, op, n) || !x.copy_in_async(s_put_rank, put_rank.data(), sizeof(uint32_t) * (size_t)n))
+            return xfail();
+        // ---- prepare: validate + tenants + growth bounds (re-run once if tenants had to be created) ----
+        for (int round = 0;; round++) {
+            if (!zero_batch_counters()) return false;
+            DistIndexMut ix = mut();
+            if (!x.prepare(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !read_counters()) return xfail();
+            if (hbc.err & ERR_BAD_KEY) return fail("malformed route key or op in apply batch"); // nothing was changed
+            if (hbc.n_unknown == 0) break;
+            if (round == 1) return fail("apply: tenant creation did not converge");
+            std::vector<uint32_t> unk(hbc.n_unknown);
+            if (!x.copy_out(unk.data(), ob.unknown_list, sizeof(uint32_t) * unk.size())) return xfail();
+            std::unordered_map<std::string, uint64_t> need; // new tenant -> nodes its puts may add
+            for (uint32_t i : unk) {
+                const std::string_view k((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
+                const size_t tlen = ((size_t)(uint8_t)k[1] << 8) | (uint8_t)k[2]; // validated by prepare
+                uint64_t levels = 1;
+                for (size_t q = 3 + tlen; q < k.size(); q++) levels += k[q] == 0;
+                need[std::string(k.substr(3, tlen))] += levels;
+            }
+            for (auto& e : need)
+                if (!create_tenant(e.first, e.second, 0)) return false;
+            if (!flush_directory()) return false;
+            ob.grow_list = s_grow; // the directory may have grown, and its scratch with it
+        }
+        if (!grow_flagged_regions(ob)) return false;
+        // ---- locate (idempotent: re-run after growing what it ran out of) ----
+        for (int attempt = 0;; attempt++) {
+            if (attempt == 8) return broke("apply: growth did not converge");
+            if (!zero_batch_counters()) return false;
+            DistIndexMut ix = mut();
+            if (!x.locate(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !read_counters()) return xfail();
+            if (hbc.err & ERR_STUCK) return broke("apply: a probe loop did not terminate");
+            if (!(hbc.err & (ERR_DICT_FULL | ERR_REGION_FULL)) && hbc.n_grow == 0) break;
+            if ((hbc.err & ERR_DICT_FULL) && !grow_dict(std::max<uint64_t>((uint64_t)dict_slots * 4, 4096), (uint64_t)dpool_cap * 2 + kb)) return false;
+            if (!grow_flagged_regions(ob)) return false;
+        }
+        // ---- sort by filter node, apply the groups ----
+        if (!x.zero(ob.group_done, n) || !x.sort_targets(ob)) return xfail();
+        for (int attempt = 0;; attempt++) {
+            if (attempt == 8) return broke("apply: id-list pool growth did not converge");
+            if (!zero_batch_counters()) return false;
+            DistIndexMut ix = mut();
+            if (!x.group(ix, ob) || !read_counters()) return xfail();
+            if (hbc.err) return broke("apply: group step failed");
+            if (res) {
+                res->added += hbc.n_added;
+                res->removed += hbc.n_removed;
+                res->dups += hbc.n_dups;
+            }
+            if (hbc.n_deferred == 0) break;
+            if (!grow_route_pos(hbc.rp_used + 2 * hbc.rp_need + 1024)) return false;
+        }
+        kpool_used += (kb + 15) & ~15ull;
+        next_id += n_put;
+        if ((uint64_t)hbc.n_tokens * 4 > dict_slots && !grow_dict((uint64_t)dict_slots * 4, dpool_cap)) return false;
+        return true;
+    }
+
+    // ---- id -> key ----
+    // false + empty error: no such route (never existed or deleted)
+    bool route_key(uint32_t id, std::string& out) {
+        out.clear();
+        if (!built || id >= next_id) return false;
+        unsigned long long r = 0;
+        if (!x.copy_out(&r, kref + id, sizeof(r))) return xfail();
+        if (r == 0) return false;
+        out.resize((size_t)(r >> KREF_LEN_SHIFT));
+        if (!x.copy_out(out.data(), kpool + (r & KREF_OFF_MASK), out.size())) return xfail();
+        return true;
+    }
+    // keys of many ids at once: out_off[n + 1], bytes appended to out (a dead id gives an empty key)
+    bool route_keys(const uint32_t* ids, uint32_t n, std::vector<uint8_t>& out, std::vector<uint64_t>& out_off) {
+        out.clear();
+        out_off.assign((size_t)n + 1, 0);
+        if (n == 0) return true;
+        if (!built) return fail("no index");
+        if (!ensure_buf(g_ids, g_ids_cap, n) || !ensure_buf(g_refs, g_refs_cap, n) || !ensure_buf(g_offs, g_offs_cap, (size_t)n + 1)) return false;
+        std::vector<unsigned long long> refs(n);
+        if (!x.copy_in(g_ids, ids, sizeof(uint32_t) * (size_t)n) || !x.gather_refs(mut(), g_ids, n, next_id, g_refs) ||
+            !x.copy_out(refs.data(), g_refs, sizeof(unsigned long long) * (size_t)n))
+            return xfail();
+        for (uint32_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + (refs[i] >> KREF_LEN_SHIFT);
+        const uint64_t total = out_off[n];
+        out.resize(total);
+        if (total == 0) return true;
+        if (!ensure_buf(g_bytes, g_bytes_cap, total)) return false;
+        if (!x.copy_in(g_offs, out_off.data(), sizeof(uint64_t) * ((size_t)n + 1)) || !x.gather_bytes(mut(), g_refs, g_offs, n, g_bytes) ||
+            !x.copy_out(out.data(), g_bytes, total))
+            return xfail();
+        return true;
+    }
+    // exact lookup (inspection only -- never used for matching): ids stored under (tenant, MQTT filter)
+    bool find(std::string_view tenant, std::string_view filter, std::vector<uint32_t>& ids) {
+        ids.clear();
+        if (!built) return true;
+        const size_t qn = tenant.size() + filter.size();
+        std::vector<uint8_t> q(qn + 32, 0);
+        if (!tenant.empty()) memcpy(q.data(), tenant.data(), tenant.size());
+        if (!filter.empty()) memcpy(q.data() + tenant.size(), filter.data(), filter.size());
+        if (!ensure_buf(g_bytes, g_bytes_cap, q.size())) return false;
+        uint32_t cap = 1024;
+        for (;;) {
+            if (!ensure_buf(g_ids, g_ids_cap, (size_t)cap + 1)) return false;
+            if (!x.copy_in(g_bytes, q.data(), q.size()) ||
+                !x.find(mut(), g_bytes, (uint32_t)tenant.size(), (uint32_t)filter.size(), g_ids, cap))
+                return xfail();
+            uint32_t cnt = 0;
+            if (!x.copy_out(&cnt, g_ids, sizeof(cnt))) return xfail();
+            if (cnt > cap) {
+                cap = cnt;
+                continue;
+            }
+            ids.resize(cnt);
+            if (cnt && !x.copy_out(ids.data(), g_ids + 1, sizeof(uint32_t) * (size_t)cnt)) return xfail();
+            return true;
+        }
+    }
+    bool stats(DistIndexStats& st) {
+        st = DistIndexStats{};
+        if (!built) return true;
+        if (!read_counters()) return xfail();
+        std::vector<TenantSlot> d(dir_slots);
+        if (!x.copy_out(d.data(), dir, sizeof(TenantSlot) * (size_t)dir_slots)) return xfail();
+        for (auto& t : d) st.n_tenants += ((t.hash_lo | t.hash_hi) != 0 && t.n_routes != 0) ? 1 : 0;
+        st.n_routes = hbc.n_routes;
+        st.n_nodes = hbc.n_nodes;
+        st.n_tokens = hbc.n_tokens;
+        st.trie_slots = trie_used;
+        st.dict_slots = dict_slots;
+        st.id_list_words = hbc.rp_used;
+        st.id_list_garbage = hbc.rp_garbage;
+        st.trie_garbage_slots = trie_garbage;
+        st.key_bytes = kpool_used;
+        st.next_id = next_id;
+        st.bytes = trie_cap * sizeof(TrieSlot) + (uint64_t)dir_slots * sizeof(TenantSlot) + names_cap + (uint64_t)dict_slots * sizeof(DictSlot) +
+                   dpool_cap + rp_cap * 4 + (uint64_t)id_cap * 12 + kpool_cap;
+        return true;
+    }
+
+    void drop() {
+        auto rel = [&](auto*& p) {
+            if (p) x.release((void*)p);
+            p = nullptr;
+        };
+        rel(trie); rel(dir); rel(names); rel(dict); rel(dpool); rel(route_pos); rel(kref); rel(khash); rel(kpool); rel(bc);
+        rel(s_key_off); rel(s_op); rel(s_put_rank); rel(s_dir_slot); rel(s_nn); rel(s_flag); rel(s_target); rel(s_order);
+        rel(s_sorted_target); rel(s_group_done); rel(s_unknown); rel(s_grow); rel(s_bt_first); rel(s_bt_nodes); rel(s_bt_keys); rel(s_bt_dir);
+        rel(g_ids); rel(g_refs); rel(g_offs); rel(g_bytes);
+        trie_cap = trie_used = 0; dir_slots = 0; names_cap = names_used = 0; dict_slots = 0; dpool_cap = 0; rp_cap = 0; id_cap = next_id = 0;
+        kpool_cap = kpool_used = 0; s_cap = 0; s_bt_cap = 0; s_grow_cap = 0; g_ids_cap = g_refs_cap = g_offs_cap = g_bytes_cap = 0;
+        tenant_slot.clear(); free_regions.clear(); dir_h.clear(); names_h.clear(); trie_garbage = 0;
+        built = false;
+    }
+
+private:
+    // ---- scratch in exec memory ----
+    uint32_t *s_key_off = nullptr, *s_put_rank = nullptr, *s_dir_slot = nullptr, *s_nn = nullptr, *s_flag = nullptr, *s_order = nullptr,
+             *s_unknown = nullptr, *s_grow = nullptr, *s_bt_first = nullptr, *s_bt_nodes = nullptr, *s_bt_keys = nullptr, *s_bt_dir = nullptr;
+    uint8_t *s_op = nullptr, *s_group_done = nullptr;
+    unsigned long long *s_target = nullptr, *s_sorted_target = nullptr;
+    size_t s_cap = 0, s_bt_cap = 0, s_grow_cap = 0;
+    uint32_t* g_ids = nullptr;
+    unsigned long long* g_refs = nullptr;
+    uint64_t* g_offs = nullptr;
+    uint8_t* g_bytes = nullptr;
+    size_t g_ids_cap = 0, g_refs_cap = 0, g_offs_cap = 0, g_bytes_cap = 0;
+    // host mirror of the directory (placement only; live counters stay on the exec side) and of the tenant names
+    std::vector<TenantSlot> dir_h;
+    std::vector<uint8_t> names_h;
+    bool dir_dirty = false;
+
+    bool fail(const std::string& m) {
+        error = m;
+        return false;
+    }
+    bool xfail() { return fail(x.err.empty() ? "exec failure" : x.err); }
+    bool broke(const std::string& m) {
+        broken = true;
+        return fail(m);
+    }
+    template <class T> bool ensure_buf(T*& p, size_t& cap, size_t need) { // grow-only, contents dropped
+        if (need <= cap) return true;
+        if (p) x.release(p);
+        const size_t want = need + need / 4 + 64;
+        p = (T*)x.alloc(want * sizeof(T));
+        cap = p ? want : 0;
+        return p ? true : fail("out of memory");
+    }
+    template <class T> bool regrow(T*& p, uint64_t old_n, uint64_t new_n) { // contents [0, old_n) survive
+        T* q = (T*)x.alloc(new_n * sizeof(T) + 16);
+        if (!q) return fail("out of memory");
+        if (p && old_n && !x.copy(q, p, old_n * sizeof(T))) return xfail();
+        if (p) {
+            if (!x.sync()) return xfail();
+            x.release(p);
+        }
+        p = q;
+        return true;
+    }
+    bool read_counters() { return x.copy_out(&hbc, bc, sizeof(BuildCounters)); }
+    bool zero_batch_counters() {
+        const size_t off = offsetof(BuildCounters, err);
+        return x.zero((uint8_t*)bc + off, sizeof(BuildCounters) - off) ? true : xfail();
+    }
+    OpBatch batch(uint32_t n) {
+        OpBatch ob{};
+        ob.key_off = s_key_off;
+        ob.n = n;
+        ob.dir_slot = s_dir_slot;
+        ob.nn = s_nn;
+        ob.flag = s_flag;
+        ob.target = s_target;
+        ob.order = s_order;
+        ob.sorted_target = s_sorted_target;
+        ob.group_done = s_group_done;
+        ob.unknown_list = s_unknown;
+        ob.grow_list = s_grow;
+        ob.bt_first = s_bt_first;
+        ob.bt_nodes = s_bt_nodes;
+        ob.bt_keys = s_bt_keys;
+        ob.bt_dir = s_bt_dir;
+        return ob;
+    }
+    bool ensure_scratch(uint32_t n, bool incremental) {
+        const size_t need = (size_t)n + 1;
+        if (need > s_cap) {
+            auto rel = [&](auto*& p) {
+                if (p) x.release((void*)p);
+                p = nullptr;
+            };
+            rel(s_key_off); rel(s_op); rel(s_put_rank); rel(s_dir_slot); rel(s_nn); rel(s_flag); rel(s_target); rel(s_order);
+            rel(s_sorted_target); rel(s_group_done); rel(s_unknown);
+            const size_t want = need + need / 4 + 64;
+            s_key_off = (uint32_t*)x.alloc(4 * want);
+            s_op = (uint8_t*)x.alloc(want);
+            s_put_rank = (uint32_t*)x.alloc(4 * want);
+            s_dir_slot = (uint32_t*)x.alloc(4 * want);
+            s_nn = (uint32_t*)x.alloc(4 * want);
+            s_flag = (uint32_t*)x.alloc(4 * want);
+            s_target = (unsigned long long*)x.alloc(8 * want);
+            s_order = (uint32_t*)x.alloc(4 * want);
+            s_sorted_target = (unsigned long long*)x.alloc(8 * want);
+            s_group_done = (uint8_t*)x.alloc(want);
+            s_unknown = (uint32_t*)x.alloc(4 * want);
+            if (!s_key_off || !s_op || !s_put_rank || !s_dir_slot || !s_nn || !s_flag || !s_target || !s_order || !s_sorted_target ||
+                !s_group_done || !s_unknown) {
+                s_cap = 0;
+                return fail("out of memory (builder scratch)");
+            }
+            s_cap = want;
+        }
+        (void)incremental;
+        const size_t gneed = 2 * (size_t)std::max<uint32_t>(dir_slots, 64);
+        if (gneed > s_grow_cap) {
+            if (s_grow) x.release(s_grow);
+            s_grow = (uint32_t*)x.alloc(4 * gneed);
+            s_grow_cap = s_grow ? gneed : 0;
+            if (!s_grow) return fail("out of memory (builder scratch)");
+        }
+        return true;
+    }
+    void release_scratch() { // after a bulk load: 10M-key scratch is not worth keeping
+        auto rel = [&](auto*& p) {
+            if (p) x.release((void*)p);
+            p = nullptr;
+        };
+        rel(s_key_off); rel(s_op); rel(s_put_rank); rel(s_dir_slot); rel(s_nn); rel(s_flag); rel(s_target); rel(s_order);
+        rel(s_sorted_target); rel(s_group_done); rel(s_unknown); rel(s_bt_first); rel(s_bt_nodes); rel(s_bt_keys); rel(s_bt_dir);
+        s_cap = 0;
+        s_bt_cap = 0;
+    }
+    bool ensure_keys(uint64_t more) {
+        const uint64_t need = kpool_used + more + 32;
+        if (need <= kpool_cap) return true;
+        if (need >= (1ull << KREF_LEN_SHIFT)) return fail("key store exceeds 1 TB");
+        const uint64_t cap = tiny ? need : std::max<uint64_t>(need + need / 2, 1u << 20);
+        if (!regrow(kpool, kpool_used, cap)) return false;
+        kpool_cap = cap;
+        return true;
+    }
+    bool ensure_ids(uint64_t need) {
+        if (need <= id_cap) return true;
+        const uint64_t cap = tiny ? need : std::min<uint64_t>(std::max<uint64_t>(need + need / 2, 1u << 16), 0xFFFFFFF0ull);
+        if (!regrow(kref, id_cap, cap) || !regrow(khash, id_cap, cap)) return false;
+        if (!x.zero(kref + id_cap, (cap - id_cap) * sizeof(unsigned long long))) return xfail();
+        id_cap = (uint32_t)cap;
+        return true;
+    }
+    bool grow_route_pos(uint64_t need) {
+        if (need <= rp_cap) return true;
+        if (need >= 0x7FFFFFF0ull) return fail("id-list pool exceeds 2^31 words: bmq_rebuild compacts it");
+        const uint64_t cap = tiny ? need : std::min<uint64_t>(std::max<uint64_t>(need + need / 2, 1u << 16), 0x7FFFFFF0ull);
+        if (!regrow(route_pos, std::min<uint64_t>(rp_cap, hbc.rp_used ? hbc.rp_used : rp_cap), cap)) return false;
+        rp_cap = cap;
+        return true;
+    }
+    // dictionary of `slots` slots (power of two) + string pool of `pool` bytes; existing entries are re-inserted
+    bool grow_dict(uint64_t slots, uint64_t pool) {
+        if (slots > (1ull << 30)) return fail("level dictionary exceeds 2^30 slots");
+        uint32_t ns = tiny ? 4 : 64;
+        while (ns < slots) ns <<= 1;
+        DictSlot* nd = (DictSlot*)x.alloc((size_t)ns * sizeof(DictSlot));
+        if (!nd) return fail("out of memory (dictionary)");
+        if (!x.zero(nd, (size_t)ns * sizeof(DictSlot))) return xfail();
+        const uint32_t np = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pool, dpool_cap), 0xFFFFFF00ull);
+        if (np > dpool_cap) {
+            if (!read_counters()) return xfail();
+            if (!regrow(dpool, std::min<uint32_t>(hbc.dpool_used, dpool_cap), np)) return false;
+            dpool_cap = np;
+        }
+        DictSlot* old = dict;
+        const uint32_t old_slots = dict_slots;
+        dict = nd;
+        dict_slots = ns;
+        if (old) {
+            if (!x.dict_rehash(old, old_slots, mut()) || !x.sync()) return xfail();
+            x.release(old);
+        }
+        return true;
+    }
+    // ---- tenants ----
+    static uint64_t hash_name(std::string_view s) {
+        uint64_t h = TENANT_HASH_INIT;
+        for (unsigned char c : s) h = tenant_hash_step(h, c);
+        return tenant_hash_final(h);
+    }
+    bool ensure_directory(size_t n_tenants) { // load factor <= 1/2; growing re-places every entry (live counters come back first)
+        if (dir_slots && n_tenants * 2 <= dir_slots) return true;
+        if (dir_dirty && !flush_directory()) return false; // entries created but not uploaded yet must survive the re-placement
+        uint32_t ns = tiny ? 2 : 64;
+        while ((size_t)ns < n_tenants * 2 + 2) ns <<= 1;
+        std::vector<TenantSlot> old;
+        if (dir) {
+            old.resize(dir_slots);
+            if (!x.copy_out(old.data(), dir, sizeof(TenantSlot) * (size_t)dir_slots)) return xfail();
+            x.release(dir);
+            dir = nullptr;
+        }
+        dir_h.assign(ns, TenantSlot{});
+        for (auto& t : old)
+            if (t.hash_lo | t.hash_hi) place(t, ns);
+        dir = (TenantSlot*)x.alloc(sizeof(TenantSlot) * (size_t)ns);
+        if (!dir) return fail("out of memory (tenant directory)");
+        dir_slots = ns;
+        tenant_slot.clear();
+        for (uint32_t d = 0; d < ns; d++)
+            if (dir_h[d].hash_lo | dir_h[d].hash_hi)
+                tenant_slot[std::string((const char*)names_h.data() + dir_h[d].name_off, dir_h[d].name_len)] = d;
+        if (!x.copy_in(dir, dir_h.data(), sizeof(TenantSlot) * (size_t)ns)) return xfail();
+        dir_dirty = false;
+        if (s_grow_cap < 2 * (size_t)ns) {
+            if (s_grow) x.release(s_grow);
+            s_grow = (uint32_t*)x.alloc(8 * (size_t)ns);
+            s_grow_cap = s_grow ? 2 * (size_t)ns : 0;
+            if (!s_grow) return fail("out of memory (builder scratch)");
+        }
+        return true;
+    }
+    uint32_t place(const TenantSlot& t, uint32_t ns) {
+        uint32_t d = (t.hash_lo ^ t.hash_hi) & (ns - 1);
+        while (dir_h[d].hash_lo | dir_h[d].hash_hi) d = (d + 1) & (ns - 1);
+        dir_h[d] = t;
+        return d;
+    }
+    // a region of `slots` free (FREE_SLOT-filled) slots; NONE64 on failure
+    bool alloc_region(uint64_t slots, uint64_t& base) {
+        for (size_t i = 0; i < free_regions.size(); i++)
+            if (free_regions[i].second >= slots && free_regions[i].second <= slots + slots / 2) { // reuse a region of similar size
+                base = free_regions[i].first;
+                const uint64_t got = free_regions[i].second;
+                free_regions.erase(free_regions.begin() + (long)i);
+                trie_garbage -= got;
+                if (!x.fill_slots(trie + base, got)) return xfail();
+                return true;
+            }
+        if (trie_used + slots > trie_cap) {
+            if (trie_used + slots >= 0xFFFFFFF0ull) return fail("trie too large (2^32 slots): bmq_rebuild compacts it");
+            const uint64_t cap = tiny ? trie_used + slots : std::min<uint64_t>(std::max<uint64_t>((trie_used + slots) * 2, 1u << 16), 0xFFFFFFF0ull);
+            if (!regrow(trie, trie_used, cap)) return false;
+            if (!x.fill_slots(trie + trie_used, cap - trie_used)) return xfail();
+            trie_cap = cap;
+        }
+        base = trie_used;
+        trie_used += slots;
+        return true;
+    }
+    uint32_t buckets_for(uint64_t nodes) const { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nodes + (tiny ? 0 : nodes / 4 + 2), tiny ? 1 : 8), 0x7FFFFFF0ull); }
+    // new tenant with room for `nodes` nodes; written to the host mirror (flush_directory uploads)
+    bool create_tenant(const std::string& name, uint64_t nodes, uint32_t n_routes) {
+        if (tenant_slot.count(name)) return true;
+        if (!ensure_directory(tenant_slot.size() + 1)) return false;
+        const uint32_t buckets = buckets_for(nodes);
+        uint64_t base;
+        if (!alloc_region(2ull * buckets, base)) return false;
+        const uint64_t h = hash_name(name);
+        TenantSlot t{};
+        t.hash_lo = (uint32_t)h;
+        t.hash_hi = (uint32_t)(h >> 32);
+        t.name_off = (uint32_t)names_h.size();
+        t.name_len = (uint32_t)name.size();
+        t.base = (uint32_t)base;
+        t.buckets = buckets;
+        t.n_routes = n_routes;
+        names_h.insert(names_h.end(), name.begin(), name.end());
+        const uint32_t d = place(t, dir_slots);
+        tenant_slot[name] = d;
+        new_dir_slots.push_back(d);
+        dir_dirty = true;
+        return true;
+    }
+    std::vector<uint32_t> new_dir_slots;
+    bool flush_directory() { // upload the entries created since the last flush + the name pool
+        if (names_h.size() + 16 > names_cap) {
+            const uint32_t cap = (uint32_t)std::max<size_t>(names_h.size() * 2 + 64, 4096);
+            if (names) {
+                if (!x.sync()) return xfail();
+                x.release(names);
+            }
+            names = (uint8_t*)x.alloc(cap);
+            if (!names) return fail("out of memory (tenant names)");
+            names_cap = cap;
+            names_used = 0;
+        }
+        if (names_h.size() > names_used) {
+            if (!x.copy_in(names + names_used, names_h.data() + names_used, names_h.size() - names_used)) return xfail();
+            names_used = (uint32_t)names_h.size();
+        }
+        for (uint32_t d : new_dir_slots)
+            if (!x.copy_in(dir + d, &dir_h[d], sizeof(TenantSlot))) return xfail();
+        new_dir_slots.clear();
+        dir_dirty = false;
+        return true;
+    }
+    // regions listed by prepare_check (hbc.n_grow entries in ob.grow_list): move each into a larger region
+    bool grow_flagged_regions(const OpBatch& ob) {
+        if (hbc.n_grow == 0) return true;
+        std::vector<uint32_t> gl(2 * (size_t)hbc.n_grow);
+        if (!x.copy_out(gl.data(), ob.grow_list, sizeof(uint32_t) * gl.size())) return xfail();
+        for (uint32_t g = 0; g < hbc.n_grow; g++) {
+            const uint32_t d = gl[2 * g];
+            TenantSlot t;
+            if (!x.copy_out(&t, dir + d, sizeof(TenantSlot))) return xfail();
+            const uint64_t need = std::max<uint64_t>(gl[2 * g + 1], (uint64_t)t.n_nodes + 1);
+            const uint32_t nb = std::max<uint32_t>(buckets_for(need + need / 2), t.buckets < 0x3FFFFFFFu ? t.buckets * 2 : t.buckets);
+            uint64_t base;
+            if (!alloc_region(2ull * nb, base)) return false;
+            if (!x.rehash(mut(), t.base, 2 * t.buckets, (uint32_t)base, nb)) return xfail();
+            const uint32_t upd[2] = {(uint32_t)base, nb};
+            if (!x.copy_in(&dir[d].base, upd, sizeof(upd))) return xfail(); // base and buckets are adjacent
+            dir_h[d].base = (uint32_t)base;
+            dir_h[d].buckets = nb;
+            free_regions.push_back({t.base, 2ull * t.buckets});
+            trie_garbage += 2ull * t.buckets;
+        }
+        if (!read_counters()) return xfail();
+        if (hbc.err & ERR_REGION_FULL) return broke("region growth failed");
+        hbc.n_grow = 0;
+        return true;
+    }
+    bool reset_empty() { // an index with no routes (apply on a fresh engine)
+        uint32_t err = 0;
+        static const uint32_t zero_off[1] = {0};
+        if (!rebuild_sorted(nullptr, zero_off, 0, err)) return false;
+        built = true;
+        generation++;
+        return true;
+    }
+    static void sort_unique(const uint8_t* keys, const uint32_t* key_off, uint32_t n, std::vector<uint8_t>& bytes, std::vector<uint32_t>& off) {
+        std::vector<std::string_view> v(n);
+        for (uint32_t i = 0; i < n; i++) v[i] = std::string_view((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
+        auto less = [](std::string_view a, std::string_view b) {
+            const size_t m = std::min(a.size(), b.size());
+            const int c = m ? memcmp(a.data(), b.data(), m) : 0;
+            return c < 0 || (c == 0 && a.size() < b.size());
+        };
+        std::sort(v.begin(), v.end(), less);
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        bytes.clear();
+        off.assign(1, 0);
+        for (auto& k : v) {
+            bytes.insert(bytes.end(), k.begin(), k.end());
+            off.push_back((uint32_t)bytes.size());
+        }
+        bytes.resize(bytes.size() + 16, 0);
+    }
+
+    // the bulk pipeline on strictly ascending keys; err receives the builder's error flags
+    bool rebuild_sorted(const uint8_t* keys, const uint32_t* key_off, uint32_t n, uint32_t& err) {
+        drop();
+        const uint64_t kb = n ? key_off[n] : 0;
+        bc = (BuildCounters*)x.alloc(sizeof(BuildCounters));
+        if (!bc) return fail("out of memory");
+        BuildCounters init{};
+        init.rp_used = 1; // word 0 is never handed out: 0 means "no list"
+        if (!x.copy_in(bc, &init, sizeof(init))) return xfail();
+        kpool_used = 16; // offset 0 is never a key: kref == 0 means "no such route"
+        if (!ensure_keys(tiny ? kb : kb + kb / 2 + (1u << 20)) || !ensure_ids(tiny ? n : (uint64_t)n + n / 2 + (1u << 16))) return false;
+        if (!x.zero(kpool, 16)) return xfail();
+        if (!grow_dict(tiny ? 64 : 1u << 16, tiny ? 64 : 1u << 20)) return false;
+        if (!grow_route_pos(tiny ? 8 : 1u << 16)) return false;
+        if (!ensure_directory(tiny ? 1 : 64)) return false;
+        next_id = 0;
+        if (n == 0) {
+            if (!x.sync()) return xfail();
+            return true;
+        }
+        if (!ensure_scratch(n, false)) return false;
+        OpBatch ob = batch(n);
+        ob.key_base = kpool_used;
+        ob.id_base = 0;
+        ob.put_rank = nullptr;
+        ob.op = nullptr;
+        ob.bulk = 1;
+        if (!x.copy_in_async(kpool + kpool_used, keys, kb) || !x.copy_in_async(s_key_off, key_off, sizeof(uint32_t) * ((size_t)n + 1)))
+            return xfail();
+        // ---- sizes: tenants (runs of the sorted scan) and their exact node counts ----
+        if (!zero_batch_counters()) return false;
+        DistIndexMut ix = mut();
+        if (!x.bulk_prepare(ix, ob) || !x.scan_flags(ob.flag, ob.order, n) || !read_counters()) return xfail();
+        err = hbc.err;
+        if (hbc.err & ERR_BAD_KEY) return fail("malformed route key");
+        if (hbc.err & ERR_UNSORTED) return fail("keys are not strictly ascending");
+        uint32_t n_ten = 0;
+        if (!x.copy_out(&n_ten, ob.order + (n - 1), sizeof(uint32_t))) return xfail();
+        if (n_ten > s_bt_cap) {
+            auto rel = [&](auto*& p) {
+                if (p) x.release((void*)p);
+                p = nullptr;
+            };
+            rel(s_bt_first); rel(s_bt_nodes); rel(s_bt_keys); rel(s_bt_dir);
+            const size_t want = (size_t)n_ten + 64;
+            s_bt_first = (uint32_t*)x.alloc(4 * want);
+            s_bt_nodes = (uint32_t*)x.alloc(4 * want);
+            s_bt_keys = (uint32_t*)x.alloc(4 * want);
+            s_bt_dir = (uint32_t*)x.alloc(4 * want);
+            if (!s_bt_first || !s_bt_nodes || !s_bt_keys || !s_bt_dir) return fail("out of memory (builder scratch)");
+            s_bt_cap = want;
+            ob = batch(n);
+            ob.key_base = kpool_used;
+            ob.bulk = 1;
+        }
+        if (!x.zero(s_bt_nodes, 4 * (size_t)n_ten) || !x.zero(s_bt_keys, 4 * (size_t)n_ten)) return xfail();
+        if (!x.bulk_tenants(ix, ob, ob.order)) return xfail();
+        std::vector<uint32_t> bt_first(n_ten), bt_nodes(n_ten), bt_keys(n_ten), bt_dir(n_ten);
+        if (!x.copy_out(bt_first.data(), s_bt_first, 4 * (size_t)n_ten) || !x.copy_out(bt_nodes.data(), s_bt_nodes, 4 * (size_t)n_ten) ||
+            !x.copy_out(bt_keys.data(), s_bt_keys, 4 * (size_t)n_ten))
+            return xfail();
+        // ---- tenants + regions ----
+        if (!ensure_directory(n_ten)) return false;
+        uint64_t total_slots = 0;
+        for (uint32_t t = 0; t < n_ten; t++) total_slots += 2ull * buckets_for(bt_nodes[t]);
+        {
+            if (total_slots >= 0xFFFFFFF0ull) return fail("trie too large (2^32 slots)");
+            const uint64_t cap = tiny ? total_slots + 2 : std::min<uint64_t>(total_slots + total_slots / 4 + (1u << 16), 0xFFFFFFF0ull); // head-room: new tenants, growth
+            trie = (TrieSlot*)x.alloc(cap * sizeof(TrieSlot));
+            if (!trie) return fail("out of device memory (trie)");
+            trie_cap = cap;
+            trie_used = 0;
+            if (!x.fill_slots(trie, cap)) return xfail();
+        }
+        for (uint32_t t = 0; t < n_ten; t++) {
+            const uint32_t ko = key_off[bt_first[t]];
+            const size_t tlen = ((size_t)keys[ko + 1] << 8) | keys[ko + 2];
+            const std::string name((const char*)keys + ko + 3, tlen);
+            if (tenant_slot.count(name)) return fail("keys are not strictly ascending"); // cannot happen after the order check
+            if (!create_tenant(name, bt_nodes[t], bt_keys[t])) return false;
+            bt_dir[t] = tenant_slot[name];
+        }
+        if (!flush_directory()) return false;
+        if (!x.copy_in(s_bt_dir, bt_dir.data(), 4 * (size_t)n_ten)) return xfail();
+        // ---- locate (re-run with a larger dictionary if it filled up), sort, groups ----
+        for (int attempt = 0;; attempt++) {
+            if (attempt == 10) return fail("rebuild: dictionary growth did not converge");
+            if (!zero_batch_counters()) return false;
+            ix = mut();
+            if (!x.locate(ix, ob) || !read_counters()) return xfail();
+            if (hbc.err & (ERR_STUCK | ERR_REGION_FULL)) return fail("rebuild: trie construction failed");
+            if (!(hbc.err & ERR_DICT_FULL)) break;
+            if (!grow_dict((uint64_t)dict_slots * 4, (uint64_t)dpool_cap * 4)) return false;
+        }
+        if (!x.zero(ob.group_done, n) || !x.sort_targets(ob)) return xfail();
+        for (int attempt = 0;; attempt++) {
+            if (attempt == 8) return fail("rebuild: id-list pool growth did not converge");
+            if (!zero_batch_counters()) return false;
+            ix = mut();
+            if (!x.group(ix, ob) || !read_counters()) return xfail();
+            if (hbc.err) return fail("rebuild: group step failed");
+            if (hbc.n_deferred == 0) break;
+            if (!grow_route_pos(hbc.rp_used + 2 * hbc.rp_need + 1024)) return false;
+        }
+        const unsigned long long nr = n;
+        if (!x.copy_in(&bc->n_routes, &nr, sizeof(nr))) return xfail();
+        kpool_used += (kb + 15) & ~15ull;
+        next_id = n;
+        // right-size the dictionary: load factor 1/4 keeps a lookup at one line, a small table stays cache resident
+        {
+            uint64_t want = 4096;
+            while (want < (uint64_t)hbc.n_tokens * 4) want <<= 1;
+            if (want != dict_slots && !grow_dict(want, dpool_cap)) return false;
+        }
+        if (!x.sync()) return xfail();
+        release_scratch();
+        return true;
+    }
+};
+
+} // namespace bmq

@@ -12,8 +12,8 @@
 //                       them level by level: every lane scans its own next level (LDS only), then ALL lanes look
 //                       their level up in the dictionary together -- one memory latency per level, not per lane.
 //                       Phase 2: the wave drains a depth-first LDS work stack of (node, topic, level, kind) items,
-//                       one item per lane per round; an item reads one 64-byte bucket (literal child lookup, the
-//                       child's header comes with it) or one 32-byte slot ('+' child / tenant root by slot index).
+//                       one item per lane per round; an item reads one 64-byte bucket: the home bucket of the edge
+//                       (node id, token of the topic's level) or (node id, '+') -- the child's header comes with it.
 //                       Pushes and matches are compacted with ballot + mbcnt.
 //                       Phase 3: matched (begin,count) ranges are counting-sorted by topic and written out.
 //   k_walk_slow       : per-lane DFS with global scratch for topics the LDS path could not finish
@@ -151,7 +151,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __device__ __forceinline__ TrieSlot unpack_slot(const uint4& a, const uint4& b) {
     TrieSlot s;
     s.parent = a.x; s.token = a.y; s.own_begin = a.z; s.own_count = a.w;
-    s.hash_begin = b.x; s.hash_count = b.y; s.plus_child = b.z; s.lit_bloom = b.w;
+    s.hash_begin = b.x; s.hash_count = b.y; s.node = b.z; s.lit_bloom = b.w;
     return s;
 }
 // One aligned 64-byte line = one trie bucket (two TrieSlots) or one dictionary group (two DictSlots), requested with
@@ -246,31 +246,32 @@ __device__ __forceinline__ uint32_t global_word_at(const uint8_t* base, uint32_t
 // ------------------------------------------------------------------------------------------------------------
 // k_resolve_tenants
 // ------------------------------------------------------------------------------------------------------------
+constexpr TenantSlot EMPTY_TENANT{0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}};
+__device__ __forceinline__ bool tenant_known(const TenantSlot& t) { return (t.hash_lo | t.hash_hi) != 0; }
+
 __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a.n_tenants) return;
     const uint8_t* base = a.tenants;
-    auto byte_at = [&](uint32_t k) -> uint32_t { return base[k]; };
-    auto word_at = [&](uint32_t k) -> uint32_t { return global_word_at(base, k); };
-    uint32_t pos = a.tenant_off[i];
-    const uint32_t start = pos, end = a.tenant_off[i + 1];
-    LevelHash h;
-    uint32_t inl[4], len;
-    bool last;
-    scan_level(pos, end, false, word_at, h, inl, len, last);
-    const uint32_t tok = dict_lookup(a.ix, h, len, inl, start, byte_at);
+    const uint32_t beg = a.tenant_off[i], end = a.tenant_off[i + 1], len = end - beg;
+    uint64_t h = TENANT_HASH_INIT;
+    for (uint32_t k = beg; k < end; k++) h = tenant_hash_step(h, base[k]);
+    h = tenant_hash_final(h);
+    const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
     TenantSlot info = EMPTY_TENANT;
-    if (tok != TOK_UNKNOWN) {
-        uint32_t d = tenant_hash(tok) & a.ix.tenant_mask;
-        for (uint32_t probes = 0; probes <= a.ix.tenant_mask; probes++) {
-            const TenantSlot t = a.ix.tenants[d];
-            if (t.token == tok) {
+    uint32_t d = (lo ^ hi) & a.ix.tenant_mask;
+    for (uint32_t probes = 0; probes <= a.ix.tenant_mask; probes++) {
+        const TenantSlot t = a.ix.tenants[d];
+        if (!tenant_known(t)) break;
+        if (t.hash_lo == lo && t.hash_hi == hi && t.name_len == len) { // the id's bytes decide
+            bool eq = true;
+            for (uint32_t k = 0; k < len && eq; k++) eq = a.ix.tenant_names[t.name_off + k] == base[beg + k];
+            if (eq) {
                 info = t;
                 break;
             }
-            if (t.token == 0) break;
-            d = (d + 1) & a.ix.tenant_mask;
         }
+        d = (d + 1) & a.ix.tenant_mask;
     }
     a.tenant_info[i] = info;
 }
@@ -278,10 +279,10 @@ __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // the per-item step shared by the LDS path and the slow path
 // ------------------------------------------------------------------------------------------------------------
-// item = (node slot, meta); meta: bits 0-5 topic-local index, bits 6-29 level, bit 31 kind
-//   kind L (0): probe the literal child of `node` with the topic's token at `level`
-//   kind H (1): `node` is itself the slot to visit ('+' child or tenant root), reached after `level` tokens
-constexpr uint32_t KIND_H = 0x80000000u;
+// item = (node id, meta); meta: bits 0-5 topic-local index, bits 6-29 level, bit 31 kind
+//   kind L (0): probe the child of `node` labelled with the topic's token at `level`
+//   kind P (1): probe the '+' child of `node` (it consumes the topic's level `level` whatever its token)
+constexpr uint32_t KIND_P = 0x80000000u;
 __device__ __forceinline__ uint32_t make_meta(uint32_t tl, uint32_t level, uint32_t kind) { return tl | (level << 6) | kind; }
 __device__ __forceinline__ uint32_t meta_level(uint32_t m) { return (m >> 6) & 0xFFFFFFu; }
 
@@ -293,19 +294,15 @@ struct StepOut {
     TrieSlot s;
 };
 
-// Both item kinds read ONE bucket line: kind L the home bucket of edge (node, token) -- which holds the child's complete
-// slot --, kind H the bucket that contains slot `node`.  Slots are region-relative; regions start on a bucket boundary.
-__device__ __forceinline__ uint32_t item_bucket(bool kind_h, uint32_t node, uint32_t tok, uint32_t buckets) {
-    return kind_h ? (node >> 1) : edge_bucket(node, tok, buckets);
-}
-// ln = bucket `bk` of the item (already loaded).  tok = the topic's token at `level` (kind L only).
+// Both item kinds read ONE bucket line: the home bucket of edge (node, token) -- which holds the child's complete slot.
+// ln = bucket `bk` of the item (already loaded).  tok = the edge label: the topic's token at `level`, or TOK_PLUS.
 // tok_at(level): the topic's token at that level; nlev: level count; sys: first level starts with '$'
 template <class TokAt>
-__device__ __forceinline__ void resolve_item(const DistIndexView& ix, Line64 ln, bool live, bool kind_h, uint32_t node,
+__device__ __forceinline__ void resolve_item(const DistIndexView& ix, Line64 ln, bool live, uint32_t node,
                                              uint32_t tok, uint32_t bk, uint32_t rbase, uint32_t rbuckets, uint32_t level,
                                              uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
-    bool m0 = kind_h ? ((node & 1u) == 0) : (ln.a0.x == node && ln.a0.y == tok);
-    bool m1 = kind_h ? ((node & 1u) != 0) : (ln.b0.x == node && ln.b0.y == tok);
+    bool m0 = ln.a0.x == node && ln.a0.y == tok;
+    bool m1 = ln.b0.x == node && ln.b0.y == tok;
     bool more = live && !m0 && !m1 && ln.a0.x != NONE && ln.b0.x != NONE;
     // home bucket full of other edges (rare at load factor 1/2): first-free probing continues.  Bounded by the region size so
     // that not even a damaged image can hang the GPU.
@@ -318,27 +315,27 @@ __device__ __forceinline__ void resolve_item(const DistIndexView& ix, Line64 ln,
     }
     o.found = live && (m0 || m1);
     o.s = m1 ? unpack_slot(ln.b0, ln.b1) : unpack_slot(ln.a0, ln.a1);
-    o.idx = kind_h ? node : 2 * bk + (m1 ? 1u : 0u);
-    o.dl = kind_h ? level : level + 1;
-    const bool root_sys = (o.dl == 0) && sys; // wildcards in filter position 0 never match a '$' topic
+    o.idx = o.s.node; // the child's node id: the parent key of its own children
+    o.dl = level + 1; // >= 1: the '$' rule (wildcards in filter position 0) is the caller's business at the root only
     o.emit_own = o.found && (o.dl == nlev) && o.s.own_count != 0;
-    o.emit_hash = o.found && o.s.hash_count != 0 && !root_sys; // "<path>/#" matches whatever follows, also nothing
+    o.emit_hash = o.found && o.s.hash_count != 0; // "<path>/#" matches whatever follows, also nothing
     o.push_l = o.push_h = false;
     if (o.found && o.dl < nlev) {
         const uint32_t t = tok_at(o.dl);
         o.push_l = t != TOK_UNKNOWN && ((o.s.lit_bloom >> bloom_bit(t)) & 1u);
-        o.push_h = o.s.plus_child != NONE && !root_sys;
+        o.push_h = (o.s.lit_bloom & BLOOM_PLUS) != 0;
     }
+    (void)sys;
 }
 
 template <class TokAt>
 __device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantSlot& rg, uint32_t node, uint32_t level,
-                                          bool kind_h, uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
-    const uint32_t tok = kind_h ? 0u : tok_at(level);
-    const uint32_t bk = item_bucket(kind_h, node, tok, rg.buckets);
+                                          bool kind_p, uint32_t nlev, bool sys, TokAt&& tok_at, StepOut& o) {
+    const uint32_t tok = kind_p ? TOK_PLUS : tok_at(level);
+    const uint32_t bk = edge_bucket(node, tok, rg.buckets);
     Line64 ln;
-    load_line64(ix.trie + rg.base + 2 * bk, ln);
-    resolve_item(ix, ln, true, kind_h, node, tok, bk, rg.base, rg.buckets, level, nlev, sys, tok_at, o);
+    load_line64(ix.trie + rg.base + 2 * (size_t)bk, ln);
+    resolve_item(ix, ln, true, node, tok, bk, rg.base, rg.buckets, level, nlev, sys, tok_at, o);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -352,7 +349,7 @@ constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9;
 constexpr uint32_t WALK_WAVES = BMQ_WALK_WAVES; // waves per k_walk workgroup
 
 __host__ __device__ inline size_t walk_union_words(uint32_t qcap, uint32_t pcap) { return 2 * (size_t)qcap + 3 * (size_t)pcap; }
-constexpr uint32_t WALK_TOPIC_WORDS = 8 * 64; // per-topic arrays, behind the union
+constexpr uint32_t WALK_TOPIC_WORDS = 6 * 64; // per-topic arrays, behind the union
 __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
     return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + WALK_TOPIC_WORDS + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
 }
@@ -376,7 +373,6 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     uint32_t* cnt_routes = cnt_pairs + 64;                    // [64]
     uint32_t* cursor = cnt_routes + 64;                       // [64]
     uint2* t_region = reinterpret_cast<uint2*>(cursor + 64);  // [64] (region base, buckets) of each topic's tenant
-    uint2* t_ids = t_region + 64;                             // [64] (route id base, route_pos base)
     const uint32_t stage_bytes = (uint32_t)(walk_union_words(a.qcap, a.pcap) + WALK_TOPIC_WORDS) * 4u;
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -419,7 +415,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
         tbytes = end - pos;
         const uint32_t ti = a.topic_tenant[t];
         if (ti < a.n_tenants) rg = a.tenant_info[ti];
-        more = rg.token != TOK_UNKNOWN; // unknown tenant: no routes, nothing to tokenise
+        more = tenant_known(rg); // unknown tenant: no routes, nothing to tokenise
         sys = more && end > pos && byte_at(pos) == '$';
     }
     for (uint32_t l = 0; __any(more); l++) {
@@ -434,7 +430,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
             more = !last;
         }
     }
-    const bool known = valid && rg.token != TOK_UNKNOWN;
+    const bool known = valid && tenant_known(rg);
     const bool deep = nlev > FAST_LEVELS;
     const bool active = known && !deep;
     wave_sync(); // staged bytes are dead from here on: the area becomes stack + range buffer + per-topic arrays
@@ -442,7 +438,6 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     cnt_pairs[lane] = 0;
     cnt_routes[lane] = 0;
     t_region[lane] = make_uint2(rg.base, rg.buckets);
-    t_ids[lane] = make_uint2(rg.rank_base, rg.rp_base);
 
     // ---- phase 2: drain the work stack ----------------------------------------------------------------------------
     // The work list is a STACK (newest items first): depth-first order keeps it at a few pending siblings per topic,
@@ -486,14 +481,14 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
         if (boot) {
             boot = false;
             o.found = active;
-            o.idx = rg.root;
+            o.idx = 0; // the tenant root's node id
             o.dl = 0;
-            o.s = TrieSlot{ROOT_PARENT, 0, 0, 0, rg.root_hash_begin, rg.root_hash_count, rg.root_plus_child, rg.root_lit_bloom};
+            o.s = TrieSlot{NONE, 0, 0, 0, rg.root_hash_begin, rg.root_hash_count, 0, rg.root_lit_bloom};
             o.emit_own = false; // a topic has at least one level
             o.emit_hash = active && rg.root_hash_count != 0 && !sys; // the filter "#"; never for '$' topics
             const uint32_t t0 = active ? tokens[lane] : TOK_UNKNOWN;
             o.push_l = active && t0 != TOK_UNKNOWN && ((rg.root_lit_bloom >> bloom_bit(t0)) & 1u);
-            o.push_h = active && rg.root_plus_child != NONE && !sys;
+            o.push_h = active && (rg.root_lit_bloom & BLOOM_PLUS) != 0 && !sys; // a first-level '+' never matches a '$' topic
         } else {
             const uint32_t take = tail < 64u ? tail : 64u;
             tail -= take;
@@ -507,18 +502,18 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
                 tmv = tmeta[meta & 63u];
             }
             tl = meta & 63u;
-            const bool kh = (meta & KIND_H) != 0;
+            const bool kp = (meta & KIND_P) != 0;
             uint2 reg = make_uint2(0u, 1u);
-            uint32_t tok = 0;
+            uint32_t tok = TOK_PLUS;
             if (live) {
                 reg = t_region[tl];
-                if (!kh) tok = tokens[meta_level(meta) * 64 + tl];
+                if (!kp) tok = tokens[meta_level(meta) * 64 + tl];
             }
-            const uint32_t bk = item_bucket(kh, node, tok, reg.y);
+            const uint32_t bk = edge_bucket(node, tok, reg.y);
             Line64 ln;
-            load_line64(a.ix.trie + (live ? reg.x + 2 * bk : 0u), ln);
+            load_line64(a.ix.trie + (live ? (size_t)reg.x + 2 * (size_t)bk : (size_t)0), ln);
             const uint32_t tlc = tl;
-            resolve_item(a.ix, ln, live, kh, node, tok, bk, reg.x, reg.y, meta_level(meta), tmv & 0xFFu, (tmv & TM_SYS) != 0,
+            resolve_item(a.ix, ln, live, node, tok, bk, reg.x, reg.y, meta_level(meta), tmv & 0xFFu, (tmv & TM_SYS) != 0,
                          [&](uint32_t l) { return tokens[l * 64 + tlc]; }, o);
             my_visits += o.found ? 1u : 0u;
         }
@@ -542,16 +537,15 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
                 pcount = 0;
                 wave_sync();
             }
-            const uint2 ids = t_ids[tl];
             if (o.emit_own) {
                 const uint32_t p = pcount + rank_below(m_own);
-                p_begin[p] = o.s.own_begin + ((o.s.own_count & RANGE_INDIRECT) ? ids.y : ids.x);
+                p_begin[p] = o.s.own_begin;
                 p_count[p] = o.s.own_count;
                 p_topic[p] = tl;
             }
             if (o.emit_hash) {
                 const uint32_t p = pcount + n_own + rank_below(m_hash);
-                p_begin[p] = o.s.hash_begin + ((o.s.hash_count & RANGE_INDIRECT) ? ids.y : ids.x);
+                p_begin[p] = o.s.hash_begin;
                 p_count[p] = o.s.hash_count;
                 p_topic[p] = tl;
             }
@@ -578,8 +572,8 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
             }
             if (o.push_h) {
                 const uint32_t p = tail + n_l + rank_below(m_h);
-                q_node[p] = o.s.plus_child;
-                q_meta[p] = make_meta(tl, o.dl + 1, KIND_H);
+                q_node[p] = o.idx;
+                q_meta[p] = make_meta(tl, o.dl, KIND_P);
             }
             tail += n_push;
         }
@@ -677,7 +671,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         const uint32_t ti = a.topic_tenant[t];
         if (ti >= a.n_tenants) continue;
         const TenantSlot rg = a.tenant_info[ti];
-        if (rg.token == TOK_UNKNOWN) continue;
+        if (!tenant_known(rg)) continue;
         // level count first (cheap scan), then scratch: nlev tokens + stack of 2-word entries.  A DFS pop pushes at most
         // two items one level deeper: <= 1 pending sibling per level + 2.
         uint32_t nlev = 1;
@@ -706,27 +700,44 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         uint32_t np = 0, nr = 0, visits = 0;
         bool ok = true;
         for (int pass = 0; pass < 2 && ok; pass++) {
-            uint32_t sp = 1, wp = 0;
-            stack[0] = rg.root;
-            stack[1] = make_meta(0, 0, KIND_H);
+            uint32_t sp = 0, wp = 0;
+            { // the tenant root: its payload is in the directory entry
+                if (rg.root_hash_count != 0 && !sys) { // the filter "#"; never for '$' topics
+                    if (pass == 0) {
+                        np++;
+                        nr += rg.root_hash_count & ~RANGE_INDIRECT;
+                    } else a.pairs[base + wp++] = MatchRange{rg.root_hash_begin, rg.root_hash_count};
+                }
+                const uint32_t t0 = toks[0];
+                if (t0 != TOK_UNKNOWN && ((rg.root_lit_bloom >> bloom_bit(t0)) & 1u)) {
+                    stack[2 * sp] = 0;
+                    stack[2 * sp + 1] = make_meta(0, 0, 0);
+                    sp++;
+                }
+                if ((rg.root_lit_bloom & BLOOM_PLUS) && !sys) {
+                    stack[2 * sp] = 0;
+                    stack[2 * sp + 1] = make_meta(0, 0, KIND_P);
+                    sp++;
+                }
+            }
             while (sp) {
                 sp--;
                 const uint32_t node = stack[2 * sp], meta = stack[2 * sp + 1];
                 StepOut o;
-                step_item(a.ix, rg, node, meta_level(meta), (meta & KIND_H) != 0, nlev, sys, [&](uint32_t l) { return toks[l]; }, o);
+                step_item(a.ix, rg, node, meta_level(meta), (meta & KIND_P) != 0, nlev, sys, [&](uint32_t l) { return toks[l]; }, o);
                 if (!o.found) continue;
-                if (pass == 0 && o.dl) visits++;
+                if (pass == 0) visits++;
                 if (o.emit_own) {
                     if (pass == 0) {
                         np++;
                         nr += o.s.own_count & ~RANGE_INDIRECT;
-                    } else a.pairs[base + wp++] = MatchRange{o.s.own_begin + ((o.s.own_count & RANGE_INDIRECT) ? rg.rp_base : rg.rank_base), o.s.own_count};
+                    } else a.pairs[base + wp++] = MatchRange{o.s.own_begin, o.s.own_count};
                 }
                 if (o.emit_hash) {
                     if (pass == 0) {
                         np++;
                         nr += o.s.hash_count & ~RANGE_INDIRECT;
-                    } else a.pairs[base + wp++] = MatchRange{o.s.hash_begin + ((o.s.hash_count & RANGE_INDIRECT) ? rg.rp_base : rg.rank_base), o.s.hash_count};
+                    } else a.pairs[base + wp++] = MatchRange{o.s.hash_begin, o.s.hash_count};
                 }
                 if (o.push_l) {
                     stack[2 * sp] = o.idx;
@@ -734,8 +745,8 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                     sp++;
                 }
                 if (o.push_h) {
-                    stack[2 * sp] = o.s.plus_child;
-                    stack[2 * sp + 1] = make_meta(0, o.dl + 1, KIND_H);
+                    stack[2 * sp] = o.idx;
+                    stack[2 * sp + 1] = make_meta(0, o.dl, KIND_P);
                     sp++;
                 }
             }

@@ -21,8 +21,11 @@
 #include <vector>
 
 #include "../../include/bmq.h"
+#include "bmq_codec.h"
+#include "bmq_dist_index.h"
 #include "bmq_dist_kernels.h"
-#include "bmq_index.h"
+#include "bmq_exec_dev.h"
+#include "bmq_exec_host.h"
 #include "bmq_retain.h"
 #include "bmq_retain_kernels.h"
 
@@ -68,12 +71,6 @@ struct RetainDevice { // the retained-topic index in HBM
     RetainIndexView view{};
 };
 
-struct DistDevice { // one epoch of the dist index in HBM
-    DevBuf trie, tenants, dict, pool, route_pos;
-    DistIndexView view{};
-    uint64_t bytes = 0;
-};
-
 } // namespace
 
 struct bmq_engine {
@@ -85,10 +82,12 @@ struct bmq_engine {
     mutable std::recursive_mutex api;  // held for the whole duration of the host-buffer entry points (they are multi-step)
     std::string err;
 
-    // dist direction
-    DistIndexHost host;
-    void* pinned_trie = nullptr; // host.trie memory currently registered with HIP
-    std::unique_ptr<DistDevice> dist;
+    // dist direction: the index lives in HBM and is built / mutated there by the builder kernels (bmq_exec_dev.h); a host-only
+    // engine (device < 0) runs the same builder on host threads (bmq_exec_host.h) for inspection -- it can never match
+    DevExec dx;
+    std::unique_ptr<DistIndex<DevExec>> dix;
+    HostExec hx;
+    std::unique_ptr<DistIndex<HostExec>> hix;
     uint64_t epoch = 0;
     bool built = false;
 
@@ -141,73 +140,6 @@ int upload(bmq_engine* e, DevBuf& b, const void* src, size_t bytes) {
     return BMQ_OK;
 }
 
-int upload_dist(bmq_engine* e) {
-    if (e->device < 0) return BMQ_OK;
-    HIPCHK(e, hipSetDevice(e->device));
-    DistIndexHost& h = e->host;
-    if (!e->dist) {
-        e->dist = std::make_unique<DistDevice>();
-        h.full_upload = true;
-    }
-    DistDevice& d = *e->dist;
-    int rc;
-    const size_t trie_bytes = h.trie.size() * sizeof(TrieSlot);
-    if (!e->pinned_trie && trie_bytes >= (64u << 20)) { // pin a large host image: region re-uploads then run at PCIe
-        h.trie.on_release = [](void* ctx, void* p) {      // speed; the index un-pins through this hook before freeing
-            bmq_engine* eng = (bmq_engine*)ctx;
-            if (eng->pinned_trie == p) {
-                (void)hipHostUnregister(p);
-                eng->pinned_trie = nullptr;
-            }
-        };
-        h.trie.release_ctx = e;
-        if (hipHostRegister((void*)h.trie.data(), trie_bytes, hipHostRegisterDefault) == hipSuccess) e->pinned_trie = (void*)h.trie.data();
-        else (void)hipGetLastError(); // not fatal: copies fall back to pageable memory
-    }
-    if (h.full_upload || d.trie.cap < trie_bytes) {
-        if ((rc = upload(e, d.trie, h.trie.data(), trie_bytes))) return rc;
-    } else { // only the regions of the tenants this batch of mutations touched
-        for (auto& r : h.dirty)
-            HIPCHK(e, hipMemcpyAsync(d.trie.as<TrieSlot>() + r.first, h.trie.data() + r.first, (size_t)r.second * sizeof(TrieSlot),
-                                     hipMemcpyHostToDevice, e->stream));
-    }
-    if ((rc = upload(e, d.tenants, h.tenants.data(), h.tenants.size() * sizeof(TenantSlot)))) return rc;
-    if (h.dict_changed || h.full_upload) {
-        if ((rc = upload(e, d.dict, h.dict.data(), h.dict.size() * sizeof(DictSlot)))) return rc;
-        if ((rc = upload(e, d.pool, h.pool.data(), h.pool.size()))) return rc;
-    }
-    if ((rc = upload(e, d.route_pos, h.route_pos.data(), h.route_pos.size() * sizeof(uint32_t)))) return rc;
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    h.full_upload = false;
-    h.dict_changed = false;
-    h.dirty.clear();
-    d.view.trie = d.trie.as<TrieSlot>();
-    d.view.tenants = d.tenants.as<TenantSlot>();
-    d.view.tenant_mask = (uint32_t)h.tenants.size() - 1;
-    d.view.dict = d.dict.as<DictSlot>();
-    d.view.dict_group_mask = (uint32_t)h.dict.size() / DICT_GROUP - 1;
-    d.view.pool = d.pool.as<uint8_t>();
-    d.view.route_pos = d.route_pos.as<uint32_t>();
-    d.bytes = d.trie.cap + d.tenants.cap + d.dict.cap + d.pool.cap + d.route_pos.cap;
-    return BMQ_OK;
-}
-
-int publish_epoch(bmq_engine* e) {
-    const auto t0 = std::chrono::steady_clock::now();
-    size_t dirty_slots = 0;
-    for (auto& r : e->host.dirty) dirty_slots += r.second;
-    const bool full = e->host.full_upload;
-    int rc = upload_dist(e);
-    if (rc) return rc;
-    if (getenv("BMQ_TIMING"))
-        fprintf(stderr, "[bmq build] %-28s %.3f s (%s, %.1f MB of regions)\n", "upload to HBM",
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), full ? "full" : "touched regions",
-                full ? e->host.trie.size() * 32 / 1e6 : dirty_slots * 32 / 1e6);
-    e->epoch++;
-    e->built = true;
-    return BMQ_OK;
-}
-
 // ---- dist batch ------------------------------------------------------------------------------------------------
 int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     const uint32_t n_blocks = (n_topics + 63) / 64;
@@ -239,7 +171,7 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
 }
 
 int launch_dist(bmq_engine* e, BatchArgs& a) {
-    a.ix = e->dist->view;
+    a.ix = e->dix->view();
     a.n_blocks = (a.n_topics + 63) / 64;
     a.tenant_info = e->b_tenant_root.as<TenantSlot>();
     a.pair_off = e->b_pair_off.as<uint32_t>();
@@ -377,18 +309,26 @@ int finish_dist(bmq_engine* e, uint64_t* out_total) {
 int check_dist_ready(bmq_engine* e) {
     if (!e) return BMQ_E_INVAL;
     if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only: matching requires a gfx950 device");
-    if (!e->built || !e->dist) return set_err(e, BMQ_E_STATE, "bmq_rebuild has not been called");
+    if (!e->built || !e->dix || !e->dix->built) return set_err(e, BMQ_E_STATE, "bmq_rebuild has not been called");
     return BMQ_OK;
 }
 
 } // namespace
+
+// run `f` on whichever index the engine has (HBM-resident, or host memory for a host-only engine)
+template <class F> static auto with_index(bmq_engine* e, F&& f) { return e->dix ? f(*e->dix) : f(*e->hix); }
+static int index_error(bmq_engine* e, const std::string& msg, bool invalid_input) {
+    if (e->dix && !e->dx.err.empty() && msg == e->dx.err) return set_err(e, BMQ_E_HIP, msg);
+    if (msg.find("out of") == 0) return set_err(e, BMQ_E_NOMEM, msg);
+    return set_err(e, invalid_input ? BMQ_E_INVAL : BMQ_E_STATE, msg);
+}
 
 // ====================================================================================================================
 // C ABI
 // ====================================================================================================================
 extern "C" {
 
-const char* bmq_version(void) { return "bifromq_amd 0.1 (gfx950)"; }
+const char* bmq_version(void) { return "bifromq_amd 0.2 (gfx950)"; }
 
 int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     if (!out) return BMQ_E_INVAL;
@@ -420,6 +360,11 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (hipHostMalloc((void**)&e->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess)
             return BMQ_E_NOMEM;
         memset(e->h_ctr, 0, sizeof(Counters));
+        e->dx.device = c.device;
+        e->dx.stream = e->stream;
+        e->dix = std::make_unique<DistIndex<DevExec>>(e->dx);
+    } else {
+        e->hix = std::make_unique<DistIndex<HostExec>>(e->hx);
     }
     *out = e.release();
     return BMQ_OK;
@@ -433,9 +378,9 @@ void bmq_engine_destroy(bmq_engine* e) {
         for (auto& ev : e->ev)
             if (ev) (void)hipEventDestroy(ev);
         if (e->h_ctr) (void)hipHostFree(e->h_ctr);
-        if (e->pinned_trie) (void)hipHostUnregister(e->pinned_trie);
-        e->pinned_trie = nullptr;
-        e->host.trie.on_release = nullptr;
+        e->dix.reset(); // frees the HBM arrays while the stream still exists
+        e->dx.release(e->dx.tmp);
+        e->dx.tmp = nullptr;
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
     delete e;
@@ -450,58 +395,131 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
     if (!e || (n_keys && (!keys || !key_off))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     static const uint32_t zero_off[1] = {0};
-    if (!e->host.rebuild(keys, n_keys ? key_off : zero_off, n_keys)) return set_err(e, BMQ_E_INVAL, e->host.error);
-    return publish_epoch(e);
+    static const uint8_t no_bytes[16] = {0};
+    e->built = false;
+    const bool ok = with_index(e, [&](auto& ix) {
+        const bool r = ix.rebuild(n_keys ? keys : no_bytes, n_keys ? key_off : zero_off, n_keys);
+        if (!r) e->err = ix.error;
+        return r;
+    });
+    if (!ok) return index_error(e, e->err, e->err.find("malformed") != std::string::npos);
+    e->epoch++;
+    e->built = true;
+    return BMQ_OK;
 }
 
 int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
     std::unique_lock<std::recursive_mutex> api_lock;
     if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || (n && (!keys || !key_off || !op))) return BMQ_E_INVAL;
-    std::lock_guard<std::mutex> g(e->mu);
     if (n == 0) return BMQ_OK;
+    // The builder kernels run on the engine stream, in order with the match batches: a mutation costs the matcher threads the
+    // duration of its kernels (well under a millisecond for 100 k ops), not a host-side rebuild.
+    std::lock_guard<std::mutex> g(e->mu);
     if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
-    if (!e->host.apply(keys, key_off, op, n)) return set_err(e, BMQ_E_INVAL, e->host.error);
-    return publish_epoch(e);
-}
-
-int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out) {
-    std::unique_lock<std::recursive_mutex> api_lock;
-    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
-    if (!e || !out) return BMQ_E_INVAL;
-    out->n_routes = e->host.n_routes;
-    out->n_tenants = e->host.n_tenants();
-    out->n_nodes = e->host.n_nodes;
-    out->n_tokens = e->host.n_tokens();
-    out->trie_slots = e->host.trie.size();
-    out->dict_slots = e->host.dict.size();
-    out->device_bytes = e->dist ? e->dist->bytes : 0;
-    out->epoch = e->epoch;
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    bool bad_input = false;
+    const bool ok = with_index(e, [&](auto& ix) {
+        const bool r = ix.apply(keys, key_off, op, n);
+        if (!r) {
+            e->err = ix.error;
+            bad_input = !ix.broken && ix.error.find("malformed") != std::string::npos;
+        }
+        return r;
+    });
+    if (!ok) return index_error(e, e->err, bad_input);
+    e->epoch++;
+    e->built = true;
     return BMQ_OK;
 }
 
-int bmq_route_key(const bmq_engine* e, uint32_t route_id, uint8_t* out, uint32_t cap, uint32_t* out_len) {
-    std::unique_lock<std::recursive_mutex> api_lock;
-    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
+int bmq_index_info_get(const bmq_engine* ce, bmq_index_info* out) {
+    bmq_engine* e = const_cast<bmq_engine*>(ce);
+    if (!e || !out) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    DistIndexStats st;
+    uint64_t generation = 0;
+    const bool ok = with_index(e, [&](auto& ix) {
+        generation = ix.generation;
+        const bool r = ix.stats(st);
+        if (!r) e->err = ix.error;
+        return r;
+    });
+    if (!ok) return index_error(e, e->err, false);
+    memset(out, 0, sizeof(*out));
+    out->n_routes = st.n_routes;
+    out->n_tenants = st.n_tenants;
+    out->n_nodes = st.n_nodes;
+    out->n_tokens = st.n_tokens;
+    out->trie_slots = st.trie_slots;
+    out->dict_slots = st.dict_slots;
+    out->device_bytes = e->dix ? st.bytes : 0;
+    out->epoch = e->epoch;
+    out->generation = generation;
+    out->next_route_id = st.next_id;
+    out->garbage_bytes = st.trie_garbage_slots * sizeof(TrieSlot) + st.id_list_garbage * 4;
+    return BMQ_OK;
+}
+
+int bmq_route_key(const bmq_engine* ce, uint32_t route_id, uint8_t* out, uint32_t cap, uint32_t* out_len) {
+    bmq_engine* e = const_cast<bmq_engine*>(ce);
     if (!e || !out_len) return BMQ_E_INVAL;
-    if (route_id >= e->host.n_routes) return BMQ_E_INVAL;
-    const std::string_view k = e->host.route_key(route_id);
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    std::string k;
+    bool hard = false;
+    const bool ok = with_index(e, [&](auto& ix) {
+        const bool r = ix.route_key(route_id, k);
+        if (!r && !ix.error.empty()) {
+            hard = true;
+            e->err = ix.error;
+        }
+        return r;
+    });
+    if (!ok) return hard ? index_error(e, e->err, false) : BMQ_E_INVAL; // no such route (never existed, or deleted)
     *out_len = (uint32_t)k.size();
     if (k.size() > cap) return BMQ_E_NOSPACE;
     if (out && !k.empty()) memcpy(out, k.data(), k.size());
     return BMQ_OK;
 }
 
-int bmq_index_find(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter,
+int bmq_route_keys(const bmq_engine* ce, const uint32_t* route_ids, uint32_t n, uint8_t* out, uint64_t cap, uint64_t* out_off) {
+    bmq_engine* e = const_cast<bmq_engine*>(ce);
+    if (!e || !out_off || (n && !route_ids)) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> off;
+    const bool ok = with_index(e, [&](auto& ix) {
+        const bool r = ix.route_keys(route_ids, n, bytes, off);
+        if (!r) e->err = ix.error;
+        return r;
+    });
+    if (!ok) return index_error(e, e->err, false);
+    memcpy(out_off, off.data(), sizeof(uint64_t) * ((size_t)n + 1));
+    if (off[n] > cap || (off[n] && !out)) return BMQ_E_NOSPACE;
+    if (off[n]) memcpy(out, bytes.data(), off[n]);
+    return BMQ_OK;
+}
+
+int bmq_index_find(const bmq_engine* ce, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter,
                    uint32_t filter_len, uint32_t* out_ids, uint32_t cap, uint32_t* out_n) {
-    std::unique_lock<std::recursive_mutex> api_lock;
-    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
+    bmq_engine* e = const_cast<bmq_engine*>(ce);
     if (!e || !out_n) return BMQ_E_INVAL;
     *out_n = 0;
+    std::lock_guard<std::mutex> g(e->mu);
     if (!e->built) return BMQ_E_STATE;
-    const std::vector<uint32_t> ids = e->host.find_filter(std::string_view((const char*)tenant, tenant_len),
-                                                          std::string_view((const char*)filter, filter_len));
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    std::vector<uint32_t> ids;
+    const bool ok = with_index(e, [&](auto& ix) {
+        const bool r = ix.find(std::string_view((const char*)tenant, tenant_len), std::string_view((const char*)filter, filter_len), ids);
+        if (!r) e->err = ix.error;
+        return r;
+    });
+    if (!ok) return index_error(e, e->err, false);
     *out_n = (uint32_t)ids.size();
     for (uint32_t i = 0; i < ids.size() && i < cap; i++) out_ids[i] = ids[i];
     return BMQ_OK;
@@ -648,40 +666,69 @@ int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, con
         rc = bmq_match_batch(e, tenant, toff, 1, tt.data(), topics, topic_off, n_topics, rp.data(), ids.data(), ids.size(), &need);
     }
     if (rc) return rc;
-    // apply the caps in id (= KV key) order
+    // MatchedRoutes applies its caps first-come in KV KEY order (DW/cache/MatchedRoutes.java:87-141).  After a rebuild ids are
+    // key ranks; routes added since carry later ids, so whenever a cap can bind the row is ordered by key BYTES first.
+    std::vector<uint8_t> kb;
+    std::vector<uint64_t> ko;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        HIPCHK(e, hipSetDevice(e->device));
+        if (!e->dix->route_keys(ids.data(), (uint32_t)need, kb, ko)) return set_err(e, BMQ_E_HIP, e->dix->error);
+    }
     std::vector<std::vector<uint32_t>> kept(n_topics);
     uint32_t n_ev = 0;
-    std::lock_guard<std::mutex> g(e->mu);
+    struct Ent {
+        uint32_t id, k;
+        uint8_t cls; // 0 transient normal, 1 persistent normal, 2 group
+    };
+    std::vector<Ent> row;
     for (uint32_t i = 0; i < n_topics; i++) {
         if (canon[i] != i) continue;
-        int64_t persistent = 0, groups = 0;
+        row.clear();
+        int64_t n_pers = 0, n_grp = 0;
         for (uint32_t k = rp[i]; k < rp[i + 1]; k++) {
-            const uint32_t id = ids[k];
+            const std::string_view key((const char*)kb.data() + ko[k], (size_t)(ko[k + 1] - ko[k]));
+            if (key.empty()) continue; // unsubscribed between the match and this lookup: the route no longer exists
             RouteKeyParts kp;
-            if (!decode_route_key(e->host.route_key(id), kp)) return set_err(e, BMQ_E_INVAL, "corrupt key set");
-            int ev_type = -1;
+            if (!decode_route_key(key, kp)) return set_err(e, BMQ_E_INVAL, "corrupt key store");
+            uint8_t cls = 2;
             if (kp.flag == 1) {
                 // subBrokerId = integer prefix of "<brokerId>\0<receiverId>\0<delivererKey>" (SCHEMA/KVSchemaUtil.java:56-58)
                 long broker = 0;
                 size_t p = 0;
                 while (p < kp.receiver.size() && kp.receiver[p] >= '0' && kp.receiver[p] <= '9') broker = broker * 10 + (kp.receiver[p++] - '0');
-                if (broker == 1 && p > 0) {
-                    if (persistent < (int64_t)max_pf) persistent++;
-                    else ev_type = 0;
-                }
-            } else {
+                cls = (broker == 1 && p > 0) ? 1 : 0;
+            }
+            n_pers += cls == 1;
+            n_grp += cls == 2;
+            row.push_back({ids[k], k, cls});
+        }
+        if (n_pers > (int64_t)max_pf || n_grp > (int64_t)max_gf)
+            std::sort(row.begin(), row.end(), [&](const Ent& x, const Ent& y) {
+                const std::string_view kx((const char*)kb.data() + ko[x.k], (size_t)(ko[x.k + 1] - ko[x.k]));
+                const std::string_view ky((const char*)kb.data() + ko[y.k], (size_t)(ko[y.k + 1] - ko[y.k]));
+                return kx < ky; // std::string_view compares as unsigned bytes, a proper prefix first: KV order
+            });
+        int64_t persistent = 0, groups = 0;
+        for (const Ent& en : row) {
+            int ev_type = -1;
+            if (en.cls == 1) {
+                if (persistent < (int64_t)max_pf) persistent++;
+                else ev_type = 0;
+            } else if (en.cls == 2) {
                 if (groups + 1 <= (int64_t)max_gf) groups++;
                 else ev_type = 1;
             }
-            if (ev_type < 0) kept[i].push_back(id);
+            if (ev_type < 0) kept[i].push_back(en.id);
             else {
                 if (out_events && n_ev < events_cap) {
                     int32_t* ev = out_events + 4 * (size_t)n_ev;
-                    ev[0] = ev_type; ev[1] = (int32_t)i; ev[2] = (int32_t)id; ev[3] = ev_type == 0 ? max_pf : max_gf;
+                    ev[0] = ev_type; ev[1] = (int32_t)i; ev[2] = (int32_t)en.id; ev[3] = ev_type == 0 ? max_pf : max_gf;
                 }
                 n_ev++;
             }
         }
+        std::sort(kept[i].begin(), kept[i].end());
     }
     if (out_n_events) *out_n_events = n_ev;
     uint64_t total = 0;

@@ -1,0 +1,190 @@
+// bmq_exec_dev.h -- DevExec: the builder functions of bmq_build_core.h as gfx950 kernels on the engine's HIP stream, over
+// HBM-resident arrays (see bmq_dist_index.h for the Exec concept).  One lane per route key / directory slot / trie slot:
+// the work is pointer chasing with lock-free CAS claims, bound by memory latency -- occupancy comes from the number of keys
+// in a batch (100 k ops = 1563 waves; a 10 M-key bulk load = 156 k waves), not from anything clever inside a lane.
+// The grouping sort and the tenant-run scan are rocPRIM/hipCUB device primitives (radix sort of 42-bit targets, prefix sum).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <string>
+
+#include "bmq_build_core.h"
+
+namespace bmq {
+
+constexpr int BK = 64; // lanes per builder workgroup: one wave, independent lanes
+
+__global__ __launch_bounds__(256) void k_b_fill_slots(TrieSlot* p, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        uint4* q = reinterpret_cast<uint4*>(p + i);
+        q[0] = make_uint4(NONE, 0u, 0u, 0u);
+        q[1] = make_uint4(0u, 0u, NONE, 0u);
+    }
+}
+__global__ __launch_bounds__(256) void k_b_iota(uint32_t* p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+__global__ __launch_bounds__(BK) void k_b_prepare(DistIndexMut ix, OpBatch ob) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < ob.n) prepare_one(ix, ob, i);
+}
+__global__ __launch_bounds__(BK) void k_b_prepare_check(DistIndexMut ix, OpBatch ob, uint32_t n_dir) {
+    const uint32_t d = blockIdx.x * BK + threadIdx.x;
+    if (d < n_dir) prepare_check_one(ix, ob, d);
+}
+__global__ __launch_bounds__(BK) void k_b_bulk_prepare(DistIndexMut ix, OpBatch ob) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < ob.n) bulk_prepare_one(ix, ob, i);
+}
+__global__ __launch_bounds__(BK) void k_b_bulk_tenants(DistIndexMut ix, OpBatch ob, const uint32_t* scan) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < ob.n) bulk_tenants_one(ix, ob, i, scan);
+}
+__global__ __launch_bounds__(BK) void k_b_locate(DistIndexMut ix, OpBatch ob) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < ob.n) locate_one(ix, ob, i);
+}
+__global__ __launch_bounds__(BK) void k_b_group(DistIndexMut ix, OpBatch ob) {
+    const uint32_t p = blockIdx.x * BK + threadIdx.x;
+    if (p < ob.n) group_one(ix, ob, p);
+}
+__global__ __launch_bounds__(BK) void k_b_rehash(DistIndexMut ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets) {
+    const uint32_t s = blockIdx.x * BK + threadIdx.x;
+    if (s < old_slots) rehash_one(ix, old_base, new_base, new_buckets, s);
+}
+__global__ __launch_bounds__(BK) void k_b_dict_rehash(const DictSlot* old, uint32_t old_slots, DistIndexMut ix) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < old_slots) dict_rehash_one(old, i, ix);
+}
+__global__ __launch_bounds__(64) void k_b_find(DistIndexMut ix, const uint8_t* q, uint32_t tenant_len, uint32_t filter_len, uint32_t* out, uint32_t cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) find_copy(ix, q, tenant_len, filter_len, out, cap);
+}
+__global__ __launch_bounds__(256) void k_b_gather_refs(DistIndexMut ix, const uint32_t* ids, uint32_t n, uint32_t id_end, unsigned long long* out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) gather_ref_one(ix, ids, i, id_end, out);
+}
+__global__ __launch_bounds__(BK) void k_b_gather_bytes(DistIndexMut ix, const unsigned long long* refs, const uint64_t* offs, uint32_t n, uint8_t* out) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < n) gather_bytes_one(ix, refs, offs, i, out);
+}
+
+struct DevExec {
+    std::string err;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void* tmp = nullptr; // hipCUB temporary storage
+    size_t tmp_cap = 0;
+
+    bool ck(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    }
+#define BMQ_X(expr) ck((expr), #expr)
+    bool launched() { return BMQ_X(hipGetLastError()); }
+
+    void* alloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes + 64) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return p;
+    }
+    void release(void* p) {
+        if (p) (void)hipFree(p);
+    }
+    ~DevExec() { release(tmp); }
+    bool sync() { return BMQ_X(hipStreamSynchronize(stream)); }
+    bool copy_in_async(void* d, const void* s, size_t n) { return n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream)); }
+    bool copy_in(void* d, const void* s, size_t n) { return copy_in_async(d, s, n) && sync(); }
+    bool copy_out(void* d, const void* s, size_t n) { return (n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream))) && sync(); }
+    bool copy(void* d, const void* s, size_t n) { return n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream)); }
+    bool zero(void* p, size_t n) { return n == 0 || BMQ_X(hipMemsetAsync(p, 0, n, stream)); }
+    static dim3 grid(unsigned long long n, unsigned b) { return dim3((unsigned)((n + b - 1) / b)); }
+
+    bool fill_slots(TrieSlot* p, uint64_t n) {
+        // at most 2^32 slots in the table, 256 per block
+        for (uint64_t o = 0; o < n; o += (1ull << 31)) {
+            const uint64_t m = std::min<uint64_t>(n - o, 1ull << 31);
+            hipLaunchKernelGGL(k_b_fill_slots, grid(m, 256), dim3(256), 0, stream, p + o, (unsigned long long)m);
+        }
+        return launched();
+    }
+    bool prepare(const DistIndexMut& ix, const OpBatch& ob) {
+        hipLaunchKernelGGL(k_b_prepare, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob);
+        return launched();
+    }
+    bool prepare_check(const DistIndexMut& ix, const OpBatch& ob, uint32_t n_dir) {
+        hipLaunchKernelGGL(k_b_prepare_check, grid(n_dir, BK), dim3(BK), 0, stream, ix, ob, n_dir);
+        return launched();
+    }
+    bool bulk_prepare(const DistIndexMut& ix, const OpBatch& ob) {
+        hipLaunchKernelGGL(k_b_bulk_prepare, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob);
+        return launched();
+    }
+    bool ensure_tmp(size_t bytes) {
+        if (bytes <= tmp_cap) return true;
+        if (!sync()) return false;
+        release(tmp);
+        tmp = alloc(bytes + bytes / 4);
+        tmp_cap = tmp ? bytes + bytes / 4 : 0;
+        if (!tmp) err = "out of device memory (sort scratch)";
+        return tmp != nullptr;
+    }
+    bool scan_flags(const uint32_t* in, uint32_t* out, uint32_t n) { // inclusive
+        size_t bytes = 0;
+        if (!BMQ_X(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, in, out, (int)n, stream))) return false;
+        if (!ensure_tmp(bytes)) return false;
+        return BMQ_X(hipcub::DeviceScan::InclusiveSum(tmp, bytes, in, out, (int)n, stream));
+    }
+    bool bulk_tenants(const DistIndexMut& ix, const OpBatch& ob, const uint32_t* scan) {
+        hipLaunchKernelGGL(k_b_bulk_tenants, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, scan);
+        return launched();
+    }
+    bool locate(const DistIndexMut& ix, const OpBatch& ob) {
+        hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob);
+        return launched();
+    }
+    bool sort_targets(const OpBatch& ob) { // stable: ops on one target stay in op order.  Values = op indices.
+        uint32_t* iota = ob.unknown_list; // free again after prepare
+        hipLaunchKernelGGL(k_b_iota, grid(ob.n, 256), dim3(256), 0, stream, iota, ob.n);
+        if (!launched()) return false;
+        size_t bytes = 0;
+        const int end_bit = (int)TARGET_KIND_SHIFT + 2;
+        if (!BMQ_X(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ob.target, ob.sorted_target, iota, ob.order, (int)ob.n, 0, end_bit, stream)))
+            return false;
+        if (!ensure_tmp(bytes)) return false;
+        return BMQ_X(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, ob.target, ob.sorted_target, iota, ob.order, (int)ob.n, 0, end_bit, stream));
+    }
+    bool group(const DistIndexMut& ix, const OpBatch& ob) {
+        hipLaunchKernelGGL(k_b_group, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob);
+        return launched();
+    }
+    bool rehash(const DistIndexMut& ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets) {
+        hipLaunchKernelGGL(k_b_rehash, grid(old_slots, BK), dim3(BK), 0, stream, ix, old_base, old_slots, new_base, new_buckets);
+        return launched();
+    }
+    bool dict_rehash(const DictSlot* old, uint32_t old_slots, const DistIndexMut& ix) {
+        hipLaunchKernelGGL(k_b_dict_rehash, grid(old_slots, BK), dim3(BK), 0, stream, old, old_slots, ix);
+        return launched();
+    }
+    bool find(const DistIndexMut& ix, const uint8_t* q, uint32_t tenant_len, uint32_t filter_len, uint32_t* out, uint32_t cap) {
+        hipLaunchKernelGGL(k_b_find, dim3(1), dim3(64), 0, stream, ix, q, tenant_len, filter_len, out, cap);
+        return launched();
+    }
+    bool gather_refs(const DistIndexMut& ix, const uint32_t* ids, uint32_t n, uint32_t id_end, unsigned long long* out) {
+        hipLaunchKernelGGL(k_b_gather_refs, grid(n, 256), dim3(256), 0, stream, ix, ids, n, id_end, out);
+        return launched();
+    }
+    bool gather_bytes(const DistIndexMut& ix, const unsigned long long* refs, const uint64_t* offs, uint32_t n, uint8_t* out) {
+        hipLaunchKernelGGL(k_b_gather_bytes, grid(n, BK), dim3(BK), 0, stream, ix, refs, offs, n, out);
+        return launched();
+    }
+#undef BMQ_X
+};
+
+} // namespace bmq

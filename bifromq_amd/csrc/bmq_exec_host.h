@@ -1,0 +1,123 @@
+// bmq_exec_host.h -- HostExec: runs the builder functions of bmq_build_core.h on host threads over host memory.
+// Used by host-only engines (bmq_config.device = -1: build / inspect an index without a GPU -- matching still requires
+// the device) and by the sanitizer fuzzers (tools/host_fuzz.cpp runs the identical builder code under ASan/UBSan and,
+// with several threads, TSan).  See bmq_dist_index.h for the Exec concept.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bmq_build_core.h"
+
+namespace bmq {
+
+struct HostExec {
+    std::string err;
+    unsigned threads = 0; // 0 = hardware concurrency (capped)
+
+    void* alloc(size_t bytes) { return malloc(bytes + 32); }
+    void release(void* p) { free(p); }
+    bool copy_in(void* d, const void* s, size_t n) {
+        if (n) memcpy(d, s, n);
+        return true;
+    }
+    bool copy_in_async(void* d, const void* s, size_t n) { return copy_in(d, s, n); }
+    bool copy_out(void* d, const void* s, size_t n) { return copy_in(d, s, n); }
+    bool copy(void* d, const void* s, size_t n) { return copy_in(d, s, n); }
+    bool zero(void* p, size_t n) {
+        if (n) memset(p, 0, n);
+        return true;
+    }
+    bool sync() { return true; }
+
+    template <class F> void par(size_t n, F&& f) {
+        unsigned hw = threads ? threads : std::min(std::thread::hardware_concurrency(), 16u);
+        if (hw == 0) hw = 1;
+        const size_t chunk = 256;
+        const unsigned nth = (unsigned)std::min<size_t>(hw, (n + chunk - 1) / chunk);
+        if (nth <= 1) {
+            for (size_t i = 0; i < n; i++) f(i);
+            return;
+        }
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const size_t b = next.fetch_add(chunk);
+                if (b >= n) break;
+                const size_t e = std::min(n, b + chunk);
+                for (size_t i = b; i < e; i++) f(i);
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned w = 1; w < nth; w++) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+    }
+
+    bool fill_slots(TrieSlot* p, uint64_t n) {
+        par(n, [&](size_t i) { p[i] = FREE_SLOT; });
+        return true;
+    }
+    bool prepare(const DistIndexMut& ix, const OpBatch& ob) {
+        par(ob.n, [&](size_t i) { prepare_one(ix, ob, (uint32_t)i); });
+        return true;
+    }
+    bool prepare_check(const DistIndexMut& ix, const OpBatch& ob, uint32_t n_dir) {
+        par(n_dir, [&](size_t d) { prepare_check_one(ix, ob, (uint32_t)d); });
+        return true;
+    }
+    bool bulk_prepare(const DistIndexMut& ix, const OpBatch& ob) {
+        par(ob.n, [&](size_t i) { bulk_prepare_one(ix, ob, (uint32_t)i); });
+        return true;
+    }
+    bool scan_flags(const uint32_t* in, uint32_t* out, uint32_t n) { // inclusive
+        uint32_t s = 0;
+        for (uint32_t i = 0; i < n; i++) out[i] = (s += in[i]);
+        return true;
+    }
+    bool bulk_tenants(const DistIndexMut& ix, const OpBatch& ob, const uint32_t* scan) {
+        par(ob.n, [&](size_t i) { bulk_tenants_one(ix, ob, (uint32_t)i, scan); });
+        return true;
+    }
+    bool locate(const DistIndexMut& ix, const OpBatch& ob) {
+        par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i); });
+        return true;
+    }
+    bool sort_targets(const OpBatch& ob) {
+        std::iota(ob.order, ob.order + ob.n, 0u);
+        std::stable_sort(ob.order, ob.order + ob.n, [&](uint32_t a, uint32_t b) { return ob.target[a] < ob.target[b]; });
+        for (uint32_t i = 0; i < ob.n; i++) ob.sorted_target[i] = ob.target[ob.order[i]];
+        return true;
+    }
+    bool group(const DistIndexMut& ix, const OpBatch& ob) {
+        par(ob.n, [&](size_t p) { group_one(ix, ob, (uint32_t)p); });
+        return true;
+    }
+    bool rehash(const DistIndexMut& ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets) {
+        par(old_slots, [&](size_t s) { rehash_one(ix, old_base, new_base, new_buckets, (uint32_t)s); });
+        return true;
+    }
+    bool dict_rehash(const DictSlot* old, uint32_t old_slots, const DistIndexMut& ix) {
+        par(old_slots, [&](size_t i) { dict_rehash_one(old, (uint32_t)i, ix); });
+        return true;
+    }
+    bool find(const DistIndexMut& ix, const uint8_t* q, uint32_t tenant_len, uint32_t filter_len, uint32_t* out, uint32_t cap) {
+        find_copy(ix, q, tenant_len, filter_len, out, cap);
+        return true;
+    }
+    bool gather_refs(const DistIndexMut& ix, const uint32_t* ids, uint32_t n, uint32_t id_end, unsigned long long* out) {
+        par(n, [&](size_t i) { gather_ref_one(ix, ids, (uint32_t)i, id_end, out); });
+        return true;
+    }
+    bool gather_bytes(const DistIndexMut& ix, const unsigned long long* refs, const uint64_t* offs, uint32_t n, uint8_t* out) {
+        par(n, [&](size_t i) { gather_bytes_one(ix, refs, offs, (uint32_t)i, out); });
+        return true;
+    }
+};
+
+} // namespace bmq

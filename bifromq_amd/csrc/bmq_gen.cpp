@@ -20,7 +20,8 @@
 #include <chrono>
 #include <atomic>
 
-#include "bmq_index.h"
+#include "bmq_codec.h"
+#include "bmq_layout.h"
 
 namespace {
 

@@ -1,16 +1,22 @@
-// bmq_layout.h -- HBM data layout shared by the host builder and the gfx950 kernels.
+// bmq_layout.h -- HBM data layout shared by the index builder (bmq_build_core.h: the same code runs as gfx950 kernels and,
+// for the sanitizer fuzzers / host-only engines, as plain C++) and the match kernels (bmq_dist_kernels.h).
 //
 // Dist direction index ("filter trie", the inverse of the reference's per-call topic trie,
-// TRIE/TopicTrieNode.java:37-163).  Every trie node is ONE 32-byte slot; a node's id IS its slot index.
-//   * all nodes of a tenant live in the tenant's private region of the slot table (TenantSlot);
-//   * inside a region, the edge (parent slot, token) hashes to a home BUCKET = two slots = one aligned 64-byte line;
-//     insertion fills the first free slot from the home bucket onwards (load factor <= 1/2), so a child lookup reads
-//     ONE line in ~92 % of the cases and gets the child's complete header with it.  Measured on MI355X the walk is
-//     bound by the rate of random 64-byte line fetches (~54 G lines/s from HBM, ~200 G/s from L2,
-//     tools/ubench_lines.hip), so lines per visited node is the figure of merit;
-//   * '+' children are reached by slot index: the walk reads the bucket line that contains the slot, so both kinds of
-//     work item cost the same single line; tenant roots travel in the directory entry (TenantSlot) and cost nothing;
-//   * '#' children are never nodes: the routes of "<path>/#" hang off the parent (hash_*).
+// TRIE/TopicTrieNode.java:37-163).  The index LIVES in HBM and is MUTATED there: bmq_rebuild / bmq_routes_apply upload
+// route keys and run builder kernels; nothing is built on host cores.
+//   * every trie node is ONE 32-byte slot; all nodes of a tenant live in the tenant's private region of the slot table;
+//   * a node has a tenant-local NODE ID (the tenant root is id 0, others are handed out by an atomic counter in the
+//     tenant's directory entry).  The edge (parent node id, token) hashes to a home BUCKET = two slots = one aligned
+//     64-byte line; insertion claims the first free slot from the home bucket onwards with one 64-bit CAS on the edge
+//     key (load factor <= 1/2), so a child lookup reads ONE line in ~92 % of the cases and gets the child's complete
+//     header with it.  Node ids are not slot positions: a region is grown by re-inserting its slots into a larger
+//     region in parallel (k_rehash_region), no id changes;
+//   * '+' children are ordinary edges with token TOK_PLUS; bit 31 of the parent's Bloom word says whether one exists;
+//   * '#' children are never nodes: the routes of "<path>/#" hang off the parent (hash_*);
+//   * the tenant root is not a slot: its payload lives in the directory entry the walk reads anyway.
+// Route ids: after bmq_rebuild the id of a route is the rank of its KV key (keys arrive sorted from the KV iterator);
+// routes added later by bmq_routes_apply get the next unused ids.  An id never changes and is never reused until the
+// next bmq_rebuild; per id the key store holds (offset, length) of the key bytes and a hash of the key's tail.
 #pragma once
 #include <stdint.h>
 
@@ -23,48 +29,49 @@
 
 namespace bmq {
 
-constexpr uint32_t NONE = 0xFFFFFFFFu;        // empty slot / no child
-constexpr uint32_t ROOT_PARENT = 0xFFFFFFFEu; // parent key of tenant roots
+constexpr uint32_t NONE = 0xFFFFFFFFu;        // empty slot / no child / node id not published yet
 constexpr uint32_t TOK_UNKNOWN = 0;           // level string not in the dictionary
 constexpr uint32_t TOK_PLUS = 1;              // the '+' edge
 constexpr uint32_t TOK_FIRST = 2;             // first dictionary token
 constexpr int FAST_LEVELS = 16;               // topics with more levels take the slow path
                                               // (Setting.MaxTopicLevels default, Setting.java:45)
 constexpr uint32_t RANGE_INDIRECT = 0x80000000u; // count flag: begin indexes route_pos[] instead of being the first id
+constexpr uint32_t BLOOM_PLUS = 0x80000000u;     // lit_bloom bit 31: the node has a '+' child
+constexpr uint64_t EDGE_EMPTY = 0x00000000FFFFFFFFull; // (parent = NONE, token = 0): free slot
 
 struct alignas(32) TrieSlot {
-    uint32_t parent;      // region-relative slot of the parent (NONE = empty slot, ROOT_PARENT = tenant root)
+    uint32_t parent;      // tenant-local node id of the parent (0 = tenant root); NONE = free slot
     uint32_t token;       // dictionary token of the edge label (TOK_PLUS for '+')
-    uint32_t own_begin;   // routes whose filter ends at this node: ids rank_base + own_begin .. +count-1, or
-    uint32_t own_count;   //   route_pos[rp_base + own_begin ..] when (own_count & RANGE_INDIRECT)
+    uint32_t own_begin;   // routes whose filter ends at this node: ids own_begin .. +count-1, or
+    uint32_t own_count;   //   route_pos[own_begin ..] when (own_count & RANGE_INDIRECT)
     uint32_t hash_begin;  // routes of "<this path>/#", same encoding
     uint32_t hash_count;
-    uint32_t plus_child;  // region-relative slot of the '+' child or NONE
-    uint32_t lit_bloom;   // 32-bit Bloom mask over the literal children's tokens; 0 = no literal child
+    uint32_t node;        // this node's tenant-local id (>= 1); NONE until the inserting thread has published it
+    uint32_t lit_bloom;   // bits 0-30: Bloom mask over the literal children's tokens; bit 31: a '+' child exists
 };
 static_assert(sizeof(TrieSlot) == 32, "TrieSlot must be 32 bytes");
 
-// Tenant directory entry: the tenant's region of the slot table.  Bucket k of the region = slots base+2k, base+2k+1.
-// Slot indices stored INSIDE a region (TrieSlot.parent, plus_child, the root) are relative to `base`, and route ids
-// inside a region are relative to `rank_base`: a region can be rebuilt, moved or re-based without touching the others.
+// Tenant directory entry = the tenant's region of the slot table + the payload of the tenant's ROOT node (every topic of the
+// tenant starts there, so the walk takes it from the directory entry it reads anyway: no line fetch, no round).
+// Bucket k of the region = slots base+2k, base+2k+1.  Open addressing by the 64-bit hash of the tenant id; the id's bytes
+// (name_off/name_len into the tenant name pool) decide equality.
 struct alignas(64) TenantSlot {
-    uint32_t token;     // dictionary token of the tenant id; 0 = empty directory slot
-    uint32_t root;      // slot of the tenant's root node, relative to base
-    uint32_t base;      // first slot of the region (even)
-    uint32_t buckets;   // number of 2-slot buckets (>= 1)
-    uint32_t rank_base; // global route id of the tenant's first route (ids are ranks in KV key order)
-    uint32_t rp_base;   // first entry of the tenant in route_pos[]
-    // copy of the root slot's payload: every topic of the tenant starts at the root, so the walk takes it from the
-    // directory entry it reads anyway instead of spending a line fetch and a round on it
+    uint32_t hash_lo, hash_hi; // 64-bit hash of the tenant id, forced non-zero; 0/0 = empty directory slot
+    uint32_t name_off, name_len;
+    uint32_t base;             // first slot of the region (even)
+    uint32_t buckets;          // number of 2-slot buckets (>= 1)
+    uint32_t n_nodes;          // node ids handed out so far (next id = n_nodes + 1)
+    uint32_t n_routes;         // live routes of the tenant
     uint32_t root_hash_begin, root_hash_count; // routes of the filter "#"
-    uint32_t root_plus_child, root_lit_bloom;
-    uint32_t pad[6];
+    uint32_t root_lit_bloom;                   // Bloom word of the root (bit 31: a first-level '+' exists)
+    uint32_t pending;          // builder scratch: upper bound of the nodes the batch being prepared may add
+    uint32_t pad[4];
 };
 static_assert(sizeof(TenantSlot) == 64, "TenantSlot must be 64 bytes");
-constexpr TenantSlot EMPTY_TENANT{0, 0, 0, 1, 0, 0, 0, 0, NONE, 0, {0, 0, 0, 0, 0, 0}};
 
 // Level dictionary: level string -> token, exact (bytes verified).  Strings <= 16 bytes live inline.  Open addressing
 // over groups of DICT_GROUP slots (one 64-byte line) at load factor <= 1/4: a lookup reads its home group in one go.
+// Insertion (builder kernels): claim a free slot by CAS on `tag`, fill it, publish `token` last (0 = not yet readable).
 constexpr uint32_t DICT_GROUP = 2;
 struct alignas(32) DictSlot {
     uint32_t tag;       // second hash, forced non-zero; 0 = empty slot
@@ -107,7 +114,7 @@ BMQ_HD uint32_t level_hash_tag(const LevelHash& h) {
     return x | 1u;
 }
 
-// home bucket of edge (parent slot, token) in a region of `buckets` buckets (fastrange: any size)
+// home bucket of edge (parent node id, token) in a region of `buckets` buckets (fastrange: any size)
 BMQ_HD uint32_t edge_bucket(uint32_t parent, uint32_t token, uint32_t buckets) {
     uint32_t h = (parent ^ rotl32(token, 16)) * 0x9E3779B1u;
     h ^= h >> 15;
@@ -115,21 +122,31 @@ BMQ_HD uint32_t edge_bucket(uint32_t parent, uint32_t token, uint32_t buckets) {
     h ^= h >> 13;
     return (uint32_t)(((uint64_t)h * buckets) >> 32);
 }
-BMQ_HD uint32_t bloom_bit(uint32_t token) { return (token ^ (token >> 5) ^ (token >> 11)) & 31u; }
-BMQ_HD uint32_t tenant_hash(uint32_t token) {
-    uint32_t x = token * 0x9E3779B1u;
-    return x ^ (x >> 15);
+// Bloom bit of a literal child token: 0..30 (bit 31 is BLOOM_PLUS)
+BMQ_HD uint32_t bloom_bit(uint32_t token) {
+    const uint32_t b = (token ^ (token >> 5) ^ (token >> 11)) & 31u;
+    return b - (b == 31u ? 1u : 0u); // 31 -> 30
+}
+// 64-bit hash of a tenant id (FNV-1a over the bytes, then a finaliser); never 0
+BMQ_HD uint64_t tenant_hash_step(uint64_t h, uint32_t byte) { return (h ^ byte) * 0x100000001B3ull; }
+constexpr uint64_t TENANT_HASH_INIT = 0xCBF29CE484222325ull;
+BMQ_HD uint64_t tenant_hash_final(uint64_t h) {
+    h ^= h >> 33;
+    h *= 0xFF51AFD7ED558CCDull;
+    h ^= h >> 29;
+    return h ? h : 1ull;
 }
 
-// Everything a kernel needs to read the dist index.
+// Everything a match kernel needs to read the dist index.
 struct DistIndexView {
     const TrieSlot* trie;
     const TenantSlot* tenants;
-    uint32_t tenant_mask;      // tenant directory slots - 1
+    uint32_t tenant_mask;        // tenant directory slots - 1
+    const uint8_t* tenant_names; // tenant id bytes (TenantSlot.name_off / name_len)
     const DictSlot* dict;
-    uint32_t dict_group_mask;  // (dictionary slots / DICT_GROUP) - 1
-    const uint8_t* pool;       // level strings longer than 16 bytes
-    const uint32_t* route_pos; // ids of the (rare) nodes whose route ids are not one contiguous rank range
+    uint32_t dict_group_mask;    // (dictionary slots / DICT_GROUP) - 1
+    const uint8_t* pool;         // level strings longer than 16 bytes
+    const uint32_t* route_pos;   // id lists of the nodes whose route ids are not one contiguous range
 };
 
 // A matched range of one filter node: ids begin .. begin+count-1, or route_pos[begin ..] if count has RANGE_INDIRECT.

@@ -99,6 +99,11 @@ private:
     bool refresh(std::vector<RTenantState*>& touched);
 };
 
+// directory hash of a tenant's dictionary token (retain direction: tenants are dictionary entries like levels)
+BMQ_HD uint32_t tenant_hash(uint32_t token) {
+    uint32_t x = token * 0x9E3779B1u;
+    return x ^ (x >> 15);
+}
 BMQ_HD uint32_t redge_bucket(uint32_t parent, uint32_t token, uint32_t mask) {
     uint32_t h = (parent ^ rotl32(token, 16)) * 0x9E3779B1u;
     h ^= h >> 15;

@@ -147,6 +147,22 @@ class Engine:
         self._check(rc)
         return buf.raw[:n.value]
 
+    def route_keys(self, route_ids) -> List[bytes]:
+        """bmq_route_keys: one device gather for many ids; a dead id gives b""."""
+        ids = np.ascontiguousarray(route_ids, dtype=np.uint32)
+        n = len(ids)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        cap = max(4096, 96 * n)
+        while True:
+            out = np.zeros(cap, dtype=np.uint8)
+            rc = _lib.lib().bmq_route_keys(self.h, _ptr(ids), n, _ptr(out), cap, _ptr(off))
+            if rc == -3:
+                cap = int(off[n])
+                continue
+            self._check(rc)
+            raw = out.tobytes()
+            return [raw[int(off[i]):int(off[i + 1])] for i in range(n)]
+
     def find(self, tenant, topic_filter) -> List[int]:
         t, f = _b(tenant), _b(topic_filter)
         n = C.c_uint32()

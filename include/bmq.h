@@ -12,9 +12,12 @@
  * Conventions
  *   - every function returns BMQ_OK (0) or a negative bmq_status; nothing throws across the ABI;
  *   - strings are packed: `bytes` + `off[n+1]` (uint32 byte offsets, off[0] == 0), UTF-8, not NUL-terminated;
- *   - a route id is the RANK of the route's KV key in unsigned-byte order among the keys the engine
- *     currently holds (== KV iteration order, the order MatchedRoutes applies fan-out caps in,
- *     DW/cache/MatchedRoutes.java:87-141).  bmq_route_key() maps an id back to its key;
+ *   - a route id is a STABLE handle of one route key.  bmq_rebuild numbers the routes by the RANK of their KV key in
+ *     unsigned-byte order (== KV iteration order, the order MatchedRoutes applies fan-out caps in,
+ *     DW/cache/MatchedRoutes.java:87-141); a route added later by bmq_routes_apply gets the next unused id.  An id never
+ *     changes and is never given to another key until the next bmq_rebuild (bmq_index_info.generation counts rebuilds);
+ *     the id of a deleted route resolves to "no such route".  bmq_route_key() / bmq_route_keys() map ids back to keys;
+ *     bmq_match_all() applies the fan-out caps in KEY order whatever the ids are;
  *   - match results are CSR: row_ptr[n+1] + ids, ids ascending inside each row;
  *   - buffers are caller-owned; *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and
  *     run asynchronously on the engine's HIP stream until bmq_match_finish().  Device string buffers (tenants,
@@ -81,7 +84,10 @@ typedef struct bmq_index_info {
     uint64_t n_routes, n_tenants, n_nodes, n_tokens;
     uint64_t trie_slots, dict_slots;      /* table sizes in 32-byte slots (trie: sum of the tenant regions)  */
     uint64_t device_bytes;                /* HBM held by the index                                          */
-    uint64_t epoch;
+    uint64_t epoch;                       /* +1 per bmq_rebuild / bmq_routes_apply                          */
+    uint64_t generation;                  /* +1 per bmq_rebuild: ids of different generations are unrelated */
+    uint64_t next_route_id;               /* ids handed out so far (live + deleted)                         */
+    uint64_t garbage_bytes;               /* HBM held by abandoned regions / id lists until the next rebuild */
 } bmq_index_info;
 
 /* ---- lifecycle -------------------------------------------------------------------------------------- */
@@ -94,18 +100,27 @@ const char* bmq_version(void);
 
 /* ---- dist direction: index maintenance -------------------------------------------------------------- */
 /* Full (re)load from a KV scan -- replaces IKVRangeCoProc.reset(Boundary) (KVAPI/IKVRangeCoProc.java:64,
- * DW/DistWorkerCoProc.java:283-291).  keys = route keys in the layout of SCHEMA/KVSchemaUtil.java:91-130;
- * any order (sorted + deduplicated internally; a KV iterator already yields them sorted). */
+ * DW/DistWorkerCoProc.java:283-291).  keys = route keys in the layout of SCHEMA/KVSchemaUtil.java:91-130 (the packed bytes
+ * must be readable 16 bytes past the last key).  The keys are uploaded and parsed, and the index is built, ON THE DEVICE
+ * (builder kernels, bmq_build_core.h).  A KV iterator yields the keys strictly ascending: that is the fast path and route
+ * id = position = rank; any other order is sorted + de-duplicated on the host first.  On failure the previous index is gone. */
 int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys);
 
 /* Post-commit route mutations -- replaces ISubscriptionCache.refresh(AddRoutesTask/RemoveRoutesTask)
  * (DW/DistWorkerCoProc.java:188-209, DW/cache/SubscriptionCache.java:127-134).  op[i]: 0 = put, 1 = delete.
- * Applied in order; the new epoch becomes visible to the next match call. */
+ * Applied in order by builder kernels on the engine stream (between match batches, which therefore never see half a batch);
+ * the call returns when the device has applied it.  A put of a key that is already there keeps its id, a delete of an absent
+ * key is a no-op; the j-th put of the batch that adds a route gets id next_route_id + j.  A malformed key or op code fails
+ * the whole batch with BMQ_E_INVAL before anything is changed. */
 int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
 
 int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out);
-/* id -> key (so the Java adapter can materialise Matching objects, SCHEMA/KVSchemaUtil.java:73-89). */
+/* id -> key (so the Java adapter can materialise Matching objects, SCHEMA/KVSchemaUtil.java:73-89).  BMQ_E_INVAL: no such
+ * route (the id was never handed out, or its route has been deleted). */
 int bmq_route_key(const bmq_engine* e, uint32_t route_id, uint8_t* out, uint32_t cap, uint32_t* out_len);
+/* Many ids at once (one device gather): out_off[n + 1] byte offsets into out; a dead id gives an empty key.
+ * BMQ_E_NOSPACE if cap < out_off[n] (offsets are still written). */
+int bmq_route_keys(const bmq_engine* e, const uint32_t* route_ids, uint32_t n, uint8_t* out, uint64_t cap, uint64_t* out_off);
 /* exact lookup (no wildcard semantics): ids of the routes stored under (tenant, topicFilter); for tests
  * and for RouteDetailCache-style inspection.  Writes up to cap ids, *out_n = total. */
 int bmq_index_find(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter,

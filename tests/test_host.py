@@ -92,11 +92,25 @@ def test_apply_put_delete_host():
     ks = [B.route_key("t", "a/%d" % i, 1, "0\0r%d\0d" % i) for i in range(50)]
     e = B.Engine(device=-1).rebuild(ks)
     e.apply([(1, ks[3]), (0, B.route_key("t", "z", 1, "0\0r\0d")), (1, ks[7]), (0, ks[7]), (1, b"\x00\x00\x01tq\x00\x00\x00\x01\x00\x00")])
-    exp = sorted((set(ks) - {ks[3]}) | {B.route_key("t", "z", 1, "0\0r\0d")})
-    assert e.info().n_routes == len(exp) and e.info().epoch == 2
-    assert [e.route_key(i) for i in range(len(exp))] == exp
+    z = B.route_key("t", "z", 1, "0\0r\0d")
+    exp = (set(ks) - {ks[3]}) | {z}
+    info = e.info()
+    assert info.n_routes == len(exp) and info.epoch == 2 and info.generation == 1 and info.next_route_id == 52
+    # ids are stable handles: survivors keep their rank, the deleted ids are dead, the two adding puts got 50 and 51
+    ranks = sorted(ks)
+    got = e.route_keys(list(range(52)))
+    assert got[:50] == [b"" if k in (ks[3], ks[7]) else k for k in ranks] and got[50:] == [z, ks[7]]
+    assert e.find("t", "z") == [50] and e.find("t", "a/7") == [51] and e.find("t", "a/3") == []
+    with pytest.raises(B.BmqError) as ei:
+        e.route_key(ranks.index(ks[3]))
+    assert ei.value.code == -1
     with pytest.raises(B.BmqError):
         e.apply([(0, b"not a key")])
+    with pytest.raises(B.BmqError):  # a bad op in the middle of a batch: nothing of the batch is applied
+        e.apply([(0, B.route_key("t", "new", 1, "0\0r\0d")), (0, b"\x01garbage")])
+    assert e.info().n_routes == len(exp) and e.find("t", "new") == []
+    e.rebuild(ks)  # a rebuild re-numbers: ranks again, new generation
+    assert e.info().generation == 2 and e.route_keys(list(range(50))) == ranks
 
 
 def test_workload_generator_is_deterministic_and_sorted():
@@ -135,24 +149,23 @@ def test_hash_sharded_workloads_partition_the_population():
 
 
 def test_host_index_fuzz_under_sanitizers():
-    """tools/host_fuzz.cpp: random rebuild / incremental-apply sequences on the host index, built with ASan + UBSan; after every
-    step ids must be the ranks of a std::set model and a CPU walk over the HBM image (directory, regions, dictionary, exactly
-    the probes k_walk does) must give the brute-force result of the matching rule for random topics.  Seed 9 is the sequence
-    that exposed the loss of untouched regions when the table grew during an apply on an engine that never uploads."""
+    """tools/host_fuzz.cpp: the index BUILDER -- the very functions the gfx950 builder kernels run (bmq_build_core.h), driven by
+    the same host control (bmq_dist_index.h) -- on host threads under ASan + UBSan and under TSan: random rebuild / apply
+    sequences with minimal initial capacities (every growth path runs all the time); after every step ids must follow the ABI's
+    rule (ranks after a rebuild, next unused id for an adding put, stable otherwise) and a CPU walk over the image (directory,
+    regions, dictionary, exactly the probes k_walk does) must give the brute-force result of the matching rule."""
     import subprocess
     csrc = os.path.join(ROOT, "bifromq_amd", "csrc")
     subprocess.run(["make", "-C", csrc, "fuzz"], check=True, capture_output=True, timeout=600)
     exe = os.path.join(ROOT, "tools", "host_fuzz")
-    for seed, rounds in ((1, 15), (9, 58)):
-        r = subprocess.run([exe, str(seed), str(rounds)], capture_output=True, text=True, timeout=600)
+    for seed, rounds, threads in ((1, 40, 4), (9, 58, 1), (3, 40, 8)):
+        r = subprocess.run([exe, str(seed), str(rounds), "3000", str(threads)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "host_fuzz ok" in r.stdout, r.stdout + r.stderr
-    # rebuild() splits the keys by tenant in parallel chunks: force many tiny chunks
-    r = subprocess.run([exe, "5", "40"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BMQ_SPLIT_CHUNK="7"))
+    r = subprocess.run([exe, "5", "20", "20000", "8"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BMQ_FUZZ_BIG="1"))
     assert r.returncode == 0 and "host_fuzz ok" in r.stdout, r.stdout + r.stderr
-    # the experimental incremental apply path (BMQ_INCREMENTAL=1: persistent per-tenant trie, no key is parsed twice)
-    for seed in ("2", "11"):
-        r = subprocess.run([exe, seed, "50"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BMQ_INCREMENTAL="1"))
-        assert r.returncode == 0 and "host_fuzz ok" in r.stdout, r.stdout + r.stderr
+    for seed in ("2", "11"):  # the lock-free inserts (dictionary slots, trie slots, Bloom words) under ThreadSanitizer
+        r = subprocess.run([exe + "_tsan", seed, "25", "3000", "8"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "host_fuzz ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
     # the retain direction's host index (tools/retain_fuzz.cpp): per-tenant add/remove, segment growth, '$' runs
     exe = os.path.join(ROOT, "tools", "retain_fuzz")
     for seed, rounds in ((1, 25), (7, 25)):
@@ -214,8 +227,11 @@ def test_churn_case_helper_on_host_only_engine():
         data, off = packed
         raw = data.tobytes()
         topics = [raw[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
-        keys = [eng.route_key(i) for i in range(int(eng.info().n_routes))]
-        rows = U.semantic_rows(O.KV(keys), tn, tt, topics)
+        all_ids = list(range(int(eng.info().next_route_id)))
+        live = [(k, i) for i, k in zip(all_ids, eng.route_keys(all_ids)) if k]  # (key, engine id) of every live route
+        live.sort()
+        rows = U.semantic_rows(O.KV([k for k, _ in live]), tn, tt, topics)  # ranks in the live key list ...
+        rows = [sorted(live[r][1] for r in rr) for rr in rows]              # ... as engine ids, ascending
         row = np.zeros(len(rows) + 1, dtype=np.uint32)
         row[1:] = np.cumsum([len(r) for r in rows])
         state["rows"] = len(rows)

@@ -71,6 +71,20 @@ def csr_rows(row_ptr, ids):
     return [ids[row_ptr[i]:row_ptr[i + 1]].tolist() for i in range(len(row_ptr) - 1)]
 
 
+def rows_as_ranks(eng, row_ptr, ids, keys_sorted, rows=None):
+    """Engine route ids are stable handles (ranks after a rebuild, later ids for routes added by bmq_routes_apply); the oracles
+    speak in ranks of the sorted key list.  Maps every id through bmq_route_keys to its key and then to the key's rank in
+    `keys_sorted` (KeyError: the engine returned a route the model does not hold), rows sorted ascending.
+    rows: only these row indices (default all)."""
+    rows = range(len(row_ptr) - 1) if rows is None else rows
+    if len(ids) == 0:
+        return [[] for _ in rows]
+    want = np.unique(np.concatenate([ids[row_ptr[i]:row_ptr[i + 1]] for i in rows] + [np.zeros(0, dtype=ids.dtype)]))
+    rank = {k: i for i, k in enumerate(keys_sorted)}
+    m = {int(u): rank[k] for u, k in zip(want, eng.route_keys(want))}
+    return [sorted(m[int(x)] for x in ids[row_ptr[i]:row_ptr[i + 1]]) for i in rows]
+
+
 def quirk_ii_filters(keys):
     """(tenant, filter F) pairs for which the KV also holds a filter F + "/" + "" + ... (next level empty).
     The reference's probe-then-seek loop can skip F's keys in that situation (SURVEY.md 8c quirk ii,
@@ -111,11 +125,62 @@ def assert_rows_equal_modulo_quirk_ii(keys, tenants, topic_tenant, reference_row
     return n_diff
 
 
+def csr_select(row_ptr, ids, sel):
+    """the CSR restricted to rows `sel` -> (row_ptr', ids')"""
+    sel = np.asarray(sel, dtype=np.int64)
+    cnt = (row_ptr[sel + 1].astype(np.int64) - row_ptr[sel].astype(np.int64))
+    rp = np.concatenate([[0], np.cumsum(cnt)])
+    idx = np.repeat(row_ptr[sel].astype(np.int64) - rp[:-1], cnt) + np.arange(rp[-1], dtype=np.int64)
+    return rp, ids[idx]
+
+
+def csr_sorted(rp, vals):
+    """every row sorted ascending (vectorised)"""
+    r = np.repeat(np.arange(len(rp) - 1, dtype=np.int64), np.diff(rp))
+    return vals[np.lexsort((vals, r))]
+
+
+def assert_csr_equal_modulo_quirk_ii(all_keys_fn, key_of, tenants, topic_tenant, ref_rp, ref_vals, got_rp, got_vals):
+    """Whole-CSR comparison for the full-size tests (millions of ids: no Python loop over rows that agree).
+    ref_*: the structural oracle in the production call pattern, rows in any order; got_*: the engine, rows ascending.
+    Rows may differ only by routes the reference LOSES to quirk (ii) (see assert_rows_equal_modulo_quirk_ii).
+    all_keys_fn() -> every key of the index (only called if some row differs); key_of(rank) -> key.  Returns #rows that differed."""
+    ref_vals = csr_sorted(ref_rp, ref_vals)
+    n = len(ref_rp) - 1
+    assert len(got_rp) - 1 == n
+    if np.array_equal(ref_rp, got_rp) and np.array_equal(ref_vals, got_vals):
+        return 0
+    rc, gc = np.diff(ref_rp), np.diff(got_rp)
+
+    def row_sums(rp, vals):  # order-independent 64-bit checksum per row (empty rows: 0)
+        x = (vals.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        cs = np.concatenate([[np.uint64(0)], np.cumsum(x, dtype=np.uint64)])
+        return cs[rp[1:]] - cs[rp[:-1]]
+
+    differ = (rc != gc) | (row_sums(ref_rp, ref_vals) != row_sums(got_rp, got_vals))
+    same = np.nonzero(~differ)[0]
+    a_rp, a = csr_select(ref_rp, ref_vals, same)
+    b_rp, b = csr_select(got_rp, got_vals, same)
+    assert np.array_equal(a, b)  # the rows whose checksums agree are really equal
+    quirk = quirk_ii_filters(all_keys_fn())
+    for i in np.nonzero(differ)[0]:
+        ref = set(ref_vals[ref_rp[i]:ref_rp[i + 1]].tolist())
+        got = set(got_vals[got_rp[i]:got_rp[i + 1]].tolist())
+        assert ref <= got, i
+        for r in got - ref:
+            flag, tenant, mqtt, _ = O.parse_route_key(key_of(r))
+            if flag != 1:
+                mqtt = mqtt.split("/", 2)[2]
+            assert (tenant, mqtt) in quirk, (i, mqtt)
+    return int(differ.sum())
+
+
 def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_tenants=16, n_sample=2000, seed=0xB1F20005):
     """configs[4]: an index of n_tenants x per_tenant generated routes, then ONE batch of n_ops mutations (50 % unsubscribes of
     existing routes, 50 % subscribes of new filters, spread over all tenants) through bmq_routes_apply, then a batch of
-    publishes.  Checked: route count, ids are ranks again (route_key of sampled ids), CSR well-formed and ascending, tenant
-    isolation with the NEW id ranges, sampled rows of the first tenants bit-exact vs the oracle on the updated key set.
+    publishes.  Checked: route count, id stability (surviving routes keep their rank ids, deleted ids are dead, the j-th new
+    route got id n_keys + j), CSR well-formed and ascending, tenant isolation of every id, sampled rows of the first tenants
+    bit-exact vs the oracle on the updated key set.
     match_fn(tenants, topic_tenant, (data, off)) -> (row_ptr, ids): the engine's batch match (GPU), or a stand-in in the CPU test
     of this helper."""
     import random
@@ -142,7 +207,9 @@ def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_ten
     per_tenant_delta = np.zeros(n_tenants, dtype=np.int64)
     owner = np.searchsorted(first, np.asarray(del_ids), side="right") - 1
     np.subtract.at(per_tenant_delta, owner, 1)
-    added = {}
+    added = {}      # key -> tenant index
+    added_id = {}   # key -> the id the engine must have given it: n_keys + (number of puts before it in the batch)
+    n_del = len(ops)
     for q in range(n_ops - n_ops // 2):
         t = rnd.randrange(n_tenants)
         # two in three new filters match nothing published ("churn/..."), the third is "<first level>/#" and matches a lot
@@ -150,24 +217,28 @@ def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_ten
         k = B.route_key(tn[t], f, 1, "0\0c%d\0d%d" % (q, q % 64))
         if k not in added:
             added[k] = t
+            added_id[k] = w.n_keys + q
             per_tenant_delta[t] += 1
         ops.append((0, k))
     eng.apply(ops)
+    assert len(ops) - n_del == n_ops - n_ops // 2
     n_new = w.n_keys - len(del_ids) + len(added)
-    assert eng.info().n_routes == n_new
-    counts = np.diff(first) + per_tenant_delta
-    new_first = np.concatenate([[0], np.cumsum(counts)])
-    assert new_first[-1] == n_new
-    # the key set of the first S tenants after the batch = exactly the ids [0, new_first[S])
+    info = eng.info()
+    assert info.n_routes == n_new and info.next_route_id == w.n_keys + (n_ops - n_ops // 2)
+    # ids are stable: survivors keep their ranks, deleted ids are dead, new routes carry the ids the ABI promises
+    deleted = set(del_ids)
+    probe = sorted(rnd.sample(range(w.n_keys), min(300, w.n_keys))) + del_ids[:50]
+    for i, k in zip(probe, eng.route_keys(probe)):
+        assert k == (b"" if i in deleted else key_at(i)), i
+    some_added = rnd.sample(sorted(added), min(200, len(added)))
+    assert eng.route_keys([added_id[k] for k in some_added]) == some_added
+    owner_of_new = {added_id[k]: t for k, t in added.items()}
+    # the key set of the first S tenants after the batch
     S = min(sample_tenants, n_tenants)
     hi_old = int(first[S])
-    deleted = set(del_ids)
     keys_s = [key_at(i) for i in range(hi_old) if i not in deleted] + [k for k, t in added.items() if t < S]
     kv = O.KV(keys_s)  # sorts
     keys_sorted = sorted(keys_s)
-    assert len(keys_sorted) == new_first[S]
-    for i in sorted(rnd.sample(range(len(keys_sorted)), min(200, len(keys_sorted)))):
-        assert eng.route_key(i) == keys_sorted[i]
     data, off, tt = w.topics(seed + 1000, n_topics)
     row, ids = match_fn(tn, tt, (data, off))
     assert row[0] == 0 and row[-1] == len(ids) and (np.diff(row.astype(np.int64)) >= 0).all()
@@ -176,15 +247,21 @@ def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_ten
         starts = row[1:-1][row[1:-1] < len(ids)]
         d[(starts - 1)[starts > 0]] = 1
         assert (d > 0).all()
+        # tenant isolation: an old id lies in its tenant's rank range, a new id belongs to the tenant its put named
         own = np.repeat(tt.astype(np.int64), np.diff(row.astype(np.int64)))
-        assert ((ids >= new_first[own]) & (ids < new_first[own + 1])).all()
+        old = ids < w.n_keys
+        assert ((ids[old] >= first[own[old]]) & (ids[old] < first[own[old] + 1])).all()
+        assert not np.isin(ids[old], np.asarray(del_ids)).any()
+        for x, o in zip(ids[~old].tolist(), own[~old].tolist()):
+            assert owner_of_new[x] == o
     cand = np.nonzero(tt < S)[0]
     sample = sorted(rnd.sample(cand.tolist(), min(n_sample, len(cand))))
     traw = data.tobytes()
     topics = [traw[off[i]:off[i + 1]] for i in sample]
     stt = tt[sample]
-    res, _ = kv.match_singletons(tn[:S], stt, O.pack(topics), threads=8)
-    got = [ids[row[i]:row[i + 1]].tolist() for i in sample]
+    import os
+    res, _ = kv.match_singletons(tn[:S], stt, O.pack(topics), threads=os.cpu_count() or 8)
+    got = rows_as_ranks(eng, row, ids, keys_sorted, rows=sample)
     assert_rows_equal_modulo_quirk_ii(keys_sorted, tn[:S], stt.tolist(), [sorted(r) for r in res.per_topic()], got)
     assert any(keys_sorted[r] in added for g in got for r in g)  # routes subscribed by the batch are matched
     return n_new

@@ -1,18 +1,25 @@
-// host_fuzz.cpp -- test tool, not product: exercises the HOST side of the dist index (bmq_index.cpp: rebuild, incremental
-// apply, region growth, directory, dictionary, indirect ranges) under AddressSanitizer/UBSan, without a GPU.
-//   * model: std::set of route keys (byte order = KV order); ids must be the ranks in it;
-//   * after every rebuild/apply the HBM image (TenantSlot directory, TrieSlot regions, DictSlot table, route_pos) is walked
-//     on the CPU exactly as k_walk does it (bucket probes, Bloom mask, root payload from the directory) for random topics
-//     and compared with a brute-force application of the matching rule of SURVEY.md 8a-0 to every key of the model.
-// Build + run: make -C bifromq_amd/csrc fuzz   (tests/test_host.py runs a short round)
+// host_fuzz.cpp -- test tool, not product: runs the index BUILDER (bmq_build_core.h -- the code the gfx950 builder kernels
+// execute, bmq_dist_index.h -- its host-side control) on host threads through HostExec, under AddressSanitizer/UBSan or
+// ThreadSanitizer, without a GPU.
+//   * model: std::map route key -> id (byte order = KV order); after a rebuild ids must be the ranks, a put gets the next id,
+//     a key keeps its id until it is deleted;
+//   * after every rebuild/apply the image (TenantSlot directory, TrieSlot regions, DictSlot table, route_pos, key store) is
+//     walked on the CPU exactly as k_walk does it (bucket probes, Bloom mask, root payload from the directory) for random
+//     topics and compared with a brute-force application of the matching rule of SURVEY.md 8a-0 to every key of the model;
+//   * tiny initial capacities (BMQ_FUZZ_SMALL, default on) force region growth, dictionary growth, id-list pool growth,
+//     directory growth and key-store growth all the time.
+// Build + run: make -C bifromq_amd/csrc fuzz   (tests/test_host.py runs short rounds)
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <random>
 #include <set>
 #include <string>
 #include <vector>
 
-#include "../bifromq_amd/csrc/bmq_index.h"
+#include "../bifromq_amd/csrc/bmq_codec.h"
+#include "../bifromq_amd/csrc/bmq_dist_index.h"
+#include "../bifromq_amd/csrc/bmq_exec_host.h"
 
 using namespace bmq;
 
@@ -42,56 +49,83 @@ static bool filter_matches(const std::vector<std::string>& f, const std::vector<
     return f.size() == t.size();
 }
 
-// the walk of k_walk, on the host image
-static std::vector<uint32_t> image_match(const DistIndexHost& h, std::string_view tenant, std::string_view topic) {
-    std::vector<uint32_t> ids;
-    const uint32_t ttok = dict_find(h.dict, h.pool, tenant);
-    if (ttok == TOK_UNKNOWN) return ids;
-    const uint32_t mask = (uint32_t)h.tenants.size() - 1;
-    uint32_t d = tenant_hash(ttok) & mask;
-    while (h.tenants[d].token != ttok) {
-        if (h.tenants[d].token == 0) return ids;
-        d = (d + 1) & mask;
+static uint32_t dict_find_host(const DistIndex<HostExec>& h, std::string_view level) {
+    LevelHash lh = level_hash_init();
+    uint32_t inl[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < level.size(); i += 4) {
+        uint32_t w = 0;
+        for (size_t k = 0; k < 4 && i + k < level.size(); k++) w |= (uint32_t)(uint8_t)level[i + k] << (8 * k);
+        level_hash_word(lh, w);
+        if (i < 16) inl[i >> 2] = w;
     }
-    const TenantSlot rg = h.tenants[d];
+    const uint32_t gmask = h.dict_slots / DICT_GROUP - 1, tag = level_hash_tag(lh);
+    uint32_t g = level_hash_slot(lh, (uint32_t)level.size()) & gmask;
+    for (uint32_t probes = 0; probes <= gmask; probes++) {
+        bool group_full = true;
+        for (uint32_t j = 0; j < DICT_GROUP; j++) {
+            const DictSlot& d = h.dict[DICT_GROUP * g + j];
+            if (!d.tag) {
+                group_full = false;
+                continue;
+            }
+            if (d.tag == tag && d.len == level.size() && d.inl[0] == inl[0] && d.inl[1] == inl[1] && d.inl[2] == inl[2] && d.inl[3] == inl[3] &&
+                (level.size() <= 16 || memcmp(h.dpool + d.pool_off, level.data(), level.size()) == 0))
+                return d.token;
+        }
+        if (!group_full) return TOK_UNKNOWN;
+        g = (g + 1) & gmask;
+    }
+    return TOK_UNKNOWN;
+}
+
+// the walk of k_walk, on the host image
+static std::vector<uint32_t> image_match(const DistIndex<HostExec>& h, std::string_view tenant, std::string_view topic, uint64_t* visits) {
+    std::vector<uint32_t> ids;
+    const DistIndexMut ix = h.mut();
+    const uint32_t d = tenant_find(ix.tenants, ix.tenant_mask, ix.tenant_names, (const uint8_t*)tenant.data(), 0, tenant.size());
+    if (d == NONE) return ids;
+    const TenantSlot rg = h.dir[d];
     const auto levels = split(topic, '/');
     std::vector<uint32_t> toks;
-    for (auto& l : levels) toks.push_back(dict_find(h.dict, h.pool, l));
+    for (auto& l : levels) toks.push_back(dict_find_host(h, l));
     const bool sys = !levels[0].empty() && levels[0][0] == '$';
     auto emit = [&](uint32_t b, uint32_t cf) {
         const uint32_t c = cf & ~RANGE_INDIRECT;
-        for (uint32_t i = 0; i < c; i++) ids.push_back((cf & RANGE_INDIRECT) ? h.route_pos[rg.rp_base + b + i] : rg.rank_base + b + i);
+        for (uint32_t i = 0; i < c; i++) ids.push_back((cf & RANGE_INDIRECT) ? h.route_pos[b + i] : b + i);
     };
     struct Item {
-        uint32_t slot, dl;
+        uint32_t node, tok, level;
     };
     std::vector<Item> st;
-    auto visit = [&](uint32_t slot, uint32_t dl, uint32_t own_b, uint32_t own_c, uint32_t hash_b, uint32_t hash_c, uint32_t plus, uint32_t bloom) {
+    auto visit = [&](uint32_t node, uint32_t dl, uint32_t own_b, uint32_t own_c, uint32_t hash_b, uint32_t hash_c, uint32_t bloom) {
         const bool root_sys = dl == 0 && sys;
         if (dl == toks.size() && own_c) emit(own_b, own_c);
         if (hash_c && !root_sys) emit(hash_b, hash_c);
         if (dl < toks.size()) {
             const uint32_t t = toks[dl];
-            if (t != TOK_UNKNOWN && ((bloom >> bloom_bit(t)) & 1u)) { // literal child: bucket probes, first-free order
-                uint32_t bk = edge_bucket(slot, t, rg.buckets);
-                for (;;) {
-                    const TrieSlot& a = h.trie[rg.base + 2 * bk];
-                    const TrieSlot& b = h.trie[rg.base + 2 * bk + 1];
-                    if (a.parent == slot && a.token == t) { st.push_back({2 * bk, dl + 1}); break; }
-                    if (b.parent == slot && b.token == t) { st.push_back({2 * bk + 1, dl + 1}); break; }
-                    if (a.parent == NONE || b.parent == NONE) break;
-                    bk = bk + 1 == rg.buckets ? 0 : bk + 1;
-                }
-            }
-            if (plus != NONE && !root_sys) st.push_back({plus, dl + 1});
+            if (t != TOK_UNKNOWN && ((bloom >> bloom_bit(t)) & 1u)) st.push_back({node, t, dl});
+            if ((bloom & BLOOM_PLUS) && !root_sys) st.push_back({node, TOK_PLUS, dl});
         }
     };
-    visit(rg.root, 0, 0, 0, rg.root_hash_begin, rg.root_hash_count, rg.root_plus_child, rg.root_lit_bloom); // round 0: payload from the directory
+    visit(0, 0, 0, 0, rg.root_hash_begin, rg.root_hash_count, rg.root_lit_bloom); // round 0: payload from the directory
     while (!st.empty()) {
         const Item it = st.back();
         st.pop_back();
-        const TrieSlot& s = h.trie[rg.base + it.slot];
-        visit(it.slot, it.dl, s.own_begin, s.own_count, s.hash_begin, s.hash_count, s.plus_child, s.lit_bloom);
+        uint32_t bk = edge_bucket(it.node, it.tok, rg.buckets);
+        for (uint32_t probes = 0; probes < rg.buckets; probes++) { // bucket probes, first-free order
+            const TrieSlot& a = h.trie[rg.base + 2 * bk];
+            const TrieSlot& b = h.trie[rg.base + 2 * bk + 1];
+            const TrieSlot* hit = nullptr;
+            if (a.parent == it.node && a.token == it.tok) hit = &a;
+            else if (b.parent == it.node && b.token == it.tok) hit = &b;
+            if (hit) {
+                if (visits) (*visits)++;
+                visit(hit->node, it.level + 1, hit->own_begin, hit->own_count, hit->hash_begin, hit->hash_count, hit->lit_bloom);
+                break;
+            }
+            if (a.parent == NONE || b.parent == NONE) break;
+            bk = bk + 1 == rg.buckets ? 0 : bk + 1;
+        }
     }
     std::sort(ids.begin(), ids.end());
     return ids;
@@ -101,9 +135,11 @@ int main(int argc, char** argv) {
     const uint64_t seed = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
     const int rounds = argc > 2 ? atoi(argv[2]) : 30;
     const size_t max_keys = argc > 3 ? (size_t)atoll(argv[3]) : 3000; // keys of a rebuild round
+    const unsigned threads = argc > 4 ? (unsigned)atoi(argv[4]) : 4;
     std::mt19937_64 rng(seed);
-    const std::vector<std::string> tenants = {"t", "tenantB", "x", "a-much-longer-tenant-identifier"};
-    const std::vector<std::string> alpha = {"a", "b", "c", "", "$sys", "+", "a-level-longer-than-sixteen-bytes", "\xE4\xBD\xA0\xE5\xA5\xBD", "0"};
+    std::vector<std::string> tenants = {"t", "tenantB", "x", "a-much-longer-tenant-identifier", ""};
+    const std::vector<std::string> alpha = {"a", "b", "c", "", "$sys", "+", "a-level-longer-than-sixteen-bytes", "\xE4\xBD\xA0\xE5\xA5\xBD", "0",
+                                            "exactly-16-bytes", "seventeen-bytes-x", "#"};
     auto rnd = [&](size_t n) { return (size_t)(rng() % n); };
     auto rand_filter = [&]() {
         std::string f;
@@ -111,7 +147,11 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < depth; i++) {
             if (i) f += '/';
             if (i + 1 == depth && rnd(5) == 0) f += "#";
-            else f += alpha[rnd(alpha.size())];
+            else {
+                std::string l = alpha[rnd(alpha.size())];
+                if (l == "#") l = "#x"; // '#' is a wildcard only as the last level; as a literal level it never appears in a valid filter
+                f += l;
+            }
         }
         return f;
     };
@@ -121,20 +161,26 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < depth; i++) {
             if (i) t += '/';
             std::string l = alpha[rnd(alpha.size())];
-            if (l == "+") l = "zz"; // topics carry no wildcards; "zz" is never a filter level
+            if (l == "+" || l == "#") l = "zz"; // topics carry no wildcards; "zz" is never a filter level
             t += l;
         }
         return t;
     };
+    uint64_t extra_tenants = 0;
     auto rand_key = [&]() {
+        if (rnd(400) == 0) tenants.push_back("late-tenant-" + std::to_string(extra_tenants++)); // tenants appear over time
         const std::string& tn = tenants[rnd(tenants.size())];
         const uint8_t flag = rnd(10) == 0 ? 2 : 1;
-        const std::string recv = flag == 1 ? "0\0inbox" + std::to_string(rnd(40)) + std::string("\0d", 2) : "g" + std::to_string(rnd(3));
-        return encode_route_key(tn, rand_filter(), flag, flag == 1 ? std::string("0\0", 2) + "inbox" + std::to_string(rnd(40)) + std::string("\0d", 2) : recv);
+        return encode_route_key(tn, rand_filter(), flag,
+                                flag == 1 ? std::string("0\0", 2) + "inbox" + std::to_string(rnd(40)) + std::string("\0d", 2) : "g" + std::to_string(rnd(3)));
     };
-    std::set<std::string> model;
-    DistIndexHost h;
-    uint64_t checks = 0;
+    std::map<std::string, uint32_t> model; // key -> id
+    uint32_t next_id = 0;
+    HostExec hx;
+    hx.threads = threads;
+    DistIndex<HostExec> h(hx);
+    h.tiny = getenv("BMQ_FUZZ_BIG") == nullptr;
+    uint64_t checks = 0, n_apply = 0, n_rebuild = 0;
     for (int round = 0; round < rounds; round++) {
         std::vector<std::string> keys;
         std::vector<uint8_t> ops;
@@ -142,26 +188,40 @@ int main(int argc, char** argv) {
         if (full) {
             model.clear();
             const size_t n = rnd(3) == 0 ? 0 : 1 + rnd(max_keys);
-            for (size_t i = 0; i < n; i++) model.insert(rand_key());
-            keys.assign(model.begin(), model.end());
-            std::shuffle(keys.begin(), keys.end(), rng);
+            std::set<std::string> ks;
+            for (size_t i = 0; i < n; i++) ks.insert(rand_key());
+            keys.assign(ks.begin(), ks.end());
+            uint32_t r = 0;
+            for (auto& k : ks) model[k] = r++;
+            next_id = r;
+            if (rnd(3) == 0) { // not a KV scan: shuffled and with a duplicate
+                std::shuffle(keys.begin(), keys.end(), rng);
+                if (!keys.empty()) keys.push_back(keys[0]);
+            }
+            n_rebuild++;
         } else {
             const size_t n = 1 + rnd(rnd(4) == 0 ? 2000 : 60);
             for (size_t i = 0; i < n; i++) {
                 if (!model.empty() && rnd(2)) { // delete an existing key (or, rarely, a key that is not there)
                     auto it = model.begin();
                     std::advance(it, rnd(std::min<size_t>(model.size(), 500)));
-                    keys.push_back(rnd(20) ? *it : rand_key());
+                    keys.push_back(rnd(20) ? it->first : rand_key());
                     ops.push_back(1);
                 } else {
-                    keys.push_back(rand_key());
+                    keys.push_back(rnd(6) == 0 && !keys.empty() ? keys[rnd(keys.size())] : rand_key()); // sometimes a key of this very batch again
                     ops.push_back(0);
                 }
             }
-            for (size_t i = 0; i < keys.size(); i++) { // in order
+            uint32_t put_no = 0;
+            for (size_t i = 0; i < keys.size(); i++) { // in order; a put's id = next_id + number of puts before it
                 if (ops[i]) model.erase(keys[i]);
-                else model.insert(keys[i]);
+                else {
+                    if (!model.count(keys[i])) model[keys[i]] = next_id + put_no;
+                    put_no++;
+                }
             }
+            next_id += put_no;
+            n_apply++;
         }
         std::vector<uint8_t> bytes;
         std::vector<uint32_t> off{0};
@@ -169,91 +229,115 @@ int main(int argc, char** argv) {
             bytes.insert(bytes.end(), k.begin(), k.end());
             off.push_back((uint32_t)bytes.size());
         }
+        bytes.resize(bytes.size() + 16, 0);
         const bool ok = full ? h.rebuild(bytes.data(), off.data(), (uint32_t)keys.size()) : h.apply(bytes.data(), off.data(), ops.data(), (uint32_t)keys.size());
         if (!ok) {
             fprintf(stderr, "round %d: %s failed: %s\n", round, full ? "rebuild" : "apply", h.error.c_str());
             return 1;
         }
-        // ids are ranks
-        if (h.n_routes != model.size()) {
-            fprintf(stderr, "round %d: n_routes %llu != %zu\n", round, (unsigned long long)h.n_routes, model.size());
+        DistIndexStats st;
+        h.stats(st);
+        if (st.n_routes != model.size() || st.next_id != next_id) {
+            fprintf(stderr, "round %d (%s): n_routes %llu (model %zu) next_id %u (model %u)\n", round, full ? "rebuild" : "apply",
+                    (unsigned long long)st.n_routes, model.size(), st.next_id, next_id);
             return 1;
         }
-        std::vector<std::string> ordered(model.begin(), model.end());
-        for (size_t i = 0; i < ordered.size(); i += 1 + ordered.size() / 300)
-            if (h.route_key((uint32_t)i) != ordered[i]) {
-                fprintf(stderr, "round %d: route_key(%zu) differs\n", round, i);
+        { // tenants with routes
+            std::set<std::string> live;
+            for (auto& e : model) {
+                RouteKeyParts kp;
+                decode_route_key(e.first, kp);
+                live.insert(std::string(kp.tenant));
+            }
+            if (st.n_tenants != live.size()) {
+                fprintf(stderr, "round %d: n_tenants %llu != %zu\n", round, (unsigned long long)st.n_tenants, live.size());
                 return 1;
             }
+        }
+        // id -> key, single and batched
+        std::vector<uint32_t> all_ids;
+        for (auto& e : model) all_ids.push_back(e.second);
+        size_t q = 0;
+        for (auto& e : model) {
+            if (q++ % (1 + model.size() / 300)) continue;
+            std::string k;
+            if (!h.route_key(e.second, k) || k != e.first) {
+                fprintf(stderr, "round %d: route_key(%u) differs\n", round, e.second);
+                return 1;
+            }
+        }
+        {
+            std::vector<uint8_t> kb;
+            std::vector<uint64_t> ko;
+            if (!h.route_keys(all_ids.data(), (uint32_t)all_ids.size(), kb, ko)) return 3;
+            size_t i = 0;
+            for (auto& e : model) {
+                if (std::string_view((const char*)kb.data() + ko[i], ko[i + 1] - ko[i]) != e.first) {
+                    fprintf(stderr, "round %d: route_keys entry %zu differs\n", round, i);
+                    return 1;
+                }
+                i++;
+            }
+        }
         // decoded form of the model, for the brute force
         struct Dec {
             std::string tenant;
             std::vector<std::string> levels;
+            uint32_t id;
         };
-        std::vector<Dec> dec(ordered.size());
-        for (size_t i = 0; i < ordered.size(); i++) {
+        std::vector<Dec> dec;
+        std::map<std::pair<std::string, std::string>, std::vector<uint32_t>> by_filter;
+        for (auto& e : model) {
             RouteKeyParts kp;
-            if (!decode_route_key(ordered[i], kp)) return 2;
-            dec[i].tenant = std::string(kp.tenant);
-            dec[i].levels = split(kp.esc_filter, '\0');
+            if (!decode_route_key(e.first, kp)) return 2;
+            dec.push_back({std::string(kp.tenant), split(kp.esc_filter, '\0'), e.second});
+            std::string mq(kp.esc_filter);
+            for (auto& c : mq)
+                if (c == '\0') c = '/';
+            by_filter[{std::string(kp.tenant), mq}].push_back(e.second);
         }
-        for (int q = 0; q < 150; q++) {
-            const std::string& tn = q % 25 == 24 ? std::string("nobody") : tenants[rnd(tenants.size())];
+        { // exact filter lookup
+            size_t i = 0;
+            for (auto& e : by_filter) {
+                if (i++ % (1 + by_filter.size() / 60)) continue;
+                std::vector<uint32_t> got, want = e.second;
+                std::sort(want.begin(), want.end());
+                if (!h.find(e.first.first, e.first.second, got)) return 3;
+                std::sort(got.begin(), got.end());
+                if (got != want) {
+                    fprintf(stderr, "round %d: find('%s','%s') gives %zu ids, model %zu\n", round, e.first.first.c_str(), e.first.second.c_str(), got.size(),
+                            want.size());
+                    return 1;
+                }
+            }
+        }
+        for (int tq = 0; tq < 150; tq++) {
+            const std::string& tn = tq % 25 == 24 ? std::string("nobody") : tenants[rnd(tenants.size())];
             const std::string topic = rand_topic();
             const auto tl = split(topic, '/');
             std::vector<uint32_t> want;
-            for (size_t i = 0; i < dec.size(); i++)
-                if (dec[i].tenant == tn && filter_matches(dec[i].levels, tl)) want.push_back((uint32_t)i);
-            const auto got = image_match(h, tn, topic);
+            for (auto& d : dec)
+                if (d.tenant == tn && filter_matches(d.levels, tl)) want.push_back(d.id);
+            std::sort(want.begin(), want.end());
+            const auto got = image_match(h, tn, topic, nullptr);
             checks++;
             if (got != want) {
                 fprintf(stderr, "round %d (%s): tenant '%s' topic '%s': image gives %zu ids, the rule %zu\n", round, full ? "rebuild" : "apply", tn.c_str(),
                         topic.c_str(), got.size(), want.size());
                 for (uint32_t id : want)
-                    if (!std::binary_search(got.begin(), got.end(), id)) {
-                        std::string f;
-                        for (auto& l : dec[id].levels) f += (f.empty() ? "" : "/") + (l.empty() ? std::string("<empty>") : l);
-                        fprintf(stderr, "  missing id %u filter %s\n", id, f.c_str());
-                        std::string mq;
-                        for (size_t li = 0; li < dec[id].levels.size(); li++) mq += (li ? "/" : "") + dec[id].levels[li];
-                        {
-                            auto it = h.by_name.find(tn);
-                            if (it != h.by_name.end()) {
-                                const TenantState& t = *it->second;
-                                uint32_t used = 0;
-                                for (uint32_t k = 0; k < 2 * t.buckets; k++) used += h.trie[t.base + k].parent != NONE;
-                                fprintf(stderr, "  tenant state: keys %zu nodes %u buckets %u cap_slots %u used slots %u\n", t.keys.size(), t.n_nodes, t.buckets,
-                                        t.cap_slots, used);
-                            }
-                        }
-                        for (auto& e : h.by_name)
-                            fprintf(stderr, "    tenant '%s': base %u cap_slots %u buckets %u nodes %u keys %zu\n", e.first.c_str(), e.second->base, e.second->cap_slots,
-                                    e.second->buckets, e.second->n_nodes, e.second->keys.size());
-                        fprintf(stderr, "    next_free %u trie.size %zu\n", h.next_free, h.trie.size());
-                        {
-                            const TenantState& t = *h.by_name.find(tn)->second;
-                            for (uint32_t k = 0; k < t.cap_slots; k++) {
-                                const TrieSlot& q = h.trie[t.base + k];
-                                fprintf(stderr, "      slot %u: parent %x token %u own %u+%u hash %u+%u plus %x bloom %08x\n", k, q.parent, q.token, q.own_begin, q.own_count,
-                                        q.hash_begin, q.hash_count, q.plus_child, q.lit_bloom);
-                            }
-                        }
-                        const auto ff = h.find_filter(tn, mq);
-                        fprintf(stderr, "  find_filter('%s') -> %zu ids%s\n", mq.c_str(), ff.size(), ff.empty() ? "" : (ff[0] == id ? " (first == id)" : " (other)"));
-                        const uint32_t ttok = dict_find(h.dict, h.pool, tn);
-                        uint32_t dd = tenant_hash(ttok) & ((uint32_t)h.tenants.size() - 1);
-                        while (h.tenants[dd].token != ttok) dd = (dd + 1) & ((uint32_t)h.tenants.size() - 1);
-                        const TenantSlot rg = h.tenants[dd];
-                        const TrieSlot& root = h.trie[rg.base + rg.root];
-                        fprintf(stderr, "  directory: root %u bloom %08x plus %u hash_count %u | root slot: bloom %08x plus %u hash_count %u\n", rg.root,
-                                rg.root_lit_bloom, rg.root_plus_child, rg.root_hash_count, root.lit_bloom, root.plus_child, root.hash_count);
-                    }
+                    if (!std::binary_search(got.begin(), got.end(), id)) fprintf(stderr, "  missing id %u\n", id);
                 for (uint32_t id : got)
                     if (!std::binary_search(want.begin(), want.end(), id)) fprintf(stderr, "  extra id %u\n", id);
                 return 1;
             }
         }
     }
-    printf("host_fuzz ok: seed %llu, %d rounds, %llu topic checks, final %zu routes\n", (unsigned long long)seed, rounds, (unsigned long long)checks, model.size());
+    DistIndexStats st;
+    h.stats(st);
+    printf("host_fuzz ok: seed %llu, %d rounds (%llu rebuilds, %llu applies), %llu topic checks, final %zu routes, %llu nodes, %llu tokens, "
+           "%llu trie slots (%llu garbage), %llu id-list words (%llu garbage)\n",
+           (unsigned long long)seed, rounds, (unsigned long long)n_rebuild, (unsigned long long)n_apply, (unsigned long long)checks, model.size(),
+           (unsigned long long)st.n_nodes, (unsigned long long)st.n_tokens, (unsigned long long)st.trie_slots, (unsigned long long)st.trie_garbage_slots,
+           (unsigned long long)st.id_list_words, (unsigned long long)st.id_list_garbage);
     return 0;
 }
