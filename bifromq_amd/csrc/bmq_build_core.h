@@ -30,53 +30,48 @@
 namespace bmq {
 
 // ------------------------------------------------------------------------------------------------------------
-// atomics: device = agent-scope HIP builtins, host = GCC/clang __atomic builtins (the fuzzers run these under TSan)
+// shared-memory accesses of the builder
 // ------------------------------------------------------------------------------------------------------------
-template <class T> BMQ_HD T atom_load(const T* p) {
+// MI355X has eight XCDs with private, mutually NON-coherent L2s, and an agent-scope acquire / release costs a cache-wide
+// buffer_inv / buffer_wbl2 (1.7-6.5 us each, MI355X_MICROARCH.md "inter-workgroup visibility").  A builder lane does a dozen
+// dependent probes per key, so fences per probe are out of the question (measured: locate of 100 k ops 1.9 ms with acquire
+// loads).  Instead every access to memory that ANOTHER lane of the SAME kernel may write goes around the caches:
+//   * claims and counters are relaxed agent-scope read-modify-write atomics (executed at the memory side, coherent by nature);
+//   * payload written before a publication is stored with relaxed agent-scope atomic stores (`sc1`: write-through, the line
+//     leaves the L2), then `s_waitcnt vmcnt(0)` drains them, then the flag is stored the same way (atom_publish);
+//   * readers poll the flag and read the payload with relaxed agent-scope atomic loads (`sc1`), which is sufficient exactly
+//     because the producer stored `sc1` (same document, "handoff-flag").
+// Data produced by an EARLIER kernel (or read only by later kernels) is accessed with plain loads / stores: kernel boundaries
+// are the acquire / release.  On the host (HostExec, sanitizer builds) the same functions use acquire / release atomics.
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return __atomic_load_n(p, __ATOMIC_ACQUIRE);
-#endif
-}
-template <class T> BMQ_HD void atom_store(T* p, T v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    __atomic_store_n(p, v, __ATOMIC_RELEASE);
-#endif
+#define BMQ_MO_LOAD __ATOMIC_RELAXED
+#define BMQ_MO_STORE __ATOMIC_RELAXED
+#define BMQ_MO_RMW __ATOMIC_RELAXED
+template <class T> BMQ_HD T atom_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> BMQ_HD void shared_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> BMQ_HD T shared_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> BMQ_HD void atom_publish(T* p, T v) { // everything this lane stored before is in memory before the flag is
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <class T> BMQ_HD T atom_cas(T* p, T expect, T desired) { // returns the value found
-#if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
-#endif
+    __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return expect;
 }
-template <class T> BMQ_HD T atom_add(T* p, T v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_fetch_add(p, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+template <class T> BMQ_HD T atom_add(T* p, T v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> BMQ_HD T atom_or(T* p, T v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
-    return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL);
-#endif
+template <class T> BMQ_HD T atom_load(const T* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+template <class T> BMQ_HD void shared_store(T* p, T v) { *p = v; } // ordered by the release store of the flag that follows
+template <class T> BMQ_HD T shared_load(const T* p) { return *p; } // ordered by the acquire load of the flag before
+template <class T> BMQ_HD void atom_publish(T* p, T v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+template <class T> BMQ_HD T atom_cas(T* p, T expect, T desired) { // returns the value found
+    __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+    return expect;
 }
-template <class T> BMQ_HD T atom_or(T* p, T v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_fetch_or(p, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return __atomic_fetch_or(p, v, __ATOMIC_ACQ_REL);
+template <class T> BMQ_HD T atom_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+template <class T> BMQ_HD T atom_or(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_ACQ_REL); }
 #endif
-}
-template <class T> BMQ_HD T atom_max(T* p, T v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_fetch_max(p, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    T cur = __atomic_load_n(p, __ATOMIC_ACQUIRE);
-    while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {}
-    return cur;
-#endif
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // state
@@ -91,10 +86,12 @@ enum : uint32_t {
 
 // Persistent counters of the index + per-batch results of the builder kernels (device memory; the host reads it back
 // after prepare and after group).
+// Same-address atomics serialise in the L2 atomic unit (~15 ns each under contention: 23 M node creations of a bulk load bumping
+// ONE counter cost 350 ms), so nothing hot counts into a single word: nodes are counted per tenant (TenantSlot.n_nodes), batch
+// results into N_CTR_LANES copies indexed by the work item, summed by the host.
+constexpr uint32_t N_CTR_LANES = 64;
 struct BuildCounters {
     // persistent
-    unsigned long long n_routes;   // live routes
-    unsigned long long n_nodes;    // trie nodes (tenant roots excluded)
     unsigned long long rp_used;    // words handed out in route_pos (word 0 is never used)
     unsigned long long rp_garbage; // words of abandoned id lists
     uint32_t n_tokens;             // dictionary tokens handed out (next = TOK_FIRST + n_tokens)
@@ -104,13 +101,12 @@ struct BuildCounters {
     uint32_t n_unknown;            // ops whose tenant is not in the directory (listed in unknown_list)
     uint32_t n_grow;               // tenants whose region must grow first (listed in grow_list)
     uint32_t n_deferred;           // groups that found the id-list pool full (re-run after the host grew it)
-    unsigned long long batch_levels; // sum of the level counts of the batch's put keys (bounds new dictionary entries)
-    unsigned long long batch_level_bytes; // sum of their lengths (bounds the string pool)
     unsigned long long rp_need;    // id-list words the deferred groups asked for
-    uint32_t n_dups;               // puts of keys that were already there
-    uint32_t n_removed;            // deletes that removed a route
-    uint32_t n_added;
     uint32_t n_bulk_tenants;       // bulk load: number of tenants (runs of equal tenant id in the sorted scan)
+    uint32_t pad0;
+    uint32_t n_dups[N_CTR_LANES];    // puts of keys that were already there
+    uint32_t n_removed[N_CTR_LANES]; // deletes that removed a route
+    uint32_t n_added[N_CTR_LANES];   // puts that added a route
 };
 
 // Everything the builder kernels touch.  All pointers are device pointers (host pointers under HostExec).
@@ -308,16 +304,16 @@ BMQ_HD uint32_t dict_intern(const DistIndexMut& ix, const LevelHash& h, uint32_t
                         atom_or(&ix.bc->err, (uint32_t)ERR_DICT_FULL);
                         off = 0; // keeps every reader inside the pool; the batch is abandoned by the host
                     } else
-                        for (uint32_t i = 0; i < len; i++) ix.dpool[off + i] = kp[start + i];
+                        for (uint32_t i = 0; i < len; i++) shared_store(ix.dpool + off + i, kp[start + i]);
                 }
-                s->len = len;
-                s->pool_off = off;
-                s->inl[0] = inl[0];
-                s->inl[1] = inl[1];
-                s->inl[2] = inl[2];
-                s->inl[3] = inl[3];
+                shared_store(&s->len, len);
+                shared_store(&s->pool_off, off);
+                shared_store(&s->inl[0], inl[0]);
+                shared_store(&s->inl[1], inl[1]);
+                shared_store(&s->inl[2], inl[2]);
+                shared_store(&s->inl[3], inl[3]);
                 const uint32_t tok = TOK_FIRST + atom_add(&ix.bc->n_tokens, 1u);
-                atom_store(&s->token, tok);
+                atom_publish(&s->token, tok);
                 return tok;
             }
         }
@@ -327,8 +323,12 @@ BMQ_HD uint32_t dict_intern(const DistIndexMut& ix, const LevelHash& h, uint32_t
                 spins++;
                 continue;
             }
-            bool eq = s->len == len && s->inl[0] == inl[0] && s->inl[1] == inl[1] && s->inl[2] == inl[2] && s->inl[3] == inl[3];
-            if (eq && len > 16) eq = bytes_equal(ix.dpool, s->pool_off, kp, start, len);
+            bool eq = shared_load(&s->len) == len && shared_load(&s->inl[0]) == inl[0] && shared_load(&s->inl[1]) == inl[1] &&
+                      shared_load(&s->inl[2]) == inl[2] && shared_load(&s->inl[3]) == inl[3];
+            if (eq && len > 16) {
+                const uint32_t po = shared_load(&s->pool_off);
+                for (uint32_t i = 16; i < len && eq; i++) eq = shared_load(ix.dpool + po + i) == kp[start + i];
+            }
             if (eq) return tok;
         }
         if (++j == DICT_GROUP) { // next group; a lookup may stop at a group with a free slot only when it is not inserting
@@ -370,8 +370,7 @@ BMQ_HD uint32_t trie_child(const DistIndexMut& ix, TenantSlot* ten, uint32_t bas
             k = atom_cas(kp64, EDGE_EMPTY, key);
             if (k == EDGE_EMPTY) { // claimed (payload of a free slot is all zero, node = NONE): publish the node id
                 const uint32_t id = atom_add(&ten->n_nodes, 1u) + 1u;
-                atom_add(&ix.bc->n_nodes, 1ull);
-                atom_store(&s->node, id);
+                atom_publish(&s->node, id);
                 slot_abs = (unsigned long long)base + 2ull * bk + j;
                 created = true;
                 return id;
@@ -444,8 +443,6 @@ BMQ_HD void prepare_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t i) {
     if (!is_put) return; // a delete adds nothing; with an unknown tenant it is a no-op
     uint32_t nl, lb;
     key_level_stats(ix.kpool, k, nl, lb);
-    atom_add(&ix.bc->batch_levels, (unsigned long long)nl);
-    atom_add(&ix.bc->batch_level_bytes, (unsigned long long)lb);
     if (d == NONE) {
         const uint32_t p = atom_add(&ix.bc->n_unknown, 1u);
         ob.unknown_list[p] = i;
@@ -483,8 +480,6 @@ BMQ_HD void bulk_prepare_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t
     }
     uint32_t nl, lb;
     key_level_stats(ix.kpool, k, nl, lb);
-    atom_add(&ix.bc->batch_levels, (unsigned long long)nl);
-    atom_add(&ix.bc->batch_level_bytes, (unsigned long long)lb);
     bool new_tenant = i == 0;
     uint32_t shared = 0;
     if (i > 0) {
@@ -762,13 +757,13 @@ BMQ_HD void group_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t p) {
     *pc = s.cf;
     ob.group_done[p] = 1;
     if (garbage) atom_add(&ix.bc->rp_garbage, garbage);
-    if (dups) atom_add(&ix.bc->n_dups, dups);
-    if (removed) atom_add(&ix.bc->n_removed, removed);
-    if (added) atom_add(&ix.bc->n_added, added);
+    const uint32_t cl = p & (N_CTR_LANES - 1);
+    if (dups) atom_add(&ix.bc->n_dups[cl], dups);
+    if (removed) atom_add(&ix.bc->n_removed[cl], removed);
+    if (added) atom_add(&ix.bc->n_added[cl], added);
     if (added != removed) {
-        atom_add(&ix.bc->n_routes, (unsigned long long)added - (unsigned long long)removed); // two's complement: may subtract
         uint32_t d = ob.dir_slot[ob.order[p]];
-        if (d != NONE) atom_add(&ix.tenants[d].n_routes, added - removed);
+        if (d != NONE) atom_add(&ix.tenants[d].n_routes, added - removed); // two's complement: may subtract
     }
 }
 

@@ -19,6 +19,7 @@
 //   std::string err;
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -44,6 +45,21 @@ struct ApplyResult {
 };
 
 template <class Exec> class DistIndex {
+    // BMQ_TIMING=1: phase times on stderr (each lap synchronises the exec first, so the numbers include the kernels)
+    struct PhaseTimer {
+        Exec& x;
+        bool on;
+        std::chrono::steady_clock::time_point t0;
+        explicit PhaseTimer(Exec& ex) : x(ex), on(getenv("BMQ_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+        void lap(const char* what) {
+            if (!on) return;
+            (void)x.sync();
+            const auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[bmq index] %-34s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        }
+    };
+
 public:
     explicit DistIndex(Exec& exec) : x(exec) {}
     ~DistIndex() { drop(); }
@@ -72,6 +88,7 @@ public:
     unsigned long long* kref = nullptr;
     uint32_t* khash = nullptr;
     uint32_t id_cap = 0, next_id = 0;
+    uint64_t n_routes = 0; // live routes (host count: rebuild sets it, every apply adds what the groups report)
     uint8_t* kpool = nullptr;
     uint64_t kpool_cap = 0, kpool_used = 0;
     BuildCounters* bc = nullptr;
@@ -154,7 +171,9 @@ public:
             n_put += op[i] == 0;
         }
         if ((uint64_t)next_id + n_put >= 0xFFFFFFF0ull) return fail("route id space exhausted: bmq_rebuild re-numbers the routes");
+        PhaseTimer pt(x);
         if (!ensure_keys(kb) || !ensure_ids(next_id + n_put) || !ensure_scratch(n, true)) return false;
+        pt.lap("apply: put ranks, buffers");
         OpBatch ob = batch(n);
         ob.key_base = kpool_used;
         ob.id_base = next_id;
@@ -164,6 +183,7 @@ public:
         if (!x.copy_in_async(kpool + kpool_used, keys, kb) || !x.copy_in_async(s_key_off, key_off, sizeof(uint32_t) * ((size_t)n + 1)) ||
             !x.copy_in_async(s_op, op, n) || !x.copy_in_async(s_put_rank, put_rank.data(), sizeof(uint32_t) * (size_t)n))
             return xfail();
+        pt.lap("apply: upload ops");
         // ---- prepare: validate + tenants + growth bounds (re-run once if tenants had to be created) ----
         for (int round = 0;; round++) {
             if (!zero_batch_counters()) return false;
@@ -187,7 +207,9 @@ public:
             if (!flush_directory()) return false;
             ob.grow_list = s_grow; // the directory may have grown, and its scratch with it
         }
+        pt.lap("apply: prepare (+ tenants)");
         if (!grow_flagged_regions(ob)) return false;
+        pt.lap("apply: region growth");
         // ---- locate (idempotent: re-run after growing what it ran out of) ----
         for (int attempt = 0;; attempt++) {
             if (attempt == 8) return broke("apply: growth did not converge");
@@ -199,22 +221,31 @@ public:
             if ((hbc.err & ERR_DICT_FULL) && !grow_dict(std::max<uint64_t>((uint64_t)dict_slots * 4, 4096), (uint64_t)dpool_cap * 2 + kb)) return false;
             if (!grow_flagged_regions(ob)) return false;
         }
+        pt.lap("apply: locate");
         // ---- sort by filter node, apply the groups ----
         if (!x.zero(ob.group_done, n) || !x.sort_targets(ob)) return xfail();
+        pt.lap("apply: sort by filter node");
         for (int attempt = 0;; attempt++) {
             if (attempt == 8) return broke("apply: id-list pool growth did not converge");
             if (!zero_batch_counters()) return false;
             DistIndexMut ix = mut();
             if (!x.group(ix, ob) || !read_counters()) return xfail();
             if (hbc.err) return broke("apply: group step failed");
-            if (res) {
-                res->added += hbc.n_added;
-                res->removed += hbc.n_removed;
-                res->dups += hbc.n_dups;
+            {
+                uint64_t a = 0, r = 0, du = 0;
+                for (uint32_t c = 0; c < N_CTR_LANES; c++) a += hbc.n_added[c], r += hbc.n_removed[c], du += hbc.n_dups[c];
+                n_routes += a;
+                n_routes -= r;
+                if (res) {
+                    res->added += (uint32_t)a;
+                    res->removed += (uint32_t)r;
+                    res->dups += (uint32_t)du;
+                }
             }
             if (hbc.n_deferred == 0) break;
             if (!grow_route_pos(hbc.rp_used + 2 * hbc.rp_need + 1024)) return false;
         }
+        pt.lap("apply: groups");
         kpool_used += (kb + 15) & ~15ull;
         next_id += n_put;
         if ((uint64_t)hbc.n_tokens * 4 > dict_slots && !grow_dict((uint64_t)dict_slots * 4, dpool_cap)) return false;
@@ -286,9 +317,12 @@ public:
         if (!read_counters()) return xfail();
         std::vector<TenantSlot> d(dir_slots);
         if (!x.copy_out(d.data(), dir, sizeof(TenantSlot) * (size_t)dir_slots)) return xfail();
-        for (auto& t : d) st.n_tenants += ((t.hash_lo | t.hash_hi) != 0 && t.n_routes != 0) ? 1 : 0;
-        st.n_routes = hbc.n_routes;
-        st.n_nodes = hbc.n_nodes;
+        for (auto& t : d)
+            if (t.hash_lo | t.hash_hi) {
+                st.n_tenants += t.n_routes != 0 ? 1 : 0;
+                st.n_nodes += t.n_nodes;
+            }
+        st.n_routes = n_routes;
         st.n_tokens = hbc.n_tokens;
         st.trie_slots = trie_used;
         st.dict_slots = dict_slots;
@@ -590,8 +624,12 @@ private:
             if (!x.copy_in(names + names_used, names_h.data() + names_used, names_h.size() - names_used)) return xfail();
             names_used = (uint32_t)names_h.size();
         }
-        for (uint32_t d : new_dir_slots)
-            if (!x.copy_in(dir + d, &dir_h[d], sizeof(TenantSlot))) return xfail();
+        if (new_dir_slots.size() == tenant_slot.size()) { // bulk load: every entry is new, one copy (no live counters to preserve yet)
+            if (!x.copy_in(dir, dir_h.data(), sizeof(TenantSlot) * (size_t)dir_slots)) return xfail();
+        } else {
+            for (uint32_t d : new_dir_slots)
+                if (!x.copy_in(dir + d, &dir_h[d], sizeof(TenantSlot))) return xfail();
+        }
         new_dir_slots.clear();
         dir_dirty = false;
         return true;
@@ -651,7 +689,9 @@ private:
 
     // the bulk pipeline on strictly ascending keys; err receives the builder's error flags
     bool rebuild_sorted(const uint8_t* keys, const uint32_t* key_off, uint32_t n, uint32_t& err) {
+        PhaseTimer pt(x);
         drop();
+        pt.lap("rebuild: drop old index");
         const uint64_t kb = n ? key_off[n] : 0;
         bc = (BuildCounters*)x.alloc(sizeof(BuildCounters));
         if (!bc) return fail("out of memory");
@@ -665,6 +705,7 @@ private:
         if (!grow_route_pos(tiny ? 8 : 1u << 16)) return false;
         if (!ensure_directory(tiny ? 1 : 64)) return false;
         next_id = 0;
+        n_routes = 0;
         if (n == 0) {
             if (!x.sync()) return xfail();
             return true;
@@ -678,6 +719,7 @@ private:
         ob.bulk = 1;
         if (!x.copy_in_async(kpool + kpool_used, keys, kb) || !x.copy_in_async(s_key_off, key_off, sizeof(uint32_t) * ((size_t)n + 1)))
             return xfail();
+        pt.lap("rebuild: alloc + upload keys");
         // ---- sizes: tenants (runs of the sorted scan) and their exact node counts ----
         if (!zero_batch_counters()) return false;
         DistIndexMut ix = mut();
@@ -710,6 +752,7 @@ private:
         if (!x.copy_out(bt_first.data(), s_bt_first, 4 * (size_t)n_ten) || !x.copy_out(bt_nodes.data(), s_bt_nodes, 4 * (size_t)n_ten) ||
             !x.copy_out(bt_keys.data(), s_bt_keys, 4 * (size_t)n_ten))
             return xfail();
+        pt.lap("rebuild: bulk prepare + tenant runs");
         // ---- tenants + regions ----
         if (!ensure_directory(n_ten)) return false;
         uint64_t total_slots = 0;
@@ -733,6 +776,7 @@ private:
         }
         if (!flush_directory()) return false;
         if (!x.copy_in(s_bt_dir, bt_dir.data(), 4 * (size_t)n_ten)) return xfail();
+        pt.lap("rebuild: directory + regions");
         // ---- locate (re-run with a larger dictionary if it filled up), sort, groups ----
         for (int attempt = 0;; attempt++) {
             if (attempt == 10) return fail("rebuild: dictionary growth did not converge");
@@ -743,7 +787,9 @@ private:
             if (!(hbc.err & ERR_DICT_FULL)) break;
             if (!grow_dict((uint64_t)dict_slots * 4, (uint64_t)dpool_cap * 4)) return false;
         }
+        pt.lap("rebuild: locate");
         if (!x.zero(ob.group_done, n) || !x.sort_targets(ob)) return xfail();
+        pt.lap("rebuild: sort by filter node");
         for (int attempt = 0;; attempt++) {
             if (attempt == 8) return fail("rebuild: id-list pool growth did not converge");
             if (!zero_batch_counters()) return false;
@@ -753,8 +799,8 @@ private:
             if (hbc.n_deferred == 0) break;
             if (!grow_route_pos(hbc.rp_used + 2 * hbc.rp_need + 1024)) return false;
         }
-        const unsigned long long nr = n;
-        if (!x.copy_in(&bc->n_routes, &nr, sizeof(nr))) return xfail();
+        pt.lap("rebuild: groups");
+        n_routes = n;
         kpool_used += (kb + 15) & ~15ull;
         next_id = n;
         // right-size the dictionary: load factor 1/4 keeps a lookup at one line, a small table stays cache resident
@@ -765,6 +811,7 @@ private:
         }
         if (!x.sync()) return xfail();
         release_scratch();
+        pt.lap("rebuild: dictionary resize, cleanup");
         return true;
     }
 };

@@ -416,9 +416,10 @@ def test_full_size_config2_properties(eng):
     sub_data[:int(sub_off[-1])] = np.frombuffer(b"".join(raw[off[i]:off[i + 1]] for i in sample), dtype=np.uint8)
     res, _ = kv.match_singletons(tn, np.zeros(len(sample), dtype=np.uint32), (sub_data, sub_off), threads=os.cpu_count() or 8)
     got_rp, got = U.csr_select(row, ids, sample)
-    n_diff = U.assert_csr_equal_modulo_quirk_ii(w.keys, kv.key, tn, None, res.row_ptr.astype(np.int64), res.routes, got_rp, got)
-    assert n_diff < len(sample) // 100
-    for i in sample[::2000]:  # authoritative semantic check on a sub-sample (O(keys) each)
+    differ = U.assert_csr_equal_modulo_quirk_ii(w.keys, kv.key, tn, None, res.row_ptr.astype(np.int64), res.routes, got_rp, got)
+    # rows where the reference loses routes to quirk (ii) (hot filters next to "<filter>/" filters: a few % of this workload) and a
+    # sub-sample of the others: the semantic oracle is authoritative (O(keys) each)
+    for i in [int(sample[j]) for j in differ[:25]] + sample[::4000].tolist():
         assert ids[row[i]:row[i + 1]].tolist() == kv.match_bruteforce(tn[0], [raw[off[i]:off[i + 1]]]).per_topic()[0]
     # duplicates: same topic string -> same row
     seen = {}
@@ -470,10 +471,9 @@ def test_full_size_config3_properties(eng):
     res, _ = kv.match_singletons(tn[:S], stt, (t_data, t_off), threads=os.cpu_count() or 8)
     got_rp, got = U.csr_select(row, ids, cand)  # ids of the first tenants are ranks in the sub-KV of exactly those tenants
     rawk = sub_bytes.tobytes()
-    n_diff = U.assert_csr_equal_modulo_quirk_ii(lambda: [rawk[sub_off[i]:sub_off[i + 1]] for i in range(hi)], kv.key, tn[:S], stt,
+    differ = U.assert_csr_equal_modulo_quirk_ii(lambda: [rawk[sub_off[i]:sub_off[i + 1]] for i in range(hi)], kv.key, tn[:S], stt,
                                                 res.row_ptr.astype(np.int64), res.routes, got_rp, got)
-    assert n_diff < len(cand) // 100
     rnd = random.Random(4)
-    for j in rnd.sample(range(len(cand)), 20):  # authoritative semantic check on a sub-sample
+    for j in differ[:20].tolist() + rnd.sample(range(len(cand)), 20):  # authoritative semantic check: quirk rows + a sub-sample
         i = int(cand[j])
         assert ids[row[i]:row[i + 1]].tolist() == kv.match_bruteforce(tn[int(tt[i])], [raw[off[i]:off[i + 1]]]).per_topic()[0]

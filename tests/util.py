@@ -144,12 +144,13 @@ def assert_csr_equal_modulo_quirk_ii(all_keys_fn, key_of, tenants, topic_tenant,
     """Whole-CSR comparison for the full-size tests (millions of ids: no Python loop over rows that agree).
     ref_*: the structural oracle in the production call pattern, rows in any order; got_*: the engine, rows ascending.
     Rows may differ only by routes the reference LOSES to quirk (ii) (see assert_rows_equal_modulo_quirk_ii).
-    all_keys_fn() -> every key of the index (only called if some row differs); key_of(rank) -> key.  Returns #rows that differed."""
+    all_keys_fn() -> every key of the index (only called if some row differs); key_of(rank) -> key.  Returns the indices of the
+    rows that differed (the caller checks a sample of them against the semantic oracle)."""
     ref_vals = csr_sorted(ref_rp, ref_vals)
     n = len(ref_rp) - 1
     assert len(got_rp) - 1 == n
     if np.array_equal(ref_rp, got_rp) and np.array_equal(ref_vals, got_vals):
-        return 0
+        return np.zeros(0, dtype=np.int64)
     rc, gc = np.diff(ref_rp), np.diff(got_rp)
 
     def row_sums(rp, vals):  # order-independent 64-bit checksum per row (empty rows: 0)
@@ -172,7 +173,7 @@ def assert_csr_equal_modulo_quirk_ii(all_keys_fn, key_of, tenants, topic_tenant,
             if flag != 1:
                 mqtt = mqtt.split("/", 2)[2]
             assert (tenant, mqtt) in quirk, (i, mqtt)
-    return int(differ.sum())
+    return np.nonzero(differ)[0]
 
 
 def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_tenants=16, n_sample=2000, seed=0xB1F20005):
