@@ -67,8 +67,16 @@ struct DevBuf {
 };
 
 struct RetainDevice { // the retained-topic index in HBM
-    DevBuf nodes, edges, tenants, dict, pool;
+    DevBuf nodes, edges, tenants, dict, pool, expire;
     RetainIndexView view{};
+};
+struct RetainLimit { // bmq_retain_match_limited in flight: select the first `limit` live ids from the ranges instead of expanding
+    bool active = false;
+    const uint32_t* d_limit = nullptr;
+    uint64_t now = 0;
+    uint32_t* d_tmp = nullptr;
+    uint32_t* d_kept = nullptr;
+    uint32_t* d_counts = nullptr;
 };
 
 } // namespace
@@ -99,7 +107,7 @@ struct bmq_engine {
     uint32_t slow_cap = 0, sort_cap = 0;
     Counters* h_ctr = nullptr; // pinned
     // staging for the host-buffer API
-    DevBuf s_tenants, s_tenant_off, s_topic_tenant, s_topics, s_topic_off, s_row_ptr, s_ids, s_lim, s_lim_ids;
+    DevBuf s_tenants, s_tenant_off, s_topic_tenant, s_topics, s_topic_off, s_row_ptr, s_ids, s_lim, s_lim_ids, s_lim_tmp;
 
     // last async batch (for bmq_match_finish)
     bool pending = false;
@@ -112,6 +120,8 @@ struct bmq_engine {
     RetainIndexHost rhost;
     RetainDevice rdev;
     bool rbuilt = false;
+    uint64_t repoch = 0; // +1 per retain rebuild / apply: topic ids are ranks and shift with every mutation
+    RetainLimit rlim;
     DevBuf r_scratch;
     uint32_t rgcap = 0;
 };

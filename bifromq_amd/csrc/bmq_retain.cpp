@@ -166,7 +166,7 @@ template <class F> void parallel_for(size_t n, F&& f) {
 }
 } // namespace
 
-bool RetainIndexHost::rebuild(std::vector<std::pair<std::string, std::string>>&& items) {
+bool RetainIndexHost::rebuild(std::vector<Item>&& items) {
     error.clear();
     by_name.clear();
     order.clear();
@@ -178,26 +178,40 @@ bool RetainIndexHost::rebuild(std::vector<std::pair<std::string, std::string>>&&
     full_upload = dict_changed = true;
     dirty.clear();
     std::vector<RTenantState*> touched;
+    std::map<RTenantState*, std::vector<Item*>> per;
     for (auto& it : items) {
-        auto f = by_name.find(it.first);
+        auto f = by_name.find(it.tenant);
         if (f == by_name.end()) {
             auto st = std::make_unique<RTenantState>();
-            st->name = it.first;
-            f = by_name.emplace(it.first, std::move(st)).first;
+            st->name = it.tenant;
+            f = by_name.emplace(it.tenant, std::move(st)).first;
             touched.push_back(f->second.get());
         }
-        f->second->topics.push_back(std::move(it.second));
+        per[f->second.get()].push_back(&it);
     }
+    std::vector<std::vector<Item*>*> lists;
+    for (RTenantState* t : touched) lists.push_back(&per[t]);
     parallel_for(touched.size(), [&](size_t i) {
-        auto& tp = touched[i]->topics;
-        std::sort(tp.begin(), tp.end(), topic_less);
-        tp.erase(std::unique(tp.begin(), tp.end()), tp.end());
+        auto& v = *lists[i];
+        std::stable_sort(v.begin(), v.end(), [](const Item* a, const Item* b) { return topic_less(a->topic, b->topic); });
+        RTenantState& t = *touched[i];
+        for (size_t k = 0; k < v.size(); k++) {
+            if (k + 1 < v.size() && v[k + 1]->topic == v[k]->topic) continue; // the last add of a topic wins
+            t.topics.push_back(std::move(v[k]->topic));
+            t.ts.push_back(v[k]->has_ts ? v[k]->ts : 0);
+            t.expiry.push_back(v[k]->has_ts ? v[k]->expiry : 0xFFFFFFFFu);
+        }
     });
     return refresh(touched);
 }
 
-bool RetainIndexHost::apply(const std::string& tenant, std::vector<std::pair<std::string, uint8_t>>&& ops) {
+bool RetainIndexHost::apply(const std::string& tenant, std::vector<Op>&& ops) {
     error.clear();
+    for (auto& op : ops)
+        if (op.op > 1) {
+            error = "op must be 0 (add) or 1 (remove)";
+            return false;
+        }
     auto f = by_name.find(tenant);
     if (f == by_name.end()) {
         auto st = std::make_unique<RTenantState>();
@@ -206,15 +220,24 @@ bool RetainIndexHost::apply(const std::string& tenant, std::vector<std::pair<std
     }
     RTenantState& t = *f->second;
     for (auto& op : ops) { // in order: IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134)
-        auto it = std::lower_bound(t.topics.begin(), t.topics.end(), op.first, topic_less);
-        const bool present = it != t.topics.end() && *it == op.first;
-        if (op.second == 0) {
-            if (!present) t.topics.insert(it, std::move(op.first));
-        } else if (op.second == 1) {
-            if (present) t.topics.erase(it);
-        } else {
-            error = "op must be 0 (add) or 1 (remove)";
-            return false;
+        auto it = std::lower_bound(t.topics.begin(), t.topics.end(), op.topic, topic_less);
+        const size_t pos = (size_t)(it - t.topics.begin());
+        const bool present = it != t.topics.end() && *it == op.topic;
+        const uint64_t ts = op.has_ts ? op.ts : 0;
+        const uint32_t ex = op.has_ts ? op.expiry : 0xFFFFFFFFu;
+        if (op.op == 0) {
+            if (!present) {
+                t.topics.insert(it, std::move(op.topic));
+                t.ts.insert(t.ts.begin() + (long)pos, ts);
+                t.expiry.insert(t.expiry.begin() + (long)pos, ex);
+            } else { // a retained message replaced by a newer one (RS/RetainStoreCoProc.java:246-249: remove + add)
+                t.ts[pos] = ts;
+                t.expiry[pos] = ex;
+            }
+        } else if (present) {
+            t.topics.erase(it);
+            t.ts.erase(t.ts.begin() + (long)pos);
+            t.expiry.erase(t.expiry.begin() + (long)pos);
         }
     }
     std::vector<RTenantState*> touched{&t};
@@ -292,6 +315,10 @@ bool RetainIndexHost::refresh(std::vector<RTenantState*>& touched) {
         return false;
     }
     n_topics = id;
+    expire_at.assign(n_topics ? n_topics : 1, RETAIN_NEVER);
+    for (RTenantState* t : order)
+        for (size_t i = 0; i < t->topics.size(); i++)
+            expire_at[t->id_base + i] = (t->ts[i] == 0 && t->expiry[i] == 0xFFFFFFFFu) ? RETAIN_NEVER : retain_expire_at(t->ts[i], t->expiry[i]);
     const uint32_t tslots = pow2_at_least((uint64_t)order.size() * 2);
     tenants.assign(tslots, RTenantSlot{0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}});
     for (RTenantState* t : order) {
@@ -306,7 +333,7 @@ bool RetainIndexHost::refresh(std::vector<RTenantState*>& touched) {
     return true;
 }
 
-bool RetainIndexHost::topic(uint32_t id, std::string_view& tenant, std::string_view& topic) const {
+bool RetainIndexHost::topic(uint32_t id, std::string_view& tenant, std::string_view& topic, uint64_t* ts, uint32_t* expiry) const {
     if (id >= n_topics || order.empty()) return false;
     size_t lo = 0, hi = order.size();
     while (hi - lo > 1) {
@@ -316,6 +343,8 @@ bool RetainIndexHost::topic(uint32_t id, std::string_view& tenant, std::string_v
     }
     tenant = order[lo]->name;
     topic = order[lo]->topics[id - order[lo]->id_base];
+    if (ts) *ts = order[lo]->ts[id - order[lo]->id_base];
+    if (expiry) *expiry = order[lo]->expiry[id - order[lo]->id_base];
     return true;
 }
 

@@ -59,11 +59,19 @@ struct RetainIndexView {
     const DictSlot* dict;
     uint32_t dict_group_mask;
     const uint8_t* pool;
+    const unsigned long long* expire_at; // per topic id: the millisecond the retained message expires at (~0: never)
 };
+
+constexpr uint64_t RETAIN_NEVER = ~0ull;
+// expireAt of RS/RetainStoreCoProc.java:298-304: physical part of the HLC timestamp (base-hlc HLC.java:145-151: hlc >>> 16, in ms)
+// plus the expiry interval in seconds
+inline uint64_t retain_expire_at(uint64_t timestamp_hlc, uint32_t expiry_seconds) { return (timestamp_hlc >> 16) + (uint64_t)expiry_seconds * 1000ull; }
 
 struct RTenantState {
     std::string name;
     std::vector<std::string> topics; // sorted (level-list byte order), unique
+    std::vector<uint64_t> ts;        // per topic: HLC timestamp given to IRetainTopicIndex.add (0 if none)
+    std::vector<uint32_t> expiry;    // per topic: expirySeconds (0xFFFFFFFF with ts 0: never expires)
     uint32_t token = 0;
     std::vector<RNode> nodes;        // breadth-first, local ids
     std::vector<REdge> edges;        // the tenant's edge region (size = 4 * buckets, power of two)
@@ -78,6 +86,7 @@ struct RetainIndexHost {
     std::vector<RTenantSlot> tenants;
     std::vector<DictSlot> dict;
     std::vector<uint8_t> pool;
+    std::vector<uint64_t> expire_at; // by topic id
     // ---- what changed since the last upload ----
     bool full_upload = true, dict_changed = true;
     std::vector<RTenantState*> dirty;
@@ -90,9 +99,22 @@ struct RetainIndexHost {
     uint64_t n_topics = 0;
     std::string error;
 
-    bool rebuild(std::vector<std::pair<std::string, std::string>>&& items);
-    bool apply(const std::string& tenant, std::vector<std::pair<std::string, uint8_t>>&& ops); // op 0 add, 1 remove
-    bool topic(uint32_t id, std::string_view& tenant, std::string_view& topic) const;
+    struct Item {
+        std::string tenant, topic;
+        uint64_t ts = 0;
+        uint32_t expiry = 0xFFFFFFFFu;
+        bool has_ts = false;
+    };
+    struct Op {
+        std::string topic;
+        uint8_t op = 0; // 0 add, 1 remove
+        uint64_t ts = 0;
+        uint32_t expiry = 0xFFFFFFFFu;
+        bool has_ts = false;
+    };
+    bool rebuild(std::vector<Item>&& items);
+    bool apply(const std::string& tenant, std::vector<Op>&& ops);
+    bool topic(uint32_t id, std::string_view& tenant, std::string_view& topic, uint64_t* ts = nullptr, uint32_t* expiry = nullptr) const;
     uint64_t n_tenants() const { return by_name.size(); }
 
 private:

@@ -377,24 +377,66 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// RetainStoreCoProc.match `limit` (RS/RetainStoreCoProc.java:167-190): keep the first limit[i] ids of every row of a
-// finished CSR (rows are ascending, so these are the smallest topic ids) and report the exact row lengths.
+// RetainStoreCoProc.match(limit, now) without expanding anything (RS/RetainStoreCoProc.java:167-190): the reference walks the
+// FULL match set and keeps the first `limit` messages that have not expired.  Its iteration order is that of a HashSet
+// (UTIL/index/StrategySet.java:31), i.e. unspecified; here it is ascending topic id.  One wave per filter works on the
+// filter's matched id RANGES (disjoint subtree intervals, straight from k_retain_walk): repeatedly take the range with the
+// smallest first id at or behind the cursor and scan its ids 64 at a time for live ones (expire_at > now) until the quota is
+// met.  With the default limit of 10 (Setting.java:77) a filter matching 5000 topics touches ~10 ids instead of 5000.
 // ------------------------------------------------------------------------------------------------------------
-// one workgroup: new_row_ptr = exclusive scan of min(row length, limit); counts = row lengths
-__global__ __launch_bounds__(1024) void k_limit_scan(const uint32_t* row_ptr, const uint32_t* limit, uint32_t n, uint32_t* new_row_ptr,
-                                                     uint32_t* counts, unsigned long long* new_total) {
+constexpr uint32_t LIM_FAST = 64; // per-filter limits up to this go through k_limit_select; larger ones through the full CSR
+__global__ __launch_bounds__(64) void k_limit_select(BatchArgs a, const uint32_t* limit, const unsigned long long* expire_at,
+                                                     unsigned long long now, uint32_t n, uint32_t* tmp_ids, uint32_t* kept, uint32_t* counts) {
+    const uint32_t lane = threadIdx.x;
+    const bool blocked = (a.ctr->status & (ST_NEED_PAIRS | ST_RETAIN_FRONT | ST_RETAIN_DEEP)) != 0; // the walk is re-run anyway
+    for (uint32_t f = blockIdx.x; f < n; f += gridDim.x) {
+        const uint32_t po = a.pair_off[f], np = blocked ? 0u : a.pair_cnt[f];
+        const uint32_t lim = min(limit[f], LIM_FAST);
+        uint32_t taken = 0, cursor = 0;
+        while (taken < lim) {
+            uint32_t bb = 0xFFFFFFFFu, bc = 0;
+            for (uint32_t k = lane; k < np; k += 64) {
+                const MatchRange r = a.pairs[po + k];
+                if (r.begin >= cursor && r.begin < bb && r.count) {
+                    bb = r.begin;
+                    bc = r.count;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t ob = __shfl_xor(bb, d), oc = __shfl_xor(bc, d);
+                if (ob < bb) {
+                    bb = ob;
+                    bc = oc;
+                }
+            }
+            if (bb == 0xFFFFFFFFu) break;
+            for (uint32_t o = 0; o < bc && taken < lim; o += 64) {
+                const uint32_t id = bb + o + lane;
+                const bool live = o + lane < bc && expire_at[id] > now;
+                const unsigned long long m = __ballot(live);
+                const uint32_t slot = taken + rank_below(m);
+                if (live && slot < lim) tmp_ids[(size_t)f * LIM_FAST + slot] = id;
+                taken = min(lim, taken + (uint32_t)__popcll(m));
+            }
+            cursor = bb + bc; // ranges of one filter are disjoint intervals
+        }
+        if (lane == 0) {
+            kept[f] = taken;
+            counts[f] = blocked ? 0u : a.route_cnt[f];
+        }
+    }
+}
+// one workgroup: row_ptr = exclusive scan of kept[]
+__global__ __launch_bounds__(1024) void k_limit_rowptr(const uint32_t* kept, uint32_t n, uint32_t* row_ptr, unsigned long long* total) {
     __shared__ unsigned long long part[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023) / 1024, lo = min(n, tid * per), hi = min(n, lo + per);
     unsigned long long s = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t c = row_ptr[i + 1] - row_ptr[i];
-        counts[i] = c;
-        s += min(c, limit[i]);
-    }
+    for (uint32_t i = lo; i < hi; i++) s += kept[i];
     part[tid] = s;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan of the per-thread sums
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
         const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
         __syncthreads();
         part[tid] += v;
@@ -402,21 +444,41 @@ __global__ __launch_bounds__(1024) void k_limit_scan(const uint32_t* row_ptr, co
     }
     unsigned long long run = part[tid] - s;
     for (uint32_t i = lo; i < hi; i++) {
-        new_row_ptr[i] = (uint32_t)run; // <= the untruncated total, which is < 2^32
-        run += min(counts[i], limit[i]);
+        row_ptr[i] = (uint32_t)run;
+        run += kept[i];
     }
     if (tid == 1023) {
-        new_row_ptr[n] = (uint32_t)part[1023];
-        *new_total = part[1023];
+        row_ptr[n] = (uint32_t)part[1023];
+        *total = part[1023];
     }
 }
-// one lane per row: rows are short after truncation (the reference's default limit is 10, Setting.java:77)
-__global__ __launch_bounds__(256) void k_limit_copy(const uint32_t* row_ptr, const uint32_t* new_row_ptr, const uint32_t* ids, uint32_t n,
-                                                    uint32_t* out_ids) {
+__global__ __launch_bounds__(256) void k_limit_compact(const uint32_t* tmp_ids, const uint32_t* row_ptr, uint32_t n, uint32_t* out_ids) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t src = row_ptr[i], dst = new_row_ptr[i], c = new_row_ptr[i + 1] - dst;
-    for (uint32_t k = 0; k < c; k++) out_ids[dst + k] = ids[src + k];
+    const uint32_t dst = row_ptr[i], c = row_ptr[i + 1] - dst;
+    for (uint32_t k = 0; k < c; k++) out_ids[dst + k] = tmp_ids[(size_t)i * LIM_FAST + k];
+}
+// limits above LIM_FAST: the finished CSR (rows ascending) is filtered row by row -- kept[i] = number of the first ids of row i that
+// are needed to collect limit[i] live ones; the live ones among them are compacted by k_limit_copy_live
+__global__ __launch_bounds__(256) void k_limit_count_live(const uint32_t* row_ptr, const uint32_t* ids, const uint32_t* limit,
+                                                          const unsigned long long* expire_at, unsigned long long now, uint32_t n, uint32_t* kept,
+                                                          uint32_t* counts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = row_ptr[i], e = row_ptr[i + 1], lim = limit[i];
+    uint32_t t = 0;
+    for (uint32_t k = b; k < e && t < lim; k++) t += expire_at[ids[k]] > now ? 1u : 0u;
+    kept[i] = t;
+    counts[i] = e - b;
+}
+__global__ __launch_bounds__(256) void k_limit_copy_live(const uint32_t* row_ptr, const uint32_t* new_row_ptr, const uint32_t* ids,
+                                                         const unsigned long long* expire_at, unsigned long long now, uint32_t n, uint32_t* out_ids) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = row_ptr[i], e = row_ptr[i + 1], dst = new_row_ptr[i], c = new_row_ptr[i + 1] - dst;
+    uint32_t t = 0;
+    for (uint32_t k = src; k < e && t < c; k++)
+        if (expire_at[ids[k]] > now) out_ids[dst + t++] = ids[k];
 }
 
 } // namespace bmq

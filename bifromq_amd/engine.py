@@ -252,22 +252,57 @@ class Engine:
         return out
 
     # ---- retain direction (IRetainTopicIndex, RS/index/IRetainTopicIndex.java:27-35) --------------------------------
-    def retain_rebuild(self, tenants: Sequence, topic_tenant, topics: Sequence = (), packed_topics=None):
-        """Load the retained-topic index; topic id = rank of (tenant, level list)."""
+    def retain_rebuild(self, tenants: Sequence, topic_tenant, topics: Sequence = (), packed_topics=None, timestamps=None, expiry=None):
+        """Load the retained-topic index; topic id = rank of (tenant, level list).  timestamps (HLC) / expiry (seconds): what
+        IRetainTopicIndex.add carries; both None = the topics never expire."""
         tdata, toff = pack(tenants)
         pdata, poff = pack(topics) if packed_topics is None else packed_topics
         tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
-        self._check(_lib.lib().bmq_retain_rebuild(self.h, _ptr(tdata), _ptr(toff), len(toff) - 1, _ptr(tt), _ptr(pdata),
-                                                  _ptr(poff), len(poff) - 1))
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, dtype=np.uint64)
+        ex = None if expiry is None else np.ascontiguousarray(expiry, dtype=np.uint32)
+        self._check(_lib.lib().bmq_retain_rebuild_ex(self.h, _ptr(tdata), _ptr(toff), len(toff) - 1, _ptr(tt), _ptr(pdata),
+                                                     _ptr(poff), len(poff) - 1, _ptr(ts), _ptr(ex)))
         return self
 
-    def retain_apply(self, tenant, ops: Sequence[Tuple[int, str]]):
-        """ops: (0 = add | 1 = remove, topic) -- IRetainTopicIndex.add / remove"""
+    def retain_apply(self, tenant, ops: Sequence):
+        """ops: (0 = add | 1 = remove, topic[, timestamp_hlc, expiry_seconds]) -- IRetainTopicIndex.add / remove"""
         t = _b(tenant)
-        data, off = pack([tp for _, tp in ops])
-        op = np.array([o for o, _ in ops], dtype=np.uint8)
-        self._check(_lib.lib().bmq_retain_apply(self.h, t, len(t), _ptr(data), _ptr(off), _ptr(op), len(ops)))
+        data, off = pack([o[1] for o in ops])
+        op = np.array([o[0] for o in ops], dtype=np.uint8)
+        if any(len(o) > 2 for o in ops):
+            ts = np.array([o[2] if len(o) > 2 else 0 for o in ops], dtype=np.uint64)
+            ex = np.array([o[3] if len(o) > 3 else 0xFFFFFFFF for o in ops], dtype=np.uint32)
+            self._check(_lib.lib().bmq_retain_apply_ex(self.h, t, len(t), _ptr(data), _ptr(off), _ptr(op), _ptr(ts), _ptr(ex), len(ops)))
+        else:
+            self._check(_lib.lib().bmq_retain_apply(self.h, t, len(t), _ptr(data), _ptr(off), _ptr(op), len(ops)))
         return self
+
+    def retain_topic_info(self, topic_id: int) -> Tuple[int, int, int]:
+        """-> (timestamp_hlc, expiry_seconds, expire_at_ms)"""
+        ts, ex, at = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        self._check(_lib.lib().bmq_retain_topic_info(self.h, topic_id, C.byref(ts), C.byref(ex), C.byref(at)))
+        return ts.value, ex.value, at.value
+
+    def retain_find_all(self) -> Tuple[int, int]:
+        """IRetainTopicIndex.findAll(): (number of topics -- the ids are 0 .. n-1, retain epoch)"""
+        n, ep = C.c_uint64(), C.c_uint64()
+        self._check(_lib.lib().bmq_retain_find_all(self.h, C.byref(n), C.byref(ep)))
+        return n.value, ep.value
+
+    def retain_expired(self, tenant, now_ms: int, override_expiry_seconds: int = -1) -> List[int]:
+        """ids whose message has expired at now_ms (tenant None: all tenants) -- the GC scan of RetainStoreCoProc."""
+        t = None if tenant is None else _b(tenant)
+        cap = 1024
+        n = C.c_uint32()
+        while True:
+            out = np.zeros(cap, dtype=np.uint32)
+            rc = _lib.lib().bmq_retain_expired(self.h, t, len(t) if t is not None else 0, now_ms, override_expiry_seconds, _ptr(out), cap,
+                                               C.byref(n))
+            if rc == -3:
+                cap = n.value
+                continue
+            self._check(rc)
+            return out[:n.value].tolist()
 
     def retain_topic(self, topic_id: int) -> Tuple[str, str]:
         buf = C.create_string_buffer(140000)
@@ -295,11 +330,11 @@ class Engine:
             self._check(rc)
             return row, ids[:need.value]
 
-    def retain_match_limited(self, tenants: Sequence, filter_tenant, filters: Sequence, limits):
-        """RetainStoreCoProc.match with per-filter limits -> (row_ptr[n+1], kept topic ids, exact match count per filter):
-        row i holds the min(limit, count) smallest matching topic ids."""
+    def retain_match_limited(self, tenants: Sequence, filter_tenant, filters: Sequence, limits, now_ms: int = 0, packed_filters=None):
+        """RetainStoreCoProc.match(limit, now) for a batch -> (row_ptr[n+1], kept topic ids, match count per filter):
+        row i holds the limits[i] smallest matching topic ids that have not expired at now_ms."""
         tdata, toff = pack(tenants)
-        pdata, poff = pack(filters)
+        pdata, poff = pack(filters) if packed_filters is None else packed_filters
         n = len(poff) - 1
         ft = np.ascontiguousarray(filter_tenant, dtype=np.uint32)
         lim = np.ascontiguousarray(limits, dtype=np.uint32)
@@ -311,7 +346,7 @@ class Engine:
         while True:
             ids = np.zeros(cap, dtype=np.uint32)
             rc = _lib.lib().bmq_retain_match_limited(self.h, _ptr(tdata), _ptr(toff), len(toff) - 1, _ptr(ft), _ptr(pdata), _ptr(poff),
-                                                     n, _ptr(lim), _ptr(row), _ptr(ids), cap, C.byref(need), _ptr(counts))
+                                                     n, _ptr(lim), now_ms, _ptr(row), _ptr(ids), cap, C.byref(need), _ptr(counts))
             if rc == -3 and need.value > cap:
                 cap = need.value
                 continue

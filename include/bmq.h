@@ -215,33 +215,59 @@ int bmq_route_key_decode(const uint8_t* key, uint32_t key_len, uint32_t spans[6]
 int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len);
 
 /* ---- retain direction (RS/index/IRetainTopicIndex.java:27-35) -------------------------------------------- */
-/* Load the retained-topic index: (tenant, topic) pairs; topic id = rank of (tenant, levels) in byte order.
- * Replaces the full-scan rebuild in RS/RetainStoreCoProc.java:134-137,279-296. */
+/* Load the retained-topic index: (tenant, topic) pairs; topic id = rank of (tenant, levels) in byte order (tenants in byte order
+ * of their ids, a tenant's topics level list by level list).  Ids are RANKS: every bmq_retain_rebuild* / bmq_retain_apply* shifts
+ * them (bmq_retain_find_all reports the retain epoch) -- resolve ids (bmq_retain_topic) before the next mutation, the way the
+ * reference reads its index under the apply thread (RS/RetainStoreCoProc.java:240-255).
+ * Replaces the full-scan rebuild in RS/RetainStoreCoProc.java:134-137,279-296.
+ * _ex: with what IRetainTopicIndex.add(tenantId, topic, timestamp, expirySeconds) carries (RS/index/IRetainTopicIndex.java:28):
+ * timestamp_hlc[i] = Message.timestamp (an HLC: milliseconds << 16 | counter, base-hlc HLC.java:145-151), expiry_seconds[i] =
+ * Message.expiryInterval; the message expires at (timestamp_hlc >> 16) + 1000 * expiry_seconds ms (RS/RetainStoreCoProc.java:298-304).
+ * Both arrays NULL (or the plain entry points): the topics never expire. */
 int bmq_retain_rebuild(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
                        const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off,
                        uint32_t n_topics);
-/* IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134). */
+int bmq_retain_rebuild_ex(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                          const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
+                          const uint64_t* timestamp_hlc, const uint32_t* expiry_seconds);
+/* IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134); op[i]: 0 = add (an add of a topic that is there
+ * replaces its timestamp / expiry: RS/RetainStoreCoProc.java:246-249), 1 = remove. */
 int bmq_retain_apply(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics,
                      const uint32_t* topic_off, const uint8_t* op, uint32_t n);
+int bmq_retain_apply_ex(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics, const uint32_t* topic_off,
+                        const uint8_t* op, const uint64_t* timestamp_hlc, const uint32_t* expiry_seconds, uint32_t n);
 /* id -> retained topic: out receives the tenant id followed by the topic (no separator), *out_tenant_len bytes of
  * tenant, *out_len bytes in total. */
 int bmq_retain_topic(const bmq_engine* e, uint32_t topic_id, uint8_t* out, uint32_t cap, uint32_t* out_len,
                      uint32_t* out_tenant_len);
+/* id -> the rest of RetainedMsgInfo (RS/index/RetainedMsgInfo.java:29-36) + the expiry instant in ms (~0: never); any out may be NULL */
+int bmq_retain_topic_info(const bmq_engine* e, uint32_t topic_id, uint64_t* out_timestamp_hlc, uint32_t* out_expiry_seconds,
+                          uint64_t* out_expire_at_ms);
+/* IRetainTopicIndex.findAll() (RS/index/RetainTopicIndex.java:140-143): the ids are exactly 0 .. *out_n_topics - 1.
+ * *out_epoch (may be NULL) counts the retain mutations so far. */
+int bmq_retain_find_all(const bmq_engine* e, uint64_t* out_n_topics, uint64_t* out_epoch);
+/* The scan of RetainStoreCoProc's GC (RS/RetainStoreCoProc.java:257-277): ids (ascending) of the topics of `tenant` (NULL: of
+ * every tenant) whose message has expired at now_ms; override_expiry_seconds >= 0 replaces the stored expiry interval as
+ * GCRequest.expirySeconds does.  Writes up to cap ids, *out_n = total; BMQ_E_NOSPACE if cap was too small. */
+int bmq_retain_expired(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, uint64_t now_ms,
+                       int64_t override_expiry_seconds, uint32_t* out_ids, uint32_t cap, uint32_t* out_n);
 /* Batch of IRetainTopicIndex.match(tenant, topicFilter) (RS/index/RetainTopicIndex.java:136-138; selector
  * :36-124; walk UTIL/index/TopicLevelTrie.java:190-249).  Output CSR of topic ids (ascending per row). */
 int bmq_retain_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
                            const uint32_t* filter_tenant, const uint8_t* filters, const uint32_t* filter_off,
                            uint32_t n_filters, uint32_t* out_row_ptr, uint32_t* out_topic_ids,
                            uint64_t out_capacity, uint64_t* out_needed);
-/* RetainStoreCoProc.match with its per-filter `limit` (RS/RetainStoreCoProc.java:167-190, limit from
- * RetainStoreCoProc.proto:63, tenant default RetainMessageMatchLimit = 10, Setting.java:77): the reference computes the
- * FULL match set and then keeps an unspecified `limit` of it (HashSet iteration order, UTIL/index/StrategySet.java:31).
- * Here: out_match_count[i] = the exact number of retained topics matching filter i (may be NULL), and row i holds the
- * min(limit[i], count) SMALLEST topic ids.  Same buffer protocol as bmq_retain_match_batch. */
+/* RetainStoreCoProc.match(tenant, filter, limit, now) (RS/RetainStoreCoProc.java:167-190; limit from RetainStoreCoProc.proto:63,
+ * tenant default RetainMessageMatchLimit = 10, Setting.java:77): the reference walks the FULL match set and returns the first
+ * `limit` messages that have not expired (expireAt > now).  The order it walks in is a HashSet's (UTIL/index/StrategySet.java:31),
+ * i.e. unspecified; here it is ascending topic id: row i = the limit[i] SMALLEST ids among the matching topics that are still
+ * live at now_ms (fewer if fewer are live; limit 0 -> empty row).  out_match_count[i] (may be NULL) = number of topics filter i
+ * matches, expired ones included.  With every limit <= 64 nothing is expanded: the ids are picked from the matched id ranges.
+ * Same buffer protocol as bmq_retain_match_batch. */
 int bmq_retain_match_limited(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
                              const uint32_t* filter_tenant, const uint8_t* filters, const uint32_t* filter_off,
-                             uint32_t n_filters, const uint32_t* limit, uint32_t* out_row_ptr, uint32_t* out_topic_ids,
-                             uint64_t out_capacity, uint64_t* out_needed, uint32_t* out_match_count);
+                             uint32_t n_filters, const uint32_t* limit, uint64_t now_ms, uint32_t* out_row_ptr,
+                             uint32_t* out_topic_ids, uint64_t out_capacity, uint64_t* out_needed, uint32_t* out_match_count);
 int bmq_retain_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t* d_tenant_off,
                                uint32_t n_tenants, const uint32_t* d_filter_tenant, const uint8_t* d_filters,
                                const uint32_t* d_filter_off, uint32_t n_filters, uint32_t* d_out_row_ptr,

@@ -18,6 +18,7 @@
 #define ENGINE(h) ((bmq_engine*)(intptr_t)(h))
 #define BATCHER(h) ((bmq_batcher*)(intptr_t)(h))
 #define ADDR(o) ((o) ? (*env)->GetDirectBufferAddress(env, (o)) : NULL)
+/* GetDirectBufferCapacity counts ELEMENTS of the buffer's type: bytes for a ByteBuffer, ints for an IntBuffer */
 #define CAP(o) ((o) ? (uint64_t)(*env)->GetDirectBufferCapacity(env, (o)) : 0u)
 #define NM(name) Java_org_apache_bifromq_dist_worker_gpu_NativeMatcher_##name
 
@@ -104,7 +105,7 @@ JNIEXPORT jlong JNICALL NM(matchBatch)(JNIEnv* env, jclass c, jlong h, jobject t
     uint64_t need = 0;
     const int rc = bmq_match_batch(ENGINE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
                                    (const uint32_t*)ADDR(topicTenant), (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
-                                   (uint32_t)nTopics, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds) / 4, &need);
+                                   (uint32_t)nTopics, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds), &need);
     return result_of(env, ENGINE(h), "bmq_match_batch", rc, need);
 }
 
@@ -119,8 +120,8 @@ JNIEXPORT jlong JNICALL NM(matchAll)(JNIEnv* env, jclass c, jlong h, jbyteArray 
     uint64_t need = 0;
     uint32_t n_events = 0;
     const int rc = bmq_match_all(ENGINE(h), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
-                                 (uint32_t)nTopics, maxPF, maxGF, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds) / 4, &need,
-                                 (int32_t*)ADDR(outEvents), (uint32_t)(CAP(outEvents) / 16), &n_events);
+                                 (uint32_t)nTopics, maxPF, maxGF, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds), &need,
+                                 (int32_t*)ADDR(outEvents), (uint32_t)(CAP(outEvents) / 4), &n_events);
     (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
     const jlong ne = (jlong)n_events;
     (*env)->SetLongArrayRegion(env, nEventsOut, 0, 1, &ne);
@@ -156,7 +157,7 @@ JNIEXPORT jlong JNICALL NM(batcherMatchAll)(JNIEnv* env, jclass c, jlong b, jbyt
     jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
     uint64_t need = 0, epoch = 0;
     const int rc = bmq_batcher_match_all(BATCHER(b), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
-                                         (uint32_t)nTopics, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds) / 4, &need, &epoch);
+                                         (uint32_t)nTopics, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds), &need, &epoch);
     (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
     const jlong ep = (jlong)epoch;
     (*env)->SetLongArrayRegion(env, epochOut, 0, 1, &ep);
@@ -184,17 +185,18 @@ JNIEXPORT void JNICALL NM(retainApply)(JNIEnv* env, jclass c, jlong h, jbyteArra
     if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_apply", rc);
 }
 /* long retainMatchLimited(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer filterTenant, ByteBuffer filters,
- *                         IntBuffer filterOff, int nFilters, IntBuffer limits, IntBuffer outRowPtr, IntBuffer outTopicIds, IntBuffer outCounts)
- * RetainStoreCoProc.match for one BatchMatchRequest: exact match counts + the `limit` smallest topic ids per filter */
+ *                         IntBuffer filterOff, int nFilters, IntBuffer limits, long nowMs, IntBuffer outRowPtr, IntBuffer outTopicIds,
+ *                         IntBuffer outCounts)
+ * RetainStoreCoProc.match(limit, now) for one BatchMatchRequest: per filter the `limit` smallest topic ids that have not expired */
 JNIEXPORT jlong JNICALL NM(retainMatchLimited)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants, jobject filterTenant,
-                                               jobject filters, jobject filterOff, jint nFilters, jobject limits, jobject outRowPtr,
+                                               jobject filters, jobject filterOff, jint nFilters, jobject limits, jlong nowMs, jobject outRowPtr,
                                                jobject outTopicIds, jobject outCounts) {
     (void)c;
     uint64_t need = 0;
     const int rc = bmq_retain_match_limited(ENGINE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
                                             (const uint32_t*)ADDR(filterTenant), (const uint8_t*)ADDR(filters), (const uint32_t*)ADDR(filterOff),
-                                            (uint32_t)nFilters, (const uint32_t*)ADDR(limits), (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outTopicIds),
-                                            CAP(outTopicIds) / 4, &need, (uint32_t*)ADDR(outCounts));
+                                            (uint32_t)nFilters, (const uint32_t*)ADDR(limits), (uint64_t)nowMs, (uint32_t*)ADDR(outRowPtr),
+                                            (uint32_t*)ADDR(outTopicIds), CAP(outTopicIds), &need, (uint32_t*)ADDR(outCounts));
     return result_of(env, ENGINE(h), "bmq_retain_match_limited", rc, need);
 }
 /* int retainTopic(long engine, int topicId, ByteBuffer out, long[] tenantLenOut)   -> total length (tenant bytes then topic bytes) */

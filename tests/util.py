@@ -125,6 +125,16 @@ def assert_rows_equal_modulo_quirk_ii(keys, tenants, topic_tenant, reference_row
     return n_diff
 
 
+def retain_order(tenant_names, topic_tenant, topics):
+    """The id order of the retained-topic index, computed independently of the engine: distinct (tenant, topic) pairs, tenants
+    in byte order of their ids, a tenant's topics ordered level list by level list (levels compared as bytes, a shorter list
+    first).  -> list of (tenant str, topic str); the engine's topic id must be the index in this list."""
+    def b(x):
+        return x if isinstance(x, bytes) else x.encode()
+    pairs = {(b(tenant_names[int(t)]), tuple(b(tp).split(b"/"))) for t, tp in zip(topic_tenant, topics)}
+    return [(t.decode(), b"/".join(lv).decode()) for t, lv in sorted(pairs)]
+
+
 def csr_select(row_ptr, ids, sel):
     """the CSR restricted to rows `sel` -> (row_ptr', ids')"""
     sel = np.asarray(sel, dtype=np.int64)

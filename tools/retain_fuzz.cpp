@@ -142,6 +142,7 @@ int main(int argc, char** argv) {
         return f;
     };
     std::map<std::string, std::set<std::string>> model; // tenant -> topics
+    std::map<std::pair<std::string, std::string>, std::pair<uint64_t, uint32_t>> stamp; // (tenant, topic) -> (HLC timestamp, expirySeconds) of its LAST add
     RetainIndexHost h;
     uint64_t checks = 0;
     for (int round = 0; round < rounds; round++) {
@@ -149,18 +150,26 @@ int main(int argc, char** argv) {
         bool ok;
         if (full) {
             model.clear();
-            std::vector<std::pair<std::string, std::string>> items;
+            stamp.clear();
+            std::vector<RetainIndexHost::Item> items;
             const size_t n = rnd(3) == 0 ? 0 : 1 + rnd(2500);
             for (size_t i = 0; i < n; i++) {
                 const std::string& tn = tenants[rnd(tenants.size())];
                 const std::string tp = rand_topic();
                 model[tn].insert(tp);
-                items.emplace_back(tn, tp);
+                RetainIndexHost::Item it;
+                it.tenant = tn;
+                it.topic = tp;
+                it.has_ts = rnd(4) != 0;
+                it.ts = (uint64_t)(1000 + rnd(100000)) << 16 | rnd(65536);
+                it.expiry = (uint32_t)rnd(500);
+                stamp[{tn, tp}] = it.has_ts ? std::make_pair(it.ts, it.expiry) : std::make_pair<uint64_t, uint32_t>(0, 0xFFFFFFFFu);
+                items.push_back(std::move(it));
             }
             ok = h.rebuild(std::move(items));
         } else {
             const std::string& tn = tenants[rnd(tenants.size())];
-            std::vector<std::pair<std::string, uint8_t>> ops;
+            std::vector<RetainIndexHost::Op> ops;
             const size_t n = 1 + rnd(rnd(4) == 0 ? 1500 : 40);
             auto& set = model[tn];
             for (size_t i = 0; i < n; i++) {
@@ -168,11 +177,22 @@ int main(int argc, char** argv) {
                     auto it = set.begin();
                     std::advance(it, rnd(std::min<size_t>(set.size(), 300)));
                     const std::string tp = rnd(20) ? *it : rand_topic();
-                    ops.emplace_back(tp, 1);
+                    RetainIndexHost::Op o;
+                    o.topic = tp;
+                    o.op = 1;
+                    ops.push_back(std::move(o));
                     set.erase(tp);
+                    stamp.erase({tn, tp});
                 } else {
                     const std::string tp = rand_topic();
-                    ops.emplace_back(tp, 0);
+                    RetainIndexHost::Op o;
+                    o.topic = tp;
+                    o.op = 0;
+                    o.has_ts = rnd(4) != 0;
+                    o.ts = (uint64_t)(1000 + rnd(100000)) << 16 | rnd(65536);
+                    o.expiry = (uint32_t)rnd(500);
+                    stamp[{tn, tp}] = o.has_ts ? std::make_pair(o.ts, o.expiry) : std::make_pair<uint64_t, uint32_t>(0, 0xFFFFFFFFu);
+                    ops.push_back(std::move(o));
                     set.insert(tp);
                 }
             }
@@ -193,7 +213,15 @@ int main(int argc, char** argv) {
         std::vector<std::pair<std::string, std::vector<std::string>>> prev;
         for (uint32_t id = 0; id < total; id++) {
             std::string_view tn, tp;
-            if (!h.topic(id, tn, tp) || !model.count(std::string(tn)) || !model[std::string(tn)].count(std::string(tp))) {
+            uint64_t ts = 0;
+            uint32_t ex = 0;
+            bool good = h.topic(id, tn, tp, &ts, &ex) && model.count(std::string(tn)) && model[std::string(tn)].count(std::string(tp));
+            if (good) { // the stamp of the last add, and the expiry instant derived from it (RS/RetainStoreCoProc.java:298-304)
+                const auto st = stamp[{std::string(tn), std::string(tp)}];
+                good = st.first == ts && st.second == ex &&
+                       h.expire_at[id] == ((ts == 0 && ex == 0xFFFFFFFFu) ? RETAIN_NEVER : (ts >> 16) + (uint64_t)ex * 1000);
+            }
+            if (!good) {
                 fprintf(stderr, "round %d: topic(%u) is not in the model\n", round, id);
                 return 1;
             }
