@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--exchange-selftest", action="store_true",
                     help="run the N>1 exchange step (RCCL all-gather of the CSR) also at world size 1, to exercise that code path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-visible (PCIe-inclusive) measurement")
     ap.add_argument("--batcher-threads", type=int, default=0,
                     help="also measure the batching front (bmq_batcher_*, SURVEY 8f-1): N native threads issue single-topic calls")
     ap.add_argument("--batcher-topics", type=int, default=200_000)
@@ -282,6 +283,8 @@ def main():
         except Exception:
             pass
 
+    if world == 1 and not args.no_host_path:
+        out["host_visible"] = host_visible(args, eng, w, batches, n, seed, rank)
     if args.batcher_threads and world == 1:  # the production call pattern (one topic per call, many threads) through the collector
         hdata, hoff, htt = batches[0][3]
         m = min(args.batcher_topics, n)
@@ -307,6 +310,66 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     emit_json(out)
+
+
+def host_visible(args, eng, w, batches, n, seed, rank):
+    """SURVEY 8d's latency definition: host enqueue -> results visible on host.  Inputs and outputs live in page-locked host
+    memory (bmq_host_alloc: what a JNI binding hands over as direct buffers).
+      * p99 / p50 latency of ONE blocking bmq_match_batch call (upload + kernels + download, nothing overlapped);
+      * throughput with two batches in flight (bmq_match_submit / bmq_match_wait): the upload of batch i+1 and the download of
+        batch i-1 overlap the kernels of batch i."""
+    import numpy as np
+
+    import bifromq_amd as B
+    from bifromq_amd.engine import pinned, _ptr
+    import ctypes as C
+
+    tdata, toff = w.tenants_packed()
+    p_t = pinned(len(tdata), np.uint8)
+    p_t[:] = tdata
+    p_to = pinned(len(toff), np.uint32)
+    p_to[:] = toff
+    hb = []
+    for b in range(2):
+        data, off, tt = w.topics(seed + 1000 * (rank + 1) + b, n, grouped=not args.ungrouped)
+        pd, po, pt = pinned(len(data), np.uint8), pinned(len(off), np.uint32), pinned(len(tt), np.uint32)
+        pd[:], po[:], pt[:] = data, off, tt
+        hb.append((pd, po, pt))
+    cap = 32 * n
+    rows = [pinned(n + 1, np.uint32) for _ in range(2)]
+    ids = [pinned(cap, np.uint32) for _ in range(2)]
+    L = B._lib.lib()
+    need = C.c_uint64()
+    lat = []
+    for i in range(args.steps + 3):
+        pd, po, pt = hb[i % 2]
+        t0 = time.perf_counter()
+        rc = L.bmq_match_batch(eng.h, _ptr(p_t), _ptr(p_to), w.n_tenants, _ptr(pt), _ptr(pd), _ptr(po), n, _ptr(rows[0]), _ptr(ids[0]), cap,
+                               C.byref(need))
+        if rc:
+            raise RuntimeError("bmq_match_batch: %d" % rc)
+        if i >= 3:
+            lat.append((time.perf_counter() - t0) * 1e3)
+    total_ids = need.value
+    # pipelined
+    K = args.steps
+    tickets = [None, None]
+    t0 = time.perf_counter()
+    for i in range(K + 1):
+        if i < K:
+            pd, po, pt = hb[i % 2]
+            tickets[i % 2] = eng.match_submit(p_t, p_to, w.n_tenants, pt, pd, po, n)
+        if i >= 1:
+            j = (i - 1) % 2
+            got = eng.match_wait(tickets[j], rows[j], ids[j])
+            assert got == total_ids or len(hb) > 1
+    sec = time.perf_counter() - t0
+    in_bytes = sum(int(x.nbytes) for x in hb[0])
+    return {"value_host_visible": n * K / sec, "unit": "topics/s", "ms_per_batch_pipelined": sec / K * 1e3,
+            "p50_host_visible_ms": float(np.percentile(lat, 50)), "p99_host_visible_ms": float(np.percentile(lat, 99)),
+            "bytes_in_per_batch": in_bytes, "bytes_out_per_batch": int(4 * (n + 1) + 4 * total_ids),
+            "note": "host buffers in, CSR out, page-locked memory; latency = one blocking bmq_match_batch (upload + kernels + download); "
+                    "throughput = bmq_match_submit/bmq_match_wait with two batches in flight"}
 
 
 def emit_json(out):

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ABI_SYMBOLS = [
     "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_routes_apply",
     "bmq_index_info_get", "bmq_route_key", "bmq_route_keys", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
-    "bmq_match_finish", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
+    "bmq_match_finish", "bmq_match_submit", "bmq_match_wait", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_retain_rebuild", "bmq_retain_rebuild_ex", "bmq_retain_apply", "bmq_retain_apply_ex", "bmq_retain_topic",
     "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
@@ -91,6 +91,10 @@ def lib() -> C.CDLL:
             "bmq_match_batch": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, P(u64)]),
             "bmq_match_batch_dev": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, vp]),
             "bmq_match_finish": (C.c_int, [vp, P(u64)]),
+            "bmq_match_submit": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, P(C.c_int)]),
+            "bmq_match_wait": (C.c_int, [vp, C.c_int, vp, vp, u64, P(u64)]),
+            "bmq_host_alloc": (vp, [C.c_size_t]),
+            "bmq_host_free": (None, [vp]),
             "bmq_sync": (C.c_int, [vp]),
             "bmq_stats_get": (C.c_int, [vp, P(Stats)]),
             "bmq_stream": (vp, [vp]),

@@ -746,8 +746,9 @@ private:
             ob.key_base = kpool_used;
             ob.bulk = 1;
         }
-        if (!x.zero(s_bt_nodes, 4 * (size_t)n_ten) || !x.zero(s_bt_keys, 4 * (size_t)n_ten)) return xfail();
-        if (!x.bulk_tenants(ix, ob, ob.order)) return xfail();
+        // run starts, then per-run key / node counts from a second scan (of nn[]; its output borrows the unknown-tenant list)
+        if (!x.bulk_tenants(ix, ob, ob.order) || !x.scan_flags(ob.nn, ob.unknown_list, n) || !x.bulk_counts(ob, n_ten, ob.unknown_list))
+            return xfail();
         std::vector<uint32_t> bt_first(n_ten), bt_nodes(n_ten), bt_keys(n_ten), bt_dir(n_ten);
         if (!x.copy_out(bt_first.data(), s_bt_first, 4 * (size_t)n_ten) || !x.copy_out(bt_nodes.data(), s_bt_nodes, 4 * (size_t)n_ten) ||
             !x.copy_out(bt_keys.data(), s_bt_keys, 4 * (size_t)n_ten))

@@ -18,7 +18,8 @@
 //                       Phase 3: matched (begin,count) ranges are counting-sorted by topic and written out.
 //   k_walk_slow       : per-lane DFS with global scratch for topics the LDS path could not finish
 //                       (more than FAST_LEVELS levels, stack overflow, too many range flushes).
-//   k_scan_blocks     : exclusive scan of the per-wave id counts.
+//   (no scan kernel)  : k_walk leaves per-wave id counts + their sums per 256 waves; every k_expand wave adds up the <= 61 + 255
+//                       values in front of it (five coalesced loads per lane) instead of waiting for a single-workgroup scan.
 //   k_expand          : per 64 rows: order each row's ranges by first id in LDS, lay them out in output order and fill the
 //                       CSR ids with fully coalesced stores (short ranges flattened, long ranges streamed).
 //   k_sort_rows       : bitonic fix-up of rows whose range list was too long to order in k_expand.
@@ -41,7 +42,7 @@ enum : uint32_t {
 };
 constexpr uint32_t ST_RERUN = ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH | ST_NEED_SPILL;
 
-struct Counters { // one per batch, zeroed before launch
+struct Counters { // one per batch, zeroed before launch (k_prologue)
     unsigned long long pair_alloc;
     unsigned long long scratch_alloc; // in uint32 units
     unsigned long long spill_alloc;   // in records
@@ -54,6 +55,8 @@ struct Counters { // one per batch, zeroed before launch
     uint32_t status;
     uint32_t pad;
 };
+constexpr uint32_t SUPER_SHIFT = 8;   // id counts are summed per 2^SUPER_SHIFT waves (super_sums) on top of the per-wave counts
+constexpr uint32_t SUPER_STRIDE = 16; // ... one sum per 128-byte line: 256 waves bump each, neighbours must not share a line
 
 // Contiguous space in the matched-range buffer is handed out by N_SUB independent allocators, each owning one slice
 // of the buffer and living in its own 128-byte line: a single counter bumped by every wave of a batch (15 625 waves
@@ -90,10 +93,11 @@ struct BatchArgs {
     MatchRange* pairs;
     unsigned long long pair_cap;
     SubAlloc* subs;          // [2 * N_SUB] allocators of `pairs` (first N_SUB) and of `spill` (second N_SUB)
-    uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, 0}; summed by k_scan_blocks
+    unsigned long long* super_sums; // [(n_blocks >> SUPER_SHIFT + 1) * SUPER_STRIDE] ids per 2^SUPER_SHIFT blocks (zeroed by k_prologue)
+    uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, 0}; summed by k_sort_rows
     uint4* spill;            // LDS range buffer flushes: {begin, count, topic-local, 0}
     unsigned long long spill_cap;
-    unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block; scanned in place to exclusive bases
+    unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block
     uint32_t n_blocks;
     uint32_t* slow_list;
     uint32_t slow_cap;
@@ -249,13 +253,22 @@ __device__ __forceinline__ uint32_t global_word_at(const uint8_t* base, uint32_t
 constexpr TenantSlot EMPTY_TENANT{0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}};
 __device__ __forceinline__ bool tenant_known(const TenantSlot& t) { return (t.hash_lo | t.hash_hi) != 0; }
 
-__global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
+// k_prologue: zeroes the batch counters / sub-allocators / super sums (what two hipMemsetAsync calls used to do) and resolves the
+// batch's tenant table, one lane per item.  zero_words: number of 8-byte words to clear in each of the three areas.
+__global__ __launch_bounds__(64) void k_prologue(BatchArgs a, uint32_t n_super) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < sizeof(Counters) / 8) reinterpret_cast<unsigned long long*>(a.ctr)[i] = 0ull;
+    if (i < sizeof(SubAlloc) * 2 * N_SUB / 8) reinterpret_cast<unsigned long long*>(a.subs)[i] = 0ull;
+    if (i < n_super) a.super_sums[(size_t)i * SUPER_STRIDE] = 0ull;
     if (i >= a.n_tenants) return;
+    // the tenant id's bytes, four at a time (a byte-wise loop is one memory latency per byte: measured 22 us for 12-byte ids)
     const uint8_t* base = a.tenants;
     const uint32_t beg = a.tenant_off[i], end = a.tenant_off[i + 1], len = end - beg;
     uint64_t h = TENANT_HASH_INIT;
-    for (uint32_t k = beg; k < end; k++) h = tenant_hash_step(h, base[k]);
+    for (uint32_t k = 0; k < len; k += 4) {
+        const uint32_t w = global_word_at(base, beg + k), nb = min(4u, len - k);
+        for (uint32_t j = 0; j < nb; j++) h = tenant_hash_step(h, (w >> (8 * j)) & 0xFFu);
+    }
     h = tenant_hash_final(h);
     const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
     TenantSlot info = EMPTY_TENANT;
@@ -265,7 +278,10 @@ __global__ __launch_bounds__(64) void k_resolve_tenants(BatchArgs a) {
         if (!tenant_known(t)) break;
         if (t.hash_lo == lo && t.hash_hi == hi && t.name_len == len) { // the id's bytes decide
             bool eq = true;
-            for (uint32_t k = 0; k < len && eq; k++) eq = a.ix.tenant_names[t.name_off + k] == base[beg + k];
+            for (uint32_t k = 0; k < len && eq; k += 4) {
+                const uint32_t nb = min(4u, len - k), m = nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                eq = ((global_word_at(a.ix.tenant_names, t.name_off + k) ^ global_word_at(base, beg + k)) & m) == 0;
+            }
             if (eq) {
                 info = t;
                 break;
@@ -649,6 +665,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     const unsigned long long wbytes = wave_sum_u64(tbytes);
     if (lane == 0) {
         a.wave_sums[blk] = wsum;
+        if (wsum) atomicAdd(&a.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], wsum);
         a.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
         if (a.dbg_wave) {
             const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
@@ -761,67 +778,12 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         a.pair_off[t] = (uint32_t)base;
         a.pair_cnt[t] = np;
         a.route_cnt[t] = nr;
-        if (nr) atomicAdd(&a.wave_sums[t >> 6], (unsigned long long)nr);
+        if (nr) {
+            atomicAdd(&a.wave_sums[t >> 6], (unsigned long long)nr);
+            atomicAdd(&a.super_sums[(size_t)(t >> (6 + SUPER_SHIFT)) * SUPER_STRIDE], (unsigned long long)nr);
+        }
         if (visits) atomicAdd(&a.ctr->n_visit, (unsigned long long)visits);
         if (np) atomicAdd(&a.ctr->n_ranges, (unsigned long long)np);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_scan_blocks -- exclusive scan of wave_sums (one workgroup of 1024 threads), total -> counters / out_total
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_blocks(BatchArgs a) {
-    __shared__ unsigned long long wave_tot[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    // every wave owns one contiguous segment; all accesses are lane-strided (coalesced, independent loads)
-    const uint32_t seg = ((a.n_blocks + 15) / 16 + 63) & ~63u;
-    const uint32_t s0 = min(wv * seg, a.n_blocks), s1 = min(s0 + seg, a.n_blocks);
-    unsigned long long s = 0, sv = 0, sr = 0, sb = 0;
-    for (uint32_t i = s0 + lane; i < s1; i += 64) {
-        s += a.wave_sums[i];
-        if (a.blk_stats) {
-            const uint4 q = a.blk_stats[i];
-            sv += q.x;
-            sr += q.y;
-            sb += q.z;
-        }
-    }
-    const unsigned long long wsum = wave_sum_u64(s);
-    { // statistics: one add per wave, on top of what the slow path counted
-        const unsigned long long wvv = wave_sum_u64(sv), wr = wave_sum_u64(sr), wb = wave_sum_u64(sb);
-        if (lane == 0) {
-            if (wvv) atomicAdd(&a.ctr->n_visit, wvv);
-            if (wr) atomicAdd(&a.ctr->n_ranges, wr);
-            if (wb) atomicAdd(&a.ctr->topic_bytes, wb);
-        }
-    }
-    if (lane == 0) wave_tot[wv] = wsum;
-    __syncthreads();
-    unsigned long long carry = 0, total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 16; w++) {
-        const unsigned long long t = wave_tot[w];
-        if (w < wv) carry += t;
-        total += t;
-    }
-    // exclusive scan of the segment, 64 elements per step, carry in a register
-    for (uint32_t i0 = s0; i0 < s1; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const unsigned long long v = i < s1 ? a.wave_sums[i] : 0ull;
-        unsigned long long inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long o = __shfl_up(inc, d);
-            if (lane >= (uint32_t)d) inc += o;
-        }
-        if (i < s1) a.wave_sums[i] = carry + inc - v;
-        carry += __shfl(inc, 63);
-    }
-    if (tid == 0) {
-        a.ctr->total_ids = total;
-        *a.out_total = total;
-        if (total > a.out_capacity) atomicOr(&a.ctr->status, ST_NOSPACE);
-        if (total >= 0xFFFFFFFFull) atomicOr(&a.ctr->status, ST_RANGE);
     }
 }
 
@@ -864,10 +826,25 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
     const uint32_t nr = valid ? a.route_cnt[t] : 0u;
     uint32_t wtotal;
     const uint32_t excl = wave_excl_scan(nr, lane, wtotal);
-    const unsigned long long wbase = a.wave_sums[blk];
+    // ids in front of this wave's rows: whole super-blocks + the waves of this wave's own super-block before it
+    unsigned long long wbase;
+    {
+        const uint32_t sb = blk >> SUPER_SHIFT;
+        unsigned long long acc = 0;
+        for (uint32_t i = lane; i < sb; i += 64) acc += a.super_sums[(size_t)i * SUPER_STRIDE];
+        for (uint32_t i = (sb << SUPER_SHIFT) + lane; i < blk; i += 64) acc += a.wave_sums[i];
+        wbase = wave_sum_u64(acc);
+    }
     const unsigned long long row = wbase + excl;
-    const bool writable = !(status & (ST_NOSPACE | ST_RANGE | ST_RERUN));
-    if (valid && !(status & ST_RANGE)) {
+    const unsigned long long wend = wbase + wtotal;
+    const bool range_err = wend >= 0xFFFFFFFFull, no_space = wend > a.out_capacity;
+    if (blk == a.n_blocks - 1 && lane == 0) { // the last wave knows the grand total
+        a.ctr->total_ids = wend;
+        *a.out_total = wend;
+    }
+    if ((range_err || no_space) && lane == 0) atomicOr(&a.ctr->status, range_err ? (uint32_t)ST_RANGE : (uint32_t)ST_NOSPACE);
+    const bool writable = !(status & ST_RERUN) && !range_err && !no_space; // rows in front of the overflow are still written
+    if (valid && !range_err) {
         a.out_row_ptr[t] = (uint32_t)row;
         if (t == a.n_topics - 1) a.out_row_ptr[a.n_topics] = (uint32_t)(row + nr);
     }
@@ -1024,6 +1001,32 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
 // k_sort_rows -- one workgroup per flagged row, normalised bitonic network in global memory
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
+    if (a.blk_stats) { // the batch statistics: per-wave records of k_walk -> counters (one atomic triple per workgroup)
+        __shared__ unsigned long long red[3][4];
+        unsigned long long sv = 0, sr = 0, sb = 0;
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.n_blocks; i += gridDim.x * 256) {
+            const uint4 q = a.blk_stats[i];
+            sv += q.x;
+            sr += q.y;
+            sb += q.z;
+        }
+        sv = wave_sum_u64(sv);
+        sr = wave_sum_u64(sr);
+        sb = wave_sum_u64(sb);
+        if ((threadIdx.x & 63u) == 0) {
+            red[0][threadIdx.x >> 6] = sv;
+            red[1][threadIdx.x >> 6] = sr;
+            red[2][threadIdx.x >> 6] = sb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long v = red[0][0] + red[0][1] + red[0][2] + red[0][3], r = red[1][0] + red[1][1] + red[1][2] + red[1][3],
+                                     b = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+            if (v) atomicAdd(&a.ctr->n_visit, v);
+            if (r) atomicAdd(&a.ctr->n_ranges, r);
+            if (b) atomicAdd(&a.ctr->topic_bytes, b);
+        }
+    }
     const uint32_t n_rows = a.ctr->sort_count < a.sort_cap ? a.ctr->sort_count : a.sort_cap;
     if (a.ctr->status & (ST_NOSPACE | ST_RANGE | ST_RERUN)) return;
     for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {

@@ -85,7 +85,6 @@ struct bmq_engine {
     bmq_config cfg{};
     int device = -1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8]{};
     std::mutex mu;             // protects engine state inside one entry point
     mutable std::recursive_mutex api;  // held for the whole duration of the host-buffer entry points (they are multi-step)
     std::string err;
@@ -99,21 +98,32 @@ struct bmq_engine {
     uint64_t epoch = 0;
     bool built = false;
 
-    // per-batch scratch
-    DevBuf b_subs, b_blk_stats, b_dbg_wave;
-    DevBuf b_tenant_root, b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch,
-        b_sort_list, b_ctr, b_total;
-    uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
-    uint32_t slow_cap = 0, sort_cap = 0;
-    Counters* h_ctr = nullptr; // pinned
-    // staging for the host-buffer API
-    DevBuf s_tenants, s_tenant_off, s_topic_tenant, s_topics, s_topic_off, s_row_ptr, s_ids, s_lim, s_lim_ids, s_lim_tmp;
-
-    // last async batch (for bmq_match_finish)
-    bool pending = false;
-    int pending_kind = 0; // 0 dist, 1 retain
-    BatchArgs last{};
-    RetainArgs rlast{};
+    // Everything ONE batch in flight needs: per-batch scratch, staging of the host-buffer API, counters, events.  Two slots, so
+    // that the asynchronous host API (bmq_match_submit / bmq_match_wait) can have the upload of batch i+1 and the download of
+    // batch i-1 in flight while the kernels of batch i run; every other entry point works on slot 0.
+    struct BatchSlot {
+        DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave;
+        DevBuf b_tenant_root, b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch, b_sort_list, b_ctr,
+            b_total;
+        uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
+        uint32_t slow_cap = 0, sort_cap = 0;
+        Counters* h_ctr = nullptr; // pinned
+        // staging for the host-buffer API
+        DevBuf s_tenants, s_tenant_off, s_topic_tenant, s_topics, s_topic_off, s_row_ptr, s_ids, s_lim, s_lim_ids, s_lim_tmp;
+        hipEvent_t ev[8]{};
+        hipEvent_t ev_in = nullptr, ev_done = nullptr; // inputs uploaded / batch (kernels + counter read-back) complete
+        // the batch in flight (for bmq_match_finish / bmq_match_wait)
+        bool pending = false;
+        int pending_kind = 0; // 0 dist, 1 retain
+        bool submitted = false; // owned by a bmq_match_submit ticket
+        uint64_t dev_cap = 0;   // ids the slot's own output buffer holds
+        uint32_t n_rows = 0;
+        BatchArgs last{};
+        RetainArgs rlast{};
+    };
+    BatchSlot slots[2];
+    BatchSlot* cur = &slots[0];
+    hipStream_t s_in = nullptr, s_out = nullptr; // copy streams of the asynchronous host API
     bmq_stats stats{};
 
     // retain direction
@@ -153,97 +163,101 @@ int upload(bmq_engine* e, DevBuf& b, const void* src, size_t bytes) {
 // ---- dist batch ------------------------------------------------------------------------------------------------
 int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     const uint32_t n_blocks = (n_topics + 63) / 64;
-    if (e->pair_cap == 0) e->pair_cap = 1u << 16;
-    e->pair_cap = std::max<uint64_t>(e->pair_cap, (uint64_t)n_topics * 4);
-    if (e->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
-    if (e->slow_cap == 0) e->slow_cap = 1024;
-    e->slow_cap = std::max<uint32_t>(e->slow_cap, n_topics / 16);
-    if (e->sort_cap == 0) e->sort_cap = 1024;
-    e->sort_cap = std::max<uint32_t>(e->sort_cap, n_topics / 64);
-    if (e->scratch_cap == 0) e->scratch_cap = (uint64_t)(e->cfg.slow_scratch_mb ? e->cfg.slow_scratch_mb : 64) * (1u << 20) / 4;
-    HIPCHK(e, e->b_tenant_root.ensure(sizeof(TenantSlot) * std::max(n_tenants, 1u)));
-    HIPCHK(e, e->b_pair_off.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
-    HIPCHK(e, e->b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
-    HIPCHK(e, e->b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
-    HIPCHK(e, e->b_pairs.ensure(sizeof(MatchRange) * e->pair_cap));
-    HIPCHK(e, e->b_subs.ensure(sizeof(SubAlloc) * 2 * N_SUB));
-    HIPCHK(e, e->b_blk_stats.ensure(sizeof(uint4) * std::max(n_blocks, 1u)));
-    if (e->spill_cap == 0) e->spill_cap = 1u << 16;
-    e->spill_cap = std::max<uint64_t>(e->spill_cap, (uint64_t)n_topics * 2);
-    HIPCHK(e, e->b_spill.ensure(sizeof(uint4) * e->spill_cap));
-    HIPCHK(e, e->b_wave_sums.ensure(sizeof(unsigned long long) * std::max(n_blocks, 1u)));
-    HIPCHK(e, e->b_slow_list.ensure(sizeof(uint32_t) * e->slow_cap));
-    HIPCHK(e, e->b_sort_list.ensure(sizeof(uint32_t) * e->sort_cap));
-    HIPCHK(e, e->b_scratch.ensure(sizeof(uint32_t) * e->scratch_cap));
-    HIPCHK(e, e->b_ctr.ensure(sizeof(Counters)));
-    HIPCHK(e, e->b_total.ensure(sizeof(unsigned long long)));
+    if (e->cur->pair_cap == 0) e->cur->pair_cap = 1u << 16;
+    e->cur->pair_cap = std::max<uint64_t>(e->cur->pair_cap, (uint64_t)n_topics * 4);
+    if (e->cur->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
+    if (e->cur->slow_cap == 0) e->cur->slow_cap = 1024;
+    e->cur->slow_cap = std::max<uint32_t>(e->cur->slow_cap, n_topics / 16);
+    if (e->cur->sort_cap == 0) e->cur->sort_cap = 1024;
+    e->cur->sort_cap = std::max<uint32_t>(e->cur->sort_cap, n_topics / 64);
+    if (e->cur->scratch_cap == 0) e->cur->scratch_cap = (uint64_t)(e->cfg.slow_scratch_mb ? e->cfg.slow_scratch_mb : 64) * (1u << 20) / 4;
+    HIPCHK(e, e->cur->b_tenant_root.ensure(sizeof(TenantSlot) * std::max(n_tenants, 1u)));
+    HIPCHK(e, e->cur->b_pair_off.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, e->cur->b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, e->cur->b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, e->cur->b_pairs.ensure(sizeof(MatchRange) * e->cur->pair_cap));
+    HIPCHK(e, e->cur->b_subs.ensure(sizeof(SubAlloc) * 2 * N_SUB));
+    HIPCHK(e, e->cur->b_super.ensure(sizeof(unsigned long long) * SUPER_STRIDE * ((n_blocks >> SUPER_SHIFT) + 2)));
+    HIPCHK(e, e->cur->b_blk_stats.ensure(sizeof(uint4) * std::max(n_blocks, 1u)));
+    if (e->cur->spill_cap == 0) e->cur->spill_cap = 1u << 16;
+    e->cur->spill_cap = std::max<uint64_t>(e->cur->spill_cap, (uint64_t)n_topics * 2);
+    HIPCHK(e, e->cur->b_spill.ensure(sizeof(uint4) * e->cur->spill_cap));
+    HIPCHK(e, e->cur->b_wave_sums.ensure(sizeof(unsigned long long) * std::max(n_blocks, 1u)));
+    HIPCHK(e, e->cur->b_slow_list.ensure(sizeof(uint32_t) * e->cur->slow_cap));
+    HIPCHK(e, e->cur->b_sort_list.ensure(sizeof(uint32_t) * e->cur->sort_cap));
+    HIPCHK(e, e->cur->b_scratch.ensure(sizeof(uint32_t) * e->cur->scratch_cap));
+    HIPCHK(e, e->cur->b_ctr.ensure(sizeof(Counters)));
+    HIPCHK(e, e->cur->b_total.ensure(sizeof(unsigned long long)));
     return BMQ_OK;
 }
 
 int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.ix = e->dix->view();
     a.n_blocks = (a.n_topics + 63) / 64;
-    a.tenant_info = e->b_tenant_root.as<TenantSlot>();
-    a.pair_off = e->b_pair_off.as<uint32_t>();
-    a.pair_cnt = e->b_pair_cnt.as<uint32_t>();
-    a.route_cnt = e->b_route_cnt.as<uint32_t>();
-    a.pairs = e->b_pairs.as<MatchRange>();
-    a.pair_cap = e->pair_cap;
-    a.subs = e->b_subs.as<SubAlloc>();
-    a.blk_stats = e->b_blk_stats.as<uint4>();
-    a.spill = e->b_spill.as<uint4>();
-    a.spill_cap = e->spill_cap;
-    a.wave_sums = e->b_wave_sums.as<unsigned long long>();
-    a.slow_list = e->b_slow_list.as<uint32_t>();
-    a.slow_cap = e->slow_cap;
-    a.scratch = e->b_scratch.as<uint32_t>();
-    a.scratch_cap = e->scratch_cap;
-    a.sort_list = e->b_sort_list.as<uint32_t>();
-    a.sort_cap = e->sort_cap;
-    a.ctr = e->b_ctr.as<Counters>();
+    a.tenant_info = e->cur->b_tenant_root.as<TenantSlot>();
+    a.pair_off = e->cur->b_pair_off.as<uint32_t>();
+    a.pair_cnt = e->cur->b_pair_cnt.as<uint32_t>();
+    a.route_cnt = e->cur->b_route_cnt.as<uint32_t>();
+    a.pairs = e->cur->b_pairs.as<MatchRange>();
+    a.pair_cap = e->cur->pair_cap;
+    a.subs = e->cur->b_subs.as<SubAlloc>();
+    a.super_sums = e->cur->b_super.as<unsigned long long>();
+    a.blk_stats = e->cur->b_blk_stats.as<uint4>();
+    a.spill = e->cur->b_spill.as<uint4>();
+    a.spill_cap = e->cur->spill_cap;
+    a.wave_sums = e->cur->b_wave_sums.as<unsigned long long>();
+    a.slow_list = e->cur->b_slow_list.as<uint32_t>();
+    a.slow_cap = e->cur->slow_cap;
+    a.scratch = e->cur->b_scratch.as<uint32_t>();
+    a.scratch_cap = e->cur->scratch_cap;
+    a.sort_list = e->cur->b_sort_list.as<uint32_t>();
+    a.sort_cap = e->cur->sort_cap;
+    a.ctr = e->cur->b_ctr.as<Counters>();
     {
         const char* dbg = getenv("BMQ_DEBUG");
         a.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
         a.dbg_wave = nullptr;
         if (a.debug_flags & 2u) {
-            HIPCHK(e, e->b_dbg_wave.ensure(sizeof(uint4) * std::max(a.n_blocks, 1u)));
-            a.dbg_wave = e->b_dbg_wave.as<uint4>();
+            HIPCHK(e, e->cur->b_dbg_wave.ensure(sizeof(uint4) * std::max(a.n_blocks, 1u)));
+            a.dbg_wave = e->cur->b_dbg_wave.as<uint4>();
         }
     }
     a.qcap = e->cfg.wave_queue_cap;
     a.pcap = e->cfg.wave_pair_cap;
     hipStream_t s = e->stream;
-    HIPCHK(e, hipMemsetAsync(a.ctr, 0, sizeof(Counters), s));
-    HIPCHK(e, hipMemsetAsync(a.subs, 0, sizeof(SubAlloc) * 2 * N_SUB, s));
-    HIPCHK(e, hipEventRecord(e->ev[0], s));
-    if (a.n_tenants) hipLaunchKernelGGL(k_resolve_tenants, dim3((a.n_tenants + 63) / 64), dim3(64), 0, s, a);
-    HIPCHK(e, hipEventRecord(e->ev[1], s));
+    HIPCHK(e, hipEventRecord(e->cur->ev[0], s));
+    {
+        const uint32_t n_super = (a.n_blocks >> SUPER_SHIFT) + 1;
+        const uint32_t items = std::max<uint32_t>(std::max<uint32_t>(a.n_tenants, n_super), (uint32_t)(sizeof(SubAlloc) * 2 * N_SUB / 8));
+        hipLaunchKernelGGL(k_prologue, dim3((items + 63) / 64), dim3(64), 0, s, a, n_super);
+    }
+    HIPCHK(e, hipEventRecord(e->cur->ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
         const dim3 grid((a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
         if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_walk, grid, block, lds, s, a);
     }
-    HIPCHK(e, hipEventRecord(e->ev[2], s));
+    HIPCHK(e, hipEventRecord(e->cur->ev[2], s));
     hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, a);
-    HIPCHK(e, hipEventRecord(e->ev[3], s));
+    HIPCHK(e, hipEventRecord(e->cur->ev[3], s));
     hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
-    HIPCHK(e, hipEventRecord(e->ev[4], s));
+    HIPCHK(e, hipEventRecord(e->cur->ev[4], s));
     hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
-    HIPCHK(e, hipEventRecord(e->ev[5], s));
-    HIPCHK(e, hipMemcpyAsync(e->h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipEventRecord(e->cur->ev[5], s));
+    HIPCHK(e, hipMemcpyAsync(e->cur->h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipEventRecord(e->cur->ev_done, s));
     HIPCHK(e, hipGetLastError());
-    e->last = a;
-    e->pending = true;
-    e->pending_kind = 0;
+    e->cur->last = a;
+    e->cur->pending = true;
+    e->cur->pending_kind = 0;
     return BMQ_OK;
 }
 
 // waits; grows internal buffers and re-runs when a kernel asked for it
 // BMQ_DEBUG=2: per-wave phase clocks of the last k_walk launch (profiling experiments only)
 static void print_wave_debug(bmq_engine* e) {
-    const BatchArgs& a = e->last;
+    const BatchArgs& a = e->cur->last;
     if (!a.dbg_wave || !a.n_blocks) return;
     std::vector<uint4> h(a.n_blocks);
     if (hipMemcpy(h.data(), a.dbg_wave, sizeof(uint4) * a.n_blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
@@ -263,51 +277,51 @@ static void print_wave_debug(bmq_engine* e) {
 
 int finish_dist(bmq_engine* e, uint64_t* out_total) {
     for (int attempt = 0; attempt < 8; attempt++) {
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (e->last.debug_flags & 2u) print_wave_debug(e);
-        const Counters c = *e->h_ctr;
+        HIPCHK(e, hipEventSynchronize(e->cur->ev_done)); // this batch only: a later batch may already be running behind it
+        if (e->cur->last.debug_flags & 2u) print_wave_debug(e);
+        const Counters c = *e->cur->h_ctr;
         const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST);
         if (grow) {
             if (grow & ST_NEED_PAIRS) {
-                e->pair_cap = e->pair_cap * 2; // slices fill unevenly: double until every sub-allocator fits
-                if (e->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
-                HIPCHK(e, e->b_pairs.ensure(sizeof(MatchRange) * e->pair_cap));
+                e->cur->pair_cap = e->cur->pair_cap * 2; // slices fill unevenly: double until every sub-allocator fits
+                if (e->cur->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
+                HIPCHK(e, e->cur->b_pairs.ensure(sizeof(MatchRange) * e->cur->pair_cap));
             }
             if (grow & ST_NEED_SPILL) {
-                e->spill_cap = e->spill_cap * 2;
-                if (e->spill_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "range spill buffer exceeds 2^32 records");
-                HIPCHK(e, e->b_spill.ensure(sizeof(uint4) * e->spill_cap));
+                e->cur->spill_cap = e->cur->spill_cap * 2;
+                if (e->cur->spill_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "range spill buffer exceeds 2^32 records");
+                HIPCHK(e, e->cur->b_spill.ensure(sizeof(uint4) * e->cur->spill_cap));
             }
             if (grow & ST_NEED_SLOW) {
-                e->slow_cap = std::max<uint32_t>(e->slow_cap * 2, c.slow_count);
-                HIPCHK(e, e->b_slow_list.ensure(sizeof(uint32_t) * e->slow_cap));
+                e->cur->slow_cap = std::max<uint32_t>(e->cur->slow_cap * 2, c.slow_count);
+                HIPCHK(e, e->cur->b_slow_list.ensure(sizeof(uint32_t) * e->cur->slow_cap));
             }
             if (grow & ST_NEED_SCRATCH) {
-                e->scratch_cap = std::max<uint64_t>(e->scratch_cap * 2, c.scratch_alloc + c.scratch_alloc / 8);
-                HIPCHK(e, e->b_scratch.ensure(sizeof(uint32_t) * e->scratch_cap));
+                e->cur->scratch_cap = std::max<uint64_t>(e->cur->scratch_cap * 2, c.scratch_alloc + c.scratch_alloc / 8);
+                HIPCHK(e, e->cur->b_scratch.ensure(sizeof(uint32_t) * e->cur->scratch_cap));
             }
             if (grow & ST_NEED_SORTLIST) {
-                e->sort_cap = std::max<uint32_t>(e->sort_cap * 2, c.sort_count);
-                HIPCHK(e, e->b_sort_list.ensure(sizeof(uint32_t) * e->sort_cap));
+                e->cur->sort_cap = std::max<uint32_t>(e->cur->sort_cap * 2, c.sort_count);
+                HIPCHK(e, e->cur->b_sort_list.ensure(sizeof(uint32_t) * e->cur->sort_cap));
             }
-            BatchArgs a = e->last;
+            BatchArgs a = e->cur->last;
             int rc = launch_dist(e, a);
             if (rc) return rc;
             continue;
         }
-        e->pending = false;
+        e->cur->pending = false;
         bmq_stats& st = e->stats;
         st = bmq_stats{};
-        st.n_topics = e->last.n_topics;
+        st.n_topics = e->cur->last.n_topics;
         st.n_visit = c.n_visit;
         st.n_match = c.total_ids;
         st.n_ranges = c.n_ranges;
         st.n_slow_topics = c.slow_count;
         st.n_sorted_rows = c.sort_count;
         st.topic_bytes = c.topic_bytes;
-        (void)hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[5]);
-        (void)hipEventElapsedTime(&st.ms_walk, e->ev[1], e->ev[2]);
-        (void)hipEventElapsedTime(&st.ms_expand, e->ev[3], e->ev[4]);
+        (void)hipEventElapsedTime(&st.ms_total, e->cur->ev[0], e->cur->ev[5]);
+        (void)hipEventElapsedTime(&st.ms_walk, e->cur->ev[1], e->cur->ev[2]);
+        (void)hipEventElapsedTime(&st.ms_expand, e->cur->ev[3], e->cur->ev[4]);
         if (out_total) *out_total = c.total_ids;
         if (c.status & ST_RANGE) return set_err(e, BMQ_E_RANGE, "batch produced >= 2^32 route ids");
         if (c.status & ST_NOSPACE) return set_err(e, BMQ_E_NOSPACE, "output buffer too small");
@@ -365,11 +379,18 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (hipGetDeviceCount(&n) != hipSuccess || c.device >= n) return BMQ_E_NODEVICE;
         if (hipSetDevice(c.device) != hipSuccess) return BMQ_E_NODEVICE;
         if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return BMQ_E_HIP;
-        for (auto& ev : e->ev)
-            if (hipEventCreate(&ev) != hipSuccess) return BMQ_E_HIP;
-        if (hipHostMalloc((void**)&e->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess)
-            return BMQ_E_NOMEM;
-        memset(e->h_ctr, 0, sizeof(Counters));
+        if (hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking) != hipSuccess)
+            return BMQ_E_HIP;
+        for (auto& sl : e->slots) {
+            for (auto& ev : sl.ev)
+                if (hipEventCreate(&ev) != hipSuccess) return BMQ_E_HIP;
+            if (hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) != hipSuccess)
+                return BMQ_E_HIP;
+            if (hipHostMalloc((void**)&sl.h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) return BMQ_E_NOMEM;
+            memset(sl.h_ctr, 0, sizeof(Counters));
+        }
         e->dx.device = c.device;
         e->dx.stream = e->stream;
         e->dix = std::make_unique<DistIndex<DevExec>>(e->dx);
@@ -385,9 +406,17 @@ void bmq_engine_destroy(bmq_engine* e) {
     if (e->device >= 0) {
         (void)hipSetDevice(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
-        for (auto& ev : e->ev)
-            if (ev) (void)hipEventDestroy(ev);
-        if (e->h_ctr) (void)hipHostFree(e->h_ctr);
+        if (e->s_in) (void)hipStreamSynchronize(e->s_in);
+        if (e->s_out) (void)hipStreamSynchronize(e->s_out);
+        for (auto& sl : e->slots) {
+            for (auto& ev : sl.ev)
+                if (ev) (void)hipEventDestroy(ev);
+            if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+            if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+            if (sl.h_ctr) (void)hipHostFree(sl.h_ctr);
+        }
+        if (e->s_in) (void)hipStreamDestroy(e->s_in);
+        if (e->s_out) (void)hipStreamDestroy(e->s_out);
         e->dix.reset(); // frees the HBM arrays while the stream still exists
         e->dx.release(e->dx.tmp);
         e->dx.tmp = nullptr;
@@ -404,7 +433,7 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
     if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || (n_keys && (!keys || !key_off))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
+    if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     static const uint32_t zero_off[1] = {0};
     static const uint8_t no_bytes[16] = {0};
@@ -428,7 +457,7 @@ int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off
     // The builder kernels run on the engine stream, in order with the match batches: a mutation costs the matcher threads the
     // duration of its kernels (well under a millisecond for 100 k ops), not a host-side rebuild.
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
+    if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     bool bad_input = false;
     const bool ok = with_index(e, [&](auto& ix) {
@@ -545,7 +574,7 @@ int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t*
         return set_err(e, BMQ_E_INVAL, "null pointer or empty batch");
     if ((uintptr_t)d_topics & 15) return set_err(e, BMQ_E_INVAL, "the topic byte buffer must be 16-byte aligned");
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
+    if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     HIPCHK(e, hipSetDevice(e->device));
     if ((rc = ensure_batch_scratch(e, n_tenants, n_topics))) return rc;
     BatchArgs a{};
@@ -567,9 +596,9 @@ int bmq_match_finish(bmq_engine* e, uint64_t* out_total) {
     if (!e) return BMQ_E_INVAL;
     if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only");
     std::lock_guard<std::mutex> g(e->mu);
-    if (!e->pending) return set_err(e, BMQ_E_STATE, "no batch in flight");
+    if (!e->cur->pending) return set_err(e, BMQ_E_STATE, "no batch in flight");
     HIPCHK(e, hipSetDevice(e->device));
-    return e->pending_kind == 0 ? finish_dist(e, out_total) : retain_finish(e, out_total);
+    return e->cur->pending_kind == 0 ? finish_dist(e, out_total) : retain_finish(e, out_total);
 }
 
 int bmq_sync(bmq_engine* e) {
@@ -605,23 +634,23 @@ int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenan
         std::lock_guard<std::mutex> g(e->mu);
         HIPCHK(e, hipSetDevice(e->device));
         const size_t tb = n_tenants ? tenant_off[n_tenants] : 0, pb = topic_off[n_topics];
-        HIPCHK(e, e->s_tenants.ensure(tb + 16));
-        HIPCHK(e, e->s_topics.ensure(pb + 16));
-        if ((rc = upload(e, e->s_tenant_off, tenant_off, sizeof(uint32_t) * (n_tenants ? n_tenants + 1 : 0)))) return rc;
-        if (tb) HIPCHK(e, hipMemcpyAsync(e->s_tenants.p, tenants, tb, hipMemcpyHostToDevice, e->stream));
-        if ((rc = upload(e, e->s_topic_tenant, topic_tenant, sizeof(uint32_t) * n_topics))) return rc;
-        if (pb) HIPCHK(e, hipMemcpyAsync(e->s_topics.p, topics, pb, hipMemcpyHostToDevice, e->stream));
-        if ((rc = upload(e, e->s_topic_off, topic_off, sizeof(uint32_t) * (n_topics + 1)))) return rc;
-        HIPCHK(e, e->s_row_ptr.ensure(sizeof(uint32_t) * (n_topics + 1)));
-        HIPCHK(e, e->b_total.ensure(sizeof(unsigned long long)));
-        dev_cap = std::max<uint64_t>(e->s_ids.cap / 4, std::max<uint64_t>((uint64_t)n_topics * 4, 1024));
-        HIPCHK(e, e->s_ids.ensure(dev_cap * 4));
+        HIPCHK(e, e->cur->s_tenants.ensure(tb + 16));
+        HIPCHK(e, e->cur->s_topics.ensure(pb + 16));
+        if ((rc = upload(e, e->cur->s_tenant_off, tenant_off, sizeof(uint32_t) * (n_tenants ? n_tenants + 1 : 0)))) return rc;
+        if (tb) HIPCHK(e, hipMemcpyAsync(e->cur->s_tenants.p, tenants, tb, hipMemcpyHostToDevice, e->stream));
+        if ((rc = upload(e, e->cur->s_topic_tenant, topic_tenant, sizeof(uint32_t) * n_topics))) return rc;
+        if (pb) HIPCHK(e, hipMemcpyAsync(e->cur->s_topics.p, topics, pb, hipMemcpyHostToDevice, e->stream));
+        if ((rc = upload(e, e->cur->s_topic_off, topic_off, sizeof(uint32_t) * (n_topics + 1)))) return rc;
+        HIPCHK(e, e->cur->s_row_ptr.ensure(sizeof(uint32_t) * (n_topics + 1)));
+        HIPCHK(e, e->cur->b_total.ensure(sizeof(unsigned long long)));
+        dev_cap = std::max<uint64_t>(e->cur->s_ids.cap / 4, std::max<uint64_t>((uint64_t)n_topics * 4, 1024));
+        HIPCHK(e, e->cur->s_ids.ensure(dev_cap * 4));
     }
     for (int attempt = 0; attempt < 3; attempt++) {
-        rc = bmq_match_batch_dev(e, e->s_tenants.as<uint8_t>(), e->s_tenant_off.as<uint32_t>(), n_tenants,
-                                 e->s_topic_tenant.as<uint32_t>(), e->s_topics.as<uint8_t>(), e->s_topic_off.as<uint32_t>(),
-                                 n_topics, e->s_row_ptr.as<uint32_t>(), e->s_ids.as<uint32_t>(), dev_cap,
-                                 e->b_total.as<uint64_t>());
+        rc = bmq_match_batch_dev(e, e->cur->s_tenants.as<uint8_t>(), e->cur->s_tenant_off.as<uint32_t>(), n_tenants,
+                                 e->cur->s_topic_tenant.as<uint32_t>(), e->cur->s_topics.as<uint8_t>(), e->cur->s_topic_off.as<uint32_t>(),
+                                 n_topics, e->cur->s_row_ptr.as<uint32_t>(), e->cur->s_ids.as<uint32_t>(), dev_cap,
+                                 e->cur->b_total.as<uint64_t>());
         if (rc) return rc;
         uint64_t total = 0;
         rc = bmq_match_finish(e, &total);
@@ -630,17 +659,144 @@ int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenan
             if (total > out_capacity || !out_route_ids) return rc; // the caller's buffer is the problem
             std::lock_guard<std::mutex> g(e->mu);
             dev_cap = total;
-            HIPCHK(e, e->s_ids.ensure(dev_cap * 4));
+            HIPCHK(e, e->cur->s_ids.ensure(dev_cap * 4));
             continue;
         }
         if (rc) return rc;
         std::lock_guard<std::mutex> g(e->mu);
-        HIPCHK(e, hipMemcpy(out_row_ptr, e->s_row_ptr.p, sizeof(uint32_t) * (n_topics + 1), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(out_row_ptr, e->cur->s_row_ptr.p, sizeof(uint32_t) * (n_topics + 1), hipMemcpyDeviceToHost));
         if (total > out_capacity || (total && !out_route_ids)) return set_err(e, BMQ_E_NOSPACE, "output buffer too small");
-        if (total) HIPCHK(e, hipMemcpy(out_route_ids, e->s_ids.p, sizeof(uint32_t) * total, hipMemcpyDeviceToHost));
+        if (total) HIPCHK(e, hipMemcpy(out_route_ids, e->cur->s_ids.p, sizeof(uint32_t) * total, hipMemcpyDeviceToHost));
         return BMQ_OK;
     }
     return set_err(e, BMQ_E_NOMEM, "device output buffer growth did not converge");
+}
+
+// ---- asynchronous host-buffer match: two batches in flight ---------------------------------------------------------------
+void* bmq_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void bmq_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                     const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, int* out_ticket) {
+    int rc = check_dist_ready(e);
+    if (rc) return rc;
+    if (!out_ticket || n_topics == 0 || !topics || !topic_off || !topic_tenant || (n_tenants && (!tenants || !tenant_off)))
+        return set_err(e, BMQ_E_INVAL, "null pointer or empty batch");
+    std::lock_guard<std::mutex> g(e->mu);
+    HIPCHK(e, hipSetDevice(e->device));
+    int k = -1;
+    for (int i = 0; i < 2; i++)
+        if (!e->slots[i].pending && !e->slots[i].submitted) {
+            k = i;
+            break;
+        }
+    if (k < 0) return set_err(e, BMQ_E_STATE, "two batches are already in flight: call bmq_match_wait first");
+    bmq_engine::BatchSlot& S = e->slots[k];
+    bmq_engine::BatchSlot* const prev = e->cur;
+    e->cur = &S;
+    struct Restore {
+        bmq_engine* e;
+        bmq_engine::BatchSlot* p;
+        ~Restore() { e->cur = p; }
+    } restore{e, prev};
+    const size_t tb = n_tenants ? tenant_off[n_tenants] : 0, pb = topic_off[n_topics];
+    HIPCHK(e, S.s_tenants.ensure(tb + 16));
+    HIPCHK(e, S.s_topics.ensure(pb + 16));
+    HIPCHK(e, S.s_tenant_off.ensure(sizeof(uint32_t) * ((size_t)n_tenants + 1)));
+    HIPCHK(e, S.s_topic_tenant.ensure(sizeof(uint32_t) * (size_t)n_topics));
+    HIPCHK(e, S.s_topic_off.ensure(sizeof(uint32_t) * ((size_t)n_topics + 1)));
+    HIPCHK(e, S.s_row_ptr.ensure(sizeof(uint32_t) * ((size_t)n_topics + 1)));
+    HIPCHK(e, S.b_total.ensure(sizeof(unsigned long long)));
+    S.dev_cap = std::max<uint64_t>(S.s_ids.cap / 4, std::max<uint64_t>((uint64_t)n_topics * 24, 1024));
+    HIPCHK(e, S.s_ids.ensure(S.dev_cap * 4));
+    if ((rc = ensure_batch_scratch(e, n_tenants, n_topics))) return rc;
+    // upload on the copy-in stream: it overlaps the kernels of the batch submitted before (pinned sources: bmq_host_alloc)
+    if (n_tenants) {
+        HIPCHK(e, hipMemcpyAsync(S.s_tenant_off.p, tenant_off, sizeof(uint32_t) * ((size_t)n_tenants + 1), hipMemcpyHostToDevice, e->s_in));
+        if (tb) HIPCHK(e, hipMemcpyAsync(S.s_tenants.p, tenants, tb, hipMemcpyHostToDevice, e->s_in));
+    }
+    HIPCHK(e, hipMemcpyAsync(S.s_topic_tenant.p, topic_tenant, sizeof(uint32_t) * (size_t)n_topics, hipMemcpyHostToDevice, e->s_in));
+    if (pb) HIPCHK(e, hipMemcpyAsync(S.s_topics.p, topics, pb, hipMemcpyHostToDevice, e->s_in));
+    HIPCHK(e, hipMemcpyAsync(S.s_topic_off.p, topic_off, sizeof(uint32_t) * ((size_t)n_topics + 1), hipMemcpyHostToDevice, e->s_in));
+    HIPCHK(e, hipEventRecord(S.ev_in, e->s_in));
+    HIPCHK(e, hipStreamWaitEvent(e->stream, S.ev_in, 0));
+    BatchArgs a{};
+    a.tenants = S.s_tenants.as<uint8_t>();
+    a.tenant_off = S.s_tenant_off.as<uint32_t>();
+    a.n_tenants = n_tenants;
+    a.topic_tenant = S.s_topic_tenant.as<uint32_t>();
+    a.topics = S.s_topics.as<uint8_t>();
+    a.topic_off = S.s_topic_off.as<uint32_t>();
+    a.n_topics = n_topics;
+    a.out_row_ptr = S.s_row_ptr.as<uint32_t>();
+    a.out_ids = S.s_ids.as<uint32_t>();
+    a.out_capacity = S.dev_cap;
+    a.out_total = S.b_total.as<unsigned long long>();
+    if ((rc = launch_dist(e, a))) return rc;
+    S.submitted = true;
+    S.n_rows = n_topics;
+    *out_ticket = k;
+    return BMQ_OK;
+}
+
+int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed) {
+    if (!e || ticket < 0 || ticket > 1 || !out_row_ptr || !out_needed) return BMQ_E_INVAL;
+    if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only");
+    bmq_engine::BatchSlot& S = e->slots[ticket];
+    uint64_t total = 0;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        if (!S.submitted) return set_err(e, BMQ_E_STATE, "no such ticket in flight");
+        HIPCHK(e, hipSetDevice(e->device));
+    }
+    (void)hipEventSynchronize(S.ev_done); // outside the lock: other threads may submit / apply meanwhile
+    std::unique_lock<std::mutex> g(e->mu);
+    int rc = BMQ_OK;
+    {
+        bmq_engine::BatchSlot* const prev = e->cur;
+        e->cur = &S;
+        for (int attempt = 0; attempt < 3; attempt++) {
+            rc = finish_dist(e, &total); // grows internal scratch and re-runs if a kernel asked for it
+            if (rc != BMQ_E_NOSPACE || total <= S.dev_cap) break;
+            S.dev_cap = total; // the slot's own id buffer was too small: it knows the size now
+            if (S.s_ids.ensure(S.dev_cap * 4) != hipSuccess) {
+                rc = set_err(e, BMQ_E_NOMEM, "out of device memory (result buffer)");
+                break;
+            }
+            BatchArgs a = S.last;
+            a.out_ids = S.s_ids.as<uint32_t>();
+            a.out_capacity = S.dev_cap;
+            if ((rc = launch_dist(e, a))) break;
+        }
+        e->cur = prev;
+    }
+    *out_needed = total;
+    const bool fits = total <= out_capacity && (total == 0 || out_route_ids);
+    hipError_t he = hipSuccess;
+    if (rc == BMQ_OK) {
+        // download on the copy-out stream: it overlaps the kernels of the batch submitted after this one.  The slot stays taken
+        // until the copy has finished; the engine lock is not held meanwhile.
+        he = hipMemcpyAsync(out_row_ptr, S.s_row_ptr.p, sizeof(uint32_t) * ((size_t)S.n_rows + 1), hipMemcpyDeviceToHost, e->s_out);
+        if (he == hipSuccess && fits && total)
+            he = hipMemcpyAsync(out_route_ids, S.s_ids.p, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, e->s_out);
+        g.unlock();
+        if (he == hipSuccess) he = hipStreamSynchronize(e->s_out);
+        g.lock();
+    }
+    S.submitted = false;
+    S.pending = false;
+    if (rc) return rc;
+    if (he != hipSuccess) return set_err(e, BMQ_E_HIP, std::string("result download: ") + hipGetErrorString(he));
+    return fits ? BMQ_OK : set_err(e, BMQ_E_NOSPACE, "output buffer too small");
 }
 
 // ---- host-side mirror of MatchedRoutes (DW/cache/MatchedRoutes.java:87-141) -------------------------------------------

@@ -43,6 +43,10 @@ __global__ __launch_bounds__(BK) void k_b_bulk_tenants(DistIndexMut ix, OpBatch 
     const uint32_t i = blockIdx.x * BK + threadIdx.x;
     if (i < ob.n) bulk_tenants_one(ix, ob, i, scan);
 }
+__global__ __launch_bounds__(BK) void k_b_bulk_counts(OpBatch ob, uint32_t n_ten, const uint32_t* nn_incl) {
+    const uint32_t t = blockIdx.x * BK + threadIdx.x;
+    if (t < n_ten) bulk_counts_one(ob, t, n_ten, nn_incl);
+}
 __global__ __launch_bounds__(BK) void k_b_locate(DistIndexMut ix, OpBatch ob) {
     const uint32_t i = blockIdx.x * BK + threadIdx.x;
     if (i < ob.n) locate_one(ix, ob, i);
@@ -143,6 +147,10 @@ struct DevExec {
     }
     bool bulk_tenants(const DistIndexMut& ix, const OpBatch& ob, const uint32_t* scan) {
         hipLaunchKernelGGL(k_b_bulk_tenants, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, scan);
+        return launched();
+    }
+    bool bulk_counts(const OpBatch& ob, uint32_t n_ten, const uint32_t* nn_incl) {
+        hipLaunchKernelGGL(k_b_bulk_counts, grid(n_ten, BK), dim3(BK), 0, stream, ob, n_ten, nn_incl);
         return launched();
     }
     bool locate(const DistIndexMut& ix, const OpBatch& ob) {

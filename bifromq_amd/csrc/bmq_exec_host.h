@@ -84,6 +84,10 @@ struct HostExec {
         par(ob.n, [&](size_t i) { bulk_tenants_one(ix, ob, (uint32_t)i, scan); });
         return true;
     }
+    bool bulk_counts(const OpBatch& ob, uint32_t n_ten, const uint32_t* nn_incl) {
+        par(n_ten, [&](size_t t) { bulk_counts_one(ob, (uint32_t)t, n_ten, nn_incl); });
+        return true;
+    }
     bool locate(const DistIndexMut& ix, const OpBatch& ob) {
         par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i); });
         return true;

@@ -38,6 +38,16 @@ def pack(strings: Sequence) -> Tuple[np.ndarray, np.ndarray]:
     return data, off
 
 
+def pinned(shape, dtype) -> np.ndarray:
+    """numpy array over page-locked host memory from bmq_host_alloc (never freed explicitly here: benchmark / test helper)."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = _lib.lib().bmq_host_alloc(max(n, 16))
+    if not p:
+        raise MemoryError("bmq_host_alloc")
+    buf = (C.c_uint8 * max(n, 16)).from_address(p)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -194,6 +204,24 @@ class Engine:
                 continue
             self._check(rc)
             return row, ids[:need.value]
+
+    # ---- asynchronous host-buffer match: two batches in flight (bmq_match_submit / bmq_match_wait) ------------------------
+    def match_submit(self, tdata, toff, n_tenants, tt, pdata, poff, n_topics) -> int:
+        """numpy arrays (ideally views of bmq_host_alloc memory, see pinned()); they must stay alive until match_wait."""
+        k = C.c_int()
+        self._check(_lib.lib().bmq_match_submit(self.h, _ptr(tdata), _ptr(toff), n_tenants, _ptr(tt), _ptr(pdata), _ptr(poff), n_topics,
+                                                C.byref(k)))
+        return k.value
+
+    def match_wait(self, ticket: int, row: np.ndarray, ids: np.ndarray) -> int:
+        """-> number of ids written (BmqError code -3 with .needed set if ids is too small)"""
+        need = C.c_uint64()
+        rc = _lib.lib().bmq_match_wait(self.h, ticket, _ptr(row), _ptr(ids), len(ids), C.byref(need))
+        if rc:
+            err = BmqError(rc, (_lib.lib().bmq_last_error(self.h) or b"").decode())
+            err.needed = need.value
+            raise err
+        return need.value
 
     def batcher(self, max_batch_topics: int = 0) -> "Batcher":
         """The batching front of SURVEY.md 8f-1 over this engine (close it before the engine)."""

@@ -156,6 +156,24 @@ int bmq_stats_get(const bmq_engine* e, bmq_stats* out);
 /* The hipStream_t the engine launches on (as void*), so a harness can bracket it with HIP events. */
 void* bmq_stream(const bmq_engine* e);
 
+/* ---- asynchronous host-buffer match (the host-visible fast path) ------------------------------------------------------ */
+/* Page-locked host memory.  Buffers from here move over PCIe by DMA at full speed and truly asynchronously; a JNI binding wraps
+ * them with NewDirectByteBuffer.  (Any host pointer is accepted everywhere; pageable memory is staged by the HIP runtime.) */
+void* bmq_host_alloc(size_t bytes);
+void bmq_host_free(void* p);
+/* bmq_match_batch split in two so that TWO batches can be in flight: the upload of batch i+1 (copy-in stream) and the download
+ * of batch i-1 (copy-out stream, inside bmq_match_wait) overlap the kernels of batch i (engine stream).  Steady state: one batch
+ * costs max(upload, kernels, download) instead of their sum.  Input buffers must stay valid and unchanged until the matching
+ * bmq_match_wait returns.  *out_ticket is 0 or 1; BMQ_E_STATE when both are taken.  bmq_match_wait blocks until the batch is
+ * done, copies row_ptr[n_topics + 1] and the ids out (same NOSPACE protocol as bmq_match_batch) and frees the ticket.
+ * Tickets may be waited for from any thread; bmq_routes_apply between a submit and its wait is applied BEHIND the submitted batch
+ * (stream order). */
+int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                     const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
+                     int* out_ticket);
+int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
+                   uint64_t* out_needed);
+
 /* ---- batching front ------------------------------------------------------------------- */
 /* Production asks for one topic per call: TenantRouteCache issues matchAll(singleton(topic)) per cache miss from
  * the matchExecutor pool (DW/cache/TenantRouteCache.java:180-193, DW/DistWorkerCoProcFactory.java:74-88).  A batcher

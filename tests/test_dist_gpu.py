@@ -477,3 +477,57 @@ def test_full_size_config3_properties(eng):
     for j in differ[:20].tolist() + rnd.sample(range(len(cand)), 20):  # authoritative semantic check: quirk rows + a sub-sample
         i = int(cand[j])
         assert ids[row[i]:row[i + 1]].tolist() == kv.match_bruteforce(tn[int(tt[i])], [raw[off[i]:off[i + 1]]]).per_topic()[0]
+
+
+def test_submit_wait_two_batches_in_flight(eng):
+    """bmq_match_submit / bmq_match_wait: two host batches in flight (upload / kernels / download overlapped), page-locked buffers
+    from bmq_host_alloc; every batch equals the blocking bmq_match_batch result, also with a bmq_routes_apply squeezed between a
+    submit and its wait (stream order: the submitted batch still sees the old routes, the next one the new ones)."""
+    from bifromq_amd.engine import pinned
+    w = B.Workload(11, 6, 3000, 1)
+    keys = w.keys()
+    eng.rebuild(keys)
+    tn = w.tenants()
+    tdata, toff = w.tenants_packed()
+    p_t, p_to = pinned(len(tdata), np.uint8), pinned(len(toff), np.uint32)
+    p_t[:], p_to[:] = tdata, toff
+    batches, expect = [], []
+    for b in range(5):
+        data, off, tt = w.topics(100 + b, 20000 + 1000 * b)
+        pd, po, pt = pinned(len(data), np.uint8), pinned(len(off), np.uint32), pinned(len(tt), np.uint32)
+        pd[:], po[:], pt[:] = data, off, tt
+        batches.append((pd, po, pt, len(tt)))
+        expect.append(eng.match_batch(tn, tt, packed_topics=(data, off)))
+    rows = [pinned(40000, np.uint32) for _ in range(2)]
+    ids = [pinned(4_000_000, np.uint32) for _ in range(2)]
+    tickets = [None, None]
+    for i in range(len(batches) + 1):
+        if i < len(batches):
+            pd, po, pt, n = batches[i]
+            tickets[i % 2] = eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
+            if i == 0:
+                with pytest.raises(B.BmqError):  # ids buffer too small for the wait: NOSPACE, the needed size is reported
+                    eng.match_wait(tickets[0], rows[0], ids[0][:1])
+                tickets[0] = eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
+        if i >= 1:
+            j = (i - 1) % 2
+            n = batches[i - 1][3]
+            got = eng.match_wait(tickets[j], rows[j], ids[j])
+            erow, eids = expect[i - 1]
+            assert got == len(eids) and (rows[j][:n + 1] == erow).all() and (ids[j][:got] == eids).all()
+    with pytest.raises(B.BmqError):
+        eng.match_wait(0, rows[0], ids[0])  # nothing in flight under that ticket
+    # a third submit while two are in flight is refused; an apply between submit and wait lands behind the submitted batch
+    pd, po, pt, n = batches[0]
+    t0 = eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
+    t1 = eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
+    with pytest.raises(B.BmqError):
+        eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
+    extra = _normal(tn[0], "#", 0, "late", "d")
+    eng.apply([(0, extra)])
+    for t in (t0, t1):
+        got = eng.match_wait(t, rows[0], ids[0])
+        assert got == len(expect[0][1]) and (ids[0][:got] == expect[0][1]).all()  # submitted before the apply
+    row2, ids2 = eng.match_batch(tn, pt, packed_topics=(pd, po))
+    assert len(ids2) > len(expect[0][1])  # the '#' route of tenant 0 now matches its non-'$' topics
+

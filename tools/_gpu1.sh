@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_dist_gpu.py tests/test_zz_churn_gpu.py tests/test_batcher_gpu.py -x -q -m gpu > gpurun_out/t_dist.log 2>&1; tail -5 gpurun_out/t_dist.log
-BMQ_TIMING=1 timeout 600 python bench.py --no-cpu-baseline --steps 5 2>&1 | grep -E "bmq index|metric" | cut -c1-300 > gpurun_out/bench_c3.log; cat gpurun_out/bench_c3.log
-BMQ_TIMING=1 timeout 600 python bench.py --churn 100000 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/bench_churn.log 2>&1; grep -E "apply:" gpurun_out/bench_churn.log | tail -8; tail -1 gpurun_out/bench_churn.log | cut -c1-300; tail -1 gpurun_out/bench_churn.log | grep -o '"churn".*"kernel_ms"' | cut -c1-200
-timeout 600 python bench.py --churn 100000 --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
+mkdir -p gpurun_out/kt
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt/c3 -o c3 -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/kt/c3.log 2>&1
+f=$(find gpurun_out/kt/c3 -name "*kernel_stats.csv" | head -1); cat $f | cut -c1-200
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt/s -o s -- python bench.py --steps 50 --warmup 5 --topics 10000 --no-cpu-baseline > gpurun_out/kt/s.log 2>&1
+f=$(find gpurun_out/kt/s -name "*kernel_stats.csv" | head -1); cat $f | cut -c1-200
