@@ -457,7 +457,9 @@ int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off
     // The builder kernels run on the engine stream, in order with the match batches: a mutation costs the matcher threads the
     // duration of its kernels (well under a millisecond for 100 k ops), not a host-side rebuild.
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
+    // a batch handed over with bmq_match_submit is simply in front of the builder kernels on the engine stream; only the
+    // caller-driven *_dev protocol (results read by the caller between launch and finish) excludes a mutation in between
+    if (e->cur->pending && !e->cur->submitted) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     bool bad_input = false;
     const bool ok = with_index(e, [&](auto& ix) {
