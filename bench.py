@@ -41,7 +41,13 @@ def main():
     ap.add_argument("--churn", type=int, default=0,
                     help="configs[4]: apply this many route mutations (50%% subscribe / 50%% unsubscribe) between batches")
     ap.add_argument("--exchange-selftest", action="store_true",
-                    help="run the N>1 exchange step (RCCL all-gather of the CSR) also at world size 1, to exercise that code path")
+                    help="run the N>1 code paths (exchange step, node-wide batch with partition) also at world size 1")
+    ap.add_argument("--exchange", default="fanout", choices=["fanout", "ids", "none"],
+                    help="N>1 exchange step: per-topic fan-out counts (what the reference sends upstream, DistWorkerCoProc.java:535-538) "
+                         "or the complete CSR as an all-gatherv of route ids")
+    ap.add_argument("--node-batch-steps", type=int, default=10,
+                    help="N>1: steps of the extra node-wide measurement (one shared Zipf batch, device-side partition, hot tenants "
+                         "split by filter, fan-out all-reduce); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-visible (PCIe-inclusive) measurement")
     ap.add_argument("--batcher-threads", type=int, default=0,
@@ -145,12 +151,15 @@ def main():
                     raise
                 cap = int(d_total.item()) * 2  # only during warm-up in practice
                 d_ids[k] = torch.zeros(cap, dtype=torch.int32, device=dev)
-        if dist is not None:  # the one exchange step: every rank's CSR (row counts + ids) to every rank over RCCL/xGMI
+        if dist is not None and args.exchange != "none":  # the one exchange step over RCCL/xGMI, on its own stream
             from bifromq_amd import shard
             if d_ids[k].numel() < total:
                 raise RuntimeError("id buffer smaller than the batch result")
             with torch.cuda.stream(ex_stream):  # results are complete (finish() synchronised the engine stream)
-                shard.exchange_csr(dist, d_row[k], d_ids[k], total, world)
+                if args.exchange == "fanout":  # 4 B per topic: every rank learns every topic's fan-out
+                    shard.exchange_counts_weak(dist, d_row[k], world)
+                else:  # all-gatherv of the complete CSR: exact sizes, one grouped broadcast per rank
+                    shard.exchange_csr_v(dist, d_row[k], d_ids[k], total, world)
                 ex_done[k] = torch.cuda.Event()
                 ex_done[k].record(ex_stream)
         return total
@@ -231,6 +240,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    node = None
+    if dist is not None and args.node_batch_steps > 0 and args.workload == "c3":
+        node = node_batch(args, rank, world, local_rank, dev, dist, total_tenants, per_tenant, mode, seed)
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -259,7 +271,12 @@ def main():
                    "index_bytes_this_rank": int(info.device_bytes), "publishes_per_batch_per_rank": n,
                    "batch_order": "random" if args.ungrouped else "grouped by tenant (one DistPack per tenant)",
                    "parallelism": "tenant-shard x%d" % world if world > 1 else "single GPU",
-                   "exchange": "RCCL all_gather of CSR (row_ptr + ids), overlapped with the next batch's match" if dist is not None else "none"},
+                   "exchange": ("none" if dist is None or args.exchange == "none" else
+                                "RCCL all-gather of per-topic fan-out counts (4 B/topic; the CSR stays on the GPU that matched: the reference "
+                                "replies fan-out per topic, DistWorkerCoProc.java:535-538), overlapped with the next batch's match"
+                                if args.exchange == "fanout" else
+                                "RCCL all-gatherv of the complete CSR (row_ptr + route ids, exact sizes, grouped per-rank broadcasts), "
+                                "overlapped with the next batch's match")},
         "p99_batch_ms": float(np.percentile(lat, 99)),
         "p50_batch_ms": float(np.percentile(lat, 50)),
         "routes_per_topic": n_match / (n * steps),
@@ -283,6 +300,8 @@ def main():
         except Exception:
             pass
 
+    if node is not None:
+        out["node_batch"] = node
     if world == 1 and not args.no_host_path:
         out["host_visible"] = host_visible(args, eng, w, batches, n, seed, rank)
     if args.batcher_threads and world == 1:  # the production call pattern (one topic per call, many threads) through the collector
@@ -310,6 +329,101 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     emit_json(out)
+
+
+def node_batch(args, rank, world, local_rank, dev, dist, total_tenants, per_tenant, mode, seed):
+    """The node-wide shape of configs[2]: ONE Zipf batch of --topics publishes over all tenants arrives (resident on every GPU),
+    each rank picks its part on the device (bifromq_amd/shard.py::partition_batch), matches it, and one all-reduce of per-topic
+    fan-out counts gives every rank the node-wide answer.  Tenants are owned by hash(tenantId) mod N; tenants whose share of the
+    publishes exceeds half a rank's fair share are SPLIT BY FILTER: their route keys are spread over all ranks by hash(route key)
+    and their publishes go to every rank (fan-outs add up).  Strong scaling: the batch is fixed, a rank matches ~1/N of it."""
+    import numpy as np
+    import torch
+
+    import bifromq_amd as B
+    from bifromq_amd import shard
+
+    n = args.topics
+    full = B.Workload(seed, total_tenants, per_tenant, mode)
+    tn = full.tenants()
+    data, off, tt = full.topics(seed + 77, n, grouped=not args.ungrouped)  # same batch on every rank
+    share = np.bincount(tt, minlength=len(tn)) / float(n)
+    hot = shard.pick_hot_tenants(share, world, 0.5)
+    owner_np = shard.topic_targets(tn, hot, world)
+    # this rank's index: its tenants (bulk load of the sorted keys) + its hash share of the split tenants' keys (apply)
+    mine = [t for t in range(total_tenants) if owner_np[t] == rank]
+    eng = B.Engine(device=local_rank)
+    wm = B.Workload(seed, len(mine), per_tenant, mode, tenant_ids=mine)
+    kb, ko = wm.keys_packed()
+    eng.rebuild_raw(kb.ctypes.data, ko.ctypes.data, wm.n_keys)
+    n_split_keys = 0
+    if hot:
+        wh = B.Workload(seed, len(hot), per_tenant, mode, tenant_ids=hot)
+        my_hot = [k for k in wh.keys() if shard.key_rank(k, world) == rank]
+        n_split_keys = len(my_hot)
+        for i in range(0, len(my_hot), 50000):
+            eng.apply([(0, k) for k in my_hot[i:i + 50000]])
+    tdata, toff = full.tenants_packed()
+    d_tenants = torch.from_numpy(tdata.copy()).to(dev)
+    d_tenant_off = torch.from_numpy(toff.astype(np.int32)).to(dev)
+    d_owner = torch.from_numpy(owner_np).to(dev)
+    d_data = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
+    d_tt = torch.from_numpy(tt.astype(np.int32)).to(dev)
+    cap = 24 * n
+    d_row = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    m_sel = 0
+
+    def step():
+        nonlocal m_sel, d_ids
+        sel, pd, po, ptt = shard.partition_batch(d_owner, d_tt, d_data, d_off, rank)
+        m = int(sel.numel())
+        m_sel = m
+        torch.cuda.current_stream().synchronize()  # the engine launches on its own stream: the partition must have landed
+        if m:
+            while True:
+                eng.match_batch_device(d_tenants.data_ptr(), d_tenant_off.data_ptr(), len(tn), ptt.data_ptr(), pd.data_ptr(), po.data_ptr(), m,
+                                       d_row.data_ptr(), d_ids.data_ptr(), d_ids.numel(), d_total.data_ptr())
+                try:
+                    eng.finish()
+                    break
+                except B.BmqError as ex:
+                    if ex.code != -3:
+                        raise
+                    d_ids = torch.zeros(int(d_total.item()) * 2, dtype=torch.int32, device=dev)
+            counts = d_row[1:m + 1] - d_row[:m]
+        else:
+            counts = torch.zeros(0, dtype=torch.int32, device=dev)
+        return shard.exchange_fanout(dist, counts, sel, n)
+
+    fan = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.node_batch_steps):
+        fan = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed, float(m_sel)], dtype=torch.float64, device=dev)
+    sel_all = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(sel_all, tmax)
+    per_rank = sel_all.view(world, 2)[:, 1].cpu().numpy()
+    elapsed = float(sel_all.view(world, 2)[:, 0].max().item())
+    # what the imbalance would be WITHOUT the split (every publish to its tenant's owner)
+    plain_owner = np.array([shard.tenant_rank(t, world) for t in tn])
+    plain = np.bincount(plain_owner[tt], minlength=world)
+    eng.close()
+    return {"value": n * args.node_batch_steps / elapsed, "unit": "topics/s", "scaling": "strong", "steps": args.node_batch_steps,
+            "ms_per_step": elapsed / args.node_batch_steps * 1e3, "publishes_per_batch_node": n, "fanout_total": int(fan.sum().item()),
+            "split_tenants": [tn[h] for h in hot], "split_route_keys_this_rank": n_split_keys,
+            "publishes_per_rank": [int(x) for x in per_rank], "imbalance_max_over_mean": float(per_rank.max() / per_rank.mean()),
+            "imbalance_without_split": float(plain.max() / plain.mean()),
+            "note": "one shared batch: device-side partition by hash(tenantId) mod N (hot tenants split by filter, publishes to all ranks) "
+                    "-> match -> all-reduce of per-topic fan-out; includes the partition and the exchange"}
 
 
 def host_visible(args, eng, w, batches, n, seed, rank):

@@ -1,7 +1,15 @@
 """Multi-GPU shape of the match path: tenants never interact, so the filter index is partitioned by
 tenant across the ranks of a node (one process per GPU) and every rank matches only the publishes of its own tenants.
-The single exchange step afterwards is an all-gather of each rank's CSR result over RCCL/xGMI
-(`torch.distributed`, backend "nccl" on GPUs, "gloo" in the CPU tests).
+The single exchange step afterwards goes over RCCL/xGMI (`torch.distributed`, backend "nccl" on GPUs -- which IS RCCL on
+ROCm --, "gloo" in the CPU tests), in one of two forms:
+  * exchange_fanout: per-topic fan-out counts (4 B per topic).  That is all the reference sends upstream: the dist worker
+    that matched delivers itself, BatchDistReply carries fan-out per topic (DW/DistWorkerCoProc.java:535-538) and dist-server
+    SUMS the fan-outs of the ranges a tenant spans (BatchDistServerCall.java:186-205);
+  * exchange_csr_v: the complete (topic -> route ids) CSR of every rank on every rank, as a true all-gatherv: counts first,
+    then one grouped broadcast per rank with its exact size (no padding to the largest rank).
+Hot tenants (Zipf) are split by FILTER: their route keys are spread over all ranks by hash(route key) mod N and their
+publishes go to every rank; the per-rank fan-outs add up (the reference's analogue: FanoutSplitHinter splits a hot range,
+DW/hinter/FanoutSplitHinter.java:49, and dist-server sums).
 
 The reference's analogue is range sharding of the tenant-prefixed key space across KV ranges
 (bifromq-dist-worker-spi SplitKey.java:34-57) with dist-server fanning a batch out per range
@@ -65,3 +73,107 @@ def merge_rows(parts: Sequence[np.ndarray], rows_all: np.ndarray, ids_all: np.nd
         for k, g in enumerate(idx):
             out[int(g)] = ids_all[r][rp[k]:rp[k + 1]].tolist()
     return out
+
+
+# ---- fan-out exchange, all-gatherv, hot-tenant split, device-side partition --------------------------------------------
+def key_rank(route_key: bytes, world: int) -> int:
+    """Owner of ONE route key of a split (hot) tenant: FNV-1a 64 of the key bytes mod N."""
+    return tenant_hash(route_key) % world
+
+
+def pick_hot_tenants(publish_share: Sequence[float], world: int, factor: float = 0.5) -> List[int]:
+    """Tenant indices whose share of the publishes exceeds `factor` of a rank's fair share (1 / world): these are split by filter.
+    (The reference decides from observed fan-out load: DW/hinter/FanoutSplitHinter.java:49.)"""
+    if world <= 1:
+        return []
+    return [i for i, s in enumerate(publish_share) if s > factor / world]
+
+
+def shard_keys(keys: Sequence[bytes], key_tenant: Sequence[int], tenant_names: Sequence, hot: Sequence[int], world: int, rank: int):
+    """Route keys rank `rank` indexes: every key of the tenants it owns + its hash share of the hot tenants' keys."""
+    hot = set(int(h) for h in hot)
+    owner = [tenant_rank(t, world) for t in tenant_names]
+    return [k for k, t in zip(keys, key_tenant) if (key_rank(k, world) if int(t) in hot else owner[int(t)]) == rank]
+
+
+def topic_targets(tenant_names: Sequence, hot: Sequence[int], world: int):
+    """owner[t] = rank that matches tenant t's publishes, or -1 = every rank (split tenant)."""
+    hot = set(int(h) for h in hot)
+    return np.array([-1 if i in hot else tenant_rank(t, world) for i, t in enumerate(tenant_names)], dtype=np.int64)
+
+
+def partition_batch(owner, topic_tenant, data, off, rank: int):
+    """This rank's part of a node-wide publish batch, computed where the batch lives (torch tensors on the GPU -- or on the CPU
+    in the tests): topics whose tenant this rank owns or whose tenant is split.  Plain tensor ops: one mask, one compaction of
+    the offsets, one gather of the bytes.
+    owner: int64 [n_tenants] (topic_targets); topic_tenant: int [n]; data: uint8 [bytes]; off: int [n + 1].
+    -> (sel [m] global topic indices, data' uint8 padded by 32 bytes, off' int32 [m + 1], topic_tenant' [m])"""
+    import torch
+
+    tt = topic_tenant.long()
+    o = owner[tt]
+    sel = torch.nonzero((o == rank) | (o < 0)).flatten()
+    off64 = off.long()
+    lens = (off64[1:] - off64[:-1])[sel]
+    new_off = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=off.device)
+    torch.cumsum(lens, 0, out=new_off[1:])
+    total = int(new_off[-1].item()) if sel.numel() else 0
+    src = torch.repeat_interleave(off64[sel] - new_off[:-1], lens) + torch.arange(total, device=off.device)
+    new_data = torch.zeros(total + 32, dtype=torch.uint8, device=data.device)
+    if total:
+        new_data[:total] = data[src]
+    return sel, new_data, new_off.to(torch.int32), topic_tenant[sel].contiguous()
+
+
+def exchange_fanout(dist, counts_local, sel, n_global: int):
+    """Node-wide per-topic fan-out: every rank adds the fan-outs of the topics it matched into a vector over the whole batch
+    (one all-reduce SUM of 4 B per topic -- split tenants are matched by every rank against its share of the filters, so their
+    counts add up, exactly what dist-server does with per-range fan-outs).  counts_local: int32 [m]; sel: [m] global indices."""
+    import torch
+
+    v = torch.zeros(n_global, dtype=torch.int32, device=counts_local.device)
+    if sel.numel():
+        v[sel] = counts_local.to(torch.int32)
+    if dist is not None:
+        dist.all_reduce(v)
+    return v
+
+
+def exchange_counts_weak(dist, row_ptr, world: int):
+    """Every rank matched its OWN batch of n topics (weak scaling): all-gather of the n fan-out counts of every rank ->
+    [world, n].  No host synchronisation, no padding: every rank contributes exactly n values."""
+    import torch
+
+    counts = (row_ptr[1:] - row_ptr[:-1]).contiguous()
+    out = torch.empty(world * counts.numel(), dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(out, counts)
+    return out.view(world, -1)
+
+
+def exchange_csr_v(dist, row_ptr, ids, total: int, world: int):
+    """True all-gatherv of every rank's CSR: totals (one small all-gather + one host read), row pointers (fixed size), then the
+    ids with their EXACT sizes -- torch.distributed.all_gather with unequal output tensors, which the NCCL/RCCL backend runs
+    as one group of per-rank broadcasts.  gloo (CPU tests) cannot take unequal sizes: padded there.
+    -> (rows_all [world, n + 1], list of world id tensors, totals list)"""
+    import torch
+
+    dev = row_ptr.device
+    cnt = torch.tensor([total], dtype=torch.int64, device=dev)
+    cnts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnts, cnt)
+    totals = [int(x) for x in cnts.cpu().tolist()]
+    rows_all = torch.empty(world * row_ptr.numel(), dtype=row_ptr.dtype, device=dev)
+    dist.all_gather_into_tensor(rows_all, row_ptr.contiguous())
+    mine = ids[:total].contiguous()
+    if dist.get_backend() == "nccl":
+        outs = [torch.empty(max(t, 0), dtype=ids.dtype, device=dev) for t in totals]
+        dist.all_gather(outs, mine)
+    else:
+        mx = max(max(totals), 1)
+        pad = torch.zeros(mx, dtype=ids.dtype, device=dev)
+        pad[:total] = mine
+        flat = torch.empty(world * mx, dtype=ids.dtype, device=dev)
+        dist.all_gather_into_tensor(flat, pad)
+        outs = [flat[r * mx:r * mx + totals[r]] for r in range(world)]
+    return rows_all.view(world, -1), outs, totals
+

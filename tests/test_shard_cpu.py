@@ -93,3 +93,73 @@ def test_tenant_hash_is_stable_and_spreads():
     assert counts.min() > 800 and counts.max() < 1200
     parts = shard.route_batch(["a", "b", "c"], np.array([0, 1, 2, 0, 0, 2]), 2)
     assert sorted(np.concatenate(parts).tolist()) == [0, 1, 2, 3, 4, 5]
+
+
+def _worker_split(rank, world, port, q):
+    """Node-wide batch, hot tenant split by filter: partition on the 'device' (torch tensors), per-rank match (oracle stands in),
+    fan-out all-reduce; plus the all-gatherv of the CSR."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = B.Workload(0xB1F20003, 6, 400, 1)
+        tn = w.tenants()
+        keys = w.keys()
+        key_tenant = np.searchsorted(w.tenant_first(), np.arange(len(keys)), side="right") - 1
+        data, off, tt = w.topics(11, 800)
+        share = np.bincount(tt, minlength=len(tn)) / len(tt)
+        hot = shard.pick_hot_tenants(share, world, 0.5)
+        assert hot, "the Zipf head must qualify as hot in this workload"
+        my_keys = shard.shard_keys(keys, key_tenant, tn, hot, world, rank)
+        kv = O.KV(my_keys)
+        owner = torch.from_numpy(shard.topic_targets(tn, hot, world))
+        sel, d2, o2, tt2 = shard.partition_batch(owner, torch.from_numpy(tt.astype(np.int64)), torch.from_numpy(data),
+                                                 torch.from_numpy(off.astype(np.int64)), rank)
+        raw = d2.numpy().tobytes()
+        o2n = o2.numpy()
+        my_topics = [raw[o2n[i]:o2n[i + 1]] for i in range(len(sel))]
+        all_topics = unpack(data, off)
+        assert my_topics == [all_topics[int(g)] for g in sel]
+        rows = [sorted(kv.match_all(tn[int(t)], [tp]).per_topic()[0]) for t, tp in zip(tt2.numpy(), my_topics)]
+        counts = torch.tensor([len(r) for r in rows], dtype=torch.int32)
+        fan = shard.exchange_fanout(dist, counts, sel, len(tt))
+        row_ptr = np.zeros(len(rows) + 1, dtype=np.int32)
+        row_ptr[1:] = np.cumsum([len(r) for r in rows])
+        # all-gatherv needs equal-sized row pointer vectors: pad to the largest part
+        n_max = torch.tensor([len(rows)], dtype=torch.int64)
+        dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+        rp = np.full(int(n_max) + 1, row_ptr[-1], dtype=np.int32)
+        rp[:len(row_ptr)] = row_ptr
+        ids = np.array([x for r in rows for x in r] or [0], dtype=np.int32)
+        rows_all, ids_list, totals = shard.exchange_csr_v(dist, torch.from_numpy(rp), torch.from_numpy(ids), int(row_ptr[-1]), world)
+        q.put((rank, hot, fan.tolist(), totals, [t.tolist() for t in ids_list], sel.tolist(), len(my_keys)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_hot_tenant_split_and_fanout_exchange():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_split, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    w = B.Workload(0xB1F20003, 6, 400, 1)
+    keys = w.keys()
+    kv = O.KV(keys)
+    data, off, tt = w.topics(11, 800)
+    tn = w.tenants()
+    topics = unpack(data, off)
+    exp = [len(kv.match_all(tn[tt[i]], [topics[i]]).per_topic()[0]) for i in range(len(topics))]
+    assert got[0][2] == exp and got[1][2] == exp             # the summed fan-out equals the unsharded oracle on every rank
+    assert got[0][6] + got[1][6] == len(keys)                 # the shards partition the route keys (hot tenant split by key hash)
+    hot = set(got[0][1])
+    both = set(got[0][5]) & set(got[1][5])
+    assert both == {i for i in range(len(tt)) if int(tt[i]) in hot}   # split tenants' publishes go to every rank, the rest to one
+    assert got[0][3] == got[1][3] and got[0][4] == got[1][4]  # all-gatherv: every rank holds every rank's ids, exact sizes
+    assert [len(x) for x in got[0][4]] == got[0][3] and sum(got[0][3]) == sum(exp)
+
