@@ -26,6 +26,7 @@
 #include "bmq_dist_kernels.h"
 #include "bmq_exec_dev.h"
 #include "bmq_exec_host.h"
+#include "bmq_range_core.h"
 #include "bmq_retain.h"
 #include "bmq_retain_kernels.h"
 
@@ -133,6 +134,7 @@ struct bmq_engine {
     uint64_t repoch = 0; // +1 per retain rebuild / apply: topic ids are ranks and shift with every mutation
     RetainLimit rlim;
     DevBuf r_scratch;
+    DevBuf range_buf; // staging of bmq_range_lookup
     uint32_t rgcap = 0;
 };
 
@@ -943,3 +945,4 @@ int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len) { return java_st
 
 #include "bmq_retain_engine.inc"
 #include "bmq_batcher.inc"
+#include "bmq_range_engine.inc"

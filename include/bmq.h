@@ -221,6 +221,19 @@ int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, con
                   int32_t max_group_fanout, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
                   uint64_t* out_needed, int32_t* out_events, uint32_t events_cap, uint32_t* out_n_events);
 
+/* ---- dist-server side range pruning ---------------------------------------------------------------------- */
+/* TenantRangeLookupCache.lookup (bifromq-dist/bifromq-dist-server/src/main/java/org/apache/bifromq/dist/server/scheduler/
+ * TenantRangeLookupCache.java:62-109) for a batch of topics of ONE tenant against the tenant's candidate KV ranges in boundary
+ * order: which ranges can hold a route whose filter matches the topic, judged -- exactly as the reference does -- from each
+ * range's Fact{firstGlobalFilterLevels, lastGlobalFilterLevels} (Fact.proto:27-34) alone.
+ *   cand_kind[c]: 0 = the range has no Fact (always kept), 1 = Fact without first/last (empty range: dropped), 2 = first/last given
+ *   first / last : packed strings, entry c = the global filter levels (tenant id first) joined by NUL
+ *   out_keep[t * n_cand + c] = 1 if candidate c is kept for topic t, else 0 (a candidate behind the point where the reference's
+ *   loop stops -- no expansion filter at or after its first filter -- is dropped, as there). */
+int bmq_range_lookup(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics, const uint32_t* topic_off,
+                     uint32_t n_topics, const uint8_t* cand_kind, const uint8_t* first, const uint32_t* first_off, const uint8_t* last,
+                     const uint32_t* last_off, uint32_t n_cand, uint8_t* out_keep);
+
 /* ---- route-key codec (SCHEMA/KVSchemaUtil.java:91-130, SCHEMA/cache/RouteDetailCache.java:53-117) ------- */
 /* flag: 1 normal (receiver = receiverUrl), 2 unordered share, 3 ordered share (receiver = group name).
  * filter = MQTT topic filter WITHOUT a $share/$oshare prefix.  Returns key length (writes if <= cap). */

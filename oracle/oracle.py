@@ -445,3 +445,28 @@ def retain_store_match(lt: "LevelTrie", tenant, topic_filter, limit: int, now: i
             out.append(i)
     return out
 
+
+def range_lookup(tenant: str, topic: str, candidates) -> List[int]:
+    """TenantRangeLookupCache.lookup(CacheKey) (bifromq-dist-server .../scheduler/TenantRangeLookupCache.java:69-106) for one
+    topic: candidates in boundary order, each None (no Fact: kept), () (Fact without first/last: an empty range, dropped) or
+    (first_levels, last_levels) -- GLOBAL filter levels, tenant id first (Fact.proto:27-34).  Walks the structural restatement of
+    the expansion iterator over the one-topic global trie.  -> indices of the candidates kept."""
+    trie = TopicTrie(True).add_topic(tenant + "/" + topic, 0)
+    itr = TopicFilterIterator(trie)
+    out = []
+    for idx, cand in enumerate(candidates):
+        if cand is None:
+            out.append(idx)
+            continue
+        if len(cand) == 0:
+            continue
+        first, last = cand
+        itr.seek("/".join(first))
+        if itr.is_valid():
+            key = itr.key().split("/")
+            if key == list(first) or "\0".join(key) <= "\0".join(last):
+                out.append(idx)
+        else:
+            break
+    return out
+

@@ -40,7 +40,11 @@ if rows:
     if fk is not None and wk is not None:
         traffic = fk * 1024 * 0.992 + wk * 1024
         with open(os.path.join("profiles", "traffic_%s.json" % R), "w") as f:
-            json.dump({"c3": traffic, "_note": "HBM bytes per k_walk launch = FETCH_SIZE*1024*0.992 (calibrated on random 64-byte line "
+            import hashlib
+            hs = hashlib.sha256()
+            for fn in ("bmq_layout.h", "bmq_dist_kernels.h", "bmq_retain_kernels.h"):
+                hs.update(open(os.path.join("bifromq_amd", "csrc", fn), "rb").read())
+            json.dump({"c3": traffic, "kernel_sources_sha": hs.hexdigest()[:16], "_note": "HBM bytes per k_walk launch = FETCH_SIZE*1024*0.992 (calibrated on random 64-byte line "
                        "fetches, tools/ubench_lines.hip) + WRITE_SIZE*1024 (uncalibrated); profiles/%s/c3_pmc_hbm.csv" % R}, f)
         print("k_walk traffic per launch: %.1f MB" % (traffic / 1e6))
 ex = os.path.join(src, "extras")
