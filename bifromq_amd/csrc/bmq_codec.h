@@ -19,4 +19,22 @@ std::string encode_route_key(std::string_view tenant, std::string_view mqtt_filt
                              std::string_view receiver);
 int32_t java_string_hash(std::string_view utf8);
 
+// ---- retain store key schema: bifromq-retain/bifromq-retain-store-schema/src/main/java/org/apache/bifromq/retain/
+// store/schema/KVSchemaUtil.java:44-73, LevelHash.java:30-50 ----
+// one byte per level: FNV-1a 32 over the level's UTF-16 code units, lowest byte
+uint8_t retain_level_hash_byte(std::string_view level_utf8);
+// retainMessageKey(tenantId, topic) = 0x00 | u16be(len tenant) | tenant | u16be(#levels) | LevelHash(levels) | escape(topic)
+std::string retain_message_key(std::string_view tenant, std::string_view topic);
+// retainKeyPrefix(tenantId, levels, filterPrefix(parse(filter))): `levels` = level count of the filter (without a trailing '#');
+// the prefix = the levels in front of the first wildcard.  Returned with the pieces MatchCallRangeRouter needs
+// (bifromq-retain-server/.../scheduler/MatchCallRangeRouter.java:60-134).
+struct RetainFilterRoute {
+    std::string key_prefix;  // retainKeyPrefix(...), or retainMessageKey for a filter without wildcards
+    std::string level_hash;  // LevelHash.hash(filterPrefix)
+    uint16_t levels = 0;
+    bool wildcard = false;    // the filter contains '+' or '#'
+    bool multi = false;       // ... ends with '#': matches any number of further levels
+};
+RetainFilterRoute retain_filter_route(std::string_view tenant, std::string_view topic_filter);
+
 } // namespace bmq

@@ -939,6 +939,26 @@ int bmq_route_key_decode(const uint8_t* key, uint32_t key_len, uint32_t spans[6]
     return kp.flag;
 }
 
+// ---- retain store key schema ---------------------------------------------------------------------------------
+uint32_t bmq_retain_message_key(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, uint8_t* out, uint32_t cap) {
+    const std::string k = retain_message_key(std::string_view((const char*)tenant, tenant_len), std::string_view((const char*)topic, topic_len));
+    if (out && k.size() <= cap) memcpy(out, k.data(), k.size());
+    return (uint32_t)k.size();
+}
+int bmq_retain_filter_route(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len, uint8_t* out_key_prefix,
+                            uint32_t cap, uint32_t* out_key_len, uint8_t* out_level_hash, uint32_t hash_cap, uint32_t* out_hash_len,
+                            uint32_t* out_levels) {
+    if (!out_key_len || !out_hash_len || !out_levels) return BMQ_E_INVAL;
+    const RetainFilterRoute r = retain_filter_route(std::string_view((const char*)tenant, tenant_len), std::string_view((const char*)filter, filter_len));
+    *out_key_len = (uint32_t)r.key_prefix.size();
+    *out_hash_len = (uint32_t)r.level_hash.size();
+    *out_levels = r.levels;
+    if (r.key_prefix.size() > cap || r.level_hash.size() > hash_cap) return BMQ_E_NOSPACE;
+    if (out_key_prefix && !r.key_prefix.empty()) memcpy(out_key_prefix, r.key_prefix.data(), r.key_prefix.size());
+    if (out_level_hash && !r.level_hash.empty()) memcpy(out_level_hash, r.level_hash.data(), r.level_hash.size());
+    return (r.wildcard ? 1 : 0) | (r.multi ? 2 : 0);
+}
+
 int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len) { return java_string_hash(std::string_view((const char*)utf8, len)); }
 
 } // extern "C"

@@ -86,6 +86,25 @@ def decode_route_key(key: bytes):
     return flag, tenant, filt, recv
 
 
+def retain_message_key(tenant, topic) -> bytes:
+    """KVSchemaUtil.retainMessageKey of the retain store schema"""
+    t, p = _b(tenant), _b(topic)
+    out = C.create_string_buffer(len(t) + 2 * len(p) + 16)
+    n = _lib.lib().bmq_retain_message_key(t, len(t), p, len(p), out, len(out))
+    return out.raw[:n]
+
+
+def retain_filter_route(tenant, topic_filter):
+    """-> (key or key prefix, LevelHash(filterPrefix), levels, has_wildcard, ends_with_hash): MatchCallRangeRouter's per-filter part"""
+    t, f = _b(tenant), _b(topic_filter)
+    out, hsh = C.create_string_buffer(len(t) + 2 * len(f) + 16), C.create_string_buffer(len(f) + 2)
+    kl, hl, lv = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = _lib.lib().bmq_retain_filter_route(t, len(t), f, len(f), out, len(out), C.byref(kl), hsh, len(hsh), C.byref(hl), C.byref(lv))
+    if rc < 0:
+        raise BmqError(rc, "bmq_retain_filter_route")
+    return out.raw[:kl.value], hsh.raw[:hl.value], lv.value, bool(rc & 1), bool(rc & 2)
+
+
 def java_string_hash(s) -> int:
     b = _b(s)
     return _lib.lib().bmq_java_string_hash(b, len(b))

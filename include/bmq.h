@@ -245,6 +245,21 @@ uint32_t bmq_route_key_encode(const uint8_t* tenant, uint32_t tenant_len, const 
 int bmq_route_key_decode(const uint8_t* key, uint32_t key_len, uint32_t spans[6]);
 int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len);
 
+/* ---- retain store key schema (bifromq-retain/bifromq-retain-store-schema/.../schema/KVSchemaUtil.java:44-73,
+ * LevelHash.java:30-50) ---------------------------------------------------------------------------------------------------------- */
+/* retainMessageKey(tenantId, topic) = 0x00 | u16be(len tenant) | tenant | u16be(#levels) | LevelHash(levels) | escape(topic);
+ * LevelHash = one byte per level (FNV-1a 32 over the level's UTF-16 code units, lowest byte).  Returns the key length. */
+uint32_t bmq_retain_message_key(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, uint8_t* out,
+                                uint32_t cap);
+/* What MatchCallRangeRouter.rangeLookup derives from ONE topic filter before it consults the range router
+ * (bifromq-retain-server/.../scheduler/MatchCallRangeRouter.java:60-134): for a filter without wildcards the exact
+ * retainMessageKey; otherwise retainKeyPrefix(tenant, levels, filterPrefix) with levels = level count (a trailing '#' not counted)
+ * and filterPrefix = the levels in front of the first wildcard, plus LevelHash(filterPrefix) (the pruning key of findCandidates).
+ * Returns a bit mask: 1 = the filter has a wildcard, 2 = it ends with '#' (matches keys of MORE levels too); negative on error. */
+int bmq_retain_filter_route(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len,
+                            uint8_t* out_key_prefix, uint32_t cap, uint32_t* out_key_len, uint8_t* out_level_hash, uint32_t hash_cap,
+                            uint32_t* out_hash_len, uint32_t* out_levels);
+
 /* ---- retain direction (RS/index/IRetainTopicIndex.java:27-35) -------------------------------------------- */
 /* Load the retained-topic index: (tenant, topic) pairs; topic id = rank of (tenant, levels) in byte order (tenants in byte order
  * of their ids, a tenant's topics level list by level list).  Ids are RANKS: every bmq_retain_rebuild* / bmq_retain_apply* shifts

@@ -470,3 +470,43 @@ def range_lookup(tenant: str, topic: str, candidates) -> List[int]:
             break
     return out
 
+
+# ---- retain store key schema (bifromq-retain-store-schema KVSchemaUtil.java:44-73, LevelHash.java:30-50) ---------------------
+def retain_level_hash(levels) -> bytes:
+    """LevelHash.hash: per level FNV-1a 32 over the UTF-16 code units (Java chars), lowest byte"""
+    out = bytearray()
+    for lv in levels:
+        h = 0x811C9DC5
+        u16 = lv.encode("utf-16-le")
+        for i in range(0, len(u16), 2):
+            h ^= u16[i] | (u16[i + 1] << 8)
+            h = (h * 0x01000193) & 0xFFFFFFFF
+        out.append(h & 0xFF)
+    return bytes(out)
+
+
+def retain_tenant_begin_key(tenant: str) -> bytes:
+    t = tenant.encode()
+    return b"\x00" + len(t).to_bytes(2, "big") + t
+
+
+def retain_message_key(tenant: str, topic: str) -> bytes:
+    levels = topic.split("/")
+    return retain_tenant_begin_key(tenant) + len(levels).to_bytes(2, "big") + retain_level_hash(levels) + topic.replace("/", "\0").encode()
+
+
+def retain_filter_prefix(levels):
+    """KVSchemaUtil.filterPrefix"""
+    if "+" in levels:
+        return levels[:levels.index("+")]
+    if levels[-1] == "#":
+        return levels[:-1]
+    return levels
+
+
+def retain_key_prefix_of_filter(tenant: str, topic_filter: str) -> bytes:
+    """KVSchemaUtilTest.toRetainMessageKeyPrefix: retainKeyPrefix(tenant, levels, filterPrefix(parse(filter)))"""
+    levels = topic_filter.split("/")
+    n = len(levels) - 1 if levels[-1] == "#" else len(levels)
+    return retain_tenant_begin_key(tenant) + n.to_bytes(2, "big") + retain_level_hash(retain_filter_prefix(levels))
+

@@ -240,3 +240,37 @@ def test_churn_case_helper_on_host_only_engine():
     n = U.churn_case(eng, oracle_match, n_tenants=12, per_tenant=400, n_ops=1200, n_topics=1500, sample_tenants=5, n_sample=300)
     assert state["rows"] == 1500 and n == eng.info().n_routes
     eng.close()
+
+
+def test_retain_key_schema_vectors_and_parity():
+    """the retain store's key schema.  Golden: KVSchemaUtilTest.java:45-79 (retainKeyPrefix of 13 filters, written
+    there in terms of tenantBeginKey / level count / LevelHash) and LevelHashTest.java:30-40 (sizes); parity: the product codec
+    against the oracle's independent restatement on random topics / filters incl. non-BMP characters."""
+    from bifromq_amd.engine import retain_filter_route, retain_message_key
+    ns = O.retain_tenant_begin_key("tenantA")
+    lb = lambda v: v.to_bytes(2, "big")
+    H = O.retain_level_hash
+    table = {"#": ns + lb(0), "/#": ns + lb(1) + H([""]), "+": ns + lb(1), "+/#": ns + lb(1), "a/#": ns + lb(1) + H(["a"]),
+             "/a": ns + lb(2) + H(["", "a"]), "a/+": ns + lb(2) + H(["a"]), "a/b": ns + lb(2) + H(["a", "b"]), "/a/#": ns + lb(2) + H(["", "a"]),
+             "/a/+": ns + lb(3) + H(["", "a"]), "/a/+/+": ns + lb(4) + H(["", "a"]), "/+/b/": ns + lb(4) + H([""]), "/+/b/+/": ns + lb(5) + H([""])}
+    for f, exp in table.items():
+        assert O.retain_key_prefix_of_filter("tenantA", f) == exp, f  # the oracle reproduces the reference's own table
+        key, lh, levels, wild, multi = retain_filter_route("tenantA", f)
+        if wild:
+            assert key == exp and lh == H(O.retain_filter_prefix(f.split("/"))), f
+        else:
+            assert key == O.retain_message_key("tenantA", f) and key.startswith(exp), f
+        assert multi == f.endswith("#") and levels == len(f.split("/")) - (1 if multi else 0)
+    assert len(H([])) == 0 and len(H([""])) == 1 and len(H(["a", "b", "c"])) == 3  # LevelHashTest
+    rnd = random.Random(5)
+    alpha = ["a", "b", "", "$sys", "你好", "😄", "x" * 30, "0", " "]
+    for _ in range(500):
+        tenant = rnd.choice(["t", "tenantA", "租户"])
+        topic = "/".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 6)))
+        assert retain_message_key(tenant, topic) == O.retain_message_key(tenant, topic)
+        f = U.rand_filter(rnd, 6, alpha)
+        key, lh, levels, wild, multi = retain_filter_route(tenant, f)
+        if wild:
+            assert key == O.retain_key_prefix_of_filter(tenant, f) and lh == H(O.retain_filter_prefix(f.split("/")))
+        else:
+            assert key == O.retain_message_key(tenant, f)
