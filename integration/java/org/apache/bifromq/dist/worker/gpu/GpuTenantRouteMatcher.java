@@ -2,9 +2,11 @@
  * Drop-in for org.apache.bifromq.dist.worker.cache.TenantRouteMatcher behind ITenantRouteMatcher
  * (bifromq-dist-worker/.../cache/ITenantRouteMatcher.java:37; created per (range, tenant) by
  * TenantRouteCacheFactory.create, TenantRouteCacheFactory.java:67-71).
- * NOT compiled in this repository (no JDK in its build image): a sketch complete enough to show every interaction with
- * the native side.  MatchedRoutes stays the reference's own class, fed in ascending route-id (= KV key) order, so the
- * fan-out caps and throttle events behave exactly as today (MatchedRoutes.java:87-141).
+ * NOT compiled in this repository (no JDK in its build image): complete enough to show every interaction with the native side.
+ * MatchedRoutes stays the reference's own class and is fed in KV KEY order, so the fan-out caps and throttle events behave
+ * exactly as today (MatchedRoutes.java:87-141).  Route ids are STABLE handles (include/bmq.h): ranks after a rebuild, later
+ * ids for routes subscribed since; an id resolves to the same key until the next rebuild ("generation"), a deleted route's id
+ * resolves to an empty key -- so the id -> Matching cache is never wrong, whatever the apply thread is doing meanwhile.
  */
 package org.apache.bifromq.dist.worker.gpu;
 
@@ -12,6 +14,9 @@ import com.google.protobuf.ByteString;
 import java.nio.ByteBuffer;
 import java.nio.ByteOrder;
 import java.nio.IntBuffer;
+import java.nio.LongBuffer;
+import java.util.ArrayList;
+import java.util.List;
 import java.nio.charset.StandardCharsets;
 import java.util.HashMap;
 import java.util.Map;
@@ -32,9 +37,12 @@ final class GpuTenantRouteMatcher implements ITenantRouteMatcher {
     static final class RangeIndex implements AutoCloseable {
         final long engine;
         final long batcher;
-        // route id -> Matching, valid for one epoch (bmq_rebuild / bmq_routes_apply bump it)
-        private volatile long cachedEpoch = -1;
-        private volatile ConcurrentHashMap<Integer, Matching> matchings = new ConcurrentHashMap<>();
+        /** (route key, Matching) per route id of ONE generation; dropped as a whole when bmq_rebuild re-numbers the routes. */
+        private record Entry(ByteString key, Matching matching) {
+        }
+
+        private volatile long cachedGeneration = -1;
+        private volatile ConcurrentHashMap<Integer, Entry> entries = new ConcurrentHashMap<>();
         private final Function<ByteString, ByteString> valueOfKey; // reader.get(routeKey): incarnation / RouteGroup
 
         RangeIndex(int device, Function<ByteString, ByteString> valueOfKey) {
@@ -43,26 +51,70 @@ final class GpuTenantRouteMatcher implements ITenantRouteMatcher {
             this.valueOfKey = valueOfKey;
         }
 
-        Matching matchingOf(int routeId, long epoch) {
-            if (epoch != cachedEpoch) {
+        /** DistWorkerCoProc.reset (DW/DistWorkerCoProc.java:283-291): the keys of reader.iterator(), packed. */
+        void reset(ByteBuffer keys, IntBuffer keyOff, int n) {
+            NativeMatcher.rebuild(engine, keys, keyOff, n); // a new generation: every cached id is void
+        }
+
+        /** Post-commit closure of DistWorkerCoProc.mutate (:188-209): added / removed route keys, in commit order. */
+        void refresh(ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n) {
+            NativeMatcher.routesApply(engine, keys, keyOff, ops, n);
+            // a re-subscribe keeps its id but may carry a new incarnation: forget the cached Matching of the keys just put
+            // (the cache is keyed by id; resolving the few put keys again is cheaper than tracking them here)
+            entries.values().removeIf(e -> e.matching() == null);
+        }
+
+        /** ids -> (key, Matching), resolving the unknown ones with ONE native gather. */
+        List<Entry> resolve(IntBuffer ids, int from, int to) {
+            long gen = NativeMatcher.generation(engine);
+            if (gen != cachedGeneration) {
                 synchronized (this) {
-                    if (epoch != cachedEpoch) {
-                        matchings = new ConcurrentHashMap<>();
-                        cachedEpoch = epoch;
+                    if (gen != cachedGeneration) {
+                        entries = new ConcurrentHashMap<>();
+                        cachedGeneration = gen;
                     }
                 }
             }
-            return matchings.computeIfAbsent(routeId, id -> {
-                ByteBuffer out = ByteBuffer.allocateDirect(512);
-                int len = NativeMatcher.routeKey(engine, id, out);
-                if (len < 0) {
-                    out = ByteBuffer.allocateDirect(-len);
-                    len = NativeMatcher.routeKey(engine, id, out);
+            ConcurrentHashMap<Integer, Entry> map = entries;
+            int missing = 0;
+            for (int k = from; k < to; k++) {
+                if (!map.containsKey(ids.get(k))) {
+                    missing++;
                 }
-                out.limit(len);
-                ByteString key = ByteString.copyFrom(out);
-                return KVSchemaUtil.buildMatchRoute(key, valueOfKey.apply(key)); // KVSchemaUtil.java:73-89
-            });
+            }
+            if (missing > 0) {
+                IntBuffer want = ByteBuffer.allocateDirect(4 * missing).order(ByteOrder.nativeOrder()).asIntBuffer();
+                for (int k = from; k < to; k++) {
+                    if (!map.containsKey(ids.get(k))) {
+                        want.put(ids.get(k));
+                    }
+                }
+                LongBuffer off = ByteBuffer.allocateDirect(8 * (missing + 1)).order(ByteOrder.nativeOrder()).asLongBuffer();
+                ByteBuffer bytes = ByteBuffer.allocateDirect(128 * missing);
+                long got = NativeMatcher.routeKeys(engine, want, missing, bytes, off);
+                if (got < 0) {
+                    bytes = ByteBuffer.allocateDirect((int) -got);
+                    got = NativeMatcher.routeKeys(engine, want, missing, bytes, off);
+                }
+                for (int j = 0; j < missing; j++) {
+                    int len = (int) (off.get(j + 1) - off.get(j));
+                    if (len == 0) {
+                        continue; // unsubscribed between the match and now: the route is gone, as a later matchAll would say
+                    }
+                    ByteBuffer slice = bytes.duplicate();
+                    slice.position((int) off.get(j)).limit((int) off.get(j + 1));
+                    ByteString key = ByteString.copyFrom(slice);
+                    map.put(want.get(j), new Entry(key, KVSchemaUtil.buildMatchRoute(key, valueOfKey.apply(key)))); // KVSchemaUtil.java:73-89
+                }
+            }
+            List<Entry> out = new ArrayList<>(to - from);
+            for (int k = from; k < to; k++) {
+                Entry e = map.get(ids.get(k));
+                if (e != null) {
+                    out.add(e);
+                }
+            }
+            return out;
         }
 
         @Override
@@ -107,7 +159,7 @@ final class GpuTenantRouteMatcher implements ITenantRouteMatcher {
         // the calling matchExecutor thread parks here until the GPU launch that carries these topics is done; the calls of all
         // threads waiting at this moment share that launch (bmq_batcher_match_all)
         long got = NativeMatcher.batcherMatchAll(index.batcher, tenantBytes, bytes, off, n, rowPtr, ids, epoch);
-        if (got < 0) { // ids too small: grow and ask again
+        while (got < 0) { // ids too small: -got ints are needed (IntBuffer capacities are in ints)
             ids = ByteBuffer.allocateDirect((int) (4 * -got)).order(ByteOrder.nativeOrder()).asIntBuffer();
             got = NativeMatcher.batcherMatchAll(index.batcher, tenantBytes, bytes, off, n, rowPtr, ids, epoch);
         }
@@ -115,8 +167,22 @@ final class GpuTenantRouteMatcher implements ITenantRouteMatcher {
         i = 0;
         for (String topic : topics) { // every input topic is a key, also with 0 routes (TenantRouteMatcherTest.java:90-110)
             MatchedRoutes mr = new MatchedRoutes(tenantId, topic, eventCollector, maxPersistentFanoutCount, maxGroupFanoutCount);
-            for (int k = rowPtr.get(i); k < rowPtr.get(i + 1); k++) { // ascending id == KV key order
-                Matching m = index.matchingOf(ids.get(k), epoch[0]);
+            List<RangeIndex.Entry> row = index.resolve(ids, rowPtr.get(i), rowPtr.get(i + 1));
+            // MatchedRoutes caps first-come in KV key order.  Ids are key ranks only for routes loaded by the last rebuild, so when a
+            // cap can bind the row is ordered by key bytes first (ByteString's unsigned lexicographical order == KV order).
+            int persistent = 0, groups = 0;
+            for (RangeIndex.Entry e : row) {
+                if (e.matching().type() == Matching.Type.Group) {
+                    groups++;
+                } else if (((NormalMatching) e.matching()).subBrokerId() == 1) {
+                    persistent++;
+                }
+            }
+            if (persistent > maxPersistentFanoutCount || groups > maxGroupFanoutCount) {
+                row.sort((a, b) -> ByteString.unsignedLexicographicalComparator().compare(a.key(), b.key()));
+            }
+            for (RangeIndex.Entry e : row) {
+                Matching m = e.matching();
                 switch (m.type()) {
                     case Normal -> mr.addNormalMatching((NormalMatching) m);
                     case Group -> mr.putGroupMatching((GroupMatching) m);

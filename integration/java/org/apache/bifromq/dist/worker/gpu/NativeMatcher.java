@@ -7,6 +7,7 @@ package org.apache.bifromq.dist.worker.gpu;
 
 import java.nio.ByteBuffer;
 import java.nio.IntBuffer;
+import java.nio.LongBuffer;
 
 final class NativeMatcher {
     static {
@@ -21,13 +22,31 @@ final class NativeMatcher {
 
     static native void destroy(long engine);
 
-    /** IKVRangeCoProc.reset(): all route keys of the range, in any order (ids become the ranks in KV key order). */
+    /** IKVRangeCoProc.reset(): all route keys of the range (a KV scan: ascending; route id = rank).  Built on the GPU. */
     static native void rebuild(long engine, ByteBuffer keys, IntBuffer keyOff, int n);
 
     /** Post-commit AddRoutesTask / RemoveRoutesTask: ops[i] 0 = put, 1 = delete; applied in order. */
     static native void routesApply(long engine, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n);
 
     static native long epoch(long engine);
+
+    /** +1 per rebuild: route ids are stable handles within a generation (a deleted route's id resolves to an empty key). */
+    static native long generation(long engine);
+
+    /** One device gather: outOff[n + 1] byte offsets into out.  @return bytes, or -(needed) */
+    static native long routeKeys(long engine, IntBuffer ids, int n, ByteBuffer out, LongBuffer outOff);
+
+    /** Page-locked direct buffer (bmq_host_alloc): hand these to matchSubmit / routesApply for full PCIe speed. */
+    static native ByteBuffer hostAlloc(long bytes);
+
+    static native void hostFree(ByteBuffer buf);
+
+    /** Two batches in flight: upload of batch i+1 and download of batch i-1 overlap the kernels of batch i. @return ticket */
+    static native int matchSubmit(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant,
+                                  ByteBuffer topics, IntBuffer topicOff, int nTopics);
+
+    /** @return number of ids, or -(needed) when outIds is too small (the ticket is consumed either way: re-submit) */
+    static native long matchWait(long engine, int ticket, IntBuffer outRowPtr, IntBuffer outIds);
 
     /** @return key length, or -(needed) when out is too small */
     static native int routeKey(long engine, int routeId, ByteBuffer out);
@@ -46,7 +65,7 @@ final class NativeMatcher {
 
     static native void batcherDestroy(long batcher);
 
-    /** Blocks until the launch that carries these topics has finished; epochOut[0] = epoch the ids are ranks of. */
+    /** Blocks until the launch that carries these topics has finished; epochOut[0] = epoch of the index the batch saw. */
     static native long batcherMatchAll(long batcher, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, int nTopics,
                                        IntBuffer outRowPtr, IntBuffer outIds, long[] epochOut);
 
@@ -55,6 +74,16 @@ final class NativeMatcher {
                                      ByteBuffer topics, IntBuffer topicOff, int nTopics);
 
     static native void retainApply(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, ByteBuffer ops, int n);
+
+    /** IRetainTopicIndex.add(tenantId, topic, timestamp, expirySeconds) / remove: ops[i] 0 = add, 1 = remove. */
+    static native void retainApplyEx(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, ByteBuffer ops,
+                                     LongBuffer timestampHlc, IntBuffer expirySeconds, int n);
+
+    /** out = {timestampHlc, expirySeconds, expireAtMs} */
+    static native void retainTopicInfo(long engine, int topicId, long[] out);
+
+    /** out = {number of topics (the ids are 0 .. n-1), retain epoch} */
+    static native void retainFindAll(long engine, long[] out);
 
     static native long retainMatchLimited(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants,
                                           IntBuffer filterTenant, ByteBuffer filters, IntBuffer filterOff, int nFilters,

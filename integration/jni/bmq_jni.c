@@ -81,6 +81,55 @@ JNIEXPORT jlong JNICALL NM(epoch)(JNIEnv* env, jclass c, jlong h) {
     }
     return (jlong)info.epoch;
 }
+/* long generation(long engine)     ids of different generations are unrelated (every rebuild re-numbers) */
+JNIEXPORT jlong JNICALL NM(generation)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    bmq_index_info info;
+    const int rc = bmq_index_info_get(ENGINE(h), &info);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_index_info_get", rc);
+        return 0;
+    }
+    return (jlong)info.generation;
+}
+/* long routeKeys(long engine, IntBuffer ids, int n, ByteBuffer out, LongBuffer outOff)   one device gather for many ids;
+ * outOff[n + 1] byte offsets into out, a dead id (unsubscribed meanwhile) gives an empty key; -> bytes, or -(needed) */
+JNIEXPORT jlong JNICALL NM(routeKeys)(JNIEnv* env, jclass c, jlong h, jobject ids, jint n, jobject out, jobject outOff) {
+    (void)c;
+    uint64_t* off = (uint64_t*)ADDR(outOff);
+    const int rc = bmq_route_keys(ENGINE(h), (const uint32_t*)ADDR(ids), (uint32_t)n, (uint8_t*)ADDR(out), CAP(out), off);
+    return result_of(env, ENGINE(h), "bmq_route_keys", rc, off ? off[n] : 0);
+}
+/* ByteBuffer hostAlloc(long bytes)      page-locked memory as a direct buffer: full-speed, truly asynchronous PCIe transfers */
+JNIEXPORT jobject JNICALL NM(hostAlloc)(JNIEnv* env, jclass c, jlong bytes) {
+    (void)c;
+    void* p = bmq_host_alloc((size_t)bytes);
+    return p ? (*env)->NewDirectByteBuffer(env, p, bytes) : NULL;
+}
+/* void hostFree(ByteBuffer buf) */
+JNIEXPORT void JNICALL NM(hostFree)(JNIEnv* env, jclass c, jobject buf) {
+    (void)c;
+    bmq_host_free(ADDR(buf));
+}
+/* int matchSubmit(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant, ByteBuffer topics,
+ *                 IntBuffer topicOff, int nTopics)      -> ticket (0 / 1); two batches may be in flight */
+JNIEXPORT jint JNICALL NM(matchSubmit)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants, jobject topicTenant,
+                                       jobject topics, jobject topicOff, jint nTopics) {
+    (void)c;
+    int ticket = -1;
+    const int rc = bmq_match_submit(ENGINE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
+                                    (const uint32_t*)ADDR(topicTenant), (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                    (uint32_t)nTopics, &ticket);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_match_submit", rc);
+    return ticket;
+}
+/* long matchWait(long engine, int ticket, IntBuffer outRowPtr, IntBuffer outIds)     -> number of ids, or -(needed) */
+JNIEXPORT jlong JNICALL NM(matchWait)(JNIEnv* env, jclass c, jlong h, jint ticket, jobject outRowPtr, jobject outIds) {
+    (void)c;
+    uint64_t need = 0;
+    const int rc = bmq_match_wait(ENGINE(h), ticket, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds), &need);
+    return result_of(env, ENGINE(h), "bmq_match_wait", rc, need);
+}
 /* int routeKey(long engine, int routeId, ByteBuffer out)    -> key length; the adapter turns it into a Matching
  *                                                              (KVSchemaUtil.buildMatchRoute(routeKey, value)) */
 JNIEXPORT jint JNICALL NM(routeKey)(JNIEnv* env, jclass c, jlong h, jint id, jobject out) {
@@ -183,6 +232,43 @@ JNIEXPORT void JNICALL NM(retainApply)(JNIEnv* env, jclass c, jlong h, jbyteArra
                                     (const uint8_t*)ADDR(ops), (uint32_t)n);
     (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
     if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_apply", rc);
+}
+/* void retainApplyEx(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, ByteBuffer ops, LongBuffer timestampHlc,
+ *                    IntBuffer expirySeconds, int n)        IRetainTopicIndex.add(tenant, topic, timestamp, expirySeconds) / remove */
+JNIEXPORT void JNICALL NM(retainApplyEx)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jobject topics, jobject topicOff, jobject ops,
+                                         jobject ts, jobject expiry, jint n) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    const int rc = bmq_retain_apply_ex(ENGINE(h), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                       (const uint8_t*)ADDR(ops), (const uint64_t*)ADDR(ts), (const uint32_t*)ADDR(expiry), (uint32_t)n);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_apply_ex", rc);
+}
+/* void retainTopicInfo(long engine, int topicId, long[] out)     out = {timestampHlc, expirySeconds, expireAtMs} */
+JNIEXPORT void JNICALL NM(retainTopicInfo)(JNIEnv* env, jclass c, jlong h, jint id, jlongArray out) {
+    (void)c;
+    uint64_t ts = 0, at = 0;
+    uint32_t ex = 0;
+    const int rc = bmq_retain_topic_info(ENGINE(h), (uint32_t)id, &ts, &ex, &at);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_retain_topic_info", rc);
+        return;
+    }
+    const jlong v[3] = {(jlong)ts, (jlong)ex, (jlong)at};
+    (*env)->SetLongArrayRegion(env, out, 0, 3, v);
+}
+/* void retainFindAll(long engine, long[] out)      out = {number of topics (ids 0 .. n-1), retain epoch} */
+JNIEXPORT void JNICALL NM(retainFindAll)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
+    (void)c;
+    uint64_t n = 0, ep = 0;
+    const int rc = bmq_retain_find_all(ENGINE(h), &n, &ep);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_retain_find_all", rc);
+        return;
+    }
+    const jlong v[2] = {(jlong)n, (jlong)ep};
+    (*env)->SetLongArrayRegion(env, out, 0, 2, v);
 }
 /* long retainMatchLimited(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer filterTenant, ByteBuffer filters,
  *                         IntBuffer filterOff, int nFilters, IntBuffer limits, long nowMs, IntBuffer outRowPtr, IntBuffer outTopicIds,

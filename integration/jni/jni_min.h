@@ -32,5 +32,6 @@ struct JNINativeInterface_ { /* only the members used by bmq_jni.c; the real tab
     jbyte* (*GetByteArrayElements)(JNIEnv* env, jbyteArray array, jboolean* isCopy);
     void (*ReleaseByteArrayElements)(JNIEnv* env, jbyteArray array, jbyte* elems, jint mode);
     void (*SetLongArrayRegion)(JNIEnv* env, jlongArray array, jsize start, jsize len, const jlong* buf);
+    jobject (*NewDirectByteBuffer)(JNIEnv* env, void* address, jlong capacity);
 };
 #endif
