@@ -314,7 +314,11 @@ def main():
     if node is not None:
         out["node_batch"] = node
     if world == 1 and not args.no_host_path:
-        out["host_visible"] = host_visible(args, eng, w, batches, n, seed, rank)
+        ids_per_batch = n_match / steps
+        if ids_per_batch * 4 <= 1 << 30:
+            out["host_visible"] = host_visible(args, eng, w, batches, n, seed, rank, int(ids_per_batch * 1.25) + 4096)
+        else:
+            out["host_visible"] = {"skipped": "a batch returns %.1f GB of route ids: the host-visible rate is PCIe bandwidth / that" % (ids_per_batch * 4 / 1e9)}
     if args.batcher_threads and world == 1:  # the production call pattern (one topic per call, many threads) through the collector
         hdata, hoff, htt = batches[0][3]
         m = min(args.batcher_topics, n)
@@ -437,7 +441,7 @@ def node_batch(args, rank, world, local_rank, dev, dist, total_tenants, per_tena
                     "-> match -> all-reduce of per-topic fan-out; includes the partition and the exchange"}
 
 
-def host_visible(args, eng, w, batches, n, seed, rank):
+def host_visible(args, eng, w, batches, n, seed, rank, cap):
     """SURVEY 8d's latency definition: host enqueue -> results visible on host.  Inputs and outputs live in page-locked host
     memory (bmq_host_alloc: what a JNI binding hands over as direct buffers).
       * p99 / p50 latency of ONE blocking bmq_match_batch call (upload + kernels + download, nothing overlapped);
@@ -460,7 +464,6 @@ def host_visible(args, eng, w, batches, n, seed, rank):
         pd, po, pt = pinned(len(data), np.uint8), pinned(len(off), np.uint32), pinned(len(tt), np.uint32)
         pd[:], po[:], pt[:] = data, off, tt
         hb.append((pd, po, pt))
-    cap = 32 * n
     rows = [pinned(n + 1, np.uint32) for _ in range(2)]
     ids = [pinned(cap, np.uint32) for _ in range(2)]
     L = B._lib.lib()

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Copies the summaries produced by tools/profile_round.sh from gpurun_out/<round>/ into profiles/<round>/ and
 derives profiles/traffic_<round>.json (HBM bytes per k_walk launch) from the two PMC passes.
-usage: python tools/collect_profiles.py r01"""
+usage: python tools/collect_profiles.py r02"""
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = os.path.join("gpurun_out", R), os.path.join("profiles", R)
 os.makedirs(dst, exist_ok=True)
 for name in ("pytest_gpu.log", "bench_c3.json", "bench_c2.json", "bench_c4.json"):

@@ -1,17 +1,17 @@
 #!/bin/bash
 # Secondary measurements quoted in DESIGN.md section 5 (run through gpurun from the repo root; results under gpurun_out/<round>/extras).
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out/$R/extras
 mkdir -p $O
 for n in 10000 100000 4000000; do
-  python bench.py --topics $n --steps 30 --warmup 5 --no-cpu-baseline > $O/sweep_$n.json 2> $O/sweep_$n.err
+  python bench.py --topics $n --steps 30 --warmup 5 --no-cpu-baseline --no-host-path > $O/sweep_$n.json 2> $O/sweep_$n.err
 done
-python bench.py --ungrouped --no-cpu-baseline > $O/ungrouped.json 2> $O/ungrouped.err
-python bench.py --exchange-selftest --no-cpu-baseline > $O/exchange_selftest.json 2> $O/exchange_selftest.err
-python bench.py --churn 100000 --steps 5 --warmup 1 --no-cpu-baseline > $O/churn100k.json 2> $O/churn100k.err
-python bench.py --no-cpu-baseline --steps 5 --warmup 2 --batcher-threads 64 > $O/batcher64.json 2> $O/batcher64.err
-python bench.py --no-cpu-baseline --steps 5 --warmup 2 --batcher-threads 256 > $O/batcher256.json 2> $O/batcher256.err
-python tools/host_path_rate.py > $O/host_path_rate.txt 2>&1
+python bench.py --ungrouped --no-cpu-baseline --no-host-path > $O/ungrouped.json 2> $O/ungrouped.err
+python bench.py --exchange-selftest --no-cpu-baseline --no-host-path > $O/exchange_selftest.json 2> $O/exchange_selftest.err
+BMQ_TIMING=1 python bench.py --churn 100000 --steps 10 --warmup 2 --no-cpu-baseline --no-host-path > $O/churn100k.json 2> $O/churn100k.err
+grep 'bmq index' $O/churn100k.err | tail -30 > $O/churn100k_phases.txt
+BMQ_TIMING=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path 2>&1 | grep 'rebuild:' > $O/rebuild_phases.txt
+python bench.py --no-cpu-baseline --no-host-path --steps 5 --warmup 2 --batcher-threads 256 > $O/batcher256.json 2> $O/batcher256.err
 python - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$O/*.json")):
@@ -22,4 +22,4 @@ for f in sorted(glob.glob("$O/*.json")):
     print(os.path.basename(f), round(d["value"] / 1e6, 1), "M/s", round(d["ms_per_step"], 3), "ms p50", round(d.get("p50_batch_ms", 0), 3), "p99",
           round(d.get("p99_batch_ms", 0), 3), {k: round(v, 3) for k, v in d["kernel_ms"].items()}, d.get("batching_front", ""), d["churn"]["apply_ms_mean"])
 PY
-tail -3 $O/host_path_rate.txt
+cat $O/rebuild_phases.txt

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates the evidence kept under profiles/<round>/ on a GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r01
+#   bash tools/profile_round.sh r02
 # Writes under gpurun_out/<round>/ (scratch); tools/collect_profiles.py then copies the summaries into profiles/<round>/.
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
