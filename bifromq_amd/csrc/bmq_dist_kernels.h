@@ -99,6 +99,7 @@ struct BatchArgs {
     unsigned long long spill_cap;
     unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block
     uint32_t n_blocks;
+    uint32_t tpw_shift;      // a wave owns 2^tpw_shift topics (6 = all 64 lanes; small batches use 4 or 2: more, shorter waves)
     uint32_t* slow_list;
     uint32_t slow_cap;
     uint32_t* scratch;
@@ -397,12 +398,16 @@ __global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
     // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
     // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
     blk = a.n_blocks - 1 - blk;
-    const uint32_t t = blk * 64 + lane;
-    const bool valid = t < a.n_topics;
+    // A wave owns TPW = 2^tpw_shift consecutive topics.  64 for large batches; a small batch is spread over more waves (16 or 4
+    // topics each): the walk phase is a chain of dependent line fetches whose length is ~ max(depth, items / 64), so a wave with
+    // fewer topics finishes sooner and a 10 k-topic batch fills the chip instead of 157 waves on 256 CUs.
+    const uint32_t tpw = 1u << a.tpw_shift;
+    const uint32_t t = (blk << a.tpw_shift) + lane;
+    const bool valid = lane < tpw && t < a.n_topics;
     const unsigned long long clk0 = a.dbg_wave ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- phase 1: tokenise ---------------------------------------------------------------------------------------------
-    const uint32_t t_first = blk * 64, t_end = min(t_first + 64, a.n_topics);
+    const uint32_t t_first = blk << a.tpw_shift, t_end = min(t_first + tpw, a.n_topics);
     const uint32_t s_beg = a.topic_off[t_first], s_end = a.topic_off[t_end]; // wave-uniform
     const uint32_t a0 = s_beg & ~15u;
     const bool staged = (s_end - a0) + 32u <= stage_bytes;
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                 }
             }
             if (pass == 0) {
-                if (np && !pair_alloc(a.subs, a.pair_cap, t >> 6, np, base)) {
+                if (np && !pair_alloc(a.subs, a.pair_cap, t >> a.tpw_shift, np, base)) {
                     atomicOr(&a.ctr->status, ST_NEED_PAIRS);
                     ok = false;
                 }
@@ -779,8 +784,8 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         a.pair_cnt[t] = np;
         a.route_cnt[t] = nr;
         if (nr) {
-            atomicAdd(&a.wave_sums[t >> 6], (unsigned long long)nr);
-            atomicAdd(&a.super_sums[(size_t)(t >> (6 + SUPER_SHIFT)) * SUPER_STRIDE], (unsigned long long)nr);
+            atomicAdd(&a.wave_sums[t >> a.tpw_shift], (unsigned long long)nr);
+            atomicAdd(&a.super_sums[(size_t)(t >> (a.tpw_shift + SUPER_SHIFT)) * SUPER_STRIDE], (unsigned long long)nr);
         }
         if (visits) atomicAdd(&a.ctr->n_visit, (unsigned long long)visits);
         if (np) atomicAdd(&a.ctr->n_ranges, (unsigned long long)np);
@@ -820,8 +825,8 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
     uint32_t* r_off = s_off[wave];
     uint32_t* r_row = s_row[wave];
     uint32_t* row_bad = s_bad[wave];
-    const uint32_t t = blk * 64 + lane;
-    const bool valid = t < a.n_topics;
+    const uint32_t t = (blk << a.tpw_shift) + lane;
+    const bool valid = lane < (1u << a.tpw_shift) && t < a.n_topics;
     const uint32_t status = a.ctr->status;
     const uint32_t nr = valid ? a.route_cnt[t] : 0u;
     uint32_t wtotal;
@@ -944,7 +949,9 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
             carry_last = (r_cnt[kn - 1] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[kn - 1] + c - 1] : r_begin[kn - 1] + c - 1;
         }
         // element generation: runs of short ranges are flattened (every lane locates its range in LDS), long ranges are
-        // streamed by the whole wave with no per-element lookup
+        // streamed by the whole wave with no per-element lookup.  (Measured and dropped in round 2: one lane per short range +
+        // wave-streaming of everything above 4 / 8 / 16 ids -- C3 k_expand 0.172 / 0.130 / 0.119 ms against 0.117 ms here, C2 1.47
+        // against 1.22 ms: streaming the many medium ranges one after the other costs more than the LDS searches save.)
         for (uint32_t k = 0; k < kn;) {
             uint32_t kl = kn; // first long range at or after k
             for (uint32_t c0 = k; c0 < kn && kl == kn; c0 += 64) {

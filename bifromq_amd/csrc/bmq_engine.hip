@@ -163,8 +163,15 @@ int upload(bmq_engine* e, DevBuf& b, const void* src, size_t bytes) {
 }
 
 // ---- dist batch ------------------------------------------------------------------------------------------------
+// topics per k_walk / k_expand wave = 2^shift: small batches are spread over more, shorter waves (see k_walk)
+uint32_t tpw_shift_for(uint32_t n_topics) {
+    if (const char* v = getenv("BMQ_TPW_SHIFT")) return (uint32_t)std::min(6, std::max(0, atoi(v))); // profiling experiments
+    return n_topics >= 131072 ? 6u : (n_topics >= 4096 ? 4u : 2u); // measured: profiles/r02/extras/tpw_sweep.txt
+}
+
 int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
-    const uint32_t n_blocks = (n_topics + 63) / 64;
+    const uint32_t sh = tpw_shift_for(n_topics);
+    const uint32_t n_blocks = (n_topics + (1u << sh) - 1) >> sh;
     if (e->cur->pair_cap == 0) e->cur->pair_cap = 1u << 16;
     e->cur->pair_cap = std::max<uint64_t>(e->cur->pair_cap, (uint64_t)n_topics * 4);
     if (e->cur->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
@@ -195,7 +202,8 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
 
 int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.ix = e->dix->view();
-    a.n_blocks = (a.n_topics + 63) / 64;
+    a.tpw_shift = tpw_shift_for(a.n_topics);
+    a.n_blocks = (a.n_topics + (1u << a.tpw_shift) - 1) >> a.tpw_shift;
     a.tenant_info = e->cur->b_tenant_root.as<TenantSlot>();
     a.pair_off = e->cur->b_pair_off.as<uint32_t>();
     a.pair_cnt = e->cur->b_pair_cnt.as<uint32_t>();

@@ -363,8 +363,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             a.pair_cnt[f] = np_total;
             a.route_cnt[f] = nr_total;
             if (nr_total) {
-                atomicAdd(&a.wave_sums[f >> 6], (unsigned long long)nr_total);
-                atomicAdd(&a.super_sums[(size_t)(f >> (6 + SUPER_SHIFT)) * SUPER_STRIDE], (unsigned long long)nr_total);
+                atomicAdd(&a.wave_sums[f >> a.tpw_shift], (unsigned long long)nr_total);
+                atomicAdd(&a.super_sums[(size_t)(f >> (a.tpw_shift + SUPER_SHIFT)) * SUPER_STRIDE], (unsigned long long)nr_total);
             }
         }
         wranges += np_total;
