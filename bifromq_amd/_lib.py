@@ -61,7 +61,7 @@ class BatcherConfig(C.Structure):
 
 class BatcherStats(C.Structure):
     _fields_ = [("n_requests", C.c_uint64), ("n_topics", C.c_uint64), ("n_batches", C.c_uint64),
-                ("max_batch_topics", C.c_uint64)]
+                ("max_batch_topics", C.c_uint64), ("n_deduped", C.c_uint64)]
 
 
 _lib = None

@@ -371,7 +371,10 @@ __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
     return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + WALK_TOPIC_WORDS + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
 }
 
-__global__ __launch_bounds__(WALK_WAVES * 64) void k_walk(BatchArgs a) {
+#ifndef BMQ_WALK_MIN_WAVES
+#define BMQ_WALK_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(BatchArgs a) {
     extern __shared__ __align__(16) uint32_t lds_all[];
     // WALK_WAVES independent waves per workgroup: every wave owns its own slice of LDS and never synchronises with its
     // neighbours.  Measured on C3 (profiles/r01): 1 wave per workgroup 0.308 ms, 2 waves 0.317 ms, 4 waves 0.320 ms -- 16 waves

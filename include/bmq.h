@@ -179,7 +179,7 @@ int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* o
  * the matchExecutor pool (DW/cache/TenantRouteCache.java:180-193, DW/DistWorkerCoProcFactory.java:74-88).  A batcher
  * collects the calls of all threads that are waiting right now into ONE bmq_match_batch (leader/follower: no timer,
  * no extra thread; the batch is whatever piled up while the previous one was on the GPU) and hands every caller
- * its rows.  Any number of threads may call bmq_batcher_match_all concurrently; the call blocks until the batch
+ * its rows (identical (tenant, topic) pairs of one launch are matched once).  Any number of threads may call bmq_batcher_match_all concurrently; the call blocks until the batch
  * that contains the request has been matched.  bmq_rebuild / bmq_routes_apply may run concurrently (they serialise
  * with the batches on the engine lock); *out_epoch tells which epoch the returned route ids are ranks of. */
 typedef struct bmq_batcher bmq_batcher;
@@ -190,6 +190,7 @@ typedef struct bmq_batcher_config {
 } bmq_batcher_config;
 typedef struct bmq_batcher_stats {
     uint64_t n_requests, n_topics, n_batches, max_batch_topics;
+    uint64_t n_deduped; /* requested topics that shared a row with an identical (tenant, topic) of the same launch */
 } bmq_batcher_stats;
 int bmq_batcher_create(bmq_engine* e, const bmq_batcher_config* cfg /* may be NULL */, bmq_batcher** out);
 /* Waits for the calls in flight; calls arriving afterwards fail with BMQ_E_STATE.  Destroy before the engine. */

@@ -151,3 +151,38 @@ def test_small_output_buffer_reports_needed(setup):
                                           C.byref(need), C.byref(epoch))
     assert rc == -3 and need.value == len(exp[i]) and row.tolist() == [0, len(exp[i])]
     b.close()
+
+
+def test_identical_requests_of_one_launch_share_a_row(setup):
+    """In-batch dedup: the same (tenant, topic) asked for by several callers at the same moment is matched once
+    per launch; every caller still gets the oracle's row.  Driven through the asynchronous side, where one batch collects many
+    requests: 4000 requests over 40 distinct (tenant, topic) pairs."""
+    eng, tn, tt, packed, topics, exp = setup
+    import threading
+    b = eng.batcher()
+    pick = list(range(0, 400, 10))
+    got, done = {}, threading.Semaphore(0)
+    N = 4000
+
+    def submit(k):
+        i = pick[k % len(pick)]
+
+        def cb(status, ids, epoch):
+            got[k] = (status, ids)
+            done.release()
+        b.submit(tn[tt[i]], topics[i], cb)
+
+    for k in range(N):
+        submit(k)
+    for _ in range(N):
+        assert done.acquire(timeout=60)
+    for k in range(N):
+        i = pick[k % len(pick)]
+        assert got[k] == (0, exp[i]), k
+    st = b.stats()
+    assert st.n_requests == N and st.n_topics == N and st.n_deduped > N // 2  # most requests rode on another request's row
+    # blocking side: one caller asking for the same topic three times in one call
+    rows, _ = b.match_all(tn[tt[0]], [topics[0], topics[5] if tt[5] == tt[0] else topics[0], topics[0]])
+    assert rows[0] == exp[0] and rows[2] == exp[0]
+    assert b.stats().n_deduped > st.n_deduped
+    b.close()
