@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/bmq.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_routes_apply",
+    "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_compact", "bmq_routes_apply",
     "bmq_index_info_get", "bmq_route_key", "bmq_route_keys", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
     "bmq_match_finish", "bmq_match_submit", "bmq_match_wait", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_range_lookup", "bmq_retain_message_key", "bmq_retain_filter_route", "bmq_retain_rebuild", "bmq_retain_rebuild_ex", "bmq_retain_apply", "bmq_retain_apply_ex", "bmq_retain_topic",
@@ -84,6 +84,7 @@ def lib() -> C.CDLL:
             "bmq_version": (C.c_char_p, []),
             "bmq_rebuild": (C.c_int, [vp, vp, vp, u32]),
             "bmq_routes_apply": (C.c_int, [vp, vp, vp, vp, u32]),
+            "bmq_compact": (C.c_int, [vp]),
             "bmq_index_info_get": (C.c_int, [vp, P(IndexInfo)]),
             "bmq_route_key": (C.c_int, [vp, u32, C.c_char_p, u32, P(u32)]),
             "bmq_route_keys": (C.c_int, [vp, vp, u32, vp, u64, vp]),

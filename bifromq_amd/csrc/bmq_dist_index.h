@@ -252,6 +252,30 @@ public:
         return true;
     }
 
+    // ---- maintenance: re-build the index from its own live routes.  Drops abandoned regions and id lists, dead trie nodes and
+    // dictionary tokens nobody uses any more; the key store shrinks to the live keys.  Route ids are re-numbered (ranks again):
+    // a new generation, exactly like a bmq_rebuild with the current key set.
+    bool compact() {
+        error.clear();
+        if (!built) return true;
+        std::vector<uint32_t> ids(next_id);
+        for (uint32_t i = 0; i < next_id; i++) ids[i] = i;
+        std::vector<uint8_t> bytes;
+        std::vector<uint64_t> off;
+        if (!route_keys(ids.data(), next_id, bytes, off)) return false;
+        if (off[next_id] >= 0xFFFFFFF0ull) return fail("compact: more than 4 GB of route keys");
+        std::vector<uint8_t> kb;
+        std::vector<uint32_t> ko{0};
+        kb.reserve(bytes.size() + 16);
+        for (uint32_t i = 0; i < next_id; i++)
+            if (off[i + 1] > off[i]) { // live
+                kb.insert(kb.end(), bytes.begin() + (long)off[i], bytes.begin() + (long)off[i + 1]);
+                ko.push_back((uint32_t)kb.size());
+            }
+        kb.resize(kb.size() + 16, 0);
+        return rebuild(kb.data(), ko.data(), (uint32_t)ko.size() - 1); // not ascending any more after churn: sorted on the host
+    }
+
     // ---- id -> key ----
     // false + empty error: no such route (never existed or deleted)
     bool route_key(uint32_t id, std::string& out) {

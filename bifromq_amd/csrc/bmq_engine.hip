@@ -117,6 +117,7 @@ struct bmq_engine {
         bool pending = false;
         int pending_kind = 0; // 0 dist, 1 retain
         bool submitted = false; // owned by a bmq_match_submit ticket
+        bool api_held = false;  // the *_dev launch took the engine's api lock; bmq_match_finish gives it back
         uint64_t dev_cap = 0;   // ids the slot's own output buffer holds
         uint32_t n_rows = 0;
         BatchArgs last{};
@@ -459,6 +460,24 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
     return BMQ_OK;
 }
 
+int bmq_compact(bmq_engine* e) {
+    std::unique_lock<std::recursive_mutex> api_lock;
+    if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
+    if (!e) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (auto& sl : e->slots)
+        if (sl.pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: finish / wait for it first");
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    const bool ok = with_index(e, [&](auto& ix) {
+        const bool r = ix.compact();
+        if (!r) e->err = ix.error;
+        return r;
+    });
+    if (!ok) return index_error(e, e->err, false);
+    e->epoch++;
+    return BMQ_OK;
+}
+
 int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
     std::unique_lock<std::recursive_mutex> api_lock;
     if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
@@ -585,6 +604,16 @@ int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t*
     if (n_topics == 0 || !d_out_row_ptr || !d_topic_off || !d_topics || !d_topic_tenant || !d_out_total)
         return set_err(e, BMQ_E_INVAL, "null pointer or empty batch");
     if ((uintptr_t)d_topics & 15) return set_err(e, BMQ_E_INVAL, "the topic byte buffer must be 16-byte aligned");
+    // The launch .. finish window belongs to ONE caller: the api lock is taken here and given back by bmq_match_finish (same
+    // thread), so a host-buffer call or a batcher launch of another thread cannot consume or overwrite this batch.
+    if (!e->api.try_lock()) return set_err(e, BMQ_E_STATE, "the engine is busy with another thread's call");
+    struct Unlock {
+        bmq_engine* e;
+        bool keep = false;
+        ~Unlock() {
+            if (!keep) e->api.unlock();
+        }
+    } api_guard{e};
     std::lock_guard<std::mutex> g(e->mu);
     if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     HIPCHK(e, hipSetDevice(e->device));
@@ -601,16 +630,30 @@ int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t*
     a.out_ids = d_out_route_ids;
     a.out_capacity = d_out_route_ids ? out_capacity : 0;
     a.out_total = (unsigned long long*)d_out_total;
-    return launch_dist(e, a);
+    rc = launch_dist(e, a);
+    if (rc == BMQ_OK) {
+        api_guard.keep = true;
+        e->cur->api_held = true;
+    }
+    return rc;
 }
 
 int bmq_match_finish(bmq_engine* e, uint64_t* out_total) {
     if (!e) return BMQ_E_INVAL;
     if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only");
-    std::lock_guard<std::mutex> g(e->mu);
-    if (!e->cur->pending) return set_err(e, BMQ_E_STATE, "no batch in flight");
-    HIPCHK(e, hipSetDevice(e->device));
-    return e->cur->pending_kind == 0 ? finish_dist(e, out_total) : retain_finish(e, out_total);
+    int rc;
+    bool give_back = false;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        if (!e->cur->pending) return set_err(e, BMQ_E_STATE, "no batch in flight");
+        HIPCHK(e, hipSetDevice(e->device));
+        rc = e->cur->pending_kind == 0 ? finish_dist(e, out_total) : retain_finish(e, out_total);
+        if (rc != BMQ_OK) e->cur->pending = false; // a failed batch is over too: the next launch starts clean
+        give_back = e->cur->api_held;
+        e->cur->api_held = false;
+    }
+    if (give_back) e->api.unlock();
+    return rc;
 }
 
 int bmq_sync(bmq_engine* e) {

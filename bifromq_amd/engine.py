@@ -161,6 +161,11 @@ class Engine:
         self._check(_lib.lib().bmq_routes_apply(self.h, _ptr(data), _ptr(off), _ptr(op), len(ops)))
         return self
 
+    def compact(self):
+        """bmq_compact: re-build from the live routes (ids become ranks again, new generation)."""
+        self._check(_lib.lib().bmq_compact(self.h))
+        return self
+
     def info(self) -> _lib.IndexInfo:
         out = _lib.IndexInfo()
         self._check(_lib.lib().bmq_index_info_get(self.h, C.byref(out)))

@@ -25,8 +25,9 @@
  *     aligned words); the host-buffer variants stage and pad internally, so host callers have no such duty;
  *   - thread-safety: every call on one engine is serialised internally (matcher threads of the reference's
  *     ForkJoinPool, DW/DistWorkerCoProcFactory.java:74-88, may all call into it); ONE device batch may be in flight
- *     per engine: bmq_match_batch_dev / bmq_retain_match_batch_dev must be followed by bmq_match_finish before the next
- *     batch, rebuild or apply.  Use one engine per stream of work (e.g. per KV range replica).
+ *     per engine through the *_dev protocol: bmq_match_batch_dev / bmq_retain_match_batch_dev take the engine for their caller
+ *     until the SAME thread calls bmq_match_finish (other threads' calls wait; another thread's *_dev launch gets BMQ_E_STATE).
+ *     bmq_match_submit / bmq_match_wait keep two host batches in flight.  Use one engine per KV range replica.
  *   - the engine REQUIRES a gfx950 device for every match call.  There is no CPU fallback: without a
  *     device bmq_engine_create(device >= 0) fails with BMQ_E_NODEVICE.
  */
@@ -113,6 +114,11 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
  * key is a no-op; the j-th put of the batch that adds a route gets id next_route_id + j.  A malformed key or op code fails
  * the whole batch with BMQ_E_INVAL before anything is changed. */
 int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
+
+/* Maintenance: re-build the index from its own live routes (the keys are gathered from the HBM key store).  Frees what churn leaves
+ * behind until then -- abandoned tenant regions and id lists, trie nodes and dictionary tokens of filters nobody subscribes to any
+ * more (bmq_index_info.garbage_bytes) -- and re-numbers the route ids to ranks: a new generation, like bmq_rebuild. */
+int bmq_compact(bmq_engine* e);
 
 int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out);
 /* id -> key (so the Java adapter can materialise Matching objects, SCHEMA/KVSchemaUtil.java:73-89).  BMQ_E_INVAL: no such

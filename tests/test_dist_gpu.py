@@ -270,6 +270,14 @@ def test_apply_then_match(eng):
         d[(row[1:-1][row[1:-1] < len(ids)] - 1)[row[1:-1][row[1:-1] < len(ids)] > 0]] = 1
         assert (d > 0).all()  # rows stay ascending although new routes carry late ids (range ordering / k_sort_rows)
         assert U.rows_as_ranks(eng, row, ids, keys_now) == U.semantic_rows(kv, tn, tt, topics)
+    # bmq_compact: the index re-built from its own live routes -- ids are ranks again, garbage gone, same answers
+    before = eng.info()
+    assert before.garbage_bytes > 0 or before.next_route_id > before.n_routes
+    eng.compact()
+    after = eng.info()
+    assert after.generation == before.generation + 1 and after.n_routes == len(live) == after.next_route_id and after.garbage_bytes == 0
+    row, ids = eng.match_batch(tn, tt, packed_topics=(data, off))
+    assert U.csr_rows(row, ids) == U.semantic_rows(kv, tn, tt, topics)
 
 
 def test_apply_creates_and_removes_tenants(eng):
@@ -530,4 +538,40 @@ def test_submit_wait_two_batches_in_flight(eng):
         assert got == len(expect[0][1]) and (ids[0][:got] == expect[0][1]).all()  # submitted before the apply
     row2, ids2 = eng.match_batch(tn, pt, packed_topics=(pd, po))
     assert len(ids2) > len(expect[0][1])  # the '#' route of tenant 0 now matches its non-'$' topics
+
+
+def test_dev_protocol_belongs_to_one_thread(eng):
+    """bmq_match_batch_dev .. bmq_match_finish is one caller's window: another thread's *_dev launch is refused meanwhile
+    (BMQ_E_STATE) instead of overwriting the batch in flight."""
+    import threading
+    import torch
+    w = B.Workload(3, 2, 500, 1)
+    eng.rebuild(w.keys())
+    tn = w.tenants()
+    data, off, tt = w.topics(1, 1000)
+    dev = torch.device("cuda", 0)
+    tdata, toff = w.tenants_packed()
+    d = [torch.from_numpy(x).to(dev) for x in (tdata.copy(), toff.astype(np.int32), tt.astype(np.int32), data, off.astype(np.int32))]
+    row = torch.zeros(1001, dtype=torch.int32, device=dev)
+    ids = torch.zeros(200000, dtype=torch.int32, device=dev)
+    tot = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    args = (d[0].data_ptr(), d[1].data_ptr(), len(tn), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), 1000, row.data_ptr(), ids.data_ptr(),
+            ids.numel(), tot.data_ptr())
+    eng.match_batch_device(*args)
+    seen = []
+
+    def other():
+        try:
+            eng.match_batch_device(*args)
+            seen.append("launched")
+        except B.BmqError as ex:
+            seen.append(ex.code)
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen == [-7]
+    n = eng.finish()
+    exp_row, exp_ids = eng.match_batch(tn, tt, packed_topics=(data, off))
+    assert n == len(exp_ids) and (ids[:n].cpu().numpy().astype(np.uint32) == exp_ids).all()
 

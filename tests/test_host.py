@@ -274,3 +274,21 @@ def test_retain_key_schema_vectors_and_parity():
             assert key == O.retain_key_prefix_of_filter(tenant, f) and lh == H(O.retain_filter_prefix(f.split("/")))
         else:
             assert key == O.retain_message_key(tenant, f)
+
+
+def test_compact_renumbers_and_frees_garbage_host():
+    """bmq_compact on a host-only engine: after churn (deleted routes, a tenant that outgrew its region twice) the index is
+    re-built from its own live keys: ids are ranks again, a new generation, no garbage, exact lookups unchanged."""
+    ks = [B.route_key("t", "a/%d" % i, 1, "0\0r%d\0d" % i) for i in range(200)]
+    e = B.Engine(device=-1).rebuild(ks)
+    e.apply([(1, k) for k in ks[::3]] + [(0, B.route_key("t", "grow/%d/+/x" % i, 1, "0\0g%d\0d" % i)) for i in range(3000)])
+    before = e.info()
+    assert before.garbage_bytes > 0 and before.next_route_id == 3200
+    live = sorted(k for k in e.route_keys(list(range(3200))) if k)
+    assert len(live) == before.n_routes == 200 - 67 + 3000
+    e.compact()
+    after = e.info()
+    assert after.generation == before.generation + 1 and after.n_routes == len(live) and after.next_route_id == len(live)
+    assert after.garbage_bytes == 0 and after.n_nodes < before.n_nodes  # the nodes of the 67 deleted filters are gone
+    assert e.route_keys(list(range(len(live)))) == live
+    assert e.find("t", "grow/7/+/x") == [live.index(B.route_key("t", "grow/7/+/x", 1, "0\0g7\0d"))] and e.find("t", "a/0") == []
