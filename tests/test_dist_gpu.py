@@ -542,22 +542,31 @@ def test_submit_wait_two_batches_in_flight(eng):
 
 def test_dev_protocol_belongs_to_one_thread(eng):
     """bmq_match_batch_dev .. bmq_match_finish is one caller's window: another thread's *_dev launch is refused meanwhile
-    (BMQ_E_STATE) instead of overwriting the batch in flight."""
+    (BMQ_E_STATE) instead of overwriting the batch in flight.  Device buffers come straight from the HIP runtime the library
+    itself is linked against (ctypes; torch would bring a second copy of the runtime into the process)."""
+    import ctypes as C
     import threading
-    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    bufs = []
+
+    def to_dev(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), a.nbytes + 64) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        bufs.append(p)
+        return p.value
+
     w = B.Workload(3, 2, 500, 1)
     eng.rebuild(w.keys())
     tn = w.tenants()
     data, off, tt = w.topics(1, 1000)
-    dev = torch.device("cuda", 0)
     tdata, toff = w.tenants_packed()
-    d = [torch.from_numpy(x).to(dev) for x in (tdata.copy(), toff.astype(np.int32), tt.astype(np.int32), data, off.astype(np.int32))]
-    row = torch.zeros(1001, dtype=torch.int32, device=dev)
-    ids = torch.zeros(200000, dtype=torch.int32, device=dev)
-    tot = torch.zeros(1, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    args = (d[0].data_ptr(), d[1].data_ptr(), len(tn), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), 1000, row.data_ptr(), ids.data_ptr(),
-            ids.numel(), tot.data_ptr())
+    d = [to_dev(np.ascontiguousarray(x)) for x in (tdata.copy(), toff.astype(np.uint32), tt.astype(np.uint32), data, off.astype(np.uint32))]
+    row, ids, tot = to_dev(np.zeros(1001, dtype=np.uint32)), to_dev(np.zeros(200000, dtype=np.uint32)), to_dev(np.zeros(1, dtype=np.uint64))
+    args = (d[0], d[1], len(tn), d[2], d[3], d[4], 1000, row, ids, 200000, tot)
     eng.match_batch_device(*args)
     seen = []
 
@@ -573,5 +582,8 @@ def test_dev_protocol_belongs_to_one_thread(eng):
     assert seen == [-7]
     n = eng.finish()
     exp_row, exp_ids = eng.match_batch(tn, tt, packed_topics=(data, off))
-    assert n == len(exp_ids) and (ids[:n].cpu().numpy().astype(np.uint32) == exp_ids).all()
-
+    got = np.zeros(n, dtype=np.uint32)
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), C.c_void_p(ids), 4 * n, 2) == 0  # hipMemcpyDeviceToHost
+    assert n == len(exp_ids) and (got == exp_ids).all()
+    for p in bufs:
+        hip.hipFree(p)
