@@ -136,10 +136,17 @@ struct bmq_engine {
     RetainLimit rlim;
     DevBuf r_scratch;
     DevBuf range_buf; // staging of bmq_range_lookup
+    // multi-GPU exchange inside the library (bmq_exchange.inc): RCCL communicator of this rank, its own stream
+    void* comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
+    hipStream_t s_ex = nullptr;
+    hipEvent_t ev_ex = nullptr;
+    DevBuf ex_buf;
     uint32_t rgcap = 0;
 };
 
 static int retain_finish(bmq_engine* e, uint64_t* out_total);
+extern "C" void bmq_comm_destroy(bmq_engine* e);
 
 namespace {
 
@@ -428,6 +435,9 @@ void bmq_engine_destroy(bmq_engine* e) {
         }
         if (e->s_in) (void)hipStreamDestroy(e->s_in);
         if (e->s_out) (void)hipStreamDestroy(e->s_out);
+        bmq_comm_destroy(e);
+        if (e->ev_ex) (void)hipEventDestroy(e->ev_ex);
+        if (e->s_ex) (void)hipStreamDestroy(e->s_ex);
         e->dix.reset(); // frees the HBM arrays while the stream still exists
         e->dx.release(e->dx.tmp);
         e->dx.tmp = nullptr;
@@ -1017,3 +1027,4 @@ int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len) { return java_st
 #include "bmq_retain_engine.inc"
 #include "bmq_batcher.inc"
 #include "bmq_range_engine.inc"
+#include "bmq_exchange.inc"

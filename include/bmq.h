@@ -180,6 +180,27 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
 int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
                    uint64_t* out_needed);
 
+/* ---- multi-GPU exchange -------------------------------------------------------------------------------------- */
+/* One process per GPU, tenants sharded by hash(tenantId) mod N; after the per-rank match ONE exchange step over RCCL / xGMI.
+ * RCCL is loaded at run time (librccl.so.1); a process that already carries it (PyTorch) keeps using that copy.
+ *   bmq_comm_unique_id : rank 0 creates the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any means
+ *   bmq_comm_init      : every rank, with its engine (ncclCommInitRank on the engine's device)
+ *   bmq_exchange_fanout: per-topic fan-out counts of every rank to every rank -- all the reference sends upstream
+ *                        (DW/DistWorkerCoProc.java:535-538).  d_row_ptr[n + 1] -> d_counts_all[world * n], all device pointers
+ *   bmq_exchange_csr   : the complete CSR of every rank on every rank: totals (-> out_totals[world], host), row pointers
+ *                        (d_rows_all[world * (n + 1)]), then a true all-gatherv of the ids into d_ids_all (rank r's ids start at
+ *                        sum(out_totals[0 .. r))): one ncclBroadcast per rank with its exact size in one group.  n must be the
+ *                        same on every rank; BMQ_E_NOSPACE if ids_cap < sum(out_totals) (totals are still reported)
+ * Both run asynchronously on the engine's exchange stream, ordered behind everything queued on the engine stream when they are
+ * called (the batch whose results they send), so they overlap the NEXT batch's match; bmq_exchange_wait blocks until done. */
+int bmq_comm_unique_id(uint8_t out[128]);
+int bmq_comm_init(bmq_engine* e, int world, int rank, const uint8_t id[128]);
+void bmq_comm_destroy(bmq_engine* e);
+int bmq_exchange_fanout(bmq_engine* e, const uint32_t* d_row_ptr, uint32_t n, uint32_t* d_counts_all);
+int bmq_exchange_csr(bmq_engine* e, const uint32_t* d_row_ptr, const uint32_t* d_ids, uint32_t n, uint64_t total,
+                     uint32_t* d_rows_all, uint32_t* d_ids_all, uint64_t ids_cap, uint64_t* out_totals);
+int bmq_exchange_wait(bmq_engine* e);
+
 /* ---- batching front ------------------------------------------------------------------- */
 /* Production asks for one topic per call: TenantRouteCache issues matchAll(singleton(topic)) per cache miss from
  * the matchExecutor pool (DW/cache/TenantRouteCache.java:180-193, DW/DistWorkerCoProcFactory.java:74-88).  A batcher

@@ -587,3 +587,65 @@ def test_dev_protocol_belongs_to_one_thread(eng):
     assert n == len(exp_ids) and (got == exp_ids).all()
     for p in bufs:
         hip.hipFree(p)
+
+
+def test_in_library_rccl_exchange_world_size_one(eng):
+    """bmq_exchange_fanout / bmq_exchange_csr (RCCL inside libbmq, bmq_exchange.inc) at world size 1 -- the largest this pool
+    offers: the communicator comes up, the collectives run on the exchange stream behind the batch, and what comes back is this
+    rank's own fan-out vector / CSR, equal to the oracle's."""
+    import ctypes as C
+    from bifromq_amd import _lib
+    L = _lib.lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    bufs = []
+
+    def to_dev(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), a.nbytes + 64) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+        bufs.append(p)
+        return p.value
+
+    def from_dev(p, n, dtype):
+        out = np.zeros(n, dtype=dtype)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(p), out.nbytes, 2) == 0
+        return out
+
+    e2 = B.Engine(device=0)  # a fresh engine: the communicator belongs to it
+    w = B.Workload(21, 3, 800, 1)
+    keys = w.keys()
+    e2.rebuild(keys)
+    tn = w.tenants()
+    n = 3000
+    data, off, tt = w.topics(2, n)
+    uid = C.create_string_buffer(128)
+    assert L.bmq_comm_unique_id(uid) == 0
+    assert L.bmq_comm_init(e2.h, 1, 0, uid) == 0
+    tdata, toff = w.tenants_packed()
+    d = [to_dev(np.ascontiguousarray(x)) for x in (tdata.copy(), toff.astype(np.uint32), tt.astype(np.uint32), data, off.astype(np.uint32))]
+    cap = 400000
+    row, ids, tot = to_dev(np.zeros(n + 1, dtype=np.uint32)), to_dev(np.zeros(cap, dtype=np.uint32)), to_dev(np.zeros(1, dtype=np.uint64))
+    counts_all, rows_all, ids_all = to_dev(np.zeros(n, dtype=np.uint32)), to_dev(np.zeros(n + 1, dtype=np.uint32)), to_dev(np.zeros(cap, dtype=np.uint32))
+    e2.match_batch_device(d[0], d[1], len(tn), d[2], d[3], d[4], n, row, ids, cap, tot)
+    total = e2.finish()
+    kv = O.KV(keys)
+    topics = [t.decode() for t in unpack(data, off)]
+    exp = U.semantic_rows(kv, tn, tt, topics)
+    assert L.bmq_exchange_fanout(e2.h, row, n, counts_all) == 0
+    totals = np.zeros(1, dtype=np.uint64)
+    assert L.bmq_exchange_csr(e2.h, row, ids, n, total, rows_all, ids_all, cap, totals.ctypes.data_as(C.c_void_p)) == 0
+    assert L.bmq_exchange_wait(e2.h) == 0
+    assert from_dev(counts_all, n, np.uint32).tolist() == [len(r) for r in exp]
+    assert int(totals[0]) == total == sum(len(r) for r in exp)
+    rp = from_dev(rows_all, n + 1, np.uint32)
+    got = from_dev(ids_all, total, np.uint32)
+    assert U.csr_rows(rp, got) == exp
+    small = np.zeros(1, dtype=np.uint64)
+    assert L.bmq_exchange_csr(e2.h, row, ids, n, total, rows_all, ids_all, 10, small.ctypes.data_as(C.c_void_p)) == -3  # NOSPACE, totals reported
+    assert int(small[0]) == total
+    for p in bufs:
+        hip.hipFree(p)
+    e2.close()
