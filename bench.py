@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--exchange", default="fanout", choices=["fanout", "ids", "none"],
                     help="N>1 exchange step: per-topic fan-out counts (what the reference sends upstream, DistWorkerCoProc.java:535-538) "
                          "or the complete CSR as an all-gatherv of route ids")
+    ap.add_argument("--exchange-impl", default="torch", choices=["torch", "lib"],
+                    help="who issues the collectives: torch.distributed (RCCL through PyTorch) or libbmq itself (bmq_exchange_*: RCCL "
+                         "loaded by the library; validated at world size 1 only on this pool, hence not the default)")
     ap.add_argument("--node-batch-steps", type=int, default=10,
                     help="N>1: steps of the extra node-wide measurement (one shared Zipf batch, device-side partition, hot tenants "
                          "split by filter, fan-out all-reduce); 0 = skip")
@@ -130,6 +133,20 @@ def main():
     d_total = torch.zeros(1, dtype=torch.int64, device=dev)
     ex_stream = torch.cuda.Stream(device=dev) if dist is not None else None
     ex_done = [None] * NBUF
+    use_lib_ex = dist is not None and args.exchange_impl == "lib" and args.exchange != "none"
+    if use_lib_ex:  # the library's own RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes
+        import ctypes as C
+        uid = C.create_string_buffer(128)
+        if rank == 0 and B._lib.lib().bmq_comm_unique_id(uid):
+            raise RuntimeError("bmq_comm_unique_id failed")
+        box = [uid.raw]
+        dist.broadcast_object_list(box, src=0)
+        if B._lib.lib().bmq_comm_init(eng.h, world, rank, box[0]):
+            raise RuntimeError("bmq_comm_init failed: %s" % B._lib.lib().bmq_last_error(eng.h))
+        d_counts_all = [torch.zeros(world * n, dtype=torch.int32, device=dev) for _ in range(NBUF)]
+        d_rows_all = [torch.zeros(world * (n + 1), dtype=torch.int32, device=dev) for _ in range(NBUF)]
+        d_ids_all = [torch.zeros(world * cap, dtype=torch.int32, device=dev) for _ in range(NBUF)] if args.exchange == "ids" else None
+        h_totals = np.zeros(world, dtype=np.uint64)
     torch.cuda.synchronize()
 
     def step(i):
@@ -137,7 +154,10 @@ def main():
         bt = batches[i % len(batches)]
         k = i % NBUF
         if ex_done[k] is not None:  # the exchange that still reads this buffer pair (issued two steps ago)
-            ex_done[k].synchronize()
+            if use_lib_ex:
+                B._lib.lib().bmq_exchange_wait(eng.h)
+            else:
+                ex_done[k].synchronize()
             ex_done[k] = None
         while True:
             eng.match_batch_device(d_tenants.data_ptr(), d_tenant_off.data_ptr(), n_tenants, bt[2].data_ptr(),
@@ -155,6 +175,19 @@ def main():
             from bifromq_amd import shard
             if d_ids[k].numel() < total:
                 raise RuntimeError("id buffer smaller than the batch result")
+            if use_lib_ex:  # asynchronous on the engine's exchange stream, behind this batch, overlapping the next one
+                L = B._lib.lib()
+                if args.exchange == "fanout":
+                    rc = L.bmq_exchange_fanout(eng.h, d_row[k].data_ptr(), n, d_counts_all[k].data_ptr())
+                else:
+                    if d_ids_all[k].numel() < world * d_ids[k].numel():  # the result buffer grew during warm-up
+                        d_ids_all[k] = torch.zeros(world * d_ids[k].numel(), dtype=torch.int32, device=dev)
+                    rc = L.bmq_exchange_csr(eng.h, d_row[k].data_ptr(), d_ids[k].data_ptr(), n, total, d_rows_all[k].data_ptr(),
+                                            d_ids_all[k].data_ptr(), d_ids_all[k].numel(), h_totals.ctypes.data)
+                if rc:
+                    raise RuntimeError("bmq_exchange failed: %d %s" % (rc, L.bmq_last_error(eng.h)))
+                ex_done[k] = True
+                return total
             with torch.cuda.stream(ex_stream):  # results are complete (finish() synchronised the engine stream)
                 if args.exchange == "fanout":  # 4 B per topic: every rank learns every topic's fan-out
                     shard.exchange_counts_weak(dist, d_row[k], world)
@@ -204,6 +237,8 @@ def main():
             raise RuntimeError("bmq_routes_apply failed: %d %s" % (rc, B._lib.lib().bmq_last_error(eng.h)))
 
     def barrier():
+        if use_lib_ex:
+            B._lib.lib().bmq_exchange_wait(eng.h)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -271,6 +306,7 @@ def main():
                    "index_bytes_this_rank": int(info.device_bytes), "publishes_per_batch_per_rank": n,
                    "batch_order": "random" if args.ungrouped else "grouped by tenant (one DistPack per tenant)",
                    "parallelism": "tenant-shard x%d" % world if world > 1 else "single GPU",
+                   "exchange_impl": None if dist is None else ("libbmq (bmq_exchange_*, RCCL loaded by the library)" if use_lib_ex else "torch.distributed (nccl backend = RCCL)"),
                    "exchange": ("none" if dist is None or args.exchange == "none" else
                                 "RCCL all-gather of per-topic fan-out counts (4 B/topic; the CSR stays on the GPU that matched: the reference "
                                 "replies fan-out per topic, DistWorkerCoProc.java:535-538), overlapped with the next batch's match"
