@@ -6,7 +6,8 @@
 // for the '$' rule, TRIE/NTopicFilterTrieNode.java:143-146 for '#' matching the parent level).
 //
 // Included only by bmq_engine.hip (hipcc --offload-arch=gfx950).  Work decomposition:
-//   k_resolve_tenants : one lane per distinct tenant of the batch -> region of the slot table
+//   k_prologue        : zeroes the batch counters and resolves the batch's tenant table, one lane per distinct tenant ->
+//                       region of the slot table + the tenant root's payload
 //   k_walk            : one wave per 64 topics, WALK_WAVES independent waves per workgroup (own LDS slice each).
 //                       Phase 1: the wave stages its topics' bytes in LDS with coalesced 16-byte loads, then walks
 //                       them level by level: every lane scans its own next level (LDS only), then ALL lanes look
@@ -249,7 +250,7 @@ __device__ __forceinline__ uint32_t global_word_at(const uint8_t* base, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_resolve_tenants
+// k_prologue
 // ------------------------------------------------------------------------------------------------------------
 constexpr TenantSlot EMPTY_TENANT{0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}};
 __device__ __forceinline__ bool tenant_known(const TenantSlot& t) { return (t.hash_lo | t.hash_hi) != 0; }

@@ -20,7 +20,7 @@ class MatchedRoutes:
     topic: str
     max_persistent_fanout: int
     max_group_fanout: int
-    route_ids: List[int] = field(default_factory=list)     # accepted routes, KV key order
+    route_ids: List[int] = field(default_factory=list)     # accepted routes, ascending id (the caps were applied in KV key order)
     throttled: List[Tuple[int, int]] = field(default_factory=list)  # (event type, rejected route id)
     persistent_fanout: int = 0
     group_fanout: int = 0

@@ -1,6 +1,7 @@
 """GPU parity tests of the dist-direction match path (HIP kernels behind the C ABI) against the CPU oracle.
 
-Bar: bit-exact -- for every (tenant, topic) the ascending list of route ids (= ranks of KV keys) equals the
+Bar: bit-exact -- for every (tenant, topic) the ascending list of route ids (ranks of the KV keys after a rebuild; stable
+handles mapped back through their keys after applies) equals the
 oracle's.  Known-answer tests are the reference's own (DWT/cache/TenantRouteMatcherTest.java:89-342,
 DWT/DistQoS0Test.java:95-150), re-run through the engine.
 """
@@ -109,6 +110,34 @@ def test_kat_group_fanout_throttling(eng):  # :305-342
     rows, ev = eng.match_all(TENANT, ["jobs/job1/progress"], 10, 1)
     assert _keys_of(eng, rows) == [[second]]  # "second comes before first ... by bucketing key" (:339-340)
     assert len(ev) == 1 and ev[0][0] == 1 and ev[0][3] == 1 and eng.route_key(ev[0][2]) == first
+
+
+def test_caps_follow_key_order_after_apply(eng):
+    """MatchedRoutes caps are first-come in KV KEY order (DW/cache/MatchedRoutes.java:87-141).  Routes subscribed through
+    bmq_routes_apply carry later ids than the routes of the last rebuild although their keys may sort FIRST: bmq_match_all must
+    order a row by key bytes before it applies a cap.  Expected = the oracle's matchAll over the sorted key set."""
+    rnd = random.Random(12)
+    base = [_normal(TENANT, "alarms/+/critical", 1, "recv%02d" % i, "d%d" % i) for i in range(10, 20)] + \
+           [B.route_key_from_mqtt(TENANT, "$share/g%02d/alarms/#" % i) for i in range(10, 16)]
+    late = [_normal(TENANT, "alarms/+/critical", 1, "recv%02d" % i, "d%d" % i) for i in range(0, 10)] + \
+           [B.route_key_from_mqtt(TENANT, "$share/g%02d/alarms/#" % i) for i in range(0, 10)] + \
+           [_normal(TENANT, "alarms/#", 0, "transient%d" % i, "d") for i in range(5)]
+    eng.rebuild(base)
+    rnd.shuffle(late)
+    eng.apply([(0, k) for k in late])
+    keys = sorted(base + late)
+    kv = O.KV(keys)
+    topic = "alarms/device1/critical"
+    for max_pf, max_gf in ((3, 2), (15, 100), (100, 4), (1, 1), (100, 100)):
+        exp = kv.match_all(TENANT, [topic], max_pf, max_gf)
+        rows, ev = eng.match_all(TENANT, [topic], max_pf, max_gf)
+        assert sorted(_keys_of(eng, rows)[0]) == sorted(keys[r] for r in exp.per_topic()[0]), (max_pf, max_gf)
+        # the throttle events name the same routes in the same (key) order, with the same type and maximum
+        assert [(t, ti, eng.route_key(rid), mx) for t, ti, rid, mx in ev] == [(t, ti, keys[rid], mx) for t, ti, rid, mx in exp.events]
+    # the rejected ones really are the LATER keys, not the later ids: with max_pf = 3 the three accepted persistent routes are recv00-02
+    rows, ev = eng.match_all(TENANT, [topic], 3, 100)
+    pers = sorted(k for k in _keys_of(eng, rows)[0] if O.parse_route_key(k)[0] == 1 and O.parse_route_key(k)[3].startswith("1\0"))
+    assert [O.parse_route_key(k)[3].split("\0")[1] for k in pers] == ["recv00", "recv01", "recv02"]
 
 
 def test_dist_qos0_vectors(eng):  # DWT/DistQoS0Test.java:95-150

@@ -1,5 +1,6 @@
 """CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, the product codec agrees
-with the oracle's, the host builder indexes every route exactly once, and matching refuses to run without a device."""
+with the oracle's, the index builder (run on host threads by a host-only engine) indexes every route exactly once, and matching
+refuses to run without a device."""
 import ctypes as C
 import os
 import random
