@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for ex in fanout ids; do timeout 600 python bench.py --no-cpu-baseline --no-host-path --steps 10 --exchange-selftest --exchange-impl lib --exchange $ex --node-batch-steps 0 > gpurun_out/b_lib_$ex.log 2>&1; tail -1 gpurun_out/b_lib_$ex.log | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$ex', round(d['value']/1e6,1), d['ms_per_step'], d['config']['exchange_impl'])" || tail -8 gpurun_out/b_lib_$ex.log; done
+timeout 600 python -m pytest tests/test_dist_gpu.py -x -q -m gpu -k "caps or kat" > gpurun_out/t_caps.log 2>&1; tail -15 gpurun_out/t_caps.log
