@@ -111,6 +111,15 @@ def main():
     kb, ko = w.keys_packed()
     eng.rebuild_raw(kb.ctypes.data, ko.ctypes.data, w.n_keys)
     t_build = time.time() - t0
+    # the same load from page-locked buffers (what a JNI caller hands over as direct buffers from bmq_host_alloc): the upload is
+    # DMA at PCIe speed instead of a staged copy of pageable memory
+    t_build_pinned = None
+    if world == 1 and not args.no_host_path:
+        pk, po_ = torch.from_numpy(kb).pin_memory(), torch.from_numpy(ko.astype(np.int32)).pin_memory()
+        t0 = time.time()
+        eng.rebuild_raw(pk.data_ptr(), po_.data_ptr(), w.n_keys)
+        t_build_pinned = time.time() - t0
+        del pk, po_
     info = eng.info()
 
     tdata, toff = w.tenants_packed()
@@ -324,7 +333,8 @@ def main():
                           "parsed and applied by the builder kernels on the engine stream (prepare, locate, sort, group); "
                           "time of the C-ABI call alone (returns when the device has applied the batch)"},
         "kernel_ms": {"k_walk": k_walk_ms, "k_expand": float(np.mean(expand_ms)), "all_kernels": float(np.mean(total_ms))},
-        "host_s": {"generate": t_gen, "rebuild": t_build},
+        "host_s": {"generate": t_gen, "rebuild": t_build, "rebuild_from_pinned_keys": t_build_pinned,
+                   "note": "bmq_rebuild = upload of the route keys + the GPU builder kernels (bulk load); wall time of the C-ABI call"},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": None,
                      # the same algorithmic bytes against ALL kernels of a batch and against the whole step (host sync included)
@@ -395,6 +405,35 @@ def node_batch(args, rank, world, local_rank, dev, dist, total_tenants, per_tena
     from bifromq_amd import shard
 
     n = args.topics
+    # A rank that fails while it sets up must not leave the others waiting in a collective: everybody reports in first.
+    setup_error = None
+    try:
+        state = _node_batch_setup(args, rank, world, local_rank, dev, total_tenants, per_tenant, mode, seed, n)
+    except Exception as ex:  # noqa: BLE001
+        setup_error, state = repr(ex), None
+    flag = torch.tensor([0 if setup_error is None else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        if state is not None:
+            state[0].close()
+        return {"skipped": "set-up failed on at least one rank" + ("" if setup_error is None else ": " + setup_error)}
+    eng, tn, tt, hot, n_split_keys, d_tenants, d_tenant_off, d_owner, d_data, d_off, d_tt = state
+    cap = 24 * n
+    d_row = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    m_sel = 0
+    return _node_batch_run(args, rank, world, dev, dist, n, eng, tn, tt, hot, n_split_keys, d_tenants, d_tenant_off, d_owner, d_data, d_off, d_tt,
+                           d_row, d_ids, d_total)
+
+
+def _node_batch_setup(args, rank, world, local_rank, dev, total_tenants, per_tenant, mode, seed, n):
+    import numpy as np
+    import torch
+
+    import bifromq_amd as B
+    from bifromq_amd import shard
+
     full = B.Workload(seed, total_tenants, per_tenant, mode)
     tn = full.tenants()
     data, off, tt = full.topics(seed + 77, n, grouped=not args.ungrouped)  # same batch on every rank
@@ -421,10 +460,18 @@ def node_batch(args, rank, world, local_rank, dev, dist, total_tenants, per_tena
     d_data = torch.from_numpy(data).to(dev)
     d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
     d_tt = torch.from_numpy(tt.astype(np.int32)).to(dev)
-    cap = 24 * n
-    d_row = torch.zeros(n + 1, dtype=torch.int32, device=dev)
-    d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
-    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    return eng, tn, tt, hot, n_split_keys, d_tenants, d_tenant_off, d_owner, d_data, d_off, d_tt
+
+
+def _node_batch_run(args, rank, world, dev, dist, n, eng, tn, tt, hot, n_split_keys, d_tenants, d_tenant_off, d_owner, d_data, d_off, d_tt,
+                    d_row, d_ids, d_total):
+    import numpy as np
+    import torch
+
+    import bifromq_amd as B
+    from bifromq_amd import shard
+
     m_sel = 0
 
     def step():
