@@ -98,6 +98,7 @@ struct bmq_engine {
     std::unique_ptr<DistIndex<HostExec>> hix;
     uint64_t epoch = 0;
     bool built = false;
+    bool kernel_events = false; // bmq_config.kernel_timing: HIP events around k_walk / k_expand of every dist batch (~4 us each)
 
     // Everything ONE batch in flight needs: per-batch scratch, staging of the host-buffer API, counters, events.  Two slots, so
     // that the asynchronous host API (bmq_match_submit / bmq_match_wait) can have the upload of batch i+1 and the download of
@@ -115,6 +116,7 @@ struct bmq_engine {
         hipEvent_t ev_in = nullptr, ev_done = nullptr; // inputs uploaded / batch (kernels + counter read-back) complete
         // the batch in flight (for bmq_match_finish / bmq_match_wait)
         bool pending = false;
+        bool timed = false; // this batch was launched with the per-kernel events (bmq_config.kernel_timing)
         int pending_kind = 0; // 0 dist, 1 retain
         bool submitted = false; // owned by a bmq_match_submit ticket
         bool api_held = false;  // the *_dev launch took the engine's api lock; bmq_match_finish gives it back
@@ -243,24 +245,25 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.qcap = e->cfg.wave_queue_cap;
     a.pcap = e->cfg.wave_pair_cap;
     hipStream_t s = e->stream;
+    e->cur->timed = e->kernel_events;
     HIPCHK(e, hipEventRecord(e->cur->ev[0], s));
     {
         const uint32_t n_super = (a.n_blocks >> SUPER_SHIFT) + 1;
         const uint32_t items = std::max<uint32_t>(std::max<uint32_t>(a.n_tenants, n_super), (uint32_t)(sizeof(SubAlloc) * 2 * N_SUB / 8));
         hipLaunchKernelGGL(k_prologue, dim3((items + 63) / 64), dim3(64), 0, s, a, n_super);
     }
-    HIPCHK(e, hipEventRecord(e->cur->ev[1], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
         const dim3 grid((a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
         if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_walk, grid, block, lds, s, a);
     }
-    HIPCHK(e, hipEventRecord(e->cur->ev[2], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[2], s));
     hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
-    HIPCHK(e, hipEventRecord(e->cur->ev[3], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[3], s));
     hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
-    HIPCHK(e, hipEventRecord(e->cur->ev[4], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[4], s));
     hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
     HIPCHK(e, hipEventRecord(e->cur->ev[5], s));
     HIPCHK(e, hipMemcpyAsync(e->cur->h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -338,8 +341,10 @@ int finish_dist(bmq_engine* e, uint64_t* out_total) {
         st.n_sorted_rows = c.sort_count;
         st.topic_bytes = c.topic_bytes;
         (void)hipEventElapsedTime(&st.ms_total, e->cur->ev[0], e->cur->ev[5]);
-        (void)hipEventElapsedTime(&st.ms_walk, e->cur->ev[1], e->cur->ev[2]);
-        (void)hipEventElapsedTime(&st.ms_expand, e->cur->ev[3], e->cur->ev[4]);
+        if (e->cur->timed) {
+            (void)hipEventElapsedTime(&st.ms_walk, e->cur->ev[1], e->cur->ev[2]);
+            (void)hipEventElapsedTime(&st.ms_expand, e->cur->ev[3], e->cur->ev[4]);
+        }
         if (out_total) *out_total = c.total_ids;
         if (c.status & ST_RANGE) return set_err(e, BMQ_E_RANGE, "batch produced >= 2^32 route ids");
         if (c.status & ST_NOSPACE) return set_err(e, BMQ_E_NOSPACE, "output buffer too small");
@@ -392,6 +397,8 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     auto e = std::make_unique<bmq_engine>();
     e->cfg = c;
     e->device = c.device;
+    e->kernel_events = c.kernel_timing != 0;
+    if (const char* v = getenv("BMQ_KERNEL_EVENTS")) e->kernel_events = atoi(v) != 0; // profiling experiments
     if (c.device >= 0) {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || c.device >= n) return BMQ_E_NODEVICE;
@@ -670,6 +677,13 @@ int bmq_sync(bmq_engine* e) {
     if (!e) return BMQ_E_INVAL;
     if (e->device < 0) return BMQ_E_NODEVICE;
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    return BMQ_OK;
+}
+
+int bmq_set_kernel_timing(bmq_engine* e, int on) {
+    if (!e) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->kernel_events = on != 0;
     return BMQ_OK;
 }
 

@@ -113,7 +113,7 @@ def java_string_hash(s) -> int:
 class Engine:
     """One engine per KV range replica (cf. DistWorkerCoProc's SubscriptionCache)."""
 
-    def __init__(self, device: int = 0, wave_queue_cap: int = 0, wave_pair_cap: int = 0, slow_scratch_mb: int = 0):
+    def __init__(self, device: int = 0, wave_queue_cap: int = 0, wave_pair_cap: int = 0, slow_scratch_mb: int = 0, kernel_timing: bool = False):
         L = _lib.lib()
         cfg = _lib.Config()
         cfg.struct_size = C.sizeof(_lib.Config)
@@ -121,6 +121,7 @@ class Engine:
         cfg.wave_queue_cap = wave_queue_cap
         cfg.wave_pair_cap = wave_pair_cap
         cfg.slow_scratch_mb = slow_scratch_mb
+        cfg.kernel_timing = 1 if kernel_timing else 0
         h = C.c_void_p()
         rc = L.bmq_engine_create(C.byref(cfg), C.byref(h))
         if rc:
@@ -297,6 +298,10 @@ class Engine:
 
     def sync(self):
         self._check(_lib.lib().bmq_sync(self.h))
+
+    def set_kernel_timing(self, on: bool):
+        """HIP events around k_walk / k_expand (stats().ms_walk / ms_expand); ~16 us per batch, off by default."""
+        self._check(_lib.lib().bmq_set_kernel_timing(self.h, 1 if on else 0))
 
     def stats(self) -> _lib.Stats:
         out = _lib.Stats()

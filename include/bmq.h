@@ -63,7 +63,9 @@ typedef struct bmq_config {
                                /* parked in global memory, never an error                                    */
     uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 160; 128..4096, x4)  */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
-    uint32_t reserved[8];
+    uint32_t kernel_timing;    /* 1: HIP events around k_walk / k_expand of every batch -> bmq_stats.ms_walk /  */
+                               /* ms_expand (costs ~4 us per event: 16 us per batch, measured); 0: only ms_total */
+    uint32_t reserved[7];
 } bmq_config;
 
 /* Counters of the last completed match batch (for roofline accounting). */
@@ -76,8 +78,8 @@ typedef struct bmq_stats {
     uint64_t n_sorted_rows;  /* rows that needed the element-level fix-up sort                              */
     uint64_t topic_bytes;    /* sum of topic lengths                                                        */
     float ms_total;          /* HIP-event time of the whole batch on the engine stream                      */
-    float ms_walk;           /* ... of the tokenise+walk kernel alone                                       */
-    float ms_expand;         /* ... of the expand kernel alone                                              */
+    float ms_walk;           /* ... of the tokenise+walk kernel alone (0 unless bmq_config.kernel_timing)   */
+    float ms_expand;         /* ... of the expand kernel alone (0 unless bmq_config.kernel_timing)          */
     float ms_reserved;
 } bmq_stats;
 
@@ -159,6 +161,8 @@ int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t*
 int bmq_match_finish(bmq_engine* e, uint64_t* out_total);
 int bmq_sync(bmq_engine* e);
 int bmq_stats_get(const bmq_engine* e, bmq_stats* out);
+/* switches bmq_config.kernel_timing at run time (profilers / bench.py); takes effect with the next batch */
+int bmq_set_kernel_timing(bmq_engine* e, int on);
 /* The hipStream_t the engine launches on (as void*), so a harness can bracket it with HIP events. */
 void* bmq_stream(const bmq_engine* e);
 

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_dist_gpu.py -x -q -m gpu -k "caps or kat" > gpurun_out/t_caps.log 2>&1; tail -15 gpurun_out/t_caps.log
+for ev in 0 1 0; do for n in 1000000 10000; do BMQ_KERNEL_EVENTS=$ev timeout 300 python bench.py --no-cpu-baseline --no-host-path --steps 40 --topics $n 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('events $ev', $n, round(d['value']/1e6,1), round(d['ms_per_step'],4), round(d['kernel_ms']['all_kernels'],4))"; done; done
