@@ -408,7 +408,8 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
     const uint32_t tpw = 1u << a.tpw_shift;
     const uint32_t t = (blk << a.tpw_shift) + lane;
     const bool valid = lane < tpw && t < a.n_topics;
-    const unsigned long long clk0 = a.dbg_wave ? __builtin_amdgcn_s_memtime() : 0ull;
+    const bool dbg_w = a.dbg_wave && (a.debug_flags & 2u);
+    const unsigned long long clk0 = dbg_w ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- phase 1: tokenise ---------------------------------------------------------------------------------------------
     const uint32_t t_first = blk << a.tpw_shift, t_end = min(t_first + tpw, a.n_topics);
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
         base = (uint32_t)sb;
         return fits;
     };
-    const unsigned long long clk1 = a.dbg_wave ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long clk1 = dbg_w ? __builtin_amdgcn_s_memtime() : 0ull;
     // Round 0 visits the tenant roots: their slot payload came with the directory entry, so no line is fetched.
     bool boot = !(a.debug_flags & 1u);
     while (boot || tail || qs_len) {
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
     }
 
     // ---- phase 3: ranges grouped by topic -> global; per-topic bookkeeping --------------------------------------
-    const unsigned long long clk2 = a.dbg_wave ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long clk2 = dbg_w ? __builtin_amdgcn_s_memtime() : 0ull;
     for (uint32_t i = lane; i < pcount; i += 64) { // counted here, once per range, instead of two LDS atomics per match
         atomicAdd(&cnt_pairs[p_topic[i]], 1u);
         atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
         a.wave_sums[blk] = wsum;
         if (wsum) atomicAdd(&a.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], wsum);
         a.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
-        if (a.dbg_wave) {
+        if (dbg_w) {
             const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
             a.dbg_wave[blk] = make_uint4((uint32_t)(clk1 - clk0), (uint32_t)(clk2 - clk1), (uint32_t)(clk3 - clk2), rounds | (items << 8));
         }
@@ -814,25 +815,59 @@ __device__ __forceinline__ uint32_t range_first_id(const DistIndexView& ix, cons
     return (r.count & RANGE_INDIRECT) ? ix.route_pos[r.begin] : r.begin;
 }
 
-// The 64 rows of a wave are one contiguous piece of the output.  Their ranges are laid out in LDS in output order with
-// the exclusive prefix of their lengths; then every lane produces output elements j, j+64, ... by locating the range
-// that covers j (binary search in LDS): stores are fully coalesced and all lanes stay busy whatever the mix of range
-// lengths (a 5000-subscriber filter next to 60 singletons).
-__global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
-    __shared__ uint32_t s_begin[EXP_WAVES][EXP_K], s_cnt[EXP_WAVES][EXP_K], s_off[EXP_WAVES][EXP_K + 8], s_row[EXP_WAVES][EXP_K];
+// The 64 rows of a wave are one contiguous piece of the output.  Their ranges are laid out in LDS in output order (whole rows per
+// pass) with the exclusive prefix of their lengths.  Long ranges (>= EXP_LONG ids) are streamed by the whole wave.  The short ones
+// are flattened: a bitmap marks the element at which every short range starts, so the range that covers element u is
+// popcount(bitmap[0..u]) - 1 -- one broadcast LDS read per 64 elements instead of a binary search per element (measured with
+// BMQ_DEBUG=4 on C3: generation 28 k of 54 k clocks per wave with the search).  Stores are coalesced and all lanes stay busy
+// whatever the mix of range lengths (a 5000-subscriber filter next to 60 singletons).
+constexpr uint32_t EXP_FLAG_WORDS = (EXP_K * (EXP_LONG - 1) + 63) / 64 + 1;
+constexpr uint32_t EXP_EPL = EXP_K / 64; // entries per lane in the prefix step
+static_assert(EXP_K % 64 == 0 && EXP_K * (EXP_LONG - 1) < 65536, "short-range space: offsets are packed into 16 bits below");
+
+// compare-exchange of (key, begin, count) triples held in registers
+__device__ __forceinline__ void cex(uint32_t& ka, uint32_t& ba, uint32_t& ca, uint32_t& kb, uint32_t& bb, uint32_t& cb) {
+    const bool sw = kb < ka;
+    const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb, b0 = sw ? bb : ba, b1 = sw ? ba : bb, c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+    ka = k0, kb = k1, ba = b0, bb = b1, ca = c0, cb = c1;
+}
+
+#ifndef BMQ_EXP_MIN_WAVES
+#define BMQ_EXP_MIN_WAVES 4
+#endif
+#ifndef BMQ_EXP_PREFETCH
+#define BMQ_EXP_PREFETCH 1
+#endif
+__global__ __launch_bounds__(EXP_WAVES * 64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) {
+    __shared__ uint32_t s_begin[EXP_WAVES][EXP_K], s_cnt[EXP_WAVES][EXP_K], s_off[EXP_WAVES][EXP_K + 8], s_delta[EXP_WAVES][EXP_K];
+    __shared__ unsigned long long s_flag[EXP_WAVES][EXP_FLAG_WORDS];
+    __shared__ uint32_t s_ind[EXP_WAVES][EXP_K / 32];
     __shared__ uint32_t s_bad[EXP_WAVES][64];
+    __shared__ unsigned long long s_rs[EXP_WAVES][2][EXP_EPL];
+    __shared__ uint32_t s_lpo[EXP_WAVES][64], s_lpx[EXP_WAVES][64];
+    __shared__ uint8_t s_nz[EXP_WAVES][64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t blk = blockIdx.x * EXP_WAVES + wave; // every wave owns one 64-row block and its own LDS slice
     if (blk >= a.n_blocks) return;
     uint32_t* r_begin = s_begin[wave];
     uint32_t* r_cnt = s_cnt[wave];
     uint32_t* r_off = s_off[wave];
-    uint32_t* r_row = s_row[wave];
+    uint32_t* c_delta = s_delta[wave];       // per SHORT range, in order: first id (or route_pos index) - its start in the short space
+    unsigned long long* flag = s_flag[wave]; // bit u: a short range starts at element u of the pass's short-range space
+    uint32_t* c_ind = s_ind[wave];           // bit o: short range o is RANGE_INDIRECT
+    uint32_t* l_po = s_lpo[wave];            // per row: where its range list starts in `pairs`, and in the wave's concatenated list
+    uint32_t* l_px = s_lpx[wave];
+    uint8_t* nz = s_nz[wave];                // the rows that have ranges, in order
     uint32_t* row_bad = s_bad[wave];
     const uint32_t t = (blk << a.tpw_shift) + lane;
     const bool valid = lane < (1u << a.tpw_shift) && t < a.n_topics;
+    const bool dbg_x = a.dbg_wave && (a.debug_flags & 4u); // BMQ_DEBUG=4: per-wave phase clocks of k_expand
+    const unsigned long long xc0 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long xc_load = 0, xc_scan = 0, xc_gen = 0;
     const uint32_t status = a.ctr->status;
     const uint32_t nr = valid ? a.route_cnt[t] : 0u;
+    const uint32_t po = valid ? a.pair_off[t] : 0u; // requested together with the counts: one round trip less in front of the ranges
+    const uint32_t np = valid ? a.pair_cnt[t] : 0u;
     uint32_t wtotal;
     const uint32_t excl = wave_excl_scan(nr, lane, wtotal);
     // ids in front of this wave's rows: whole super-blocks + the waves of this wave's own super-block before it
@@ -858,46 +893,130 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
         if (t == a.n_topics - 1) a.out_row_ptr[a.n_topics] = (uint32_t)(row + nr);
     }
     if (!writable || wtotal == 0) return;
-    const uint32_t po = valid ? a.pair_off[t] : 0u;
-    const uint32_t np = valid ? a.pair_cnt[t] : 0u;
     uint32_t ptotal;
     const uint32_t pexcl = wave_excl_scan(np, lane, ptotal);
-    const bool one_pass = ptotal <= EXP_K; // all ranges of the wave fit one LDS layout: they are ordered there, in LDS
-    // order this topic's ranges by first id (usually 1-5 ranges; already ordered lists are left alone)
-    if (!one_pass && np > 1 && np <= SORT_PAIRS) {
-        MatchRange* pr = a.pairs + po;
-        for (uint32_t i = 1; i < np; i++) {
-            const MatchRange x = pr[i];
-            const uint32_t kx = range_first_id(a.ix, x);
-            uint32_t j = i;
-            while (j > 0 && range_first_id(a.ix, pr[j - 1]) > kx) {
-                pr[j] = pr[j - 1];
-                j--;
-            }
-            if (j != i) pr[j] = x;
-        }
+    // k_walk lays the ranges of a wave's 64 rows out as ONE contiguous piece of `pairs`, row after row (rows finished by
+    // k_walk_slow live elsewhere: then every lane copies its own list)
+    const unsigned long long m_np = __ballot(np != 0);
+    const uint32_t first_l = m_np ? (uint32_t)__ffsll((long long)m_np) - 1u : 0u;
+    const uint32_t po0 = __shfl(po, first_l) - __shfl(pexcl, first_l);
+    const bool contiguous = __all(np == 0 || po == po0 + pexcl);
+#if BMQ_EXP_PREFETCH
+    MatchRange pf[EXP_EPL]; // the ranges of the coming pass (contiguous layout only)
+#pragma unroll
+    for (uint32_t i = 0; i < EXP_EPL; i++) {
+        pf[i] = MatchRange{0u, 0u};
+        const uint32_t k = lane + 64 * i;
+        if (contiguous && k < ptotal) pf[i] = a.pairs[po0 + k];
     }
+#endif
     row_bad[lane] = 0;
+    l_po[lane] = po;
+    l_px[lane] = pexcl;
+    if (np) nz[rank_below(m_np)] = (uint8_t)lane;
+    for (uint32_t i = lane; i < EXP_FLAG_WORDS; i += 64) flag[i] = 0ull;
+    if (lane < EXP_K / 32) c_ind[lane] = 0u;
+    if (lane < 2 * EXP_EPL) (&s_rs[wave][0][0])[lane] = 0ull;
     wave_sync();
+    const unsigned long long xc1 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t pass = 0;
+    // the row an entry of the current pass belongs to: rows with ranges are counted through the pass's row-start bitmap
+    auto row_of = [&](const unsigned long long* rs, uint32_t ord0, uint32_t e) -> uint32_t {
+        uint32_t c = (uint32_t)__popcll(rs[e >> 6] & ((2ull << (e & 63u)) - 1ull));
+        for (uint32_t w = 0; w < (e >> 6); w++) c += (uint32_t)__popcll(rs[w]);
+        return nz[ord0 + c - 1u];
+    };
     unsigned long long out_done = 0; // output elements produced by earlier LDS passes
-    uint32_t carry_row = 64, carry_last = 0;
-    for (uint32_t k0 = 0; k0 < ptotal; k0 += EXP_K) {
-        const uint32_t kn = min(EXP_K, ptotal - k0);
-        // every lane copies the part of its own range list that falls into [k0, k0 + kn)
+    uint32_t carry_last = 0;
+    for (uint32_t k0 = 0; k0 < ptotal;) {
+        const unsigned long long xp0 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
+        // A pass takes EXP_K ranges, but never a part of a row that is ordered here (<= SORT_PAIRS ranges: usually 1-5; longer
+        // lists are left to the order check + k_sort_rows): such a row waits for the next pass.
+        uint32_t kn = min(EXP_K, ptotal - k0);
         {
-            const uint32_t lo = pexcl > k0 ? pexcl : k0, hi = min(pexcl + np, k0 + kn);
-            for (uint32_t k = lo; k < hi; k++) {
-                const MatchRange r = a.pairs[po + (k - pexcl)];
-                r_begin[k - k0] = r.begin;
-                r_cnt[k - k0] = r.count;
-                r_row[k - k0] = lane;
+            const uint32_t kend = k0 + kn;
+            const unsigned long long m = __ballot(pexcl < kend && kend < pexcl + np && np <= SORT_PAIRS);
+            if (m) kn = __shfl(pexcl, (int)__ffsll((long long)m) - 1) - k0;
+        }
+        const uint32_t lo = pexcl > k0 ? pexcl : k0, hi = min(pexcl + np, k0 + kn);
+        // row-start bitmap of this pass: bit e = a row's list starts (or, for e = 0, continues) at entry e
+        unsigned long long* rs = s_rs[wave][pass & 1u];
+        if (lane < EXP_EPL) s_rs[wave][(pass + 1u) & 1u][lane] = 0ull; // the next pass's bitmap
+        if (lo < hi) atomicOr(&rs[(lo - k0) >> 6], 1ull << ((lo - k0) & 63u));
+        const unsigned long long m_k0 = __ballot(np != 0 && pexcl <= k0 && k0 < pexcl + np); // the row entry 0 belongs to
+        const uint32_t lk = (uint32_t)__ffsll((long long)m_k0) - 1u;
+        const uint32_t ord0 = (uint32_t)__popcll(m_np & ((1ull << lk) - 1ull));
+        const bool continues = __shfl(pexcl, lk) < k0; // entry 0 continues the last row of the previous pass
+        pass++;
+        if (contiguous) { // one request per 64 ranges
+#if BMQ_EXP_PREFETCH
+#pragma unroll
+            for (uint32_t i = 0; i < EXP_EPL; i++) {
+                const uint32_t k = lane + 64 * i;
+                if (k < kn) {
+                    r_begin[k] = pf[i].begin;
+                    r_cnt[k] = pf[i].count;
+                }
             }
-            if (one_pass && np > 1 && np <= SORT_PAIRS) { // insertion sort of this lane's own segment, in LDS
-                for (uint32_t i = pexcl + 1; i < pexcl + np; i++) {
+            // the next pass's ranges are requested now and land while this pass is produced
+#pragma unroll
+            for (uint32_t i = 0; i < EXP_EPL; i++) {
+                const uint32_t k = k0 + kn + lane + 64 * i;
+                if (k < ptotal) pf[i] = a.pairs[po0 + k];
+            }
+#else
+            for (uint32_t k = lane; k < kn; k += 64) {
+                const MatchRange r = a.pairs[po0 + k0 + k];
+                r_begin[k] = r.begin;
+                r_cnt[k] = r.count;
+            }
+#endif
+            wave_sync();
+        } else { // every row has its own list (retain direction, rows finished by k_walk_slow): gathered, still 64 ranges per request
+            wave_sync();
+            for (uint32_t e = lane; e < kn; e += 64) {
+                const uint32_t l = row_of(rs, ord0, e);
+                const MatchRange r = a.pairs[l_po[l] + (k0 + e - l_px[l])];
+                r_begin[e] = r.begin;
+                r_cnt[e] = r.count;
+            }
+            wave_sync();
+        }
+        // order this lane's own (whole) segment by first id
+        if (np > 1 && np <= SORT_PAIRS && lo < hi) {
+            const uint32_t sb = pexcl - k0;
+            if (np <= 8) { // in registers: one round of LDS reads, a 19-comparator network, one round of writes
+                uint32_t kk[8], bb[8], cc[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    const bool in = i < np;
+                    bb[i] = in ? r_begin[sb + i] : 0u;
+                    cc[i] = in ? r_cnt[sb + i] : 0u;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++)
+                    kk[i] = i < np ? ((cc[i] & RANGE_INDIRECT) ? a.ix.route_pos[bb[i]] : bb[i]) : 0xFFFFFFFFu;
+#define BMQ_CEX(x, y) cex(kk[x], bb[x], cc[x], kk[y], bb[y], cc[y])
+                BMQ_CEX(0, 1); BMQ_CEX(2, 3); BMQ_CEX(4, 5); BMQ_CEX(6, 7);
+                BMQ_CEX(0, 2); BMQ_CEX(1, 3); BMQ_CEX(4, 6); BMQ_CEX(5, 7);
+                BMQ_CEX(1, 2); BMQ_CEX(5, 6); BMQ_CEX(0, 4); BMQ_CEX(3, 7);
+                BMQ_CEX(1, 5); BMQ_CEX(2, 6);
+                BMQ_CEX(1, 4); BMQ_CEX(3, 6);
+                BMQ_CEX(2, 4); BMQ_CEX(3, 5);
+                BMQ_CEX(3, 4);
+#undef BMQ_CEX
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++)
+                    if (i < np) {
+                        r_begin[sb + i] = bb[i];
+                        r_cnt[sb + i] = cc[i];
+                    }
+            } else { // insertion sort in LDS
+                for (uint32_t i = sb + 1; i < sb + np; i++) {
                     const uint32_t xb = r_begin[i], xc = r_cnt[i];
                     const uint32_t kx = (xc & RANGE_INDIRECT) ? a.ix.route_pos[xb] : xb;
                     uint32_t j = i;
-                    while (j > pexcl) {
+                    while (j > sb) {
                         const uint32_t yb = r_begin[j - 1], yc = r_cnt[j - 1];
                         if (((yc & RANGE_INDIRECT) ? a.ix.route_pos[yb] : yb) <= kx) break;
                         r_begin[j] = yb;
@@ -912,21 +1031,41 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
             }
         }
         wave_sync();
-        // exclusive prefix of the range lengths: 16 consecutive entries per lane + one wave scan
+        const unsigned long long xp1 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
+        uint32_t stot; // short ranges of this pass: elements | ranges << 16
+        // exclusive prefixes: EXP_EPL consecutive entries per lane + wave scans.  Every range gets its output offset; a SHORT range
+        // also its ordinal among the short ranges, its start in the short-range space (marked in the bitmap) and c_delta.
         {
-            uint32_t s = 0;
-            const uint32_t e0 = lane * (EXP_K / 64);
-            for (uint32_t i = 0; i < EXP_K / 64; i++) {
+            uint32_t eb[EXP_EPL], ec[EXP_EPL];
+            uint32_t s = 0, ss = 0; // ss: short length sum | short count << 16
+            const uint32_t e0 = lane * EXP_EPL;
+#pragma unroll
+            for (uint32_t i = 0; i < EXP_EPL; i++) {
                 const uint32_t e = e0 + i;
-                s += e < kn ? (r_cnt[e] & ~RANGE_INDIRECT) : 0u;
+                eb[i] = e < kn ? r_begin[e] : 0u;
+                ec[i] = e < kn ? r_cnt[e] : 0u;
+                const uint32_t len = ec[i] & ~RANGE_INDIRECT;
+                s += len;
+                if (len != 0 && len < EXP_LONG) ss += len + (1u << 16);
             }
             uint32_t tot;
             uint32_t run = wave_excl_scan(s, lane, tot);
-            for (uint32_t i = 0; i < EXP_K / 64; i++) {
+            const uint32_t srun = wave_excl_scan(ss, lane, stot);
+            uint32_t us = srun & 0xFFFFu, ord = srun >> 16;
+#pragma unroll
+            for (uint32_t i = 0; i < EXP_EPL; i++) {
                 const uint32_t e = e0 + i;
                 if (e < kn) {
+                    const uint32_t len = ec[i] & ~RANGE_INDIRECT;
                     r_off[e] = run;
-                    run += r_cnt[e] & ~RANGE_INDIRECT;
+                    run += len;
+                    if (len != 0 && len < EXP_LONG) {
+                        c_delta[ord] = eb[i] - us;
+                        if (ec[i] & RANGE_INDIRECT) atomicOr(&c_ind[ord >> 5], 1u << (ord & 31u));
+                        atomicOr(&flag[us >> 6], 1ull << (us & 63u));
+                        us += len;
+                        ord++;
+                    }
                 }
             }
             if (lane == 63) r_off[kn] = tot;
@@ -935,27 +1074,29 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
         const uint32_t T = r_off[kn];
         uint32_t* out = a.out_ids + wbase + out_done;
         // ids ascend inside a range by construction, so order is checked at range boundaries only: the first id of a range
-        // against the last id of the previous range of the same row (also across LDS passes: carry_*)
+        // against the last id of the previous range of the same row (also across LDS passes: carry_last)
         for (uint32_t e = lane; e < kn; e += 64) {
-            const uint32_t rr = r_row[e];
-            const uint32_t fid = (r_cnt[e] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[e]] : r_begin[e];
-            uint32_t prow = carry_row, plast = carry_last;
-            if (e > 0) {
-                const uint32_t c = r_cnt[e - 1] & ~RANGE_INDIRECT;
-                prow = r_row[e - 1];
-                plast = (r_cnt[e - 1] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[e - 1] + c - 1] : r_begin[e - 1] + c - 1;
+            const bool same_row = e ? !((rs[e >> 6] >> (e & 63u)) & 1ull) : continues;
+            if (same_row) {
+                const uint32_t fid = (r_cnt[e] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[e]] : r_begin[e];
+                uint32_t plast = carry_last;
+                if (e > 0) {
+                    const uint32_t c = r_cnt[e - 1] & ~RANGE_INDIRECT;
+                    plast = (r_cnt[e - 1] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[e - 1] + c - 1] : r_begin[e - 1] + c - 1;
+                }
+                if (fid <= plast) row_bad[row_of(rs, ord0, e)] = 1;
             }
-            if (prow == rr && fid <= plast) row_bad[rr] = 1;
         }
         {
             const uint32_t c = r_cnt[kn - 1] & ~RANGE_INDIRECT;
-            carry_row = r_row[kn - 1];
             carry_last = (r_cnt[kn - 1] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[kn - 1] + c - 1] : r_begin[kn - 1] + c - 1;
         }
-        // element generation: runs of short ranges are flattened (every lane locates its range in LDS), long ranges are
-        // streamed by the whole wave with no per-element lookup.  (Measured and dropped in round 2: one lane per short range +
-        // wave-streaming of everything above 4 / 8 / 16 ids -- C3 k_expand 0.172 / 0.130 / 0.119 ms against 0.117 ms here, C2 1.47
-        // against 1.22 ms: streaming the many medium ranges one after the other costs more than the LDS searches save.)
+        const unsigned long long xp2 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
+        // element generation.  (Measured and dropped in round 2: one lane per short range + wave-streaming of everything above
+        // 4 / 8 / 16 ids -- C3 k_expand 0.172 / 0.130 / 0.119 ms, C2 1.47 against 1.22 ms: streaming the many medium ranges one after
+        // the other costs more than the LDS lookups save.)
+        uint32_t ub = 0;          // short-range space: start of the current run of short ranges
+        uint32_t fc = 0, fo = 0;  // fo = short ranges that start before bitmap word fc
         for (uint32_t k = 0; k < kn;) {
             uint32_t kl = kn; // first long range at or after k
             for (uint32_t c0 = k; c0 < kn && kl == kn; c0 += 64) {
@@ -963,21 +1104,20 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
                 if (m) kl = c0 + (uint32_t)__ffsll((long long)m) - 1;
             }
             if (kl > k) {
-                const uint32_t jhi = r_off[kl];
-                uint32_t kc = k;
-                for (uint32_t j = r_off[k] + lane; j < jhi; j += 64) {
-                    if (r_off[kc + 1] <= j) {
-                        uint32_t lo = kc + 1, hi = kl; // largest index in [kc + 1, kl) with r_off <= j
-                        while (hi - lo > 1) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (r_off[mid] <= j) lo = mid;
-                            else hi = mid;
-                        }
-                        kc = lo;
+                const uint32_t jb = r_off[k];
+                const uint32_t ue = ub + (r_off[kl] - jb);
+                for (uint32_t c = ub & ~63u; c < ue; c += 64) {
+                    while (fc < (c >> 6)) fo += (uint32_t)__popcll(flag[fc++]);
+                    const unsigned long long m = flag[c >> 6];
+                    const uint32_t u = c + lane;
+                    if (u >= ub && u < ue) {
+                        const uint32_t o = fo + (uint32_t)__popcll(m & ((2ull << lane) - 1ull)) - 1u;
+                        const uint32_t v = c_delta[o] + u;
+                        const bool ind = (c_ind[o >> 5] >> (o & 31u)) & 1u;
+                        out[jb + (u - ub)] = ind ? a.ix.route_pos[v] : v;
                     }
-                    const uint32_t o = j - r_off[kc];
-                    out[j] = (r_cnt[kc] & RANGE_INDIRECT) ? a.ix.route_pos[r_begin[kc] + o] : r_begin[kc] + o;
                 }
+                ub = ue;
             }
             if (kl < kn) {
                 const uint32_t b = r_begin[kl], cf = r_cnt[kl], c = cf & ~RANGE_INDIRECT;
@@ -999,8 +1139,18 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void k_expand(BatchArgs a) {
             k = kl + 1;
         }
         out_done += T;
+        k0 += kn;
         wave_sync();
+        // only what this pass marked is cleared for the next one
+        for (uint32_t i = lane; i <= ((stot & 0xFFFFu) >> 6); i += 64) flag[i] = 0ull;
+        if (lane < EXP_K / 32 && lane <= (stot >> 21)) c_ind[lane] = 0u;
+        wave_sync();
+        if (dbg_x) {
+            const unsigned long long xp3 = __builtin_amdgcn_s_memtime();
+            xc_load += xp1 - xp0, xc_scan += xp2 - xp1, xc_gen += xp3 - xp2;
+        }
     }
+    if (dbg_x && lane == 0) a.dbg_wave[blk] = make_uint4((uint32_t)(xc1 - xc0), (uint32_t)xc_load, (uint32_t)xc_scan, (uint32_t)xc_gen);
     if (valid && row_bad[lane] && nr > 1) {
         const uint32_t sp = atomicAdd(&a.ctr->sort_count, 1u);
         if (sp < a.sort_cap) a.sort_list[sp] = t;

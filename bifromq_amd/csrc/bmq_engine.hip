@@ -237,7 +237,7 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
         const char* dbg = getenv("BMQ_DEBUG");
         a.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
         a.dbg_wave = nullptr;
-        if (a.debug_flags & 2u) {
+        if (a.debug_flags & 6u) {
             HIPCHK(e, e->cur->b_dbg_wave.ensure(sizeof(uint4) * std::max(a.n_blocks, 1u)));
             a.dbg_wave = e->cur->b_dbg_wave.as<uint4>();
         }
@@ -282,6 +282,13 @@ static void print_wave_debug(bmq_engine* e) {
     if (!a.dbg_wave || !a.n_blocks) return;
     std::vector<uint4> h(a.n_blocks);
     if (hipMemcpy(h.data(), a.dbg_wave, sizeof(uint4) * a.n_blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (a.debug_flags & 4u) { // k_expand: head (row pointers, wave base) | range load + order | prefix + order check | id generation
+        double p[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < a.n_blocks; i++) p[0] += h[i].x, p[1] += h[i].y, p[2] += h[i].z, p[3] += h[i].w;
+        fprintf(stderr, "[bmq] k_expand waves=%u clocks/wave: head %.0f load+order %.0f prefix+check %.0f generate %.0f\n", a.n_blocks,
+                p[0] / a.n_blocks, p[1] / a.n_blocks, p[2] / a.n_blocks, p[3] / a.n_blocks);
+        return;
+    }
     double s1 = 0, s2 = 0, s3 = 0, sr = 0, si = 0;
     std::vector<uint32_t> r(a.n_blocks), c2(a.n_blocks);
     for (uint32_t i = 0; i < a.n_blocks; i++) {
@@ -299,7 +306,7 @@ static void print_wave_debug(bmq_engine* e) {
 int finish_dist(bmq_engine* e, uint64_t* out_total) {
     for (int attempt = 0; attempt < 8; attempt++) {
         HIPCHK(e, hipEventSynchronize(e->cur->ev_done)); // this batch only: a later batch may already be running behind it
-        if (e->cur->last.debug_flags & 2u) print_wave_debug(e);
+        if (e->cur->last.debug_flags & 6u) print_wave_debug(e);
         const Counters c = *e->cur->h_ctr;
         const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST);
         if (grow) {
