@@ -95,7 +95,8 @@ struct BatchArgs {
     unsigned long long pair_cap;
     SubAlloc* subs;          // [2 * N_SUB] allocators of `pairs` (first N_SUB) and of `spill` (second N_SUB)
     unsigned long long* super_sums; // [(n_blocks >> SUPER_SHIFT + 1) * SUPER_STRIDE] ids per 2^SUPER_SHIFT blocks (zeroed by k_prologue)
-    uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, 0}; summed by k_sort_rows
+    uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, 0} written by k_walk; the last
+                             // k_expand wave of every super-block sums its 256 records into ctr (null: retain direction)
     uint4* spill;            // LDS range buffer flushes: {begin, count, topic-local, 0}
     unsigned long long spill_cap;
     unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block
@@ -263,12 +264,16 @@ __global__ __launch_bounds__(64) void k_prologue(BatchArgs a, uint32_t n_super) 
     if (i < sizeof(SubAlloc) * 2 * N_SUB / 8) reinterpret_cast<unsigned long long*>(a.subs)[i] = 0ull;
     if (i < n_super) a.super_sums[(size_t)i * SUPER_STRIDE] = 0ull;
     if (i >= a.n_tenants) return;
-    // the tenant id's bytes, four at a time (a byte-wise loop is one memory latency per byte: measured 22 us for 12-byte ids)
+    // The tenant id's bytes: the first 16 are requested together (a byte-wise loop is one memory latency per byte: measured 22 us
+    // for 12-byte ids; word by word still one latency per word -- the kernel is a chain of dependent round trips and nothing else)
     const uint8_t* base = a.tenants;
     const uint32_t beg = a.tenant_off[i], end = a.tenant_off[i + 1], len = end - beg;
+    uint32_t w4[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) w4[k] = 4 * k < len ? global_word_at(base, beg + 4 * k) : 0u;
     uint64_t h = TENANT_HASH_INIT;
     for (uint32_t k = 0; k < len; k += 4) {
-        const uint32_t w = global_word_at(base, beg + k), nb = min(4u, len - k);
+        const uint32_t w = k < 16 ? w4[k >> 2] : global_word_at(base, beg + k), nb = min(4u, len - k);
         for (uint32_t j = 0; j < nb; j++) h = tenant_hash_step(h, (w >> (8 * j)) & 0xFFu);
     }
     h = tenant_hash_final(h);
@@ -279,10 +284,15 @@ __global__ __launch_bounds__(64) void k_prologue(BatchArgs a, uint32_t n_super) 
         const TenantSlot t = a.ix.tenants[d];
         if (!tenant_known(t)) break;
         if (t.hash_lo == lo && t.hash_hi == hi && t.name_len == len) { // the id's bytes decide
+            uint32_t n4[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) n4[k] = 4 * k < len ? global_word_at(a.ix.tenant_names, t.name_off + 4 * k) : 0u;
             bool eq = true;
             for (uint32_t k = 0; k < len && eq; k += 4) {
                 const uint32_t nb = min(4u, len - k), m = nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-                eq = ((global_word_at(a.ix.tenant_names, t.name_off + k) ^ global_word_at(base, beg + k)) & m) == 0;
+                const uint32_t x = k < 16 ? n4[k >> 2] : global_word_at(a.ix.tenant_names, t.name_off + k);
+                const uint32_t y = k < 16 ? w4[k >> 2] : global_word_at(base, beg + k);
+                eq = ((x ^ y) & m) == 0;
             }
             if (eq) {
                 info = t;
@@ -676,6 +686,8 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
     if (lane == 0) {
         a.wave_sums[blk] = wsum;
         if (wsum) atomicAdd(&a.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], wsum);
+        // statistics: a plain store per wave.  (Atomics were measured twice: on the batch counters they set the kernel's duration,
+        // three more per wave on the super-block's line still cost +20 us per 1 M topics and +7 us per 10 k.)
         a.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
         if (dbg_w) {
             const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
@@ -802,7 +814,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr uint32_t SORT_PAIRS = 32;  // range lists up to this length are ordered in place (insertion sort)
 #ifndef BMQ_EXP_K
-#define BMQ_EXP_K 256 // measured: 256 -> k_expand 0.112 ms on C3, 512 -> 0.123 ms; C2 unchanged, C4 +5 %
+#define BMQ_EXP_K 320 // measured (round 2, 4 workgroups per CU by VGPRs): 256 -> C3 0.099 / C2 1.128 / C4 0.689 ms, 320 -> 0.098 / 1.045 / 0.687, 384 -> 0.100 / 1.083 / 0.700 (LDS then allows 3 workgroups)
 #endif
 #ifndef BMQ_EXP_WAVES
 #define BMQ_EXP_WAVES 4
@@ -821,7 +833,7 @@ __device__ __forceinline__ uint32_t range_first_id(const DistIndexView& ix, cons
 // popcount(bitmap[0..u]) - 1 -- one broadcast LDS read per 64 elements instead of a binary search per element (measured with
 // BMQ_DEBUG=4 on C3: generation 28 k of 54 k clocks per wave with the search).  Stores are coalesced and all lanes stay busy
 // whatever the mix of range lengths (a 5000-subscriber filter next to 60 singletons).
-constexpr uint32_t EXP_FLAG_WORDS = (EXP_K * (EXP_LONG - 1) + 63) / 64 + 1;
+constexpr uint32_t EXP_FLAG_WORDS = (EXP_K * (EXP_LONG - 1) + 63) / 64 + 2;
 constexpr uint32_t EXP_EPL = EXP_K / 64; // entries per lane in the prefix step
 static_assert(EXP_K % 64 == 0 && EXP_K * (EXP_LONG - 1) < 65536, "short-range space: offsets are packed into 16 bits below");
 
@@ -864,6 +876,20 @@ __global__ __launch_bounds__(EXP_WAVES * 64, BMQ_EXP_MIN_WAVES) void k_expand(Ba
     const bool dbg_x = a.dbg_wave && (a.debug_flags & 4u); // BMQ_DEBUG=4: per-wave phase clocks of k_expand
     const unsigned long long xc0 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long xc_load = 0, xc_scan = 0, xc_gen = 0;
+    if (a.blk_stats && ((blk & ((1u << SUPER_SHIFT) - 1u)) == (1u << SUPER_SHIFT) - 1u || blk == a.n_blocks - 1)) {
+        // the batch statistics: the last wave of every super-block sums the records k_walk left for its (up to) 256 blocks
+        unsigned long long v = 0, r = 0, b = 0;
+        for (uint32_t i = ((blk >> SUPER_SHIFT) << SUPER_SHIFT) + lane; i <= blk; i += 64) {
+            const uint4 q = a.blk_stats[i];
+            v += q.x, r += q.y, b += q.z;
+        }
+        v = wave_sum_u64(v), r = wave_sum_u64(r), b = wave_sum_u64(b);
+        if (lane == 0) {
+            if (v) atomicAdd(&a.ctr->n_visit, v);
+            if (r) atomicAdd(&a.ctr->n_ranges, r);
+            if (b) atomicAdd(&a.ctr->topic_bytes, b);
+        }
+    }
     const uint32_t status = a.ctr->status;
     const uint32_t nr = valid ? a.route_cnt[t] : 0u;
     const uint32_t po = valid ? a.pair_off[t] : 0u; // requested together with the counts: one round trip less in front of the ranges
@@ -1096,7 +1122,8 @@ __global__ __launch_bounds__(EXP_WAVES * 64, BMQ_EXP_MIN_WAVES) void k_expand(Ba
         // 4 / 8 / 16 ids -- C3 k_expand 0.172 / 0.130 / 0.119 ms, C2 1.47 against 1.22 ms: streaming the many medium ranges one after
         // the other costs more than the LDS lookups save.)
         uint32_t ub = 0;          // short-range space: start of the current run of short ranges
-        uint32_t fc = 0, fo = 0;  // fo = short ranges that start before bitmap word fc
+        uint32_t fw = 0, fo = 0;  // fo = short ranges that start before bitmap word fw
+        unsigned long long fm = flag[0], fnext = flag[1]; // words fw and fw + 1 (EXP_FLAG_WORDS has one spare word)
         for (uint32_t k = 0; k < kn;) {
             uint32_t kl = kn; // first long range at or after k
             for (uint32_t c0 = k; c0 < kn && kl == kn; c0 += 64) {
@@ -1107,8 +1134,13 @@ __global__ __launch_bounds__(EXP_WAVES * 64, BMQ_EXP_MIN_WAVES) void k_expand(Ba
                 const uint32_t jb = r_off[k];
                 const uint32_t ue = ub + (r_off[kl] - jb);
                 for (uint32_t c = ub & ~63u; c < ue; c += 64) {
-                    while (fc < (c >> 6)) fo += (uint32_t)__popcll(flag[fc++]);
-                    const unsigned long long m = flag[c >> 6];
+                    if (fw < (c >> 6)) { // the chunks of a pass are visited in order: at most one word further
+                        fo += (uint32_t)__popcll(fm);
+                        fw++;
+                        fm = fnext;
+                        fnext = flag[min(fw + 1u, EXP_FLAG_WORDS - 1u)]; // for the chunk after this one
+                    }
+                    const unsigned long long m = fm;
                     const uint32_t u = c + lane;
                     if (u >= ub && u < ue) {
                         const uint32_t o = fo + (uint32_t)__popcll(m & ((2ull << lane) - 1ull)) - 1u;
@@ -1162,32 +1194,6 @@ __global__ __launch_bounds__(EXP_WAVES * 64, BMQ_EXP_MIN_WAVES) void k_expand(Ba
 // k_sort_rows -- one workgroup per flagged row, normalised bitonic network in global memory
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
-    if (a.blk_stats) { // the batch statistics: per-wave records of k_walk -> counters (one atomic triple per workgroup)
-        __shared__ unsigned long long red[3][4];
-        unsigned long long sv = 0, sr = 0, sb = 0;
-        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.n_blocks; i += gridDim.x * 256) {
-            const uint4 q = a.blk_stats[i];
-            sv += q.x;
-            sr += q.y;
-            sb += q.z;
-        }
-        sv = wave_sum_u64(sv);
-        sr = wave_sum_u64(sr);
-        sb = wave_sum_u64(sb);
-        if ((threadIdx.x & 63u) == 0) {
-            red[0][threadIdx.x >> 6] = sv;
-            red[1][threadIdx.x >> 6] = sr;
-            red[2][threadIdx.x >> 6] = sb;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long v = red[0][0] + red[0][1] + red[0][2] + red[0][3], r = red[1][0] + red[1][1] + red[1][2] + red[1][3],
-                                     b = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-            if (v) atomicAdd(&a.ctr->n_visit, v);
-            if (r) atomicAdd(&a.ctr->n_ranges, r);
-            if (b) atomicAdd(&a.ctr->topic_bytes, b);
-        }
-    }
     const uint32_t n_rows = a.ctr->sort_count < a.sort_cap ? a.ctr->sort_count : a.sort_cap;
     if (a.ctr->status & (ST_NOSPACE | ST_RANGE | ST_RERUN)) return;
     for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {

@@ -98,6 +98,8 @@ struct bmq_engine {
     std::unique_ptr<DistIndex<HostExec>> hix;
     uint64_t epoch = 0;
     bool built = false;
+    bool slow_on = false, sort_on = false; // the repair kernels are in the pipeline (see launch_dist)
+    uint32_t slow_idle = 0, sort_idle = 0; // consecutive batches that ran them for nothing
     bool kernel_events = false; // bmq_config.kernel_timing: HIP events around k_walk / k_expand of every dist batch (~4 us each)
 
     // Everything ONE batch in flight needs: per-batch scratch, staging of the host-buffer API, counters, events.  Two slots, so
@@ -116,6 +118,7 @@ struct bmq_engine {
         hipEvent_t ev_in = nullptr, ev_done = nullptr; // inputs uploaded / batch (kernels + counter read-back) complete
         // the batch in flight (for bmq_match_finish / bmq_match_wait)
         bool pending = false;
+        bool ran_slow = false, ran_sort = false; // k_walk_slow / k_sort_rows were part of this batch's launch
         bool timed = false; // this batch was launched with the per-kernel events (bmq_config.kernel_timing)
         int pending_kind = 0; // 0 dist, 1 retain
         bool submitted = false; // owned by a bmq_match_submit ticket
@@ -197,9 +200,9 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     HIPCHK(e, e->cur->b_pairs.ensure(sizeof(MatchRange) * e->cur->pair_cap));
     HIPCHK(e, e->cur->b_subs.ensure(sizeof(SubAlloc) * 2 * N_SUB));
     HIPCHK(e, e->cur->b_super.ensure(sizeof(unsigned long long) * SUPER_STRIDE * ((n_blocks >> SUPER_SHIFT) + 2)));
-    HIPCHK(e, e->cur->b_blk_stats.ensure(sizeof(uint4) * std::max(n_blocks, 1u)));
     if (e->cur->spill_cap == 0) e->cur->spill_cap = 1u << 16;
     e->cur->spill_cap = std::max<uint64_t>(e->cur->spill_cap, (uint64_t)n_topics * 2);
+    HIPCHK(e, e->cur->b_blk_stats.ensure(sizeof(uint4) * std::max(n_blocks, 1u)));
     HIPCHK(e, e->cur->b_spill.ensure(sizeof(uint4) * e->cur->spill_cap));
     HIPCHK(e, e->cur->b_wave_sums.ensure(sizeof(unsigned long long) * std::max(n_blocks, 1u)));
     HIPCHK(e, e->cur->b_slow_list.ensure(sizeof(uint32_t) * e->cur->slow_cap));
@@ -209,6 +212,8 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     HIPCHK(e, e->cur->b_total.ensure(sizeof(unsigned long long)));
     return BMQ_OK;
 }
+
+constexpr uint32_t REPAIR_IDLE_BATCHES = 32;
 
 int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.ix = e->dix->view();
@@ -260,11 +265,16 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
         hipLaunchKernelGGL(k_walk, grid, block, lds, s, a);
     }
     if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[2], s));
-    hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
+    // The two repair kernels run only while batches need them (finish_dist turns them on -- and completes the batch that found
+    // out -- and off again): topics deeper than FAST_LEVELS (the broker rejects them: Setting.MaxTopicLevels = 16) and rows whose
+    // ranges do not come out in ascending id order.  A launch that finds nothing to do still costs its slot in the stream.
+    e->cur->ran_slow = e->slow_on;
+    e->cur->ran_sort = e->sort_on;
+    if (e->slow_on) hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
     if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[3], s));
     hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
     if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[4], s));
-    hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
+    if (e->sort_on) hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
     HIPCHK(e, hipEventRecord(e->cur->ev[5], s));
     HIPCHK(e, hipMemcpyAsync(e->cur->h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipEventRecord(e->cur->ev_done, s));
@@ -332,11 +342,28 @@ int finish_dist(bmq_engine* e, uint64_t* out_total) {
                 e->cur->sort_cap = std::max<uint32_t>(e->cur->sort_cap * 2, c.sort_count);
                 HIPCHK(e, e->cur->b_sort_list.ensure(sizeof(uint32_t) * e->cur->sort_cap));
             }
+            if (c.sort_count) e->sort_on = true, e->sort_idle = 0;
+            if (c.slow_count) e->slow_on = true, e->slow_idle = 0;
             BatchArgs a = e->cur->last;
             int rc = launch_dist(e, a);
             if (rc) return rc;
             continue;
         }
+        if (c.slow_count && !e->cur->ran_slow) { // deep topics and k_walk_slow was not in the pipeline: the batch runs again with it
+            e->slow_on = true, e->slow_idle = 0;
+            BatchArgs a = e->cur->last;
+            int rc = launch_dist(e, a);
+            if (rc) return rc;
+            continue;
+        }
+        if (c.sort_count && !e->cur->ran_sort && !(c.status & (ST_RANGE | ST_NOSPACE))) { // rows to order: only that kernel
+            e->sort_on = true, e->sort_idle = 0;
+            hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, e->stream, e->cur->last);
+            HIPCHK(e, hipGetLastError());
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+        }
+        if (e->cur->ran_slow && (c.slow_count ? (e->slow_idle = 0) : ++e->slow_idle) >= REPAIR_IDLE_BATCHES) e->slow_on = false;
+        if (e->cur->ran_sort && (c.sort_count ? (e->sort_idle = 0) : ++e->sort_idle) >= REPAIR_IDLE_BATCHES) e->sort_on = false;
         e->cur->pending = false;
         bmq_stats& st = e->stats;
         st = bmq_stats{};
