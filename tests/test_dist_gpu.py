@@ -235,6 +235,40 @@ def test_slow_path_equals_fast_path():
     assert tiny.stats().n_visit == nv
 
 
+def test_repair_kernels_come_and_go():
+    """k_walk_slow / k_sort_rows are launched only while batches need them: a batch that needs one and did not have it is completed
+    (re-run / sorted) by the finish step, 32 batches without need switch the kernel off again -- results identical throughout."""
+    rnd = random.Random(77)
+    alphabet = ["a", "b"]
+    keys = sorted({U.rand_route_key(rnd, "t", U.rand_filter(rnd, 5, alphabet), i) for i in range(3000)} |
+                  {U.rand_route_key(rnd, "t", "/".join(["a"] * 20 + ["#"]), 900001), U.rand_route_key(rnd, "t", "/".join(["+"] * 18), 900002)})
+    kv = O.KV(keys)
+    shallow = [U.rand_topic(rnd, 5, alphabet) for _ in range(300)]
+    deep = shallow[:50] + ["/".join(["a"] * n) for n in (17, 18, 21, 25)]
+    exp_shallow = U.semantic_rows(kv, ["t"], [0] * len(shallow), shallow)
+    exp_deep = U.semantic_rows(kv, ["t"], [0] * len(deep), deep)
+    eng = B.Engine(device=0).rebuild(keys)
+    for cycle in range(2):
+        assert eng.match_tenant("t", deep) == exp_deep          # first batch of the engine / after the kernels were dropped
+        assert eng.stats().n_slow_topics == 4
+        assert eng.match_tenant("t", deep) == exp_deep          # with the slow kernel in the pipeline
+        for _ in range(40):                                     # > REPAIR_IDLE_BATCHES quiet batches
+            assert eng.match_tenant("t", shallow) == exp_shallow
+            assert eng.stats().n_slow_topics == 0
+    # rows that need the fix-up sort: > 32 ranges per row, ranges not ascending (the case of test_many_ranges_per_row)
+    keys2 = sorted({U.rand_route_key(rnd, "t", f, i) for i, f in enumerate(
+        ["/".join(rnd.choice(["+", "x"]) for _ in range(7)) for _ in range(400)] + ["x/#", "+/#", "#"])})
+    kv2 = O.KV(keys2)
+    eng2 = B.Engine(device=0).rebuild(keys2)
+    t7 = ["/".join(["x"] * 7), "x/x", "y"]
+    exp7 = U.semantic_rows(kv2, ["t"], [0] * len(t7), t7)
+    for cycle in range(2):
+        assert eng2.match_tenant("t", t7) == exp7
+        assert eng2.match_tenant("t", t7) == exp7
+        for _ in range(40):
+            assert eng2.match_tenant("t", t7[1:]) == exp7[1:]
+
+
 def test_interleaved_key_ranges(eng):
     # SURVEY 8c quirk (ii): keys of filter "x" (bucket byte b) interleave with keys of "x/..." whose next level
     # is empty, so the ids of ONE filter are not a contiguous rank range (indirect ranges in the index).  No single

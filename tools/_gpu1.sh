@@ -1,13 +1,5 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out
-one() {
-python bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$1 c3', round(d['ms_per_step'],4), round(d.get('ms_per_step_without_kernel_timing'),4), d['kernel_ms'])"
-python bench.py --topics 10000 --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$1 10k', round(d['ms_per_step'],4), round(d.get('ms_per_step_without_kernel_timing'),4), d['kernel_ms'])"
-}
-for r in 1 2; do
-unset BMQ_LIB; one new
-export BMQ_LIB=/root/repo/bifromq_amd/variants/libbmq_prev.so; one prev
-done
+bash tools/profile_round.sh r02 > gpurun_out/profile_round.log 2>&1
+bash tools/measure_extras.sh r02 > gpurun_out/extras.log 2>&1
+tail -5 gpurun_out/profile_round.log; tail -30 gpurun_out/extras.log

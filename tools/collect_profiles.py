@@ -47,6 +47,15 @@ if rows:
             json.dump({"c3": traffic, "kernel_sources_sha": hs.hexdigest()[:16], "_note": "HBM bytes per k_walk launch = FETCH_SIZE*1024*0.992 (calibrated on random 64-byte line "
                        "fetches, tools/ubench_lines.hip) + WRITE_SIZE*1024 (uncalibrated); profiles/%s/c3_pmc_hbm.csv" % R}, f)
         print("k_walk traffic per launch: %.1f MB" % (traffic / 1e6))
+        # the round's C3 bench line ran before the counter passes: its roofline.traffic is filled in from them here
+        bj = os.path.join(dst, "bench_c3.json")
+        if os.path.exists(bj):
+            d = json.loads(open(bj).read().strip().splitlines()[-1])
+            if d["roofline"].get("traffic") is None and d["roofline"].get("kernel") == "k_walk":
+                d["roofline"]["traffic"] = traffic
+                d["roofline"]["traffic_source"] = ("profiles/traffic_%s.json: PMC passes of the same profile round (tools/profile_round.sh), "
+                                                   "filled in by tools/collect_profiles.py" % R)
+                open(bj, "w").write(json.dumps(d) + "\n")
 ex = os.path.join(src, "extras")
 if os.path.isdir(ex):  # tools/measure_extras.sh
     os.makedirs(os.path.join(dst, "extras"), exist_ok=True)
