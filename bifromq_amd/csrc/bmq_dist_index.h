@@ -621,6 +621,7 @@ private:
         t.hash_hi = (uint32_t)(h >> 32);
         t.name_off = (uint32_t)names_h.size();
         t.name_len = (uint32_t)name.size();
+        memcpy(t.name16, name.data(), std::min<size_t>(name.size(), 16));
         t.base = (uint32_t)base;
         t.buckets = buckets;
         t.n_routes = n_routes;

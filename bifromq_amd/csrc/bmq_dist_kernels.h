@@ -6,10 +6,11 @@
 // for the '$' rule, TRIE/NTopicFilterTrieNode.java:143-146 for '#' matching the parent level).
 //
 // Included only by bmq_engine.hip (hipcc --offload-arch=gfx950).  Work decomposition:
-//   k_prologue        : zeroes the batch counters and resolves the batch's tenant table, one lane per distinct tenant ->
-//                       region of the slot table + the tenant root's payload
+//   (no prologue)     : the batch's tenants are resolved by the walk kernels themselves (a wave's topics usually share one
+//                       tenant: the directory lookup then runs on the scalar unit); the batch counters are zeroed BEHIND the
+//                       previous batch of the slot (k_reset) -- a batch starts on its walk kernel.
 //   k_walk            : one wave per 64 topics, WALK_WAVES independent waves per workgroup (own LDS slice each).
-//                       Phase 1: the wave stages its topics' bytes in LDS with coalesced 16-byte loads, then walks
+//                       Phase 1: tenant directory entry; the wave stages its topics' bytes in LDS with coalesced 16-byte loads, then walks
 //                       them level by level: every lane scans its own next level (LDS only), then ALL lanes look
 //                       their level up in the dictionary together -- one memory latency per level, not per lane.
 //                       Phase 2: the wave drains a depth-first LDS work stack of (node, topic, level, kind) items,
@@ -17,13 +18,15 @@
 //                       (node id, token of the topic's level) or (node id, '+') -- the child's header comes with it.
 //                       Pushes and matches are compacted with ballot + mbcnt.
 //                       Phase 3: matched (begin,count) ranges are counting-sorted by topic and written out.
-//   k_walk_slow       : per-lane DFS with global scratch for topics the LDS path could not finish
-//                       (more than FAST_LEVELS levels, stack overflow, too many range flushes).
+//   k_walk_slow       : per-lane DFS with global scratch for topics of more than FAST_LEVELS levels.  Launched only while
+//                       batches have such topics (the finish step re-runs the batch that found out: bmq_engine.hip).
 //   (no scan kernel)  : k_walk leaves per-wave id counts + their sums per 256 waves; every k_expand wave adds up the <= 61 + 255
 //                       values in front of it (five coalesced loads per lane) instead of waiting for a single-workgroup scan.
 //   k_expand          : per 64 rows: order each row's ranges by first id in LDS, lay them out in output order and fill the
-//                       CSR ids with fully coalesced stores (short ranges flattened, long ranges streamed).
-//   k_sort_rows       : bitonic fix-up of rows whose range list was too long to order in k_expand.
+//                       CSR ids with fully coalesced stores (short ranges located through a start bitmap, long ranges streamed);
+//                       the last wave of every 256 sums the batch statistics k_walk left per wave.
+//   k_sort_rows       : bitonic fix-up of rows whose range list was too long to order in k_expand; launched only while batches
+//                       have such rows.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -43,7 +46,7 @@ enum : uint32_t {
 };
 constexpr uint32_t ST_RERUN = ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH | ST_NEED_SPILL;
 
-struct Counters { // one per batch, zeroed before launch (k_prologue)
+struct Counters { // one per batch slot, zeroed behind every batch (k_reset)
     unsigned long long pair_alloc;
     unsigned long long scratch_alloc; // in uint32 units
     unsigned long long spill_alloc;   // in records
@@ -87,14 +90,13 @@ struct BatchArgs {
     const uint32_t* topic_off;
     uint32_t n_topics;
     // per-batch scratch (device)
-    TenantSlot* tenant_info; // [n_tenants] region of each batch tenant (token == 0: unknown tenant)
     uint32_t* pair_off;      // [n_topics]
     uint32_t* pair_cnt;      // [n_topics]
     uint32_t* route_cnt;     // [n_topics]
     MatchRange* pairs;
     unsigned long long pair_cap;
     SubAlloc* subs;          // [2 * N_SUB] allocators of `pairs` (first N_SUB) and of `spill` (second N_SUB)
-    unsigned long long* super_sums; // [(n_blocks >> SUPER_SHIFT + 1) * SUPER_STRIDE] ids per 2^SUPER_SHIFT blocks (zeroed by k_prologue)
+    unsigned long long* super_sums; // [(n_blocks >> SUPER_SHIFT + 1) * SUPER_STRIDE] ids per 2^SUPER_SHIFT blocks (zeroed by k_reset)
     uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, 0} written by k_walk; the last
                              // k_expand wave of every super-block sums its 256 records into ctr (null: retain direction)
     uint4* spill;            // LDS range buffer flushes: {begin, count, topic-local, 0}
@@ -251,57 +253,139 @@ __device__ __forceinline__ uint32_t global_word_at(const uint8_t* base, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_prologue
+// batch slot reset, tenant directory lookup
 // ------------------------------------------------------------------------------------------------------------
 constexpr TenantSlot EMPTY_TENANT{0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}};
 __device__ __forceinline__ bool tenant_known(const TenantSlot& t) { return (t.hash_lo | t.hash_hi) != 0; }
 
-// k_prologue: zeroes the batch counters / sub-allocators / super sums (what two hipMemsetAsync calls used to do) and resolves the
-// batch's tenant table, one lane per item.  zero_words: number of 8-byte words to clear in each of the three areas.
-__global__ __launch_bounds__(64) void k_prologue(BatchArgs a, uint32_t n_super) {
+// k_reset: zeroes the batch counters / sub-allocators / super sums of a batch slot.  Enqueued BEHIND a batch (after its counters
+// were copied out), so that the next batch on the slot starts on its walk kernel: in front of the batch the same work was measured
+// at 19-40 us of a 0.42 ms step (profiles/r02, k_prologue), a chain of cold round trips that nothing overlapped.
+__global__ __launch_bounds__(64) void k_reset(Counters* ctr, SubAlloc* subs, unsigned long long* super_sums, uint32_t n_super) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i < sizeof(Counters) / 8) reinterpret_cast<unsigned long long*>(a.ctr)[i] = 0ull;
-    if (i < sizeof(SubAlloc) * 2 * N_SUB / 8) reinterpret_cast<unsigned long long*>(a.subs)[i] = 0ull;
-    if (i < n_super) a.super_sums[(size_t)i * SUPER_STRIDE] = 0ull;
-    if (i >= a.n_tenants) return;
-    // The tenant id's bytes: the first 16 are requested together (a byte-wise loop is one memory latency per byte: measured 22 us
-    // for 12-byte ids; word by word still one latency per word -- the kernel is a chain of dependent round trips and nothing else)
-    const uint8_t* base = a.tenants;
-    const uint32_t beg = a.tenant_off[i], end = a.tenant_off[i + 1], len = end - beg;
-    uint32_t w4[4];
+    if (i < sizeof(Counters) / 8) reinterpret_cast<unsigned long long*>(ctr)[i] = 0ull;
+    if (i < sizeof(SubAlloc) * 2 * N_SUB / 8) reinterpret_cast<unsigned long long*>(subs)[i] = 0ull;
+    if (i < n_super) super_sums[(size_t)i * SUPER_STRIDE] = 0ull;
+}
+
+// The directory entry of a batch tenant (EMPTY_TENANT: no such tenant).  Resolved by the walk kernels themselves, per topic: the
+// lanes of a wave mostly share one tenant (batches arrive grouped by tenant) and every wave of the launch keeps the few lines
+// involved hot in L2 -- as a kernel of its own in front of the walk the same lookups were cold, dependent round trips.
+// Three dependent requests (offsets -> id bytes -> directory slot); k_walk issues them one per tokeniser iteration, where each
+// lands under the dictionary lookup's wait.
+struct TenantQuery {
+    uint32_t beg = 0, len = 0;    // the id's bytes in the batch's tenant table
+    uint32_t raw[5] = {0, 0, 0, 0, 0}; // stage 0: the two offsets; stage 1: the aligned dwords around the first 16 bytes
+    uint32_t w[4] = {0, 0, 0, 0}; // the first 16 bytes, zero padded
+    uint32_t lo = 0, hi = 0, d = 0;
+    TenantSlot slot = EMPTY_TENANT; // directory slot d
+};
+// A stage only REQUESTS its data and works on what the previous stage requested: nothing waits inside the stage it was asked in.
+__device__ __forceinline__ void tenant_stage(const BatchArgs& a, uint32_t ti, TenantQuery& q, uint32_t st) {
+    if (st == 0) {
+        q.raw[0] = a.tenant_off[ti];
+        q.raw[1] = a.tenant_off[ti + 1];
+    } else if (st == 1) { // the first 16 bytes are requested together (a byte-wise loop is one memory latency per byte)
+        q.beg = q.raw[0];
+        q.len = q.raw[1] - q.raw[0];
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(a.tenants + (q.beg & ~3u));
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) w4[k] = 4 * k < len ? global_word_at(base, beg + 4 * k) : 0u;
+        for (uint32_t k = 0; k < 5; k++) q.raw[k] = 4 * k < q.len + 3 ? p[k] : 0u; // (packed inputs are padded by 16 bytes)
+    } else {
+        const uint32_t sh = q.beg & 3u;
+        uint64_t h = TENANT_HASH_INIT;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { // (constant indices: the words stay in registers)
+            const uint32_t w = __builtin_amdgcn_alignbyte(q.raw[k + 1], q.raw[k], sh);
+            const uint32_t nb = q.len > 4 * k ? min(4u, q.len - 4 * k) : 0u;
+            q.w[k] = nb >= 4 ? w : (w & ((1u << (8 * nb)) - 1u)); // zero padded like TenantSlot.name16
+            for (uint32_t j = 0; j < 4; j++)
+                if (4 * k + j < q.len) h = tenant_hash_step(h, (q.w[k] >> (8 * j)) & 0xFFu);
+        }
+        for (uint32_t k = 16; k < q.len; k += 4) {
+            const uint32_t w = global_word_at(a.tenants, q.beg + k), nb = min(4u, q.len - k);
+            for (uint32_t j = 0; j < nb; j++) h = tenant_hash_step(h, (w >> (8 * j)) & 0xFFu);
+        }
+        h = tenant_hash_final(h);
+        q.lo = (uint32_t)h, q.hi = (uint32_t)(h >> 32);
+        q.d = (q.lo ^ q.hi) & a.ix.tenant_mask;
+        q.slot = a.ix.tenants[q.d];
+    }
+}
+// after the three stages: the id's bytes decide; a displaced entry costs further directory slots
+__device__ __forceinline__ TenantSlot tenant_verdict(const BatchArgs& a, const TenantQuery& q) {
+    TenantSlot t = q.slot;
+    uint32_t d = q.d;
+    for (uint32_t probes = 0; probes <= a.ix.tenant_mask; probes++) {
+        if (!tenant_known(t)) break;
+        if (t.hash_lo == q.lo && t.hash_hi == q.hi && t.name_len == q.len) {
+            // both sides are zero padded to 16 bytes: the first four words compare whole
+            bool eq = t.name16[0] == q.w[0] && t.name16[1] == q.w[1] && t.name16[2] == q.w[2] && t.name16[3] == q.w[3];
+            for (uint32_t k = 16; k < q.len && eq; k += 4) {
+                const uint32_t nb = min(4u, q.len - k), m = nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                eq = ((global_word_at(a.ix.tenant_names, t.name_off + k) ^ global_word_at(a.tenants, q.beg + k)) & m) == 0;
+            }
+            if (eq) return t;
+        }
+        d = (d + 1) & a.ix.tenant_mask;
+        t = a.ix.tenants[d];
+    }
+    return EMPTY_TENANT;
+}
+// The same lookup for a wave-uniform tenant, on the scalar unit: the loads go through the constant address space (s_load, scalar
+// cache), which is legal because neither the batch's tenant table nor the index is written while a batch runs.
+typedef const uint32_t __attribute__((address_space(4))) * ScalarWords;
+__device__ __forceinline__ ScalarWords scalar_words(const void* p) { return (ScalarWords)(uintptr_t)p; }
+__device__ __forceinline__ uint32_t scalar_word_at(const void* base, uint32_t p) { // 4 bytes at byte offset p, any alignment
+    ScalarWords q = scalar_words(base) + (p >> 2);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], p & 3u);
+}
+__device__ __forceinline__ TenantSlot resolve_tenant_uniform(const BatchArgs& a, uint32_t ti) {
+    ScalarWords off = scalar_words(a.tenant_off);
+    const uint32_t beg = off[ti], len = off[ti + 1] - beg;
+    uint32_t w[4];
     uint64_t h = TENANT_HASH_INIT;
-    for (uint32_t k = 0; k < len; k += 4) {
-        const uint32_t w = k < 16 ? w4[k >> 2] : global_word_at(base, beg + k), nb = min(4u, len - k);
-        for (uint32_t j = 0; j < nb; j++) h = tenant_hash_step(h, (w >> (8 * j)) & 0xFFu);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t x = 4 * k < len ? scalar_word_at(a.tenants, beg + 4 * k) : 0u;
+        const uint32_t nb = len > 4 * k ? min(4u, len - 4 * k) : 0u;
+        w[k] = nb >= 4 ? x : (x & ((1u << (8 * nb)) - 1u));
+        for (uint32_t j = 0; j < 4; j++)
+            if (4 * k + j < len) h = tenant_hash_step(h, (w[k] >> (8 * j)) & 0xFFu);
+    }
+    for (uint32_t k = 16; k < len; k += 4) {
+        const uint32_t x = scalar_word_at(a.tenants, beg + k), nb = min(4u, len - k);
+        for (uint32_t j = 0; j < nb; j++) h = tenant_hash_step(h, (x >> (8 * j)) & 0xFFu);
     }
     h = tenant_hash_final(h);
     const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
-    TenantSlot info = EMPTY_TENANT;
     uint32_t d = (lo ^ hi) & a.ix.tenant_mask;
     for (uint32_t probes = 0; probes <= a.ix.tenant_mask; probes++) {
-        const TenantSlot t = a.ix.tenants[d];
+        ScalarWords sp = scalar_words(a.ix.tenants + d);
+        TenantSlot t;
+        t.hash_lo = sp[0], t.hash_hi = sp[1], t.name_off = sp[2], t.name_len = sp[3];
+        t.base = sp[4], t.buckets = sp[5], t.n_nodes = sp[6], t.n_routes = sp[7];
+        t.root_hash_begin = sp[8], t.root_hash_count = sp[9], t.root_lit_bloom = sp[10], t.pending = sp[11];
+        t.name16[0] = sp[12], t.name16[1] = sp[13], t.name16[2] = sp[14], t.name16[3] = sp[15];
         if (!tenant_known(t)) break;
-        if (t.hash_lo == lo && t.hash_hi == hi && t.name_len == len) { // the id's bytes decide
-            uint32_t n4[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) n4[k] = 4 * k < len ? global_word_at(a.ix.tenant_names, t.name_off + 4 * k) : 0u;
-            bool eq = true;
-            for (uint32_t k = 0; k < len && eq; k += 4) {
+        if (t.hash_lo == lo && t.hash_hi == hi && t.name_len == len) {
+            bool eq = t.name16[0] == w[0] && t.name16[1] == w[1] && t.name16[2] == w[2] && t.name16[3] == w[3];
+            for (uint32_t k = 16; k < len && eq; k += 4) {
                 const uint32_t nb = min(4u, len - k), m = nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-                const uint32_t x = k < 16 ? n4[k >> 2] : global_word_at(a.ix.tenant_names, t.name_off + k);
-                const uint32_t y = k < 16 ? w4[k >> 2] : global_word_at(base, beg + k);
-                eq = ((x ^ y) & m) == 0;
+                eq = ((scalar_word_at(a.ix.tenant_names, t.name_off + k) ^ scalar_word_at(a.tenants, beg + k)) & m) == 0;
             }
-            if (eq) {
-                info = t;
-                break;
-            }
+            if (eq) return t;
         }
         d = (d + 1) & a.ix.tenant_mask;
     }
-    a.tenant_info[i] = info;
+    return EMPTY_TENANT;
+}
+__device__ __forceinline__ TenantSlot resolve_tenant(const BatchArgs& a, uint32_t ti) {
+    TenantQuery q;
+    tenant_stage(a, ti, q, 0);
+    tenant_stage(a, ti, q, 1);
+    tenant_stage(a, ti, q, 2);
+    return tenant_verdict(a, q);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -442,19 +526,31 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
         return __builtin_amdgcn_alignbyte(un[(rel >> 2) + 1], un[rel >> 2], rel & 3u);
     };
 
-    uint32_t nlev = 0, tbytes = 0, pos = 0, end = 0;
-    bool sys = false, more = false;
-    TenantSlot rg = EMPTY_TENANT;
+    uint32_t nlev = 0, tbytes = 0, pos = 0, end = 0, ti = 0;
+    bool sys = false, more = false, t_ok = false;
     if (valid) {
         pos = a.topic_off[t];
         end = a.topic_off[t + 1];
         tbytes = end - pos;
-        const uint32_t ti = a.topic_tenant[t];
-        if (ti < a.n_tenants) rg = a.tenant_info[ti];
-        more = tenant_known(rg); // unknown tenant: no routes, nothing to tokenise
+        ti = a.topic_tenant[t];
+        t_ok = ti < a.n_tenants;
+        more = t_ok; // (a topic of a tenant the index does not know is tokenised for nothing: rare, and the answer comes late)
         sys = more && end > pos && byte_at(pos) == '$';
     }
-    for (uint32_t l = 0; __any(more); l++) {
+    // The tenant's directory entry.  A wave's topics usually share one tenant (batches arrive grouped by tenant): then the lookup
+    // is wave-uniform and runs on the scalar unit -- it costs the vector memory pipeline, which bounds this kernel, nothing.  A
+    // wave that straddles tenants resolves per lane, one request per tokeniser iteration (they land under the dictionary waits).
+    const uint32_t ti0 = __builtin_amdgcn_readfirstlane(ti); // lane 0 is valid in every wave that exists
+    const bool uni = __all(!valid || ti == ti0);
+    TenantSlot rg = EMPTY_TENANT;
+    if (uni) {
+        if (ti0 < a.n_tenants) rg = resolve_tenant_uniform(a, ti0);
+        more = more && tenant_known(rg); // unknown tenant: no routes, nothing to tokenise
+    }
+    TenantQuery tq;
+    uint32_t l = 0;
+    for (; __any(more); l++) {
+        if (!uni && l < 3 && t_ok) tenant_stage(a, ti, tq, l);
         LevelHash h;
         uint32_t inl[4], len = 0;
         const uint32_t start = pos;
@@ -465,6 +561,11 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
             if (l < FAST_LEVELS) tokens[l * 64 + lane] = dict_lookup(a.ix, h, len, inl, start, byte_at);
             more = !last;
         }
+    }
+    if (!uni) {
+        for (uint32_t st = l; st < 3; st++) // a wave of topics with fewer than three levels
+            if (t_ok) tenant_stage(a, ti, tq, st);
+        if (t_ok) rg = tenant_verdict(a, tq);
     }
     const bool known = valid && tenant_known(rg);
     const bool deep = nlev > FAST_LEVELS;
@@ -709,7 +810,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
         const uint32_t ti = a.topic_tenant[t];
         if (ti >= a.n_tenants) continue;
-        const TenantSlot rg = a.tenant_info[ti];
+        const TenantSlot rg = resolve_tenant(a, ti);
         if (!tenant_known(rg)) continue;
         // level count first (cheap scan), then scratch: nlev tokens + stack of 2-word entries.  A DFS pop pushes at most
         // two items one level deeper: <= 1 pending sibling per level + 2.

@@ -107,7 +107,7 @@ struct bmq_engine {
     // batch i-1 in flight while the kernels of batch i run; every other entry point works on slot 0.
     struct BatchSlot {
         DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave;
-        DevBuf b_tenant_root, b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch, b_sort_list, b_ctr,
+        DevBuf b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch, b_sort_list, b_ctr,
             b_total;
         uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
         uint32_t slow_cap = 0, sort_cap = 0;
@@ -118,6 +118,7 @@ struct bmq_engine {
         hipEvent_t ev_in = nullptr, ev_done = nullptr; // inputs uploaded / batch (kernels + counter read-back) complete
         // the batch in flight (for bmq_match_finish / bmq_match_wait)
         bool pending = false;
+        bool clean = false; // counters / allocators / super sums are zero (k_reset ran behind the last batch of the slot)
         bool ran_slow = false, ran_sort = false; // k_walk_slow / k_sort_rows were part of this batch's launch
         bool timed = false; // this batch was launched with the per-kernel events (bmq_config.kernel_timing)
         int pending_kind = 0; // 0 dist, 1 retain
@@ -193,11 +194,11 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     if (e->cur->sort_cap == 0) e->cur->sort_cap = 1024;
     e->cur->sort_cap = std::max<uint32_t>(e->cur->sort_cap, n_topics / 64);
     if (e->cur->scratch_cap == 0) e->cur->scratch_cap = (uint64_t)(e->cfg.slow_scratch_mb ? e->cfg.slow_scratch_mb : 64) * (1u << 20) / 4;
-    HIPCHK(e, e->cur->b_tenant_root.ensure(sizeof(TenantSlot) * std::max(n_tenants, 1u)));
     HIPCHK(e, e->cur->b_pair_off.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->cur->b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->cur->b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
     HIPCHK(e, e->cur->b_pairs.ensure(sizeof(MatchRange) * e->cur->pair_cap));
+    const void *p_subs = e->cur->b_subs.p, *p_super = e->cur->b_super.p, *p_ctr = e->cur->b_ctr.p;
     HIPCHK(e, e->cur->b_subs.ensure(sizeof(SubAlloc) * 2 * N_SUB));
     HIPCHK(e, e->cur->b_super.ensure(sizeof(unsigned long long) * SUPER_STRIDE * ((n_blocks >> SUPER_SHIFT) + 2)));
     if (e->cur->spill_cap == 0) e->cur->spill_cap = 1u << 16;
@@ -210,16 +211,25 @@ int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
     HIPCHK(e, e->cur->b_scratch.ensure(sizeof(uint32_t) * e->cur->scratch_cap));
     HIPCHK(e, e->cur->b_ctr.ensure(sizeof(Counters)));
     HIPCHK(e, e->cur->b_total.ensure(sizeof(unsigned long long)));
+    if (p_subs != e->cur->b_subs.p || p_super != e->cur->b_super.p || p_ctr != e->cur->b_ctr.p) e->cur->clean = false; // fresh memory
     return BMQ_OK;
 }
 
 constexpr uint32_t REPAIR_IDLE_BATCHES = 32;
 
+// zero state of a batch slot's counters, range allocators and super-block sums (k_reset), whole capacity
+void reset_slot(bmq_engine* e, hipStream_t s) {
+    const uint32_t n_super = (uint32_t)(e->cur->b_super.cap / (sizeof(unsigned long long) * SUPER_STRIDE));
+    const uint32_t items = std::max<uint32_t>(n_super, (uint32_t)(sizeof(SubAlloc) * 2 * N_SUB / 8));
+    hipLaunchKernelGGL(k_reset, dim3((items + 63) / 64), dim3(64), 0, s, e->cur->b_ctr.as<Counters>(), e->cur->b_subs.as<SubAlloc>(),
+                       e->cur->b_super.as<unsigned long long>(), n_super);
+    e->cur->clean = true;
+}
+
 int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.ix = e->dix->view();
     a.tpw_shift = tpw_shift_for(a.n_topics);
     a.n_blocks = (a.n_topics + (1u << a.tpw_shift) - 1) >> a.tpw_shift;
-    a.tenant_info = e->cur->b_tenant_root.as<TenantSlot>();
     a.pair_off = e->cur->b_pair_off.as<uint32_t>();
     a.pair_cnt = e->cur->b_pair_cnt.as<uint32_t>();
     a.route_cnt = e->cur->b_route_cnt.as<uint32_t>();
@@ -251,12 +261,8 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     a.pcap = e->cfg.wave_pair_cap;
     hipStream_t s = e->stream;
     e->cur->timed = e->kernel_events;
+    if (!e->cur->clean) reset_slot(e, s); // first batch of the slot, buffers regrown, or a retain batch ran on it
     HIPCHK(e, hipEventRecord(e->cur->ev[0], s));
-    {
-        const uint32_t n_super = (a.n_blocks >> SUPER_SHIFT) + 1;
-        const uint32_t items = std::max<uint32_t>(std::max<uint32_t>(a.n_tenants, n_super), (uint32_t)(sizeof(SubAlloc) * 2 * N_SUB / 8));
-        hipLaunchKernelGGL(k_prologue, dim3((items + 63) / 64), dim3(64), 0, s, a, n_super);
-    }
     if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
@@ -278,6 +284,7 @@ int launch_dist(bmq_engine* e, BatchArgs& a) {
     HIPCHK(e, hipEventRecord(e->cur->ev[5], s));
     HIPCHK(e, hipMemcpyAsync(e->cur->h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipEventRecord(e->cur->ev_done, s));
+    reset_slot(e, s); // behind the batch: the counters / allocators are clean again when the next batch arrives
     HIPCHK(e, hipGetLastError());
     e->cur->last = a;
     e->cur->pending = true;
@@ -358,7 +365,10 @@ int finish_dist(bmq_engine* e, uint64_t* out_total) {
         }
         if (c.sort_count && !e->cur->ran_sort && !(c.status & (ST_RANGE | ST_NOSPACE))) { // rows to order: only that kernel
             e->sort_on = true, e->sort_idle = 0;
+            // the slot's counters were reset behind the batch: k_sort_rows reads the row count from them
+            HIPCHK(e, hipMemcpyAsync(e->cur->last.ctr, e->cur->h_ctr, sizeof(Counters), hipMemcpyHostToDevice, e->stream));
             hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, e->stream, e->cur->last);
+            reset_slot(e, e->stream);
             HIPCHK(e, hipGetLastError());
             HIPCHK(e, hipStreamSynchronize(e->stream));
         }

@@ -65,7 +65,7 @@ struct alignas(64) TenantSlot {
     uint32_t root_hash_begin, root_hash_count; // routes of the filter "#"
     uint32_t root_lit_bloom;                   // Bloom word of the root (bit 31: a first-level '+' exists)
     uint32_t pending;          // builder scratch: upper bound of the nodes the batch being prepared may add
-    uint32_t pad[4];
+    uint32_t name16[4];        // the first 16 bytes of the tenant id (zero padded): ids up to 16 bytes are compared without the pool
 };
 static_assert(sizeof(TenantSlot) == 64, "TenantSlot must be 64 bytes");
 
