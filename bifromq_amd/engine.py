@@ -105,6 +105,46 @@ def retain_filter_route(tenant, topic_filter):
     return out.raw[:kl.value], hsh.raw[:hl.value], lv.value, bool(rc & 1), bool(rc & 2)
 
 
+class RangeRouter:
+    """The client-side KV range router: boundaries (start | None, end | None) in BoundaryUtil.compare order
+    (KVRangeRouterUtil.java:41-103); lookups return indices into that list."""
+
+    def __init__(self, boundaries):
+        self.n = len(boundaries)
+        self.flags = np.array([(1 if s is not None else 0) | (2 if e is not None else 0) for s, e in boundaries], dtype=np.uint8)
+        self.start, self.start_off = pack([s or b"" for s, _ in boundaries])
+        self.end, self.end_off = pack([e or b"" for _, e in boundaries])
+
+    def _args(self):
+        return (_ptr(self.flags), _ptr(self.start), _ptr(self.start_off), _ptr(self.end), _ptr(self.end_off), self.n)
+
+    def find_by_key(self, key: bytes):
+        out = C.c_int32()
+        rc = _lib.lib().bmq_router_find_by_key(*self._args(), key, len(key), C.byref(out))
+        if rc < 0:
+            raise BmqError(rc, "bmq_router_find_by_key")
+        return None if out.value < 0 else out.value
+
+    def find_by_boundary(self, start, end):
+        first, count = C.c_uint32(), C.c_uint32()
+        fl = (1 if start is not None else 0) | (2 if end is not None else 0)
+        rc = _lib.lib().bmq_router_find_by_boundary(*self._args(), fl, start or b"", len(start or b""), end or b"", len(end or b""),
+                                                    C.byref(first), C.byref(count))
+        if rc < 0:
+            raise BmqError(rc, "bmq_router_find_by_boundary")
+        return list(range(first.value, first.value + count.value))
+
+    def retain_range_lookup(self, tenant, topic_filters, exact: bool = False):
+        """MatchCallRangeRouter.rangeLookup -> per filter the indices of the ranges it is sent to (exact: BMQ_ROUTER_EXACT)"""
+        t = _b(tenant)
+        fb, fo = pack(topic_filters)
+        keep = np.zeros((len(topic_filters), self.n), dtype=np.uint8)
+        rc = _lib.lib().bmq_retain_range_lookup(t, len(t), _ptr(fb), _ptr(fo), len(topic_filters), *self._args(), 1 if exact else 0, _ptr(keep))
+        if rc < 0:
+            raise BmqError(rc, "bmq_retain_range_lookup")
+        return [np.nonzero(keep[i])[0].tolist() for i in range(len(topic_filters))]
+
+
 def java_string_hash(s) -> int:
     b = _b(s)
     return _lib.lib().bmq_java_string_hash(b, len(b))

@@ -292,6 +292,42 @@ int bmq_retain_filter_route(const uint8_t* tenant, uint32_t tenant_len, const ui
                             uint8_t* out_key_prefix, uint32_t cap, uint32_t* out_key_len, uint8_t* out_level_hash, uint32_t hash_cap,
                             uint32_t* out_hash_len, uint32_t* out_levels);
 
+/* ---- KV range router: the step between a match request and the range replicas that serve it ----------- */
+/* The reference's client-side router is a TreeMap<Boundary, KVRangeSetting> in BoundaryUtil.compare order
+ * (base-kv/base-kv-type-proto/.../utils/BoundaryUtil.java:142-195); here it is an array of n_ranges boundaries in that order:
+ *   range_flags[r]        : bit 0 = the boundary has a start key, bit 1 = it has an end key (an absent side is open; a present key may
+ *                           be empty: NULL_BOUNDARY = no start, end "")
+ *   start/start_off, end/end_off : packed keys, entry r empty where the side is absent
+ * BMQ_E_INVAL if the array is not strictly ascending in that order.
+ * KVRangeRouterUtil.findByKey (base-kv/base-kv-store-client/.../client/KVRangeRouterUtil.java:41-52): *out_index = the range that holds
+ * `key`, or -1.  KVRangeRouterUtil.findByBoundary (:54-103): the ranges it returns are contiguous: [*out_first, *out_first + *out_count);
+ * query_flags as range_flags.  (Where TreeMap.subMap would throw "fromKey > toKey" -- a router that does not cover the query's start --
+ * the result is empty.) */
+int bmq_router_find_by_key(const uint8_t* range_flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end,
+                           const uint32_t* end_off, uint32_t n_ranges, const uint8_t* key, uint32_t key_len, int32_t* out_index);
+int bmq_router_find_by_boundary(const uint8_t* range_flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end,
+                                const uint32_t* end_off, uint32_t n_ranges, uint8_t query_flags, const uint8_t* q_start, uint32_t q_start_len,
+                                const uint8_t* q_end, uint32_t q_end_len, uint32_t* out_first, uint32_t* out_count);
+/* MatchCallRangeRouter.rangeLookup(tenantId, topicFilters, effectiveRouter) (bifromq-retain/bifromq-retain-server/.../scheduler/
+ * MatchCallRangeRouter.java:56-134) for a batch of topic filters of ONE tenant: out_keep[f * n_ranges + r] = 1 if filter f has to be
+ * sent to range r -- a plain topic to the range holding its retainMessageKey, a filter of a fixed level count to the ranges
+ * overlapping [retainKeyPrefix, upperBound), a filter ending in '#' to the ranges overlapping [retainKeyPrefix, end of the tenant)
+ * minus those findCandidates prunes by LevelHash (:96-133).  BMQ_E_INVAL: a plain topic no range holds (the reference asserts), or a
+ * boundary key findCandidates cannot parse (the reference throws).  One deviation: a filter prefix whose LevelHash is all 0xFF bytes
+ * makes the reference fail with a NullPointerException (upperBound(levelHash) == null); here its upper bound is open and nothing is
+ * pruned by the first rule.
+ * mode BMQ_ROUTER_REFERENCE reproduces findCandidates rule for rule.  Those rules look at the LevelHash of a range's start / end key
+ * only, as if a range never spanned two level counts: a range [key of 4 levels, key of 6 levels) is pruned for `a/#` when its start
+ * key's hash sorts behind hash(a), although every 5-level topic under `a` lives in it (tests/test_router.py shows the case) -- retained
+ * messages are then missing from the reply.  mode BMQ_ROUTER_EXACT keeps a range iff it meets one of the key intervals
+ * [tenant | L | hash(prefix), tenant | L | upperBound(hash(prefix))), L >= levels, the filter can match in: never a range too few,
+ * never one too many. */
+#define BMQ_ROUTER_REFERENCE 0u
+#define BMQ_ROUTER_EXACT 1u
+int bmq_retain_range_lookup(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filters, const uint32_t* filter_off, uint32_t n_filters,
+                            const uint8_t* range_flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end,
+                            const uint32_t* end_off, uint32_t n_ranges, uint32_t mode, uint8_t* out_keep);
+
 /* ---- retain direction (RS/index/IRetainTopicIndex.java:27-35) -------------------------------------------- */
 /* Load the retained-topic index: (tenant, topic) pairs; topic id = rank of (tenant, levels) in byte order (tenants in byte order
  * of their ids, a tenant's topics level list by level list).  Ids are RANKS: every bmq_retain_rebuild* / bmq_retain_apply* shifts

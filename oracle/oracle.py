@@ -510,3 +510,151 @@ def retain_key_prefix_of_filter(tenant: str, topic_filter: str) -> bytes:
     n = len(levels) - 1 if levels[-1] == "#" else len(levels)
     return retain_tenant_begin_key(tenant) + n.to_bytes(2, "big") + retain_level_hash(retain_filter_prefix(levels))
 
+
+
+# ---- KV range router (base-kv BoundaryUtil.java:122-195,241-252,299-339; KVRangeRouterUtil.java:41-103) and the retain-server's
+# MatchCallRangeRouter.rangeLookup (MatchCallRangeRouter.java:56-134).  A boundary is (start | None, end | None); the router is a list
+# of boundaries and every TreeMap operation is restated as a linear scan over it in BoundaryUtil.compare order. ----------------------
+def _cmp(a: bytes, b: bytes) -> int:
+    return (a > b) - (a < b)  # bytes compare as unsigned, lexicographically: ByteString.unsignedLexicographicalComparator
+
+
+def boundary_compare_start(a, b) -> int:
+    """BoundaryUtil.compareStartKey (:159-170): null is the smallest start"""
+    if a is None and b is None:
+        return 0
+    if a is None:
+        return -1
+    if b is None:
+        return 1
+    return _cmp(a, b)
+
+
+def boundary_compare_end(a, b) -> int:
+    """BoundaryUtil.compareEndKeys (:184-195): null is the greatest end"""
+    if a is None and b is None:
+        return 0
+    if a is None:
+        return 1
+    if b is None:
+        return -1
+    return _cmp(a, b)
+
+
+def boundary_compare(b1, b2) -> int:
+    """BoundaryUtil.compare(Boundary, Boundary) (:142-145)"""
+    c = boundary_compare_start(b1[0], b2[0])
+    return c if c else boundary_compare_end(b1[1], b2[1])
+
+
+def boundary_upper_bound(key: bytes):
+    """BoundaryUtil.upperBound (:299-339): strip trailing 0xFF, bump the last byte; None = open end"""
+    i = len(key)
+    if i == 0:
+        return None
+    while True:
+        i -= 1
+        if i < 0 or key[i] < 0xFF:
+            break
+    if i < 0:
+        return None
+    return key[:i] + bytes([key[i] + 1])
+
+
+def boundary_in_range(key: bytes, b) -> bool:
+    """BoundaryUtil.inRange(key, boundary) (:241-263)"""
+    if b[0] is not None and _cmp(key, b[0]) < 0:
+        return False
+    if b[1] is not None:
+        return _cmp(key, b[1]) < 0
+    return True
+
+
+def _sorted_router(router):
+    import functools
+    return sorted(range(len(router)), key=functools.cmp_to_key(lambda i, j: boundary_compare(router[i], router[j])))
+
+
+def router_find_by_key(key: bytes, router):
+    """KVRangeRouterUtil.findByKey (:41-52): floorEntry(Boundary{startKey = key}), then inRange -> index into router or None"""
+    probe = (key, None)
+    floor = None
+    for i in _sorted_router(router):
+        if boundary_compare(router[i], probe) <= 0:
+            floor = i
+    if floor is not None and boundary_in_range(key, router[floor]):
+        return floor
+    return None
+
+
+def router_find_by_boundary(boundary, router) -> List[int]:
+    """KVRangeRouterUtil.findByBoundary (:54-103) -> indices into router, in router order.  TreeMap.subMap throws where
+    fromKey > toKey; that case yields [] here."""
+    order = _sorted_router(router)
+    if not order:
+        return []
+    start, end = boundary
+    if start is None and end is None:
+        return order
+    if start is None:
+        b_end = (end, end)
+        return [i for i in order if boundary_compare(router[i], b_end) < 0]  # headMap(boundaryEnd, false)
+    b_start = (start, start)
+    floor = None
+    for i in order:
+        if boundary_compare(router[i], b_start) <= 0:
+            floor = i
+    if floor is None:
+        floor = order[0]
+    include_from = boundary_compare_end(router[floor][1], start) > 0
+    out = []
+    for i in order:
+        c = boundary_compare(router[i], router[floor])
+        if c < 0 or (c == 0 and not include_from):
+            continue
+        if end is not None and boundary_compare(router[i], (end, end)) >= 0:  # subMap(.., boundaryEnd, false) / tailMap
+            continue
+        out.append(i)
+    return out
+
+
+def retain_parse_level_hash(key: bytes) -> bytes:
+    """KVSchemaUtil.parseLevelHash of the retain schema (KVSchemaUtil.java:79-85)"""
+    tl = int.from_bytes(key[1:3], "big")
+    lv = 3 + tl
+    n = int.from_bytes(key[lv:lv + 2], "big")
+    if len(key) < lv + 2 + n:
+        raise IndexError("parseLevelHash")
+    return key[lv + 2:lv + 2 + n]
+
+
+def retain_range_lookup(tenant: str, topic_filter: str, router) -> List[int]:
+    """MatchCallRangeRouter.rangeLookup for one topic filter (:58-95) + findCandidates (:96-133) -> indices into router"""
+    levels = topic_filter.split("/")
+    if "+" not in levels and levels[-1] != "#":
+        i = router_find_by_key(retain_message_key(tenant, topic_filter), router)
+        assert i is not None
+        return [i]
+    fixed = levels[-1] != "#"
+    prefix = retain_filter_prefix(levels)
+    n = len(levels) if fixed else len(levels) - 1
+    begin = retain_tenant_begin_key(tenant) + n.to_bytes(2, "big") + retain_level_hash(prefix)
+    if fixed:
+        return router_find_by_boundary((begin, boundary_upper_bound(begin)), router)
+    end = boundary_upper_bound(retain_tenant_begin_key(tenant))
+    cands = router_find_by_boundary((begin, end), router)
+    if not prefix:
+        return cands
+    lh = retain_level_hash(prefix)
+    lh_ub = boundary_upper_bound(lh)  # None: the reference dereferences it (NullPointerException); treated as open here
+    out = []
+    for i in cands:
+        cs, ce = router[i]
+        if boundary_compare_start(cs, begin) > 0:
+            h = retain_parse_level_hash(cs)
+            if lh_ub is not None and _cmp(lh_ub, h) <= 0:
+                continue
+        if boundary_compare_end(ce, end) <= 0 and _cmp(retain_parse_level_hash(ce), lh) <= 0:
+            continue
+        out.append(i)
+    return out
