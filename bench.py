@@ -379,6 +379,8 @@ def main():
     if node is not None:
         out["node_batch"] = node
     if world == 1 and not args.no_host_path:
+        out["fanout_group"] = fanout_group_leg(eng, d_row[0], d_ids[0], n, dev, torch, np)
+    if world == 1 and not args.no_host_path:
         ids_per_batch = n_match / steps
         if ids_per_batch * 4 <= 1 << 30:
             out["host_visible"] = host_visible(args, eng, w, batches, n, seed, rank, int(ids_per_batch * 1.25) + 4096)
@@ -600,6 +602,36 @@ def host_visible(args, eng, w, batches, n, seed, rank, cap):
             "bytes_in_per_batch": in_bytes, "bytes_out_per_batch": int(4 * (n + 1) + 4 * total_ids),
             "note": "host buffers in, CSR out, page-locked memory; latency = one blocking bmq_match_batch (upload + kernels + download); "
                     "throughput = bmq_match_submit/bmq_match_wait with two batches in flight"}
+
+
+def fanout_group_leg(eng, d_row, d_ids, n, dev, torch, np, reps=10):
+    """SURVEY.md 8f-4, the step behind the match: bmq_fanout_group_dev (segmented sort of the CSR by DelivererKey) on the CSR the last
+    batch left in HBM.  Outside the timed region; never fails the bench line."""
+    import bifromq_amd as B
+    try:
+        total = int(d_row[n].item())
+        if total == 0 or total > (1 << 28):
+            return {"skipped": "%d pairs" % total}
+        gcap = 1 << 16
+        ot, orr = torch.zeros(total, dtype=torch.int32, device=dev), torch.zeros(total, dtype=torch.int32, device=dev)
+        goff, grep = torch.zeros(gcap + 1, dtype=torch.int32, device=dev), torch.zeros(gcap, dtype=torch.int32, device=dev)
+        a = (d_row.data_ptr(), d_ids.data_ptr(), n, total, ot.data_ptr(), orr.data_ptr(), goff.data_ptr(), grep.data_ptr(), gcap)
+        t0 = time.perf_counter()
+        ng, sp = eng.fanout_group_device(*a)  # first call: parses the key tail of every route the batch touches
+        first = (time.perf_counter() - t0) * 1e3
+        ms = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ng, sp = eng.fanout_group_device(*a)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        sizes = np.diff(goff[:ng + 1].cpu().numpy().astype(np.int64))
+        return {"pairs": total, "groups": int(ng), "special": int(sp), "ms_first_call": first, "ms": float(np.median(ms)),
+                "pairs_per_s": total / (float(np.median(ms)) * 1e-3), "largest_group_pairs": int(sizes.max()) if ng else 0,
+                "note": "bmq_fanout_group_dev on the device-resident CSR of one batch: (topic, route) pairs regrouped by "
+                        "DelivererKey(subBrokerId, delivererKey) as DeliverExecutorGroup.submit + the deliverer's batcher do; wall time of "
+                        "the C-ABI call (it returns when the group table is complete)"}
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)}
 
 
 def kernel_sources_sha():

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
     "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get",
-    "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
+    "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
 ]
 
 
@@ -132,6 +132,8 @@ def lib() -> C.CDLL:
             "bmq_batcher_match_all": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, vp, vp, u64, P(u64), P(u64)]),
             "bmq_batcher_submit": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32, vp, vp]),
             "bmq_batcher_stats_get": (C.c_int, [vp, P(BatcherStats)]),
+            "bmq_fanout_group": (C.c_int, [vp, vp, vp, u32, vp, vp, u64, vp, vp, u32, P(u32), P(u32)]),
+            "bmq_fanout_group_dev": (C.c_int, [vp, vp, vp, u32, u64, vp, vp, vp, vp, u32, P(u32), P(u32)]),
             "bmq_router_find_by_key": (C.c_int, [vp, vp, vp, vp, vp, u32, C.c_char_p, u32, P(i32)]),
             "bmq_router_find_by_boundary": (C.c_int, [vp, vp, vp, vp, vp, u32, C.c_uint8, C.c_char_p, u32, C.c_char_p, u32, P(u32), P(u32)]),
             "bmq_retain_range_lookup": (C.c_int, [C.c_char_p, u32, vp, vp, u32, vp, vp, vp, vp, vp, u32, u32, vp]),

@@ -26,6 +26,7 @@
 #include "bmq_dist_kernels.h"
 #include "bmq_exec_dev.h"
 #include "bmq_exec_host.h"
+#include "bmq_fanout.h"
 #include "bmq_range_core.h"
 #include "bmq_retain.h"
 #include "bmq_retain_kernels.h"
@@ -142,6 +143,10 @@ struct bmq_engine {
     RetainLimit rlim;
     DevBuf r_scratch;
     DevBuf range_buf; // staging of bmq_range_lookup
+    // fan-out grouping (bmq_fanout.h): group table + per-route cache, created by the first call
+    std::unique_ptr<Fanout<DevExec>> dfo;
+    std::unique_ptr<Fanout<HostExec>> hfo;
+    DevBuf fo_buf; // staging of bmq_fanout_group
     // multi-GPU exchange inside the library (bmq_exchange.inc): RCCL communicator of this rank, its own stream
     void* comm = nullptr;
     int comm_world = 0, comm_rank = 0;
@@ -489,6 +494,7 @@ void bmq_engine_destroy(bmq_engine* e) {
         bmq_comm_destroy(e);
         if (e->ev_ex) (void)hipEventDestroy(e->ev_ex);
         if (e->s_ex) (void)hipStreamDestroy(e->s_ex);
+        e->dfo.reset();
         e->dix.reset(); // frees the HBM arrays while the stream still exists
         e->dx.release(e->dx.tmp);
         e->dx.tmp = nullptr;
@@ -1086,3 +1092,4 @@ int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len) { return java_st
 #include "bmq_batcher.inc"
 #include "bmq_range_engine.inc"
 #include "bmq_exchange.inc"
+#include "bmq_fanout_engine.inc"

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "bmq_build_core.h"
+#include "bmq_fanout_core.h"
 
 namespace bmq {
 
@@ -73,6 +74,28 @@ __global__ __launch_bounds__(256) void k_b_gather_refs(DistIndexMut ix, const ui
 __global__ __launch_bounds__(BK) void k_b_gather_bytes(DistIndexMut ix, const unsigned long long* refs, const uint64_t* offs, uint32_t n, uint8_t* out) {
     const uint32_t i = blockIdx.x * BK + threadIdx.x;
     if (i < n) gather_bytes_one(ix, refs, offs, i, out);
+}
+
+// fan-out grouping (bmq_fanout_core.h): one lane per (topic, route) pair
+__global__ __launch_bounds__(256) void k_fo_fill(DistIndexMut ix, FanoutState st, FanoutBatch b) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < b.total) fo_fill_one(ix, st, b, i);
+}
+__global__ __launch_bounds__(256) void k_fo_verify(DistIndexMut ix, FanoutState st, FanoutBatch b) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < b.total) fo_verify_one(ix, st, b, i);
+}
+__global__ __launch_bounds__(256) void k_fo_keys(DistIndexMut ix, FanoutState st, FanoutBatch b) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < b.total) fo_key_one(ix, st, b, i);
+}
+__global__ __launch_bounds__(256) void k_fo_emit(FanoutBatch b) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < b.total) fo_emit_one(b, j);
+}
+__global__ __launch_bounds__(256) void k_fo_groups(FanoutState st, FanoutBatch b) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < b.total) fo_group_one(st, b, j);
 }
 
 struct DevExec {
@@ -182,6 +205,34 @@ struct DevExec {
     }
     bool find(const DistIndexMut& ix, const uint8_t* q, uint32_t tenant_len, uint32_t filter_len, uint32_t* out, uint32_t cap) {
         hipLaunchKernelGGL(k_b_find, dim3(1), dim3(64), 0, stream, ix, q, tenant_len, filter_len, out, cap);
+        return launched();
+    }
+    // ---- fan-out grouping (bmq_fanout.h) ----
+    bool fill_bytes(void* p, int byte, size_t n) { return n == 0 || BMQ_X(hipMemsetAsync(p, byte, n, stream)); }
+    bool fo_fill(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b) {
+        hipLaunchKernelGGL(k_fo_fill, grid(b.total, 256), dim3(256), 0, stream, ix, st, b);
+        return launched();
+    }
+    bool fo_verify(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b) {
+        hipLaunchKernelGGL(k_fo_verify, grid(b.total, 256), dim3(256), 0, stream, ix, st, b);
+        return launched();
+    }
+    bool fo_keys(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b) {
+        hipLaunchKernelGGL(k_fo_keys, grid(b.total, 256), dim3(256), 0, stream, ix, st, b);
+        return launched();
+    }
+    bool sort_pairs32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int end_bit) {
+        size_t bytes = 0; // LSD radix sort: stable
+        if (!BMQ_X(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, stream))) return false;
+        if (!ensure_tmp(bytes)) return false;
+        return BMQ_X(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, stream));
+    }
+    bool fo_emit(const FanoutBatch& b) {
+        hipLaunchKernelGGL(k_fo_emit, grid(b.total, 256), dim3(256), 0, stream, b);
+        return launched();
+    }
+    bool fo_groups(const FanoutState& st, const FanoutBatch& b) {
+        hipLaunchKernelGGL(k_fo_groups, grid(b.total, 256), dim3(256), 0, stream, st, b);
         return launched();
     }
     bool gather_refs(const DistIndexMut& ix, const uint32_t* ids, uint32_t n, uint32_t id_end, unsigned long long* out) {

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "bmq_build_core.h"
+#include "bmq_fanout_core.h"
 
 namespace bmq {
 
@@ -112,6 +113,41 @@ struct HostExec {
     }
     bool find(const DistIndexMut& ix, const uint8_t* q, uint32_t tenant_len, uint32_t filter_len, uint32_t* out, uint32_t cap) {
         find_copy(ix, q, tenant_len, filter_len, out, cap);
+        return true;
+    }
+    // ---- fan-out grouping (bmq_fanout.h) ----
+    bool fill_bytes(void* p, int byte, size_t n) {
+        if (n) memset(p, byte, n);
+        return true;
+    }
+    bool fo_fill(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b) {
+        par(b.total, [&](size_t i) { fo_fill_one(ix, st, b, (uint32_t)i); });
+        return true;
+    }
+    bool fo_verify(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b) {
+        par(b.total, [&](size_t i) { fo_verify_one(ix, st, b, (uint32_t)i); });
+        return true;
+    }
+    bool fo_keys(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b) {
+        par(b.total, [&](size_t i) { fo_key_one(ix, st, b, (uint32_t)i); });
+        return true;
+    }
+    bool sort_pairs32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int /*end_bit*/) {
+        std::vector<uint32_t> order(n);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return keys_in[a] < keys_in[c]; });
+        for (uint32_t i = 0; i < n; i++) {
+            keys_out[i] = keys_in[order[i]];
+            vals_out[i] = vals_in[order[i]];
+        }
+        return true;
+    }
+    bool fo_emit(const FanoutBatch& b) {
+        par(b.total, [&](size_t j) { fo_emit_one(b, (uint32_t)j); });
+        return true;
+    }
+    bool fo_groups(const FanoutState& st, const FanoutBatch& b) {
+        par(b.total, [&](size_t j) { fo_group_one(st, b, (uint32_t)j); });
         return true;
     }
     bool gather_refs(const DistIndexMut& ix, const uint32_t* ids, uint32_t n, uint32_t id_end, unsigned long long* out) {

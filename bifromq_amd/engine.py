@@ -331,6 +331,35 @@ class Engine:
         self._check(_lib.lib().bmq_match_batch_dev(self.h, d_tenants, d_tenant_off, n_tenants, d_topic_tenant, d_topics,
                                                    d_topic_off, n_topics, d_row_ptr, d_ids, capacity, d_total))
 
+    # ---- fan-out grouping --------------------------------------------------------------------------------
+    def fanout_group(self, row_ptr, route_ids, group_cap: int = 256):
+        """Segmented sort of a match CSR by DelivererKey -> (out_topic, out_route, group_off, group_rep, special)."""
+        row = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        ids = np.ascontiguousarray(route_ids, dtype=np.uint32)
+        n, total = len(row) - 1, int(row[-1])
+        ot, orr = np.zeros(max(total, 1), dtype=np.uint32), np.zeros(max(total, 1), dtype=np.uint32)
+        ng, sp = C.c_uint32(), C.c_uint32()
+        while True:
+            goff, grep = np.zeros(group_cap + 1, dtype=np.uint32), np.zeros(max(group_cap, 1), dtype=np.uint32)
+            rc = _lib.lib().bmq_fanout_group(self.h, _ptr(row), _ptr(ids), n, _ptr(ot), _ptr(orr), total, _ptr(goff), _ptr(grep), group_cap,
+                                             C.byref(ng), C.byref(sp))
+            if rc == -3 and ng.value > group_cap:
+                group_cap = ng.value
+                continue
+            self._check(rc)
+            return ot[:total], orr[:total], goff[:ng.value + 1], grep[:ng.value], sp.value
+
+    def fanout_group_device(self, d_row_ptr, d_ids, n_topics, total, d_out_topic, d_out_route, d_group_off, d_group_rep, group_cap):
+        """All d_* are device pointers (ints).  -> (n_groups, special); BmqError -3 (.needed = groups) if group_cap is too small."""
+        ng, sp = C.c_uint32(), C.c_uint32()
+        rc = _lib.lib().bmq_fanout_group_dev(self.h, d_row_ptr, d_ids, n_topics, total, d_out_topic, d_out_route, d_group_off, d_group_rep,
+                                             group_cap, C.byref(ng), C.byref(sp))
+        if rc:
+            err = BmqError(rc, (_lib.lib().bmq_last_error(self.h) or b"").decode())
+            err.needed = ng.value
+            raise err
+        return ng.value, sp.value
+
     def finish(self) -> int:
         total = C.c_uint64()
         self._check(_lib.lib().bmq_match_finish(self.h, C.byref(total)))

@@ -253,6 +253,33 @@ int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, con
                   int32_t max_group_fanout, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
                   uint64_t* out_needed, int32_t* out_events, uint32_t events_cap, uint32_t* out_n_events);
 
+/* ---- fan-out grouping: the step behind the match --------------------------------------------------------------- */
+/* DistWorkerCoProc.batchDist hands every topic's matched routes to DeliverExecutorGroup.submit (DW/DeliverExecutorGroup.java:112-241);
+ * each NormalMatching becomes a DeliveryCall (DW/DeliverExecutor.java:85-90) that the deliverer batches by
+ * DelivererKey(subBrokerId, delivererKey) (bifromq-deliverer/.../DelivererKey.java:22, BatchDeliveryCall.java:71-76: per key, tenant ->
+ * message pack -> set of MatchInfo).  This is that regrouping for a whole match batch, as a segmented sort of its CSR on the device:
+ *   in : row_ptr[n_topics + 1], route_ids[row_ptr[n_topics]]                  (what bmq_match_batch* returned)
+ *   out: out_topic[k], out_route[k], k < row_ptr[n_topics]: the (topic index, route id) pairs ordered by (group, topic, route id);
+ *        out_group_off[*out_n_groups + 1]: group g owns the pairs out_group_off[g] .. out_group_off[g + 1];
+ *        out_group_rep[g]: a route id of the group (bmq_route_key of it gives the group's subBrokerId and delivererKey: the first
+ *        and the third NUL-separated part of its receiverUrl, SCHEMA/KVSchemaUtil.java:56-58), 0xFFFFFFFE for the group of
+ *        shared-subscription routes (flag 2 / 3: DeliverExecutorGroup.java:243-279 picks the receiver per message), 0xFFFFFFFF for
+ *        the group of ids whose route has been deleted since the match.
+ * A group = one DelivererKey, exactly (key bytes are compared, not only hashes).  The normal groups come first, in no particular
+ * order (the reference's batcher map is a HashMap), then the shared-subscription group (*out_special bit 0), then the dead group
+ * (bit 1).  The fan-out caps of submit() are not applied here: the count caps were applied by MatchedRoutes in key order
+ * (bmq_match_all), the byte / bandwidth throttles depend on the message.
+ * BMQ_E_NOSPACE: pair_cap < row_ptr[n_topics], or group_cap < *out_n_groups (the pairs are written, the group table is not).
+ * Works on a host-only engine too (it is not a match: the same per-pair functions run on host threads).
+ * _dev: all six array arguments are device pointers (the CSR may be the one bmq_match_batch_dev left in HBM, after
+ * bmq_match_finish); runs on the engine stream and returns when the groups are complete. */
+int bmq_fanout_group(bmq_engine* e, const uint32_t* row_ptr, const uint32_t* route_ids, uint32_t n_topics, uint32_t* out_topic,
+                     uint32_t* out_route, uint64_t pair_cap, uint32_t* out_group_off, uint32_t* out_group_rep, uint32_t group_cap,
+                     uint32_t* out_n_groups, uint32_t* out_special);
+int bmq_fanout_group_dev(bmq_engine* e, const uint32_t* d_row_ptr, const uint32_t* d_route_ids, uint32_t n_topics, uint64_t total,
+                         uint32_t* d_out_topic, uint32_t* d_out_route, uint32_t* d_out_group_off, uint32_t* d_out_group_rep,
+                         uint32_t group_cap, uint32_t* out_n_groups, uint32_t* out_special);
+
 /* ---- dist-server side range pruning ---------------------------------------------------------------------- */
 /* TenantRangeLookupCache.lookup (bifromq-dist/bifromq-dist-server/src/main/java/org/apache/bifromq/dist/server/scheduler/
  * TenantRangeLookupCache.java:62-109) for a batch of topics of ONE tenant against the tenant's candidate KV ranges in boundary

@@ -658,3 +658,35 @@ def retain_range_lookup(tenant: str, topic_filter: str, router) -> List[int]:
             continue
         out.append(i)
     return out
+
+
+# ---- fan-out grouping: what happens to the matched routes of a batch behind the match (DW/DeliverExecutorGroup.java:112-241,
+# DW/DeliverExecutor.java:85-90, bifromq-deliverer BatchDeliveryCall.java:71-76, DelivererKey.java:22) ---------------------------
+def deliverer_key_of(route_key_bytes: bytes):
+    """-> (subBrokerId, delivererKey) of a normal route (SCHEMA/cache/ReceiverCache.java:32-37: receiverUrl.split(NUL), parts[0]
+    parsed as int, parts[2]), or None for a shared-subscription route (flag 2 / 3)."""
+    flag, _tenant, _filt, recv = parse_route_key(route_key_bytes)
+    if flag != FLAG_NORMAL:
+        return None
+    parts = recv.split("\0")
+    return int(parts[0]), parts[2]
+
+
+def fanout_groups(key_of, per_topic_routes):
+    """DeliverExecutorGroup.submit for every topic of a batch: each NormalMatching -> DeliverExecutor.send -> a DeliveryCall batched under
+    DelivererKey(subBrokerId, delivererKey); BatchDeliveryCall.add files it under tenant -> message pack (topic) -> MatchInfo set.
+    key_of(route id) -> route key bytes, or None if the route is gone.
+    -> ({DelivererKey: [(topic index, route id), ...] in (topic, route) order}, shared-subscription pairs, dead pairs)"""
+    batches, shared, dead = {}, [], []
+    for t, routes in enumerate(per_topic_routes):
+        for rid in routes:
+            k = key_of(rid)
+            if k is None:
+                dead.append((t, rid))
+                continue
+            dk = deliverer_key_of(k)
+            if dk is None:
+                shared.append((t, rid))  # GroupMatching: the receiver is picked per message (DeliverExecutorGroup.java:243-279)
+            else:
+                batches.setdefault(dk, []).append((t, rid))
+    return batches, shared, dead
