@@ -21,6 +21,13 @@
 
 namespace bmq {
 
+// Words several lanes of one pass may write (always the same value, or values pass 2 treats alike): relaxed atomics on both sides.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> BMQ_HD void fo_store(T* p, T v) { shared_store(p, v); }
+#else
+template <class T> BMQ_HD void fo_store(T* p, T v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+#endif
+
 constexpr uint32_t FO_UNSET = 0xFFFFFFFFu; // dgroup[id]: not computed yet
 constexpr uint32_t FO_NEW = 0x80000000u;   // dgroup[id] flag: mapped in this pass, bytes not verified against the slot's first route yet
 enum : uint32_t { FO_ERR_FULL = 1u, FO_ERR_COLLISION = 2u, FO_ERR_CSR = 4u };
@@ -87,12 +94,12 @@ BMQ_HD bool fo_same_deliverer(const uint8_t* kp, const DelivererSpan& a, const D
 BMQ_HD void fo_fill_one(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b, uint32_t i) {
     const uint32_t id = b.ids[i];
     if (id >= b.id_end || id >= st.id_cap) return; // counted as dead in pass 3
-    if (shared_load(st.dgroup + id) != FO_UNSET) return;
+    if (atom_load(st.dgroup + id) != FO_UNSET) return;
     const unsigned long long r = ix.kref[id];
     if (r == 0) return; // deleted meanwhile: not cached (the id is never handed out again before the next rebuild, but stays dead)
     DelivererSpan s;
     if (!fo_deliverer_span(ix.kpool, r & KREF_OFF_MASK, r >> KREF_LEN_SHIFT, s)) {
-        shared_store(st.dgroup + id, st.gt_cap); // shared subscription
+        fo_store(st.dgroup + id, st.gt_cap); // shared subscription
         return;
     }
     const unsigned long long h = fo_hash(ix.kpool, s, st.seed);
@@ -100,16 +107,16 @@ BMQ_HD void fo_fill_one(const DistIndexMut& ix, const FanoutState& st, const Fan
     uint32_t slot = (uint32_t)(h >> 17) & mask;
     for (uint32_t probe = 0; probe < st.gt_cap; probe++, slot = (slot + 1) & mask) {
         // thousands of routes share a deliverer key: look before claiming, so that only the first comers pay for an atomic
-        unsigned long long cur = shared_load(st.gt_hash + slot);
+        unsigned long long cur = atom_load(st.gt_hash + slot);
         if (cur == 0) cur = atom_cas(st.gt_hash + slot, 0ull, h);
         if (cur == 0) { // claimed: this route is the slot's reference
-            shared_store(st.gt_rep + slot, id);
+            fo_store(st.gt_rep + slot, id);
             atom_add(st.flags + 1, 1u);
-            shared_store(st.dgroup + id, slot); // nothing to verify against
+            fo_store(st.dgroup + id, slot); // nothing to verify against
             return;
         }
         if (cur == h) {
-            shared_store(st.dgroup + id, slot | FO_NEW);
+            fo_store(st.dgroup + id, slot | FO_NEW);
             return;
         }
     }
@@ -119,7 +126,7 @@ BMQ_HD void fo_fill_one(const DistIndexMut& ix, const FanoutState& st, const Fan
 BMQ_HD void fo_verify_one(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b, uint32_t i) {
     const uint32_t id = b.ids[i];
     if (id >= b.id_end || id >= st.id_cap) return;
-    const uint32_t g = shared_load(st.dgroup + id);
+    const uint32_t g = atom_load(st.dgroup + id);
     if (g == FO_UNSET || !(g & FO_NEW)) return;
     const uint32_t slot = g & ~FO_NEW;
     const uint32_t rep = st.gt_rep[slot];
@@ -130,7 +137,7 @@ BMQ_HD void fo_verify_one(const DistIndexMut& ix, const FanoutState& st, const F
         fo_deliverer_span(ix.kpool, rr & KREF_OFF_MASK, rr >> KREF_LEN_SHIFT, c))
         same = fo_same_deliverer(ix.kpool, a, c);
     if (!same) atom_or(st.flags + 0, (uint32_t)FO_ERR_COLLISION);
-    shared_store(st.dgroup + id, slot);
+    fo_store(st.dgroup + id, slot);
 }
 // pass 3, one lane per pair: sort key = group slot (shared subscriptions: gt_cap, dead ids: gt_cap + 1), value = position
 // (a route deleted since the match is dead whatever the cache remembers of it)

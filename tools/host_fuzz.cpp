@@ -20,6 +20,7 @@
 #include "../bifromq_amd/csrc/bmq_codec.h"
 #include "../bifromq_amd/csrc/bmq_dist_index.h"
 #include "../bifromq_amd/csrc/bmq_exec_host.h"
+#include "../bifromq_amd/csrc/bmq_fanout.h"
 
 using namespace bmq;
 
@@ -171,8 +172,11 @@ int main(int argc, char** argv) {
         if (rnd(400) == 0) tenants.push_back("late-tenant-" + std::to_string(extra_tenants++)); // tenants appear over time
         const std::string& tn = tenants[rnd(tenants.size())];
         const uint8_t flag = rnd(10) == 0 ? 2 : 1;
+        // receiverUrl = subBrokerId NUL receiverId NUL delivererKey: a few brokers x a few deliverer keys (the fan-out grouping below)
         return encode_route_key(tn, rand_filter(), flag,
-                                flag == 1 ? std::string("0\0", 2) + "inbox" + std::to_string(rnd(40)) + std::string("\0d", 2) : "g" + std::to_string(rnd(3)));
+                                flag == 1 ? std::to_string(rnd(3)) + std::string("\0", 1) + "inbox" + std::to_string(rnd(40)) + std::string("\0d", 2) +
+                                                std::to_string(rnd(12))
+                                          : "g" + std::to_string(rnd(3)));
     };
     std::map<std::string, uint32_t> model; // key -> id
     uint32_t next_id = 0;
@@ -180,7 +184,9 @@ int main(int argc, char** argv) {
     hx.threads = threads;
     DistIndex<HostExec> h(hx);
     h.tiny = getenv("BMQ_FUZZ_BIG") == nullptr;
-    uint64_t checks = 0, n_apply = 0, n_rebuild = 0;
+    uint64_t checks = 0, n_apply = 0, n_rebuild = 0, fo_pairs = 0;
+    Fanout<HostExec> fo(hx, h); // fan-out grouping (bmq_fanout.h) over the same index, kept across rebuilds and applies
+    fo.initial_table = 4;       // 36 deliverer keys: the group table grows twice
     for (int round = 0; round < rounds; round++) {
         std::vector<std::string> keys;
         std::vector<uint8_t> ops;
@@ -311,6 +317,67 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        if (h.built) { // fan-out grouping of a random CSR (ids live, deleted and never handed out) against the model
+            std::map<uint32_t, const std::string*> by_id;
+            for (auto& e : model) by_id[e.second] = &e.first;
+            const uint32_t n_rows = 1 + (uint32_t)rnd(rnd(4) == 0 ? 800 : 40); // now and then enough pairs for several host threads
+            std::vector<uint32_t> row{0}, ids;
+            for (uint32_t r = 0; r < n_rows; r++) {
+                std::set<uint32_t> s;
+                for (size_t k = rnd(4) ? rnd(30) : 0; k > 0; k--) s.insert((uint32_t)rnd(next_id + 3));
+                ids.insert(ids.end(), s.begin(), s.end());
+                row.push_back((uint32_t)ids.size());
+            }
+            const uint32_t total = (uint32_t)ids.size(), gcap = 64;
+            std::vector<uint32_t> ot(total + 1), orr(total + 1), goff(gcap + 1), grep(gcap);
+            ids.resize(total + 4);
+            FanoutResult fr;
+            if (!fo.group(row.data(), ids.data(), n_rows, total, ot.data(), orr.data(), goff.data(), grep.data(), gcap, fr) || fr.group_overflow) {
+                fprintf(stderr, "round %d: fan-out grouping failed: %s\n", round, fo.error.c_str());
+                return 1;
+            }
+            // model: DelivererKey (subBrokerId, delivererKey) / "shared" / "dead" -> pairs in (row, id) order
+            std::map<std::string, std::vector<std::pair<uint32_t, uint32_t>>> want, got;
+            for (uint32_t r = 0; r < n_rows; r++)
+                for (uint32_t k = row[r]; k < row[r + 1]; k++) {
+                    auto it = by_id.find(ids[k]);
+                    std::string name = "dead";
+                    if (it != by_id.end()) {
+                        RouteKeyParts kp;
+                        decode_route_key(*it->second, kp);
+                        if (kp.flag != 1) name = "shared";
+                        else {
+                            const auto parts = split(kp.receiver, '\0');
+                            name = "k:" + parts[0] + "|" + parts[2];
+                        }
+                    }
+                    want[name].push_back({r, ids[k]});
+                }
+            bool bad = goff[0] != 0 || goff[fr.n_groups] != total;
+            for (uint32_t g = 0; g < fr.n_groups && !bad; g++) {
+                std::string name = grep[g] == 0xFFFFFFFFu ? "dead" : grep[g] == 0xFFFFFFFEu ? "shared" : "";
+                if (name.empty()) {
+                    auto it = by_id.find(grep[g]);
+                    if (it == by_id.end()) {
+                        bad = true;
+                        break;
+                    }
+                    RouteKeyParts kp;
+                    decode_route_key(*it->second, kp);
+                    const auto parts = split(kp.receiver, '\0');
+                    name = "k:" + parts[0] + "|" + parts[2];
+                }
+                if (got.count(name)) bad = true;
+                for (uint32_t k = goff[g]; k < goff[g + 1]; k++) got[name].push_back({ot[k], orr[k]});
+            }
+            const uint32_t sp = (want.count("shared") ? 1u : 0u) | (want.count("dead") ? 2u : 0u);
+            if (bad || got != want || fr.special != sp) {
+                fprintf(stderr, "round %d: fan-out groups differ from the model (%zu vs %zu groups, special %u vs %u)\n", round, got.size(), want.size(),
+                        fr.special, sp);
+                return 1;
+            }
+            fo_pairs += total;
+        }
         for (int tq = 0; tq < 150; tq++) {
             const std::string& tn = tq % 25 == 24 ? std::string("nobody") : tenants[rnd(tenants.size())];
             const std::string topic = rand_topic();
@@ -335,9 +402,9 @@ int main(int argc, char** argv) {
     DistIndexStats st;
     h.stats(st);
     printf("host_fuzz ok: seed %llu, %d rounds (%llu rebuilds, %llu applies), %llu topic checks, final %zu routes, %llu nodes, %llu tokens, "
-           "%llu trie slots (%llu garbage), %llu id-list words (%llu garbage)\n",
+           "%llu trie slots (%llu garbage), %llu id-list words (%llu garbage), %llu fan-out pairs grouped\n",
            (unsigned long long)seed, rounds, (unsigned long long)n_rebuild, (unsigned long long)n_apply, (unsigned long long)checks, model.size(),
            (unsigned long long)st.n_nodes, (unsigned long long)st.n_tokens, (unsigned long long)st.trie_slots, (unsigned long long)st.trie_garbage_slots,
-           (unsigned long long)st.id_list_words, (unsigned long long)st.id_list_garbage);
+           (unsigned long long)st.id_list_words, (unsigned long long)st.id_list_garbage, (unsigned long long)fo_pairs);
     return 0;
 }
