@@ -406,6 +406,22 @@ def main():
                                                  "max_topics_per_launch": int(bs.max_batch_topics),
                                                  "rows_equal_blocking_path": bool((cnt2 == cnt).all() and (hsh2 == hsh).all())}
         bt.close()
+        # the route cache in front of it (bmq_route_cache_*: TenantRouteCache + TopicIndex on the engine's side): the same calls, twice over
+        # the same topics -- pass 1 loads through the batching front, pass 2 is answered on the host
+        try:
+            bt = eng.batcher()
+            rc_ = B.RouteCache(bt, max_routes_per_tenant=1 << 40)
+            cnt3, hsh3, secs = rc_.drive(w.tenants(), htt[:m], sub, args.batcher_threads, passes=2)
+            cs = rc_.stats()
+            out["batching_front"]["route_cache"] = {
+                "threads": args.batcher_threads, "calls_per_s_first_pass": m / secs[0], "calls_per_s_second_pass": m / secs[1],
+                "hits": int(cs.hits), "misses": int(cs.misses), "entries": int(cs.entries), "cached_routes": int(cs.cached_routes),
+                "rows_equal_blocking_path": bool((cnt3 == cnt).all() and (hsh3 == hsh).all()),
+                "note": "bmq_route_cache_get: ISubscriptionCache.get per (tenant, topic); Zipf repeats inside pass 1 already hit"}
+            rc_.close()
+            bt.close()
+        except Exception as ex:  # noqa: BLE001
+            out["batching_front"]["route_cache"] = {"error": repr(ex)}
     if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n)
     if dist is not None:

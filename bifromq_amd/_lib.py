@@ -24,7 +24,8 @@ ABI_SYMBOLS = [
     "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
     "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get",
-    "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
+    "bmq_route_cache_create", "bmq_route_cache_destroy", "bmq_route_cache_get", "bmq_route_cache_is_cached", "bmq_route_cache_apply",
+    "bmq_route_cache_rebuild", "bmq_route_cache_reset", "bmq_route_cache_stats_get", "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
 ]
 
 
@@ -65,6 +66,16 @@ class BatcherConfig(C.Structure):
 class BatcherStats(C.Structure):
     _fields_ = [("n_requests", C.c_uint64), ("n_topics", C.c_uint64), ("n_batches", C.c_uint64),
                 ("max_batch_topics", C.c_uint64), ("n_deduped", C.c_uint64)]
+
+
+class RouteCacheConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("mutation_log_entries", C.c_uint32), ("max_routes_per_tenant", C.c_uint64), ("expiry_ms", C.c_uint64),
+                ("reserved", C.c_uint64 * 4)]
+
+
+class RouteCacheStats(C.Structure):
+    _fields_ = [("hits", C.c_uint64), ("misses", C.c_uint64), ("evictions", C.c_uint64), ("invalidations", C.c_uint64), ("expired", C.c_uint64),
+                ("stale_loads", C.c_uint64), ("entries", C.c_uint64), ("cached_routes", C.c_uint64)]
 
 
 _lib = None
@@ -132,6 +143,14 @@ def lib() -> C.CDLL:
             "bmq_batcher_match_all": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, vp, vp, u64, P(u64), P(u64)]),
             "bmq_batcher_submit": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32, vp, vp]),
             "bmq_batcher_stats_get": (C.c_int, [vp, P(BatcherStats)]),
+            "bmq_route_cache_create": (C.c_int, [vp, vp, P(RouteCacheConfig), P(vp)]),
+            "bmq_route_cache_destroy": (None, [vp]),
+            "bmq_route_cache_get": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32, u64, vp, u32, P(u32), P(u64)]),
+            "bmq_route_cache_is_cached": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32]),
+            "bmq_route_cache_apply": (C.c_int, [vp, vp, vp, vp, u32]),
+            "bmq_route_cache_rebuild": (C.c_int, [vp, vp, vp, u32]),
+            "bmq_route_cache_reset": (C.c_int, [vp]),
+            "bmq_route_cache_stats_get": (C.c_int, [vp, P(RouteCacheStats)]),
             "bmq_fanout_group": (C.c_int, [vp, vp, vp, u32, vp, vp, u64, vp, vp, u32, P(u32), P(u32)]),
             "bmq_fanout_group_dev": (C.c_int, [vp, vp, vp, u32, u64, vp, vp, vp, vp, u32, P(u32), P(u32)]),
             "bmq_router_find_by_key": (C.c_int, [vp, vp, vp, vp, vp, u32, C.c_char_p, u32, P(i32)]),
@@ -165,6 +184,7 @@ def gen() -> C.CDLL:
             "bmqgen_retain": (u32, [vp, u64, u32, C.c_int]),
             "bmqgen_drive_singletons": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, vp, vp, C.POINTER(C.c_double)]),
             "bmqgen_row_hash": (u64, [vp, u64]),
+            "bmqgen_drive_cache": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, u32, vp, vp, C.POINTER(C.c_double)]),
             "bmqgen_drive_async": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, vp, vp, C.POINTER(C.c_double)]),
         }
         for name, (res, args) in sig.items():

@@ -1,0 +1,398 @@
+// bmq_cache.cpp -- the route cache in front of the batching front: the engine-side counterpart of
+//   ISubscriptionCache            DW/cache/ISubscriptionCache.java:30-40    get / isCached / refresh / reset
+//   SubscriptionCache             DW/cache/SubscriptionCache.java:117-146   tenant -> TenantRouteCache
+//   TenantRouteCache              DW/cache/TenantRouteCache.java:116-296    topic -> matched routes, loads through matchAll(singleton),
+//                                                                            Add/RemoveRoutes tasks patch the entries index.match(filter) finds
+//   TopicIndex                    DW/TopicIndex.java:39-156                 trie of the CACHED topics, queried with a topic filter
+// Plain C++ over the C ABI (include/bmq.h): a miss goes through bmq_batcher_match_all (one GPU launch for everything missing right
+// now), a hit never leaves the host.  Route mutations go to the engine (bmq_routes_apply) and then drop every cached topic the
+// mutated filters match (the reference patches those entries in place; an invalidated entry reloads to the same set on its next
+// access, which is what the reference's own reload computes).
+//
+// What keeps a stale result out of the cache: a load carries the engine epoch it was matched at; every mutation is logged per tenant
+// with the epoch it produced.  An insert first checks the log for mutations newer than its match epoch whose filter matches the topic
+// (the reference serialises loads and patches of a tenant in one task loop, TenantRouteCache.java:208-212 -- same effect, no queue).
+#include "../../include/bmq.h"
+#include "bmq_codec.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+namespace bmq {
+namespace cache {
+
+inline std::vector<std::string_view> split(std::string_view s, char sep) { // TopicUtil.parse(topic, false): empty levels kept
+    std::vector<std::string_view> out;
+    size_t b = 0;
+    for (size_t i = 0; i <= s.size(); i++)
+        if (i == s.size() || s[i] == sep) {
+            out.push_back(s.substr(b, i - b));
+            b = i + 1;
+        }
+    return out;
+}
+
+// SURVEY.md 8a-0 on level lists: does `filter` match `topic`?
+inline bool filter_matches(const std::vector<std::string_view>& f, const std::vector<std::string_view>& t) {
+    const bool sys = !t.empty() && !t[0].empty() && t[0][0] == '$';
+    for (size_t i = 0; i < f.size(); i++) {
+        if (f[i] == "#" && i + 1 == f.size()) return !(i == 0 && sys);
+        if (i >= t.size()) return false;
+        if (f[i] == "+") {
+            if (i == 0 && sys) return false;
+            continue;
+        }
+        if (f[i] != t[i]) return false;
+    }
+    return f.size() == t.size();
+}
+
+struct Entry {
+    std::string topic;
+    std::vector<uint32_t> ids; // ascending
+    uint64_t epoch = 0;        // engine epoch of the match
+    uint64_t last_access_ms = 0;
+    std::list<Entry*>::iterator lru;
+    uint64_t weight() const { return ids.empty() ? 1 : ids.size(); } // TenantRouteCache.java:108-111
+};
+
+// TopicIndex (DW/TopicIndex.java:39-156): trie of the cached topics; match(filter) walks it as TopicMatcher's selector does
+struct TopicIndex {
+    struct Node {
+        std::unordered_map<std::string, std::unique_ptr<Node>> children;
+        Entry* value = nullptr;
+    };
+    Node root;
+    void add(const std::vector<std::string_view>& levels, Entry* e) {
+        Node* n = &root;
+        for (auto lv : levels) {
+            auto& c = n->children[std::string(lv)];
+            if (!c) c = std::make_unique<Node>();
+            n = c.get();
+        }
+        n->value = e;
+    }
+    void remove(const std::vector<std::string_view>& levels) { remove_at(root, levels, 0); }
+    template <class F> void match(const std::vector<std::string_view>& filter, F&& f) const { walk(root, filter, 0, f); }
+
+private:
+    static bool remove_at(Node& n, const std::vector<std::string_view>& levels, size_t i) { // true: n is empty now
+        if (i == levels.size()) n.value = nullptr;
+        else {
+            auto it = n.children.find(std::string(levels[i]));
+            if (it != n.children.end() && remove_at(*it->second, levels, i + 1)) n.children.erase(it);
+        }
+        return !n.value && n.children.empty();
+    }
+    template <class F> static void all_below(const Node& n, F& f) {
+        if (n.value) f(n.value);
+        for (auto& c : n.children) all_below(*c.second, f);
+    }
+    template <class F> static void walk(const Node& n, const std::vector<std::string_view>& flt, size_t i, F& f) {
+        if (i == flt.size()) {
+            if (n.value) f(n.value);
+            return;
+        }
+        const std::string_view lv = flt[i];
+        const bool last = i + 1 == flt.size();
+        if (lv == "#" && last) { // the node itself ("a/#" matches "a") and everything below; at level 0 not the '$' topics
+            if (i > 0 && n.value) f(n.value);
+            for (auto& c : n.children)
+                if (!(i == 0 && !c.first.empty() && c.first[0] == '$')) all_below(*c.second, f);
+            return;
+        }
+        if (lv == "+") {
+            for (auto& c : n.children)
+                if (!(i == 0 && !c.first.empty() && c.first[0] == '$')) walk(*c.second, flt, i + 1, f);
+            return;
+        }
+        auto it = n.children.find(std::string(lv));
+        if (it != n.children.end()) walk(*it->second, flt, i + 1, f);
+    }
+};
+
+struct Mutation {
+    uint64_t epoch;
+    std::vector<std::string> filter;
+};
+
+struct TenantCache { // TenantRouteCache
+    std::mutex mu;
+    std::unordered_map<std::string, std::unique_ptr<Entry>> entries;
+    std::list<Entry*> lru; // front = most recently used
+    uint64_t weight = 0;
+    TopicIndex index;
+    std::vector<Mutation> log; // ascending epochs; complete for epochs > log_floor
+    uint64_t log_floor = 0;
+};
+
+} // namespace cache
+} // namespace bmq
+
+using namespace bmq;
+using namespace bmq::cache;
+
+struct bmq_route_cache {
+    bmq_engine* e = nullptr;
+    bmq_batcher* b = nullptr;
+    uint64_t max_routes_per_tenant = 200000; // DistMaxCachedRoutesPerTenant
+    uint64_t expiry_ms = 60000;              // DistTopicMatchExpirySeconds
+    uint32_t log_keep = 4096;
+    std::shared_mutex tmu;
+    std::unordered_map<std::string, std::unique_ptr<TenantCache>> tenants;
+    std::mutex apply_mu; // one refresh at a time, in commit order (ISubscriptionCache.refresh comes from the range's apply thread)
+    uint64_t created_floor = 0;
+    std::atomic<bool> bypass{false}; // a rebuild is replacing the index: serve nothing from the cache, cache nothing
+    std::atomic<uint64_t> hits{0}, misses{0}, evictions{0}, invalidations{0}, stale_loads{0}, expired{0};
+
+    TenantCache* find(std::string_view tenant) {
+        std::shared_lock<std::shared_mutex> g(tmu);
+        auto it = tenants.find(std::string(tenant));
+        return it == tenants.end() ? nullptr : it->second.get();
+    }
+    TenantCache* obtain(std::string_view tenant) {
+        if (TenantCache* t = find(tenant)) return t;
+        std::unique_lock<std::shared_mutex> g(tmu);
+        auto& p = tenants[std::string(tenant)];
+        if (!p) {
+            p = std::make_unique<TenantCache>();
+            p->log_floor = created_floor; // mutations before the tenant cache existed were never logged for it
+        }
+        return p.get();
+    }
+    // tenant lock held
+    void drop(TenantCache& t, Entry* en) {
+        t.index.remove(split(en->topic, '/'));
+        t.weight -= en->weight();
+        t.lru.erase(en->lru);
+        t.entries.erase(en->topic); // frees en
+    }
+};
+
+extern "C" {
+
+int bmq_route_cache_create(bmq_engine* e, bmq_batcher* b, const bmq_route_cache_config* cfg, bmq_route_cache** out) {
+    if (!e || !b || !out) return BMQ_E_INVAL;
+    *out = nullptr;
+    auto c = std::make_unique<bmq_route_cache>();
+    c->e = e;
+    c->b = b;
+    if (cfg) {
+        if (cfg->struct_size < 8 || cfg->struct_size > sizeof(bmq_route_cache_config)) return BMQ_E_INVAL;
+        bmq_route_cache_config k{};
+        memcpy(&k, cfg, cfg->struct_size);
+        if (k.max_routes_per_tenant) c->max_routes_per_tenant = k.max_routes_per_tenant;
+        if (k.expiry_ms) c->expiry_ms = k.expiry_ms;
+        if (k.mutation_log_entries) c->log_keep = k.mutation_log_entries;
+    }
+    bmq_index_info info{};
+    if (bmq_index_info_get(e, &info) == BMQ_OK) c->created_floor = info.epoch;
+    *out = c.release();
+    return BMQ_OK;
+}
+
+void bmq_route_cache_destroy(bmq_route_cache* c) { delete c; }
+
+int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, uint64_t now_ms,
+                        uint32_t* out_route_ids, uint32_t cap, uint32_t* out_n, uint64_t* out_epoch) {
+    if (!c || !out_n || (tenant_len && !tenant) || (topic_len && !topic)) return BMQ_E_INVAL;
+    const std::string_view tn((const char*)tenant, tenant_len), tp((const char*)topic, topic_len);
+    TenantCache* t = c->obtain(tn);
+    const bool bypass = c->bypass.load();
+    if (!bypass) {
+        std::lock_guard<std::mutex> g(t->mu);
+        auto it = t->entries.find(std::string(tp));
+        if (it != t->entries.end()) {
+            Entry* en = it->second.get();
+            if (now_ms - en->last_access_ms >= c->expiry_ms && now_ms >= en->last_access_ms) { // expireAfterAccess
+                c->expired++;
+                c->drop(*t, en);
+            } else {
+                c->hits++;
+                en->last_access_ms = now_ms;
+                t->lru.splice(t->lru.begin(), t->lru, en->lru);
+                *out_n = (uint32_t)en->ids.size();
+                if (out_epoch) *out_epoch = en->epoch;
+                if (en->ids.size() > cap) return BMQ_E_NOSPACE;
+                if (!en->ids.empty()) memcpy(out_route_ids, en->ids.data(), en->ids.size() * 4);
+                return BMQ_OK;
+            }
+        }
+    }
+    c->misses++;
+    // load: matchAll(singleton(topic)) through the batching front (TenantRouteCache.java:180-193)
+    const uint32_t off[2] = {0, topic_len};
+    uint32_t row[2] = {0, 0};
+    std::vector<uint32_t> ids(64);
+    uint64_t needed = 0, epoch = 0;
+    int rc = bmq_batcher_match_all(c->b, tenant, tenant_len, topic, off, 1, row, ids.data(), ids.size(), &needed, &epoch);
+    if (rc == BMQ_E_NOSPACE) {
+        ids.resize(needed);
+        rc = bmq_batcher_match_all(c->b, tenant, tenant_len, topic, off, 1, row, ids.data(), ids.size(), &needed, &epoch);
+    }
+    if (rc != BMQ_OK) return rc;
+    ids.resize(needed);
+    *out_n = (uint32_t)ids.size();
+    if (out_epoch) *out_epoch = epoch;
+    const bool fits = ids.size() <= cap;
+    if (fits && !ids.empty()) memcpy(out_route_ids, ids.data(), ids.size() * 4);
+    if (!bypass && !c->bypass.load()) {
+        std::lock_guard<std::mutex> g(t->mu);
+        bool stale = epoch < t->log_floor; // mutations in (epoch, log_floor] are unknown here
+        if (!stale && !t->log.empty() && t->log.back().epoch > epoch) {
+            const auto tl = split(tp, '/');
+            for (size_t k = t->log.size(); k-- > 0 && t->log[k].epoch > epoch && !stale;) {
+                std::vector<std::string_view> fl(t->log[k].filter.begin(), t->log[k].filter.end());
+                stale = filter_matches(fl, tl);
+            }
+        }
+        if (stale) c->stale_loads++; // correct as of its epoch (the caller gets it), but not what the next caller should see
+        else {
+            auto& slot = t->entries[std::string(tp)];
+            if (slot) { // another thread loaded the same topic meanwhile: keep the newer
+                if (slot->epoch >= epoch) return fits ? BMQ_OK : BMQ_E_NOSPACE;
+                c->drop(*t, slot.get());
+            }
+            auto en = std::make_unique<Entry>();
+            en->topic = std::string(tp);
+            en->ids = std::move(ids);
+            en->epoch = epoch;
+            en->last_access_ms = now_ms;
+            t->lru.push_front(en.get());
+            en->lru = t->lru.begin();
+            t->weight += en->weight();
+            t->index.add(split(en->topic, '/'), en.get());
+            t->entries[en->topic] = std::move(en);
+            while (t->weight > c->max_routes_per_tenant && t->lru.size() > 1) { // maximumWeight: least recently used first
+                c->evictions++;
+                c->drop(*t, t->lru.back());
+            }
+        }
+    }
+    return fits ? BMQ_OK : BMQ_E_NOSPACE;
+}
+
+int bmq_route_cache_is_cached(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len) {
+    if (!c) return BMQ_E_INVAL;
+    TenantCache* t = c->find(std::string_view((const char*)tenant, tenant_len));
+    if (!t) return 0;
+    const auto fl = split(std::string_view((const char*)filter, filter_len), '/');
+    bool any = false;
+    std::lock_guard<std::mutex> g(t->mu);
+    t->index.match(fl, [&](Entry*) { any = true; });
+    return any ? 1 : 0;
+}
+
+int bmq_route_cache_apply(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+    if (!c || (n && (!keys || !key_off))) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> ag(c->apply_mu);
+    const int rc = bmq_routes_apply(c->e, keys, key_off, op, n);
+    if (rc != BMQ_OK) return rc;
+    bmq_index_info info{};
+    const int ri = bmq_index_info_get(c->e, &info);
+    if (ri != BMQ_OK) return ri;
+    // per tenant that has a cache: log the filters, drop the cached topics they match
+    std::unordered_map<std::string, std::vector<std::vector<std::string>>> by_tenant;
+    for (uint32_t i = 0; i < n; i++) {
+        RouteKeyParts kp;
+        if (!decode_route_key(std::string_view((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]), kp)) continue; // the engine refused it already
+        std::vector<std::string> fl;
+        for (auto lv : split(kp.esc_filter, '\0')) fl.emplace_back(lv);
+        by_tenant[std::string(kp.tenant)].push_back(std::move(fl));
+    }
+    {
+        std::unique_lock<std::shared_mutex> g(c->tmu);
+        c->created_floor = info.epoch;
+    }
+    for (auto& bt : by_tenant) {
+        TenantCache* t = c->find(bt.first);
+        if (!t) continue;
+        std::lock_guard<std::mutex> g(t->mu);
+        std::vector<Entry*> hit;
+        for (auto& fl : bt.second) {
+            std::vector<std::string_view> fv(fl.begin(), fl.end());
+            t->index.match(fv, [&](Entry* en) { hit.push_back(en); });
+            t->log.push_back({info.epoch, std::move(fl)});
+        }
+        if (t->log.size() > c->log_keep) { // forget the oldest: loads older than what is left are not cached
+            const size_t cut = t->log.size() - c->log_keep / 2;
+            t->log_floor = t->log[cut - 1].epoch;
+            t->log.erase(t->log.begin(), t->log.begin() + (long)cut);
+        }
+        std::sort(hit.begin(), hit.end()); // a topic may be hit by several filters of the batch
+        hit.erase(std::unique(hit.begin(), hit.end()), hit.end());
+        for (Entry* en : hit) {
+            c->invalidations++;
+            c->drop(*t, en);
+        }
+    }
+    return BMQ_OK;
+}
+
+namespace {
+// drop every entry and forget the log: nothing matched at or before `floor_epoch` is cached afterwards.  Tenant objects stay (other
+// threads may hold pointers to them).
+void clear_all(bmq_route_cache* c, uint64_t floor_epoch) {
+    std::unique_lock<std::shared_mutex> g(c->tmu);
+    c->created_floor = floor_epoch;
+    for (auto& t : c->tenants) {
+        std::lock_guard<std::mutex> tg(t.second->mu);
+        t.second->index = TopicIndex{};
+        t.second->lru.clear();
+        t.second->entries.clear();
+        t.second->weight = 0;
+        t.second->log.clear();
+        t.second->log_floor = floor_epoch;
+    }
+}
+} // namespace
+
+int bmq_route_cache_reset(bmq_route_cache* c) {
+    if (!c) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> ag(c->apply_mu);
+    bmq_index_info info{};
+    const int ri = bmq_index_info_get(c->e, &info);
+    clear_all(c, ri == BMQ_OK ? info.epoch : ~0ull);
+    return BMQ_OK;
+}
+
+int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys) {
+    if (!c) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> ag(c->apply_mu);
+    c->bypass = true; // route ids of the old generation must not be served once the engine holds the new one
+    const int rc = bmq_rebuild(c->e, keys, key_off, n_keys);
+    bmq_index_info info{};
+    const int ri = bmq_index_info_get(c->e, &info);
+    clear_all(c, ri == BMQ_OK ? info.epoch : ~0ull);
+    c->bypass = false;
+    return rc;
+}
+
+int bmq_route_cache_stats_get(bmq_route_cache* c, bmq_route_cache_stats* out) {
+    if (!c || !out) return BMQ_E_INVAL;
+    memset(out, 0, sizeof(*out));
+    out->hits = c->hits;
+    out->misses = c->misses;
+    out->evictions = c->evictions;
+    out->invalidations = c->invalidations;
+    out->stale_loads = c->stale_loads;
+    out->expired = c->expired;
+    std::shared_lock<std::shared_mutex> g(c->tmu);
+    for (auto& t : c->tenants) {
+        std::lock_guard<std::mutex> tg(t.second->mu);
+        out->entries += t.second->entries.size();
+        out->cached_routes += t.second->weight;
+    }
+    return BMQ_OK;
+}
+
+} // extern "C"

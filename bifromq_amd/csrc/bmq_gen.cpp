@@ -381,6 +381,53 @@ int bmqgen_drive_singletons(void* fn, void* batcher, const uint8_t* tenants, con
     return err.load();
 }
 
+// ---- the same through the route cache (bmq_route_cache_get): n_threads threads, every topic once, `passes` times over the batch (the
+// second pass of a batch finds what the first one loaded)
+typedef int (*cache_get_fn)(void*, const uint8_t*, uint32_t, const uint8_t*, uint32_t, uint64_t, uint32_t*, uint32_t, uint32_t*, uint64_t*);
+int bmqgen_drive_cache(void* fn, void* cache, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                       const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, uint32_t n_threads, uint32_t passes, uint32_t* out_count,
+                       uint64_t* out_hash, double* out_seconds) {
+    if (!fn || !cache || !n_threads) return -1;
+    const cache_get_fn get = (cache_get_fn)fn;
+    std::atomic<int> err{0};
+    for (uint32_t pass = 0; pass < passes && !err.load(); pass++) {
+        std::atomic<uint32_t> next{0};
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (uint32_t w = 0; w < n_threads; w++)
+            th.emplace_back([&] {
+                std::vector<uint32_t> ids(1024);
+                for (;;) {
+                    const uint32_t i = next.fetch_add(1);
+                    if (i >= n_topics || err.load()) break;
+                    const uint32_t ti = topic_tenant[i];
+                    if (ti >= n_tenants) {
+                        err = -1;
+                        break;
+                    }
+                    uint32_t n = 0;
+                    uint64_t epoch = 0;
+                    int rc;
+                    for (;;) {
+                        rc = get(cache, tenants + tenant_off[ti], tenant_off[ti + 1] - tenant_off[ti], topics + topic_off[i], topic_off[i + 1] - topic_off[i],
+                                 1000, ids.data(), (uint32_t)ids.size(), &n, &epoch);
+                        if (rc != -3) break; // BMQ_E_NOSPACE: grow and ask again
+                        ids.resize((size_t)n + 64);
+                    }
+                    if (rc) {
+                        err = rc;
+                        break;
+                    }
+                    out_count[i] = n;
+                    out_hash[i] = bmqgen_row_hash(ids.data(), n);
+                }
+            });
+        for (auto& t : th) t.join();
+        if (out_seconds) out_seconds[pass] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return err.load();
+}
+
 // ---- the same for the asynchronous side (bmq_batcher_submit): n_threads threads submit every topic once, as fast as the batcher
 // takes them; the callback records count + row hash; returns when every callback has run.
 typedef void (*batcher_cb)(void*, int, const uint32_t*, uint32_t, uint64_t);

@@ -588,3 +588,90 @@ class Batcher:
         if rc:
             raise BmqError(rc, "bmqgen_drive_singletons")
         return cnt, hsh, sec.value
+
+
+class RouteCache:
+    """bmq_route_cache_*: ISubscriptionCache (DW/cache/ISubscriptionCache.java:30-40) on the engine's side of the boundary -- topic ->
+    matched routes per tenant, loads through the batching front, TopicIndex-style invalidation by route mutations."""
+
+    def __init__(self, batcher: Batcher, max_routes_per_tenant: int = 0, expiry_ms: int = 0, mutation_log_entries: int = 0):
+        cfg = _lib.RouteCacheConfig()
+        cfg.struct_size = C.sizeof(_lib.RouteCacheConfig)
+        cfg.max_routes_per_tenant = max_routes_per_tenant
+        cfg.expiry_ms = expiry_ms
+        cfg.mutation_log_entries = mutation_log_entries
+        h = C.c_void_p()
+        rc = _lib.lib().bmq_route_cache_create(batcher.engine.h, batcher.h, C.byref(cfg), C.byref(h))
+        if rc:
+            raise BmqError(rc, "bmq_route_cache_create failed")
+        self.h = h
+        self.batcher = batcher  # keeps batcher and engine alive
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().bmq_route_cache_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc:
+            raise BmqError(rc, what + ": " + (_lib.lib().bmq_last_error(self.batcher.engine.h) or b"").decode())
+
+    def get(self, tenant, topic, now_ms: int = 0) -> Tuple[List[int], int]:
+        """ISubscriptionCache.get -> (ascending route ids, engine epoch they were matched at)"""
+        t, p = _b(tenant), _b(topic)
+        cap = 64
+        n, ep = C.c_uint32(), C.c_uint64()
+        while True:
+            ids = np.zeros(cap, dtype=np.uint32)
+            rc = _lib.lib().bmq_route_cache_get(self.h, t, len(t), p, len(p), now_ms, _ptr(ids), cap, C.byref(n), C.byref(ep))
+            if rc == -3:
+                cap = n.value + 16
+                continue
+            self._check(rc, "bmq_route_cache_get")
+            return ids[:n.value].tolist(), int(ep.value)
+
+    def is_cached(self, tenant, topic_filter) -> bool:
+        t, f = _b(tenant), _b(topic_filter)
+        rc = _lib.lib().bmq_route_cache_is_cached(self.h, t, len(t), f, len(f))
+        if rc < 0:
+            raise BmqError(rc, "bmq_route_cache_is_cached")
+        return rc == 1
+
+    def apply(self, ops: Sequence[Tuple[int, bytes]]):
+        """ISubscriptionCache.refresh: [(0 = put | 1 = delete, route key)] -> engine, then invalidation"""
+        data, off = pack([k for _, k in ops])
+        op = np.array([o for o, _ in ops], dtype=np.uint8)
+        self._check(_lib.lib().bmq_route_cache_apply(self.h, _ptr(data), _ptr(off), _ptr(op), len(ops)), "bmq_route_cache_apply")
+
+    def rebuild(self, keys: Iterable[bytes]):
+        data, off = pack(sorted(keys))
+        self._check(_lib.lib().bmq_route_cache_rebuild(self.h, _ptr(data), _ptr(off), len(off) - 1), "bmq_route_cache_rebuild")
+
+    def reset(self):
+        self._check(_lib.lib().bmq_route_cache_reset(self.h), "bmq_route_cache_reset")
+
+    def stats(self) -> "_lib.RouteCacheStats":
+        st = _lib.RouteCacheStats()
+        self._check(_lib.lib().bmq_route_cache_stats_get(self.h, C.byref(st)), "bmq_route_cache_stats_get")
+        return st
+
+    def drive(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed: Tuple[np.ndarray, np.ndarray], n_threads: int, passes: int = 2):
+        """n_threads native threads call bmq_route_cache_get once per topic, `passes` times over the batch.
+        -> (ids per topic, row hash per topic, seconds per pass)"""
+        tdata, toff = pack(tenants)
+        pdata, poff = topics_packed
+        n = len(poff) - 1
+        cnt, hsh = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint64)
+        sec = (C.c_double * passes)()
+        tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
+        rc = _lib.gen().bmqgen_drive_cache(C.cast(_lib.lib().bmq_route_cache_get, C.c_void_p), self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(tt),
+                                           _ptr(pdata), _ptr(poff), n, n_threads, passes, _ptr(cnt), _ptr(hsh), sec)
+        if rc:
+            raise BmqError(rc, "bmqgen_drive_cache")
+        return cnt, hsh, list(sec)

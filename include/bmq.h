@@ -243,6 +243,46 @@ int bmq_batcher_submit(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_le
                        bmq_batcher_cb cb, void* user);
 int bmq_batcher_stats_get(bmq_batcher* b, bmq_batcher_stats* out);
 
+/* ---- route cache ---------------------------------------------------------------------------------- */
+/* ISubscriptionCache (DW/cache/ISubscriptionCache.java:30-40) on the engine's side of the boundary: SubscriptionCache ->
+ * TenantRouteCache (DW/cache/TenantRouteCache.java:116-296: topic -> matched routes, loaded by matchAll(singleton(topic)), bounded by
+ * DistMaxCachedRoutesPerTenant with weight max(1, #routes), expireAfterAccess DistTopicMatchExpirySeconds) with its TopicIndex
+ * (DW/TopicIndex.java:39-156: the cached topics, queried with the topic filter of a route mutation).  A hit is answered on the host;
+ * a miss goes through the batching front, i.e. into ONE GPU launch with every other miss of the moment.
+ *   get       ISubscriptionCache.get(tenantId, topic): the matched route ids (ascending; caps not applied), *out_epoch = the engine
+ *             epoch they were matched at.  now_ms is the caller's clock (Caffeine's Ticker).  BMQ_E_NOSPACE + *out_n if cap is short.
+ *   is_cached ISubscriptionCache.isCached(tenantId, filterLevels) = !index.match(filterLevels).isEmpty(): 1 / 0
+ *   apply     ISubscriptionCache.refresh(AddRoutesTask / RemoveRoutesTask): bmq_routes_apply on the engine, then every cached topic
+ *             one of the mutated filters matches is dropped and reloads on its next get (the reference patches those entries in
+ *             place -- TenantRouteCache.java:224-277 -- which yields the same route set a reload computes).  A load that was matched
+ *             before a mutation but finishes after it is recognised by its epoch and not cached.
+ *   rebuild   IKVRangeCoProc.reset: bmq_rebuild + drop everything (route ids of different generations are unrelated); nothing is
+ *             served from the cache while the engine swaps the index.   reset: drop everything (ISubscriptionCache.reset(boundary)).
+ * Any number of threads may call get / is_cached; apply / rebuild / reset come from one thread at a time (the range's apply thread)
+ * and may run concurrently with the getters.  Destroy before the batcher. */
+typedef struct bmq_route_cache bmq_route_cache;
+typedef struct bmq_route_cache_config {
+    uint32_t struct_size;
+    uint32_t mutation_log_entries;   /* per tenant; default 4096 */
+    uint64_t max_routes_per_tenant;  /* DistMaxCachedRoutesPerTenant, default 200000 */
+    uint64_t expiry_ms;              /* DistTopicMatchExpirySeconds, default 60000 */
+    uint64_t reserved[4];
+} bmq_route_cache_config;
+typedef struct bmq_route_cache_stats {
+    uint64_t hits, misses, evictions, invalidations, expired;
+    uint64_t stale_loads;            /* loads overtaken by a mutation of a matching filter: returned to their caller, not cached */
+    uint64_t entries, cached_routes; /* now */
+} bmq_route_cache_stats;
+int bmq_route_cache_create(bmq_engine* e, bmq_batcher* b, const bmq_route_cache_config* cfg /* may be NULL */, bmq_route_cache** out);
+void bmq_route_cache_destroy(bmq_route_cache* c);
+int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, uint64_t now_ms,
+                        uint32_t* out_route_ids, uint32_t cap, uint32_t* out_n, uint64_t* out_epoch);
+int bmq_route_cache_is_cached(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len);
+int bmq_route_cache_apply(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
+int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys);
+int bmq_route_cache_reset(bmq_route_cache* c);
+int bmq_route_cache_stats_get(bmq_route_cache* c, bmq_route_cache_stats* out);
+
 /* ---- host-side mirror of MatchedRoutes (fan-out caps in KV order) -------------------------------------- */
 /* One ITenantRouteMatcher.matchAll(topics, maxPersistentFanout, maxGroupFanout) call for one tenant,
  * including DW/cache/MatchedRoutes.java:87-141: persistent (subBrokerId == 1) and group fan-out caps applied

@@ -186,3 +186,76 @@ def test_identical_requests_of_one_launch_share_a_row(setup):
     assert rows[0] == exp[0] and rows[2] == exp[0]
     assert b.stats().n_deduped > st.n_deduped
     b.close()
+
+
+# ---- the route cache in front of the batching front (bmq_route_cache_*) ------------------------------------
+def test_route_cache_get_hit_invalidate_against_oracle(setup):
+    """ISubscriptionCache.get / isCached / refresh on the real engine: a miss is a GPU match through the batching front, a hit never
+    reaches the engine, a route mutation drops exactly the cached topics its filter matches, and what a get returns afterwards is the
+    oracle's row on the updated key set."""
+    eng0, tn, tt, _, topics, exp = setup
+    w = B.Workload(21, 6, 1500, 1)
+    keys = w.keys()
+    eng = B.Engine(device=0).rebuild(keys)  # own engine: this test mutates the index
+    b = eng.batcher()
+    c = B.RouteCache(b)
+    idx = list(range(0, 3000, 7))
+    for i in idx:
+        ids, ep = c.get(tn[tt[i]], topics[i], now_ms=5)
+        assert ids == exp[i] and ep == eng.info().epoch
+    n_batches = b.stats().n_batches
+    for i in idx:
+        assert c.get(tn[tt[i]], topics[i], now_ms=6)[0] == exp[i]
+    st = c.stats()
+    assert b.stats().n_batches == n_batches  # second round: hits only
+    distinct = len({(int(tt[i]), topics[i]) for i in idx})
+    assert st.misses == distinct and st.hits == 2 * len(idx) - distinct and st.entries == distinct
+    # mutate: a '#' subscription under tenant 0's most common first level, and the unsubscribe of one existing route
+    t0 = tn[0]
+    lv0 = topics[[i for i in idx if tt[i] == 0][0]].split("/")[0]
+    new_key = B.route_key(t0, lv0 + "/#", 1, "0\0cacheTest\0d1")
+    gone = keys[[i for i, k in enumerate(keys) if B.decode_route_key(k)[1] == t0][0]]
+    assert c.is_cached(t0, lv0 + "/#")
+    c.apply([(0, new_key), (1, gone)])
+    keys2 = sorted((set(keys) | {new_key}) - {gone})
+    assert not c.is_cached(t0, lv0 + "/#")  # every cached topic under lv0 was dropped
+    assert c.stats().invalidations >= 1
+    kv2 = O.KV(keys2)
+    sel = [i for i in idx if tt[i] == 0]
+    want = U.semantic_rows(kv2, tn, tt[sel], [topics[i] for i in sel])
+    for j, i in enumerate(sel):
+        ids, ep = c.get(t0, topics[i], now_ms=7)
+        got = sorted(keys2.index(k) for k in eng.route_keys(np.array(ids, dtype=np.uint32))) if ids else []
+        assert got == want[j], topics[i]
+        assert ep == eng.info().epoch
+    # other tenants' entries survived the mutation
+    other = [i for i in idx if tt[i] != 0][:50]
+    nb = b.stats().n_batches
+    for i in other:
+        assert c.get(tn[tt[i]], topics[i], now_ms=8)[0] == exp[i]
+    assert b.stats().n_batches == nb
+    # rebuild through the cache: a new generation, nothing old is served
+    c.rebuild(keys2)
+    assert c.stats().entries == 0
+    for j, i in enumerate(sel[:40]):
+        assert c.get(t0, topics[i], now_ms=9)[0] == want[j]  # ids are ranks again
+    c.close()
+    b.close()
+    eng.close()
+
+
+def test_route_cache_native_threads_two_passes(setup):
+    """64 native threads through bmq_route_cache_get, twice over the batch: pass one loads (misses collected into shared launches by the
+    batching front), pass two is served from the host; both passes give exactly the oracle's rows."""
+    eng, tn, tt, packed, topics, exp = setup
+    b = eng.batcher()
+    c = B.RouteCache(b, max_routes_per_tenant=10_000_000)
+    cnt, hsh, sec = c.drive(tn, tt, packed, n_threads=64, passes=2)
+    assert cnt.tolist() == [len(r) for r in exp]
+    assert hsh.tolist() == [_row_hash(r) for r in exp]
+    st = c.stats()
+    distinct = len({(int(tt[i]), topics[i]) for i in range(len(topics))})
+    assert st.entries == distinct and st.hits >= len(topics)  # the whole second pass hit
+    assert st.misses >= distinct  # concurrent first requests of one topic may both load
+    c.close()
+    b.close()

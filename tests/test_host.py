@@ -293,3 +293,18 @@ def test_compact_renumbers_and_frees_garbage_host():
     assert after.garbage_bytes == 0 and after.n_nodes < before.n_nodes  # the nodes of the 67 deleted filters are gone
     assert e.route_keys(list(range(len(live)))) == live
     assert e.find("t", "grow/7/+/x") == [live.index(B.route_key("t", "grow/7/+/x", 1, "0\0g7\0d"))] and e.find("t", "a/0") == []
+
+
+def test_route_cache_under_sanitizers():
+    """tools/cache_fuzz.cpp: the route cache (bmq_cache.cpp: ISubscriptionCache / TenantRouteCache / TopicIndex on the engine's side of
+    the boundary) over a stand-in engine, under ASan + UBSan and under TSan: TopicIndex against the reference's golden table
+    (DWT/TopicIndexTest.java:41-73) and the matching rule, hit / invalidate / evict / expire / rebuild behaviour, and getter threads
+    against a mutator -- no load overtaken by a mutation may end up cached."""
+    import subprocess
+    csrc = os.path.join(ROOT, "bifromq_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "cachefuzz"], check=True, capture_output=True, timeout=600)
+    exe = os.path.join(ROOT, "tools", "cache_fuzz")
+    r = subprocess.run([exe, "1", "6", "1200"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "cache_fuzz ok" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe + "_tsan", "2", "6", "1200"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "cache_fuzz ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr

@@ -1,0 +1,397 @@
+// cache_fuzz.cpp -- test tool, not product: the route cache (bifromq_amd/csrc/bmq_cache.cpp) under AddressSanitizer/UBSan and
+// ThreadSanitizer, without a GPU.  The engine and the batching front behind the cache are replaced by a stand-in that matches by brute
+// force over a std::map model and counts epochs exactly as the engine does, so that every answer can be checked:
+//   1. TopicIndex against the reference's golden table (DWT/TopicIndexTest.java:41-73) and against the matching rule on random input;
+//   2. single-threaded cache behaviour: miss -> hit, isCached, invalidation by a matching mutation only, weight-bounded LRU eviction,
+//      expire-after-access, rebuild;
+//   3. getter threads against a mutator thread: every answer equals the brute force at the epoch it reports, and once everything has
+//      settled no cached entry differs from the brute force on the final model (a load overtaken by a mutation must not be cached).
+// Build + run: make -C bifromq_amd/csrc cachefuzz   (tests/test_host.py runs both builds)
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <random>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../bifromq_amd/csrc/bmq_cache.cpp"
+#include "../bifromq_amd/csrc/bmq_codec.h"
+
+// ---- stand-in engine ---------------------------------------------------------------------------------------------------------------
+struct bmq_engine {
+    std::mutex mu;
+    std::map<std::string, uint32_t> model; // route key -> id
+    uint32_t next_id = 0;
+    uint64_t epoch = 1, generation = 1;
+    std::vector<std::map<std::string, uint32_t>> history{{}, {}}; // history[epoch] = model at that epoch
+    std::atomic<int> match_delay_us{0};
+    std::atomic<uint64_t> n_match{0};
+};
+struct bmq_batcher {
+    bmq_engine* e;
+};
+
+static std::vector<uint32_t> brute(const std::map<std::string, uint32_t>& model, std::string_view tenant, std::string_view topic) {
+    std::vector<uint32_t> out;
+    const auto tl = bmq::cache::split(topic, '/');
+    for (auto& kv : model) {
+        bmq::RouteKeyParts kp;
+        if (!bmq::decode_route_key(kv.first, kp) || kp.tenant != tenant) continue;
+        if (bmq::cache::filter_matches(bmq::cache::split(kp.esc_filter, '\0'), tl)) out.push_back(kv.second);
+    }
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+extern "C" {
+int bmq_batcher_match_all(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
+                          uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed, uint64_t* out_epoch) {
+    if (n_topics != 1) return BMQ_E_INVAL;
+    std::vector<uint32_t> ids;
+    {
+        std::lock_guard<std::mutex> g(b->e->mu);
+        ids = brute(b->e->model, std::string_view((const char*)tenant, tenant_len),
+                    std::string_view((const char*)topics + topic_off[0], topic_off[1] - topic_off[0]));
+        *out_epoch = b->e->epoch;
+    }
+    b->e->n_match++;
+    if (const int d = b->e->match_delay_us.load()) std::this_thread::sleep_for(std::chrono::microseconds(d)); // the answer travels a while
+    out_row_ptr[0] = 0;
+    out_row_ptr[1] = (uint32_t)ids.size();
+    *out_needed = ids.size();
+    if (ids.size() > out_capacity) return BMQ_E_NOSPACE;
+    for (size_t i = 0; i < ids.size(); i++) out_route_ids[i] = ids[i];
+    return BMQ_OK;
+}
+int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+    std::lock_guard<std::mutex> g(e->mu);
+    for (uint32_t i = 0; i < n; i++) {
+        const std::string k((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
+        if (op && op[i]) e->model.erase(k);
+        else if (!e->model.count(k)) e->model[k] = e->next_id++;
+    }
+    e->epoch++;
+    e->history.push_back(e->model);
+    return BMQ_OK;
+}
+int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uint32_t n) {
+    std::lock_guard<std::mutex> g(e->mu);
+    std::set<std::string> ks;
+    for (uint32_t i = 0; i < n; i++) ks.emplace((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
+    e->model.clear();
+    e->next_id = 0;
+    for (auto& k : ks) e->model[k] = e->next_id++;
+    e->epoch++;
+    e->generation++;
+    e->history.push_back(e->model);
+    return BMQ_OK;
+}
+int bmq_index_info_get(const bmq_engine* ce, bmq_index_info* out) {
+    bmq_engine* e = const_cast<bmq_engine*>(ce);
+    std::lock_guard<std::mutex> g(e->mu);
+    memset(out, 0, sizeof(*out));
+    out->epoch = e->epoch;
+    out->generation = e->generation;
+    out->n_routes = e->model.size();
+    return BMQ_OK;
+}
+}
+
+static int g_fail = 0;
+#define EXPECT(c)                                                       \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            fprintf(stderr, "cache_fuzz: %s (line %d)\n", #c, __LINE__); \
+            g_fail++;                                                   \
+        }                                                               \
+    } while (0)
+
+// ---- 1. TopicIndex ------------------------------------------------------------------------------------------------------------------
+static std::set<std::string> index_match(const bmq::cache::TopicIndex& ix, const std::string& filter) {
+    std::set<std::string> out;
+    ix.match(bmq::cache::split(filter, '/'), [&](bmq::cache::Entry* e) { out.insert(e->topic); });
+    return out;
+}
+static void test_topic_index(uint64_t seed) {
+    using namespace bmq::cache;
+    // DWT/TopicIndexTest.java:41-73
+    const std::vector<std::string> topics = {"/", "/a", "/b", "a", "a/", "a/b", "a/b/c", "$a", "$a/", "$a/b"};
+    std::vector<std::unique_ptr<Entry>> es;
+    TopicIndex ix;
+    for (auto& t : topics) {
+        es.push_back(std::make_unique<Entry>());
+        es.back()->topic = t;
+        ix.add(split(es.back()->topic, '/'), es.back().get());
+    }
+    using S = std::set<std::string>;
+    const std::vector<std::pair<std::string, S>> table = {
+        {"/", {"/"}}, {"/a", {"/a"}}, {"/b", {"/b"}}, {"a", {"a"}}, {"a/", {"a/"}}, {"a/b", {"a/b"}}, {"a/b/c", {"a/b/c"}}, {"$a", {"$a"}},
+        {"$a/", {"$a/"}}, {"$a/b", {"$a/b"}}, {"", {}}, {"fakeTopic", {}},
+        {"#", {"/", "/a", "/b", "a", "a/", "a/b", "a/b/c"}}, {"+", {"a"}}, {"+/#", {"/", "/a", "/b", "a", "a/", "a/b", "a/b/c"}},
+        {"+/+", {"/", "/a", "/b", "a/", "a/b"}}, {"+/+/#", {"/", "/a", "/b", "a/", "a/b", "a/b/c"}},
+        {"/+", {"/", "/a", "/b"}}, {"/+/#", {"/", "/a", "/b"}}, {"/#", {"/", "/a", "/b"}},
+        {"a/+", {"a/", "a/b"}}, {"a/#", {"a", "a/", "a/b", "a/b/c"}},
+        {"$a/+", {"$a/", "$a/b"}}, {"$a/+/#", {"$a/", "$a/b"}}, {"$a/#", {"$a", "$a/", "$a/b"}}};
+    for (auto& row : table) EXPECT(index_match(ix, row.first) == row.second);
+    // remove: DWT/TopicIndexTest.java (remove then match)
+    ix.remove(split("a/b", '/'));
+    EXPECT(index_match(ix, "a/#") == (S{"a", "a/", "a/b/c"}));
+    ix.remove(split("a/b/c", '/'));
+    EXPECT(index_match(ix, "a/#") == (S{"a", "a/"}));
+    // random: the trie walk == the rule applied to every topic
+    std::mt19937_64 rng(seed);
+    const std::vector<std::string> alpha = {"a", "b", "", "$s", "c", "dd"};
+    auto level = [&]() { return alpha[rng() % alpha.size()]; };
+    for (int round = 0; round < 50; round++) {
+        TopicIndex rx;
+        std::vector<std::unique_ptr<Entry>> re;
+        std::set<std::string> ts;
+        for (int i = 0; i < 40; i++) {
+            std::string t;
+            for (size_t d = 1 + rng() % 4, k = 0; k < d; k++) t += (k ? "/" : "") + level();
+            ts.insert(t);
+        }
+        for (auto& t : ts) {
+            re.push_back(std::make_unique<Entry>());
+            re.back()->topic = t;
+            rx.add(split(re.back()->topic, '/'), re.back().get());
+        }
+        for (int q = 0; q < 60; q++) {
+            std::string f;
+            const size_t d = 1 + rng() % 4;
+            for (size_t k = 0; k < d; k++) {
+                const int r = (int)(rng() % 10);
+                f += (k ? "/" : "") + (r < 2 ? std::string("+") : (r == 2 && k + 1 == d ? std::string("#") : level()));
+            }
+            S want;
+            for (auto& t : ts)
+                if (filter_matches(split(f, '/'), split(t, '/'))) want.insert(t);
+            EXPECT(index_match(rx, f) == want);
+        }
+        // removing half leaves exactly the other half reachable
+        size_t i = 0;
+        S left;
+        for (auto& t : ts)
+            if (i++ % 2) rx.remove(split(t, '/'));
+            else left.insert(t);
+        S sys_free;
+        for (auto& t : left)
+            if (t.empty() || t[0] != '$') sys_free.insert(t);
+        EXPECT(index_match(rx, "#") == sys_free);
+    }
+}
+
+// ---- helpers --------------------------------------------------------------------------------------------------------------------------
+struct Packed {
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> off{0};
+    std::vector<uint8_t> op;
+    void add(const std::string& k, uint8_t o) {
+        bytes.insert(bytes.end(), k.begin(), k.end());
+        off.push_back((uint32_t)bytes.size());
+        op.push_back(o);
+    }
+};
+static std::string key_of(const std::string& tenant, const std::string& filter, int rid) {
+    return bmq::encode_route_key(tenant, filter, 1, std::string("0\0", 2) + "inbox" + std::to_string(rid) + std::string("\0d", 2));
+}
+static bool cache_get(bmq_route_cache* c, const std::string& tenant, const std::string& topic, uint64_t now, std::vector<uint32_t>& ids, uint64_t& epoch,
+                      size_t first_cap = 4) {
+    ids.assign(first_cap, 0); // small on purpose: the NOSPACE protocol runs all the time
+    for (;;) {
+        uint32_t n = 0;
+        const int rc = bmq_route_cache_get(c, (const uint8_t*)tenant.data(), (uint32_t)tenant.size(), (const uint8_t*)topic.data(), (uint32_t)topic.size(),
+                                           now, ids.data(), (uint32_t)ids.size(), &n, &epoch);
+        if (rc == BMQ_E_NOSPACE) { // the row may have grown again by the next call
+            ids.assign(n, 0);
+            continue;
+        }
+        ids.resize(n);
+        return rc == BMQ_OK;
+    }
+}
+static int is_cached(bmq_route_cache* c, const std::string& tenant, const std::string& filter) {
+    return bmq_route_cache_is_cached(c, (const uint8_t*)tenant.data(), (uint32_t)tenant.size(), (const uint8_t*)filter.data(), (uint32_t)filter.size());
+}
+
+// ---- 2. single-threaded behaviour --------------------------------------------------------------------------------------------------
+static void test_behaviour() {
+    bmq_engine e;
+    bmq_batcher b{&e};
+    bmq_route_cache_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    cfg.max_routes_per_tenant = 12;
+    cfg.expiry_ms = 1000;
+    bmq_route_cache* c = nullptr;
+    EXPECT(bmq_route_cache_create(&e, &b, &cfg, &c) == BMQ_OK);
+    Packed p;
+    for (int i = 0; i < 5; i++) p.add(key_of("t", "a/+", i), 0);
+    p.add(key_of("t", "a/b", 9), 0);
+    p.add(key_of("u", "#", 1), 0);
+    EXPECT(bmq_route_cache_apply(c, p.bytes.data(), p.off.data(), p.op.data(), (uint32_t)p.op.size()) == BMQ_OK);
+    std::vector<uint32_t> ids;
+    uint64_t ep = 0;
+    bmq_route_cache_stats st{};
+    EXPECT(cache_get(c, "t", "a/b", 10, ids, ep, 16) && ids.size() == 6 && ep == 2); // 5 x a/+ and a/b
+    EXPECT(cache_get(c, "t", "a/b", 20, ids, ep, 16) && ids.size() == 6);
+    EXPECT(cache_get(c, "t", "x", 20, ids, ep, 16) && ids.empty());
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.hits == 1 && st.misses == 2 && st.entries == 2 && st.cached_routes == 7); // an empty row weighs 1
+    EXPECT(is_cached(c, "t", "a/+") == 1 && is_cached(c, "t", "#") == 1 && is_cached(c, "t", "b/#") == 0 && is_cached(c, "nobody", "#") == 0);
+    // a mutation of a filter that matches no cached topic leaves the cache alone; one that matches drops exactly those topics
+    Packed q;
+    q.add(key_of("t", "b/c", 1), 0);
+    EXPECT(bmq_route_cache_apply(c, q.bytes.data(), q.off.data(), q.op.data(), 1) == BMQ_OK);
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.invalidations == 0 && st.entries == 2);
+    Packed r;
+    r.add(key_of("t", "a/#", 7), 0);
+    r.add(key_of("t", "a/+", 0), 1);
+    EXPECT(bmq_route_cache_apply(c, r.bytes.data(), r.off.data(), r.op.data(), 2) == BMQ_OK);
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.invalidations == 1 && st.entries == 1 && is_cached(c, "t", "a/b") == 0 && is_cached(c, "t", "x") == 1);
+    EXPECT(cache_get(c, "t", "a/b", 30, ids, ep, 16) && ids.size() == 6 && ep == 4); // -1 a/+ route, +1 a/#
+    // weight-bounded LRU: rows of 6 (a/b), 5, 5 ids: the third load evicts the least recently used
+    EXPECT(cache_get(c, "t", "a/c", 31, ids, ep, 16) && ids.size() == 5);
+    EXPECT(cache_get(c, "t", "a/b", 32, ids, ep, 16)); // touch a/b: "x" (weight 1) and a/c are older
+    EXPECT(cache_get(c, "t", "a/d", 33, ids, ep, 16) && ids.size() == 5);
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.evictions >= 1 && st.cached_routes <= 12 && is_cached(c, "t", "a/b") == 1 && is_cached(c, "t", "a/d") == 1);
+    // expire after access
+    const uint64_t loads = e.n_match;
+    EXPECT(cache_get(c, "t", "a/b", 900, ids, ep, 16) && e.n_match == loads);      // hit, access time moves on
+    EXPECT(cache_get(c, "t", "a/b", 1850, ids, ep, 16) && e.n_match == loads);     // 950 ms after the last access: still there
+    EXPECT(cache_get(c, "t", "a/b", 2900, ids, ep, 16) && e.n_match == loads + 1); // 1050 ms: expired, reloaded
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.expired == 1);
+    // rebuild: ids renumbered, nothing of the old generation survives
+    Packed nb;
+    nb.add(key_of("t", "a/b", 100), 0);
+    EXPECT(bmq_route_cache_rebuild(c, nb.bytes.data(), nb.off.data(), 1) == BMQ_OK);
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.entries == 0);
+    EXPECT(cache_get(c, "t", "a/b", 3000, ids, ep, 16) && ids == std::vector<uint32_t>{0});
+    EXPECT(cache_get(c, "u", "zz", 3000, ids, ep, 16) && ids.empty());
+    EXPECT(bmq_route_cache_reset(c) == BMQ_OK && is_cached(c, "t", "#") == 0);
+    bmq_route_cache_destroy(c);
+}
+
+// ---- 3. getters against a mutator ---------------------------------------------------------------------------------------------------
+static void test_concurrent(uint64_t seed, int n_threads, int ms) {
+    bmq_engine e;
+    e.match_delay_us = 40;
+    bmq_batcher b{&e};
+    bmq_route_cache_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    cfg.max_routes_per_tenant = 400;
+    cfg.mutation_log_entries = 64; // the log is cut all the time: loads older than it must be refused, not trusted
+    bmq_route_cache* c = nullptr;
+    EXPECT(bmq_route_cache_create(&e, &b, &cfg, &c) == BMQ_OK);
+    const std::vector<std::string> tenants = {"t", "u", "tenant-three"};
+    const std::vector<std::string> alpha = {"a", "b", "c", "", "$s"};
+    auto topic_of = [&](std::mt19937_64& r) {
+        std::string t;
+        for (size_t d = 1 + r() % 3, k = 0; k < d; k++) t += (k ? "/" : "") + alpha[r() % alpha.size()];
+        return t;
+    };
+    auto filter_of = [&](std::mt19937_64& r) {
+        std::string f;
+        const size_t d = 1 + r() % 3;
+        for (size_t k = 0; k < d; k++) {
+            const int x = (int)(r() % 8);
+            f += (k ? "/" : "") + (x == 0 ? std::string("+") : (x == 1 && k + 1 == d ? std::string("#") : alpha[r() % alpha.size()]));
+        }
+        return f;
+    };
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> n_get{0}, n_apply{0};
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_threads; w++)
+        th.emplace_back([&, w]() {
+            std::mt19937_64 r(seed * 977 + (uint64_t)w);
+            std::vector<uint32_t> ids;
+            uint64_t ep = 0;
+            while (!stop) {
+                const std::string& tn = tenants[r() % tenants.size()];
+                const std::string tp = topic_of(r);
+                if (!cache_get(c, tn, tp, 1000, ids, ep)) {
+                    EXPECT(!"get failed");
+                    break;
+                }
+                std::map<std::string, uint32_t> snap;
+                {
+                    std::lock_guard<std::mutex> g(e.mu);
+                    EXPECT(ep < e.history.size());
+                    snap = e.history[ep < e.history.size() ? ep : 0];
+                }
+                EXPECT(ids == brute(snap, tn, tp)); // whatever came back is the truth of the epoch it names
+                n_get++;
+            }
+        });
+    std::thread mut([&]() {
+        std::mt19937_64 r(seed * 31 + 5);
+        std::vector<std::string> live;
+        while (!stop) {
+            Packed p;
+            const size_t n = 1 + r() % 6;
+            for (size_t i = 0; i < n; i++) {
+                if (!live.empty() && r() % 2) {
+                    const size_t k = r() % live.size();
+                    p.add(live[k], 1);
+                    live.erase(live.begin() + (long)k);
+                } else {
+                    live.push_back(key_of(tenants[r() % tenants.size()], filter_of(r), (int)(r() % 50)));
+                    p.add(live.back(), 0);
+                }
+            }
+            EXPECT(bmq_route_cache_apply(c, p.bytes.data(), p.off.data(), p.op.data(), (uint32_t)p.op.size()) == BMQ_OK);
+            n_apply++;
+            std::this_thread::sleep_for(std::chrono::microseconds(150));
+        }
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+    stop = true;
+    for (auto& t : th) t.join();
+    mut.join();
+    // settled: what the cache serves now is the truth of the FINAL model -- a load overtaken by a mutation was not cached
+    e.match_delay_us = 0;
+    std::mt19937_64 r(seed);
+    std::vector<uint32_t> ids;
+    uint64_t ep = 0;
+    uint64_t served = 0;
+    for (auto& tn : tenants)
+        for (int q = 0; q < 400; q++) {
+            const std::string tp = topic_of(r);
+            const uint64_t before = e.n_match;
+            EXPECT(cache_get(c, tn, tp, 1000, ids, ep));
+            served += e.n_match == before;
+            EXPECT(ids == brute(e.model, tn, tp));
+        }
+    bmq_route_cache_stats st{};
+    bmq_route_cache_stats_get(c, &st);
+    printf("  concurrent: %llu gets, %llu applies, hits %llu misses %llu invalidations %llu stale loads refused %llu evictions %llu; %llu of 1200 final "
+           "probes served from the cache\n",
+           (unsigned long long)n_get.load(), (unsigned long long)n_apply.load(), (unsigned long long)st.hits, (unsigned long long)st.misses,
+           (unsigned long long)st.invalidations, (unsigned long long)st.stale_loads, (unsigned long long)st.evictions, (unsigned long long)served);
+    EXPECT(st.hits > 0 && st.invalidations > 0);
+    bmq_route_cache_destroy(c);
+}
+
+int main(int argc, char** argv) {
+    const uint64_t seed = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
+    const int threads = argc > 2 ? atoi(argv[2]) : 6;
+    const int ms = argc > 3 ? atoi(argv[3]) : 1500;
+    test_topic_index(seed);
+    test_behaviour();
+    test_concurrent(seed, threads, ms);
+    if (g_fail) {
+        fprintf(stderr, "cache_fuzz FAILED: %d\n", g_fail);
+        return 1;
+    }
+    printf("cache_fuzz ok: seed %llu\n", (unsigned long long)seed);
+    return 0;
+}
