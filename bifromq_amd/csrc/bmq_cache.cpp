@@ -21,7 +21,7 @@
 #include <list>
 #include <memory>
 #include <mutex>
-#include <shared_mutex>
+#include <thread>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -59,8 +59,10 @@ inline bool filter_matches(const std::vector<std::string_view>& f, const std::ve
 struct Entry {
     std::string topic;
     std::vector<uint32_t> ids; // ascending
+    uint64_t hash = 0;         // hash64(topic)
     uint64_t epoch = 0;        // engine epoch of the match
     uint64_t last_access_ms = 0;
+    Entry* next_same_hash = nullptr;
     std::list<Entry*>::iterator lru;
     uint64_t weight() const { return ids.empty() ? 1 : ids.size(); } // TenantRouteCache.java:108-111
 };
@@ -125,12 +127,79 @@ struct Mutation {
     std::vector<std::string> filter;
 };
 
-struct TenantCache { // TenantRouteCache
-    std::mutex mu;
-    std::unordered_map<std::string, std::unique_ptr<Entry>> entries;
-    std::list<Entry*> lru; // front = most recently used
+inline uint64_t hash64(std::string_view s, uint64_t h = 0xCBF29CE484222325ull) {
+    for (unsigned char ch : s) h = (h ^ ch) * 0x100000001B3ull;
+    h ^= h >> 32;
+    h *= 0xD6E8FEB86659FD93ull;
+    h ^= h >> 32;
+    return h;
+}
+
+// Hits come from hundreds of matcher threads and take ~100 ns: a futex-backed mutex would spend more time handing over than working.
+struct Spin {
+    std::atomic<uint32_t> f{0};
+    void lock() {
+        for (unsigned n = 0;; n++) {
+            if (!f.exchange(1, std::memory_order_acquire)) return;
+            while (f.load(std::memory_order_relaxed)) {
+                if ((++n & 63) == 0) std::this_thread::yield();
+                else __builtin_ia32_pause();
+            }
+        }
+    }
+    void unlock() { f.store(0, std::memory_order_release); }
+};
+
+// One slice of a tenant's cache: the topics whose hash falls into it, their LRU order, their trie.  A tenant has several, so that
+// the publishes of one hot tenant do not queue behind one lock.
+struct alignas(64) Shard {
+    Spin mu;
+    std::unordered_map<uint64_t, Entry*> table; // topic hash -> chain (next_same_hash)
+    std::list<Entry*> lru;                      // front = most recently used
     uint64_t weight = 0;
     TopicIndex index;
+    uint64_t hits = 0, misses = 0, evictions = 0, invalidations = 0, stale_loads = 0, expired = 0, entries = 0;
+
+    Entry* find(uint64_t h, std::string_view topic) const {
+        auto it = table.find(h);
+        for (Entry* en = it == table.end() ? nullptr : it->second; en; en = en->next_same_hash)
+            if (en->topic == topic) return en;
+        return nullptr;
+    }
+    void insert(Entry* en) {
+        Entry*& head = table[en->hash];
+        en->next_same_hash = head;
+        head = en;
+        lru.push_front(en);
+        en->lru = lru.begin();
+        weight += en->weight();
+        index.add(split(en->topic, '/'), en);
+        entries++;
+    }
+    void drop(Entry* en) {
+        index.remove(split(en->topic, '/'));
+        weight -= en->weight();
+        lru.erase(en->lru);
+        auto it = table.find(en->hash);
+        Entry** pp = &it->second;
+        while (*pp != en) pp = &(*pp)->next_same_hash;
+        *pp = en->next_same_hash;
+        if (!it->second) table.erase(it);
+        entries--;
+        delete en;
+    }
+    void clear() {
+        while (!lru.empty()) drop(lru.back());
+    }
+    ~Shard() { clear(); }
+};
+
+struct TenantCache { // TenantRouteCache
+    std::string name;
+    uint64_t hash = 0;
+    TenantCache* next = nullptr; // chain of the tenant table bucket (immutable once published)
+    std::unique_ptr<Shard[]> shards;
+    std::mutex log_mu;
     std::vector<Mutation> log; // ascending epochs; complete for epochs > log_floor
     uint64_t log_floor = 0;
 };
@@ -147,36 +216,62 @@ struct bmq_route_cache {
     uint64_t max_routes_per_tenant = 200000; // DistMaxCachedRoutesPerTenant
     uint64_t expiry_ms = 60000;              // DistTopicMatchExpirySeconds
     uint32_t log_keep = 4096;
-    std::shared_mutex tmu;
-    std::unordered_map<std::string, std::unique_ptr<TenantCache>> tenants;
+    uint32_t n_shards = 16;                  // per tenant, power of two
+    // tenant table: insert-only chained hash with atomic bucket heads -- a lookup takes no lock and writes nothing
+    static constexpr uint32_t TBUCKETS = 1u << 14;
+    std::unique_ptr<std::atomic<TenantCache*>[]> buckets;
     std::mutex apply_mu; // one refresh at a time, in commit order (ISubscriptionCache.refresh comes from the range's apply thread)
-    uint64_t created_floor = 0;
+    std::atomic<uint64_t> created_floor{0};
     std::atomic<bool> bypass{false}; // a rebuild is replacing the index: serve nothing from the cache, cache nothing
-    std::atomic<uint64_t> hits{0}, misses{0}, evictions{0}, invalidations{0}, stale_loads{0}, expired{0};
 
-    TenantCache* find(std::string_view tenant) {
-        std::shared_lock<std::shared_mutex> g(tmu);
-        auto it = tenants.find(std::string(tenant));
-        return it == tenants.end() ? nullptr : it->second.get();
+    bmq_route_cache() : buckets(new std::atomic<TenantCache*>[TBUCKETS]) {
+        for (uint32_t i = 0; i < TBUCKETS; i++) buckets[i].store(nullptr, std::memory_order_relaxed);
+    }
+    ~bmq_route_cache() {
+        for (uint32_t i = 0; i < TBUCKETS; i++)
+            for (TenantCache* t = buckets[i].load(); t;) {
+                TenantCache* nx = t->next;
+                delete t;
+                t = nx;
+            }
+    }
+    TenantCache* find(std::string_view tenant, uint64_t h) const {
+        for (TenantCache* t = buckets[h & (TBUCKETS - 1)].load(std::memory_order_acquire); t; t = t->next)
+            if (t->hash == h && t->name == tenant) return t;
+        return nullptr;
     }
     TenantCache* obtain(std::string_view tenant) {
-        if (TenantCache* t = find(tenant)) return t;
-        std::unique_lock<std::shared_mutex> g(tmu);
-        auto& p = tenants[std::string(tenant)];
-        if (!p) {
-            p = std::make_unique<TenantCache>();
-            p->log_floor = created_floor; // mutations before the tenant cache existed were never logged for it
+        const uint64_t h = hash64(tenant);
+        if (TenantCache* t = find(tenant, h)) return t;
+        auto nt = std::make_unique<TenantCache>();
+        nt->name = std::string(tenant);
+        nt->hash = h;
+        nt->shards.reset(new Shard[n_shards]);
+        nt->log_floor = created_floor.load(); // mutations before the tenant cache existed were never logged for it
+        std::atomic<TenantCache*>& head = buckets[h & (TBUCKETS - 1)];
+        TenantCache* old = head.load(std::memory_order_acquire);
+        for (;;) {
+            for (TenantCache* t = old; t; t = t->next)
+                if (t->hash == h && t->name == tenant) return t; // somebody else published it meanwhile
+            nt->next = old;
+            if (head.compare_exchange_weak(old, nt.get(), std::memory_order_release, std::memory_order_acquire)) return nt.release();
         }
-        return p.get();
     }
-    // tenant lock held
-    void drop(TenantCache& t, Entry* en) {
-        t.index.remove(split(en->topic, '/'));
-        t.weight -= en->weight();
-        t.lru.erase(en->lru);
-        t.entries.erase(en->topic); // frees en
+    template <class F> void for_each_tenant(F&& f) {
+        for (uint32_t i = 0; i < TBUCKETS; i++)
+            for (TenantCache* t = buckets[i].load(std::memory_order_acquire); t; t = t->next) f(*t);
     }
+    Shard& shard_of(TenantCache& t, uint64_t topic_hash) const { return t.shards[(topic_hash >> 40) & (n_shards - 1)]; }
+    uint64_t shard_budget() const { return std::max<uint64_t>(1, max_routes_per_tenant / n_shards); }
 };
+
+namespace {
+struct SpinGuard {
+    Spin& s;
+    explicit SpinGuard(Spin& sp) : s(sp) { s.lock(); }
+    ~SpinGuard() { s.unlock(); }
+};
+} // namespace
 
 extern "C" {
 
@@ -193,6 +288,10 @@ int bmq_route_cache_create(bmq_engine* e, bmq_batcher* b, const bmq_route_cache_
         if (k.max_routes_per_tenant) c->max_routes_per_tenant = k.max_routes_per_tenant;
         if (k.expiry_ms) c->expiry_ms = k.expiry_ms;
         if (k.mutation_log_entries) c->log_keep = k.mutation_log_entries;
+        if (k.shards_per_tenant) {
+            if (k.shards_per_tenant > 1024 || (k.shards_per_tenant & (k.shards_per_tenant - 1))) return BMQ_E_INVAL;
+            c->n_shards = (uint32_t)k.shards_per_tenant;
+        }
     }
     bmq_index_info info{};
     if (bmq_index_info_get(e, &info) == BMQ_OK) c->created_floor = info.epoch;
@@ -207,19 +306,19 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
     if (!c || !out_n || (tenant_len && !tenant) || (topic_len && !topic)) return BMQ_E_INVAL;
     const std::string_view tn((const char*)tenant, tenant_len), tp((const char*)topic, topic_len);
     TenantCache* t = c->obtain(tn);
-    const bool bypass = c->bypass.load();
+    const uint64_t th = hash64(tp);
+    Shard& sh = c->shard_of(*t, th);
+    const bool bypass = c->bypass.load(std::memory_order_acquire);
     if (!bypass) {
-        std::lock_guard<std::mutex> g(t->mu);
-        auto it = t->entries.find(std::string(tp));
-        if (it != t->entries.end()) {
-            Entry* en = it->second.get();
-            if (now_ms - en->last_access_ms >= c->expiry_ms && now_ms >= en->last_access_ms) { // expireAfterAccess
-                c->expired++;
-                c->drop(*t, en);
+        SpinGuard g(sh.mu);
+        if (Entry* en = sh.find(th, tp)) {
+            if (now_ms >= en->last_access_ms && now_ms - en->last_access_ms >= c->expiry_ms) { // expireAfterAccess
+                sh.expired++;
+                sh.drop(en);
             } else {
-                c->hits++;
+                sh.hits++;
                 en->last_access_ms = now_ms;
-                t->lru.splice(t->lru.begin(), t->lru, en->lru);
+                if (en->lru != sh.lru.begin()) sh.lru.splice(sh.lru.begin(), sh.lru, en->lru);
                 *out_n = (uint32_t)en->ids.size();
                 if (out_epoch) *out_epoch = en->epoch;
                 if (en->ids.size() > cap) return BMQ_E_NOSPACE;
@@ -227,8 +326,8 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
                 return BMQ_OK;
             }
         }
+        sh.misses++;
     }
-    c->misses++;
     // load: matchAll(singleton(topic)) through the batching front (TenantRouteCache.java:180-193)
     const uint32_t off[2] = {0, topic_len};
     uint32_t row[2] = {0, 0};
@@ -245,36 +344,35 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
     if (out_epoch) *out_epoch = epoch;
     const bool fits = ids.size() <= cap;
     if (fits && !ids.empty()) memcpy(out_route_ids, ids.data(), ids.size() * 4);
-    if (!bypass && !c->bypass.load()) {
-        std::lock_guard<std::mutex> g(t->mu);
-        bool stale = epoch < t->log_floor; // mutations in (epoch, log_floor] are unknown here
-        if (!stale && !t->log.empty() && t->log.back().epoch > epoch) {
-            const auto tl = split(tp, '/');
-            for (size_t k = t->log.size(); k-- > 0 && t->log[k].epoch > epoch && !stale;) {
+    if (!bypass && !c->bypass.load(std::memory_order_acquire)) {
+        auto en = std::make_unique<Entry>(); // built outside the lock
+        en->topic = std::string(tp);
+        en->ids = std::move(ids);
+        en->hash = th;
+        en->epoch = epoch;
+        en->last_access_ms = now_ms;
+        const auto tl = split(tp, '/');
+        SpinGuard g(sh.mu);
+        bool stale;
+        { // shard lock, then log lock: a mutation logs first and invalidates the shards afterwards, so it either shows up here or
+          // finds the entry
+            std::lock_guard<std::mutex> lg(t->log_mu);
+            stale = epoch < t->log_floor; // mutations in (epoch, log_floor] are unknown here
+            for (size_t k = t->log.size(); !stale && k-- > 0 && t->log[k].epoch > epoch;) {
                 std::vector<std::string_view> fl(t->log[k].filter.begin(), t->log[k].filter.end());
                 stale = filter_matches(fl, tl);
             }
         }
-        if (stale) c->stale_loads++; // correct as of its epoch (the caller gets it), but not what the next caller should see
+        if (stale) sh.stale_loads++; // correct as of its epoch (the caller gets it), but not what the next caller should see
         else {
-            auto& slot = t->entries[std::string(tp)];
-            if (slot) { // another thread loaded the same topic meanwhile: keep the newer
-                if (slot->epoch >= epoch) return fits ? BMQ_OK : BMQ_E_NOSPACE;
-                c->drop(*t, slot.get());
-            }
-            auto en = std::make_unique<Entry>();
-            en->topic = std::string(tp);
-            en->ids = std::move(ids);
-            en->epoch = epoch;
-            en->last_access_ms = now_ms;
-            t->lru.push_front(en.get());
-            en->lru = t->lru.begin();
-            t->weight += en->weight();
-            t->index.add(split(en->topic, '/'), en.get());
-            t->entries[en->topic] = std::move(en);
-            while (t->weight > c->max_routes_per_tenant && t->lru.size() > 1) { // maximumWeight: least recently used first
-                c->evictions++;
-                c->drop(*t, t->lru.back());
+            Entry* have = sh.find(th, tp);
+            if (have && have->epoch >= epoch) return fits ? BMQ_OK : BMQ_E_NOSPACE; // another thread loaded the same topic meanwhile
+            if (have) sh.drop(have);
+            sh.insert(en.release());
+            const uint64_t budget = c->shard_budget();
+            while (sh.weight > budget && sh.lru.size() > 1) { // maximumWeight: least recently used first
+                sh.evictions++;
+                sh.drop(sh.lru.back());
             }
         }
     }
@@ -283,12 +381,15 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
 
 int bmq_route_cache_is_cached(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len) {
     if (!c) return BMQ_E_INVAL;
-    TenantCache* t = c->find(std::string_view((const char*)tenant, tenant_len));
+    const std::string_view tn((const char*)tenant, tenant_len);
+    TenantCache* t = c->find(tn, hash64(tn));
     if (!t) return 0;
     const auto fl = split(std::string_view((const char*)filter, filter_len), '/');
     bool any = false;
-    std::lock_guard<std::mutex> g(t->mu);
-    t->index.match(fl, [&](Entry*) { any = true; });
+    for (uint32_t s = 0; s < c->n_shards && !any; s++) {
+        SpinGuard g(t->shards[s].mu);
+        t->shards[s].index.match(fl, [&](Entry*) { any = true; });
+    }
     return any ? 1 : 0;
 }
 
@@ -300,7 +401,7 @@ int bmq_route_cache_apply(bmq_route_cache* c, const uint8_t* keys, const uint32_
     bmq_index_info info{};
     const int ri = bmq_index_info_get(c->e, &info);
     if (ri != BMQ_OK) return ri;
-    // per tenant that has a cache: log the filters, drop the cached topics they match
+    // per tenant that has a cache: log the filters, then drop the cached topics they match
     std::unordered_map<std::string, std::vector<std::vector<std::string>>> by_tenant;
     for (uint32_t i = 0; i < n; i++) {
         RouteKeyParts kp;
@@ -309,50 +410,55 @@ int bmq_route_cache_apply(bmq_route_cache* c, const uint8_t* keys, const uint32_
         for (auto lv : split(kp.esc_filter, '\0')) fl.emplace_back(lv);
         by_tenant[std::string(kp.tenant)].push_back(std::move(fl));
     }
-    {
-        std::unique_lock<std::shared_mutex> g(c->tmu);
-        c->created_floor = info.epoch;
-    }
+    c->created_floor = info.epoch;
     for (auto& bt : by_tenant) {
-        TenantCache* t = c->find(bt.first);
+        TenantCache* t = c->find(bt.first, hash64(bt.first));
         if (!t) continue;
-        std::lock_guard<std::mutex> g(t->mu);
-        std::vector<Entry*> hit;
-        for (auto& fl : bt.second) {
-            std::vector<std::string_view> fv(fl.begin(), fl.end());
-            t->index.match(fv, [&](Entry* en) { hit.push_back(en); });
-            t->log.push_back({info.epoch, std::move(fl)});
+        {
+            std::lock_guard<std::mutex> lg(t->log_mu);
+            for (auto& fl : bt.second) t->log.push_back({info.epoch, fl});
+            if (t->log.size() > c->log_keep) { // forget the oldest: loads older than what is left are not cached
+                const size_t cut = t->log.size() - c->log_keep / 2;
+                t->log_floor = t->log[cut - 1].epoch;
+                t->log.erase(t->log.begin(), t->log.begin() + (long)cut);
+            }
         }
-        if (t->log.size() > c->log_keep) { // forget the oldest: loads older than what is left are not cached
-            const size_t cut = t->log.size() - c->log_keep / 2;
-            t->log_floor = t->log[cut - 1].epoch;
-            t->log.erase(t->log.begin(), t->log.begin() + (long)cut);
-        }
-        std::sort(hit.begin(), hit.end()); // a topic may be hit by several filters of the batch
-        hit.erase(std::unique(hit.begin(), hit.end()), hit.end());
-        for (Entry* en : hit) {
-            c->invalidations++;
-            c->drop(*t, en);
+        for (uint32_t s = 0; s < c->n_shards; s++) {
+            Shard& sh = t->shards[s];
+            SpinGuard g(sh.mu);
+            if (sh.lru.empty()) continue;
+            std::vector<Entry*> hit;
+            for (auto& fl : bt.second) {
+                std::vector<std::string_view> fv(fl.begin(), fl.end());
+                sh.index.match(fv, [&](Entry* en) { hit.push_back(en); });
+            }
+            std::sort(hit.begin(), hit.end()); // a topic may be hit by several filters of the batch
+            hit.erase(std::unique(hit.begin(), hit.end()), hit.end());
+            for (Entry* en : hit) {
+                sh.invalidations++;
+                sh.drop(en);
+            }
         }
     }
     return BMQ_OK;
 }
 
 namespace {
-// drop every entry and forget the log: nothing matched at or before `floor_epoch` is cached afterwards.  Tenant objects stay (other
-// threads may hold pointers to them).
+// drop every entry and forget the log: nothing matched before `floor_epoch` is cached afterwards.  Tenant objects stay (other threads
+// may hold pointers to them).
 void clear_all(bmq_route_cache* c, uint64_t floor_epoch) {
-    std::unique_lock<std::shared_mutex> g(c->tmu);
     c->created_floor = floor_epoch;
-    for (auto& t : c->tenants) {
-        std::lock_guard<std::mutex> tg(t.second->mu);
-        t.second->index = TopicIndex{};
-        t.second->lru.clear();
-        t.second->entries.clear();
-        t.second->weight = 0;
-        t.second->log.clear();
-        t.second->log_floor = floor_epoch;
-    }
+    c->for_each_tenant([&](TenantCache& t) {
+        {
+            std::lock_guard<std::mutex> lg(t.log_mu);
+            t.log.clear();
+            t.log_floor = floor_epoch;
+        }
+        for (uint32_t s = 0; s < c->n_shards; s++) {
+            SpinGuard g(t.shards[s].mu);
+            t.shards[s].clear();
+        }
+    });
 }
 } // namespace
 
@@ -368,30 +474,32 @@ int bmq_route_cache_reset(bmq_route_cache* c) {
 int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys) {
     if (!c) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> ag(c->apply_mu);
-    c->bypass = true; // route ids of the old generation must not be served once the engine holds the new one
+    c->bypass.store(true, std::memory_order_release); // route ids of the old generation must not be served once the engine holds the new one
     const int rc = bmq_rebuild(c->e, keys, key_off, n_keys);
     bmq_index_info info{};
     const int ri = bmq_index_info_get(c->e, &info);
     clear_all(c, ri == BMQ_OK ? info.epoch : ~0ull);
-    c->bypass = false;
+    c->bypass.store(false, std::memory_order_release);
     return rc;
 }
 
 int bmq_route_cache_stats_get(bmq_route_cache* c, bmq_route_cache_stats* out) {
     if (!c || !out) return BMQ_E_INVAL;
     memset(out, 0, sizeof(*out));
-    out->hits = c->hits;
-    out->misses = c->misses;
-    out->evictions = c->evictions;
-    out->invalidations = c->invalidations;
-    out->stale_loads = c->stale_loads;
-    out->expired = c->expired;
-    std::shared_lock<std::shared_mutex> g(c->tmu);
-    for (auto& t : c->tenants) {
-        std::lock_guard<std::mutex> tg(t.second->mu);
-        out->entries += t.second->entries.size();
-        out->cached_routes += t.second->weight;
-    }
+    c->for_each_tenant([&](TenantCache& t) {
+        for (uint32_t s = 0; s < c->n_shards; s++) {
+            Shard& sh = t.shards[s];
+            SpinGuard g(sh.mu);
+            out->hits += sh.hits;
+            out->misses += sh.misses;
+            out->evictions += sh.evictions;
+            out->invalidations += sh.invalidations;
+            out->stale_loads += sh.stale_loads;
+            out->expired += sh.expired;
+            out->entries += sh.entries;
+            out->cached_routes += sh.weight;
+        }
+    });
     return BMQ_OK;
 }
 

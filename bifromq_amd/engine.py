@@ -594,12 +594,13 @@ class RouteCache:
     """bmq_route_cache_*: ISubscriptionCache (DW/cache/ISubscriptionCache.java:30-40) on the engine's side of the boundary -- topic ->
     matched routes per tenant, loads through the batching front, TopicIndex-style invalidation by route mutations."""
 
-    def __init__(self, batcher: Batcher, max_routes_per_tenant: int = 0, expiry_ms: int = 0, mutation_log_entries: int = 0):
+    def __init__(self, batcher: Batcher, max_routes_per_tenant: int = 0, expiry_ms: int = 0, mutation_log_entries: int = 0, shards_per_tenant: int = 0):
         cfg = _lib.RouteCacheConfig()
         cfg.struct_size = C.sizeof(_lib.RouteCacheConfig)
         cfg.max_routes_per_tenant = max_routes_per_tenant
         cfg.expiry_ms = expiry_ms
         cfg.mutation_log_entries = mutation_log_entries
+        cfg.shards_per_tenant = shards_per_tenant
         h = C.c_void_p()
         rc = _lib.lib().bmq_route_cache_create(batcher.engine.h, batcher.h, C.byref(cfg), C.byref(h))
         if rc:

@@ -266,7 +266,9 @@ typedef struct bmq_route_cache_config {
     uint32_t mutation_log_entries;   /* per tenant; default 4096 */
     uint64_t max_routes_per_tenant;  /* DistMaxCachedRoutesPerTenant, default 200000 */
     uint64_t expiry_ms;              /* DistTopicMatchExpirySeconds, default 60000 */
-    uint64_t reserved[4];
+    uint64_t shards_per_tenant;      /* power of two, default 16: a tenant's topics are spread over that many independently locked */
+                                     /* slices (each with 1/n of the route budget), so one hot tenant does not serialise its callers */
+    uint64_t reserved[3];
 } bmq_route_cache_config;
 typedef struct bmq_route_cache_stats {
     uint64_t hits, misses, evictions, invalidations, expired;

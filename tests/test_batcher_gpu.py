@@ -227,7 +227,8 @@ def test_route_cache_get_hit_invalidate_against_oracle(setup):
         ids, ep = c.get(t0, topics[i], now_ms=7)
         got = sorted(keys2.index(k) for k in eng.route_keys(np.array(ids, dtype=np.uint32))) if ids else []
         assert got == want[j], topics[i]
-        assert ep == eng.info().epoch
+        # reloaded (its topic is under lv0: matched by the new filter) or still the entry of the first round
+        assert ep == (eng.info().epoch if topics[i].split("/")[0] == lv0 and not topics[i].startswith("$") else ep) and ep <= eng.info().epoch
     # other tenants' entries survived the mutation
     other = [i for i in idx if tt[i] != 0][:50]
     nb = b.stats().n_batches

@@ -193,13 +193,13 @@ def test_gpu_device_resident_csr_and_table_growth():
         assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(p), out.nbytes, 2) == 0
         return out
 
-    tenants, keys, topics, tt = _workload(12, n_filters=20000, n_topics=20000, dkeys=700, shared=0.02)
+    tenants, keys, topics, tt = _workload(12, n_filters=20000, n_topics=5000, dkeys=700, shared=0.02)
     eng = B.Engine(device=0).rebuild(keys)
     n = len(topics)
     tdata, toff = B.pack(tenants)
     pdata, poff = B.pack(topics)
     d = [to_dev(np.ascontiguousarray(x)) for x in (tdata, toff, tt, pdata, poff)]
-    cap = 4000000
+    cap = 16000000
     row, ids, tot = to_dev(np.zeros(n + 1, dtype=np.uint32)), to_dev(np.zeros(cap, dtype=np.uint32)), to_dev(np.zeros(1, dtype=np.uint64))
     eng.match_batch_device(d[0], d[1], len(tenants), d[2], d[3], d[4], n, row, ids, cap, tot)
     total = eng.finish()

@@ -226,6 +226,7 @@ static void test_behaviour() {
     cfg.struct_size = sizeof(cfg);
     cfg.max_routes_per_tenant = 12;
     cfg.expiry_ms = 1000;
+    cfg.shards_per_tenant = 1; // one slice: the LRU order below is the tenant's
     bmq_route_cache* c = nullptr;
     EXPECT(bmq_route_cache_create(&e, &b, &cfg, &c) == BMQ_OK);
     Packed p;
@@ -288,6 +289,7 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
     bmq_route_cache_config cfg{};
     cfg.struct_size = sizeof(cfg);
     cfg.max_routes_per_tenant = 400;
+    cfg.shards_per_tenant = 4;
     cfg.mutation_log_entries = 64; // the log is cut all the time: loads older than it must be refused, not trusted
     bmq_route_cache* c = nullptr;
     EXPECT(bmq_route_cache_create(&e, &b, &cfg, &c) == BMQ_OK);
@@ -381,7 +383,60 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
     bmq_route_cache_destroy(c);
 }
 
+// ---- hit-path throughput (not a test): cache_fuzz perf <threads> <calls per thread> ------------------------------------------------
+static void perf(int n_threads, int calls) {
+    bmq_engine e;
+    bmq_batcher b{&e};
+    bmq_route_cache_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    cfg.max_routes_per_tenant = 1ull << 40;
+    bmq_route_cache* c = nullptr;
+    bmq_route_cache_create(&e, &b, &cfg, &c);
+    const int n_tenants = 1000, n_topics = 100000;
+    std::mt19937_64 r(7);
+    std::vector<double> cdf(n_tenants);
+    double acc = 0;
+    for (int i = 0; i < n_tenants; i++) cdf[i] = (acc += 1.0 / (i + 1));
+    std::vector<std::pair<std::string, std::string>> q(n_topics);
+    for (auto& p : q) {
+        const double u = (r() >> 11) * (1.0 / 9007199254740992.0) * acc;
+        const int t = (int)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+        p = {"tenant" + std::to_string(1000000 + t), "l0_" + std::to_string(r() % 8) + "/l1_" + std::to_string(r() % 64) + "/l2_" + std::to_string(r() % 512) +
+                                                          "/l3_" + std::to_string(r() % 64)};
+    }
+    std::vector<uint32_t> ids;
+    uint64_t ep;
+    for (auto& p : q) cache_get(c, p.first, p.second, 1, ids, ep, 64); // load
+    std::atomic<uint64_t> sum{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_threads; w++)
+        th.emplace_back([&, w]() {
+            std::mt19937_64 rr(w);
+            uint32_t out[64], n = 0;
+            uint64_t epoch = 0, local = 0;
+            for (int i = 0; i < calls; i++) {
+                auto& p = q[rr() % q.size()];
+                bmq_route_cache_get(c, (const uint8_t*)p.first.data(), (uint32_t)p.first.size(), (const uint8_t*)p.second.data(), (uint32_t)p.second.size(), 2,
+                                    out, 64, &n, &epoch);
+                local += n;
+            }
+            sum += local;
+        });
+    for (auto& t : th) t.join();
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    bmq_route_cache_stats st{};
+    bmq_route_cache_stats_get(c, &st);
+    printf("perf: %d threads x %d hits in %.3f s = %.2f M gets/s (entries %llu, hits %llu, misses %llu)\n", n_threads, calls, sec,
+           n_threads * (double)calls / sec / 1e6, (unsigned long long)st.entries, (unsigned long long)st.hits, (unsigned long long)st.misses);
+    bmq_route_cache_destroy(c);
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "perf") {
+        perf(argc > 2 ? atoi(argv[2]) : 8, argc > 3 ? atoi(argv[3]) : 1000000);
+        return 0;
+    }
     const uint64_t seed = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
     const int threads = argc > 2 ? atoi(argv[2]) : 6;
     const int ms = argc > 3 ? atoi(argv[3]) : 1500;
