@@ -393,7 +393,7 @@ def main():
         bt = eng.batcher()
         cnt, hsh, sec = bt.drive_singletons(w.tenants(), htt[:m], sub, args.batcher_threads)
         bs = bt.stats()
-        out["batching_front"] = {"threads": args.batcher_threads, "single_topic_calls": m, "calls_per_s": m / sec,
+        out["batching_front"] = {"threads": args.batcher_threads, "host_cpus_granted": effective_cpus(), "single_topic_calls": m, "calls_per_s": m / sec,
                                  "launches": int(bs.n_batches), "mean_topics_per_launch": bs.n_topics / max(1, bs.n_batches),
                                  "max_topics_per_launch": int(bs.max_batch_topics), "ids_returned": int(cnt.sum()),
                                  "note": "bmq_batcher_match_all, blocking callers: a launch holds at most one topic per thread"}
@@ -771,14 +771,35 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
             lt.add(tn[0], raw[off[i]:off[i + 1]], i)
         fdata, foff, ft = batches[0][3]
         m = min(n, 20000)
-        cores = os.cpu_count() or 1
+        cores = effective_cpus()
         res, sec = lt.match_batch(tn, ft[:m], (fdata, foff[:m + 1]), threads=cores)
-        out["cpu_baseline"] = {"value": m / sec, "unit": "filters/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": m / sec, "unit": "filters/s", "cores": cores, "logical_cpus_visible": os.cpu_count(), "kind": "port",
                                "sample": "first %d filters of batch 0 against the full 1M-topic TopicLevelTrie restatement on "
                                          "%d threads; %.1f s" % (m, cores, sec)}
     if world > 1:
         dist.destroy_process_group()
     emit_json(out)
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (cpu.max).  The GPU boxes of this
+    project show 256 logical CPUs and grant a quota of 16: threads beyond that only take turns (and get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+        except Exception:  # noqa: BLE001
+            pass
+    try:  # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p_ > 0:
+            n = min(n, max(1, int(q / p_ + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
 
 
 def cpu_baseline(args, w, host_batch, n):
@@ -790,7 +811,7 @@ def cpu_baseline(args, w, host_batch, n):
 
     from oracle import oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()  # threads = the CPUs the cgroup grants (more threads only take turns)
     S = min(args.cpu_sample_tenants, w.n_tenants)
     first = w.tenant_first()
     kb, ko = w.keys_packed()
@@ -822,7 +843,7 @@ def cpu_baseline(args, w, host_batch, n):
         wb = list(ex.map(whole, jobs))
     sec_wb = time.perf_counter() - t0
     n_distinct = sum(len(set(v)) for v in by_tenant.values())
-    return {"value": len(sel) / sec, "unit": "topics/s", "cores": cores, "kind": "port",
+    return {"value": len(sel) / sec, "unit": "topics/s", "cores": cores, "logical_cpus_visible": os.cpu_count(), "kind": "port",
             "sample": "%d publishes of batch 0 addressed to the first %d tenants (%d route keys) of rank 0's shard; one "
                       "matchAll(singleton(topic)) per publish on %d threads; %.1f s" % (len(sel), S, hi, cores, sec),
             "reference_livelocks_stepped_over": int(res.livelocks),

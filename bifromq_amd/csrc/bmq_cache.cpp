@@ -21,6 +21,7 @@
 #include <list>
 #include <memory>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <string>
 #include <string_view>
@@ -135,19 +136,23 @@ inline uint64_t hash64(std::string_view s, uint64_t h = 0xCBF29CE484222325ull) {
     return h;
 }
 
-// Hits come from hundreds of matcher threads and take ~100 ns: a futex-backed mutex would spend more time handing over than working.
+// Hits come from hundreds of matcher threads and hold the lock for ~100 ns: spin briefly, then sleep in the kernel (glibc's adaptive
+// mutex).  Pure spinning collapses when the threads outnumber the CPUs the process may use (a container's CPU quota: the GPU boxes of
+// this project show 256 CPUs and grant 16), a plain mutex pays a futex hand-over for every short wait.
 struct Spin {
-    std::atomic<uint32_t> f{0};
-    void lock() {
-        for (unsigned n = 0;; n++) {
-            if (!f.exchange(1, std::memory_order_acquire)) return;
-            while (f.load(std::memory_order_relaxed)) {
-                if ((++n & 63) == 0) std::this_thread::yield();
-                else __builtin_ia32_pause();
-            }
-        }
+    pthread_mutex_t m;
+    Spin() {
+        pthread_mutexattr_t a;
+        pthread_mutexattr_init(&a);
+        pthread_mutexattr_settype(&a, PTHREAD_MUTEX_ADAPTIVE_NP);
+        pthread_mutex_init(&m, &a);
+        pthread_mutexattr_destroy(&a);
     }
-    void unlock() { f.store(0, std::memory_order_release); }
+    ~Spin() { pthread_mutex_destroy(&m); }
+    Spin(const Spin&) = delete;
+    Spin& operator=(const Spin&) = delete;
+    void lock() { pthread_mutex_lock(&m); }
+    void unlock() { pthread_mutex_unlock(&m); }
 };
 
 // One slice of a tenant's cache: the topics whose hash falls into it, their LRU order, their trie.  A tenant has several, so that

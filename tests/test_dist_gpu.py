@@ -199,7 +199,7 @@ def test_generated_workload_parity(eng):
         # (1) the reference's production call pattern -- one matchAll(singleton(topic)) per topic -- on EVERY topic;
         # rows may differ only where the reference itself loses routes (quirk ii / the trailing-'/' livelock,
         # see oracle/bmq_oracle.cpp); (2) whole-batch matchAll on a slice; (3) authoritative semantic rows on a sample
-        res, _ = kv.match_singletons(tn, tt, (data, off), threads=os.cpu_count() or 8)
+        res, _ = kv.match_singletons(tn, tt, (data, off), threads=U.host_threads())
         n_diff = U.assert_rows_equal_modulo_quirk_ii(w.keys(), tn, tt, [sorted(r) for r in res.per_topic()], got)
         assert n_diff <= n_topics // 100
         m = 3000
@@ -487,7 +487,7 @@ def test_full_size_config2_properties(eng):
     sub_off = np.concatenate([[0], np.cumsum((off[sample + 1] - off[sample]).astype(np.int64))]).astype(np.uint32)
     sub_data = np.zeros(int(sub_off[-1]) + 32, dtype=np.uint8)
     sub_data[:int(sub_off[-1])] = np.frombuffer(b"".join(raw[off[i]:off[i + 1]] for i in sample), dtype=np.uint8)
-    res, _ = kv.match_singletons(tn, np.zeros(len(sample), dtype=np.uint32), (sub_data, sub_off), threads=os.cpu_count() or 8)
+    res, _ = kv.match_singletons(tn, np.zeros(len(sample), dtype=np.uint32), (sub_data, sub_off), threads=U.host_threads())
     got_rp, got = U.csr_select(row, ids, sample)
     differ = U.assert_csr_equal_modulo_quirk_ii(w.keys, kv.key, tn, None, res.row_ptr.astype(np.int64), res.routes, got_rp, got)
     # rows where the reference loses routes to quirk (ii) (hot filters next to "<filter>/" filters: a few % of this workload) and a
@@ -541,7 +541,7 @@ def test_full_size_config3_properties(eng):
     t_data = np.zeros(int(t_off[-1]) + 32, dtype=np.uint8)
     t_data[:int(t_off[-1])] = np.frombuffer(b"".join(raw[off[i]:off[i + 1]] for i in cand), dtype=np.uint8)
     stt = tt[cand]
-    res, _ = kv.match_singletons(tn[:S], stt, (t_data, t_off), threads=os.cpu_count() or 8)
+    res, _ = kv.match_singletons(tn[:S], stt, (t_data, t_off), threads=U.host_threads())
     got_rp, got = U.csr_select(row, ids, cand)  # ids of the first tenants are ranks in the sub-KV of exactly those tenants
     rawk = sub_bytes.tobytes()
     differ = U.assert_csr_equal_modulo_quirk_ii(lambda: [rawk[sub_off[i]:sub_off[i + 1]] for i in range(hi)], kv.key, tn[:S], stt,

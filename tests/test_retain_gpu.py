@@ -96,7 +96,7 @@ def test_generated_workload_parity(eng):
     assert i == len({(int(t), p) for t, p in zip(tt, unpack(data, off))})
     fdata, foff, ft = w.retain(0xB1F20004 + 1, 20000, filters=True)
     row, ids = eng.retain_match_batch(tn, ft, packed_filters=(fdata, foff))
-    res, _ = lt.match_batch(tn, ft, (fdata, foff), threads=os.cpu_count() or 8)
+    res, _ = lt.match_batch(tn, ft, (fdata, foff), threads=U.host_threads())
     assert U.csr_rows(row, ids) == [sorted(r) for r in res.per_topic()]
     assert (np.diff(row.astype(np.int64)) >= 0).all()
 
@@ -252,7 +252,7 @@ def test_full_size_config4_properties(eng):
     sample = sorted(rnd.sample(range(100_000), 20000))
     raw = fdata.tobytes()
     filters = [raw[foff[i]:foff[i + 1]] for i in sample]
-    res, _ = lt.match_batch(tn, np.zeros(len(sample), dtype=np.uint32), O.pack(filters), threads=os.cpu_count() or 8)
+    res, _ = lt.match_batch(tn, np.zeros(len(sample), dtype=np.uint32), O.pack(filters), threads=U.host_threads())
     exp = [sorted(r) for r in res.per_topic()]
     got = [ids[row[i]:row[i + 1]].tolist() for i in sample]
     assert sum(len(g) for g in got) == sum(len(e) for e in exp)
