@@ -1,0 +1,157 @@
+/*
+ * Drop-in for org.apache.bifromq.dist.worker.cache.SubscriptionCache behind ISubscriptionCache
+ * (bifromq-dist-worker/.../cache/ISubscriptionCache.java:30-40; created per range replica in DistWorkerCoProcFactory.java:91-93).
+ * NOT compiled in this repository (no JDK in its build image): complete enough to show every interaction with the native side.
+ *
+ * The reference keeps, per tenant, a Caffeine cache topic -> MatchedRoutes plus a TopicIndex of the cached topics, loads a miss
+ * with matchAll(singleton(topic)) and patches entries on route mutations (TenantRouteCache.java:116-296).  Here all of that sits
+ * on the native side (bmq_route_cache_*: include/bmq.h): get() is one JNI call -- a hit is answered from host memory, a miss joins
+ * the GPU launch that carries every other miss of the moment -- and refresh() hands the mutated route keys to the engine, which
+ * applies them to the HBM-resident index and drops the cached topics their filters match.
+ * What stays Java: turning route ids into Matching objects (GpuTenantRouteMatcher.RangeIndex.matchingOf, cached per generation) and the
+ * MatchedRoutes fan-out caps (fed in KV key order, as today).
+ */
+package org.apache.bifromq.dist.worker.gpu;
+
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.nio.IntBuffer;
+import java.nio.charset.StandardCharsets;
+import java.util.LinkedHashSet;
+import java.util.List;
+import java.util.Map;
+import java.util.Set;
+import java.util.concurrent.CompletableFuture;
+import java.util.concurrent.Executor;
+import org.apache.bifromq.basekv.proto.Boundary;
+import org.apache.bifromq.dist.worker.cache.ISubscriptionCache;
+import org.apache.bifromq.dist.worker.cache.task.AddRoutesTask;
+import org.apache.bifromq.dist.worker.cache.task.RefreshEntriesTask;
+import org.apache.bifromq.dist.worker.schema.KVSchemaUtil;
+import org.apache.bifromq.dist.worker.schema.cache.Matching;
+import org.apache.bifromq.type.RouteMatcher;
+
+final class GpuSubscriptionCache implements ISubscriptionCache {
+    private final GpuTenantRouteMatcher.RangeIndex index; // engine + batching front + id -> Matching
+    private final long cache;
+    private final Executor matchExecutor; // dist_worker_match_parallelism threads, DistWorkerCoProcFactory.java:74-88
+    private static final ThreadLocal<IntBuffer> IDS =
+        ThreadLocal.withInitial(() -> ByteBuffer.allocateDirect(4 * 4096).order(ByteOrder.nativeOrder()).asIntBuffer());
+
+    GpuSubscriptionCache(GpuTenantRouteMatcher.RangeIndex index, Executor matchExecutor) {
+        this.index = index;
+        this.matchExecutor = matchExecutor;
+        // 0, 0: DistMaxCachedRoutesPerTenant (200 000) and DistTopicMatchExpirySeconds (60 s), the reference's defaults
+        this.cache = NativeMatcher.routeCacheCreate(index.engine, index.batcher, 0, 0);
+    }
+
+    /** SubscriptionCache.get (SubscriptionCache.java:117-122): the matched routes of (tenant, topic). */
+    @Override
+    public CompletableFuture<Set<Matching>> get(String tenantId, String topic) {
+        // a miss blocks its thread until the shared launch has finished, exactly like the reference's cache loader does on matchExecutor
+        return CompletableFuture.supplyAsync(() -> {
+            byte[] tn = tenantId.getBytes(StandardCharsets.UTF_8);
+            byte[] tp = topic.getBytes(StandardCharsets.UTF_8);
+            long[] epoch = new long[1];
+            IntBuffer ids = IDS.get();
+            long n = NativeMatcher.routeCacheGet(cache, tn, tp, System.currentTimeMillis(), ids, epoch);
+            while (n < 0) { // the row is longer than the buffer: grow and ask again (it may have grown once more meanwhile)
+                ids = ByteBuffer.allocateDirect((int) (-n + 64) * 4).order(ByteOrder.nativeOrder()).asIntBuffer();
+                IDS.set(ids);
+                n = NativeMatcher.routeCacheGet(cache, tn, tp, System.currentTimeMillis(), ids, epoch);
+            }
+            Set<Matching> out = new LinkedHashSet<>((int) n * 2);
+            // ids -> Matching, cached per generation, the unknown ones resolved with ONE native gather; a route unsubscribed between
+            // the match and now is simply absent
+            index.resolve(ids, 0, (int) n).forEach(e -> out.add(e.matching()));
+            return out;
+        }, matchExecutor);
+    }
+
+    /** SubscriptionCache.isCached (:125-131) = !TopicIndex.match(filterLevels).isEmpty() */
+    @Override
+    public boolean isCached(String tenantId, List<String> filterLevels) {
+        return NativeMatcher.routeCacheIsCached(cache, tenantId.getBytes(StandardCharsets.UTF_8),
+            String.join("/", filterLevels).getBytes(StandardCharsets.UTF_8)) != 0;
+    }
+
+    /**
+     * SubscriptionCache.refresh (:134-141), called from the post-commit closure of DistWorkerCoProc.mutate (:188-209) in commit
+     * order: the added / removed routes become ONE bmq_route_cache_apply (ops 0 = put, 1 = delete).
+     */
+    @Override
+    public void refresh(Map<String, RefreshEntriesTask> tenantRefreshTasks) {
+        PackedKeys p = new PackedKeys();
+        tenantRefreshTasks.forEach((tenantId, task) -> {
+            byte op = (byte) (task instanceof AddRoutesTask ? 0 : 1);
+            for (Map.Entry<RouteMatcher, Set<Matching>> e : task.routes.entrySet()) {
+                for (Matching m : e.getValue()) {
+                    p.add(GpuTenantRouteMatcher.routeKeyOf(tenantId, e.getKey(), m), op); // KVSchemaUtil.toNormalRouteKey / toGroupRouteKey
+                }
+            }
+        });
+        if (p.n > 0) {
+            NativeMatcher.routeCacheApply(cache, p.bytes(), p.offsets(), p.ops(), p.n);
+            index.forgetResolved(); // a re-subscribe keeps its id but may carry a new incarnation in the value
+        }
+    }
+
+    /** SubscriptionCache.reset(boundary) (:144-146): the range's boundary changed; cached matches of the old boundary are void. */
+    @Override
+    public void reset(Boundary boundary) {
+        NativeMatcher.routeCacheReset(cache);
+    }
+
+    /** IKVRangeCoProc.reset (DistWorkerCoProc.java:283-291): full reload from reader.iterator(); nothing old is served meanwhile. */
+    void rebuild(ByteBuffer keys, IntBuffer keyOff, int n) {
+        NativeMatcher.routeCacheRebuild(cache, keys, keyOff, n);
+    }
+
+    @Override
+    public void close() {
+        NativeMatcher.routeCacheDestroy(cache); // before the batcher and the engine (RangeIndex.close)
+    }
+
+    /** route keys + op codes packed into direct buffers (16 bytes of padding behind the last key, as include/bmq.h asks) */
+    static final class PackedKeys {
+        private ByteBuffer bytes = ByteBuffer.allocateDirect(1 << 16).order(ByteOrder.nativeOrder());
+        private IntBuffer off = ByteBuffer.allocateDirect(4 * 1025).order(ByteOrder.nativeOrder()).asIntBuffer().put(0, 0);
+        private ByteBuffer ops = ByteBuffer.allocateDirect(1024);
+        int n;
+
+        void add(com.google.protobuf.ByteString key, byte op) {
+            if (bytes.remaining() < key.size() + 16) {
+                bytes = grow(bytes, bytes.position() + key.size() + 16);
+            }
+            if (n + 2 > off.capacity()) {
+                IntBuffer o = ByteBuffer.allocateDirect(8 * off.capacity()).order(ByteOrder.nativeOrder()).asIntBuffer();
+                for (int i = 0; i <= n; i++) {
+                    o.put(i, off.get(i));
+                }
+                off = o;
+                ops = grow(ops, 2 * ops.capacity());
+            }
+            key.copyTo(bytes);
+            ops.put(n, op);
+            off.put(++n, bytes.position());
+        }
+
+        private static ByteBuffer grow(ByteBuffer b, int need) {
+            ByteBuffer g = ByteBuffer.allocateDirect(Math.max(need, 2 * b.capacity())).order(ByteOrder.nativeOrder());
+            b.flip();
+            return g.put(b);
+        }
+
+        ByteBuffer bytes() {
+            return bytes;
+        }
+
+        IntBuffer offsets() {
+            return off;
+        }
+
+        ByteBuffer ops() {
+            return ops;
+        }
+    }
+}

@@ -38,7 +38,7 @@ final class GpuTenantRouteMatcher implements ITenantRouteMatcher {
         final long engine;
         final long batcher;
         /** (route key, Matching) per route id of ONE generation; dropped as a whole when bmq_rebuild re-numbers the routes. */
-        private record Entry(ByteString key, Matching matching) {
+        record Entry(ByteString key, Matching matching) {
         }
 
         private volatile long cachedGeneration = -1;
@@ -62,6 +62,11 @@ final class GpuTenantRouteMatcher implements ITenantRouteMatcher {
             // a re-subscribe keeps its id but may carry a new incarnation: forget the cached Matching of the keys just put
             // (the cache is keyed by id; resolving the few put keys again is cheaper than tracking them here)
             entries.values().removeIf(e -> e.matching() == null);
+        }
+
+        /** After route keys were re-put through another path (GpuSubscriptionCache.refresh): drop what was resolved before. */
+        void forgetResolved() {
+            entries.clear();
         }
 
         /** ids -> (key, Matching), resolving the unknown ones with ONE native gather. */
@@ -122,6 +127,13 @@ final class GpuTenantRouteMatcher implements ITenantRouteMatcher {
             NativeMatcher.batcherDestroy(batcher); // before the engine
             NativeMatcher.destroy(engine);
         }
+    }
+
+    /** The KV key of one route of a RefreshEntriesTask: KVSchemaUtil.toNormalRouteKey / toGroupRouteKey (KVSchemaUtil.java:108-120). */
+    static ByteString routeKeyOf(String tenantId, org.apache.bifromq.type.RouteMatcher matcher, Matching m) {
+        return m.type() == Matching.Type.Normal
+            ? KVSchemaUtil.toNormalRouteKey(tenantId, matcher, ((NormalMatching) m).receiverUrl())
+            : KVSchemaUtil.toGroupRouteKey(tenantId, matcher);
     }
 
     private final String tenantId;

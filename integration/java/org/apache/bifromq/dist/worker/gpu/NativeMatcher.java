@@ -87,7 +87,39 @@ final class NativeMatcher {
 
     static native long retainMatchLimited(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants,
                                           IntBuffer filterTenant, ByteBuffer filters, IntBuffer filterOff, int nFilters,
-                                          IntBuffer limits, IntBuffer outRowPtr, IntBuffer outTopicIds, IntBuffer outCounts);
+                                          IntBuffer limits, long nowMs, IntBuffer outRowPtr, IntBuffer outTopicIds,
+                                          IntBuffer outCounts);
 
     static native int retainTopic(long engine, int topicId, ByteBuffer out, long[] tenantLenOut);
+
+    // ---- range pruning / routers ----
+    /** TenantRangeLookupCache.lookup for a batch of topics of one tenant: outKeep[t * nCand + c] = 1 if candidate range c is kept. */
+    static native void rangeLookup(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, int nTopics, ByteBuffer candKind,
+                                   ByteBuffer first, IntBuffer firstOff, ByteBuffer last, IntBuffer lastOff, int nCand, ByteBuffer outKeep);
+
+    /** MatchCallRangeRouter.rangeLookup: boundaries in BoundaryUtil.compare order; mode 0 = reference rules, 1 = exact. */
+    static native void retainRangeLookup(byte[] tenant, ByteBuffer filters, IntBuffer filterOff, int nFilters, ByteBuffer rangeFlags,
+                                         ByteBuffer start, IntBuffer startOff, ByteBuffer end, IntBuffer endOff, int nRanges, int mode,
+                                         ByteBuffer outKeep);
+
+    // ---- fan-out grouping ----
+    /** (topic, route) pairs of a match batch regrouped by DelivererKey; out = {nGroups, special}. @return pairs, or -(groups needed) */
+    static native long fanoutGroup(long engine, IntBuffer rowPtr, IntBuffer routeIds, int nTopics, IntBuffer outTopic, IntBuffer outRoute,
+                                   IntBuffer outGroupOff, IntBuffer outGroupRep, long[] out);
+
+    // ---- route cache (ISubscriptionCache on the engine's side) ----
+    static native long routeCacheCreate(long engine, long batcher, long maxRoutesPerTenant, long expiryMs);
+
+    static native void routeCacheDestroy(long cache);
+
+    /** ISubscriptionCache.get: @return number of route ids, or -(needed); epochOut[0] = the engine epoch they were matched at */
+    static native long routeCacheGet(long cache, byte[] tenant, byte[] topic, long nowMs, IntBuffer outIds, long[] epochOut);
+
+    static native int routeCacheIsCached(long cache, byte[] tenant, byte[] filter);
+
+    static native void routeCacheApply(long cache, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n);
+
+    static native void routeCacheRebuild(long cache, ByteBuffer keys, IntBuffer keyOff, int n);
+
+    static native void routeCacheReset(long cache);
 }

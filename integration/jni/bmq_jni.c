@@ -299,3 +299,128 @@ JNIEXPORT jint JNICALL NM(retainTopic)(JNIEnv* env, jclass c, jlong h, jint id, 
     }
     return (jint)len;
 }
+
+/* ---- range pruning / routers ---- */
+/* void rangeLookup(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, int nTopics, ByteBuffer candKind, ByteBuffer first,
+ *                  IntBuffer firstOff, ByteBuffer last, IntBuffer lastOff, int nCand, ByteBuffer outKeep)
+ * TenantRangeLookupCache.lookup for a batch of topics of one tenant: outKeep[t * nCand + c] */
+JNIEXPORT void JNICALL NM(rangeLookup)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jobject topics, jobject topicOff, jint nTopics,
+                                       jobject candKind, jobject first, jobject firstOff, jobject last, jobject lastOff, jint nCand, jobject outKeep) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    const int rc = bmq_range_lookup(ENGINE(h), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                    (uint32_t)nTopics, (const uint8_t*)ADDR(candKind), (const uint8_t*)ADDR(first), (const uint32_t*)ADDR(firstOff),
+                                    (const uint8_t*)ADDR(last), (const uint32_t*)ADDR(lastOff), (uint32_t)nCand, (uint8_t*)ADDR(outKeep));
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_range_lookup", rc);
+}
+/* void retainRangeLookup(byte[] tenant, ByteBuffer filters, IntBuffer filterOff, int nFilters, ByteBuffer rangeFlags, ByteBuffer start,
+ *                        IntBuffer startOff, ByteBuffer end, IntBuffer endOff, int nRanges, int mode, ByteBuffer outKeep)
+ * MatchCallRangeRouter.rangeLookup over the effective router given as boundaries in BoundaryUtil.compare order; mode 0 = the
+ * reference's findCandidates rules, 1 = exact; outKeep[f * nRanges + r] */
+JNIEXPORT void JNICALL NM(retainRangeLookup)(JNIEnv* env, jclass c, jbyteArray tenant, jobject filters, jobject filterOff, jint nFilters,
+                                             jobject rangeFlags, jobject start, jobject startOff, jobject end, jobject endOff, jint nRanges, jint mode,
+                                             jobject outKeep) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    const int rc = bmq_retain_range_lookup((const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(filters), (const uint32_t*)ADDR(filterOff),
+                                           (uint32_t)nFilters, (const uint8_t*)ADDR(rangeFlags), (const uint8_t*)ADDR(start),
+                                           (const uint32_t*)ADDR(startOff), (const uint8_t*)ADDR(end), (const uint32_t*)ADDR(endOff), (uint32_t)nRanges,
+                                           (uint32_t)mode, (uint8_t*)ADDR(outKeep));
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    if (rc != BMQ_OK) throw_state(env, NULL, "bmq_retain_range_lookup", rc);
+}
+
+/* ---- fan-out grouping ---- */
+/* long fanoutGroup(long engine, IntBuffer rowPtr, IntBuffer routeIds, int nTopics, IntBuffer outTopic, IntBuffer outRoute,
+ *                  IntBuffer outGroupOff, IntBuffer outGroupRep, long[] out)       out = {nGroups, special}
+ * the (topic, route) pairs of a match batch regrouped by DelivererKey; -> pairs, or -(groups needed) when outGroupRep is too small */
+JNIEXPORT jlong JNICALL NM(fanoutGroup)(JNIEnv* env, jclass c, jlong h, jobject rowPtr, jobject routeIds, jint nTopics, jobject outTopic,
+                                        jobject outRoute, jobject outGroupOff, jobject outGroupRep, jlongArray out) {
+    (void)c;
+    uint32_t ng = 0, sp = 0;
+    const uint32_t* row = (const uint32_t*)ADDR(rowPtr);
+    const int rc = bmq_fanout_group(ENGINE(h), row, (const uint32_t*)ADDR(routeIds), (uint32_t)nTopics, (uint32_t*)ADDR(outTopic),
+                                    (uint32_t*)ADDR(outRoute), CAP(outRoute), (uint32_t*)ADDR(outGroupOff), (uint32_t*)ADDR(outGroupRep),
+                                    (uint32_t)CAP(outGroupRep), &ng, &sp);
+    const jlong v[2] = {(jlong)ng, (jlong)sp};
+    (*env)->SetLongArrayRegion(env, out, 0, 2, v);
+    if (rc == BMQ_E_NOSPACE) return -(jlong)(ng ? ng : 1);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_fanout_group", rc);
+        return 0;
+    }
+    return row ? (jlong)row[nTopics] : 0;
+}
+
+/* ---- route cache (ISubscriptionCache on the engine's side) ---- */
+#define CACHE(h) ((bmq_route_cache*)(intptr_t)(h))
+/* long routeCacheCreate(long engine, long batcher, long maxRoutesPerTenant, long expiryMs)     0 = the reference's defaults */
+JNIEXPORT jlong JNICALL NM(routeCacheCreate)(JNIEnv* env, jclass c, jlong h, jlong b, jlong maxRoutes, jlong expiryMs) {
+    (void)c;
+    bmq_route_cache_config cfg = {0};
+    cfg.struct_size = sizeof cfg;
+    cfg.max_routes_per_tenant = (uint64_t)maxRoutes;
+    cfg.expiry_ms = (uint64_t)expiryMs;
+    bmq_route_cache* rc_ = NULL;
+    const int rc = bmq_route_cache_create(ENGINE(h), BATCHER(b), &cfg, &rc_);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_route_cache_create", rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)rc_;
+}
+/* void routeCacheDestroy(long cache) */
+JNIEXPORT void JNICALL NM(routeCacheDestroy)(JNIEnv* env, jclass c, jlong h) {
+    (void)env, (void)c;
+    bmq_route_cache_destroy(CACHE(h));
+}
+/* long routeCacheGet(long cache, byte[] tenant, byte[] topic, long nowMs, IntBuffer outIds, long[] epochOut)
+ * ISubscriptionCache.get(tenantId, topic): -> number of route ids, or -(needed); a hit never leaves the host */
+JNIEXPORT jlong JNICALL NM(routeCacheGet)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jbyteArray topic, jlong nowMs, jobject outIds,
+                                          jlongArray epochOut) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant), pl = (*env)->GetArrayLength(env, topic);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    jbyte* tp = (*env)->GetByteArrayElements(env, topic, NULL);
+    uint32_t n = 0;
+    uint64_t epoch = 0;
+    const int rc = bmq_route_cache_get(CACHE(h), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)tp, (uint32_t)pl, (uint64_t)nowMs,
+                                       (uint32_t*)ADDR(outIds), (uint32_t)CAP(outIds), &n, &epoch);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    (*env)->ReleaseByteArrayElements(env, topic, tp, JNI_ABORT);
+    const jlong ep = (jlong)epoch;
+    (*env)->SetLongArrayRegion(env, epochOut, 0, 1, &ep);
+    return result_of(env, NULL, "bmq_route_cache_get", rc, n);
+}
+/* int routeCacheIsCached(long cache, byte[] tenant, byte[] filter)      ISubscriptionCache.isCached: 1 / 0 */
+JNIEXPORT jint JNICALL NM(routeCacheIsCached)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jbyteArray filter) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant), fl = (*env)->GetArrayLength(env, filter);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    jbyte* ft = (*env)->GetByteArrayElements(env, filter, NULL);
+    const int rc = bmq_route_cache_is_cached(CACHE(h), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ft, (uint32_t)fl);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    (*env)->ReleaseByteArrayElements(env, filter, ft, JNI_ABORT);
+    if (rc < 0) throw_state(env, NULL, "bmq_route_cache_is_cached", rc);
+    return rc > 0;
+}
+/* void routeCacheApply(long cache, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n)     ISubscriptionCache.refresh */
+JNIEXPORT void JNICALL NM(routeCacheApply)(JNIEnv* env, jclass c, jlong h, jobject keys, jobject keyOff, jobject ops, jint n) {
+    (void)c;
+    const int rc = bmq_route_cache_apply(CACHE(h), (const uint8_t*)ADDR(keys), (const uint32_t*)ADDR(keyOff), (const uint8_t*)ADDR(ops), (uint32_t)n);
+    if (rc != BMQ_OK) throw_state(env, NULL, "bmq_route_cache_apply", rc);
+}
+/* void routeCacheRebuild(long cache, ByteBuffer keys, IntBuffer keyOff, int n)      IKVRangeCoProc.reset through the cache */
+JNIEXPORT void JNICALL NM(routeCacheRebuild)(JNIEnv* env, jclass c, jlong h, jobject keys, jobject keyOff, jint n) {
+    (void)c;
+    const int rc = bmq_route_cache_rebuild(CACHE(h), (const uint8_t*)ADDR(keys), (const uint32_t*)ADDR(keyOff), (uint32_t)n);
+    if (rc != BMQ_OK) throw_state(env, NULL, "bmq_route_cache_rebuild", rc);
+}
+/* void routeCacheReset(long cache)      ISubscriptionCache.reset(boundary) */
+JNIEXPORT void JNICALL NM(routeCacheReset)(JNIEnv* env, jclass c, jlong h) {
+    (void)env, (void)c;
+    (void)bmq_route_cache_reset(CACHE(h));
+}

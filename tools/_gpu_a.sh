@@ -2,17 +2,12 @@
 cd /root/repo
 mkdir -p gpurun_out/a
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_batcher_gpu.py -m gpu -q > gpurun_out/a/pytest_gpu3.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/a/pytest_gpu3.log
-tail -3 gpurun_out/a/pytest_gpu3.log
-timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --batcher-threads 256 > gpurun_out/a/batcher256.json 2> gpurun_out/a/batcher256.err
-python - <<'PY'
-import json
-try:
-    d = json.loads(open("gpurun_out/a/batcher256.json").read().strip().splitlines()[-1])
-    print(json.dumps(d.get("batching_front"), indent=1))
-except Exception as ex:
-    print("no bench line", ex)
-PY
-tail -3 gpurun_out/a/batcher256.err
-g++ -O2 -std=c++17 -pthread -o /tmp/cache_perf tools/cache_fuzz.cpp bifromq_amd/csrc/bmq_codec.cpp && for t in 16 64 256; do /tmp/cache_perf perf $t 400000; done
+one() {
+python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-host-path 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],4), round(d.get('ms_per_step_without_kernel_timing'),4), d['kernel_ms'])"
+}
+for r in 1 2; do
+unset BMQ_LIB BMQ_QCAP BMQ_PCAP; one base
+export BMQ_QCAP=128 BMQ_PCAP=128; one base_q128
+export BMQ_LIB=/root/repo/bifromq_amd/variants/libbmq_mw5.so; one mw5_q128
+done
