@@ -550,6 +550,33 @@ def test_full_size_config3_properties(eng):
     for j in differ[:20].tolist() + rnd.sample(range(len(cand)), 20):  # authoritative semantic check: quirk rows + a sub-sample
         i = int(cand[j])
         assert ids[row[i]:row[i + 1]].tolist() == kv.match_bruteforce(tn[int(tt[i])], [raw[off[i]:off[i + 1]]]).per_topic()[0]
+    # fan-out grouping of the whole batch (~18 M (topic, route) pairs regrouped by DelivererKey), size-independent properties:
+    # a permutation of the pairs; inside a group (topic, route) ascending; one DelivererKey per group and one group per DelivererKey
+    # (checked on a sample of pairs of every group through their route keys)
+    ot, orr, goff, grep, special = eng.fanout_group(row, ids, group_cap=4096)
+    assert goff[0] == 0 and goff[-1] == len(ids) and (np.diff(goff.astype(np.int64)) > 0).all()
+    pair_in = (np.repeat(np.arange(n, dtype=np.int64), counts) << 32) | ids.astype(np.int64)
+    pair_out = (ot.astype(np.int64) << 32) | orr.astype(np.int64)
+    assert (np.sort(pair_out) == pair_in).all()  # the input pairs are already in (topic, route) order
+    inside = np.ones(len(pair_out) - 1, dtype=bool)
+    inside[goff[1:-1].astype(np.int64) - 1] = False  # group boundaries
+    assert (np.diff(pair_out)[inside] > 0).all()
+    seen_keys = {}
+    for g in range(len(goff) - 1):
+        lo, hi_ = int(goff[g]), int(goff[g + 1])
+        if int(grep[g]) >= 0xFFFFFFFE:
+            assert g >= len(goff) - 3  # the special groups come last
+            if int(grep[g]) == 0xFFFFFFFE:  # shared subscriptions: every route of the group is a $share / $oshare route
+                smp = orr[lo:hi_][:200]
+                assert all(O.parse_route_key(k)[0] in (2, 3) for k in eng.route_keys(smp))
+            continue
+        pick = np.unique(np.concatenate([orr[lo:lo + 50], orr[hi_ - 50:hi_], orr[lo:hi_][:: max(1, (hi_ - lo) // 100)], [grep[g]]]))
+        dks = {O.deliverer_key_of(k) for k in eng.route_keys(pick)}
+        assert len(dks) == 1 and None not in dks, g
+        dk = dks.pop()
+        assert dk not in seen_keys
+        seen_keys[dk] = g
+    assert len(seen_keys) == 64 and not (special & 2)  # the generator's 64 deliverer keys d0..d63 under broker 0
 
 
 def test_submit_wait_two_batches_in_flight(eng):
