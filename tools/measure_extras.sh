@@ -9,18 +9,15 @@ done
 python bench.py --ungrouped --no-cpu-baseline --no-host-path > $O/ungrouped.json 2> $O/ungrouped.err
 python bench.py --exchange-selftest --no-cpu-baseline --no-host-path > $O/exchange_selftest.json 2> $O/exchange_selftest.err
 python bench.py --exchange-selftest --exchange-impl lib --no-cpu-baseline --no-host-path > $O/exchange_selftest_lib.json 2> $O/exchange_selftest_lib.err
-# topics per wave for small batches (tpw_shift_for in bmq_engine.hip): 64 / 16 / 4 topics per wave on a 10 k and a 1 k batch
-for n in 10000 1000; do for t in 6 4 2; do
-  BMQ_TPW_SHIFT=$t python bench.py --topics $n --steps 100 --warmup 5 --no-cpu-baseline --no-host-path 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('topics $n tpw_shift $t ms_per_step %.4f without_kernel_timing %.4f' % (d['ms_per_step'], d['ms_per_step_without_kernel_timing']), d['kernel_ms'])"
-done; done > $O/tpw_sweep.txt
 # per-wave phase clocks of k_walk (BMQ_DEBUG=2) and k_expand (BMQ_DEBUG=4), C3
 (BMQ_DEBUG=2 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-path 2>&1 >/dev/null | grep 'k_walk waves' | tail -1
  BMQ_DEBUG=4 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-path 2>&1 >/dev/null | grep 'k_expand waves' | tail -1) > $O/wave_clocks.txt
 BMQ_TIMING=1 python bench.py --churn 100000 --steps 10 --warmup 2 --no-cpu-baseline --no-host-path > $O/churn100k.json 2> $O/churn100k.err
 grep 'bmq index' $O/churn100k.err | tail -30 > $O/churn100k_phases.txt
 BMQ_TIMING=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path 2>&1 | grep 'rebuild:' > $O/rebuild_phases.txt
-python bench.py --no-cpu-baseline --no-host-path --steps 5 --warmup 2 --batcher-threads 256 > $O/batcher256.json 2> $O/batcher256.err
+for th in 16 64 256; do  # the box grants 16 CPUs (cgroup quota) whatever nproc says: 16 threads = one per CPU
+  python bench.py --no-cpu-baseline --no-host-path --steps 5 --warmup 2 --batcher-threads $th > $O/batcher$th.json 2> $O/batcher$th.err
+done
 python - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$O/*.json")):
@@ -31,4 +28,4 @@ for f in sorted(glob.glob("$O/*.json")):
     print(os.path.basename(f), round(d["value"] / 1e6, 1), "M/s", round(d["ms_per_step"], 3), "ms p50", round(d.get("p50_batch_ms", 0), 3), "p99",
           round(d.get("p99_batch_ms", 0), 3), {k: round(v, 3) for k, v in d["kernel_ms"].items()}, d.get("batching_front", ""), d["churn"]["apply_ms_mean"])
 PY
-cat $O/rebuild_phases.txt $O/tpw_sweep.txt $O/wave_clocks.txt
+cat $O/rebuild_phases.txt $O/wave_clocks.txt
