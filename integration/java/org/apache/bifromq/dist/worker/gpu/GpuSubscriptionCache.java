@@ -8,7 +8,7 @@
  * on the native side (bmq_route_cache_*: include/bmq.h): get() is one JNI call -- a hit is answered from host memory, a miss joins
  * the GPU launch that carries every other miss of the moment -- and refresh() hands the mutated route keys to the engine, which
  * applies them to the HBM-resident index and drops the cached topics their filters match.
- * What stays Java: turning route ids into Matching objects (GpuTenantRouteMatcher.RangeIndex.matchingOf, cached per generation) and the
+ * What stays Java: turning route ids into Matching objects (GpuTenantRouteMatcher.RangeIndex.resolve, cached per generation) and the
  * MatchedRoutes fan-out caps (fed in KV key order, as today).
  */
 package org.apache.bifromq.dist.worker.gpu;
