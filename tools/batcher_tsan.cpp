@@ -37,6 +37,8 @@ static uint32_t fake_id(std::string_view tenant, std::string_view topic, uint32_
     return h % 1000003u + k;
 }
 static std::atomic<uint64_t> g_batches{0};
+static std::atomic<int> g_launch_us{30}; // what a launch costs: slept away in the sanitizer runs, busy-waited in perf mode
+static std::atomic<bool> g_busy_wait{false};
 
 extern "C" int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
                                const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
@@ -54,7 +56,10 @@ extern "C" int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint
     out_row_ptr[n_topics] = (uint32_t)total;
     *out_needed = total;
     if (total > out_capacity) return BMQ_E_NOSPACE;
-    std::this_thread::sleep_for(std::chrono::microseconds(30)); // a launch takes a while: requests pile up meanwhile
+    if (g_busy_wait.load()) { // perf mode: the GPU takes this long, the calling thread waits for it (hipStreamSynchronize)
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(g_launch_us.load());
+        while (std::chrono::steady_clock::now() < until) std::this_thread::yield();
+    } else std::this_thread::sleep_for(std::chrono::microseconds(g_launch_us.load())); // a launch takes a while: requests pile up meanwhile
     for (uint32_t i = 0; i < n_topics; i++) {
         const std::string_view tn((const char*)tenants + tenant_off[topic_tenant[i]], tenant_off[topic_tenant[i] + 1] - tenant_off[topic_tenant[i]]);
         const std::string_view tp((const char*)topics + topic_off[i], topic_off[i + 1] - topic_off[i]);
@@ -86,7 +91,38 @@ static void on_done(void* user, int status, const uint32_t* ids, uint32_t n, uin
     c->done->fetch_add(1);
 }
 
-int main() {
+// batcher_tsan perf <threads> <calls per thread> <launch us>: blocking single-topic calls per second over the stand-in (not a test)
+static int perf(int n_threads, int calls, int launch_us) {
+    bmq_engine eng;
+    g_launch_us = launch_us;
+    g_busy_wait = true;
+    bmq_batcher* b = nullptr;
+    bmq_batcher_create(&eng, nullptr, &b);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_threads; w++)
+        th.emplace_back([&, w] {
+            std::mt19937 rng(w);
+            uint32_t row[2], ids[16];
+            for (int it = 0; it < calls; it++) {
+                const std::string tp = "a/" + std::to_string(rng() % 100000);
+                const uint32_t off[2] = {0, (uint32_t)tp.size()};
+                uint64_t need = 0, epoch = 0;
+                bmq_batcher_match_all(b, (const uint8_t*)"tenant", 6, (const uint8_t*)tp.data(), off, 1, row, ids, 16, &need, &epoch);
+            }
+        });
+    for (auto& t : th) t.join();
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    bmq_batcher_stats st;
+    bmq_batcher_stats_get(b, &st);
+    printf("perf: %d threads x %d calls, launch %d us: %.0f calls/s, %llu launches, %.1f topics/launch, %.1f us per launch cycle\n", n_threads, calls, launch_us,
+           n_threads * (double)calls / sec, (unsigned long long)st.n_batches, (double)st.n_topics / st.n_batches, sec * 1e6 / st.n_batches);
+    bmq_batcher_destroy(b);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "perf") return perf(argc > 2 ? atoi(argv[2]) : 64, argc > 3 ? atoi(argv[3]) : 2000, argc > 4 ? atoi(argv[4]) : 100);
     bmq_engine eng;
     const char* tenants[] = {"t", "tenantB", "x-long-tenant"};
     for (int pass = 0; pass < 3; pass++) {
