@@ -121,7 +121,39 @@ static int perf(int n_threads, int calls, int launch_us) {
     return 0;
 }
 
+// batcher_tsan perf_async <threads> <calls per thread> <launch us>: bmq_batcher_submit from a few threads, callbacks counted
+static void count_cb(void* user, int, const uint32_t*, uint32_t, uint64_t) { ((std::atomic<uint64_t>*)user)->fetch_add(1, std::memory_order_relaxed); }
+static int perf_async(int n_threads, int calls, int launch_us) {
+    bmq_engine eng;
+    g_launch_us = launch_us;
+    g_busy_wait = true;
+    bmq_batcher* b = nullptr;
+    bmq_batcher_create(&eng, nullptr, &b);
+    std::atomic<uint64_t> done{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_threads; w++)
+        th.emplace_back([&, w] {
+            std::mt19937 rng(w);
+            char tp[32];
+            for (int it = 0; it < calls; it++) {
+                const int n = snprintf(tp, sizeof tp, "l0_%u/l1_%u/l2_%u", (unsigned)(rng() % 8), (unsigned)(rng() % 64), (unsigned)(rng() % 4096));
+                bmq_batcher_submit(b, (const uint8_t*)"tenant000017", 12, (const uint8_t*)tp, (uint32_t)n, count_cb, &done);
+            }
+        });
+    for (auto& t : th) t.join();
+    bmq_batcher_stats st;
+    bmq_batcher_destroy(b); // drains
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("perf_async: %d threads x %d submits, launch %d us: %.0f calls/s (%llu callbacks)\n", n_threads, calls, launch_us, n_threads * (double)calls / sec,
+           (unsigned long long)done.load());
+    (void)st;
+    return done.load() == (uint64_t)n_threads * calls ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "perf_async")
+        return perf_async(argc > 2 ? atoi(argv[2]) : 4, argc > 3 ? atoi(argv[3]) : 200000, argc > 4 ? atoi(argv[4]) : 100);
     if (argc > 1 && std::string(argv[1]) == "perf") return perf(argc > 2 ? atoi(argv[2]) : 64, argc > 3 ? atoi(argv[3]) : 2000, argc > 4 ? atoi(argv[4]) : 100);
     bmq_engine eng;
     const char* tenants[] = {"t", "tenantB", "x-long-tenant"};
