@@ -306,6 +306,72 @@ int bmq_route_cache_create(bmq_engine* e, bmq_batcher* b, const bmq_route_cache_
 
 void bmq_route_cache_destroy(bmq_route_cache* c) { delete c; }
 
+namespace {
+// A loaded row goes into the cache unless a mutation that could change it has been applied since it was matched.
+void store_loaded(bmq_route_cache* c, TenantCache* t, Shard& sh, std::string_view tp, uint64_t th, std::vector<uint32_t>&& ids, uint64_t epoch,
+                  uint64_t now_ms) {
+    auto en = std::make_unique<Entry>(); // built outside the lock
+    en->topic = std::string(tp);
+    en->ids = std::move(ids);
+    en->hash = th;
+    en->epoch = epoch;
+    en->last_access_ms = now_ms;
+    const auto tl = split(tp, '/');
+    SpinGuard g(sh.mu);
+    bool stale;
+    { // shard lock, then log lock: a mutation logs first and invalidates the shards afterwards, so it either shows up here or finds the entry
+        std::lock_guard<std::mutex> lg(t->log_mu);
+        stale = epoch < t->log_floor; // mutations in (epoch, log_floor] are unknown here
+        for (size_t k = t->log.size(); !stale && k-- > 0 && t->log[k].epoch > epoch;) {
+            std::vector<std::string_view> fl(t->log[k].filter.begin(), t->log[k].filter.end());
+            stale = filter_matches(fl, tl);
+        }
+    }
+    if (stale) { // correct as of its epoch (the caller gets it), but not what the next caller should see
+        sh.stale_loads++;
+        return;
+    }
+    Entry* have = sh.find(th, tp);
+    if (have && have->epoch >= epoch) return; // another thread loaded the same topic meanwhile
+    if (have) sh.drop(have);
+    sh.insert(en.release());
+    const uint64_t budget = c->shard_budget();
+    while (sh.weight > budget && sh.lru.size() > 1) { // maximumWeight: least recently used first
+        sh.evictions++;
+        sh.drop(sh.lru.back());
+    }
+}
+// a live entry, touched -- or nullptr (an expired one is dropped on the way).  Shard lock held.
+Entry* lookup_live(bmq_route_cache* c, Shard& sh, std::string_view tp, uint64_t th, uint64_t now_ms) {
+    Entry* en = sh.find(th, tp);
+    if (!en) return nullptr;
+    if (now_ms >= en->last_access_ms && now_ms - en->last_access_ms >= c->expiry_ms) { // expireAfterAccess
+        sh.expired++;
+        sh.drop(en);
+        return nullptr;
+    }
+    sh.hits++;
+    en->last_access_ms = now_ms;
+    if (en->lru != sh.lru.begin()) sh.lru.splice(sh.lru.begin(), sh.lru, en->lru);
+    return en;
+}
+struct AsyncLoad { // a miss of bmq_route_cache_get_async on its way through the batching front
+    bmq_route_cache* c;
+    TenantCache* t;
+    std::string topic;
+    uint64_t th, now_ms;
+    bool bypass;
+    bmq_route_cache_cb cb;
+    void* user;
+};
+void async_loaded(void* user, int status, const uint32_t* ids, uint32_t n, uint64_t epoch) { // on the batcher's dispatcher thread
+    std::unique_ptr<AsyncLoad> a((AsyncLoad*)user);
+    if (status == BMQ_OK && !a->bypass && !a->c->bypass.load(std::memory_order_acquire))
+        store_loaded(a->c, a->t, a->c->shard_of(*a->t, a->th), a->topic, a->th, std::vector<uint32_t>(ids, ids + n), epoch, a->now_ms);
+    a->cb(a->user, status, ids, n, epoch);
+}
+} // namespace
+
 int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, uint64_t now_ms,
                         uint32_t* out_route_ids, uint32_t cap, uint32_t* out_n, uint64_t* out_epoch) {
     if (!c || !out_n || (tenant_len && !tenant) || (topic_len && !topic)) return BMQ_E_INVAL;
@@ -316,20 +382,12 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
     const bool bypass = c->bypass.load(std::memory_order_acquire);
     if (!bypass) {
         SpinGuard g(sh.mu);
-        if (Entry* en = sh.find(th, tp)) {
-            if (now_ms >= en->last_access_ms && now_ms - en->last_access_ms >= c->expiry_ms) { // expireAfterAccess
-                sh.expired++;
-                sh.drop(en);
-            } else {
-                sh.hits++;
-                en->last_access_ms = now_ms;
-                if (en->lru != sh.lru.begin()) sh.lru.splice(sh.lru.begin(), sh.lru, en->lru);
-                *out_n = (uint32_t)en->ids.size();
-                if (out_epoch) *out_epoch = en->epoch;
-                if (en->ids.size() > cap) return BMQ_E_NOSPACE;
-                if (!en->ids.empty()) memcpy(out_route_ids, en->ids.data(), en->ids.size() * 4);
-                return BMQ_OK;
-            }
+        if (Entry* en = lookup_live(c, sh, tp, th, now_ms)) {
+            *out_n = (uint32_t)en->ids.size();
+            if (out_epoch) *out_epoch = en->epoch;
+            if (en->ids.size() > cap) return BMQ_E_NOSPACE;
+            if (!en->ids.empty()) memcpy(out_route_ids, en->ids.data(), en->ids.size() * 4);
+            return BMQ_OK;
         }
         sh.misses++;
     }
@@ -349,39 +407,39 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
     if (out_epoch) *out_epoch = epoch;
     const bool fits = ids.size() <= cap;
     if (fits && !ids.empty()) memcpy(out_route_ids, ids.data(), ids.size() * 4);
-    if (!bypass && !c->bypass.load(std::memory_order_acquire)) {
-        auto en = std::make_unique<Entry>(); // built outside the lock
-        en->topic = std::string(tp);
-        en->ids = std::move(ids);
-        en->hash = th;
-        en->epoch = epoch;
-        en->last_access_ms = now_ms;
-        const auto tl = split(tp, '/');
-        SpinGuard g(sh.mu);
-        bool stale;
-        { // shard lock, then log lock: a mutation logs first and invalidates the shards afterwards, so it either shows up here or
-          // finds the entry
-            std::lock_guard<std::mutex> lg(t->log_mu);
-            stale = epoch < t->log_floor; // mutations in (epoch, log_floor] are unknown here
-            for (size_t k = t->log.size(); !stale && k-- > 0 && t->log[k].epoch > epoch;) {
-                std::vector<std::string_view> fl(t->log[k].filter.begin(), t->log[k].filter.end());
-                stale = filter_matches(fl, tl);
-            }
+    if (!bypass && !c->bypass.load(std::memory_order_acquire)) store_loaded(c, t, sh, tp, th, std::move(ids), epoch, now_ms);
+    return fits ? BMQ_OK : BMQ_E_NOSPACE;
+}
+
+int bmq_route_cache_get_async(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, uint64_t now_ms,
+                              bmq_route_cache_cb cb, void* user) {
+    if (!c || !cb || (tenant_len && !tenant) || (topic_len && !topic)) return BMQ_E_INVAL;
+    const std::string_view tn((const char*)tenant, tenant_len), tp((const char*)topic, topic_len);
+    TenantCache* t = c->obtain(tn);
+    const uint64_t th = hash64(tp);
+    Shard& sh = c->shard_of(*t, th);
+    const bool bypass = c->bypass.load(std::memory_order_acquire);
+    if (!bypass) {
+        std::vector<uint32_t> ids; // copied out: the callback runs without the lock
+        uint64_t epoch = 0;
+        bool hit = false;
+        {
+            SpinGuard g(sh.mu);
+            if (Entry* en = lookup_live(c, sh, tp, th, now_ms)) {
+                ids = en->ids;
+                epoch = en->epoch;
+                hit = true;
+            } else sh.misses++;
         }
-        if (stale) sh.stale_loads++; // correct as of its epoch (the caller gets it), but not what the next caller should see
-        else {
-            Entry* have = sh.find(th, tp);
-            if (have && have->epoch >= epoch) return fits ? BMQ_OK : BMQ_E_NOSPACE; // another thread loaded the same topic meanwhile
-            if (have) sh.drop(have);
-            sh.insert(en.release());
-            const uint64_t budget = c->shard_budget();
-            while (sh.weight > budget && sh.lru.size() > 1) { // maximumWeight: least recently used first
-                sh.evictions++;
-                sh.drop(sh.lru.back());
-            }
+        if (hit) { // a completed future: the callback runs on the caller's thread, before this call returns
+            cb(user, BMQ_OK, ids.data(), (uint32_t)ids.size(), epoch);
+            return BMQ_OK;
         }
     }
-    return fits ? BMQ_OK : BMQ_E_NOSPACE;
+    auto a = std::make_unique<AsyncLoad>(AsyncLoad{c, t, std::string(tp), th, now_ms, bypass, cb, user});
+    const int rc = bmq_batcher_submit(c->b, tenant, tenant_len, topic, topic_len, async_loaded, a.get());
+    if (rc == BMQ_OK) a.release(); // async_loaded owns it now
+    return rc;
 }
 
 int bmq_route_cache_is_cached(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len) {

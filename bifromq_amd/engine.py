@@ -637,6 +637,29 @@ class RouteCache:
             self._check(rc, "bmq_route_cache_get")
             return ids[:n.value].tolist(), int(ep.value)
 
+    CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64)
+
+    def get_async(self, tenant, topic, on_done, now_ms: int = 0):
+        """bmq_route_cache_get_async: on_done(status, ids list, epoch) runs inline on a hit, on the batcher's dispatcher thread after a miss"""
+        t, p = _b(tenant), _b(topic)
+        if not hasattr(self, "_live"):
+            self._live, self._seq = {}, 0
+        self._seq += 1
+        key = self._seq
+
+        def tramp(_user, status, ids, n, epoch):
+            try:
+                on_done(status, [ids[i] for i in range(n)], epoch)
+            finally:
+                self._live.pop(key, None)
+
+        cb = RouteCache.CALLBACK(tramp)
+        self._live[key] = cb  # keeps the trampoline alive until it has run
+        rc = _lib.lib().bmq_route_cache_get_async(self.h, t, len(t), p, len(p), now_ms, C.cast(cb, C.c_void_p), None)
+        if rc:
+            self._live.pop(key, None)
+            raise BmqError(rc, "bmq_route_cache_get_async")
+
     def is_cached(self, tenant, topic_filter) -> bool:
         t, f = _b(tenant), _b(topic_filter)
         rc = _lib.lib().bmq_route_cache_is_cached(self.h, t, len(t), f, len(f))

@@ -279,6 +279,14 @@ int bmq_route_cache_create(bmq_engine* e, bmq_batcher* b, const bmq_route_cache_
 void bmq_route_cache_destroy(bmq_route_cache* c);
 int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, uint64_t now_ms,
                         uint32_t* out_route_ids, uint32_t cap, uint32_t* out_n, uint64_t* out_epoch);
+/* The same as a future (ISubscriptionCache.get returns a CompletableFuture; Caffeine's AsyncLoadingCache, TenantRouteCache.java:116-139):
+ * a hit calls cb(user, BMQ_OK, ids, n, epoch) on the calling thread before the call returns; a miss is handed to bmq_batcher_submit and
+ * cb runs on the batcher's dispatcher thread once the launch that carries it has finished (the row is cached first, under the same
+ * epoch rule).  `route_ids` is only valid during the callback.  Nobody blocks on the GPU: a few threads keep millions of gets per
+ * second in flight. */
+typedef void (*bmq_route_cache_cb)(void* user, int status, const uint32_t* route_ids, uint32_t n_ids, uint64_t epoch);
+int bmq_route_cache_get_async(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len,
+                              uint64_t now_ms, bmq_route_cache_cb cb, void* user);
 int bmq_route_cache_is_cached(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len);
 int bmq_route_cache_apply(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
 int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys);

@@ -260,3 +260,39 @@ def test_route_cache_native_threads_two_passes(setup):
     assert st.misses >= distinct  # concurrent first requests of one topic may both load
     c.close()
     b.close()
+
+
+def test_route_cache_get_async_futures(setup):
+    """bmq_route_cache_get_async: a miss completes from the batcher's dispatcher thread (and is cached on the way), a hit completes
+    inline before the call returns; every completion carries exactly the oracle's row."""
+    eng, tn, tt, _, topics, exp = setup
+    b = eng.batcher()
+    c = B.RouteCache(b)
+    idx = list(range(0, 2000, 3))
+    got, lock, done = {}, threading.Lock(), threading.Event()
+
+    def on_done_for(i):
+        def f(status, ids, epoch):
+            with lock:
+                got.setdefault(i, []).append((status, ids, epoch, threading.get_ident()))
+                if sum(len(v) for v in got.values()) == len(idx):
+                    done.set()
+        return f
+    for i in idx:
+        c.get_async(tn[tt[i]], topics[i], on_done_for(i), now_ms=1)
+    assert done.wait(30)
+    me = threading.get_ident()
+    for i in idx:
+        (status, ids, epoch, _), = got[i]
+        assert status == 0 and ids == exp[i] and epoch == eng.info().epoch
+    assert any(tid != me for v in got.values() for (_, _, _, tid) in v)  # misses completed on the dispatcher thread
+    # everything is cached now: the second round completes inline, on this thread, without a launch
+    nb = b.stats().n_batches
+    got.clear()
+    done.clear()
+    for i in idx:
+        c.get_async(tn[tt[i]], topics[i], on_done_for(i), now_ms=2)
+        assert got[i][-1][3] == me and got[i][-1][1] == exp[i]  # already called back when get_async returns
+    assert b.stats().n_batches == nb and c.stats().hits >= len(idx)
+    c.close()
+    b.close()

@@ -9,6 +9,7 @@
 // Build + run: make -C bifromq_amd/csrc cachefuzz   (tests/test_host.py runs both builds)
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <map>
 #include <mutex>
@@ -31,8 +32,27 @@ struct bmq_engine {
     std::atomic<int> match_delay_us{0};
     std::atomic<uint64_t> n_match{0};
 };
-struct bmq_batcher {
+struct bmq_batcher { // blocking side: matches inline; asynchronous side: a dispatcher thread, as the real front has
     bmq_engine* e;
+    struct Req {
+        std::string tenant, topic;
+        bmq_batcher_cb cb;
+        void* user;
+    };
+    std::mutex qm;
+    std::condition_variable qcv;
+    std::vector<Req> queue;
+    std::thread dispatcher;
+    bool stop = false;
+    explicit bmq_batcher(bmq_engine* eng) : e(eng) {}
+    ~bmq_batcher() {
+        {
+            std::lock_guard<std::mutex> g(qm);
+            stop = true;
+        }
+        qcv.notify_all();
+        if (dispatcher.joinable()) dispatcher.join();
+    }
 };
 
 static std::vector<uint32_t> brute(const std::map<std::string, uint32_t>& model, std::string_view tenant, std::string_view topic) {
@@ -65,6 +85,35 @@ int bmq_batcher_match_all(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant
     *out_needed = ids.size();
     if (ids.size() > out_capacity) return BMQ_E_NOSPACE;
     for (size_t i = 0; i < ids.size(); i++) out_route_ids[i] = ids[i];
+    return BMQ_OK;
+}
+int bmq_batcher_submit(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, bmq_batcher_cb cb, void* user) {
+    std::lock_guard<std::mutex> g(b->qm);
+    if (b->stop) return BMQ_E_STATE;
+    if (!b->dispatcher.joinable())
+        b->dispatcher = std::thread([b] {
+            for (;;) {
+                std::vector<bmq_batcher::Req> batch;
+                {
+                    std::unique_lock<std::mutex> lk(b->qm);
+                    b->qcv.wait(lk, [&] { return b->stop || !b->queue.empty(); });
+                    if (b->queue.empty()) return;
+                    batch.swap(b->queue);
+                }
+                std::vector<std::vector<uint32_t>> rows;
+                uint64_t epoch;
+                {
+                    std::lock_guard<std::mutex> eg(b->e->mu); // one "launch": every row of the batch sees the same epoch
+                    for (auto& r : batch) rows.push_back(brute(b->e->model, r.tenant, r.topic));
+                    epoch = b->e->epoch;
+                }
+                b->e->n_match += batch.size();
+                if (const int d = b->e->match_delay_us.load()) std::this_thread::sleep_for(std::chrono::microseconds(d));
+                for (size_t i = 0; i < batch.size(); i++) batch[i].cb(batch[i].user, BMQ_OK, rows[i].data(), (uint32_t)rows[i].size(), epoch);
+            }
+        });
+    b->queue.push_back({std::string((const char*)tenant, tenant_len), std::string((const char*)topic, topic_len), cb, user});
+    b->qcv.notify_one();
     return BMQ_OK;
 }
 int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
@@ -221,7 +270,7 @@ static int is_cached(bmq_route_cache* c, const std::string& tenant, const std::s
 // ---- 2. single-threaded behaviour --------------------------------------------------------------------------------------------------
 static void test_behaviour() {
     bmq_engine e;
-    bmq_batcher b{&e};
+    bmq_batcher b(&e);
     bmq_route_cache_config cfg{};
     cfg.struct_size = sizeof(cfg);
     cfg.max_routes_per_tenant = 12;
@@ -285,7 +334,7 @@ static void test_behaviour() {
 static void test_concurrent(uint64_t seed, int n_threads, int ms) {
     bmq_engine e;
     e.match_delay_us = 40;
-    bmq_batcher b{&e};
+    bmq_batcher b(&e);
     bmq_route_cache_config cfg{};
     cfg.struct_size = sizeof(cfg);
     cfg.max_routes_per_tenant = 400;
@@ -334,6 +383,37 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
                 n_get++;
             }
         });
+    // two more getters use the future-shaped call: hits are called back inline, misses from the stand-in's dispatcher thread
+    struct AsyncCtx {
+        bmq_engine* e;
+        std::string tenant, topic;
+        std::atomic<uint64_t>* n_cb;
+    };
+    auto on_async = +[](void* user, int status, const uint32_t* ids, uint32_t n, uint64_t epoch) {
+        std::unique_ptr<AsyncCtx> a((AsyncCtx*)user);
+        EXPECT(status == BMQ_OK);
+        std::map<std::string, uint32_t> snap;
+        {
+            std::lock_guard<std::mutex> g(a->e->mu);
+            EXPECT(epoch < a->e->history.size());
+            snap = a->e->history[epoch < a->e->history.size() ? epoch : 0];
+        }
+        EXPECT(std::vector<uint32_t>(ids, ids + n) == brute(snap, a->tenant, a->topic));
+        a->n_cb->fetch_add(1);
+    };
+    std::atomic<uint64_t> n_async{0}, n_async_cb{0};
+    for (int w = 0; w < 2; w++)
+        th.emplace_back([&, w]() {
+            std::mt19937_64 r(seed * 55 + (uint64_t)w);
+            while (!stop) {
+                auto a = new AsyncCtx{&e, tenants[r() % tenants.size()], topic_of(r), &n_async_cb};
+                const int rc = bmq_route_cache_get_async(c, (const uint8_t*)a->tenant.data(), (uint32_t)a->tenant.size(), (const uint8_t*)a->topic.data(),
+                                                         (uint32_t)a->topic.size(), 1000, on_async, a);
+                EXPECT(rc == BMQ_OK);
+                n_async++;
+                if (n_async.load() - n_async_cb.load() > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100)); // bounded backlog
+            }
+        });
     std::thread mut([&]() {
         std::mt19937_64 r(seed * 31 + 5);
         std::vector<std::string> live;
@@ -359,6 +439,8 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
     stop = true;
     for (auto& t : th) t.join();
     mut.join();
+    for (int spin = 0; spin < 20000 && n_async_cb.load() < n_async.load(); spin++) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    EXPECT(n_async_cb.load() == n_async.load() && n_async.load() > 0); // every future completed
     // settled: what the cache serves now is the truth of the FINAL model -- a load overtaken by a mutation was not cached
     e.match_delay_us = 0;
     std::mt19937_64 r(seed);
@@ -375,7 +457,8 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
         }
     bmq_route_cache_stats st{};
     bmq_route_cache_stats_get(c, &st);
-    printf("  concurrent: %llu gets, %llu applies, hits %llu misses %llu invalidations %llu stale loads refused %llu evictions %llu; %llu of 1200 final "
+    printf("  concurrent: %llu async gets, ", (unsigned long long)n_async.load());
+    printf("%llu gets, %llu applies, hits %llu misses %llu invalidations %llu stale loads refused %llu evictions %llu; %llu of 1200 final "
            "probes served from the cache\n",
            (unsigned long long)n_get.load(), (unsigned long long)n_apply.load(), (unsigned long long)st.hits, (unsigned long long)st.misses,
            (unsigned long long)st.invalidations, (unsigned long long)st.stale_loads, (unsigned long long)st.evictions, (unsigned long long)served);
@@ -386,7 +469,7 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
 // ---- hit-path throughput (not a test): cache_fuzz perf <threads> <calls per thread> ------------------------------------------------
 static void perf(int n_threads, int calls) {
     bmq_engine e;
-    bmq_batcher b{&e};
+    bmq_batcher b(&e);
     bmq_route_cache_config cfg{};
     cfg.struct_size = sizeof(cfg);
     cfg.max_routes_per_tenant = 1ull << 40;
