@@ -420,6 +420,14 @@ def main():
                 "note": "bmq_route_cache_get: ISubscriptionCache.get per (tenant, topic); Zipf repeats inside pass 1 already hit"}
             rc_.close()
             bt.close()
+            bt = eng.batcher()  # the future-shaped call from 4 threads: nobody blocks, misses ride the asynchronous side of the front
+            rc_ = B.RouteCache(bt, max_routes_per_tenant=1 << 40)
+            cnt4, hsh4, secs4 = rc_.drive(w.tenants(), htt[:m], sub, 4, passes=2, asynchronous=True)
+            out["batching_front"]["route_cache"]["get_async"] = {
+                "threads": 4, "calls_per_s_first_pass": m / secs4[0], "calls_per_s_second_pass": m / secs4[1],
+                "launches": int(bt.stats().n_batches), "rows_equal_blocking_path": bool((cnt4 == cnt).all() and (hsh4 == hsh).all())}
+            rc_.close()
+            bt.close()
         except Exception as ex:  # noqa: BLE001
             out["batching_front"]["route_cache"] = {"error": repr(ex)}
     if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only (rank 0's host cores)

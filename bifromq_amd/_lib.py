@@ -186,6 +186,7 @@ def gen() -> C.CDLL:
             "bmqgen_drive_singletons": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, vp, vp, C.POINTER(C.c_double)]),
             "bmqgen_row_hash": (u64, [vp, u64]),
             "bmqgen_drive_cache": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, u32, vp, vp, C.POINTER(C.c_double)]),
+            "bmqgen_drive_cache_async": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, u32, vp, vp, C.POINTER(C.c_double)]),
             "bmqgen_drive_async": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, u32, u32, vp, vp, C.POINTER(C.c_double)]),
         }
         for name, (res, args) in sig.items():

@@ -484,4 +484,43 @@ int bmqgen_drive_async(void* fn, void* batcher, const uint8_t* tenants, const ui
     return ctx.err.load();
 }
 
+// ---- and through the route cache's future-shaped call (bmq_route_cache_get_async): n_threads threads issue every topic once per pass
+// without ever blocking on the GPU; hits complete inline, misses from the batcher's dispatcher thread
+typedef int (*cache_get_async_fn)(void*, const uint8_t*, uint32_t, const uint8_t*, uint32_t, uint64_t, batcher_cb, void*);
+int bmqgen_drive_cache_async(void* fn, void* cache, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                             const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, uint32_t n_threads, uint32_t passes,
+                             uint32_t* out_count, uint64_t* out_hash, double* out_seconds) {
+    if (!fn || !cache || !n_threads) return -1;
+    const cache_get_async_fn get = (cache_get_async_fn)fn;
+    std::vector<AsyncReq> reqs(n_topics);
+    for (uint32_t pass = 0; pass < passes; pass++) {
+        AsyncCtx ctx;
+        ctx.out_count = out_count;
+        ctx.out_hash = out_hash;
+        std::atomic<uint32_t> submitted{0};
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (uint32_t w = 0; w < n_threads; w++)
+            th.emplace_back([&, w] {
+                for (uint32_t i = w; i < n_topics && !ctx.err.load(); i += n_threads) {
+                    const uint32_t ti = topic_tenant[i];
+                    reqs[i] = AsyncReq{&ctx, i};
+                    const int rc = ti < n_tenants ? get(cache, tenants + tenant_off[ti], tenant_off[ti + 1] - tenant_off[ti], topics + topic_off[i],
+                                                        topic_off[i + 1] - topic_off[i], 1000, drive_cb, &reqs[i])
+                                                  : -1;
+                    if (rc) {
+                        ctx.err = rc;
+                        break;
+                    }
+                    submitted.fetch_add(1);
+                }
+            });
+        for (auto& t : th) t.join();
+        while (ctx.done.load() < submitted.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (out_seconds) out_seconds[pass] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (ctx.err.load()) return ctx.err.load();
+    }
+    return 0;
+}
+
 } // extern "C"

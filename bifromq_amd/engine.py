@@ -685,8 +685,9 @@ class RouteCache:
         self._check(_lib.lib().bmq_route_cache_stats_get(self.h, C.byref(st)), "bmq_route_cache_stats_get")
         return st
 
-    def drive(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed: Tuple[np.ndarray, np.ndarray], n_threads: int, passes: int = 2):
-        """n_threads native threads call bmq_route_cache_get once per topic, `passes` times over the batch.
+    def drive(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed: Tuple[np.ndarray, np.ndarray], n_threads: int, passes: int = 2,
+              asynchronous: bool = False):
+        """n_threads native threads call bmq_route_cache_get (or _get_async) once per topic, `passes` times over the batch.
         -> (ids per topic, row hash per topic, seconds per pass)"""
         tdata, toff = pack(tenants)
         pdata, poff = topics_packed
@@ -694,7 +695,9 @@ class RouteCache:
         cnt, hsh = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint64)
         sec = (C.c_double * passes)()
         tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
-        rc = _lib.gen().bmqgen_drive_cache(C.cast(_lib.lib().bmq_route_cache_get, C.c_void_p), self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(tt),
+        fn, drv = ((_lib.lib().bmq_route_cache_get_async, _lib.gen().bmqgen_drive_cache_async) if asynchronous else
+                   (_lib.lib().bmq_route_cache_get, _lib.gen().bmqgen_drive_cache))
+        rc = drv(C.cast(fn, C.c_void_p), self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(tt),
                                            _ptr(pdata), _ptr(poff), n, n_threads, passes, _ptr(cnt), _ptr(hsh), sec)
         if rc:
             raise BmqError(rc, "bmqgen_drive_cache")
