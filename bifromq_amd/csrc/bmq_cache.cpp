@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <list>
 #include <memory>
@@ -228,6 +229,8 @@ struct bmq_route_cache {
     std::mutex apply_mu; // one refresh at a time, in commit order (ISubscriptionCache.refresh comes from the range's apply thread)
     std::atomic<uint64_t> created_floor{0};
     std::atomic<bool> bypass{false}; // a rebuild is replacing the index: serve nothing from the cache, cache nothing
+    std::atomic<uint64_t> async_inflight{0}; // misses of get_async still with the batching front
+    std::atomic<uint64_t> cold_misses{0};    // gets for a tenant that has no cache yet
 
     bmq_route_cache() : buckets(new std::atomic<TenantCache*>[TBUCKETS]) {
         for (uint32_t i = 0; i < TBUCKETS; i++) buckets[i].store(nullptr, std::memory_order_relaxed);
@@ -304,7 +307,12 @@ int bmq_route_cache_create(bmq_engine* e, bmq_batcher* b, const bmq_route_cache_
     return BMQ_OK;
 }
 
-void bmq_route_cache_destroy(bmq_route_cache* c) { delete c; }
+void bmq_route_cache_destroy(bmq_route_cache* c) {
+    if (!c) return;
+    // futures still on their way complete first (the batcher's dispatcher thread calls them back): it outlives the cache
+    while (c->async_inflight.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    delete c;
+}
 
 namespace {
 // A loaded row goes into the cache unless a mutation that could change it has been applied since it was matched.
@@ -357,8 +365,7 @@ Entry* lookup_live(bmq_route_cache* c, Shard& sh, std::string_view tp, uint64_t 
 }
 struct AsyncLoad { // a miss of bmq_route_cache_get_async on its way through the batching front
     bmq_route_cache* c;
-    TenantCache* t;
-    std::string topic;
+    std::string tenant, topic;
     uint64_t th, now_ms;
     bool bypass;
     bmq_route_cache_cb cb;
@@ -366,9 +373,12 @@ struct AsyncLoad { // a miss of bmq_route_cache_get_async on its way through the
 };
 void async_loaded(void* user, int status, const uint32_t* ids, uint32_t n, uint64_t epoch) { // on the batcher's dispatcher thread
     std::unique_ptr<AsyncLoad> a((AsyncLoad*)user);
-    if (status == BMQ_OK && !a->bypass && !a->c->bypass.load(std::memory_order_acquire))
-        store_loaded(a->c, a->t, a->c->shard_of(*a->t, a->th), a->topic, a->th, std::vector<uint32_t>(ids, ids + n), epoch, a->now_ms);
+    if (status == BMQ_OK && !a->bypass && !a->c->bypass.load(std::memory_order_acquire)) {
+        TenantCache* t = a->c->obtain(a->tenant);
+        store_loaded(a->c, t, a->c->shard_of(*t, a->th), a->topic, a->th, std::vector<uint32_t>(ids, ids + n), epoch, a->now_ms);
+    }
     a->cb(a->user, status, ids, n, epoch);
+    a->c->async_inflight.fetch_sub(1, std::memory_order_acq_rel); // last touch of the cache: bmq_route_cache_destroy waits for this
 }
 } // namespace
 
@@ -376,11 +386,11 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
                         uint32_t* out_route_ids, uint32_t cap, uint32_t* out_n, uint64_t* out_epoch) {
     if (!c || !out_n || (tenant_len && !tenant) || (topic_len && !topic)) return BMQ_E_INVAL;
     const std::string_view tn((const char*)tenant, tenant_len), tp((const char*)topic, topic_len);
-    TenantCache* t = c->obtain(tn);
+    TenantCache* t = c->find(tn, hash64(tn)); // a tenant gets its cache with its first loaded row, not with its first question
     const uint64_t th = hash64(tp);
-    Shard& sh = c->shard_of(*t, th);
     const bool bypass = c->bypass.load(std::memory_order_acquire);
-    if (!bypass) {
+    if (!bypass && t) {
+        Shard& sh = c->shard_of(*t, th);
         SpinGuard g(sh.mu);
         if (Entry* en = lookup_live(c, sh, tp, th, now_ms)) {
             *out_n = (uint32_t)en->ids.size();
@@ -390,7 +400,7 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
             return BMQ_OK;
         }
         sh.misses++;
-    }
+    } else if (!bypass) c->cold_misses.fetch_add(1, std::memory_order_relaxed);
     // load: matchAll(singleton(topic)) through the batching front (TenantRouteCache.java:180-193)
     const uint32_t off[2] = {0, topic_len};
     uint32_t row[2] = {0, 0};
@@ -407,7 +417,10 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
     if (out_epoch) *out_epoch = epoch;
     const bool fits = ids.size() <= cap;
     if (fits && !ids.empty()) memcpy(out_route_ids, ids.data(), ids.size() * 4);
-    if (!bypass && !c->bypass.load(std::memory_order_acquire)) store_loaded(c, t, sh, tp, th, std::move(ids), epoch, now_ms);
+    if (!bypass && !c->bypass.load(std::memory_order_acquire)) {
+        if (!t) t = c->obtain(tn);
+        store_loaded(c, t, c->shard_of(*t, th), tp, th, std::move(ids), epoch, now_ms);
+    }
     return fits ? BMQ_OK : BMQ_E_NOSPACE;
 }
 
@@ -415,11 +428,11 @@ int bmq_route_cache_get_async(bmq_route_cache* c, const uint8_t* tenant, uint32_
                               bmq_route_cache_cb cb, void* user) {
     if (!c || !cb || (tenant_len && !tenant) || (topic_len && !topic)) return BMQ_E_INVAL;
     const std::string_view tn((const char*)tenant, tenant_len), tp((const char*)topic, topic_len);
-    TenantCache* t = c->obtain(tn);
+    TenantCache* t = c->find(tn, hash64(tn));
     const uint64_t th = hash64(tp);
-    Shard& sh = c->shard_of(*t, th);
     const bool bypass = c->bypass.load(std::memory_order_acquire);
-    if (!bypass) {
+    if (!bypass && t) {
+        Shard& sh = c->shard_of(*t, th);
         std::vector<uint32_t> ids; // copied out: the callback runs without the lock
         uint64_t epoch = 0;
         bool hit = false;
@@ -435,10 +448,12 @@ int bmq_route_cache_get_async(bmq_route_cache* c, const uint8_t* tenant, uint32_
             cb(user, BMQ_OK, ids.data(), (uint32_t)ids.size(), epoch);
             return BMQ_OK;
         }
-    }
-    auto a = std::make_unique<AsyncLoad>(AsyncLoad{c, t, std::string(tp), th, now_ms, bypass, cb, user});
+    } else if (!bypass) c->cold_misses.fetch_add(1, std::memory_order_relaxed);
+    auto a = std::make_unique<AsyncLoad>(AsyncLoad{c, std::string(tn), std::string(tp), th, now_ms, bypass, cb, user});
+    c->async_inflight.fetch_add(1, std::memory_order_acq_rel);
     const int rc = bmq_batcher_submit(c->b, tenant, tenant_len, topic, topic_len, async_loaded, a.get());
     if (rc == BMQ_OK) a.release(); // async_loaded owns it now
+    else c->async_inflight.fetch_sub(1, std::memory_order_acq_rel);
     return rc;
 }
 
@@ -549,6 +564,7 @@ int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint3
 int bmq_route_cache_stats_get(bmq_route_cache* c, bmq_route_cache_stats* out) {
     if (!c || !out) return BMQ_E_INVAL;
     memset(out, 0, sizeof(*out));
+    out->misses = c->cold_misses.load(std::memory_order_relaxed);
     c->for_each_tenant([&](TenantCache& t) {
         for (uint32_t s = 0; s < c->n_shards; s++) {
             Shard& sh = t.shards[s];

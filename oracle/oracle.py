@@ -690,3 +690,50 @@ def fanout_groups(key_of, per_topic_routes):
             else:
                 batches.setdefault(dk, []).append((t, rid))
     return batches, shared, dead
+
+
+# ---- TenantRouteCache's patch path (DW/cache/TenantRouteCache.java:208-296) at the level of route identity (= KV route key) ---------
+class TenantRouteCacheModel:
+    """One tenant's route cache as the reference maintains it: a load stores matchAll(singleton(topic)) (:217-230) and files the topic in
+    the TopicIndex; AddRoutes / RemoveRoutes tasks PATCH the cached rows index.match(filterLevels) finds (:243-291) through
+    MatchedRoutes.addNormalMatching / removeNormalMatching / putGroupMatching / removeGroupMatching (MatchedRoutes.java:87-141, caps
+    INT_MAX).  Used to pin that dropping those rows and re-matching them -- what bmq_route_cache_apply does -- serves the same sets."""
+
+    def __init__(self, tenant: str):
+        self.tenant = tenant
+        self.index = LevelTrie(0)      # TopicIndex<RouteCacheKey>
+        self.topic_no = {}             # topic -> value filed in the index
+        self.topics = []
+        self.cached = {}               # topic -> set of route keys (a group route = its one key: MatchedRoutes keeps one GroupMatching
+                                       # per mqttTopicFilter, putGroupMatching replaces it)
+
+    def load(self, topic: str, kv_keys):
+        """LoadEntryTask: matchAll(singleton(topic)) over the CURRENT routes, cacheKey filed in the index"""
+        rows = KV(sorted(kv_keys)).match_bruteforce(self.tenant, [topic]).per_topic()[0]
+        ks = sorted(kv_keys)
+        self.cached[topic] = {ks[r] for r in rows}
+        if topic not in self.topic_no:
+            self.topic_no[topic] = len(self.topics)
+            self.topics.append(topic)
+        self.index.add(None, topic, self.topic_no[topic])
+
+    def evict(self, topic: str):
+        """Caffeine's removalListener: index.remove(key.topic, key) (:117-118)"""
+        if topic in self.cached:
+            del self.cached[topic]
+            self.index.remove(None, topic, self.topic_no[topic])
+
+    def _hit(self, filter_levels):
+        return [self.topics[v] for v in self.index.match(None, "/".join(filter_levels))]
+
+    def add_routes(self, filter_levels, route_keys):
+        """AddRoutesTask (:243-266): addNormalMatching / putGroupMatching on every cached row the filter matches"""
+        for topic in self._hit(filter_levels):
+            if topic in self.cached:
+                self.cached[topic] |= set(route_keys)
+
+    def remove_routes(self, filter_levels, route_keys, group_still_has_members=False):
+        """RemoveRoutesTask (:268-291): removeNormalMatching; a group route is removed only when its last member left"""
+        for topic in self._hit(filter_levels):
+            if topic in self.cached and not group_still_has_members:
+                self.cached[topic] -= set(route_keys)

@@ -460,3 +460,51 @@ def test_golden_files_match_the_inline_tables():
     assert [tuple(r) for r in rows["rows"]] == [(f, t) for f, t in INDEX_ROWS + TOPIC_INDEX_EXTRA_ROWS]
     fx = json.load(open(os.path.join(g, "expansion_fixtures.json"), encoding="utf-8"))
     assert fx["global"] == GLOBAL_TOPIC_TO_FILTERS and fx["local"] == LOCAL_TOPIC_TO_FILTERS
+
+
+def test_route_cache_patch_equals_rematch():
+    """The reference PATCHES cached rows on route mutations (TenantRouteCache.java:243-291: index.match(filterLevels) -> add / remove the
+    Matching); bmq_route_cache_apply DROPS those rows and re-matches them on the next get.  Restated at the level of route identity
+    (oracle.TenantRouteCacheModel over the restated TopicIndex), the patched rows equal a fresh matchAll on the updated routes after
+    every step of random load / subscribe / unsubscribe / evict sequences -- so both serve the same sets."""
+    import random
+    rnd = random.Random(77)
+    alpha = ["a", "b", "", "$s", "c"]
+
+    def topic():
+        return "/".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 3)))
+
+    def filt():
+        lv = [rnd.choice(alpha + ["+"]) for _ in range(rnd.randint(1, 3))]
+        if rnd.random() < 0.25:
+            lv.append("#")
+        return "/".join(lv)
+    for trial in range(6):
+        tenant = "t%d" % trial
+        model = O.TenantRouteCacheModel(tenant)
+        keys = set()
+        for step in range(120):
+            p = rnd.random()
+            if p < 0.35 or not keys:
+                f = filt()
+                shared = rnd.random() < 0.2
+                k = O.route_key_from_mqtt(tenant, ("$share/g%d/" % rnd.randint(0, 2) + f) if shared else f,
+                                          "" if shared else O.receiver_url(rnd.choice([0, 1]), "i%d" % rnd.randint(0, 9), "d"))
+                if k not in keys:
+                    keys.add(k)
+                    model.add_routes(f.split("/"), [k])
+            elif p < 0.55:
+                k = rnd.choice(sorted(keys))
+                keys.discard(k)
+                flag, _, mqtt, _ = O.parse_route_key(k)
+                f = mqtt if flag == 1 else mqtt.split("/", 2)[2]
+                model.remove_routes(f.split("/"), [k])
+            elif p < 0.9:
+                model.load(topic(), keys)
+            elif model.cached:
+                model.evict(rnd.choice(sorted(model.cached)))
+            ks = sorted(keys)
+            kv = O.KV(ks)
+            for t, got in model.cached.items():
+                want = {ks[r] for r in kv.match_bruteforce(tenant, [t]).per_topic()[0]}
+                assert got == want, (trial, step, t)
