@@ -182,3 +182,16 @@ def test_router_argument_checks():
     # router that does not reach the query start: TreeMap.subMap would throw; nothing is returned
     assert RangeRouter([(b"x", b"y")]).find_by_boundary(b"a", b"b") == []
     assert O.router_find_by_boundary((b"a", b"b"), [(b"x", b"y")]) == []
+
+
+def test_router_under_sanitizers():
+    """tools/router_fuzz.cpp: bmq_router.cpp under ASan + UBSan with hostile boundary keys (empty, truncated inside the key header,
+    all 0xFF, other tenants'): a lookup succeeds or reports BMQ_E_INVAL, find_by_boundary returns exactly the overlapping ranges, EXACT
+    mode always asks the range holding a matching retained topic."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "bifromq_amd", "csrc"), "routerfuzz"], check=True, capture_output=True, timeout=600)
+    for seed in ("1", "7"):
+        r = subprocess.run([os.path.join(root, "tools", "router_fuzz"), seed, "500"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "router_fuzz ok" in r.stdout, r.stdout + r.stderr
