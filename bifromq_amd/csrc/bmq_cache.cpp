@@ -457,6 +457,118 @@ int bmq_route_cache_get_async(bmq_route_cache* c, const uint8_t* tenant, uint32_
     return rc;
 }
 
+int bmq_route_cache_get_batch(bmq_route_cache* c, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                              const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, uint64_t now_ms, uint32_t* out_row_ptr,
+                              uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed, uint8_t* out_hit) {
+    if (!c || !out_row_ptr || !out_needed || (n_topics && (!topics || !topic_off || !topic_tenant)) || (n_tenants && (!tenants || !tenant_off)))
+        return BMQ_E_INVAL;
+    *out_needed = 0;
+    out_row_ptr[0] = 0;
+    if (n_topics == 0) return BMQ_OK;
+    for (uint32_t i = 0; i < n_topics; i++)
+        if (topic_tenant[i] >= n_tenants) return BMQ_E_INVAL;
+    const bool bypass = c->bypass.load(std::memory_order_acquire);
+    // pass 1: the cache.  Hits are copied out at once (an entry may be gone a moment later); misses are listed, identical ones once.
+    std::vector<TenantCache*> tcache(n_tenants);
+    std::vector<uint64_t> thash(n_tenants);
+    for (uint32_t t = 0; t < n_tenants; t++) {
+        const std::string_view tn((const char*)tenants + tenant_off[t], tenant_off[t + 1] - tenant_off[t]);
+        thash[t] = hash64(tn);
+        tcache[t] = c->find(tn, thash[t]);
+    }
+    struct Row {
+        uint64_t off = 0; // into hit_ids, or (miss) the row of the launch
+        uint32_t n = 0;
+        bool hit = false;
+    };
+    std::vector<Row> rows(n_topics);
+    std::vector<uint32_t> hit_ids;
+    std::vector<uint32_t> miss_first;                  // launch row -> first topic index asking for it
+    std::unordered_map<uint64_t, uint32_t> miss_row;   // hash of (tenant, topic) -> launch row (bytes compared)
+    std::vector<uint64_t> phash(n_topics);
+    for (uint32_t i = 0; i < n_topics; i++) {
+        const uint32_t ti = topic_tenant[i];
+        const std::string_view tp((const char*)topics + topic_off[i], topic_off[i + 1] - topic_off[i]);
+        const uint64_t th = phash[i] = hash64(tp);
+        if (!bypass && tcache[ti]) {
+            Shard& sh = c->shard_of(*tcache[ti], th);
+            SpinGuard g(sh.mu);
+            if (Entry* en = lookup_live(c, sh, tp, th, now_ms)) {
+                rows[i].hit = true;
+                rows[i].off = hit_ids.size();
+                rows[i].n = (uint32_t)en->ids.size();
+                hit_ids.insert(hit_ids.end(), en->ids.begin(), en->ids.end());
+                continue;
+            }
+            sh.misses++;
+        } else if (!bypass) c->cold_misses.fetch_add(1, std::memory_order_relaxed);
+        uint64_t key = th ^ (thash[ti] * 0x9E3779B97F4A7C15ull);
+        for (;; key++) { // open chaining on the 64-bit key: a different pair with the same key takes the next one
+            auto it = miss_row.find(key);
+            if (it == miss_row.end()) {
+                miss_row.emplace(key, (uint32_t)miss_first.size());
+                rows[i].off = miss_first.size();
+                miss_first.push_back(i);
+                break;
+            }
+            const uint32_t j = miss_first[it->second];
+            if (topic_tenant[j] == ti && topic_off[j + 1] - topic_off[j] == tp.size() &&
+                (tp.empty() || !memcmp(topics + topic_off[j], tp.data(), tp.size()))) {
+                rows[i].off = it->second;
+                break;
+            }
+        }
+    }
+    // pass 2: ONE launch for everything missing
+    std::vector<uint32_t> m_row, m_ids;
+    uint64_t epoch = 0;
+    const uint32_t n_miss = (uint32_t)miss_first.size();
+    if (n_miss) {
+        std::vector<uint8_t> m_topics;
+        std::vector<uint32_t> m_off{0}, m_tenant(n_miss);
+        for (uint32_t r = 0; r < n_miss; r++) {
+            const uint32_t i = miss_first[r];
+            m_topics.insert(m_topics.end(), topics + topic_off[i], topics + topic_off[i + 1]);
+            m_off.push_back((uint32_t)m_topics.size());
+            m_tenant[r] = topic_tenant[i];
+        }
+        m_topics.resize(m_topics.size() + 16, 0); // the engine reads whole 16-byte groups
+        m_row.resize((size_t)n_miss + 1);
+        m_ids.resize(std::max<size_t>(1024, (size_t)n_miss * 16));
+        uint64_t need = 0;
+        int rc = BMQ_OK;
+        for (int attempt = 0; attempt < 3; attempt++) {
+            rc = bmq_batcher_match_batch(c->b, tenants, tenant_off, n_tenants, m_tenant.data(), m_topics.data(), m_off.data(), n_miss, m_row.data(),
+                                         m_ids.data(), m_ids.size(), &need, &epoch);
+            if (rc != BMQ_E_NOSPACE) break;
+            m_ids.resize(need + need / 8 + 64);
+        }
+        if (rc != BMQ_OK) return rc;
+        if (!bypass && !c->bypass.load(std::memory_order_acquire))
+            for (uint32_t r = 0; r < n_miss; r++) {
+                const uint32_t i = miss_first[r], ti = topic_tenant[i];
+                if (!tcache[ti]) tcache[ti] = c->obtain(std::string_view((const char*)tenants + tenant_off[ti], tenant_off[ti + 1] - tenant_off[ti]));
+                const std::string_view tp((const char*)topics + topic_off[i], topic_off[i + 1] - topic_off[i]);
+                store_loaded(c, tcache[ti], c->shard_of(*tcache[ti], phash[i]), tp, phash[i], std::vector<uint32_t>(m_ids.begin() + m_row[r], m_ids.begin() + m_row[r + 1]),
+                             epoch, now_ms);
+            }
+    }
+    // pass 3: the CSR
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_topics; i++) {
+        if (!rows[i].hit) rows[i].n = m_row[rows[i].off + 1] - m_row[rows[i].off];
+        total += rows[i].n;
+        if (total >= 0xFFFFFFFFull) return BMQ_E_RANGE;
+        out_row_ptr[i + 1] = (uint32_t)total;
+        if (out_hit) out_hit[i] = rows[i].hit ? 1 : 0;
+    }
+    *out_needed = total;
+    if (total > out_capacity || (total && !out_route_ids)) return BMQ_E_NOSPACE;
+    for (uint32_t i = 0; i < n_topics; i++)
+        if (rows[i].n) memcpy(out_route_ids + out_row_ptr[i], rows[i].hit ? hit_ids.data() + rows[i].off : m_ids.data() + m_row[rows[i].off], (size_t)rows[i].n * 4);
+    return BMQ_OK;
+}
+
 int bmq_route_cache_is_cached(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len) {
     if (!c) return BMQ_E_INVAL;
     const std::string_view tn((const char*)tenant, tenant_len);

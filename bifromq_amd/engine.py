@@ -637,6 +637,24 @@ class RouteCache:
             self._check(rc, "bmq_route_cache_get")
             return ids[:n.value].tolist(), int(ep.value)
 
+    def get_batch(self, tenants: Sequence, topic_tenant, topics: Sequence, now_ms: int = 0):
+        """bmq_route_cache_get_batch: a whole BatchDistRequest -> (row_ptr, route ids, hit flags); misses share ONE launch"""
+        tdata, toff = pack(tenants)
+        pdata, poff = pack(topics)
+        n = len(topics)
+        tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
+        row, hit = np.zeros(n + 1, dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint8)
+        cap, need = max(256, 8 * n), C.c_uint64()
+        while True:
+            ids = np.zeros(cap, dtype=np.uint32)
+            rc = _lib.lib().bmq_route_cache_get_batch(self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(tt), _ptr(pdata), _ptr(poff), n, now_ms,
+                                                      _ptr(row), _ptr(ids), cap, C.byref(need), _ptr(hit))
+            if rc == -3 and need.value > cap:
+                cap = int(need.value)
+                continue
+            self._check(rc, "bmq_route_cache_get_batch")
+            return row, ids[:need.value], hit[:n].astype(bool)
+
     CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64)
 
     def get_async(self, tenant, topic, on_done, now_ms: int = 0):

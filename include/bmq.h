@@ -232,6 +232,12 @@ void bmq_batcher_destroy(bmq_batcher* b);
 int bmq_batcher_match_all(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics,
                           const uint32_t* topic_off, uint32_t n_topics, uint32_t* out_row_ptr,
                           uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed, uint64_t* out_epoch);
+/* A whole multi-tenant batch (the arguments of bmq_match_batch) as ONE launch of its own, taking its turn with the collected launches;
+ * *out_epoch = the epoch of the index the batch saw (bmq_match_batch alone cannot tell).  For callers that already hold many topics:
+ * bmq_route_cache_get_batch matches the cache misses of one BatchDistRequest this way. */
+int bmq_batcher_match_batch(bmq_batcher* b, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                            const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, uint32_t* out_row_ptr, uint32_t* out_route_ids,
+                            uint64_t out_capacity, uint64_t* out_needed, uint64_t* out_epoch);
 /* Asynchronous form for loaders that return a future (Caffeine's AsyncCache in TenantRouteCache.java:116-139): the topic is
  * copied and packed into the batch being collected and the call returns at once; a dispatcher thread owned by the batcher
  * (started by the first submit) matches whatever has been collected whenever the engine is free and then calls
@@ -287,6 +293,14 @@ int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tena
 typedef void (*bmq_route_cache_cb)(void* user, int status, const uint32_t* route_ids, uint32_t n_ids, uint64_t epoch);
 int bmq_route_cache_get_async(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len,
                               uint64_t now_ms, bmq_route_cache_cb cb, void* user);
+/* DistWorkerCoProc.batchDist (DW/DistWorkerCoProc.java:515-552) asks the cache once per (tenant, topic) of a BatchDistRequest; this is the
+ * whole request in one call (arguments and CSR output as bmq_match_batch): the rows of cached topics are copied from the cache, all the
+ * others -- identical (tenant, topic) pairs once -- are matched in ONE launch (bmq_batcher_match_batch) and cached under the epoch rule.
+ * out_hit[i] (may be NULL) = 1 if row i came from the cache.  BMQ_E_NOSPACE + *out_needed if out_capacity is short (row pointers are
+ * written; what was loaded is cached, so the second call hits). */
+int bmq_route_cache_get_batch(bmq_route_cache* c, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                              const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, uint64_t now_ms, uint32_t* out_row_ptr,
+                              uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed, uint8_t* out_hit);
 int bmq_route_cache_is_cached(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filter, uint32_t filter_len);
 int bmq_route_cache_apply(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
 int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys);

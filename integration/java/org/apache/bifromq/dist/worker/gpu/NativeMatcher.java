@@ -115,6 +115,14 @@ final class NativeMatcher {
     /** ISubscriptionCache.get: @return number of route ids, or -(needed); epochOut[0] = the engine epoch they were matched at */
     static native long routeCacheGet(long cache, byte[] tenant, byte[] topic, long nowMs, IntBuffer outIds, long[] epochOut);
 
+    /**
+     * A whole BatchDistRequest (DistWorkerCoProc.batchDist): cached rows are copied from the host, every miss of the request travels in
+     * ONE launch.  outHit[i] = 1 if row i came from the cache.  @return number of ids, or -(needed)
+     */
+    static native long routeCacheGetBatch(long cache, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant,
+                                          ByteBuffer topics, IntBuffer topicOff, int nTopics, long nowMs, IntBuffer outRowPtr,
+                                          IntBuffer outIds, ByteBuffer outHit);
+
     static native int routeCacheIsCached(long cache, byte[] tenant, byte[] filter);
 
     static native void routeCacheApply(long cache, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n);

@@ -424,3 +424,17 @@ JNIEXPORT void JNICALL NM(routeCacheReset)(JNIEnv* env, jclass c, jlong h) {
     (void)env, (void)c;
     (void)bmq_route_cache_reset(CACHE(h));
 }
+/* long routeCacheGetBatch(long cache, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant, ByteBuffer topics,
+ *                         IntBuffer topicOff, int nTopics, long nowMs, IntBuffer outRowPtr, IntBuffer outIds, ByteBuffer outHit)
+ * a whole BatchDistRequest (DistWorkerCoProc.batchDist): cached rows from the host, every miss in ONE launch; -> ids, or -(needed) */
+JNIEXPORT jlong JNICALL NM(routeCacheGetBatch)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants, jobject topicTenant,
+                                               jobject topics, jobject topicOff, jint nTopics, jlong nowMs, jobject outRowPtr, jobject outIds,
+                                               jobject outHit) {
+    (void)c;
+    uint64_t need = 0;
+    const int rc = bmq_route_cache_get_batch(CACHE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
+                                             (const uint32_t*)ADDR(topicTenant), (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                             (uint32_t)nTopics, (uint64_t)nowMs, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds), &need,
+                                             (uint8_t*)ADDR(outHit));
+    return result_of(env, NULL, "bmq_route_cache_get_batch", rc, need);
+}

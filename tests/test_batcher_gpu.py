@@ -296,3 +296,39 @@ def test_route_cache_get_async_futures(setup):
     assert b.stats().n_batches == nb and c.stats().hits >= len(idx)
     c.close()
     b.close()
+
+
+def test_route_cache_get_batch_one_launch_for_all_misses(setup):
+    """bmq_route_cache_get_batch: a whole BatchDistRequest (all tenants) in one call -- every miss of the request, identical ones once,
+    travels in ONE launch; the second call is served from the cache; rows equal the oracle either way, also after a mutation."""
+    eng0, tn, tt, _, topics, exp = setup
+    w = B.Workload(21, 6, 1500, 1)
+    keys = w.keys()
+    eng = B.Engine(device=0).rebuild(keys)
+    b = eng.batcher()
+    c = B.RouteCache(b, max_routes_per_tenant=10_000_000)
+    sel = list(range(0, 6000, 2))
+    row, ids, hit = c.get_batch(tn, tt[sel], [topics[i] for i in sel], now_ms=1)
+    assert U.csr_rows(row, ids) == [exp[i] for i in sel]
+    assert b.stats().n_batches == 1 and not hit.any()  # one launch carried everything
+    distinct = len({(int(tt[i]), topics[i]) for i in sel})
+    assert b.stats().n_topics == distinct and c.stats().entries == distinct  # identical (tenant, topic) pairs matched once
+    row2, ids2, hit2 = c.get_batch(tn, tt[sel], [topics[i] for i in sel], now_ms=2)
+    assert hit2.all() and b.stats().n_batches == 1 and (row2 == row).all() and (ids2 == ids).all()
+    # a '#' subscription under one first level of tenant 0: those rows are re-matched (one more launch), the rest still hit
+    t0 = tn[0]
+    lv0 = topics[[i for i in sel if tt[i] == 0][0]].split("/")[0]
+    new_key = B.route_key(t0, lv0 + "/#", 1, "0\0batchTest\0d2")
+    c.apply([(0, new_key)])
+    keys2 = sorted(set(keys) | {new_key})
+    row3, ids3, hit3 = c.get_batch(tn, tt[sel], [topics[i] for i in sel], now_ms=3)
+    assert b.stats().n_batches == 2 and hit3.any() and not hit3.all()
+    want = U.semantic_rows(O.KV(keys2), tn, tt[sel], [topics[i] for i in sel])
+    got = U.rows_as_ranks(eng, row3, ids3, keys2)
+    assert got == want
+    for j, i in enumerate(sel):
+        affected = tt[i] == 0 and topics[i].split("/")[0] == lv0 and not topics[i].startswith("$")
+        assert bool(hit3[j]) == (not affected), topics[i]
+    c.close()
+    b.close()
+    eng.close()

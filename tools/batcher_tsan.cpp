@@ -207,6 +207,33 @@ int main(int argc, char** argv) {
                     }
                 }
             });
+        th.emplace_back([&] { // whole multi-tenant batches as launches of their own (bmq_batcher_match_batch), in turn with the collected ones
+            std::mt19937 rng(4242 + pass);
+            for (int it = 0; it < 60; it++) {
+                const uint32_t n = 1 + rng() % 20;
+                std::string tn_bytes = "ttenantBx-long-tenant";
+                const uint32_t tenant_off[4] = {0, 1, 8, 21};
+                std::string bytes;
+                std::vector<uint32_t> off{0}, tt(n);
+                std::vector<std::string> tps(n);
+                for (uint32_t i = 0; i < n; i++) {
+                    tps[i] = "b/" + std::to_string(rng() % 50);
+                    tt[i] = rng() % 3;
+                    bytes += tps[i];
+                    off.push_back((uint32_t)bytes.size());
+                }
+                std::vector<uint32_t> row(n + 1), ids(200);
+                uint64_t need = 0, epoch = 0;
+                const int rc = bmq_batcher_match_batch(b, (const uint8_t*)tn_bytes.data(), tenant_off, 3, tt.data(), (const uint8_t*)bytes.data(), off.data(), n,
+                                                       row.data(), ids.data(), ids.size(), &need, &epoch);
+                EXPECT(rc == BMQ_OK && epoch >= 1);
+                for (uint32_t i = 0; i < n && rc == BMQ_OK; i++) {
+                    const std::string tn = tenants[tt[i]];
+                    EXPECT(row[i + 1] - row[i] == fake_count(tn, tps[i]));
+                    for (uint32_t k = 0; k < row[i + 1] - row[i]; k++) EXPECT(ids[row[i] + k] == fake_id(tn, tps[i], k));
+                }
+            }
+        });
         std::atomic<int> done{0};
         std::vector<std::unique_ptr<CbCtx>> ctxs;
         std::mutex cm;
@@ -234,7 +261,7 @@ int main(int argc, char** argv) {
         mutator.join();
         bmq_batcher_stats st;
         EXPECT(bmq_batcher_stats_get(b, &st) == BMQ_OK && st.n_requests >= 24 * 150);
-        if (cfg.max_batch_topics) EXPECT(st.max_batch_topics <= std::max<uint64_t>(cfg.max_batch_topics, 6));
+        if (cfg.max_batch_topics) EXPECT(st.max_batch_topics <= std::max<uint64_t>(cfg.max_batch_topics, 20)); // a request larger than the bound runs alone; bmq_batcher_match_batch launches are not collected at all
         bmq_batcher_destroy(b); // drains the asynchronous side: every submitted request has been called back when it returns
         EXPECT(done.load() == submitted.load() && submitted.load() == 1600);
     }

@@ -30,7 +30,7 @@ struct bmq_engine {
     uint64_t epoch = 1, generation = 1;
     std::vector<std::map<std::string, uint32_t>> history{{}, {}}; // history[epoch] = model at that epoch
     std::atomic<int> match_delay_us{0};
-    std::atomic<uint64_t> n_match{0};
+    std::atomic<uint64_t> n_match{0}, n_launch{0};
 };
 struct bmq_batcher { // blocking side: matches inline; asynchronous side: a dispatcher thread, as the real front has
     bmq_engine* e;
@@ -85,6 +85,34 @@ int bmq_batcher_match_all(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant
     *out_needed = ids.size();
     if (ids.size() > out_capacity) return BMQ_E_NOSPACE;
     for (size_t i = 0; i < ids.size(); i++) out_route_ids[i] = ids[i];
+    return BMQ_OK;
+}
+int bmq_batcher_match_batch(bmq_batcher* b, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                            const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, uint32_t* out_row_ptr, uint32_t* out_route_ids,
+                            uint64_t out_capacity, uint64_t* out_needed, uint64_t* out_epoch) {
+    std::vector<std::vector<uint32_t>> rows(n_topics);
+    {
+        std::lock_guard<std::mutex> g(b->e->mu); // one launch: one epoch
+        for (uint32_t i = 0; i < n_topics; i++) {
+            if (topic_tenant[i] >= n_tenants) return BMQ_E_INVAL;
+            rows[i] = brute(b->e->model, std::string_view((const char*)tenants + tenant_off[topic_tenant[i]], tenant_off[topic_tenant[i] + 1] - tenant_off[topic_tenant[i]]),
+                            std::string_view((const char*)topics + topic_off[i], topic_off[i + 1] - topic_off[i]));
+        }
+        *out_epoch = b->e->epoch;
+    }
+    b->e->n_match += n_topics;
+    b->e->n_launch++;
+    if (const int d = b->e->match_delay_us.load()) std::this_thread::sleep_for(std::chrono::microseconds(d));
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_topics; i++) {
+        out_row_ptr[i] = (uint32_t)total;
+        total += rows[i].size();
+    }
+    out_row_ptr[n_topics] = (uint32_t)total;
+    *out_needed = total;
+    if (total > out_capacity) return BMQ_E_NOSPACE;
+    for (uint32_t i = 0; i < n_topics; i++)
+        for (size_t k = 0; k < rows[i].size(); k++) out_route_ids[out_row_ptr[i] + k] = rows[i][k];
     return BMQ_OK;
 }
 int bmq_batcher_submit(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, bmq_batcher_cb cb, void* user) {
@@ -318,6 +346,36 @@ static void test_behaviour() {
     EXPECT(cache_get(c, "t", "a/b", 2900, ids, ep, 16) && e.n_match == loads + 1); // 1050 ms: expired, reloaded
     bmq_route_cache_stats_get(c, &st);
     EXPECT(st.expired == 1);
+    { // a whole BatchDistRequest in one call: hits from the cache, all misses (identical ones once) in ONE launch
+        const std::string tn_bytes = "tu";
+        const uint32_t tenant_off[3] = {0, 1, 2};
+        const std::vector<std::string> tps = {"a/b", "a/zz", "a/zz", "zz", "a/zz", "q"};
+        const uint32_t tt[6] = {0, 0, 0, 1, 1, 0}; // "a/zz" twice for t and once for u: two launch rows
+        std::string bytes;
+        std::vector<uint32_t> off{0};
+        for (auto& t : tps) {
+            bytes += t;
+            off.push_back((uint32_t)bytes.size());
+        }
+        bytes.append(16, '\0');
+        uint32_t row[7];
+        uint8_t hit[6];
+        std::vector<uint32_t> out(2);
+        uint64_t need = 0;
+        const uint64_t launches = e.n_launch, matched = e.n_match;
+        int rc = bmq_route_cache_get_batch(c, (const uint8_t*)tn_bytes.data(), tenant_off, 2, tt, (const uint8_t*)bytes.data(), off.data(), 6, 2950, row, out.data(),
+                                           out.size(), &need, hit);
+        EXPECT(rc == BMQ_E_NOSPACE && need == 6 + 5 + 5 + 1 + 1 + 0 && e.n_launch == launches + 1 && e.n_match == matched + 4); // 4 distinct misses
+        out.resize(need);
+        rc = bmq_route_cache_get_batch(c, (const uint8_t*)tn_bytes.data(), tenant_off, 2, tt, (const uint8_t*)bytes.data(), off.data(), 6, 2960, row, out.data(),
+                                       out.size(), &need, hit);
+        EXPECT(rc == BMQ_OK && e.n_launch == launches + 1); // everything was cached by the first call
+        for (int i = 0; i < 6; i++) {
+            EXPECT(hit[i] == 1);
+            const std::vector<uint32_t> got(out.begin() + row[i], out.begin() + row[i + 1]);
+            EXPECT(got == brute(e.model, tt[i] ? "u" : "t", tps[i]));
+        }
+    }
     // rebuild: ids renumbered, nothing of the old generation survives
     Packed nb;
     nb.add(key_of("t", "a/b", 100), 0);
@@ -414,6 +472,49 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
                 if (n_async.load() - n_async_cb.load() > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100)); // bounded backlog
             }
         });
+    th.emplace_back([&]() { // and one asks for whole batches
+        std::mt19937_64 r(seed * 91);
+        std::string tn_bytes;
+        std::vector<uint32_t> tenant_off{0};
+        for (auto& t : tenants) {
+            tn_bytes += t;
+            tenant_off.push_back((uint32_t)tn_bytes.size());
+        }
+        while (!stop) {
+            const uint32_t n = 1 + (uint32_t)(r() % 24);
+            std::string bytes;
+            std::vector<uint32_t> off{0}, tt(n);
+            std::vector<std::string> tps(n);
+            for (uint32_t i = 0; i < n; i++) {
+                tps[i] = topic_of(r);
+                tt[i] = (uint32_t)(r() % tenants.size());
+                bytes += tps[i];
+                off.push_back((uint32_t)bytes.size());
+            }
+            bytes.append(16, '\0');
+            std::vector<uint32_t> row(n + 1), out(256);
+            uint64_t need = 0;
+            int rc;
+            while ((rc = bmq_route_cache_get_batch(c, (const uint8_t*)tn_bytes.data(), tenant_off.data(), (uint32_t)tenants.size(), tt.data(),
+                                                   (const uint8_t*)bytes.data(), off.data(), n, 1000, row.data(), out.data(), out.size(), &need, nullptr)) ==
+                   BMQ_E_NOSPACE)
+                out.resize(need + 16);
+            EXPECT(rc == BMQ_OK);
+            // rows of one call may come from different epochs (hits) -- each must be the truth of SOME epoch up to now
+            std::vector<std::map<std::string, uint32_t>> hist;
+            {
+                std::lock_guard<std::mutex> g(e.mu);
+                hist = e.history;
+            }
+            for (uint32_t i = 0; i < n && rc == BMQ_OK; i++) {
+                const std::vector<uint32_t> got(out.begin() + row[i], out.begin() + row[i + 1]);
+                bool ok = false;
+                for (size_t ep = hist.size(); ep-- > 1 && !ok;) ok = got == brute(hist[ep], tenants[tt[i]], tps[i]);
+                EXPECT(ok);
+            }
+            n_get += n;
+        }
+    });
     std::thread mut([&]() {
         std::mt19937_64 r(seed * 31 + 5);
         std::vector<std::string> live;
