@@ -645,15 +645,18 @@ class RouteCache:
         tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
         row, hit = np.zeros(n + 1, dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint8)
         cap, need = max(256, 8 * n), C.c_uint64()
+        first_hit = None
         while True:
             ids = np.zeros(cap, dtype=np.uint32)
             rc = _lib.lib().bmq_route_cache_get_batch(self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(tt), _ptr(pdata), _ptr(poff), n, now_ms,
                                                       _ptr(row), _ptr(ids), cap, C.byref(need), _ptr(hit))
+            if first_hit is None:  # a call that ran out of room has loaded (and cached) its misses already: the retry would call them hits
+                first_hit = hit[:n].astype(bool)
             if rc == -3 and need.value > cap:
                 cap = int(need.value)
                 continue
             self._check(rc, "bmq_route_cache_get_batch")
-            return row, ids[:need.value], hit[:n].astype(bool)
+            return row, ids[:need.value], first_hit
 
     CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64)
 
