@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
     "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get",
     "bmq_route_cache_create", "bmq_route_cache_destroy", "bmq_route_cache_get", "bmq_route_cache_get_async", "bmq_route_cache_get_batch", "bmq_batcher_match_batch", "bmq_route_cache_is_cached", "bmq_route_cache_apply",
-    "bmq_route_cache_rebuild", "bmq_route_cache_reset", "bmq_route_cache_stats_get", "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
+    "bmq_route_cache_rebuild", "bmq_route_cache_reset", "bmq_route_cache_expire", "bmq_route_cache_stats_get", "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
 ]
 
 
@@ -153,6 +153,7 @@ def lib() -> C.CDLL:
             "bmq_route_cache_apply": (C.c_int, [vp, vp, vp, vp, u32]),
             "bmq_route_cache_rebuild": (C.c_int, [vp, vp, vp, u32]),
             "bmq_route_cache_reset": (C.c_int, [vp]),
+            "bmq_route_cache_expire": (C.c_int, [vp, u64, P(u64)]),
             "bmq_route_cache_stats_get": (C.c_int, [vp, P(RouteCacheStats)]),
             "bmq_fanout_group": (C.c_int, [vp, vp, vp, u32, vp, vp, u64, vp, vp, u32, P(u32), P(u32)]),
             "bmq_fanout_group_dev": (C.c_int, [vp, vp, vp, u32, u64, vp, vp, vp, vp, u32, P(u32), P(u32)]),

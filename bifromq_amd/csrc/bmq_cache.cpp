@@ -673,6 +673,27 @@ int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint3
     return rc;
 }
 
+int bmq_route_cache_expire(bmq_route_cache* c, uint64_t now_ms, uint64_t* out_dropped) {
+    if (!c) return BMQ_E_INVAL;
+    uint64_t dropped = 0;
+    c->for_each_tenant([&](TenantCache& t) {
+        for (uint32_t s = 0; s < c->n_shards; s++) {
+            Shard& sh = t.shards[s];
+            SpinGuard g(sh.mu);
+            // the LRU order is the order of last access: the idle entries are at the back, the first live one ends the sweep
+            while (!sh.lru.empty()) {
+                Entry* en = sh.lru.back();
+                if (!(now_ms >= en->last_access_ms && now_ms - en->last_access_ms >= c->expiry_ms)) break;
+                sh.expired++;
+                sh.drop(en);
+                dropped++;
+            }
+        }
+    });
+    if (out_dropped) *out_dropped = dropped;
+    return BMQ_OK;
+}
+
 int bmq_route_cache_stats_get(bmq_route_cache* c, bmq_route_cache_stats* out) {
     if (!c || !out) return BMQ_E_INVAL;
     memset(out, 0, sizeof(*out));

@@ -701,6 +701,12 @@ class RouteCache:
     def reset(self):
         self._check(_lib.lib().bmq_route_cache_reset(self.h), "bmq_route_cache_reset")
 
+    def expire(self, now_ms: int) -> int:
+        """drop every entry not accessed for expiry_ms -> number dropped"""
+        n = C.c_uint64()
+        self._check(_lib.lib().bmq_route_cache_expire(self.h, now_ms, C.byref(n)), "bmq_route_cache_expire")
+        return int(n.value)
+
     def stats(self) -> "_lib.RouteCacheStats":
         st = _lib.RouteCacheStats()
         self._check(_lib.lib().bmq_route_cache_stats_get(self.h, C.byref(st)), "bmq_route_cache_stats_get")

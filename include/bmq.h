@@ -305,6 +305,10 @@ int bmq_route_cache_is_cached(bmq_route_cache* c, const uint8_t* tenant, uint32_
 int bmq_route_cache_apply(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
 int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint32_t* key_off, uint32_t n_keys);
 int bmq_route_cache_reset(bmq_route_cache* c);
+/* Caffeine expires idle entries from a scheduler thread (TenantRouteCache.java:104-114: expireAfterAccess + Scheduler.systemScheduler());
+ * here get() drops an expired entry when it meets one and this sweep -- to be called now and then by the owner -- drops the rest: every entry
+ * not accessed for expiry_ms at now_ms.  *out_dropped (may be NULL) = entries dropped. */
+int bmq_route_cache_expire(bmq_route_cache* c, uint64_t now_ms, uint64_t* out_dropped);
 int bmq_route_cache_stats_get(bmq_route_cache* c, bmq_route_cache_stats* out);
 
 /* ---- host-side mirror of MatchedRoutes (fan-out caps in KV order) -------------------------------------- */

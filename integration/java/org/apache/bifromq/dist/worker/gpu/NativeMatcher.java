@@ -130,4 +130,7 @@ final class NativeMatcher {
     static native void routeCacheRebuild(long cache, ByteBuffer keys, IntBuffer keyOff, int n);
 
     static native void routeCacheReset(long cache);
+
+    /** Drops the entries idle for expiryMs (what Caffeine's scheduler thread does); call it from a timer. @return entries dropped */
+    static native long routeCacheExpire(long cache, long nowMs);
 }

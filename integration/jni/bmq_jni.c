@@ -438,3 +438,10 @@ JNIEXPORT jlong JNICALL NM(routeCacheGetBatch)(JNIEnv* env, jclass c, jlong h, j
                                              (uint8_t*)ADDR(outHit));
     return result_of(env, NULL, "bmq_route_cache_get_batch", rc, need);
 }
+/* long routeCacheExpire(long cache, long nowMs)      the sweep Caffeine's scheduler does: -> entries dropped */
+JNIEXPORT jlong JNICALL NM(routeCacheExpire)(JNIEnv* env, jclass c, jlong h, jlong nowMs) {
+    (void)env, (void)c;
+    uint64_t n = 0;
+    (void)bmq_route_cache_expire(CACHE(h), (uint64_t)nowMs, &n);
+    return (jlong)n;
+}

@@ -376,6 +376,15 @@ static void test_behaviour() {
             EXPECT(got == brute(e.model, tt[i] ? "u" : "t", tps[i]));
         }
     }
+    { // the sweep: everything idle for a second goes, what was touched since stays
+        uint64_t dropped = 0;
+        bmq_route_cache_stats_get(c, &st);
+        const uint64_t before = st.entries;
+        EXPECT(cache_get(c, "t", "a/d", 3500, ids, ep, 16)); // touch (or load) a/d at 3500
+        EXPECT(bmq_route_cache_expire(c, 4100, &dropped) == BMQ_OK); // idle since 2960 or earlier: more than a second
+        bmq_route_cache_stats_get(c, &st);
+        EXPECT(dropped >= 1 && st.entries + dropped >= before && is_cached(c, "t", "a/d") == 1 && is_cached(c, "t", "a/b") == 0); // a/b idle since 2960
+    }
     // rebuild: ids renumbered, nothing of the old generation survives
     Packed nb;
     nb.add(key_of("t", "a/b", 100), 0);
