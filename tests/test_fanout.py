@@ -132,6 +132,35 @@ def test_host_engine_after_churn_and_dead_ids():
     eng.close()
 
 
+def test_reference_delivery_cases():
+    """The delivery side of the reference's own end-to-end tests as known answers for the grouping (oracle restatement AND engine):
+    DWT/DistQoS0Test.java:95-150 (testDistCase2: three routes, two deliverers -- writer1 = (MqttBroker, "batch1") receives 2 MatchInfos,
+    writer2 = (InboxService, "batch2") receives 1) and :152-193 (testDistCase3: two inboxes behind ONE deliverer key -> one delivery
+    request carrying both MatchInfos for the one topic)."""
+    MQTT_BROKER, INBOX_SERVICE = 0, 1  # DWT/DistWorkerTest.java:130-131
+    tenant = "tenantA"
+    keys = sorted([O.route_key_from_mqtt(tenant, "/你好/hello/😄", O.receiver_url(MQTT_BROKER, "inbox1", "batch1")),
+                   O.route_key_from_mqtt(tenant, "/#", O.receiver_url(MQTT_BROKER, "inbox1", "batch1")),
+                   O.route_key_from_mqtt(tenant, "/#", O.receiver_url(INBOX_SERVICE, "inbox2", "batch2")),
+                   O.route_key_from_mqtt(tenant, "/a/b/c", O.receiver_url(MQTT_BROKER, "inbox1", "batch1")),
+                   O.route_key_from_mqtt(tenant, "/a/b/c", O.receiver_url(MQTT_BROKER, "inbox2", "batch1"))])
+    eng = B.Engine(device=-1).rebuild(keys)
+    kv = O.KV(keys)
+    # case 2: fan-out 3 (DistQoS0Test.java:103-104), 2 + 1 by deliverer
+    rows = U.semantic_rows(kv, [tenant], np.zeros(1, dtype=np.uint32), ["/你好/hello/😄"])
+    assert len(rows[0]) == 3
+    groups, shared, dead = O.fanout_groups(lambda i: keys[i], rows)
+    assert {k: len(v) for k, v in groups.items()} == {(MQTT_BROKER, "batch1"): 2, (INBOX_SERVICE, "batch2"): 1} and not shared and not dead
+    assert _check(eng, rows, lambda i: keys[i], eng.fanout_group(*_csr(rows))) == 2
+    # case 3: both inboxes of /a/b/c (and the MqttBroker '/#' route) sit behind (MqttBroker, "batch1"): ONE group carries them for the topic
+    rows = U.semantic_rows(kv, [tenant], np.zeros(1, dtype=np.uint32), ["/a/b/c"])
+    groups, shared, dead = O.fanout_groups(lambda i: keys[i], rows)
+    inboxes = {O.parse_route_key(keys[r])[3].split("\0")[1] for (_, r) in groups[(MQTT_BROKER, "batch1")] if O.parse_route_key(keys[r])[2] == "/a/b/c"}
+    assert inboxes == {"inbox1", "inbox2"}
+    assert _check(eng, rows, lambda i: keys[i], eng.fanout_group(*_csr(rows))) == 2  # (MqttBroker, batch1) and the InboxService '/#' route
+    eng.close()
+
+
 def test_argument_checks():
     eng = B.Engine(device=-1)
     with pytest.raises(B.BmqError):  # no index yet
