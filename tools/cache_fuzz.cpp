@@ -2,7 +2,8 @@
 // ThreadSanitizer, without a GPU.  The engine and the batching front behind the cache are replaced by a stand-in that matches by brute
 // force over a std::map model and counts epochs exactly as the engine does, so that every answer can be checked:
 //   1. TopicIndex against the reference's golden table (DWT/TopicIndexTest.java:41-73) and against the matching rule on random input;
-//   2. single-threaded cache behaviour: miss -> hit, isCached, invalidation by a matching mutation only, weight-bounded LRU eviction,
+//   2. the reference's own cache scenarios (DWT/cache/TenantRouteCacheTest.java: load + index on first access, reuse without reload, Add /
+//      RemoveRoutes tasks, a task overtaking a load, weight bound with empty rows, index clean-up on expiry) and more single-threaded behaviour: miss -> hit, isCached, invalidation by a matching mutation only, weight-bounded LRU eviction,
 //      expire-after-access, rebuild;
 //   3. getter threads against a mutator thread: every answer equals the brute force at the epoch it reports, and once everything has
 //      settled no cached entry differs from the brute force on the final model (a load overtaken by a mutation must not be cached).
@@ -31,6 +32,8 @@ struct bmq_engine {
     std::vector<std::map<std::string, uint32_t>> history{{}, {}}; // history[epoch] = model at that epoch
     std::atomic<int> match_delay_us{0};
     std::atomic<uint64_t> n_match{0}, n_launch{0};
+    std::atomic<bool> hold_loads{false}; // a load that has read the model waits here until released (TenantRouteCacheTest.java:257-292)
+    std::atomic<int> loads_waiting{0};
 };
 struct bmq_batcher { // blocking side: matches inline; asynchronous side: a dispatcher thread, as the real front has
     bmq_engine* e;
@@ -80,6 +83,11 @@ int bmq_batcher_match_all(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant
     }
     b->e->n_match++;
     if (const int d = b->e->match_delay_us.load()) std::this_thread::sleep_for(std::chrono::microseconds(d)); // the answer travels a while
+    if (b->e->hold_loads.load()) {
+        b->e->loads_waiting++;
+        while (b->e->hold_loads.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        b->e->loads_waiting--;
+    }
     out_row_ptr[0] = 0;
     out_row_ptr[1] = (uint32_t)ids.size();
     *out_needed = ids.size();
@@ -397,6 +405,100 @@ static void test_behaviour() {
     bmq_route_cache_destroy(c);
 }
 
+// ---- 2b. the reference's own TenantRouteCacheTest scenarios (DWT/cache/TenantRouteCacheTest.java), on route ids ------------------------
+static std::string group_key(const std::string& tenant, const std::string& filter, const std::string& group) { return bmq::encode_route_key(tenant, filter, 2, group); }
+static void test_reference_cases() {
+    const std::string TENANT = "tenantA", TOPIC = "sensor/temperature"; // :76-77
+    auto apply = [](bmq_route_cache* c, const std::vector<std::pair<std::string, uint8_t>>& ops) {
+        Packed p;
+        for (auto& o : ops) p.add(o.first, o.second);
+        EXPECT(bmq_route_cache_apply(c, p.bytes.data(), p.off.data(), p.op.data(), (uint32_t)p.op.size()) == BMQ_OK);
+    };
+    auto has = [](const std::vector<uint32_t>& ids, uint32_t id) { return std::find(ids.begin(), ids.end(), id) != ids.end(); };
+    std::vector<uint32_t> ids;
+    uint64_t ep = 0;
+    { // shouldLoadAndIndexRoutesOnFirstAccess :110-125, shouldReuseCachedValueWithoutReload :127-143
+        bmq_engine e;
+        bmq_batcher b(&e);
+        bmq_route_cache* c = nullptr;
+        EXPECT(bmq_route_cache_create(&e, &b, nullptr, &c) == BMQ_OK);
+        const std::string existing = key_of(TENANT, TOPIC, 1);
+        apply(c, {{existing, 0}});
+        EXPECT(is_cached(c, TENANT, TOPIC) == 0);
+        EXPECT(cache_get(c, TENANT, TOPIC, 1, ids, ep, 16) && ids == std::vector<uint32_t>{e.model[existing]} && e.n_match == 1);
+        EXPECT(is_cached(c, TENANT, TOPIC) == 1);
+        EXPECT(cache_get(c, TENANT, TOPIC, 2, ids, ep, 16) && ids == std::vector<uint32_t>{e.model[existing]} && e.n_match == 1); // matcher called once
+        // shouldApplyAddRoutesTask :187-214: a normal route on the topic and a group route on "sensor/#" show up in the cached topic
+        const std::string new_normal = key_of(TENANT, TOPIC, 2), new_group = group_key(TENANT, "sensor/#", "groupA");
+        apply(c, {{new_normal, 0}, {new_group, 0}});
+        EXPECT(cache_get(c, TENANT, TOPIC, 3, ids, ep, 16) && ids.size() == 3 && has(ids, e.model[new_normal]) && has(ids, e.model[new_group]));
+        // shouldApplyRemoveRoutesTask :216-254: the normal route and the emptied group go, a group that only lost a member stays (its key
+        // -- hence its id -- is untouched: the membership lives in the value)
+        const std::string updatable = group_key(TENANT, "sensor/+", "groupUpdate");
+        apply(c, {{updatable, 0}});
+        EXPECT(cache_get(c, TENANT, TOPIC, 4, ids, ep, 16) && ids.size() == 4);
+        const uint32_t id_updatable = e.model[updatable], id_existing = e.model[existing];
+        apply(c, {{existing, 1}, {new_group, 1}});
+        EXPECT(cache_get(c, TENANT, TOPIC, 5, ids, ep, 16) && ids.size() == 2 && !has(ids, id_existing) && has(ids, id_updatable) && has(ids, e.model[new_normal]));
+        bmq_route_cache_destroy(c);
+    }
+    { // shouldQueueTasksUntilLoadCompletes :256-292: an AddRoutes task arrives while the load of the topic is still running
+        bmq_engine e;
+        bmq_batcher b(&e);
+        bmq_route_cache* c = nullptr;
+        EXPECT(bmq_route_cache_create(&e, &b, nullptr, &c) == BMQ_OK);
+        const std::string existing = key_of(TENANT, TOPIC, 1), new_normal = key_of(TENANT, TOPIC, 2);
+        apply(c, {{existing, 0}});
+        e.hold_loads = true;
+        std::vector<uint32_t> first;
+        std::thread loader([&] {
+            uint64_t ep2 = 0;
+            EXPECT(cache_get(c, TENANT, TOPIC, 1, first, ep2, 16));
+        });
+        while (e.loads_waiting.load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(50)); // loadStarted
+        apply(c, {{new_normal, 0}});                                                                     // refresh(AddRoutesTask) meanwhile
+        e.hold_loads = false;                                                                            // allowLoad
+        loader.join();
+        EXPECT(first == std::vector<uint32_t>{e.model[existing]}); // the future completes with what the load saw
+        EXPECT(cache_get(c, TENANT, TOPIC, 2, ids, ep, 16) && ids.size() == 2 && has(ids, e.model[new_normal])); // ... and the next get sees the addition
+        bmq_route_cache_stats st{};
+        bmq_route_cache_stats_get(c, &st);
+        EXPECT(st.stale_loads == 1); // the overtaken load was not cached
+        bmq_route_cache_destroy(c);
+    }
+    { // shouldBoundZeroRouteTopicsByMaxWeight :359-417: 100 topics without routes, max weight 10 -> at most 12 cached / indexed
+        bmq_engine e;
+        bmq_batcher b(&e);
+        bmq_route_cache_config cfg{};
+        cfg.struct_size = sizeof(cfg);
+        cfg.max_routes_per_tenant = 10;
+        cfg.shards_per_tenant = 1;
+        bmq_route_cache* c = nullptr;
+        EXPECT(bmq_route_cache_create(&e, &b, &cfg, &c) == BMQ_OK);
+        for (int i = 0; i < 100; i++) EXPECT(cache_get(c, TENANT, "sensor/t" + std::to_string(i), 1, ids, ep, 16) && ids.empty());
+        bmq_route_cache_stats st{};
+        bmq_route_cache_stats_get(c, &st);
+        EXPECT(st.entries <= 12 && st.entries >= 1 && st.cached_routes <= 12 && st.evictions >= 88);
+        int indexed = 0;
+        for (int i = 0; i < 100; i++) indexed += is_cached(c, TENANT, "sensor/t" + std::to_string(i));
+        EXPECT(indexed == (int)st.entries && is_cached(c, TENANT, "#") == 1); // the index is bounded along with the cache
+        bmq_route_cache_destroy(c);
+    }
+    { // shouldCleanupIndexOnExpiryAndExplicitInvalidation :419-470 (EXPIRY = 1 minute :78)
+        bmq_engine e;
+        bmq_batcher b(&e);
+        bmq_route_cache* c = nullptr;
+        EXPECT(bmq_route_cache_create(&e, &b, nullptr, &c) == BMQ_OK);
+        apply(c, {{key_of(TENANT, TOPIC, 1), 0}});
+        EXPECT(cache_get(c, TENANT, TOPIC, 0, ids, ep, 16) && ids.size() == 1 && is_cached(c, TENANT, TOPIC) == 1);
+        uint64_t dropped = 0;
+        EXPECT(bmq_route_cache_expire(c, 60001, &dropped) == BMQ_OK && dropped == 1 && is_cached(c, TENANT, TOPIC) == 0); // ticker.advance(EXPIRY + 1 ms); cleanUp()
+        EXPECT(cache_get(c, TENANT, TOPIC, 60002, ids, ep, 16) && is_cached(c, TENANT, TOPIC) == 1 && e.n_match == 2);    // loaded again
+        EXPECT(bmq_route_cache_reset(c) == BMQ_OK && is_cached(c, TENANT, TOPIC) == 0);                                   // explicit invalidation
+        bmq_route_cache_destroy(c);
+    }
+}
+
 // ---- 3. getters against a mutator ---------------------------------------------------------------------------------------------------
 static void test_concurrent(uint64_t seed, int n_threads, int ms) {
     bmq_engine e;
@@ -635,6 +737,7 @@ int main(int argc, char** argv) {
     const int ms = argc > 3 ? atoi(argv[3]) : 1500;
     test_topic_index(seed);
     test_behaviour();
+    test_reference_cases();
     test_concurrent(seed, threads, ms);
     if (g_fail) {
         fprintf(stderr, "cache_fuzz FAILED: %d\n", g_fail);
