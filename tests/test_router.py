@@ -195,3 +195,33 @@ def test_router_under_sanitizers():
     for seed in ("1", "7"):
         r = subprocess.run([os.path.join(root, "tools", "router_fuzz"), seed, "500"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "router_fuzz ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_boundary_util_vectors():
+    """base-kv/base-kv-type-proto/src/test/java/org/apache/bifromq/basekv/utils/BoundaryUtilTest.java: findUpperBound (:148-169) and the
+    compare* cases (:396-525) -- for the oracle's restatement, and for the product through the order it accepts a router in (it takes the
+    boundaries of a TreeMap ordered by BoundaryUtil.compare: strictly ascending or BMQ_E_INVAL)."""
+    ub = O.boundary_upper_bound
+    assert ub(b"") is None  # MIN_KEY
+    assert ub(bytes([1, 2, 3])) == bytes([1, 2, 4])
+    assert ub(bytes([1, 2, 0xFF])) == bytes([1, 3])
+    assert ub(bytes([1, 0xFF, 0xFF])) == bytes([2])
+    assert ub(bytes([0xFF, 0xFF, 0xFF])) is None
+    for k in (b"", bytes([1, 2, 3]), bytes([1, 2, 0xFF]), bytes([0xFF] * 3)):
+        assert O.boundary_compare_end(k, ub(k)) < 0
+    assert O.boundary_compare_start(None, None) == 0 and O.boundary_compare_start(None, b"a") == -1
+    assert O.boundary_compare_start(b"a", None) == 1 and O.boundary_compare_start(b"a", b"b") == -1
+    assert O.boundary_compare_end(None, None) == 0 and O.boundary_compare_end(None, b"a") == 1
+    assert O.boundary_compare_end(b"a", None) == -1 and O.boundary_compare_end(b"a", b"b") == -1
+    cases = [((b"a", b"c"), (b"a", b"c"), 0), ((b"a", b"c"), (b"b", b"c"), -1), ((b"a", b"b"), (b"a", b"c"), -1),
+             ((b"a", None), (b"a", b"c"), 1), ((None, None), (b"a", b"b"), -1), ((b"a", None), (b"a", b"b"), 1)]
+    for b1, b2, want in cases:
+        assert O.boundary_compare(b1, b2) == want, (b1, b2)
+
+        def accepted(order):
+            try:
+                RangeRouter(order).find_by_key(b"zz")
+                return True
+            except BmqError:
+                return False
+        assert accepted([b1, b2]) == (want < 0) and accepted([b2, b1]) == (want > 0), (b1, b2)
