@@ -115,6 +115,59 @@ print("range_shim ok" if not bad else "range_shim FAILED %%d" %% bad)
     return subprocess.run(["python3", "-c", code], capture_output=True, text=True, timeout=900, env=env)
 
 
+# bifromq-dist/bifromq-dist-server/src/test/java/org/apache/bifromq/dist/server/scheduler/TenantRangeLookupCacheTest.java:106-330:
+# (topic, candidates in boundary order, indices of the candidates lookup() returns).  None = no Fact, () = Fact without first / last.
+_T = "tenantA"
+REFERENCE_LOOKUP_CASES = [
+    ("singleCandidateFullFactCovers :114-125", "m/n", [([_T, "a"], [_T, "z"])], [0]),
+    ("singleCandidateFullFactNotCover :127-137", "a/b", [([_T, "m"], [_T, "z"])], []),
+    ("singleCandidateMissingFirstOrLastIsEmptyRange :139-157", "a", [()], []),
+    ("singleCandidateNoFactIsIncluded :159-169", "topic", [None], [0]),
+    ("multiCandidatesTwoCoveringAndOneNot :171-195", "n/1", [([_T, "a"], [_T, "z"]), ([_T, "n"], [_T, "s"]), ([_T, "t"], [_T, "z"])], [0, 1]),
+    ("multiCandidatesMixWithNoFact :197-220", "z/1", [None, ([_T, "x"], [_T, "z"]), ([_T, "z"], [_T, "zz"])], [0, 2]),
+    ("multiCandidatesLastLessThanTopicThenFollowingCovers :222-238", "n/1", [([_T, "a"], [_T, "m"]), ([_T, "n"], [_T, "z"])], [1]),
+    ("earlyStopTopicLessThanFirstOfFirstCandidate :240-255", "a", [([_T, "b"], [_T, "c"]), None], []),
+    ("earlyStopAfterIncludingNoFactFirst :257-273", "a", [None, ([_T, "b"], [_T, "c"])], [0]),
+    ("includeWhenEqualToFirstOrLast :275-288 (first)", "b", [([_T, "b"], [_T, "z"])], [0]),
+    ("includeWhenEqualToFirstOrLast :275-288 (last)", "b", [([_T, "a"], [_T, "b"])], [0]),
+    ("multiLevelTopicAndOrder :290-309", "a/b/c", [([_T, "a", "b"], [_T, "a", "z"]), ([_T, "b"], [_T, "c"])], [0]),
+    ("cacheFunctionalConsistency :311-330 (a)", "n/1", [([_T, "a"], [_T, "m"]), ([_T, "n"], [_T, "z"])], [1]),
+    ("cacheFunctionalConsistency :311-330 (b)", "n/1", [([_T, "x"], [_T, "z"])], []),
+]
+
+
+def test_reference_lookup_cases_oracle_and_core(shim):
+    """The reference's own TenantRangeLookupCacheTest as known answers: the oracle restatement (structural expansion iterator) and the
+    function the GPU kernel runs (bmq_range_core.h, host build under ASan) both return exactly the ranges the test expects."""
+    for name, topic, cands, want in REFERENCE_LOOKUP_CASES:
+        assert O.range_lookup(_T, topic, cands) == want, name
+    code = r'''
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_range import REFERENCE_LOOKUP_CASES, cand_arrays
+L = C.CDLL(%r)
+bad = 0
+for name, topic, cands, want in REFERENCE_LOOKUP_CASES:
+    kind, fd, fo, ld, lo = cand_arrays(cands)
+    tb, tp = b"tenantA", topic.encode()
+    toff = np.array([0, len(tp)], dtype=np.uint32)
+    tdata = np.frombuffer(tp + b"\0" * 32, dtype=np.uint8).copy()
+    keep = np.zeros(len(cands), dtype=np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.range_lookup_host(tb, len(tb), p(tdata), p(toff), 1, p(kind), p(fd), p(fo), p(ld), p(lo), len(cands), p(keep))
+    got = [c for c in range(len(cands)) if keep[c]]
+    if got != want:
+        bad += 1
+        print("MISMATCH", name, got, want)
+print("reference cases ok" if not bad else "reference cases FAILED")
+''' % (ROOT, shim)
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    env["ASAN_OPTIONS"] = "detect_leaks=0"
+    r = subprocess.run(["python3", "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "reference cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_range_core_matches_the_expansion_iterator(shim, seed):
     r = _run_shim(shim, seed, 250)
