@@ -508,3 +508,46 @@ def test_route_cache_patch_equals_rematch():
             for t, got in model.cached.items():
                 want = {ks[r] for r in kv.match_bruteforce(tenant, [t]).per_topic()[0]}
                 assert got == want, (trial, step, t)
+
+
+def test_retain_match_test_vectors():
+    """bifromq-retain/bifromq-retain-store/src/test/java/org/apache/bifromq/retain/store/RetainMatchTest.java:38-122 (wildcardTopicFilter:
+    four retained topics, 17 filters) and :124-135 (matchLimit: limit 0 -> nothing, limit 1 -> one message) against the oracle's
+    RetainTopicIndex restatement and its RetainStoreCoProc.match(limit, now)."""
+    tenant = "tenantA"
+    topics = ["/a/b/c", "/a/b/", "/c/", "a"]  # message1 .. message4
+    lt = O.LevelTrie(1)
+    for i, t in enumerate(topics):
+        lt.add(tenant, t, i)
+    table = [("#", [0, 1, 2, 3]), ("+", [3]), ("+/#", [0, 1, 2, 3]), ("+/+/#", [0, 1, 2]), ("+/+/+", [2]), ("/#", [0, 1, 2]), ("/c/#", [2]),
+             ("/a/+", []), ("/a/#", [0, 1]), ("/a/+/+", [0, 1]), ("/a/+/#", [0, 1]), ("/+/b/", [1]), ("/+/b/#", [0, 1]), ("/a/b/c/#", [0]),
+             ("/a/b/#", [0, 1])]
+    for f, want in table:
+        assert sorted(lt.match(tenant, f)) == want, f
+        assert sorted(i for i, t in enumerate(topics) if O.semantic_match(t, f)) == want, f  # '$' rule aside, the same rule as the dist side
+        assert O.retain_store_match(lt, tenant, f, 10, 0, lambda i: 1 << 62) == want, f  # limit 10: everything, ascending ids
+    never = lambda i: 1 << 62
+    lt3 = O.LevelTrie(1)
+    for i, t in enumerate(topics[:3]):
+        lt3.add(tenant, t, i)
+    assert O.retain_store_match(lt3, tenant, "#", 0, 0, never) == []       # :133
+    assert len(O.retain_store_match(lt3, tenant, "#", 1, 0, never)) == 1   # :134
+    assert lt.match("otherTenant", "#") == []
+
+
+def test_retain_gc_test_vectors():
+    """bifromq-retain/bifromq-retain-store/src/test/java/org/apache/bifromq/retain/store/GCTest.java:44-57 (a message with timestamp 0 and
+    expiry 1 s is matched at now = 0 and gone at now = 1100 ms) and :76-84 (GC at 1100 ms with expirySeconds overridden to 1: "/a" stamped
+    0 expires, "/b" stamped 1000 ms << 16 stays) against the oracle's expireAt arithmetic (RetainStoreCoProc.java:298-304)."""
+    tenant = "tenantA"
+    lt = O.LevelTrie(1)
+    lt.add(tenant, "/a", 0)
+    exp = {0: O.retain_expire_at(0, 1)}
+    assert exp[0] == 1000
+    assert O.retain_store_match(lt, tenant, "/a", 1, 0, exp.__getitem__) == [0]     # :52
+    assert O.retain_store_match(lt, tenant, "/a", 1, 1100, exp.__getitem__) == []   # :56
+    # gcTenantWithExpirySeconds: the override replaces the stored expiry interval
+    stamps = {"/a": (0, 2), "/b": (1000 << 16, 3)}
+    expired = sorted(t for t, (ts, _ex) in stamps.items() if O.retain_expire_at(ts, 1) <= 1100)
+    assert expired == ["/a"]
+    assert sorted(t for t, (ts, ex) in stamps.items() if O.retain_expire_at(ts, ex) <= 1100) == []  # with their own intervals both live
