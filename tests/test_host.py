@@ -308,3 +308,39 @@ def test_route_cache_under_sanitizers():
     assert r.returncode == 0 and "cache_fuzz ok" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([exe + "_tsan", "2", "6", "1200"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "cache_fuzz ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
+
+
+def test_route_detail_and_receiver_cache_cases():
+    """SCHEMA/cache/RouteDetailCacheTest.java:46-131 (a route key parses back to tenant, receiverUrl / group, type and the ORIGINAL MQTT topic
+    filter, for normal, $share and $oshare routes; an unknown flag byte is refused) and ReceiverCacheTest.java:38-52 (receiverUrl ->
+    subBrokerId, receiverId, delivererKey) -- for the product codec (bmq_route_key_decode) and the oracle's parser, on the UUID-shaped
+    inputs the reference tests use."""
+    import uuid
+    for _ in range(20):
+        tenant = "tenant-%s" % uuid.uuid4()
+        broker = uuid.uuid4().int & 0x7FFFFFFF
+        rid, dk = "inbox-%s" % uuid.uuid4(), "deliverer-%s" % uuid.uuid4()
+        url = O.receiver_url(broker, rid, dk)
+        # normal route
+        f = "/home/%s" % uuid.uuid4()
+        k = O.route_key_from_mqtt(tenant, f, url)
+        assert k == B.route_key_from_mqtt(tenant, f, url)
+        assert O.parse_route_key(k) == (1, tenant, f, url) == B.decode_route_key(k)
+        assert O.deliverer_key_of(k) == (broker, dk)  # ReceiverCache.get(url): parts[0] as int, parts[2]
+        # unordered / ordered share: the group is the receiver part, the MQTT filter comes back with its prefix
+        for prefix, flag in (("$share", 2), ("$oshare", 3)):
+            orig = "%s/group-%s/s/%s" % (prefix, uuid.uuid4(), uuid.uuid4())
+            gk = O.route_key_from_mqtt(tenant, orig)
+            assert gk == B.route_key_from_mqtt(tenant, orig)
+            flag_got, tn, mqtt, group = O.parse_route_key(gk)
+            assert (flag_got, tn, mqtt) == (flag, tenant, orig) and group == orig.split("/")[1]
+            assert B.decode_route_key(gk) == (flag, tenant, orig, group)
+            assert O.deliverer_key_of(gk) is None
+        # equal content -> equal parse; different tenants -> different keys (RouteDetailCacheTest.java:99-127)
+        assert O.parse_route_key(bytes(bytearray(k))) == O.parse_route_key(k)
+        assert O.route_key_from_mqtt("tenant-" + str(uuid.uuid4()), f, url) != k
+        # unsupportedFlagThrows (:129-141): a flag byte other than 1 / 2 / 3
+        bad = bytearray(k)
+        rlen = int.from_bytes(k[-2:], "big")
+        bad[len(k) - 2 - rlen - 1] = 9
+        assert O.parse_route_key(bytes(bad)) is None and B.decode_route_key(bytes(bad)) is None
