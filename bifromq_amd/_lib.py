@@ -70,7 +70,7 @@ class BatcherStats(C.Structure):
 
 class RouteCacheConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mutation_log_entries", C.c_uint32), ("max_routes_per_tenant", C.c_uint64), ("expiry_ms", C.c_uint64),
-                ("shards_per_tenant", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+                ("shards_per_tenant", C.c_uint64), ("direct_batch_topics", C.c_uint64), ("reserved", C.c_uint64 * 2)]
 
 
 class RouteCacheStats(C.Structure):

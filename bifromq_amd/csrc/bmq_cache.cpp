@@ -223,6 +223,7 @@ struct bmq_route_cache {
     uint64_t expiry_ms = 60000;              // DistTopicMatchExpirySeconds
     uint32_t log_keep = 4096;
     uint32_t n_shards = 16;                  // per tenant, power of two
+    uint32_t direct_batch = 8192;            // get_batch: requests of at least this many topics are matched without the cache
     // tenant table: insert-only chained hash with atomic bucket heads -- a lookup takes no lock and writes nothing
     static constexpr uint32_t TBUCKETS = 1u << 14;
     std::unique_ptr<std::atomic<TenantCache*>[]> buckets;
@@ -296,6 +297,7 @@ int bmq_route_cache_create(bmq_engine* e, bmq_batcher* b, const bmq_route_cache_
         if (k.max_routes_per_tenant) c->max_routes_per_tenant = k.max_routes_per_tenant;
         if (k.expiry_ms) c->expiry_ms = k.expiry_ms;
         if (k.mutation_log_entries) c->log_keep = k.mutation_log_entries;
+        if (k.direct_batch_topics) c->direct_batch = (uint32_t)std::min<uint64_t>(k.direct_batch_topics, 0xFFFFFFFFull);
         if (k.shards_per_tenant) {
             if (k.shards_per_tenant > 1024 || (k.shards_per_tenant & (k.shards_per_tenant - 1))) return BMQ_E_INVAL;
             c->n_shards = (uint32_t)k.shards_per_tenant;
@@ -467,6 +469,14 @@ int bmq_route_cache_get_batch(bmq_route_cache* c, const uint8_t* tenants, const 
     if (n_topics == 0) return BMQ_OK;
     for (uint32_t i = 0; i < n_topics; i++)
         if (topic_tenant[i] >= n_tenants) return BMQ_E_INVAL;
+    if (n_topics >= c->direct_batch) {
+        // A big request is cheaper to match than to look up: one cache probe costs ~0.1-1 us of one host thread, the engine resolves
+        // 10 k topics in 0.09 ms and a million in 0.4 ms.  Straight to one launch; the cache is not touched.
+        uint64_t epoch = 0;
+        if (out_hit) memset(out_hit, 0, n_topics);
+        return bmq_batcher_match_batch(c->b, tenants, tenant_off, n_tenants, topic_tenant, topics, topic_off, n_topics, out_row_ptr, out_route_ids,
+                                       out_capacity, out_needed, &epoch);
+    }
     const bool bypass = c->bypass.load(std::memory_order_acquire);
     // pass 1: the cache.  Hits are copied out at once (an entry may be gone a moment later); misses are listed, identical ones once.
     std::vector<TenantCache*> tcache(n_tenants);

@@ -274,7 +274,9 @@ typedef struct bmq_route_cache_config {
     uint64_t expiry_ms;              /* DistTopicMatchExpirySeconds, default 60000 */
     uint64_t shards_per_tenant;      /* power of two, default 16: a tenant's topics are spread over that many independently locked */
                                      /* slices (each with 1/n of the route budget), so one hot tenant does not serialise its callers */
-    uint64_t reserved[3];
+    uint64_t direct_batch_topics;    /* bmq_route_cache_get_batch: a request of at least this many topics (default 8192) is matched in one */
+                                     /* launch without consulting or filling the cache -- at that size the GPU is faster than the probes */
+    uint64_t reserved[2];
 } bmq_route_cache_config;
 typedef struct bmq_route_cache_stats {
     uint64_t hits, misses, evictions, invalidations, expired;
@@ -297,7 +299,8 @@ int bmq_route_cache_get_async(bmq_route_cache* c, const uint8_t* tenant, uint32_
  * whole request in one call (arguments and CSR output as bmq_match_batch): the rows of cached topics are copied from the cache, all the
  * others -- identical (tenant, topic) pairs once -- are matched in ONE launch (bmq_batcher_match_batch) and cached under the epoch rule.
  * out_hit[i] (may be NULL) = 1 if row i came from the cache.  BMQ_E_NOSPACE + *out_needed if out_capacity is short (row pointers are
- * written; what was loaded is cached, so the second call hits). */
+ * written; what was loaded is cached, so the second call hits).  Requests of bmq_route_cache_config.direct_batch_topics topics and more
+ * skip the cache altogether: topics must then be readable 16 bytes past their end, as for bmq_match_batch. */
 int bmq_route_cache_get_batch(bmq_route_cache* c, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
                               const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, uint64_t now_ms, uint32_t* out_row_ptr,
                               uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed, uint8_t* out_hit);

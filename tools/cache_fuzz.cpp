@@ -393,6 +393,27 @@ static void test_behaviour() {
         bmq_route_cache_stats_get(c, &st);
         EXPECT(dropped >= 1 && st.entries + dropped >= before && is_cached(c, "t", "a/d") == 1 && is_cached(c, "t", "a/b") == 0); // a/b idle since 2960
     }
+    { // a request of direct_batch_topics topics and more goes straight to one launch: no probes, nothing cached
+        bmq_route_cache_config big{};
+        big.struct_size = sizeof(big);
+        big.direct_batch_topics = 4;
+        bmq_route_cache* c2 = nullptr;
+        EXPECT(bmq_route_cache_create(&e, &b, &big, &c2) == BMQ_OK);
+        const uint32_t tenant_off[2] = {0, 1};
+        const std::string bytes = std::string("a/ba/ca/da/e") + std::string(16, '\0');
+        const uint32_t off[5] = {0, 3, 6, 9, 12}, tt[4] = {0, 0, 0, 0};
+        uint32_t row[5], out[64];
+        uint8_t hit[4] = {9, 9, 9, 9};
+        uint64_t need = 0;
+        const uint64_t launches = e.n_launch;
+        EXPECT(bmq_route_cache_get_batch(c2, (const uint8_t*)"t", tenant_off, 1, tt, (const uint8_t*)bytes.data(), off, 4, 5000, row, out, 64, &need, hit) == BMQ_OK);
+        EXPECT(e.n_launch == launches + 1 && hit[0] == 0 && hit[3] == 0);
+        for (int i = 0; i < 4; i++) EXPECT(std::vector<uint32_t>(out + row[i], out + row[i + 1]) == brute(e.model, "t", bytes.substr(off[i], 3)));
+        bmq_route_cache_stats s2{};
+        bmq_route_cache_stats_get(c2, &s2);
+        EXPECT(s2.entries == 0 && s2.misses == 0);
+        bmq_route_cache_destroy(c2);
+    }
     // rebuild: ids renumbered, nothing of the old generation survives
     Packed nb;
     nb.add(key_of("t", "a/b", 100), 0);
