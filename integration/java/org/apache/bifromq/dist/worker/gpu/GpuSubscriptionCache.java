@@ -48,24 +48,43 @@ final class GpuSubscriptionCache implements ISubscriptionCache {
     /** SubscriptionCache.get (SubscriptionCache.java:117-122): the matched routes of (tenant, topic). */
     @Override
     public CompletableFuture<Set<Matching>> get(String tenantId, String topic) {
-        // a miss blocks its thread until the shared launch has finished, exactly like the reference's cache loader does on matchExecutor
-        return CompletableFuture.supplyAsync(() -> {
-            byte[] tn = tenantId.getBytes(StandardCharsets.UTF_8);
-            byte[] tp = topic.getBytes(StandardCharsets.UTF_8);
-            long[] epoch = new long[1];
-            IntBuffer ids = IDS.get();
-            long n = NativeMatcher.routeCacheGet(cache, tn, tp, System.currentTimeMillis(), ids, epoch);
-            while (n < 0) { // the row is longer than the buffer: grow and ask again (it may have grown once more meanwhile)
-                ids = ByteBuffer.allocateDirect((int) (-n + 64) * 4).order(ByteOrder.nativeOrder()).asIntBuffer();
-                IDS.set(ids);
-                n = NativeMatcher.routeCacheGet(cache, tn, tp, System.currentTimeMillis(), ids, epoch);
-            }
-            Set<Matching> out = new LinkedHashSet<>((int) n * 2);
+        // bmq_route_cache_get_async: a hit completes the future before this method returns; a miss joins the launch of all misses of the
+        // moment and completes from the batching front's dispatcher thread -- no matcher thread is parked meanwhile (the reference parks one
+        // per miss: TenantRouteCache.java:180-193).  Resolving ids to Matching objects may touch the KV store: handed to matchExecutor.
+        CompletableFuture<int[]> ids = new CompletableFuture<>();
+        NativeMatcher.routeCacheGetAsync(cache, tenantId.getBytes(StandardCharsets.UTF_8), topic.getBytes(StandardCharsets.UTF_8),
+            System.currentTimeMillis(), (status, routeIds, epoch) -> {
+                if (status == 0) {
+                    ids.complete(routeIds);
+                } else {
+                    ids.completeExceptionally(new IllegalStateException("bmq_route_cache_get_async: " + status));
+                }
+            });
+        return ids.thenApplyAsync(routeIds -> {
+            Set<Matching> out = new LinkedHashSet<>(routeIds.length * 2);
+            IntBuffer buf = IntBuffer.wrap(routeIds);
             // ids -> Matching, cached per generation, the unknown ones resolved with ONE native gather; a route unsubscribed between
             // the match and now is simply absent
-            index.resolve(ids, 0, (int) n).forEach(e -> out.add(e.matching()));
+            index.resolve(buf, 0, routeIds.length).forEach(e -> out.add(e.matching()));
             return out;
         }, matchExecutor);
+    }
+
+    /** The same, parking the calling thread for a miss (what the reference's cache loader does on matchExecutor). */
+    Set<Matching> getBlocking(String tenantId, String topic) {
+        byte[] tn = tenantId.getBytes(StandardCharsets.UTF_8);
+        byte[] tp = topic.getBytes(StandardCharsets.UTF_8);
+        long[] epoch = new long[1];
+        IntBuffer ids = IDS.get();
+        long n = NativeMatcher.routeCacheGet(cache, tn, tp, System.currentTimeMillis(), ids, epoch);
+        while (n < 0) { // the row is longer than the buffer: grow and ask again (it may have grown once more meanwhile)
+            ids = ByteBuffer.allocateDirect((int) (-n + 64) * 4).order(ByteOrder.nativeOrder()).asIntBuffer();
+            IDS.set(ids);
+            n = NativeMatcher.routeCacheGet(cache, tn, tp, System.currentTimeMillis(), ids, epoch);
+        }
+        Set<Matching> out = new LinkedHashSet<>((int) n * 2);
+        index.resolve(ids, 0, (int) n).forEach(e -> out.add(e.matching()));
+        return out;
     }
 
     /** SubscriptionCache.isCached (:125-131) = !TopicIndex.match(filterLevels).isEmpty() */

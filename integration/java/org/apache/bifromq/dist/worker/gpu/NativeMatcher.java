@@ -123,6 +123,14 @@ final class NativeMatcher {
                                           ByteBuffer topics, IntBuffer topicOff, int nTopics, long nowMs, IntBuffer outRowPtr,
                                           IntBuffer outIds, ByteBuffer outHit);
 
+    /** Completed by the native side: on the calling thread for a hit, on the batching front's dispatcher thread for a miss. */
+    interface RouteCallback {
+        void onRoutes(int status, int[] routeIds, long epoch);
+    }
+
+    /** ISubscriptionCache.get as a future: nobody blocks on the GPU. */
+    static native void routeCacheGetAsync(long cache, byte[] tenant, byte[] topic, long nowMs, RouteCallback cb);
+
     static native int routeCacheIsCached(long cache, byte[] tenant, byte[] filter);
 
     static native void routeCacheApply(long cache, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n);

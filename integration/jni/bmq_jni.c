@@ -12,6 +12,7 @@
 #endif
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "bmq.h"
 
@@ -444,4 +445,55 @@ JNIEXPORT jlong JNICALL NM(routeCacheExpire)(JNIEnv* env, jclass c, jlong h, jlo
     uint64_t n = 0;
     (void)bmq_route_cache_expire(CACHE(h), (uint64_t)nowMs, &n);
     return (jlong)n;
+}
+
+/* ---- futures: bmq_route_cache_get_async completes a Java callback object ---------------------------------------------------------- */
+/* void routeCacheGetAsync(long cache, byte[] tenant, byte[] topic, long nowMs, RouteCallback cb)
+ * cb.onRoutes(int status, int[] routeIds, long epoch) runs on the calling thread for a cache hit (before this method returns) and on the
+ * batching front's dispatcher thread for a miss -- that thread is attached to the JVM as a daemon the first time it calls back.  The Java
+ * side completes a CompletableFuture in onRoutes (GpuSubscriptionCache.get). */
+static JavaVM* g_vm;
+typedef struct async_ctx {
+    jobject cb; /* global ref */
+} async_ctx;
+static void async_done(void* user, int status, const uint32_t* ids, uint32_t n, uint64_t epoch) {
+    async_ctx* a = (async_ctx*)user;
+    JNIEnv* env = NULL;
+    if ((*g_vm)->GetEnv(g_vm, (void**)&env, JNI_VERSION_1_8) != JNI_OK && (*g_vm)->AttachCurrentThreadAsDaemon(g_vm, (void**)&env, NULL) != JNI_OK) {
+        free(a); /* no JVM to call back into: the future stays incomplete, as it would on any lost thread */
+        return;
+    }
+    jclass cls = (*env)->GetObjectClass(env, a->cb);
+    jmethodID m = (*env)->GetMethodID(env, cls, "onRoutes", "(I[IJ)V");
+    jintArray arr = (*env)->NewIntArray(env, (jsize)n);
+    if (m && arr) {
+        if (n) (*env)->SetIntArrayRegion(env, arr, 0, (jsize)n, (const jint*)ids);
+        (*env)->CallVoidMethod(env, a->cb, m, (jint)status, arr, (jlong)epoch);
+        if ((*env)->ExceptionCheck(env)) (*env)->ExceptionClear(env); /* a throwing callback must not poison the dispatcher thread */
+    }
+    if (arr) (*env)->DeleteLocalRef(env, arr);
+    (*env)->DeleteLocalRef(env, cls);
+    (*env)->DeleteGlobalRef(env, a->cb);
+    free(a);
+}
+JNIEXPORT void JNICALL NM(routeCacheGetAsync)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jbyteArray topic, jlong nowMs, jobject cb) {
+    (void)c;
+    if (!g_vm) (*env)->GetJavaVM(env, &g_vm);
+    async_ctx* a = (async_ctx*)malloc(sizeof *a);
+    if (!a) {
+        throw_state(env, NULL, "routeCacheGetAsync: out of memory", BMQ_E_NOMEM);
+        return;
+    }
+    a->cb = (*env)->NewGlobalRef(env, cb);
+    const jsize tl = (*env)->GetArrayLength(env, tenant), pl = (*env)->GetArrayLength(env, topic);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    jbyte* tp = (*env)->GetByteArrayElements(env, topic, NULL);
+    const int rc = bmq_route_cache_get_async(CACHE(h), (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)tp, (uint32_t)pl, (uint64_t)nowMs, async_done, a);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    (*env)->ReleaseByteArrayElements(env, topic, tp, JNI_ABORT);
+    if (rc != BMQ_OK) { /* not submitted: nobody will call back */
+        (*env)->DeleteGlobalRef(env, a->cb);
+        free(a);
+        throw_state(env, NULL, "bmq_route_cache_get_async", rc);
+    }
 }

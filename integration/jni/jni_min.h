@@ -17,12 +17,19 @@ typedef jobject jthrowable;
 typedef jobject jarray;
 typedef jarray jbyteArray;
 typedef jarray jlongArray;
+typedef jarray jintArray;
+struct _jmethodID;
+typedef struct _jmethodID* jmethodID;
+#define JNI_OK 0
+#define JNI_VERSION_1_8 0x00010008
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
 #define JNI_ABORT 2
 
 struct JNINativeInterface_;
 typedef const struct JNINativeInterface_* JNIEnv;
+struct JNIInvokeInterface_;
+typedef const struct JNIInvokeInterface_* JavaVM;
 struct JNINativeInterface_ { /* only the members used by bmq_jni.c; the real table has 230 entries */
     jclass (*FindClass)(JNIEnv* env, const char* name);
     jint (*ThrowNew)(JNIEnv* env, jclass clazz, const char* msg);
@@ -33,5 +40,21 @@ struct JNINativeInterface_ { /* only the members used by bmq_jni.c; the real tab
     void (*ReleaseByteArrayElements)(JNIEnv* env, jbyteArray array, jbyte* elems, jint mode);
     void (*SetLongArrayRegion)(JNIEnv* env, jlongArray array, jsize start, jsize len, const jlong* buf);
     jobject (*NewDirectByteBuffer)(JNIEnv* env, void* address, jlong capacity);
+    /* for callbacks from native threads (routeCacheGetAsync) */
+    jobject (*NewGlobalRef)(JNIEnv* env, jobject obj);
+    void (*DeleteGlobalRef)(JNIEnv* env, jobject ref);
+    jclass (*GetObjectClass)(JNIEnv* env, jobject obj);
+    jmethodID (*GetMethodID)(JNIEnv* env, jclass clazz, const char* name, const char* sig);
+    void (*CallVoidMethod)(JNIEnv* env, jobject obj, jmethodID method, ...);
+    jintArray (*NewIntArray)(JNIEnv* env, jsize len);
+    void (*SetIntArrayRegion)(JNIEnv* env, jintArray array, jsize start, jsize len, const jint* buf);
+    void (*DeleteLocalRef)(JNIEnv* env, jobject ref);
+    jboolean (*ExceptionCheck)(JNIEnv* env);
+    void (*ExceptionClear)(JNIEnv* env);
+    jint (*GetJavaVM)(JNIEnv* env, JavaVM** vm);
+};
+struct JNIInvokeInterface_ { /* only the members used */
+    jint (*GetEnv)(JavaVM* vm, void** penv, jint version);
+    jint (*AttachCurrentThreadAsDaemon)(JavaVM* vm, void** penv, void* args);
 };
 #endif
