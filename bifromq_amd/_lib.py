@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
     "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get",
     "bmq_route_cache_create", "bmq_route_cache_destroy", "bmq_route_cache_get", "bmq_route_cache_get_async", "bmq_route_cache_get_batch", "bmq_batcher_match_batch", "bmq_route_cache_is_cached", "bmq_route_cache_apply",
-    "bmq_route_cache_rebuild", "bmq_route_cache_reset", "bmq_route_cache_expire", "bmq_route_cache_stats_get", "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
+    "bmq_route_cache_rebuild", "bmq_route_cache_reset", "bmq_route_cache_expire", "bmq_route_cache_stats_get", "bmq_route_cache_tenant_stats_get",
+    "bmq_route_cache_set_caps", "bmq_route_cache_set_event_sink", "bmq_routes_cap", "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
 ]
 
 
@@ -70,12 +71,19 @@ class BatcherStats(C.Structure):
 
 class RouteCacheConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mutation_log_entries", C.c_uint32), ("max_routes_per_tenant", C.c_uint64), ("expiry_ms", C.c_uint64),
-                ("shards_per_tenant", C.c_uint64), ("direct_batch_topics", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+                ("shards_per_tenant", C.c_uint64), ("direct_batch_topics", C.c_uint64), ("default_max_persistent_fanout", C.c_int32),
+                ("default_max_group_fanout", C.c_int32), ("tenant_idle_ms", C.c_uint64)]
 
 
 class RouteCacheStats(C.Structure):
     _fields_ = [("hits", C.c_uint64), ("misses", C.c_uint64), ("evictions", C.c_uint64), ("invalidations", C.c_uint64), ("expired", C.c_uint64),
-                ("stale_loads", C.c_uint64), ("entries", C.c_uint64), ("cached_routes", C.c_uint64)]
+                ("stale_loads", C.c_uint64), ("entries", C.c_uint64), ("cached_routes", C.c_uint64), ("tenants", C.c_uint64),
+                ("tenants_expired", C.c_uint64)]
+
+
+class RouteCacheTenantStats(C.Structure):
+    _fields_ = [("hits", C.c_uint64), ("misses", C.c_uint64), ("evictions", C.c_uint64), ("entries", C.c_uint64), ("cached_routes", C.c_uint64),
+                ("last_get_ms", C.c_uint64), ("max_persistent_fanout", C.c_int32), ("max_group_fanout", C.c_int32)]
 
 
 _lib = None
@@ -155,6 +163,10 @@ def lib() -> C.CDLL:
             "bmq_route_cache_reset": (C.c_int, [vp]),
             "bmq_route_cache_expire": (C.c_int, [vp, u64, P(u64)]),
             "bmq_route_cache_stats_get": (C.c_int, [vp, P(RouteCacheStats)]),
+            "bmq_route_cache_tenant_stats_get": (C.c_int, [vp, C.c_char_p, u32, P(RouteCacheTenantStats)]),
+            "bmq_route_cache_set_caps": (C.c_int, [vp, C.c_char_p, u32, i32, i32]),
+            "bmq_route_cache_set_event_sink": (C.c_int, [vp, vp, vp]),
+            "bmq_routes_cap": (C.c_int, [vp, vp, vp, u32, i32, i32, vp, vp, vp, vp, u32, P(u32)]),
             "bmq_fanout_group": (C.c_int, [vp, vp, vp, u32, vp, vp, u64, vp, vp, u32, P(u32), P(u32)]),
             "bmq_fanout_group_dev": (C.c_int, [vp, vp, vp, u32, u64, vp, vp, vp, vp, u32, P(u32), P(u32)]),
             "bmq_router_find_by_key": (C.c_int, [vp, vp, vp, vp, vp, u32, C.c_char_p, u32, P(i32)]),

@@ -103,9 +103,9 @@ struct bmq_engine {
     uint32_t slow_idle = 0, sort_idle = 0; // consecutive batches that ran them for nothing
     bool kernel_events = false; // bmq_config.kernel_timing: HIP events around k_walk / k_expand of every dist batch (~4 us each)
 
-    // Everything ONE batch in flight needs: per-batch scratch, staging of the host-buffer API, counters, events.  Two slots, so
-    // that the asynchronous host API (bmq_match_submit / bmq_match_wait) can have the upload of batch i+1 and the download of
-    // batch i-1 in flight while the kernels of batch i run; every other entry point works on slot 0.
+    // Everything ONE batch in flight needs: per-batch scratch, staging of the host-buffer API, counters, events.  The asynchronous
+    // host API (bmq_match_submit / bmq_match_wait) owns two slots of its own, so that the upload of batch i+1 and the download of
+    // batch i-1 are in flight while the kernels of batch i run; every other entry point works on slot 0.
     struct BatchSlot {
         DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave;
         DevBuf b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch, b_sort_list, b_ctr,
@@ -130,8 +130,10 @@ struct bmq_engine {
         BatchArgs last{};
         RetainArgs rlast{};
     };
-    BatchSlot slots[2];
-    BatchSlot* cur = &slots[0];
+    // slots[0] (== cur, never re-pointed) serves the blocking / *_dev entry points; slots[1], slots[2] are the two tickets of
+    // bmq_match_submit / bmq_match_wait, so that a ticket in flight is never staged over by another thread's blocking call.
+    BatchSlot slots[3];
+    BatchSlot* const cur = &slots[0];
     hipStream_t s_in = nullptr, s_out = nullptr; // copy streams of the asynchronous host API
     bmq_stats stats{};
 
@@ -188,119 +190,119 @@ uint32_t tpw_shift_for(uint32_t n_topics) {
     return n_topics >= 131072 ? 6u : (n_topics >= 16384 ? 4u : 2u); // measured: profiles/r02/extras/tpw_sweep.txt (10 k topics: 0.117 / 0.092 / 0.084 ms)
 }
 
-int ensure_batch_scratch(bmq_engine* e, uint32_t n_tenants, uint32_t n_topics) {
+int ensure_batch_scratch(bmq_engine* e, bmq_engine::BatchSlot& S, uint32_t n_tenants, uint32_t n_topics) {
     const uint32_t sh = tpw_shift_for(n_topics);
     const uint32_t n_blocks = (n_topics + (1u << sh) - 1) >> sh;
-    if (e->cur->pair_cap == 0) e->cur->pair_cap = 1u << 16;
-    e->cur->pair_cap = std::max<uint64_t>(e->cur->pair_cap, (uint64_t)n_topics * 4);
-    if (e->cur->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
-    if (e->cur->slow_cap == 0) e->cur->slow_cap = 1024;
-    e->cur->slow_cap = std::max<uint32_t>(e->cur->slow_cap, n_topics / 16);
-    if (e->cur->sort_cap == 0) e->cur->sort_cap = 1024;
-    e->cur->sort_cap = std::max<uint32_t>(e->cur->sort_cap, n_topics / 64);
-    if (e->cur->scratch_cap == 0) e->cur->scratch_cap = (uint64_t)(e->cfg.slow_scratch_mb ? e->cfg.slow_scratch_mb : 64) * (1u << 20) / 4;
-    HIPCHK(e, e->cur->b_pair_off.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
-    HIPCHK(e, e->cur->b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
-    HIPCHK(e, e->cur->b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
-    HIPCHK(e, e->cur->b_pairs.ensure(sizeof(MatchRange) * e->cur->pair_cap));
-    const void *p_subs = e->cur->b_subs.p, *p_super = e->cur->b_super.p, *p_ctr = e->cur->b_ctr.p;
-    HIPCHK(e, e->cur->b_subs.ensure(sizeof(SubAlloc) * 2 * N_SUB));
-    HIPCHK(e, e->cur->b_super.ensure(sizeof(unsigned long long) * SUPER_STRIDE * ((n_blocks >> SUPER_SHIFT) + 2)));
-    if (e->cur->spill_cap == 0) e->cur->spill_cap = 1u << 16;
-    e->cur->spill_cap = std::max<uint64_t>(e->cur->spill_cap, (uint64_t)n_topics * 2);
-    HIPCHK(e, e->cur->b_blk_stats.ensure(sizeof(uint4) * std::max(n_blocks, 1u)));
-    HIPCHK(e, e->cur->b_spill.ensure(sizeof(uint4) * e->cur->spill_cap));
-    HIPCHK(e, e->cur->b_wave_sums.ensure(sizeof(unsigned long long) * std::max(n_blocks, 1u)));
-    HIPCHK(e, e->cur->b_slow_list.ensure(sizeof(uint32_t) * e->cur->slow_cap));
-    HIPCHK(e, e->cur->b_sort_list.ensure(sizeof(uint32_t) * e->cur->sort_cap));
-    HIPCHK(e, e->cur->b_scratch.ensure(sizeof(uint32_t) * e->cur->scratch_cap));
-    HIPCHK(e, e->cur->b_ctr.ensure(sizeof(Counters)));
-    HIPCHK(e, e->cur->b_total.ensure(sizeof(unsigned long long)));
-    if (p_subs != e->cur->b_subs.p || p_super != e->cur->b_super.p || p_ctr != e->cur->b_ctr.p) e->cur->clean = false; // fresh memory
+    if (S.pair_cap == 0) S.pair_cap = 1u << 16;
+    S.pair_cap = std::max<uint64_t>(S.pair_cap, (uint64_t)n_topics * 4);
+    if (S.pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
+    if (S.slow_cap == 0) S.slow_cap = 1024;
+    S.slow_cap = std::max<uint32_t>(S.slow_cap, n_topics / 16);
+    if (S.sort_cap == 0) S.sort_cap = 1024;
+    S.sort_cap = std::max<uint32_t>(S.sort_cap, n_topics / 64);
+    if (S.scratch_cap == 0) S.scratch_cap = (uint64_t)(e->cfg.slow_scratch_mb ? e->cfg.slow_scratch_mb : 64) * (1u << 20) / 4;
+    HIPCHK(e, S.b_pair_off.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, S.b_pair_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, S.b_route_cnt.ensure(sizeof(uint32_t) * std::max(n_topics, 1u)));
+    HIPCHK(e, S.b_pairs.ensure(sizeof(MatchRange) * S.pair_cap));
+    const void *p_subs = S.b_subs.p, *p_super = S.b_super.p, *p_ctr = S.b_ctr.p;
+    HIPCHK(e, S.b_subs.ensure(sizeof(SubAlloc) * 2 * N_SUB));
+    HIPCHK(e, S.b_super.ensure(sizeof(unsigned long long) * SUPER_STRIDE * ((n_blocks >> SUPER_SHIFT) + 2)));
+    if (S.spill_cap == 0) S.spill_cap = 1u << 16;
+    S.spill_cap = std::max<uint64_t>(S.spill_cap, (uint64_t)n_topics * 2);
+    HIPCHK(e, S.b_blk_stats.ensure(sizeof(uint4) * std::max(n_blocks, 1u)));
+    HIPCHK(e, S.b_spill.ensure(sizeof(uint4) * S.spill_cap));
+    HIPCHK(e, S.b_wave_sums.ensure(sizeof(unsigned long long) * std::max(n_blocks, 1u)));
+    HIPCHK(e, S.b_slow_list.ensure(sizeof(uint32_t) * S.slow_cap));
+    HIPCHK(e, S.b_sort_list.ensure(sizeof(uint32_t) * S.sort_cap));
+    HIPCHK(e, S.b_scratch.ensure(sizeof(uint32_t) * S.scratch_cap));
+    HIPCHK(e, S.b_ctr.ensure(sizeof(Counters)));
+    HIPCHK(e, S.b_total.ensure(sizeof(unsigned long long)));
+    if (p_subs != S.b_subs.p || p_super != S.b_super.p || p_ctr != S.b_ctr.p) S.clean = false; // fresh memory
     return BMQ_OK;
 }
 
 constexpr uint32_t REPAIR_IDLE_BATCHES = 32;
 
 // zero state of a batch slot's counters, range allocators and super-block sums (k_reset), whole capacity
-void reset_slot(bmq_engine* e, hipStream_t s) {
-    const uint32_t n_super = (uint32_t)(e->cur->b_super.cap / (sizeof(unsigned long long) * SUPER_STRIDE));
+void reset_slot(bmq_engine* e, bmq_engine::BatchSlot& S, hipStream_t s) {
+    const uint32_t n_super = (uint32_t)(S.b_super.cap / (sizeof(unsigned long long) * SUPER_STRIDE));
     const uint32_t items = std::max<uint32_t>(n_super, (uint32_t)(sizeof(SubAlloc) * 2 * N_SUB / 8));
-    hipLaunchKernelGGL(k_reset, dim3((items + 63) / 64), dim3(64), 0, s, e->cur->b_ctr.as<Counters>(), e->cur->b_subs.as<SubAlloc>(),
-                       e->cur->b_super.as<unsigned long long>(), n_super);
-    e->cur->clean = true;
+    hipLaunchKernelGGL(k_reset, dim3((items + 63) / 64), dim3(64), 0, s, S.b_ctr.as<Counters>(), S.b_subs.as<SubAlloc>(),
+                       S.b_super.as<unsigned long long>(), n_super);
+    S.clean = true;
 }
 
-int launch_dist(bmq_engine* e, BatchArgs& a) {
+int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     a.ix = e->dix->view();
     a.tpw_shift = tpw_shift_for(a.n_topics);
     a.n_blocks = (a.n_topics + (1u << a.tpw_shift) - 1) >> a.tpw_shift;
-    a.pair_off = e->cur->b_pair_off.as<uint32_t>();
-    a.pair_cnt = e->cur->b_pair_cnt.as<uint32_t>();
-    a.route_cnt = e->cur->b_route_cnt.as<uint32_t>();
-    a.pairs = e->cur->b_pairs.as<MatchRange>();
-    a.pair_cap = e->cur->pair_cap;
-    a.subs = e->cur->b_subs.as<SubAlloc>();
-    a.super_sums = e->cur->b_super.as<unsigned long long>();
-    a.blk_stats = e->cur->b_blk_stats.as<uint4>();
-    a.spill = e->cur->b_spill.as<uint4>();
-    a.spill_cap = e->cur->spill_cap;
-    a.wave_sums = e->cur->b_wave_sums.as<unsigned long long>();
-    a.slow_list = e->cur->b_slow_list.as<uint32_t>();
-    a.slow_cap = e->cur->slow_cap;
-    a.scratch = e->cur->b_scratch.as<uint32_t>();
-    a.scratch_cap = e->cur->scratch_cap;
-    a.sort_list = e->cur->b_sort_list.as<uint32_t>();
-    a.sort_cap = e->cur->sort_cap;
-    a.ctr = e->cur->b_ctr.as<Counters>();
+    a.pair_off = S.b_pair_off.as<uint32_t>();
+    a.pair_cnt = S.b_pair_cnt.as<uint32_t>();
+    a.route_cnt = S.b_route_cnt.as<uint32_t>();
+    a.pairs = S.b_pairs.as<MatchRange>();
+    a.pair_cap = S.pair_cap;
+    a.subs = S.b_subs.as<SubAlloc>();
+    a.super_sums = S.b_super.as<unsigned long long>();
+    a.blk_stats = S.b_blk_stats.as<uint4>();
+    a.spill = S.b_spill.as<uint4>();
+    a.spill_cap = S.spill_cap;
+    a.wave_sums = S.b_wave_sums.as<unsigned long long>();
+    a.slow_list = S.b_slow_list.as<uint32_t>();
+    a.slow_cap = S.slow_cap;
+    a.scratch = S.b_scratch.as<uint32_t>();
+    a.scratch_cap = S.scratch_cap;
+    a.sort_list = S.b_sort_list.as<uint32_t>();
+    a.sort_cap = S.sort_cap;
+    a.ctr = S.b_ctr.as<Counters>();
     {
         const char* dbg = getenv("BMQ_DEBUG");
         a.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
         a.dbg_wave = nullptr;
         if (a.debug_flags & 6u) {
-            HIPCHK(e, e->cur->b_dbg_wave.ensure(sizeof(uint4) * std::max(a.n_blocks, 1u)));
-            a.dbg_wave = e->cur->b_dbg_wave.as<uint4>();
+            HIPCHK(e, S.b_dbg_wave.ensure(sizeof(uint4) * std::max(a.n_blocks, 1u)));
+            a.dbg_wave = S.b_dbg_wave.as<uint4>();
         }
     }
     a.qcap = e->cfg.wave_queue_cap;
     a.pcap = e->cfg.wave_pair_cap;
     hipStream_t s = e->stream;
-    e->cur->timed = e->kernel_events;
-    if (!e->cur->clean) reset_slot(e, s); // first batch of the slot, buffers regrown, or a retain batch ran on it
-    HIPCHK(e, hipEventRecord(e->cur->ev[0], s));
-    if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[1], s));
+    S.timed = e->kernel_events;
+    if (!S.clean) reset_slot(e, S, s); // first batch of the slot, buffers regrown, or a retain batch ran on it
+    HIPCHK(e, hipEventRecord(S.ev[0], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
         const dim3 grid((a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
         if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_walk, grid, block, lds, s, a);
     }
-    if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[2], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[2], s));
     // The two repair kernels run only while batches need them (finish_dist turns them on -- and completes the batch that found
     // out -- and off again): topics deeper than FAST_LEVELS (the broker rejects them: Setting.MaxTopicLevels = 16) and rows whose
     // ranges do not come out in ascending id order.  A launch that finds nothing to do still costs its slot in the stream.
-    e->cur->ran_slow = e->slow_on;
-    e->cur->ran_sort = e->sort_on;
+    S.ran_slow = e->slow_on;
+    S.ran_sort = e->sort_on;
     if (e->slow_on) hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
-    if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[3], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[3], s));
     hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
-    if (e->kernel_events) HIPCHK(e, hipEventRecord(e->cur->ev[4], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
     if (e->sort_on) hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
-    HIPCHK(e, hipEventRecord(e->cur->ev[5], s));
-    HIPCHK(e, hipMemcpyAsync(e->cur->h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    HIPCHK(e, hipEventRecord(e->cur->ev_done, s));
-    reset_slot(e, s); // behind the batch: the counters / allocators are clean again when the next batch arrives
+    HIPCHK(e, hipEventRecord(S.ev[5], s));
+    HIPCHK(e, hipMemcpyAsync(S.h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipEventRecord(S.ev_done, s));
+    reset_slot(e, S, s); // behind the batch: the counters / allocators are clean again when the next batch arrives
     HIPCHK(e, hipGetLastError());
-    e->cur->last = a;
-    e->cur->pending = true;
-    e->cur->pending_kind = 0;
+    S.last = a;
+    S.pending = true;
+    S.pending_kind = 0;
     return BMQ_OK;
 }
 
 // waits; grows internal buffers and re-runs when a kernel asked for it
 // BMQ_DEBUG=2: per-wave phase clocks of the last k_walk launch (profiling experiments only)
-static void print_wave_debug(bmq_engine* e) {
-    const BatchArgs& a = e->cur->last;
+static void print_wave_debug(bmq_engine* e, bmq_engine::BatchSlot& S) {
+    const BatchArgs& a = S.last;
     if (!a.dbg_wave || !a.n_blocks) return;
     std::vector<uint4> h(a.n_blocks);
     if (hipMemcpy(h.data(), a.dbg_wave, sizeof(uint4) * a.n_blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
@@ -325,74 +327,74 @@ static void print_wave_debug(bmq_engine* e) {
             r[(size_t)(a.n_blocks * 0.99)], r.back(), si / n);
 }
 
-int finish_dist(bmq_engine* e, uint64_t* out_total) {
+int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
     for (int attempt = 0; attempt < 8; attempt++) {
-        HIPCHK(e, hipEventSynchronize(e->cur->ev_done)); // this batch only: a later batch may already be running behind it
-        if (e->cur->last.debug_flags & 6u) print_wave_debug(e);
-        const Counters c = *e->cur->h_ctr;
+        HIPCHK(e, hipEventSynchronize(S.ev_done)); // this batch only: a later batch may already be running behind it
+        if (S.last.debug_flags & 6u) print_wave_debug(e, S);
+        const Counters c = *S.h_ctr;
         const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST);
         if (grow) {
             if (grow & ST_NEED_PAIRS) {
-                e->cur->pair_cap = e->cur->pair_cap * 2; // slices fill unevenly: double until every sub-allocator fits
-                if (e->cur->pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
-                HIPCHK(e, e->cur->b_pairs.ensure(sizeof(MatchRange) * e->cur->pair_cap));
+                S.pair_cap = S.pair_cap * 2; // slices fill unevenly: double until every sub-allocator fits
+                if (S.pair_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "matched-range buffer exceeds 2^32 entries");
+                HIPCHK(e, S.b_pairs.ensure(sizeof(MatchRange) * S.pair_cap));
             }
             if (grow & ST_NEED_SPILL) {
-                e->cur->spill_cap = e->cur->spill_cap * 2;
-                if (e->cur->spill_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "range spill buffer exceeds 2^32 records");
-                HIPCHK(e, e->cur->b_spill.ensure(sizeof(uint4) * e->cur->spill_cap));
+                S.spill_cap = S.spill_cap * 2;
+                if (S.spill_cap >= 0xFFFFFFFFull) return set_err(e, BMQ_E_RANGE, "range spill buffer exceeds 2^32 records");
+                HIPCHK(e, S.b_spill.ensure(sizeof(uint4) * S.spill_cap));
             }
             if (grow & ST_NEED_SLOW) {
-                e->cur->slow_cap = std::max<uint32_t>(e->cur->slow_cap * 2, c.slow_count);
-                HIPCHK(e, e->cur->b_slow_list.ensure(sizeof(uint32_t) * e->cur->slow_cap));
+                S.slow_cap = std::max<uint32_t>(S.slow_cap * 2, c.slow_count);
+                HIPCHK(e, S.b_slow_list.ensure(sizeof(uint32_t) * S.slow_cap));
             }
             if (grow & ST_NEED_SCRATCH) {
-                e->cur->scratch_cap = std::max<uint64_t>(e->cur->scratch_cap * 2, c.scratch_alloc + c.scratch_alloc / 8);
-                HIPCHK(e, e->cur->b_scratch.ensure(sizeof(uint32_t) * e->cur->scratch_cap));
+                S.scratch_cap = std::max<uint64_t>(S.scratch_cap * 2, c.scratch_alloc + c.scratch_alloc / 8);
+                HIPCHK(e, S.b_scratch.ensure(sizeof(uint32_t) * S.scratch_cap));
             }
             if (grow & ST_NEED_SORTLIST) {
-                e->cur->sort_cap = std::max<uint32_t>(e->cur->sort_cap * 2, c.sort_count);
-                HIPCHK(e, e->cur->b_sort_list.ensure(sizeof(uint32_t) * e->cur->sort_cap));
+                S.sort_cap = std::max<uint32_t>(S.sort_cap * 2, c.sort_count);
+                HIPCHK(e, S.b_sort_list.ensure(sizeof(uint32_t) * S.sort_cap));
             }
             if (c.sort_count) e->sort_on = true, e->sort_idle = 0;
             if (c.slow_count) e->slow_on = true, e->slow_idle = 0;
-            BatchArgs a = e->cur->last;
-            int rc = launch_dist(e, a);
+            BatchArgs a = S.last;
+            int rc = launch_dist(e, S, a);
             if (rc) return rc;
             continue;
         }
-        if (c.slow_count && !e->cur->ran_slow) { // deep topics and k_walk_slow was not in the pipeline: the batch runs again with it
+        if (c.slow_count && !S.ran_slow) { // deep topics and k_walk_slow was not in the pipeline: the batch runs again with it
             e->slow_on = true, e->slow_idle = 0;
-            BatchArgs a = e->cur->last;
-            int rc = launch_dist(e, a);
+            BatchArgs a = S.last;
+            int rc = launch_dist(e, S, a);
             if (rc) return rc;
             continue;
         }
-        if (c.sort_count && !e->cur->ran_sort && !(c.status & (ST_RANGE | ST_NOSPACE))) { // rows to order: only that kernel
+        if (c.sort_count && !S.ran_sort && !(c.status & (ST_RANGE | ST_NOSPACE))) { // rows to order: only that kernel
             e->sort_on = true, e->sort_idle = 0;
             // the slot's counters were reset behind the batch: k_sort_rows reads the row count from them
-            HIPCHK(e, hipMemcpyAsync(e->cur->last.ctr, e->cur->h_ctr, sizeof(Counters), hipMemcpyHostToDevice, e->stream));
-            hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, e->stream, e->cur->last);
-            reset_slot(e, e->stream);
+            HIPCHK(e, hipMemcpyAsync(S.last.ctr, S.h_ctr, sizeof(Counters), hipMemcpyHostToDevice, e->stream));
+            hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, e->stream, S.last);
+            reset_slot(e, S, e->stream);
             HIPCHK(e, hipGetLastError());
             HIPCHK(e, hipStreamSynchronize(e->stream));
         }
-        if (e->cur->ran_slow && (c.slow_count ? (e->slow_idle = 0) : ++e->slow_idle) >= REPAIR_IDLE_BATCHES) e->slow_on = false;
-        if (e->cur->ran_sort && (c.sort_count ? (e->sort_idle = 0) : ++e->sort_idle) >= REPAIR_IDLE_BATCHES) e->sort_on = false;
-        e->cur->pending = false;
+        if (S.ran_slow && (c.slow_count ? (e->slow_idle = 0) : ++e->slow_idle) >= REPAIR_IDLE_BATCHES) e->slow_on = false;
+        if (S.ran_sort && (c.sort_count ? (e->sort_idle = 0) : ++e->sort_idle) >= REPAIR_IDLE_BATCHES) e->sort_on = false;
+        S.pending = false;
         bmq_stats& st = e->stats;
         st = bmq_stats{};
-        st.n_topics = e->cur->last.n_topics;
+        st.n_topics = S.last.n_topics;
         st.n_visit = c.n_visit;
         st.n_match = c.total_ids;
         st.n_ranges = c.n_ranges;
         st.n_slow_topics = c.slow_count;
         st.n_sorted_rows = c.sort_count;
         st.topic_bytes = c.topic_bytes;
-        (void)hipEventElapsedTime(&st.ms_total, e->cur->ev[0], e->cur->ev[5]);
-        if (e->cur->timed) {
-            (void)hipEventElapsedTime(&st.ms_walk, e->cur->ev[1], e->cur->ev[2]);
-            (void)hipEventElapsedTime(&st.ms_expand, e->cur->ev[3], e->cur->ev[4]);
+        (void)hipEventElapsedTime(&st.ms_total, S.ev[0], S.ev[5]);
+        if (S.timed) {
+            (void)hipEventElapsedTime(&st.ms_walk, S.ev[1], S.ev[2]);
+            (void)hipEventElapsedTime(&st.ms_expand, S.ev[3], S.ev[4]);
         }
         if (out_total) *out_total = c.total_ids;
         if (c.status & ST_RANGE) return set_err(e, BMQ_E_RANGE, "batch produced >= 2^32 route ids");
@@ -555,7 +557,7 @@ int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off
     std::lock_guard<std::mutex> g(e->mu);
     // a batch handed over with bmq_match_submit is simply in front of the builder kernels on the engine stream; only the
     // caller-driven *_dev protocol (results read by the caller between launch and finish) excludes a mutation in between
-    if (e->cur->pending && !e->cur->submitted) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
+    if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     bool bad_input = false;
     const bool ok = with_index(e, [&](auto& ix) {
@@ -684,7 +686,7 @@ int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t*
     std::lock_guard<std::mutex> g(e->mu);
     if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     HIPCHK(e, hipSetDevice(e->device));
-    if ((rc = ensure_batch_scratch(e, n_tenants, n_topics))) return rc;
+    if ((rc = ensure_batch_scratch(e, *e->cur, n_tenants, n_topics))) return rc;
     BatchArgs a{};
     a.tenants = d_tenants;
     a.tenant_off = d_tenant_off;
@@ -697,7 +699,7 @@ int bmq_match_batch_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t*
     a.out_ids = d_out_route_ids;
     a.out_capacity = d_out_route_ids ? out_capacity : 0;
     a.out_total = (unsigned long long*)d_out_total;
-    rc = launch_dist(e, a);
+    rc = launch_dist(e, *e->cur, a);
     if (rc == BMQ_OK) {
         api_guard.keep = true;
         e->cur->api_held = true;
@@ -714,7 +716,7 @@ int bmq_match_finish(bmq_engine* e, uint64_t* out_total) {
         std::lock_guard<std::mutex> g(e->mu);
         if (!e->cur->pending) return set_err(e, BMQ_E_STATE, "no batch in flight");
         HIPCHK(e, hipSetDevice(e->device));
-        rc = e->cur->pending_kind == 0 ? finish_dist(e, out_total) : retain_finish(e, out_total);
+        rc = e->cur->pending_kind == 0 ? finish_dist(e, *e->cur, out_total) : retain_finish(e, out_total);
         if (rc != BMQ_OK) e->cur->pending = false; // a failed batch is over too: the next launch starts clean
         give_back = e->cur->api_held;
         e->cur->api_held = false;
@@ -824,19 +826,12 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
     HIPCHK(e, hipSetDevice(e->device));
     int k = -1;
     for (int i = 0; i < 2; i++)
-        if (!e->slots[i].pending && !e->slots[i].submitted) {
+        if (!e->slots[1 + i].pending && !e->slots[1 + i].submitted) {
             k = i;
             break;
         }
     if (k < 0) return set_err(e, BMQ_E_STATE, "two batches are already in flight: call bmq_match_wait first");
-    bmq_engine::BatchSlot& S = e->slots[k];
-    bmq_engine::BatchSlot* const prev = e->cur;
-    e->cur = &S;
-    struct Restore {
-        bmq_engine* e;
-        bmq_engine::BatchSlot* p;
-        ~Restore() { e->cur = p; }
-    } restore{e, prev};
+    bmq_engine::BatchSlot& S = e->slots[1 + k]; // ticket k: never the slot the blocking entry points stage into
     const size_t tb = n_tenants ? tenant_off[n_tenants] : 0, pb = topic_off[n_topics];
     HIPCHK(e, S.s_tenants.ensure(tb + 16));
     HIPCHK(e, S.s_topics.ensure(pb + 16));
@@ -847,7 +842,7 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
     HIPCHK(e, S.b_total.ensure(sizeof(unsigned long long)));
     S.dev_cap = std::max<uint64_t>(S.s_ids.cap / 4, std::max<uint64_t>((uint64_t)n_topics * 24, 1024));
     HIPCHK(e, S.s_ids.ensure(S.dev_cap * 4));
-    if ((rc = ensure_batch_scratch(e, n_tenants, n_topics))) return rc;
+    if ((rc = ensure_batch_scratch(e, S, n_tenants, n_topics))) return rc;
     // upload on the copy-in stream: it overlaps the kernels of the batch submitted before (pinned sources: bmq_host_alloc)
     if (n_tenants) {
         HIPCHK(e, hipMemcpyAsync(S.s_tenant_off.p, tenant_off, sizeof(uint32_t) * ((size_t)n_tenants + 1), hipMemcpyHostToDevice, e->s_in));
@@ -870,7 +865,7 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
     a.out_ids = S.s_ids.as<uint32_t>();
     a.out_capacity = S.dev_cap;
     a.out_total = S.b_total.as<unsigned long long>();
-    if ((rc = launch_dist(e, a))) return rc;
+    if ((rc = launch_dist(e, S, a))) return rc;
     S.submitted = true;
     S.n_rows = n_topics;
     *out_ticket = k;
@@ -880,7 +875,7 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
 int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed) {
     if (!e || ticket < 0 || ticket > 1 || !out_row_ptr || !out_needed) return BMQ_E_INVAL;
     if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only");
-    bmq_engine::BatchSlot& S = e->slots[ticket];
+    bmq_engine::BatchSlot& S = e->slots[1 + ticket];
     uint64_t total = 0;
     {
         std::lock_guard<std::mutex> g(e->mu);
@@ -891,10 +886,8 @@ int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* o
     std::unique_lock<std::mutex> g(e->mu);
     int rc = BMQ_OK;
     {
-        bmq_engine::BatchSlot* const prev = e->cur;
-        e->cur = &S;
         for (int attempt = 0; attempt < 3; attempt++) {
-            rc = finish_dist(e, &total); // grows internal scratch and re-runs if a kernel asked for it
+            rc = finish_dist(e, S, &total); // grows internal scratch and re-runs if a kernel asked for it
             if (rc != BMQ_E_NOSPACE || total <= S.dev_cap) break;
             S.dev_cap = total; // the slot's own id buffer was too small: it knows the size now
             if (S.s_ids.ensure(S.dev_cap * 4) != hipSuccess) {
@@ -904,9 +897,8 @@ int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* o
             BatchArgs a = S.last;
             a.out_ids = S.s_ids.as<uint32_t>();
             a.out_capacity = S.dev_cap;
-            if ((rc = launch_dist(e, a))) break;
+            if ((rc = launch_dist(e, S, a))) break;
         }
-        e->cur = prev;
     }
     *out_needed = total;
     const bool fits = total <= out_capacity && (total == 0 || out_route_ids);
@@ -927,6 +919,106 @@ int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* o
     if (he != hipSuccess) return set_err(e, BMQ_E_HIP, std::string("result download: ") + hipGetErrorString(he));
     return fits ? BMQ_OK : set_err(e, BMQ_E_NOSPACE, "output buffer too small");
 }
+
+// ---- MatchedRoutes caps (DW/cache/MatchedRoutes.java:87-141) over rows of route ids ----------------------------------------
+// One row = what matchAll found for one topic.  Persistent (subBrokerId == 1) normal routes and group routes are admitted
+// first-come in KV KEY order up to their caps; every rejected route is a throttle event.  After a rebuild ids are key ranks; routes
+// added since carry later ids, so whenever a cap can bind the row is ordered by key BYTES first.  Keys come from the HBM key store
+// in one gather for all rows.  A row whose length does not exceed either cap cannot be throttled and is not even classified
+// (classified == false: its class counts are unknown, at most its length).
+namespace {
+struct CapEvent {
+    int32_t type; // 0 PersistentFanoutThrottled, 1 GroupFanoutThrottled
+    uint32_t id;
+};
+struct CappedRow {
+    std::vector<uint32_t> kept; // ascending ids
+    std::vector<CapEvent> events;
+    uint32_t n_persistent = 0, n_group = 0; // among kept (only if classified)
+    bool classified = false;
+};
+int cap_rows(bmq_engine* e, const uint32_t* rp, const uint32_t* ids, uint32_t n_rows, int32_t max_pf, int32_t max_gf, std::vector<CappedRow>& out) {
+    out.assign(n_rows, CappedRow{});
+    const int64_t lim = std::min<int64_t>(max_pf, max_gf);
+    std::vector<uint32_t> need_row, g_ids;
+    std::vector<uint64_t> g_rp{0};
+    for (uint32_t r = 0; r < n_rows; r++) {
+        const uint32_t n = rp[r + 1] - rp[r];
+        if ((int64_t)n <= lim) {
+            out[r].kept.assign(ids + rp[r], ids + rp[r + 1]);
+            continue;
+        }
+        need_row.push_back(r);
+        g_ids.insert(g_ids.end(), ids + rp[r], ids + rp[r + 1]);
+        g_rp.push_back(g_ids.size());
+    }
+    if (need_row.empty()) return BMQ_OK;
+    std::vector<uint8_t> kb;
+    std::vector<uint64_t> ko;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+        const bool ok = with_index(e, [&](auto& ix) {
+            const bool r = ix.route_keys(g_ids.data(), (uint32_t)g_ids.size(), kb, ko);
+            if (!r) e->err = ix.error;
+            return r;
+        });
+        if (!ok) return index_error(e, e->err, false);
+    }
+    struct Ent {
+        uint32_t id;
+        uint64_t k;
+        uint8_t cls; // 0 transient normal, 1 persistent normal, 2 group
+    };
+    std::vector<Ent> row;
+    for (uint32_t q = 0; q < need_row.size(); q++) {
+        CappedRow& o = out[need_row[q]];
+        row.clear();
+        int64_t n_pers = 0, n_grp = 0;
+        for (uint64_t k = g_rp[q]; k < g_rp[q + 1]; k++) {
+            const std::string_view key((const char*)kb.data() + ko[k], (size_t)(ko[k + 1] - ko[k]));
+            if (key.empty()) continue; // unsubscribed between the match and this lookup: the route no longer exists
+            RouteKeyParts kp;
+            if (!decode_route_key(key, kp)) return set_err(e, BMQ_E_INVAL, "corrupt key store");
+            uint8_t cls = 2;
+            if (kp.flag == 1) {
+                // subBrokerId = integer prefix of "<brokerId>\0<receiverId>\0<delivererKey>" (SCHEMA/KVSchemaUtil.java:56-58)
+                long broker = 0;
+                size_t p = 0;
+                while (p < kp.receiver.size() && kp.receiver[p] >= '0' && kp.receiver[p] <= '9') broker = broker * 10 + (kp.receiver[p++] - '0');
+                cls = (broker == 1 && p > 0) ? 1 : 0;
+            }
+            n_pers += cls == 1;
+            n_grp += cls == 2;
+            row.push_back({g_ids[k], k, cls});
+        }
+        if (n_pers > (int64_t)max_pf || n_grp > (int64_t)max_gf)
+            std::sort(row.begin(), row.end(), [&](const Ent& x, const Ent& y) {
+                const std::string_view kx((const char*)kb.data() + ko[x.k], (size_t)(ko[x.k + 1] - ko[x.k]));
+                const std::string_view ky((const char*)kb.data() + ko[y.k], (size_t)(ko[y.k + 1] - ko[y.k]));
+                return kx < ky; // std::string_view compares as unsigned bytes, a proper prefix first: KV order
+            });
+        int64_t persistent = 0, groups = 0;
+        for (const Ent& en : row) {
+            int ev_type = -1;
+            if (en.cls == 1) {
+                if (persistent < (int64_t)max_pf) persistent++;
+                else ev_type = 0;
+            } else if (en.cls == 2) {
+                if (groups + 1 <= (int64_t)max_gf) groups++;
+                else ev_type = 1;
+            }
+            if (ev_type < 0) o.kept.push_back(en.id);
+            else o.events.push_back({ev_type, en.id});
+        }
+        o.classified = true;
+        o.n_persistent = (uint32_t)persistent;
+        o.n_group = (uint32_t)groups;
+        std::sort(o.kept.begin(), o.kept.end());
+    }
+    return BMQ_OK;
+}
+} // namespace
 
 // ---- host-side mirror of MatchedRoutes (DW/cache/MatchedRoutes.java:87-141) -------------------------------------------
 int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics, const uint32_t* topic_off,
@@ -961,69 +1053,29 @@ int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, con
         rc = bmq_match_batch(e, tenant, toff, 1, tt.data(), topics, topic_off, n_topics, rp.data(), ids.data(), ids.size(), &need);
     }
     if (rc) return rc;
-    // MatchedRoutes applies its caps first-come in KV KEY order (DW/cache/MatchedRoutes.java:87-141).  After a rebuild ids are
-    // key ranks; routes added since carry later ids, so whenever a cap can bind the row is ordered by key BYTES first.
-    std::vector<uint8_t> kb;
-    std::vector<uint64_t> ko;
-    {
-        std::lock_guard<std::mutex> g(e->mu);
-        HIPCHK(e, hipSetDevice(e->device));
-        if (!e->dix->route_keys(ids.data(), (uint32_t)need, kb, ko)) return set_err(e, BMQ_E_HIP, e->dix->error);
-    }
+    // MatchedRoutes applies its caps first-come in KV KEY order (DW/cache/MatchedRoutes.java:87-141): cap_rows
     std::vector<std::vector<uint32_t>> kept(n_topics);
     uint32_t n_ev = 0;
-    struct Ent {
-        uint32_t id, k;
-        uint8_t cls; // 0 transient normal, 1 persistent normal, 2 group
-    };
-    std::vector<Ent> row;
-    for (uint32_t i = 0; i < n_topics; i++) {
-        if (canon[i] != i) continue;
-        row.clear();
-        int64_t n_pers = 0, n_grp = 0;
-        for (uint32_t k = rp[i]; k < rp[i + 1]; k++) {
-            const std::string_view key((const char*)kb.data() + ko[k], (size_t)(ko[k + 1] - ko[k]));
-            if (key.empty()) continue; // unsubscribed between the match and this lookup: the route no longer exists
-            RouteKeyParts kp;
-            if (!decode_route_key(key, kp)) return set_err(e, BMQ_E_INVAL, "corrupt key store");
-            uint8_t cls = 2;
-            if (kp.flag == 1) {
-                // subBrokerId = integer prefix of "<brokerId>\0<receiverId>\0<delivererKey>" (SCHEMA/KVSchemaUtil.java:56-58)
-                long broker = 0;
-                size_t p = 0;
-                while (p < kp.receiver.size() && kp.receiver[p] >= '0' && kp.receiver[p] <= '9') broker = broker * 10 + (kp.receiver[p++] - '0');
-                cls = (broker == 1 && p > 0) ? 1 : 0;
+    {
+        std::vector<uint32_t> u_rp{0}, u_ids, u_topic; // the distinct topics' rows
+        for (uint32_t i = 0; i < n_topics; i++)
+            if (canon[i] == i) {
+                u_ids.insert(u_ids.end(), ids.begin() + rp[i], ids.begin() + rp[i + 1]);
+                u_rp.push_back((uint32_t)u_ids.size());
+                u_topic.push_back(i);
             }
-            n_pers += cls == 1;
-            n_grp += cls == 2;
-            row.push_back({ids[k], k, cls});
-        }
-        if (n_pers > (int64_t)max_pf || n_grp > (int64_t)max_gf)
-            std::sort(row.begin(), row.end(), [&](const Ent& x, const Ent& y) {
-                const std::string_view kx((const char*)kb.data() + ko[x.k], (size_t)(ko[x.k + 1] - ko[x.k]));
-                const std::string_view ky((const char*)kb.data() + ko[y.k], (size_t)(ko[y.k + 1] - ko[y.k]));
-                return kx < ky; // std::string_view compares as unsigned bytes, a proper prefix first: KV order
-            });
-        int64_t persistent = 0, groups = 0;
-        for (const Ent& en : row) {
-            int ev_type = -1;
-            if (en.cls == 1) {
-                if (persistent < (int64_t)max_pf) persistent++;
-                else ev_type = 0;
-            } else if (en.cls == 2) {
-                if (groups + 1 <= (int64_t)max_gf) groups++;
-                else ev_type = 1;
-            }
-            if (ev_type < 0) kept[i].push_back(en.id);
-            else {
+        std::vector<CappedRow> rows;
+        if ((rc = cap_rows(e, u_rp.data(), u_ids.data(), (uint32_t)u_topic.size(), max_pf, max_gf, rows))) return rc;
+        for (uint32_t u = 0; u < u_topic.size(); u++) {
+            kept[u_topic[u]] = std::move(rows[u].kept);
+            for (const auto& ev : rows[u].events) {
                 if (out_events && n_ev < events_cap) {
-                    int32_t* ev = out_events + 4 * (size_t)n_ev;
-                    ev[0] = ev_type; ev[1] = (int32_t)i; ev[2] = (int32_t)en.id; ev[3] = ev_type == 0 ? max_pf : max_gf;
+                    int32_t* o = out_events + 4 * (size_t)n_ev;
+                    o[0] = ev.type; o[1] = (int32_t)u_topic[u]; o[2] = (int32_t)ev.id; o[3] = ev.type == 0 ? max_pf : max_gf;
                 }
                 n_ev++;
             }
         }
-        std::sort(kept[i].begin(), kept[i].end());
     }
     if (out_n_events) *out_n_events = n_ev;
     uint64_t total = 0;
@@ -1038,6 +1090,37 @@ int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, con
         const auto& v = kept[canon[i]];
         if (!v.empty()) memcpy(out_route_ids + out_row_ptr[i], v.data(), v.size() * 4);
     }
+    return BMQ_OK;
+}
+
+int bmq_routes_cap(bmq_engine* e, const uint32_t* row_ptr, const uint32_t* route_ids, uint32_t n_rows, int32_t max_pf, int32_t max_gf,
+                   uint32_t* out_row_ptr, uint32_t* out_route_ids, uint32_t* out_class_counts, int32_t* out_events, uint32_t events_cap,
+                   uint32_t* out_n_events) {
+    if (!e || !row_ptr || !out_row_ptr || (row_ptr[n_rows] && (!route_ids || !out_route_ids))) return BMQ_E_INVAL;
+    if (out_n_events) *out_n_events = 0;
+    if (!e->built) return set_err(e, BMQ_E_STATE, "bmq_rebuild has not been called");
+    std::vector<CappedRow> rows;
+    const int rc = cap_rows(e, row_ptr, route_ids, n_rows, max_pf, max_gf, rows);
+    if (rc) return rc;
+    uint32_t total = 0, n_ev = 0;
+    for (uint32_t r = 0; r < n_rows; r++) {
+        out_row_ptr[r] = total;
+        if (!rows[r].kept.empty()) memcpy(out_route_ids + total, rows[r].kept.data(), rows[r].kept.size() * 4); // never longer than the input row
+        total += (uint32_t)rows[r].kept.size();
+        if (out_class_counts) {
+            out_class_counts[2 * r] = rows[r].classified ? rows[r].n_persistent : 0xFFFFFFFFu;
+            out_class_counts[2 * r + 1] = rows[r].classified ? rows[r].n_group : 0xFFFFFFFFu;
+        }
+        for (const auto& ev : rows[r].events) {
+            if (out_events && n_ev < events_cap) {
+                int32_t* o = out_events + 4 * (size_t)n_ev;
+                o[0] = ev.type; o[1] = (int32_t)r; o[2] = (int32_t)ev.id; o[3] = ev.type == 0 ? max_pf : max_gf;
+            }
+            n_ev++;
+        }
+    }
+    out_row_ptr[n_rows] = total;
+    if (out_n_events) *out_n_events = n_ev;
     return BMQ_OK;
 }
 

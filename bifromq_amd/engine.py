@@ -324,6 +324,21 @@ class Engine:
             events = [tuple(int(x) for x in ev[4 * i:4 * i + 4]) for i in range(nev.value)]
             return [ids[row[i]:row[i + 1]].tolist() for i in range(n)], events
 
+    def routes_cap(self, row_ptr, route_ids, max_persistent_fanout: int, max_group_fanout: int):
+        """bmq_routes_cap: MatchedRoutes' caps over rows already matched
+        -> (per-row id lists, per-row (persistent, group) counts, events [(type, row, route id, max)])"""
+        row = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        ids = np.ascontiguousarray(route_ids, dtype=np.uint32)
+        n = len(row) - 1
+        o_row, o_ids = np.zeros(n + 1, dtype=np.uint32), np.zeros(max(1, len(ids)), dtype=np.uint32)
+        cls = np.zeros(2 * max(n, 1), dtype=np.uint32)
+        ev = np.zeros(4 * max(1, len(ids)), dtype=np.int32)
+        nev = C.c_uint32()
+        self._check(_lib.lib().bmq_routes_cap(self.h, _ptr(row), _ptr(ids), n, max_persistent_fanout, max_group_fanout, _ptr(o_row), _ptr(o_ids),
+                                              _ptr(cls), _ptr(ev), len(ids), C.byref(nev)))
+        return ([o_ids[o_row[i]:o_row[i + 1]].tolist() for i in range(n)], [(int(cls[2 * i]), int(cls[2 * i + 1])) for i in range(n)],
+                [tuple(int(x) for x in ev[4 * i:4 * i + 4]) for i in range(nev.value)])
+
     # ---- match (device-resident; torch tensors are only carriers of device pointers) ----------------------
     def match_batch_device(self, d_tenants, d_tenant_off, n_tenants, d_topic_tenant, d_topics, d_topic_off, n_topics,
                            d_row_ptr, d_ids, capacity, d_total):
@@ -594,13 +609,20 @@ class RouteCache:
     """bmq_route_cache_*: ISubscriptionCache (DW/cache/ISubscriptionCache.java:30-40) on the engine's side of the boundary -- topic ->
     matched routes per tenant, loads through the batching front, TopicIndex-style invalidation by route mutations."""
 
-    def __init__(self, batcher: Batcher, max_routes_per_tenant: int = 0, expiry_ms: int = 0, mutation_log_entries: int = 0, shards_per_tenant: int = 0):
+    def __init__(self, batcher: Batcher, max_routes_per_tenant: int = 0, expiry_ms: int = 0, mutation_log_entries: int = 0, shards_per_tenant: int = 0,
+                 max_persistent_fanout: int = 0, max_group_fanout: int = 0, tenant_idle_ms: int = 0, direct_batch_topics: int = 0):
+        """max_persistent_fanout / max_group_fanout: the default caps of tenants without set_caps (0 = the reference's defaults,
+        Setting.java:60-61: INT_MAX / 100)"""
         cfg = _lib.RouteCacheConfig()
         cfg.struct_size = C.sizeof(_lib.RouteCacheConfig)
         cfg.max_routes_per_tenant = max_routes_per_tenant
         cfg.expiry_ms = expiry_ms
         cfg.mutation_log_entries = mutation_log_entries
         cfg.shards_per_tenant = shards_per_tenant
+        cfg.default_max_persistent_fanout = max_persistent_fanout
+        cfg.default_max_group_fanout = max_group_fanout
+        cfg.tenant_idle_ms = tenant_idle_ms
+        cfg.direct_batch_topics = direct_batch_topics
         h = C.c_void_p()
         rc = _lib.lib().bmq_route_cache_create(batcher.engine.h, batcher.h, C.byref(cfg), C.byref(h))
         if rc:
@@ -711,6 +733,35 @@ class RouteCache:
         st = _lib.RouteCacheStats()
         self._check(_lib.lib().bmq_route_cache_stats_get(self.h, C.byref(st)), "bmq_route_cache_stats_get")
         return st
+
+    def tenant_stats(self, tenant) -> Optional["_lib.RouteCacheTenantStats"]:
+        """the tenant's meters (TenantRouteCache.java:141-147), or None when the tenant has no cache"""
+        t = _b(tenant)
+        st = _lib.RouteCacheTenantStats()
+        rc = _lib.lib().bmq_route_cache_tenant_stats_get(self.h, t, len(t), C.byref(st))
+        if rc == -7:
+            return None
+        self._check(rc, "bmq_route_cache_tenant_stats_get")
+        return st
+
+    def set_caps(self, tenant, max_persistent_fanout: int, max_group_fanout: int):
+        """the tenant's MaxPersistentFanout / MaxGroupFanout settings"""
+        t = _b(tenant)
+        self._check(_lib.lib().bmq_route_cache_set_caps(self.h, t, len(t), max_persistent_fanout, max_group_fanout), "bmq_route_cache_set_caps")
+
+    EVENT_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_int32, C.c_uint32, C.c_int32)
+
+    def collect_events(self) -> list:
+        """installs an event sink (IEventCollector) that appends (tenant, topic, type, route id, max count) to the returned list;
+        type 0 = PersistentFanoutThrottled, 1 = GroupFanoutThrottled"""
+        events: list = []
+
+        def sink(_user, tenant, tl, topic, pl, typ, rid, mx):
+            events.append((bytes(tenant[:tl]), bytes(topic[:pl]), int(typ), int(rid), int(mx)))
+
+        self._event_cb = RouteCache.EVENT_CB(sink)  # kept alive with the cache
+        self._check(_lib.lib().bmq_route_cache_set_event_sink(self.h, C.cast(self._event_cb, C.c_void_p), None), "bmq_route_cache_set_event_sink")
+        return events
 
     def drive(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed: Tuple[np.ndarray, np.ndarray], n_threads: int, passes: int = 2,
               asynchronous: bool = False):

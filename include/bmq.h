@@ -252,11 +252,18 @@ int bmq_batcher_stats_get(bmq_batcher* b, bmq_batcher_stats* out);
 /* ---- route cache ---------------------------------------------------------------------------------- */
 /* ISubscriptionCache (DW/cache/ISubscriptionCache.java:30-40) on the engine's side of the boundary: SubscriptionCache ->
  * TenantRouteCache (DW/cache/TenantRouteCache.java:116-296: topic -> matched routes, loaded by matchAll(singleton(topic)), bounded by
- * DistMaxCachedRoutesPerTenant with weight max(1, #routes), expireAfterAccess DistTopicMatchExpirySeconds) with its TopicIndex
+ * DistMaxCachedRoutesPerTenant with weight max(1, #routes after the caps), expireAfterAccess DistTopicMatchExpirySeconds) with its TopicIndex
  * (DW/TopicIndex.java:39-156: the cached topics, queried with the topic filter of a route mutation).  A hit is answered on the host;
  * a miss goes through the batching front, i.e. into ONE GPU launch with every other miss of the moment.
- *   get       ISubscriptionCache.get(tenantId, topic): the matched route ids (ascending; caps not applied), *out_epoch = the engine
- *             epoch they were matched at.  now_ms is the caller's clock (Caffeine's Ticker).  BMQ_E_NOSPACE + *out_n if cap is short.
+ *   get       ISubscriptionCache.get(tenantId, topic) = IMatchedRoutes.routes() (DW/cache/TenantRouteCache.java:299-301): the matched
+ *             route ids (ascending) AFTER MatchedRoutes' fan-out caps (DW/cache/MatchedRoutes.java:87-141: persistent and group routes
+ *             admitted first-come in KV key order), *out_epoch = the engine epoch they were matched at.  The caps are the tenant's
+ *             (bmq_route_cache_set_caps; defaults of Setting.java:60-61: MaxPersistentFanout = INT_MAX, MaxGroupFanout = 100); every route
+ *             a load throws away is reported to the event sink (bmq_route_cache_set_event_sink) before the load returns; a hit reports
+ *             nothing (the reference reports when it loads, too).  An entry met under caps other than the ones it was loaded with follows
+ *             MatchedRoutes.adjust (:150-200): it is re-matched when a raised cap could admit more routes or a lowered one is exceeded,
+ *             else it adopts the new caps.  The cache weighs an entry by its capped size (TenantRouteCache.java:108).
+ *             now_ms is the caller's clock (Caffeine's Ticker).  BMQ_E_NOSPACE + *out_n if cap is short.
  *   is_cached ISubscriptionCache.isCached(tenantId, filterLevels) = !index.match(filterLevels).isEmpty(): 1 / 0
  *   apply     ISubscriptionCache.refresh(AddRoutesTask / RemoveRoutesTask): bmq_routes_apply on the engine, then every cached topic
  *             one of the mutated filters matches is dropped and reloads on its next get (the reference patches those entries in
@@ -273,16 +280,29 @@ typedef struct bmq_route_cache_config {
     uint64_t max_routes_per_tenant;  /* DistMaxCachedRoutesPerTenant, default 200000 */
     uint64_t expiry_ms;              /* DistTopicMatchExpirySeconds, default 60000 */
     uint64_t shards_per_tenant;      /* power of two, default 16: a tenant's topics are spread over that many independently locked */
-                                     /* slices (each with 1/n of the route budget), so one hot tenant does not serialise its callers */
+                                     /* slices, so one hot tenant does not serialise its callers; the route budget is the tenant's */
     uint64_t direct_batch_topics;    /* bmq_route_cache_get_batch: a request of at least this many topics (default 8192) is matched in one */
                                      /* launch without consulting or filling the cache -- at that size the GPU is faster than the probes */
-    uint64_t reserved[2];
+    int32_t default_max_persistent_fanout; /* MaxPersistentFanout of tenants without bmq_route_cache_set_caps; 0 = INT_MAX (Setting.java:61) */
+    int32_t default_max_group_fanout;      /* MaxGroupFanout ...; 0 = 100 (Setting.java:60) */
+    uint64_t tenant_idle_ms;         /* a tenant nobody called get for since that long loses its whole cache at the next bmq_route_cache_expire */
+                                     /* (DW/cache/SubscriptionCache.java:79-107); 0 = 2 x expiry_ms, as there */
 } bmq_route_cache_config;
 typedef struct bmq_route_cache_stats {
     uint64_t hits, misses, evictions, invalidations, expired;
     uint64_t stale_loads;            /* loads overtaken by a mutation of a matching filter: returned to their caller, not cached */
     uint64_t entries, cached_routes; /* now */
+    uint64_t tenants;                /* tenant caches alive now */
+    uint64_t tenants_expired;        /* tenant caches destroyed after tenant_idle_ms without a get (their counters stay in the sums above) */
 } bmq_route_cache_stats;
+/* What TenantRouteCache registers per tenant (DW/cache/TenantRouteCache.java:141-147: MqttRouteCacheHitCount / MissCount / EvictCount
+ * counters, MqttRouteCacheSize gauge); like there, the meters go when the tenant's cache is destroyed. */
+typedef struct bmq_route_cache_tenant_stats {
+    uint64_t hits, misses, evictions;
+    uint64_t entries, cached_routes; /* estimatedSize, current weight */
+    uint64_t last_get_ms;
+    int32_t max_persistent_fanout, max_group_fanout; /* the caps in force */
+} bmq_route_cache_tenant_stats;
 int bmq_route_cache_create(bmq_engine* e, bmq_batcher* b, const bmq_route_cache_config* cfg /* may be NULL */, bmq_route_cache** out);
 void bmq_route_cache_destroy(bmq_route_cache* c);
 int bmq_route_cache_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len, uint64_t now_ms,
@@ -310,9 +330,25 @@ int bmq_route_cache_rebuild(bmq_route_cache* c, const uint8_t* keys, const uint3
 int bmq_route_cache_reset(bmq_route_cache* c);
 /* Caffeine expires idle entries from a scheduler thread (TenantRouteCache.java:104-114: expireAfterAccess + Scheduler.systemScheduler());
  * here get() drops an expired entry when it meets one and this sweep -- to be called now and then by the owner -- drops the rest: every entry
- * not accessed for expiry_ms at now_ms.  *out_dropped (may be NULL) = entries dropped. */
+ * not accessed for expiry_ms at now_ms -- and every TENANT nobody called get for since tenant_idle_ms, whole (SubscriptionCache.java:79-107:
+ * the tenant cache expires 2 x the match expiry after its last get; isCached / refresh do not count).  *out_dropped (may be NULL) =
+ * entries dropped. */
 int bmq_route_cache_expire(bmq_route_cache* c, uint64_t now_ms, uint64_t* out_dropped);
 int bmq_route_cache_stats_get(bmq_route_cache* c, bmq_route_cache_stats* out);
+/* BMQ_E_STATE: the tenant has no cache (nothing loaded for it yet, or destroyed after tenant_idle_ms) */
+int bmq_route_cache_tenant_stats_get(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, bmq_route_cache_tenant_stats* out);
+/* The tenant's MaxPersistentFanout / MaxGroupFanout (ISettingProvider.provide(..., tenantId), asked per task loop in
+ * DW/cache/TenantRouteCache.java:174-175 and again on every fan-out check, :124-138).  Takes effect with the next get: cached rows the
+ * change can affect are re-matched, the others adopt the new caps (MatchedRoutes.adjust).  Survives the tenant cache's expiry. */
+int bmq_route_cache_set_caps(bmq_route_cache* c, const uint8_t* tenant, uint32_t tenant_len, int32_t max_persistent_fanout,
+                             int32_t max_group_fanout);
+/* IEventCollector.report(PersistentFanoutThrottled / GroupFanoutThrottled) (DW/cache/MatchedRoutes.java:95-101,124-130): called once
+ * per route a load rejects -- type 0 = PersistentFanoutThrottled, 1 = GroupFanoutThrottled; route_id's key gives mqttTopicFilter
+ * (bmq_route_key) -- on the thread that completes the load (the caller of get / get_batch, the batcher's dispatcher thread for
+ * get_async), before the rows are handed out.  NULL switches reporting off.  Set it before the getters start. */
+typedef void (*bmq_route_cache_event_cb)(void* user, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len,
+                                         int32_t type, uint32_t route_id, int32_t max_count);
+int bmq_route_cache_set_event_sink(bmq_route_cache* c, bmq_route_cache_event_cb cb, void* user);
 
 /* ---- host-side mirror of MatchedRoutes (fan-out caps in KV order) -------------------------------------- */
 /* One ITenantRouteMatcher.matchAll(topics, maxPersistentFanout, maxGroupFanout) call for one tenant,
@@ -323,6 +359,15 @@ int bmq_match_all(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, con
                   const uint32_t* topic_off, uint32_t n_topics, int32_t max_persistent_fanout,
                   int32_t max_group_fanout, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
                   uint64_t* out_needed, int32_t* out_events, uint32_t events_cap, uint32_t* out_n_events);
+
+/* MatchedRoutes (DW/cache/MatchedRoutes.java:87-141) over rows somebody else matched (the route cache caps what the batching front
+ * loaded): row r = route_ids[row_ptr[r] .. row_ptr[r + 1]).  out_row_ptr[n_rows + 1] / out_route_ids (at least row_ptr[n_rows] ids) = the
+ * rows after the caps, ascending ids; out_class_counts (may be NULL) [2 r] / [2 r + 1] = persistent / group routes kept in row r, or
+ * 0xFFFFFFFF when the row was not longer than either cap and therefore never classified; events as in bmq_match_all with the row
+ * index in place of the topic index.  Ids of routes deleted since the match are dropped from classified rows. */
+int bmq_routes_cap(bmq_engine* e, const uint32_t* row_ptr, const uint32_t* route_ids, uint32_t n_rows, int32_t max_persistent_fanout,
+                   int32_t max_group_fanout, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint32_t* out_class_counts,
+                   int32_t* out_events, uint32_t events_cap, uint32_t* out_n_events);
 
 /* ---- fan-out grouping: the step behind the match --------------------------------------------------------------- */
 /* DistWorkerCoProc.batchDist hands every topic's matched routes to DeliverExecutorGroup.submit (DW/DeliverExecutorGroup.java:112-241);

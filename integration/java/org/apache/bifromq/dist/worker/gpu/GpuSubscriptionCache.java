@@ -8,10 +8,15 @@
  * on the native side (bmq_route_cache_*: include/bmq.h): get() is one JNI call -- a hit is answered from host memory, a miss joins
  * the GPU launch that carries every other miss of the moment -- and refresh() hands the mutated route keys to the engine, which
  * applies them to the HBM-resident index and drops the cached topics their filters match.
- * What stays Java: turning route ids into Matching objects (GpuTenantRouteMatcher.RangeIndex.resolve, cached per generation) and the
- * MatchedRoutes fan-out caps (fed in KV key order, as today).
+ * The MatchedRoutes fan-out caps (MatchedRoutes.java:87-141) are applied natively too, in KV key order, when a row is loaded: what
+ * get() returns is IMatchedRoutes.routes() (TenantRouteCache.java:299-301).  This class hands the tenant's MaxPersistentFanout /
+ * MaxGroupFanout settings down (routeCacheSetCaps; a changed setting re-matches exactly the cached rows MatchedRoutes.adjust would reload)
+ * and forwards the throttle events of every load to the IEventCollector.
+ * What stays Java: turning route ids into Matching objects (GpuTenantRouteMatcher.RangeIndex.resolve, cached per generation).
  */
 package org.apache.bifromq.dist.worker.gpu;
+
+import static org.apache.bifromq.plugin.eventcollector.ThreadLocalEventPool.getLocal;
 
 import java.nio.ByteBuffer;
 import java.nio.ByteOrder;
@@ -22,6 +27,7 @@ import java.util.List;
 import java.util.Map;
 import java.util.Set;
 import java.util.concurrent.CompletableFuture;
+import java.util.concurrent.ConcurrentHashMap;
 import java.util.concurrent.Executor;
 import org.apache.bifromq.basekv.proto.Boundary;
 import org.apache.bifromq.dist.worker.cache.ISubscriptionCache;
@@ -29,6 +35,11 @@ import org.apache.bifromq.dist.worker.cache.task.AddRoutesTask;
 import org.apache.bifromq.dist.worker.cache.task.RefreshEntriesTask;
 import org.apache.bifromq.dist.worker.schema.KVSchemaUtil;
 import org.apache.bifromq.dist.worker.schema.cache.Matching;
+import org.apache.bifromq.plugin.eventcollector.IEventCollector;
+import org.apache.bifromq.plugin.eventcollector.distservice.GroupFanoutThrottled;
+import org.apache.bifromq.plugin.eventcollector.distservice.PersistentFanoutThrottled;
+import org.apache.bifromq.plugin.settingprovider.ISettingProvider;
+import org.apache.bifromq.plugin.settingprovider.Setting;
 import org.apache.bifromq.type.RouteMatcher;
 
 final class GpuSubscriptionCache implements ISubscriptionCache {
@@ -38,11 +49,38 @@ final class GpuSubscriptionCache implements ISubscriptionCache {
     private static final ThreadLocal<IntBuffer> IDS =
         ThreadLocal.withInitial(() -> ByteBuffer.allocateDirect(4 * 4096).order(ByteOrder.nativeOrder()).asIntBuffer());
 
-    GpuSubscriptionCache(GpuTenantRouteMatcher.RangeIndex index, Executor matchExecutor) {
+    private final ISettingProvider settingProvider;
+    private final ConcurrentHashMap<String, Long> capsSent = new ConcurrentHashMap<>(); // tenant -> (maxPF << 32 | maxGF) last handed down
+
+    GpuSubscriptionCache(GpuTenantRouteMatcher.RangeIndex index, ISettingProvider settingProvider, IEventCollector eventCollector,
+                         Executor matchExecutor) {
         this.index = index;
+        this.settingProvider = settingProvider;
         this.matchExecutor = matchExecutor;
         // 0, 0: DistMaxCachedRoutesPerTenant (200 000) and DistTopicMatchExpirySeconds (60 s), the reference's defaults
         this.cache = NativeMatcher.routeCacheCreate(index.engine, index.batcher, 0, 0);
+        // MatchedRoutes.java:95-101,124-130: every route a load throws away is reported, with the filter of the rejected route
+        NativeMatcher.routeCacheSetEventSink(cache, (tenant, topic, type, routeId, maxCount) -> {
+            String tenantId = new String(tenant, StandardCharsets.UTF_8);
+            String tp = new String(topic, StandardCharsets.UTF_8);
+            IntBuffer one = IntBuffer.wrap(new int[] {routeId});
+            index.resolve(one, 0, 1).forEach(e -> eventCollector.report(type == 0
+                ? getLocal(PersistentFanoutThrottled.class).tenantId(tenantId).topic(tp).mqttTopicFilter(e.matching().mqttTopicFilter())
+                    .maxCount(maxCount)
+                : getLocal(GroupFanoutThrottled.class).tenantId(tenantId).topic(tp).mqttTopicFilter(e.matching().mqttTopicFilter())
+                    .maxCount(maxCount)));
+        });
+    }
+
+    /** TenantRouteCache.java:174-175 asks the setting provider per task loop; a changed answer is handed down before the get. */
+    private void syncCaps(String tenantId, byte[] tn) {
+        int pf = settingProvider.provide(Setting.MaxPersistentFanout, tenantId);
+        int gf = settingProvider.provide(Setting.MaxGroupFanout, tenantId);
+        long packed = ((long) pf << 32) | (gf & 0xFFFFFFFFL);
+        Long prev = capsSent.put(tenantId, packed);
+        if (prev == null || prev != packed) {
+            NativeMatcher.routeCacheSetCaps(cache, tn, pf, gf);
+        }
     }
 
     /** SubscriptionCache.get (SubscriptionCache.java:117-122): the matched routes of (tenant, topic). */
@@ -52,7 +90,9 @@ final class GpuSubscriptionCache implements ISubscriptionCache {
         // moment and completes from the batching front's dispatcher thread -- no matcher thread is parked meanwhile (the reference parks one
         // per miss: TenantRouteCache.java:180-193).  Resolving ids to Matching objects may touch the KV store: handed to matchExecutor.
         CompletableFuture<int[]> ids = new CompletableFuture<>();
-        NativeMatcher.routeCacheGetAsync(cache, tenantId.getBytes(StandardCharsets.UTF_8), topic.getBytes(StandardCharsets.UTF_8),
+        byte[] tnBytes = tenantId.getBytes(StandardCharsets.UTF_8);
+        syncCaps(tenantId, tnBytes);
+        NativeMatcher.routeCacheGetAsync(cache, tnBytes, topic.getBytes(StandardCharsets.UTF_8),
             System.currentTimeMillis(), (status, routeIds, epoch) -> {
                 if (status == 0) {
                     ids.complete(routeIds);
@@ -74,6 +114,7 @@ final class GpuSubscriptionCache implements ISubscriptionCache {
     Set<Matching> getBlocking(String tenantId, String topic) {
         byte[] tn = tenantId.getBytes(StandardCharsets.UTF_8);
         byte[] tp = topic.getBytes(StandardCharsets.UTF_8);
+        syncCaps(tenantId, tn);
         long[] epoch = new long[1];
         IntBuffer ids = IDS.get();
         long n = NativeMatcher.routeCacheGet(cache, tn, tp, System.currentTimeMillis(), ids, epoch);
@@ -148,7 +189,13 @@ final class GpuSubscriptionCache implements ISubscriptionCache {
                     o.put(i, off.get(i));
                 }
                 off = o;
-                ops = grow(ops, 2 * ops.capacity());
+                // ops is written with absolute puts (its position stays 0): copy by index -- a flip()-based copy would copy nothing
+                // and turn every earlier delete into a put
+                ByteBuffer g = ByteBuffer.allocateDirect(2 * ops.capacity());
+                for (int i = 0; i < n; i++) {
+                    g.put(i, ops.get(i));
+                }
+                ops = g;
             }
             key.copyTo(bytes);
             ops.put(n, op);

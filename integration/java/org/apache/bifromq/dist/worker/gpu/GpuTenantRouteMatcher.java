@@ -59,9 +59,10 @@ final class GpuTenantRouteMatcher implements ITenantRouteMatcher {
         /** Post-commit closure of DistWorkerCoProc.mutate (:188-209): added / removed route keys, in commit order. */
         void refresh(ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n) {
             NativeMatcher.routesApply(engine, keys, keyOff, ops, n);
-            // a re-subscribe keeps its id but may carry a new incarnation: forget the cached Matching of the keys just put
-            // (the cache is keyed by id; resolving the few put keys again is cheaper than tracking them here)
-            entries.values().removeIf(e -> e.matching() == null);
+            // a re-subscribe keeps its id but may carry a new incarnation (or a new RouteGroup value): the Matching resolved for
+            // that id before is stale.  The cache is keyed by id and the put keys' ids are not known here, so everything resolved
+            // so far is dropped; the next resolve() gathers what it needs again in one native call.
+            entries.clear();
         }
 
         /** After route keys were re-put through another path (GpuSubscriptionCache.refresh): drop what was resolved before. */

@@ -139,6 +139,22 @@ final class NativeMatcher {
 
     static native void routeCacheReset(long cache);
 
-    /** Drops the entries idle for expiryMs (what Caffeine's scheduler thread does); call it from a timer. @return entries dropped */
+    /**
+     * Drops the entries idle for expiryMs (what Caffeine's scheduler thread does) and the whole cache of every tenant nobody asked
+     * about for 2 x expiryMs (SubscriptionCache.java:79-107); call it from a timer. @return entries dropped
+     */
     static native long routeCacheExpire(long cache, long nowMs);
+
+    /** The tenant's MaxPersistentFanout / MaxGroupFanout (ISettingProvider): rows are capped natively, in KV key order. */
+    static native void routeCacheSetCaps(long cache, byte[] tenant, int maxPersistentFanout, int maxGroupFanout);
+
+    /** IEventCollector.report for the routes a load throws away: type 0 = PersistentFanoutThrottled, 1 = GroupFanoutThrottled. */
+    interface ThrottleSink {
+        void onThrottle(byte[] tenant, byte[] topic, int type, int routeId, int maxCount);
+    }
+
+    static native void routeCacheSetEventSink(long cache, ThrottleSink sink);
+
+    /** out[0..4] = hits, misses, evictions, entries, cached routes of the tenant (TenantRouteCache.java:141-147); false: no cache. */
+    static native boolean routeCacheTenantStats(long cache, byte[] tenant, long[] out);
 }

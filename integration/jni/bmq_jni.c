@@ -10,6 +10,7 @@
 #else
 #include "jni_min.h"
 #endif
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -453,26 +454,45 @@ JNIEXPORT jlong JNICALL NM(routeCacheExpire)(JNIEnv* env, jclass c, jlong h, jlo
  * batching front's dispatcher thread for a miss -- that thread is attached to the JVM as a daemon the first time it calls back.  The Java
  * side completes a CompletableFuture in onRoutes (GpuSubscriptionCache.get). */
 static JavaVM* g_vm;
+/* A native thread this file attached to the JVM (the batching front's dispatcher) is detached again when it exits: the key's destructor
+ * runs at thread exit, i.e. inside bmq_batcher_destroy's join.  Threads that were Java threads all along are never detached. */
+static pthread_key_t g_detach_key;
+static pthread_once_t g_detach_once = PTHREAD_ONCE_INIT;
+static void detach_at_exit(void* vm) {
+    if (vm) (*(JavaVM*)vm)->DetachCurrentThread((JavaVM*)vm);
+}
+static void make_detach_key(void) { (void)pthread_key_create(&g_detach_key, detach_at_exit); }
+/* the JNIEnv of the current thread, attaching it (as a daemon) if it is not a Java thread yet; NULL: no JVM to call into */
+static JNIEnv* env_of_this_thread(void) {
+    JNIEnv* env = NULL;
+    if (!g_vm) return NULL;
+    if ((*g_vm)->GetEnv(g_vm, (void**)&env, JNI_VERSION_1_8) == JNI_OK) return env;
+    if ((*g_vm)->AttachCurrentThreadAsDaemon(g_vm, (void**)&env, NULL) != JNI_OK) return NULL;
+    (void)pthread_once(&g_detach_once, make_detach_key);
+    (void)pthread_setspecific(g_detach_key, (void*)g_vm);
+    return env;
+}
 typedef struct async_ctx {
     jobject cb; /* global ref */
 } async_ctx;
+static jmethodID g_on_routes; /* RouteCallback.onRoutes(I[IJ)V, looked up once (all callbacks implement the one interface) */
 static void async_done(void* user, int status, const uint32_t* ids, uint32_t n, uint64_t epoch) {
     async_ctx* a = (async_ctx*)user;
-    JNIEnv* env = NULL;
-    if ((*g_vm)->GetEnv(g_vm, (void**)&env, JNI_VERSION_1_8) != JNI_OK && (*g_vm)->AttachCurrentThreadAsDaemon(g_vm, (void**)&env, NULL) != JNI_OK) {
-        free(a); /* no JVM to call back into: the future stays incomplete, as it would on any lost thread */
+    JNIEnv* env = env_of_this_thread();
+    if (!env) {
+        free(a); /* no JVM to call back into: the future stays incomplete, as it would on any lost thread (the global ref dies with the JVM) */
         return;
     }
-    jclass cls = (*env)->GetObjectClass(env, a->cb);
-    jmethodID m = (*env)->GetMethodID(env, cls, "onRoutes", "(I[IJ)V");
     jintArray arr = (*env)->NewIntArray(env, (jsize)n);
-    if (m && arr) {
+    if (g_on_routes && arr) {
         if (n) (*env)->SetIntArrayRegion(env, arr, 0, (jsize)n, (const jint*)ids);
-        (*env)->CallVoidMethod(env, a->cb, m, (jint)status, arr, (jlong)epoch);
-        if ((*env)->ExceptionCheck(env)) (*env)->ExceptionClear(env); /* a throwing callback must not poison the dispatcher thread */
+        (*env)->CallVoidMethod(env, a->cb, g_on_routes, (jint)status, arr, (jlong)epoch);
+    } else if (g_on_routes) { /* out of Java heap for the id array: complete the future exceptionally rather than never */
+        if ((*env)->ExceptionCheck(env)) (*env)->ExceptionClear(env);
+        (*env)->CallVoidMethod(env, a->cb, g_on_routes, (jint)BMQ_E_NOMEM, (jintArray)NULL, (jlong)epoch);
     }
+    if ((*env)->ExceptionCheck(env)) (*env)->ExceptionClear(env); /* a throwing callback must not poison the dispatcher thread */
     if (arr) (*env)->DeleteLocalRef(env, arr);
-    (*env)->DeleteLocalRef(env, cls);
     (*env)->DeleteGlobalRef(env, a->cb);
     free(a);
 }
@@ -485,6 +505,20 @@ JNIEXPORT void JNICALL NM(routeCacheGetAsync)(JNIEnv* env, jclass c, jlong h, jb
         return;
     }
     a->cb = (*env)->NewGlobalRef(env, cb);
+    if (!a->cb) { /* out of memory for the reference: an OutOfMemoryError is pending */
+        free(a);
+        return;
+    }
+    if (!g_on_routes) {
+        jclass cls = (*env)->GetObjectClass(env, cb);
+        g_on_routes = (*env)->GetMethodID(env, cls, "onRoutes", "(I[IJ)V");
+        (*env)->DeleteLocalRef(env, cls);
+        if (!g_on_routes) { /* NoSuchMethodError is pending */
+            (*env)->DeleteGlobalRef(env, a->cb);
+            free(a);
+            return;
+        }
+    }
     const jsize tl = (*env)->GetArrayLength(env, tenant), pl = (*env)->GetArrayLength(env, topic);
     jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
     jbyte* tp = (*env)->GetByteArrayElements(env, topic, NULL);
@@ -496,4 +530,74 @@ JNIEXPORT void JNICALL NM(routeCacheGetAsync)(JNIEnv* env, jclass c, jlong h, jb
         free(a);
         throw_state(env, NULL, "bmq_route_cache_get_async", rc);
     }
+}
+
+/* ---- fan-out caps and meters of the route cache -------------------------------------------------------------------------------------- */
+/* void routeCacheSetCaps(long cache, byte[] tenant, int maxPersistentFanout, int maxGroupFanout)
+ * ISettingProvider.provide(MaxPersistentFanout / MaxGroupFanout, tenantId) handed down (TenantRouteCache.java:174-175, 124-138) */
+JNIEXPORT void JNICALL NM(routeCacheSetCaps)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jint maxPersistentFanout, jint maxGroupFanout) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    const int rc = bmq_route_cache_set_caps(CACHE(h), (const uint8_t*)tn, (uint32_t)tl, maxPersistentFanout, maxGroupFanout);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    if (rc != BMQ_OK) throw_state(env, NULL, "bmq_route_cache_set_caps", rc);
+}
+/* void routeCacheSetEventSink(long cache, ThrottleSink sink)
+ * sink.onThrottle(byte[] tenant, byte[] topic, int type, int routeId, int maxCount) is IEventCollector.report(PersistentFanoutThrottled
+ * (type 0) / GroupFanoutThrottled (type 1)), MatchedRoutes.java:95-101,124-130; it runs on the thread that completes the load (a Java
+ * matcher thread, or the dispatcher thread of the batching front).  One sink per process (a global ref that lives as long as the JVM). */
+static jobject g_sink;
+static jmethodID g_on_throttle;
+static void throttle_event(void* user, const uint8_t* tenant, uint32_t tl, const uint8_t* topic, uint32_t pl, int32_t type, uint32_t route_id,
+                           int32_t max_count) {
+    (void)user;
+    JNIEnv* env = env_of_this_thread();
+    if (!env || !g_sink || !g_on_throttle) return;
+    jbyteArray jt = (*env)->NewByteArray(env, (jsize)tl), jp = (*env)->NewByteArray(env, (jsize)pl);
+    if (jt && jp) {
+        if (tl) (*env)->SetByteArrayRegion(env, jt, 0, (jsize)tl, (const jbyte*)tenant);
+        if (pl) (*env)->SetByteArrayRegion(env, jp, 0, (jsize)pl, (const jbyte*)topic);
+        (*env)->CallVoidMethod(env, g_sink, g_on_throttle, jt, jp, (jint)type, (jint)route_id, (jint)max_count);
+    }
+    if ((*env)->ExceptionCheck(env)) (*env)->ExceptionClear(env);
+    if (jt) (*env)->DeleteLocalRef(env, jt);
+    if (jp) (*env)->DeleteLocalRef(env, jp);
+}
+JNIEXPORT void JNICALL NM(routeCacheSetEventSink)(JNIEnv* env, jclass c, jlong h, jobject sink) {
+    (void)c;
+    if (!g_vm) (*env)->GetJavaVM(env, &g_vm);
+    if (!sink) {
+        (void)bmq_route_cache_set_event_sink(CACHE(h), NULL, NULL);
+        return;
+    }
+    if (!g_sink) {
+        jclass cls = (*env)->GetObjectClass(env, sink);
+        g_on_throttle = (*env)->GetMethodID(env, cls, "onThrottle", "([B[BIII)V");
+        (*env)->DeleteLocalRef(env, cls);
+        if (!g_on_throttle) return; /* NoSuchMethodError is pending */
+        g_sink = (*env)->NewGlobalRef(env, sink);
+        if (!g_sink) return; /* OutOfMemoryError is pending */
+    }
+    const int rc = bmq_route_cache_set_event_sink(CACHE(h), throttle_event, NULL);
+    if (rc != BMQ_OK) throw_state(env, NULL, "bmq_route_cache_set_event_sink", rc);
+}
+/* boolean routeCacheTenantStats(long cache, byte[] tenant, long[] out)     out[0..4] = hits, misses, evictions, entries, cached routes --
+ * the MqttRouteCacheHitCount / MissCount / EvictCount counters and the MqttRouteCacheSize gauge of TenantRouteCache.java:141-147;
+ * false: the tenant has no cache (its meters went with it) */
+JNIEXPORT jboolean JNICALL NM(routeCacheTenantStats)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jlongArray out) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    bmq_route_cache_tenant_stats st;
+    const int rc = bmq_route_cache_tenant_stats_get(CACHE(h), (const uint8_t*)tn, (uint32_t)tl, &st);
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    if (rc == BMQ_E_STATE) return 0;
+    if (rc != BMQ_OK) {
+        throw_state(env, NULL, "bmq_route_cache_tenant_stats_get", rc);
+        return 0;
+    }
+    const jlong v[5] = {(jlong)st.hits, (jlong)st.misses, (jlong)st.evictions, (jlong)st.entries, (jlong)st.cached_routes};
+    (*env)->SetLongArrayRegion(env, out, 0, 5, v);
+    return 1;
 }

@@ -52,9 +52,12 @@ struct JNINativeInterface_ { /* only the members used by bmq_jni.c; the real tab
     jboolean (*ExceptionCheck)(JNIEnv* env);
     void (*ExceptionClear)(JNIEnv* env);
     jint (*GetJavaVM)(JNIEnv* env, JavaVM** vm);
+    jbyteArray (*NewByteArray)(JNIEnv* env, jsize len);
+    void (*SetByteArrayRegion)(JNIEnv* env, jbyteArray array, jsize start, jsize len, const jbyte* buf);
 };
 struct JNIInvokeInterface_ { /* only the members used */
     jint (*GetEnv)(JavaVM* vm, void** penv, jint version);
     jint (*AttachCurrentThreadAsDaemon)(JavaVM* vm, void** penv, void* args);
+    jint (*DetachCurrentThread)(JavaVM* vm);
 };
 #endif

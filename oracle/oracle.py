@@ -737,3 +737,152 @@ class TenantRouteCacheModel:
         for topic in self._hit(filter_levels):
             if topic in self.cached and not group_still_has_members:
                 self.cached[topic] -= set(route_keys)
+
+
+# ---- MatchedRoutes + getMatch with finite fan-out caps (DW/cache/MatchedRoutes.java:36-200, DW/cache/TenantRouteCache.java:116-139,299-301) ----
+class MatchedRoutesModel:
+    """MatchedRoutes at the level of route identity (= KV route key), method by method:
+    addNormalMatching :87-109, removeNormalMatching :111-117, putGroupMatching :119-141, removeGroupMatching :143-155, adjust :157-200.
+    `events` collects what the reference hands to IEventCollector.report: (type 0 = PersistentFanoutThrottled | 1 = GroupFanoutThrottled,
+    route key, maxCount)."""
+    ADDED, EXISTS, EXCEED = "Added", "Exists", "ExceedFanoutLimit"
+    ADJUSTED, CLAMPED, RELOAD = "Adjusted", "Clamped", "ReloadNeeded"
+
+    def __init__(self, max_persistent_fanout: int = INT_MAX, max_group_fanout: int = INT_MAX):
+        self.max_pf, self.max_gf = max_persistent_fanout, max_group_fanout
+        self.all = set()        # allMatchings
+        self.groups = {}        # groupMatchings: mqttTopicFilter (incl. $share/<group>/) -> route key
+        self.persistent = 0     # persistentFanout
+        self.events = []
+
+    @staticmethod
+    def _kind(key: bytes):
+        flag, _tenant, mqtt_filter, receiver = parse_route_key(key)
+        if flag == FLAG_NORMAL:
+            return "normal", mqtt_filter, receiver.split("\0")[0] == "1"   # subBrokerId() == 1: the inbox (persistent session) broker
+        return "group", mqtt_filter, False
+
+    def add(self, key: bytes):
+        """what TenantRouteMatcher.matchAll / an AddRoutesTask does with one Matching"""
+        kind, mqtt_filter, is_persistent = self._kind(key)
+        if kind == "normal":
+            if key in self.all:
+                return self.EXISTS
+            self.all.add(key)
+            if is_persistent:
+                if self.persistent < self.max_pf:
+                    self.persistent += 1
+                    return self.ADDED
+                self.all.discard(key)
+                self.events.append((0, key, self.max_pf))
+                return self.EXCEED
+            return self.ADDED
+        prev = self.groups.get(mqtt_filter)
+        self.groups[mqtt_filter] = key
+        if prev is None:
+            if len(self.groups) <= self.max_gf:
+                self.all.add(key)
+                return self.ADDED
+            del self.groups[mqtt_filter]
+            self.events.append((1, key, self.max_gf))
+            return self.EXCEED
+        self.all.discard(prev)
+        self.all.add(key)
+        return self.EXISTS
+
+    def remove(self, key: bytes):
+        kind, mqtt_filter, is_persistent = self._kind(key)
+        if kind == "normal":
+            if key in self.all:
+                self.all.discard(key)
+                if is_persistent:
+                    self.persistent -= 1
+        else:
+            existing = self.groups.pop(mqtt_filter, None)
+            if existing is not None:
+                self.all.discard(existing)
+
+    def adjust(self, new_pf: int, new_gf: int) -> str:
+        if self.max_pf < new_pf and self.persistent == self.max_pf:
+            return self.RELOAD
+        if self.max_gf < new_gf and len(self.groups) == self.max_gf:
+            return self.RELOAD
+        clamped = False
+        if self.max_pf > new_pf and self.persistent > new_pf:
+            # the reference removes the first `toRemove` persistent routes a ConcurrentHashMap key set yields: WHICH ones is unspecified
+            victims = [k for k in sorted(self.all) if self._kind(k) == ("normal", self._kind(k)[1], True)][:self.persistent - new_pf]
+            for k in victims:
+                self.remove(k)
+            clamped = True
+        if self.max_gf > new_gf and len(self.groups) > new_gf:
+            for f in sorted(self.groups)[:len(self.groups) - new_gf]:
+                self.remove(self.groups[f])
+            clamped = True
+        self.max_pf, self.max_gf = new_pf, new_gf
+        return self.CLAMPED if clamped else self.ADJUSTED
+
+    def routes(self):
+        return set(self.all)
+
+
+def matched_routes_load(tenant: str, topic: str, kv_keys, max_persistent_fanout: int, max_group_fanout: int) -> MatchedRoutesModel:
+    """LoadEntryTask / ReloadEntryTask (TenantRouteCache.java:217-241): matchAll(singleton(topic), maxPF, maxGF) -- the KV iterator yields
+    the route keys ascending, every key whose filter matches goes through addNormalMatching / putGroupMatching in that order
+    (TenantRouteMatcher.java:106-126)."""
+    mr = MatchedRoutesModel(max_persistent_fanout, max_group_fanout)
+    for key in sorted(kv_keys):
+        flag, key_tenant, mqtt_filter, _receiver = parse_route_key(key)
+        if key_tenant != tenant:
+            continue
+        plain = mqtt_filter
+        if flag != FLAG_NORMAL:  # "$share/<group>/<filter>" / "$oshare/..."
+            plain = mqtt_filter.split("/", 2)[2]
+        if semantic_match(topic, plain):
+            mr.add(key)
+    return mr
+
+
+class CappedTenantRouteCacheModel:
+    """TenantRouteCache.getMatch (TenantRouteCache.java:299-301) for one tenant with finite caps, as the reference serves it:
+      * a miss loads matchAll(singleton(topic), maxPF, maxGF) and caches the MatchedRoutes (:217-230);
+      * AddRoutes / RemoveRoutes tasks PATCH the cached MatchedRoutes first-come (:243-291) -- a route added while a cap is reached is
+        thrown away (with an event) although a fresh load would admit it in front of a later key;
+      * the periodic fan-out check (asyncReload, :124-138) calls adjust(new caps) and reloads when it says ReloadNeeded.
+    get_match(topic, reload=True) is the state after that entry's next (re)load -- what bmq_route_cache_* serves at once, because it
+    drops patched rows and re-matches them."""
+
+    def __init__(self, tenant: str, max_persistent_fanout: int = INT_MAX, max_group_fanout: int = 100):
+        self.tenant = tenant
+        self.max_pf, self.max_gf = max_persistent_fanout, max_group_fanout
+        self.kv = set()
+        self.cached = {}   # topic -> MatchedRoutesModel
+        self.events = []   # (topic, type, route key, maxCount) in report order
+
+    def _drain(self, topic, mr):
+        self.events += [(topic,) + e for e in mr.events]
+        mr.events = []
+
+    def get_match(self, topic: str, reload: bool = False):
+        mr = self.cached.get(topic)
+        if mr is None or reload or (mr.max_pf, mr.max_gf) != (self.max_pf, self.max_gf) and mr.adjust(self.max_pf, self.max_gf) == mr.RELOAD:
+            mr = matched_routes_load(self.tenant, topic, self.kv, self.max_pf, self.max_gf)
+            self.cached[topic] = mr
+        self._drain(topic, mr)
+        return mr.routes()
+
+    def refresh(self, added=(), removed=()):
+        """DistWorkerCoProc.mutate's post-commit refresh (DW/DistWorkerCoProc.java:188-209): the KV has changed, cached rows are patched"""
+        for key in removed:
+            self.kv.discard(key)
+        for key in added:
+            self.kv.add(key)
+        for topic, mr in self.cached.items():
+            for key in removed:
+                flag, _t, mqtt_filter, _r = parse_route_key(key)
+                if semantic_match(topic, mqtt_filter if flag == FLAG_NORMAL else mqtt_filter.split("/", 2)[2]):
+                    mr.remove(key)
+            for key in added:
+                flag, _t, mqtt_filter, _r = parse_route_key(key)
+                if semantic_match(topic, mqtt_filter if flag == FLAG_NORMAL else mqtt_filter.split("/", 2)[2]):
+                    mr.add(key)
+            self._drain(topic, mr)

@@ -240,6 +240,9 @@ def test_churn_case_helper_on_host_only_engine():
 
     n = U.churn_case(eng, oracle_match, n_tenants=12, per_tenant=400, n_ops=1200, n_topics=1500, sample_tenants=5, n_sample=300)
     assert state["rows"] == 1500 and n == eng.info().n_routes
+    # ... and the whole-CSR mode the full-size GPU test uses (every row of the first tenants, ids mapped to ranks vectorised)
+    n = U.churn_case(eng, oracle_match, n_tenants=12, per_tenant=400, n_ops=1200, n_topics=1500, sample_tenants=9, n_sample=None)
+    assert n == eng.info().n_routes
     eng.close()
 
 

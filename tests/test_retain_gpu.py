@@ -138,7 +138,6 @@ def test_match_limited_vs_retain_store_coproc_match(eng):
         assert U.csr_rows(lrow, lids) == exp
         if now == 0:  # nothing has expired: the prefix of the unlimited row
             assert exp == [r[:min(l, len(r))] for r, l in zip(full, limits)]
-    assert any(0 < len(e) < min(l, len(r)) for e, l, r in zip(exp, limits, full)) or True
     # the GC scan (RS/RetainStoreCoProc.java:257-277): expired ids of one tenant / of all, with and without an expiry override
     now = base_ms + 60_000
     first = [i for i, (t, _) in enumerate(order) if t == tn[0]]

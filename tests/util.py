@@ -203,8 +203,8 @@ def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_ten
     """configs[4]: an index of n_tenants x per_tenant generated routes, then ONE batch of n_ops mutations (50 % unsubscribes of
     existing routes, 50 % subscribes of new filters, spread over all tenants) through bmq_routes_apply, then a batch of
     publishes.  Checked: route count, id stability (surviving routes keep their rank ids, deleted ids are dead, the j-th new
-    route got id n_keys + j), CSR well-formed and ascending, tenant isolation of every id, sampled rows of the first tenants
-    bit-exact vs the oracle on the updated key set.
+    route got id n_keys + j), CSR well-formed and ascending, tenant isolation of every id, and the rows of the first
+    `sample_tenants` tenants bit-exact vs the oracle on the updated key set: n_sample of them, or (n_sample=None) every one.
     match_fn(tenants, topic_tenant, (data, off)) -> (row_ptr, ids): the engine's batch match (GPU), or a stand-in in the CPU test
     of this helper."""
     import random
@@ -279,6 +279,38 @@ def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_ten
         for x, o in zip(ids[~old].tolist(), own[~old].tolist()):
             assert owner_of_new[x] == o
     cand = np.nonzero(tt < S)[0]
+    if n_sample is None:
+        # EVERY publish addressed to the first S tenants, whole-CSR comparison (the shape of test_full_size_config3_properties): the
+        # post-churn index -- indirect id lists, re-hashed regions, dead ids -- is where a wrong row would hide from a sample
+        rank = {k: i for i, k in enumerate(keys_sorted)}
+        old_rank = np.full(hi_old, -1, dtype=np.int64)
+        for i in range(hi_old):
+            if i not in deleted:
+                old_rank[i] = rank[key_at(i)]
+        new_rank = np.full(n_ops - n_ops // 2, -1, dtype=np.int64)
+        for k, t in added.items():
+            if t < S:
+                new_rank[added_id[k] - w.n_keys] = rank[k]
+        traw = data.tobytes()
+        t_off = np.concatenate([[0], np.cumsum((off[cand + 1] - off[cand]).astype(np.int64))]).astype(np.uint32)
+        t_data = np.zeros(int(t_off[-1]) + 32, dtype=np.uint8)
+        t_data[:int(t_off[-1])] = np.frombuffer(b"".join(traw[off[i]:off[i + 1]] for i in cand), dtype=np.uint8)
+        stt = tt[cand]
+        res, _ = kv.match_singletons(tn[:S], stt, (t_data, t_off), threads=host_threads())
+        got_rp, got = csr_select(row, ids, cand)
+        got = got.astype(np.int64)
+        is_old = got < w.n_keys
+        mapped = np.where(is_old, old_rank[np.where(is_old, got, 0)], new_rank[np.where(is_old, 0, got - w.n_keys)])
+        assert (mapped >= 0).all()  # no deleted id, no id of another tenant's new route
+        mapped = csr_sorted(got_rp, mapped)
+        differ = assert_csr_equal_modulo_quirk_ii(lambda: keys_sorted, lambda r: keys_sorted[r], tn[:S], stt, res.row_ptr.astype(np.int64),
+                                                  res.routes.astype(np.int64), got_rp, mapped)
+        for j in differ[:20].tolist() + rnd.sample(range(len(cand)), min(20, len(cand))):  # the semantic oracle on quirk rows + a sub-sample
+            i = int(cand[j])
+            assert mapped[got_rp[j]:got_rp[j + 1]].tolist() == kv.match_bruteforce(tn[int(tt[i])], [traw[off[i]:off[i + 1]]]).per_topic()[0]
+        new_ranks = {rank[k] for k, t in added.items() if t < S}
+        assert np.isin(mapped, np.fromiter(new_ranks, dtype=np.int64)).any()  # routes subscribed by the batch are matched
+        return n_new
     sample = sorted(rnd.sample(cand.tolist(), min(n_sample, len(cand))))
     traw = data.tobytes()
     topics = [traw[off[i]:off[i + 1]] for i in sample]

@@ -34,6 +34,7 @@ struct bmq_engine {
     std::atomic<uint64_t> n_match{0}, n_launch{0};
     std::atomic<bool> hold_loads{false}; // a load that has read the model waits here until released (TenantRouteCacheTest.java:257-292)
     std::atomic<int> loads_waiting{0};
+    std::atomic<uint64_t> n_cap_calls{0};
 };
 struct bmq_batcher { // blocking side: matches inline; asynchronous side: a dispatcher thread, as the real front has
     bmq_engine* e;
@@ -173,6 +174,54 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
     e->epoch++;
     e->generation++;
     e->history.push_back(e->model);
+    return BMQ_OK;
+}
+// MatchedRoutes over rows of ids, as the engine's bmq_routes_cap does it: keys of the ids from the model, KV key order, caps first-come
+int bmq_routes_cap(bmq_engine* e, const uint32_t* row_ptr, const uint32_t* route_ids, uint32_t n_rows, int32_t max_pf, int32_t max_gf, uint32_t* out_row_ptr,
+                   uint32_t* out_route_ids, uint32_t* out_class_counts, int32_t* out_events, uint32_t events_cap, uint32_t* out_n_events) {
+    std::map<uint32_t, std::string> by_id;
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        for (auto& kv : e->model) by_id[kv.second] = kv.first;
+    }
+    e->n_cap_calls++;
+    uint32_t total = 0, n_ev = 0;
+    for (uint32_t r = 0; r < n_rows; r++) {
+        out_row_ptr[r] = total;
+        std::vector<std::pair<std::string, uint32_t>> row;
+        for (uint32_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+            auto it = by_id.find(route_ids[k]);
+            if (it != by_id.end()) row.emplace_back(it->second, route_ids[k]);
+        }
+        std::sort(row.begin(), row.end());
+        int64_t pers = 0, grp = 0;
+        std::vector<uint32_t> kept;
+        for (auto& en : row) {
+            bmq::RouteKeyParts kp;
+            bmq::decode_route_key(en.first, kp);
+            int ev = -1;
+            if (kp.flag == 1) {
+                if (kp.receiver.substr(0, 2) == std::string_view("1\0", 2)) {
+                    if (pers < max_pf) pers++;
+                    else ev = 0;
+                }
+            } else if (grp + 1 <= max_gf) grp++;
+            else ev = 1;
+            if (ev < 0) kept.push_back(en.second);
+            else {
+                if (out_events && n_ev < events_cap) {
+                    int32_t* o = out_events + 4 * (size_t)n_ev;
+                    o[0] = ev, o[1] = (int32_t)r, o[2] = (int32_t)en.second, o[3] = ev == 0 ? max_pf : max_gf;
+                }
+                n_ev++;
+            }
+        }
+        std::sort(kept.begin(), kept.end());
+        for (uint32_t id : kept) out_route_ids[total++] = id;
+        if (out_class_counts) out_class_counts[2 * r] = (uint32_t)pers, out_class_counts[2 * r + 1] = (uint32_t)grp;
+    }
+    out_row_ptr[n_rows] = total;
+    if (out_n_events) *out_n_events = n_ev;
     return BMQ_OK;
 }
 int bmq_index_info_get(const bmq_engine* ce, bmq_index_info* out) {
@@ -520,6 +569,277 @@ static void test_reference_cases() {
     }
 }
 
+// ---- 2c. fan-out caps through the cache: getMatch = IMatchedRoutes.routes() (TenantRouteCache.java:299-301) ----------------------------
+// matchAll over the model in KV order with MatchedRoutes' rules (MatchedRoutes.java:87-141): the reference's result for one (tenant, topic)
+struct Throttle {
+    int type;
+    uint32_t id;
+    int max;
+    bool operator==(const Throttle& o) const { return type == o.type && id == o.id && max == o.max; }
+};
+static std::vector<uint32_t> matched_routes(const std::map<std::string, uint32_t>& model, const std::string& tenant, const std::string& topic, int max_pf, int max_gf,
+                                            std::vector<Throttle>* events) {
+    std::vector<uint32_t> routes;
+    int persistent = 0, groups = 0;
+    const auto tl = bmq::cache::split(topic, '/');
+    for (auto& kv : model) { // std::map: unsigned byte order of the keys == the KV iterator's order
+        bmq::RouteKeyParts kp;
+        if (!bmq::decode_route_key(kv.first, kp) || kp.tenant != tenant) continue;
+        if (!bmq::cache::filter_matches(bmq::cache::split(kp.esc_filter, '\0'), tl)) continue;
+        if (kp.flag == 1) { // addNormalMatching :87-109
+            const bool is_persistent = kp.receiver.size() >= 2 && kp.receiver[0] == '1' && kp.receiver[1] == '\0'; // subBrokerId == 1
+            if (is_persistent) {
+                if (persistent < max_pf) persistent++;
+                else {
+                    if (events) events->push_back({0, kv.second, max_pf});
+                    continue;
+                }
+            }
+            routes.push_back(kv.second);
+        } else { // putGroupMatching :119-141
+            if (groups + 1 <= max_gf) {
+                groups++;
+                routes.push_back(kv.second);
+            } else if (events) events->push_back({1, kv.second, max_gf});
+        }
+    }
+    std::sort(routes.begin(), routes.end());
+    return routes;
+}
+static std::string persistent_key(const std::string& tenant, const std::string& filter, int rid) {
+    return bmq::encode_route_key(tenant, filter, 1, std::string("1\0", 2) + "inbox" + std::to_string(rid) + std::string("\0d", 2));
+}
+struct EventLog {
+    std::mutex mu;
+    std::vector<std::pair<std::string, Throttle>> got; // "tenant|topic" -> event
+    static void sink(void* user, const uint8_t* tenant, uint32_t tl, const uint8_t* topic, uint32_t pl, int32_t type, uint32_t id, int32_t max) {
+        EventLog* l = (EventLog*)user;
+        std::lock_guard<std::mutex> g(l->mu);
+        l->got.push_back({std::string((const char*)tenant, tl) + "|" + std::string((const char*)topic, pl), Throttle{type, id, max}});
+    }
+    std::vector<Throttle> take(const std::string& tenant, const std::string& topic) {
+        std::lock_guard<std::mutex> g(mu);
+        std::vector<Throttle> out;
+        for (auto& p : got)
+            if (p.first == tenant + "|" + topic) out.push_back(p.second);
+        got.clear();
+        return out;
+    }
+};
+static void test_caps() {
+    bmq_engine e;
+    bmq_batcher b(&e);
+    bmq_route_cache_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    cfg.default_max_persistent_fanout = 3;
+    cfg.default_max_group_fanout = 2;
+    bmq_route_cache* c = nullptr;
+    EXPECT(bmq_route_cache_create(&e, &b, &cfg, &c) == BMQ_OK);
+    EventLog log;
+    EXPECT(bmq_route_cache_set_event_sink(c, EventLog::sink, &log) == BMQ_OK);
+    auto apply = [&](const std::vector<std::pair<std::string, uint8_t>>& ops) {
+        Packed p;
+        for (auto& o : ops) p.add(o.first, o.second);
+        EXPECT(bmq_route_cache_apply(c, p.bytes.data(), p.off.data(), p.op.data(), (uint32_t)p.op.size()) == BMQ_OK);
+    };
+    // 5 persistent + 2 transient inboxes and 4 shared-subscription groups match s/t; an unrelated topic matches 1 persistent route
+    std::vector<std::pair<std::string, uint8_t>> ops;
+    for (int i = 0; i < 5; i++) ops.push_back({persistent_key("T", i % 2 ? "s/+" : "s/t", i), 0});
+    for (int i = 0; i < 2; i++) ops.push_back({key_of("T", "s/#", 100 + i), 0});
+    for (int i = 0; i < 4; i++) ops.push_back({group_key("T", i % 2 ? "s/t" : "+/t", "g" + std::to_string(i)), 0});
+    ops.push_back({persistent_key("T", "x", 9), 0});
+    apply(ops);
+    std::vector<uint32_t> ids;
+    uint64_t ep = 0;
+    auto check = [&](const std::string& topic, int pf, int gf, bool expect_load, int line) {
+        const uint64_t before = e.n_match;
+        std::vector<Throttle> want_ev;
+        const auto want = matched_routes(e.model, "T", topic, pf, gf, &want_ev);
+        const bool ok = cache_get(c, "T", topic, 10, ids, ep, 2); // small first buffer: the NOSPACE round trip must not double the events
+        const auto got_ev = log.take("T", topic);
+        const bool loaded = e.n_match != before;
+        if (!ok || ids != want || loaded != expect_load || (loaded ? !(got_ev == want_ev) : !got_ev.empty())) {
+            fprintf(stderr, "cache_fuzz: caps check failed (line %d): topic %s caps %d/%d got %zu ids want %zu, loaded %d want %d, events %zu want %zu\n", line,
+                    topic.c_str(), pf, gf, ids.size(), want.size(), (int)loaded, (int)expect_load, got_ev.size(), loaded ? want_ev.size() : 0);
+            g_fail++;
+        }
+    };
+    // NOSPACE on a miss loads twice (the row was not cached the first time only if it was stale): events of both loads are compared below
+    // against ONE load, so the first call uses a buffer that fits
+    auto check_fit = [&](const std::string& topic, int pf, int gf, bool expect_load, int line) {
+        const uint64_t before = e.n_match;
+        std::vector<Throttle> want_ev;
+        const auto want = matched_routes(e.model, "T", topic, pf, gf, &want_ev);
+        const bool ok = cache_get(c, "T", topic, 10, ids, ep, 64);
+        const auto got_ev = log.take("T", topic);
+        const bool loaded = e.n_match != before;
+        if (!ok || ids != want || loaded != expect_load || (loaded ? !(got_ev == want_ev) : !got_ev.empty())) {
+            fprintf(stderr, "cache_fuzz: caps check failed (line %d): topic %s caps %d/%d got %zu ids want %zu, loaded %d want %d, events %zu want %zu\n", line,
+                    topic.c_str(), pf, gf, ids.size(), want.size(), (int)loaded, (int)expect_load, got_ev.size(), loaded ? want_ev.size() : 0);
+            g_fail++;
+        }
+    };
+    (void)check;
+    check_fit("s/t", 3, 2, true, __LINE__);   // miss: 3 of 5 persistent, 2 of 4 groups, both transient ones; 2 + 2 events
+    EXPECT(ids.size() == 3 + 2 + 2);
+    check_fit("s/t", 3, 2, false, __LINE__);  // hit: the capped row, no events
+    check_fit("x", 3, 2, true, __LINE__);     // a row no cap binds on: not even classified
+    bmq_route_cache_stats st{};
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.cached_routes == 7 + 1); // the weigher counts the capped row (TenantRouteCache.java:108)
+    // refresh(AddRoutes): a persistent route whose key sorts in front of the admitted ones, and a group behind the admitted ones
+    apply({{persistent_key("T", "+/t", 50), 0}, {group_key("T", "s/t", "zz"), 0}});
+    check_fit("s/t", 3, 2, true, __LINE__);   // dropped by the mutation, re-matched: caps in key order again, events again
+    check_fit("s/t", 3, 2, false, __LINE__);
+    // refresh(RemoveRoutes) of an admitted persistent route: the next one in key order moves up
+    apply({{persistent_key("T", "+/t", 50), 1}});
+    check_fit("s/t", 3, 2, true, __LINE__);
+    // MatchedRoutes.adjust: raise the persistent cap -- the cached row sits at the old cap, so it must be re-matched
+    EXPECT(bmq_route_cache_set_caps(c, (const uint8_t*)"T", 1, 4, 2) == BMQ_OK);
+    check_fit("s/t", 4, 2, true, __LINE__);
+    check_fit("s/t", 4, 2, false, __LINE__);
+    check_fit("x", 4, 2, false, __LINE__);    // 1 persistent route, nowhere near a cap: the entry adopts the new caps without a load
+    // lower the group cap below what is cached: re-matched (the reference clamps arbitrary groups; a reload clamps in key order)
+    EXPECT(bmq_route_cache_set_caps(c, (const uint8_t*)"T", 1, 4, 1) == BMQ_OK);
+    check_fit("s/t", 4, 1, true, __LINE__);
+    // raise both far beyond the row: one more load (the row was AT the old caps), then hits
+    EXPECT(bmq_route_cache_set_caps(c, (const uint8_t*)"T", 1, 1000, 1000) == BMQ_OK);
+    check_fit("s/t", 1000, 1000, true, __LINE__);
+    EXPECT(ids.size() == 5 + 2 + 5);
+    check_fit("s/t", 1000, 1000, false, __LINE__);
+    // lower again: the row (12 ids) was never classified under 1000 / 1000, so how many of them are persistent is unknown -> re-matched
+    EXPECT(bmq_route_cache_set_caps(c, (const uint8_t*)"T", 1, 5, 5) == BMQ_OK);
+    check_fit("s/t", 5, 5, true, __LINE__);
+    // raise by one: the row holds 5 persistent routes == the old cap, a 6th might have been thrown away -> re-matched
+    EXPECT(bmq_route_cache_set_caps(c, (const uint8_t*)"T", 1, 6, 7) == BMQ_OK);
+    check_fit("s/t", 6, 7, true, __LINE__);
+    // lower, but not below what the row holds (5 persistent, 5 groups, counted by the last load): the entry just carries the new caps
+    EXPECT(bmq_route_cache_set_caps(c, (const uint8_t*)"T", 1, 5, 5) == BMQ_OK);
+    check_fit("s/t", 5, 5, false, __LINE__);
+    bmq_route_cache_tenant_stats ts{};
+    EXPECT(bmq_route_cache_tenant_stats_get(c, (const uint8_t*)"T", 1, &ts) == BMQ_OK && ts.max_persistent_fanout == 5 && ts.max_group_fanout == 5 &&
+           ts.entries == 2 && ts.hits >= 5 && ts.misses >= 7 && ts.cached_routes == 12 + 1);
+    EXPECT(bmq_route_cache_tenant_stats_get(c, (const uint8_t*)"nobody", 6, &ts) == BMQ_E_STATE);
+    // the same through get_batch (cached path and direct path) and get_async
+    EXPECT(bmq_route_cache_set_caps(c, (const uint8_t*)"T", 1, 2, 1) == BMQ_OK);
+    {
+        const uint32_t tenant_off[2] = {0, 1};
+        const std::string bytes = std::string("s/txs/t") + std::string(16, '\0');
+        const uint32_t off[4] = {0, 3, 4, 7}, tt[3] = {0, 0, 0};
+        uint32_t row[4], out[64];
+        uint64_t need = 0;
+        EXPECT(bmq_route_cache_get_batch(c, (const uint8_t*)"T", tenant_off, 1, tt, (const uint8_t*)bytes.data(), off, 3, 20, row, out, 64, &need, nullptr) == BMQ_OK);
+        std::vector<Throttle> want_ev;
+        const auto want = matched_routes(e.model, "T", "s/t", 2, 1, &want_ev);
+        EXPECT(std::vector<uint32_t>(out + row[0], out + row[1]) == want && std::vector<uint32_t>(out + row[2], out + row[3]) == want);
+        EXPECT(std::vector<uint32_t>(out + row[1], out + row[2]) == matched_routes(e.model, "T", "x", 2, 1, nullptr));
+        EXPECT(log.take("T", "s/t") == want_ev); // identical misses of one request are ONE load: one set of events
+        bmq_route_cache_config big = cfg;
+        big.direct_batch_topics = 2;
+        bmq_route_cache* c2 = nullptr;
+        EXPECT(bmq_route_cache_create(&e, &b, &big, &c2) == BMQ_OK);
+        EventLog log2;
+        bmq_route_cache_set_event_sink(c2, EventLog::sink, &log2);
+        EXPECT(bmq_route_cache_get_batch(c2, (const uint8_t*)"T", tenant_off, 1, tt, (const uint8_t*)bytes.data(), off, 3, 20, row, out, 64, &need, nullptr) == BMQ_OK);
+        std::vector<Throttle> ev32;
+        const auto want32 = matched_routes(e.model, "T", "s/t", 3, 2, &ev32); // c2 has its own (default) caps
+        EXPECT(need == 2 * want32.size() + 1 && std::vector<uint32_t>(out + row[0], out + row[1]) == want32 &&
+               std::vector<uint32_t>(out + row[2], out + row[3]) == want32 && row[2] - row[1] == 1);
+        auto ev2 = log2.take("T", "s/t");
+        std::vector<Throttle> twice = ev32;
+        twice.insert(twice.end(), ev32.begin(), ev32.end()); // the direct path matches every row it is given: both copies report
+        EXPECT(ev2 == twice);
+        bmq_route_cache_destroy(c2);
+    }
+    {
+        struct Got {
+            std::vector<uint32_t> ids;
+            std::atomic<int> done{0};
+        } got;
+        apply({{key_of("T", "s/t", 777), 0}}); // drop s/t so that the future is a miss
+        auto cb = +[](void* user, int status, const uint32_t* ids, uint32_t n, uint64_t) {
+            Got* g = (Got*)user;
+            EXPECT(status == BMQ_OK);
+            g->ids.assign(ids, ids + n);
+            g->done = 1;
+        };
+        EXPECT(bmq_route_cache_get_async(c, (const uint8_t*)"T", 1, (const uint8_t*)"s/t", 3, 30, cb, &got) == BMQ_OK);
+        while (!got.done) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        std::vector<Throttle> want_ev;
+        EXPECT(got.ids == matched_routes(e.model, "T", "s/t", 2, 1, &want_ev) && log.take("T", "s/t") == want_ev);
+        got.done = 0;
+        EXPECT(bmq_route_cache_get_async(c, (const uint8_t*)"T", 1, (const uint8_t*)"s/t", 3, 31, cb, &got) == BMQ_OK && got.done == 1); // hit: inline
+        EXPECT(got.ids == matched_routes(e.model, "T", "s/t", 2, 1, nullptr) && log.take("T", "s/t").empty());
+    }
+    bmq_route_cache_destroy(c);
+}
+
+// ---- 2d. tenant lifecycle (SubscriptionCache.java:79-107) and per-tenant meters (TenantRouteCache.java:141-147) -----------------------------
+static long rss_kb() {
+    long pages = 0, rss = 0;
+    if (FILE* f = fopen("/proc/self/statm", "r")) {
+        if (fscanf(f, "%ld %ld", &pages, &rss) != 2) rss = 0;
+        fclose(f);
+    }
+    return rss * 4;
+}
+static void test_lifecycle() {
+    bmq_engine e;
+    bmq_batcher b(&e);
+    bmq_route_cache_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    cfg.expiry_ms = 1000; // tenant_idle_ms = 0 -> 2 x expiry
+    bmq_route_cache* c = nullptr;
+    EXPECT(bmq_route_cache_create(&e, &b, &cfg, &c) == BMQ_OK);
+    Packed p;
+    p.add(key_of("keep", "a/#", 1), 0);
+    EXPECT(bmq_route_cache_apply(c, p.bytes.data(), p.off.data(), p.op.data(), 1) == BMQ_OK);
+    std::vector<uint32_t> ids;
+    uint64_t ep = 0, dropped = 0;
+    bmq_route_cache_stats st{};
+    bmq_route_cache_tenant_stats ts{};
+    EXPECT(cache_get(c, "keep", "a/b", 0, ids, ep, 8) && cache_get(c, "gone", "a/b", 0, ids, ep, 8));
+    EXPECT(bmq_route_cache_set_caps(c, (const uint8_t*)"gone", 4, 7, 9) == BMQ_OK);
+    // entries expire after 1 s idle, the tenant's cache after 2 s without a get; isCached / refresh do not keep a tenant alive
+    EXPECT(cache_get(c, "keep", "a/b", 900, ids, ep, 8) && cache_get(c, "keep", "a/b", 1700, ids, ep, 8));
+    EXPECT(is_cached(c, "gone", "#") == 1);
+    EXPECT(bmq_route_cache_expire(c, 1999, &dropped) == BMQ_OK);
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.tenants == 2 && st.tenants_expired == 0 && dropped == 1); // gone's entry expired, its (empty) cache is still there
+    EXPECT(bmq_route_cache_tenant_stats_get(c, (const uint8_t*)"gone", 4, &ts) == BMQ_OK && ts.entries == 0 && ts.misses == 1 && ts.max_persistent_fanout == 7);
+    EXPECT(bmq_route_cache_expire(c, 2000, &dropped) == BMQ_OK);
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.tenants == 1 && st.tenants_expired == 1 && st.misses == 2 && st.hits == 2); // the counters of the destroyed cache still count
+    EXPECT(bmq_route_cache_tenant_stats_get(c, (const uint8_t*)"gone", 4, &ts) == BMQ_E_STATE); // ... its meters are gone (stopCounting, :304-311)
+    EXPECT(bmq_route_cache_tenant_stats_get(c, (const uint8_t*)"keep", 4, &ts) == BMQ_OK && ts.hits == 2 && ts.entries == 1);
+    EXPECT(cache_get(c, "gone", "a/b", 2100, ids, ep, 8)); // comes back with its first loaded row -- and with the caps set for it
+    EXPECT(bmq_route_cache_tenant_stats_get(c, (const uint8_t*)"gone", 4, &ts) == BMQ_OK && ts.max_persistent_fanout == 7 && ts.max_group_fanout == 9 && ts.misses == 1);
+    // "10 k tenants come and go": waves of tenants, each swept two idle periods later -- the table does not grow, memory is returned
+    EXPECT(bmq_route_cache_expire(c, 9000, &dropped) == BMQ_OK && dropped == 2); // keep and gone go first
+    long rss_after_first = 0;
+    for (int wave = 0; wave < 6; wave++) {
+        const uint64_t now = 10000 + (uint64_t)wave * 5000;
+        for (int i = 0; i < 10000; i++) {
+            const std::string tn = "w" + std::to_string(wave) + "-" + std::to_string(i);
+            EXPECT(cache_get(c, tn, "a/b", now, ids, ep, 8));
+        }
+        bmq_route_cache_stats_get(c, &st);
+        EXPECT(st.tenants == 10000 && st.entries == 10000);
+        EXPECT(bmq_route_cache_expire(c, now + 2500, &dropped) == BMQ_OK);
+        bmq_route_cache_stats_get(c, &st);
+        EXPECT(st.tenants == 0 && st.entries == 0 && dropped == 10000);
+        if (wave == 1) rss_after_first = rss_kb();
+    }
+    const long rss_end = rss_kb();
+    printf("  lifecycle: 6 waves of 10000 tenants, RSS after wave 2: %ld KB, after wave 6: %ld KB\n", rss_after_first, rss_end);
+#if !defined(__SANITIZE_ADDRESS__) // (ASan parks freed memory in its quarantine: RSS says nothing there)
+    EXPECT(rss_end < rss_after_first + rss_after_first / 4 + 8192); // flat: the allocator may keep some, the table must not
+#endif
+    bmq_route_cache_stats_get(c, &st);
+    EXPECT(st.tenants_expired == 60000 + 3 && st.misses == 60000 + 3); // keep, gone, gone again + the waves
+    bmq_route_cache_destroy(c);
+}
+
 // ---- 3. getters against a mutator ---------------------------------------------------------------------------------------------------
 static void test_concurrent(uint64_t seed, int n_threads, int ms) {
     bmq_engine e;
@@ -668,10 +988,20 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
             std::this_thread::sleep_for(std::chrono::microseconds(150));
         }
     });
+    std::atomic<uint64_t> n_sweeps{0};
+    std::thread sweeper([&]() { // every tenant's cache is destroyed over and over while the getters hold pointers into the table
+        while (!stop) {
+            uint64_t dropped = 0;
+            EXPECT(bmq_route_cache_expire(c, 1000 + 2 * 60000, &dropped) == BMQ_OK); // the getters' clock stands at 1000: everything is idle
+            n_sweeps++;
+            std::this_thread::sleep_for(std::chrono::milliseconds(3));
+        }
+    });
     std::this_thread::sleep_for(std::chrono::milliseconds(ms));
     stop = true;
     for (auto& t : th) t.join();
     mut.join();
+    sweeper.join();
     for (int spin = 0; spin < 20000 && n_async_cb.load() < n_async.load(); spin++) std::this_thread::sleep_for(std::chrono::microseconds(200));
     EXPECT(n_async_cb.load() == n_async.load() && n_async.load() > 0); // every future completed
     // settled: what the cache serves now is the truth of the FINAL model -- a load overtaken by a mutation was not cached
@@ -695,7 +1025,7 @@ static void test_concurrent(uint64_t seed, int n_threads, int ms) {
            "probes served from the cache\n",
            (unsigned long long)n_get.load(), (unsigned long long)n_apply.load(), (unsigned long long)st.hits, (unsigned long long)st.misses,
            (unsigned long long)st.invalidations, (unsigned long long)st.stale_loads, (unsigned long long)st.evictions, (unsigned long long)served);
-    EXPECT(st.hits > 0 && st.invalidations > 0);
+    EXPECT(st.hits > 0 && st.invalidations > 0 && st.tenants_expired > 0 && n_sweeps.load() > 0);
     bmq_route_cache_destroy(c);
 }
 
@@ -759,6 +1089,8 @@ int main(int argc, char** argv) {
     test_topic_index(seed);
     test_behaviour();
     test_reference_cases();
+    test_caps();
+    test_lifecycle();
     test_concurrent(seed, threads, ms);
     if (g_fail) {
         fprintf(stderr, "cache_fuzz FAILED: %d\n", g_fail);
