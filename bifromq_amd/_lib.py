@@ -21,7 +21,8 @@ ABI_SYMBOLS = [
     "bmq_match_finish", "bmq_set_kernel_timing", "bmq_match_submit", "bmq_match_wait", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_range_lookup", "bmq_comm_unique_id", "bmq_comm_init", "bmq_comm_destroy", "bmq_exchange_fanout",
     "bmq_exchange_csr", "bmq_exchange_wait", "bmq_retain_message_key", "bmq_retain_filter_route", "bmq_retain_rebuild", "bmq_retain_rebuild_ex", "bmq_retain_apply", "bmq_retain_apply_ex", "bmq_retain_topic",
-    "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired",
+    "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired", "bmq_retain_apply_batch", "bmq_retain_compact", "bmq_retain_info_get",
+    "bmq_retain_live_ids", "bmq_retain_topics",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
     "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get",
     "bmq_route_cache_create", "bmq_route_cache_destroy", "bmq_route_cache_get", "bmq_route_cache_get_async", "bmq_route_cache_get_batch", "bmq_batcher_match_batch", "bmq_route_cache_is_cached", "bmq_route_cache_apply",
@@ -79,6 +80,12 @@ class RouteCacheStats(C.Structure):
     _fields_ = [("hits", C.c_uint64), ("misses", C.c_uint64), ("evictions", C.c_uint64), ("invalidations", C.c_uint64), ("expired", C.c_uint64),
                 ("stale_loads", C.c_uint64), ("entries", C.c_uint64), ("cached_routes", C.c_uint64), ("tenants", C.c_uint64),
                 ("tenants_expired", C.c_uint64)]
+
+
+class RetainInfo(C.Structure):
+    _fields_ = [("n_topics", C.c_uint64), ("n_tenants", C.c_uint64), ("id_bound", C.c_uint64), ("loaded_topics", C.c_uint64),
+                ("loaded_removed", C.c_uint64), ("added_ids", C.c_uint64), ("overlay_nodes", C.c_uint64), ("epoch", C.c_uint64),
+                ("generation", C.c_uint64)]
 
 
 class RouteCacheTenantStats(C.Structure):
@@ -143,6 +150,11 @@ def lib() -> C.CDLL:
             "bmq_retain_find_all": (C.c_int, [vp, P(u64), P(u64)]),
             "bmq_retain_expired": (C.c_int, [vp, C.c_char_p, u32, u64, C.c_int64, vp, u32, P(u32)]),
             "bmq_retain_topic": (C.c_int, [vp, u32, C.c_char_p, u32, P(u32), P(u32)]),
+            "bmq_retain_topics": (C.c_int, [vp, vp, u32, vp, u64, vp, vp]),
+            "bmq_retain_apply_batch": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, u32, vp]),
+            "bmq_retain_compact": (C.c_int, [vp]),
+            "bmq_retain_info_get": (C.c_int, [vp, P(RetainInfo)]),
+            "bmq_retain_live_ids": (C.c_int, [vp, C.c_char_p, u32, vp, u32, P(u32)]),
             "bmq_retain_match_batch": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, P(u64)]),
             "bmq_retain_match_batch_dev": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, vp]),
             "bmq_retain_match_limited": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, u64, vp, vp, u64, P(u64), vp]),

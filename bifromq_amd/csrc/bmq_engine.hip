@@ -29,6 +29,7 @@
 #include "bmq_fanout.h"
 #include "bmq_range_core.h"
 #include "bmq_retain.h"
+#include "bmq_retain_dyn.h"
 #include "bmq_retain_kernels.h"
 
 using namespace bmq;
@@ -68,8 +69,8 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct RetainDevice { // the retained-topic index in HBM
-    DevBuf nodes, edges, tenants, dict, pool, expire;
+struct RetainDevice { // the bulk-loaded part of the retained-topic index in HBM (the mutable part: RetainDyn, bmq_retain_dyn.h)
+    DevBuf nodes, edges, tenants, dict, pool;
     RetainIndexView view{};
 };
 struct RetainLimit { // bmq_retain_match_limited in flight: select the first `limit` live ids from the ranges instead of expanding
@@ -140,8 +141,12 @@ struct bmq_engine {
     // retain direction
     RetainIndexHost rhost;
     RetainDevice rdev;
+    std::unique_ptr<RetainDyn<DevExec>> drt;  // dead bitmap + overlay trie + per-id payload, mutated on the device
+    std::unique_ptr<RetainDyn<HostExec>> hrt; // ... of a host-only engine (inspection, sanitizer fuzzers)
+    RetainIndexView rhview{};                 // host-only engine: the bulk-loaded arrays where RetainIndexHost keeps them
     bool rbuilt = false;
-    uint64_t repoch = 0; // +1 per retain rebuild / apply: topic ids are ranks and shift with every mutation
+    uint64_t repoch = 0;      // +1 per retain rebuild / apply / compact
+    uint64_t rgeneration = 0; // +1 per retain rebuild / compact: topic ids of different generations are unrelated
     RetainLimit rlim;
     DevBuf r_scratch;
     DevBuf range_buf; // staging of bmq_range_lookup
@@ -470,8 +475,10 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         e->dx.device = c.device;
         e->dx.stream = e->stream;
         e->dix = std::make_unique<DistIndex<DevExec>>(e->dx);
+        e->drt = std::make_unique<RetainDyn<DevExec>>(e->dx);
     } else {
         e->hix = std::make_unique<DistIndex<HostExec>>(e->hx);
+        e->hrt = std::make_unique<RetainDyn<HostExec>>(e->hx);
     }
     *out = e.release();
     return BMQ_OK;
@@ -497,6 +504,7 @@ void bmq_engine_destroy(bmq_engine* e) {
         if (e->ev_ex) (void)hipEventDestroy(e->ev_ex);
         if (e->s_ex) (void)hipStreamDestroy(e->s_ex);
         e->dfo.reset();
+        e->drt.reset();
         e->dix.reset(); // frees the HBM arrays while the stream still exists
         e->dx.release(e->dx.tmp);
         e->dx.tmp = nullptr;

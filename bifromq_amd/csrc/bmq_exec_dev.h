@@ -11,6 +11,7 @@
 
 #include "bmq_build_core.h"
 #include "bmq_fanout_core.h"
+#include "bmq_retain_core.h"
 
 namespace bmq {
 
@@ -96,6 +97,62 @@ __global__ __launch_bounds__(256) void k_fo_emit(FanoutBatch b) {
 __global__ __launch_bounds__(256) void k_fo_groups(FanoutState st, FanoutBatch b) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < b.total) fo_group_one(st, b, j);
+}
+
+// retain direction: mutation of the retained-topic index (bmq_retain_core.h), one lane per op / per id
+__global__ __launch_bounds__(BK) void k_r_locate(RetainMut m, RetainOps ob, uint32_t phase) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < ob.n) rlocate_one(m, ob, i, phase);
+}
+__global__ __launch_bounds__(BK) void k_r_commit(RetainMut m, RetainOps ob) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < ob.n) rcommit_one(m, ob, i);
+}
+// dead ids in front of every 64-id word: ONE workgroup (a million ids are 16 k words; 100 M ids 1.6 M words = 1.5 k per thread)
+__global__ __launch_bounds__(1024) void k_r_rank(const unsigned long long* bits, uint32_t* rank, uint32_t n_words) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_words + 1023) / 1024, lo = min(n_words, tid * per), hi = min(n_words, lo + per);
+    uint32_t s = 0;
+    for (uint32_t w = lo; w < hi; w++) s += (uint32_t)__popcll(bits[w]);
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t w = lo; w < hi; w++) {
+        rank[w] = run;
+        run += (uint32_t)__popcll(bits[w]);
+    }
+    if (tid == 1023) rank[n_words] = part[1023];
+}
+__global__ __launch_bounds__(256) void k_r_rehash(RetainMut m, uint32_t n_nodes) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_nodes) ov_rehash_one(m, i);
+}
+__global__ __launch_bounds__(BK) void k_r_topic_len(RetainMut m, const uint32_t* ids, uint32_t n, uint32_t* lens) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < n) ov_topic_len_one(m, ids, i, lens);
+}
+__global__ __launch_bounds__(BK) void k_r_topic_write(RetainMut m, const uint32_t* ids, uint32_t n, const unsigned long long* offs, uint8_t* out) {
+    const uint32_t i = blockIdx.x * BK + threadIdx.x;
+    if (i < n) ov_topic_write_one(m, ids, i, offs, out);
+}
+__global__ __launch_bounds__(256) void k_r_gc_flags(RetainMut m, GcQuery q, uint8_t* flags) {
+    const uint32_t id = blockIdx.x * 256 + threadIdx.x;
+    if (id < q.n_ids) flags[id] = (uint8_t)gc_flag_one(m, q, id);
+}
+__global__ __launch_bounds__(64) void k_r_find_tenant(RetainMut m, const uint8_t* name, uint32_t len, uint32_t* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    LevelScan lv;
+    unsigned long long pos = 0;
+    lv.start = 0;
+    scan_level_bytes<0u>(name, pos, len, lv.h, lv.inl, lv.len);
+    out[0] = ov_find(m.onodes, m.oedges, m.oedge_mask, m.opool, 0u, lv.h.h1, lv.h.h2, lv.len, name, 0);
 }
 
 struct DevExec {
@@ -241,6 +298,47 @@ struct DevExec {
     }
     bool gather_bytes(const DistIndexMut& ix, const unsigned long long* refs, const uint64_t* offs, uint32_t n, uint8_t* out) {
         hipLaunchKernelGGL(k_b_gather_bytes, grid(n, BK), dim3(BK), 0, stream, ix, refs, offs, n, out);
+        return launched();
+    }
+    // ---- retain direction (bmq_retain_core.h) ----
+    bool r_locate(const RetainMut& m, const RetainOps& ob) {
+        hipLaunchKernelGGL(k_r_locate, grid(ob.n, BK), dim3(BK), 0, stream, m, ob, 0u); // the adds: overlay nodes come into being
+        hipLaunchKernelGGL(k_r_locate, grid(ob.n, BK), dim3(BK), 0, stream, m, ob, 1u); // the removes: they find them
+        return launched();
+    }
+    bool r_commit(const RetainMut& m, const RetainOps& ob) {
+        hipLaunchKernelGGL(k_r_commit, grid(ob.n, BK), dim3(BK), 0, stream, m, ob);
+        return launched();
+    }
+    bool r_rank(const RetainMut& m, uint32_t n_words) {
+        hipLaunchKernelGGL(k_r_rank, dim3(1), dim3(1024), 0, stream, m.dead_bits, m.dead_rank, n_words);
+        return launched();
+    }
+    bool r_rehash(const RetainMut& m, uint32_t n_nodes) {
+        hipLaunchKernelGGL(k_r_rehash, grid(n_nodes, 256), dim3(256), 0, stream, m, n_nodes);
+        return launched();
+    }
+    bool r_topic_lens(const RetainMut& m, const uint32_t* ids, uint32_t n, uint32_t* lens) {
+        hipLaunchKernelGGL(k_r_topic_len, grid(n, BK), dim3(BK), 0, stream, m, ids, n, lens);
+        return launched();
+    }
+    bool r_topic_write(const RetainMut& m, const uint32_t* ids, uint32_t n, const unsigned long long* offs, uint8_t* out) {
+        hipLaunchKernelGGL(k_r_topic_write, grid(n, BK), dim3(BK), 0, stream, m, ids, n, offs, out);
+        return launched();
+    }
+    // ids (ascending) gc_flag_one accepts -> out_ids[0 .. *out_count); flags: scratch of q.n_ids bytes
+    bool r_gc_select(const RetainMut& m, const GcQuery& q, uint8_t* flags, uint32_t* out_ids, uint32_t* out_count) {
+        if (q.n_ids == 0) return zero(out_count, sizeof(uint32_t));
+        hipLaunchKernelGGL(k_r_gc_flags, grid(q.n_ids, 256), dim3(256), 0, stream, m, q, flags);
+        if (!launched()) return false;
+        hipcub::CountingInputIterator<uint32_t> iota(0u);
+        size_t bytes = 0;
+        if (!BMQ_X(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota, flags, out_ids, out_count, (int)q.n_ids, stream))) return false;
+        if (!ensure_tmp(bytes)) return false;
+        return BMQ_X(hipcub::DeviceSelect::Flagged(tmp, bytes, iota, flags, out_ids, out_count, (int)q.n_ids, stream));
+    }
+    bool r_find_tenant(const RetainMut& m, const uint8_t* name, uint32_t len, uint32_t* out) {
+        hipLaunchKernelGGL(k_r_find_tenant, dim3(1), dim3(64), 0, stream, m, name, len, out);
         return launched();
     }
 #undef BMQ_X

@@ -14,6 +14,7 @@
 
 #include "bmq_build_core.h"
 #include "bmq_fanout_core.h"
+#include "bmq_retain_core.h"
 
 namespace bmq {
 
@@ -156,6 +157,52 @@ struct HostExec {
     }
     bool gather_bytes(const DistIndexMut& ix, const unsigned long long* refs, const uint64_t* offs, uint32_t n, uint8_t* out) {
         par(n, [&](size_t i) { gather_bytes_one(ix, refs, offs, (uint32_t)i, out); });
+        return true;
+    }
+    // ---- retain direction (bmq_retain_core.h) ----
+    bool r_locate(const RetainMut& m, const RetainOps& ob) {
+        par(ob.n, [&](size_t i) { rlocate_one(m, ob, (uint32_t)i, 0u); });
+        par(ob.n, [&](size_t i) { rlocate_one(m, ob, (uint32_t)i, 1u); });
+        return true;
+    }
+    bool r_commit(const RetainMut& m, const RetainOps& ob) {
+        par(ob.n, [&](size_t i) { rcommit_one(m, ob, (uint32_t)i); });
+        return true;
+    }
+    bool r_rank(const RetainMut& m, uint32_t n_words) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < n_words; w++) {
+            m.dead_rank[w] = run;
+            run += (uint32_t)__builtin_popcountll(m.dead_bits[w]);
+        }
+        m.dead_rank[n_words] = run;
+        return true;
+    }
+    bool r_rehash(const RetainMut& m, uint32_t n_nodes) {
+        par(n_nodes, [&](size_t i) { ov_rehash_one(m, (uint32_t)i); });
+        return true;
+    }
+    bool r_topic_lens(const RetainMut& m, const uint32_t* ids, uint32_t n, uint32_t* lens) {
+        par(n, [&](size_t i) { ov_topic_len_one(m, ids, (uint32_t)i, lens); });
+        return true;
+    }
+    bool r_topic_write(const RetainMut& m, const uint32_t* ids, uint32_t n, const unsigned long long* offs, uint8_t* out) {
+        par(n, [&](size_t i) { ov_topic_write_one(m, ids, (uint32_t)i, offs, out); });
+        return true;
+    }
+    bool r_gc_select(const RetainMut& m, const GcQuery& q, uint8_t* /*flags*/, uint32_t* out_ids, uint32_t* out_count) {
+        uint32_t n = 0;
+        for (uint32_t id = 0; id < q.n_ids; id++)
+            if (gc_flag_one(m, q, id)) out_ids[n++] = id;
+        *out_count = n;
+        return true;
+    }
+    bool r_find_tenant(const RetainMut& m, const uint8_t* name, uint32_t len, uint32_t* out) {
+        LevelScan lv;
+        unsigned long long pos = 0;
+        lv.start = 0;
+        scan_level_bytes<0u>(name, pos, len, lv.h, lv.inl, lv.len);
+        out[0] = ov_find(m.onodes, m.oedges, m.oedge_mask, m.opool, 0u, lv.h.h1, lv.h.h2, lv.len, name, 0);
         return true;
     }
 };

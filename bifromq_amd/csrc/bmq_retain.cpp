@@ -205,45 +205,6 @@ bool RetainIndexHost::rebuild(std::vector<Item>&& items) {
     return refresh(touched);
 }
 
-bool RetainIndexHost::apply(const std::string& tenant, std::vector<Op>&& ops) {
-    error.clear();
-    for (auto& op : ops)
-        if (op.op > 1) {
-            error = "op must be 0 (add) or 1 (remove)";
-            return false;
-        }
-    auto f = by_name.find(tenant);
-    if (f == by_name.end()) {
-        auto st = std::make_unique<RTenantState>();
-        st->name = tenant;
-        f = by_name.emplace(tenant, std::move(st)).first;
-    }
-    RTenantState& t = *f->second;
-    for (auto& op : ops) { // in order: IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134)
-        auto it = std::lower_bound(t.topics.begin(), t.topics.end(), op.topic, topic_less);
-        const size_t pos = (size_t)(it - t.topics.begin());
-        const bool present = it != t.topics.end() && *it == op.topic;
-        const uint64_t ts = op.has_ts ? op.ts : 0;
-        const uint32_t ex = op.has_ts ? op.expiry : 0xFFFFFFFFu;
-        if (op.op == 0) {
-            if (!present) {
-                t.topics.insert(it, std::move(op.topic));
-                t.ts.insert(t.ts.begin() + (long)pos, ts);
-                t.expiry.insert(t.expiry.begin() + (long)pos, ex);
-            } else { // a retained message replaced by a newer one (RS/RetainStoreCoProc.java:246-249: remove + add)
-                t.ts[pos] = ts;
-                t.expiry[pos] = ex;
-            }
-        } else if (present) {
-            t.topics.erase(it);
-            t.ts.erase(t.ts.begin() + (long)pos);
-            t.expiry.erase(t.expiry.begin() + (long)pos);
-        }
-    }
-    std::vector<RTenantState*> touched{&t};
-    return refresh(touched);
-}
-
 bool RetainIndexHost::refresh(std::vector<RTenantState*>& touched) {
     std::vector<RTenantState*> live;
     for (RTenantState* t : touched) {

@@ -3,7 +3,8 @@
 // Replaces RetainTopicIndex (RS/index/RetainTopicIndex.java:35-144), a TopicLevelTrie keyed [tenantId, levels...]
 // walked recursively with the RetainMatcher branch selector (:36-124; UTIL/index/TopicLevelTrie.java:190-249).
 //
-// Layout (host builds, HBM holds), everything PER TENANT so that add/remove rebuild and re-upload one tenant only:
+// Layout of a BULK LOAD (host builds, HBM holds; immutable until the next one -- add / remove in between mutate the overlay of
+// bmq_retain_core.h on the device), per tenant:
 //   * topic id = id_base(tenant) + rank of the topic's level list in byte order, so every trie subtree is ONE contiguous
 //     id range: a trailing '#' is answered with (begin, count) ranges instead of a subtree traversal;
 //   * a tenant's nodes are numbered breadth first (local ids, root = 0) with children sorted by label bytes, so the
@@ -51,6 +52,30 @@ struct alignas(64) RTenantSlot { // tenant directory entry (token == 0: empty)
 };
 static_assert(sizeof(RTenantSlot) == 64, "RTenantSlot must be 64 bytes");
 
+constexpr uint32_t ON_SYS = 0x80000000u; // ONode.str_len flag: the label starts with '$'
+struct alignas(32) ONode {               // one overlay node = one level of a topic added since the last bulk load
+    uint32_t parent;                     // overlay node of the parent level (the root, node 0, has parent NONE; its children are tenants)
+    uint32_t h1, h2;                     // LevelHash of the label
+    uint32_t str_off;                    // the label's bytes in the overlay string pool
+    uint32_t str_len;                    // | ON_SYS
+    uint32_t first_child, next_sibling;  // child list (NONE ends it): what '+' and '#' enumerate
+    uint32_t topic_id;                   // id of the topic that ends here (NONE: none ever did); whether it is retained NOW says the dead bit
+};
+static_assert(sizeof(ONode) == 32, "ONode must be 32 bytes");
+
+// What the match kernels read on top of the bulk-loaded index.
+struct RetainDynView {
+    const ONode* onodes;
+    const uint32_t* oedges; // node index, 0 = empty (the root is nobody's child)
+    uint32_t oedge_mask;
+    const uint8_t* opool;
+    const unsigned long long* dead_bits; // bit id: the id is not retained now (removed, or never handed out)
+    const uint32_t* dead_rank;           // dead ids in front of word w
+    uint32_t base_n;                     // ids below are bulk-loaded ranks, ids from here on belong to overlay topics
+    uint32_t use_dead;                   // some bulk-loaded id is dead: matched ranges are counted / expanded through the bitmap
+    uint32_t ov_live;                    // overlay topics handed out so far (0: the overlay walk is skipped)
+};
+
 struct RetainIndexView {
     const RNode* nodes;
     const REdge* edges;
@@ -59,13 +84,14 @@ struct RetainIndexView {
     const DictSlot* dict;
     uint32_t dict_group_mask;
     const uint8_t* pool;
-    const unsigned long long* expire_at; // per topic id: the millisecond the retained message expires at (~0: never)
+    const unsigned long long* expire_at; // per topic id: the millisecond the retained message expires at (~0: never; 0: removed)
+    RetainDynView dyn;                   // what changed since the bulk load (bmq_retain_core.h)
 };
 
 constexpr uint64_t RETAIN_NEVER = ~0ull;
 // expireAt of RS/RetainStoreCoProc.java:298-304: physical part of the HLC timestamp (base-hlc HLC.java:145-151: hlc >>> 16, in ms)
 // plus the expiry interval in seconds
-inline uint64_t retain_expire_at(uint64_t timestamp_hlc, uint32_t expiry_seconds) { return (timestamp_hlc >> 16) + (uint64_t)expiry_seconds * 1000ull; }
+BMQ_HD uint64_t retain_expire_at(uint64_t timestamp_hlc, uint32_t expiry_seconds) { return (timestamp_hlc >> 16) + (uint64_t)expiry_seconds * 1000ull; }
 
 struct RTenantState {
     std::string name;
@@ -105,15 +131,7 @@ struct RetainIndexHost {
         uint32_t expiry = 0xFFFFFFFFu;
         bool has_ts = false;
     };
-    struct Op {
-        std::string topic;
-        uint8_t op = 0; // 0 add, 1 remove
-        uint64_t ts = 0;
-        uint32_t expiry = 0xFFFFFFFFu;
-        bool has_ts = false;
-    };
-    bool rebuild(std::vector<Item>&& items);
-    bool apply(const std::string& tenant, std::vector<Op>&& ops);
+    bool rebuild(std::vector<Item>&& items); // (add / remove between bulk loads: bmq_retain_core.h, on the device)
     bool topic(uint32_t id, std::string_view& tenant, std::string_view& topic, uint64_t* ts = nullptr, uint32_t* expiry = nullptr) const;
     uint64_t n_tenants() const { return by_name.size(); }
 

@@ -14,12 +14,14 @@
 
 #include "bmq_dist_kernels.h"
 #include "bmq_retain.h"
+#include "bmq_retain_core.h"
 
 namespace bmq {
 
 constexpr uint32_t R_MAXL = 64;        // filter levels supported by the kernel
 constexpr uint32_t R_FRONT = 768;      // frontier ranges kept in LDS (per buffer)
 constexpr uint32_t R_OUT = 512;        // matched ranges of one filter buffered in LDS (more: a second, writing walk)
+constexpr uint32_t OV_OUT = 256;       // matched OVERLAY topic ids of one filter ordered in LDS (more: flushed unordered, the row is repaired)
 constexpr uint32_t RT_PLUS = 0xFFFFFFFDu, RT_HASH = 0xFFFFFFFCu; // level kinds next to dictionary tokens
 constexpr uint32_t ST_RETAIN_DEEP = 128u, ST_RETAIN_FRONT = 256u;
 
@@ -76,6 +78,9 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
     __shared__ uint32_t fb0[R_FRONT], fc0[R_FRONT], fb1[R_FRONT], fc1[R_FRONT];
     __shared__ uint32_t sh[12];
     __shared__ uint32_t ob[R_OUT], oc[R_OUT];
+    __shared__ uint32_t lh1[R_MAXL + 1], lh2[R_MAXL + 1], llen[R_MAXL + 1]; // level hashes: the overlay is keyed by them
+    __shared__ uint32_t ovb[OV_OUT], ovs[OV_OUT];
+    const RetainDynView dyn = r.ix.dyn;
     const uint32_t lane = threadIdx.x;
     uint2* gs = r.gscratch + (size_t)blockIdx.x * 2 * r.gcap;
     const uint32_t cap = R_FRONT + r.gcap;
@@ -127,10 +132,14 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                     tok = dict_lookup(dv, h, len, inl, start, fbyte);
                 }
                 ftok[lane] = tok;
+                lh1[lane] = h.h1;
+                lh2[lane] = h.h2;
+                llen[lane] = len;
             }
             if (lane == 63) { // tenant -> root
                 const uint32_t ti = r.filter_tenant[f];
                 uint32_t tok = TOK_UNKNOWN;
+                sh[9] = NONE; // the tenant's node in the overlay trie
                 if (ti < r.n_tenants) {
                     const uint8_t* tb = r.tenants;
                     auto tbyte = [&](uint32_t k) -> uint32_t { return tb[k]; };
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                     dv.dict_group_mask = r.ix.dict_group_mask;
                     dv.pool = r.ix.pool;
                     tok = dict_lookup(dv, h, len, inl, start, tbyte);
+                    if (r.ix.dyn.ov_live) sh[9] = ov_find(r.ix.dyn.onodes, r.ix.dyn.oedges, r.ix.dyn.oedge_mask, r.ix.dyn.opool, 0u, h.h1, h.h2, len, tb, start);
                 }
                 uint32_t root = NONE;
                 if (tok != TOK_UNKNOWN) {
@@ -171,7 +181,8 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
         }
         __syncthreads();
         const uint32_t root = deep ? NONE : sh[0];
-        ten.node_base = sh[1]; ten.edge_base = sh[2]; ten.edge_bucket_mask = sh[3]; ten.id_base = sh[4];
+        const uint32_t tnode = (deep || !dyn.ov_live) ? NONE : sh[9];
+        ten.node_base = sh[1]; ten.edge_base = sh[2]; ten.edge_bucket_mask = sh[3]; ten.id_base = root != NONE ? sh[4] : 0u;
         ten.sys_node_lo = sh[5]; ten.sys_node_hi = sh[6]; ten.sys_id_lo = sh[7]; ten.sys_id_hi = sh[8];
         if (deep && lane == 0) atomicOr(&a.ctr->status, ST_RETAIN_DEEP);
 
@@ -183,16 +194,20 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             const uint32_t vinc = pass == 0 ? 1u : 0u; // nodes touched are counted once, in the counting pass
             auto emit = [&](bool pred, uint32_t b, uint32_t c) {
                 const unsigned long long m = __ballot(pred);
+                uint32_t live = c;
                 if (pred) { // b is a tenant-local topic rank: ids are global
-                    const uint32_t p = wp + rank_below(m);
-                    if (pass == 1) a.pairs[base + p] = MatchRange{ten.id_base + b, c};
+                    const uint32_t p = wp + rank_below(m), g = ten.id_base + b;
+                    if (pass == 1) a.pairs[base + p] = MatchRange{g, c};
                     else if (p < R_OUT) { // first walk: keep the ranges in LDS, most filters never need the second walk
-                        ob[p] = ten.id_base + b;
+                        ob[p] = g;
                         oc[p] = c;
                     }
+                    // topics removed since the bulk load keep their ids: the range stays whole, its live count comes from the rank
+                    // directory of the dead bitmap (two lookups), and the expansion skips the dead ids
+                    if (dyn.use_dead && g < dyn.base_n) live = c - (dead_before(dyn.dead_bits, dyn.dead_rank, g + c) - dead_before(dyn.dead_bits, dyn.dead_rank, g));
                 }
                 wp += (uint32_t)__popcll(m);
-                unsigned long long s = pred ? c : 0u;
+                unsigned long long s = pred ? live : 0u;
                 nr += (uint32_t)wave_sum_u64(s);
             };
             Frontier cur{fb0, fc0, gs}, nxt{fb1, fc1, gs + r.gcap};
@@ -341,6 +356,119 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                 }
             }
             __syncthreads();
+            // ---- the overlay: topics added since the bulk load (bmq_retain_core.h).  A small hashed trie keyed (parent node, level
+            // hash), labels verified in its string pool, walked with a frontier of single nodes; '+' and '#' follow child lists.  Its
+            // topics carry ids above every bulk-loaded id, so ordering them among themselves keeps the row ascending. ----------------
+            if (tnode != NONE) {
+                Frontier ocur{fb0, fc0, gs}, onxt{fb1, fc1, gs + r.gcap};
+                uint32_t on = 1, n_ov = 0;
+                bool oflow = false;
+                if (lane == 0) ocur.put(0, tnode, 1);
+                __syncthreads();
+                auto take = [&](bool pred, uint32_t id) { // a matched overlay topic (wave-uniform call sites only)
+                    const unsigned long long m = __ballot(pred);
+                    const uint32_t cnt = (uint32_t)__popcll(m);
+                    if (n_ov + cnt > OV_OUT) { // the buffer is full: what it holds goes out unordered (k_sort_rows repairs the row)
+                        for (uint32_t i0 = 0; i0 < n_ov; i0 += 64) {
+                            const bool in = i0 + lane < n_ov;
+                            emit(in, (in ? ovb[i0 + lane] : 0u) - ten.id_base, 1);
+                        }
+                        n_ov = 0;
+                        wave_sync();
+                    }
+                    if (pred) ovb[n_ov + rank_below(m)] = id;
+                    n_ov += cnt;
+                };
+                auto live_topic = [&](uint32_t node) -> uint32_t { // id of the topic retained at an overlay node, or NONE
+                    const uint32_t id = dyn.onodes[node].topic_id;
+                    return (id != NONE && !id_dead(dyn.dead_bits, id)) ? id : NONE;
+                };
+                auto push_children = [&](uint32_t node, bool skip_sys) { // per lane: the child list of one node into the next frontier
+                    for (uint32_t c = dyn.onodes[node].first_child; c != NONE; c = dyn.onodes[c].next_sibling) {
+                        if (skip_sys && (dyn.onodes[c].str_len & ON_SYS)) continue; // a first-level wildcard never matches a '$' level
+                        const uint32_t p = atomicAdd(&sh[10], 1u);
+                        if (p < cap) onxt.put(p, c, 1);
+                        else oflow = true;
+                    }
+                };
+                bool odone = false;
+                for (uint32_t l = 0; l < nlev && on && !odone; l++) {
+                    const uint32_t kind = ftok[l];
+                    if (kind == RT_HASH) { // the frontier's nodes (from level 1 on: "a/#" matches "a") and everything below, level by level
+                        bool first = true;
+                        while (on) {
+                            if (lane == 0) sh[10] = 0;
+                            __syncthreads();
+                            for (uint32_t i0 = 0; i0 < on; i0 += 64) {
+                                const bool in = i0 + lane < on;
+                                const uint32_t node = in ? ocur.get(i0 + lane).x : 0u;
+                                uint32_t id = NONE;
+                                if (in) {
+                                    if (!(first && l == 0)) id = live_topic(node); // (at level 0 the first frontier is the tenant itself)
+                                    visits += vinc;
+                                    push_children(node, first && l == 0);
+                                }
+                                take(id != NONE, id);
+                            }
+                            __syncthreads();
+                            on = min(sh[10], cap);
+                            const Frontier t = ocur;
+                            ocur = onxt;
+                            onxt = t;
+                            first = false;
+                            __syncthreads();
+                        }
+                        odone = true;
+                        break;
+                    }
+                    if (lane == 0) sh[10] = 0;
+                    __syncthreads();
+                    for (uint32_t i0 = 0; i0 < on; i0 += 64) {
+                        if (i0 + lane >= on) continue;
+                        const uint32_t node = ocur.get(i0 + lane).x;
+                        visits += vinc;
+                        if (kind == RT_PLUS) push_children(node, l == 0);
+                        else {
+                            const uint32_t c = ov_find(dyn.onodes, dyn.oedges, dyn.oedge_mask, dyn.opool, node, lh1[l], lh2[l], llen[l], r.filters, lev_start[l]);
+                            if (c != NONE) {
+                                const uint32_t p = atomicAdd(&sh[10], 1u);
+                                if (p < cap) onxt.put(p, c, 1);
+                                else oflow = true;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    on = min(sh[10], cap);
+                    const Frontier t = ocur;
+                    ocur = onxt;
+                    onxt = t;
+                    __syncthreads();
+                }
+                if (!odone) // the filter ended without '#': topics that end exactly at a frontier node
+                    for (uint32_t i0 = 0; i0 < on; i0 += 64) {
+                        const bool in = i0 + lane < on;
+                        uint32_t id = NONE;
+                        if (in) {
+                            id = live_topic(ocur.get(i0 + lane).x);
+                            visits += vinc;
+                        }
+                        take(id != NONE, id);
+                    }
+                if (__any(oflow) && lane == 0) atomicOr(&a.ctr->status, ST_RETAIN_FRONT); // the batch is re-run with a larger frontier
+                wave_sync();
+                for (uint32_t j = lane; j < n_ov; j += 64) { // order what the buffer holds: rank of every id among the others
+                    const uint32_t x = ovb[j];
+                    uint32_t rk = 0;
+                    for (uint32_t k = 0; k < n_ov; k++) rk += ovb[k] < x ? 1u : 0u;
+                    ovs[rk] = x;
+                }
+                wave_sync();
+                for (uint32_t i0 = 0; i0 < n_ov; i0 += 64) {
+                    const bool in = i0 + lane < n_ov;
+                    emit(in, (in ? ovs[i0 + lane] : 0u) - ten.id_base, 1);
+                }
+                __syncthreads();
+            }
             if (pass == 0) {
                 np_total = wp;
                 nr_total = nr;
@@ -482,6 +610,67 @@ __global__ __launch_bounds__(256) void k_limit_copy_live(const uint32_t* row_ptr
     uint32_t t = 0;
     for (uint32_t k = src; k < e && t < c; k++)
         if (expire_at[ids[k]] > now) out_ids[dst + t++] = ids[k];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_retain_expand_dyn -- CSR of a retain batch when bulk-loaded ids have been removed since the load (RetainDynView.use_dead): the
+// matched ranges still cover the removed ids (they keep their place in the id space), route_cnt holds the LIVE counts, and this
+// expansion drops the dead ids on the way out.  One wave per 64 rows (k_expand's blocking and row-base arithmetic); a row's ranges
+// are streamed 64 ids at a time, live lanes compacted by ballot: reads one bitmap word per 64 ids, writes whole lines.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_retain_expand_dyn(BatchArgs a, const unsigned long long* dead_bits, uint32_t base_n) {
+    const uint32_t lane = threadIdx.x, blk = blockIdx.x;
+    if (blk >= a.n_blocks) return;
+    const uint32_t t = (blk << a.tpw_shift) + lane;
+    const bool valid = t < a.n_topics;
+    const uint32_t status = a.ctr->status;
+    const uint32_t nr = valid ? a.route_cnt[t] : 0u, po = valid ? a.pair_off[t] : 0u, np = valid ? a.pair_cnt[t] : 0u;
+    uint32_t wtotal;
+    const uint32_t excl = wave_excl_scan(nr, lane, wtotal);
+    unsigned long long wbase;
+    {
+        const uint32_t sb = blk >> SUPER_SHIFT;
+        unsigned long long acc = 0;
+        for (uint32_t i = lane; i < sb; i += 64) acc += a.super_sums[(size_t)i * SUPER_STRIDE];
+        for (uint32_t i = (sb << SUPER_SHIFT) + lane; i < blk; i += 64) acc += a.wave_sums[i];
+        wbase = wave_sum_u64(acc);
+    }
+    const unsigned long long row = wbase + excl, wend = wbase + wtotal;
+    const bool range_err = wend >= 0xFFFFFFFFull, no_space = wend > a.out_capacity;
+    if (blk == a.n_blocks - 1 && lane == 0) {
+        a.ctr->total_ids = wend;
+        *a.out_total = wend;
+    }
+    if ((range_err || no_space) && lane == 0) atomicOr(&a.ctr->status, range_err ? (uint32_t)ST_RANGE : (uint32_t)ST_NOSPACE);
+    if (valid && !range_err) {
+        a.out_row_ptr[t] = (uint32_t)row;
+        if (t == a.n_topics - 1) a.out_row_ptr[a.n_topics] = (uint32_t)(row + nr);
+    }
+    if ((status & (ST_NEED_PAIRS | ST_RETAIN_FRONT | ST_RETAIN_DEEP)) || range_err || no_space || wtotal == 0) return;
+    for (uint32_t l = 0; l < 64; l++) { // the wave works through its rows one after the other
+        const uint32_t r_np = __shfl(np, (int)l), r_po = __shfl(po, (int)l), r_nr = __shfl(nr, (int)l);
+        if (r_np == 0 || r_nr == 0) continue;
+        uint32_t* out = a.out_ids + (wbase + __shfl(excl, (int)l));
+        uint32_t done = 0, prev_last = 0;
+        bool bad = false;
+        for (uint32_t k = 0; k < r_np; k++) {
+            const MatchRange rg = a.pairs[r_po + k]; // wave-uniform
+            if (k && rg.begin <= prev_last) bad = true; // ranges out of order (overlay ids flushed unordered): the row is sorted afterwards
+            prev_last = rg.begin + rg.count - 1;
+            for (uint32_t o = 0; o < rg.count; o += 64) {
+                const uint32_t id = rg.begin + o + lane;
+                const bool live = o + lane < rg.count && !(id < base_n && id_dead(dead_bits, id)); // (overlay topics were checked by the walk)
+                const unsigned long long m = __ballot(live);
+                if (live) out[done + rank_below(m)] = id;
+                done += (uint32_t)__popcll(m);
+            }
+        }
+        if (bad && r_nr > 1 && lane == 0) {
+            const uint32_t sp = atomicAdd(&a.ctr->sort_count, 1u);
+            if (sp < a.sort_cap) a.sort_list[sp] = (blk << a.tpw_shift) + l;
+            else atomicOr(&a.ctr->status, ST_NEED_SORTLIST);
+        }
+    }
 }
 
 } // namespace bmq

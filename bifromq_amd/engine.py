@@ -418,6 +418,67 @@ class Engine:
             self._check(_lib.lib().bmq_retain_apply(self.h, t, len(t), _ptr(data), _ptr(off), _ptr(op), len(ops)))
         return self
 
+    def retain_apply_batch(self, tenants: Sequence, op_tenant, ops: Sequence, packed_topics=None, op_codes=None, timestamps=None, expiry=None):
+        """bmq_retain_apply_batch: ops of several tenants in one call.  ops: (0 = add | 1 = remove, topic[, timestamp_hlc, expiry_seconds])
+        -- or packed_topics + op_codes (+ timestamps, expiry) for large batches.  -> the topic id of every op (0xFFFFFFFF: no-op)"""
+        tdata, toff = pack(tenants)
+        if packed_topics is None:
+            data, off = pack([o[1] for o in ops])
+            op = np.array([o[0] for o in ops], dtype=np.uint8)
+            if any(len(o) > 2 for o in ops):
+                timestamps = np.array([o[2] if len(o) > 2 else 0 for o in ops], dtype=np.uint64)
+                expiry = np.array([o[3] if len(o) > 3 else 0xFFFFFFFF for o in ops], dtype=np.uint32)
+        else:
+            data, off = packed_topics
+            op = np.ascontiguousarray(op_codes, dtype=np.uint8)
+        n = len(off) - 1
+        ot = None if op_tenant is None else np.ascontiguousarray(op_tenant, dtype=np.uint32)
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, dtype=np.uint64)
+        ex = None if expiry is None else np.ascontiguousarray(expiry, dtype=np.uint32)
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        self._check(_lib.lib().bmq_retain_apply_batch(self.h, _ptr(tdata), _ptr(toff), len(tenants), _ptr(ot), _ptr(data), _ptr(off), _ptr(op),
+                                                      _ptr(ts), _ptr(ex), n, _ptr(out)))
+        return out[:n]
+
+    def retain_compact(self):
+        self._check(_lib.lib().bmq_retain_compact(self.h))
+        return self
+
+    def retain_info(self) -> "_lib.RetainInfo":
+        st = _lib.RetainInfo()
+        self._check(_lib.lib().bmq_retain_info_get(self.h, C.byref(st)))
+        return st
+
+    def retain_live_ids(self, tenant=None) -> List[int]:
+        """ids of the retained topics, ascending (tenant None: of every tenant) -- IRetainTopicIndex.findAll()"""
+        t = None if tenant is None else _b(tenant)
+        cap = 1024
+        n = C.c_uint32()
+        while True:
+            out = np.zeros(cap, dtype=np.uint32)
+            rc = _lib.lib().bmq_retain_live_ids(self.h, t, len(t) if t is not None else 0, _ptr(out), cap, C.byref(n))
+            if rc == -3:
+                cap = n.value
+                continue
+            self._check(rc)
+            return out[:n.value].tolist()
+
+    def retain_topics(self, topic_ids) -> List[Tuple[str, str]]:
+        """many ids -> [(tenant, topic)] (("", "") for an unknown id)"""
+        ids = np.ascontiguousarray(topic_ids, dtype=np.uint32)
+        n = len(ids)
+        off, tl = np.zeros(n + 1, dtype=np.uint64), np.zeros(max(n, 1), dtype=np.uint32)
+        cap = max(4096, 64 * n)
+        while True:
+            out = np.zeros(cap, dtype=np.uint8)
+            rc = _lib.lib().bmq_retain_topics(self.h, _ptr(ids), n, _ptr(out), cap, _ptr(off), _ptr(tl))
+            if rc == -3:
+                cap = int(off[n]) + 16
+                continue
+            self._check(rc)
+            raw = out.tobytes()
+            return [(raw[int(off[i]):int(off[i]) + int(tl[i])].decode(), raw[int(off[i]) + int(tl[i]):int(off[i + 1])].decode()) for i in range(n)]
+
     def retain_topic_info(self, topic_id: int) -> Tuple[int, int, int]:
         """-> (timestamp_hlc, expiry_seconds, expire_at_ms)"""
         ts, ex, at = C.c_uint64(), C.c_uint32(), C.c_uint64()
@@ -425,7 +486,7 @@ class Engine:
         return ts.value, ex.value, at.value
 
     def retain_find_all(self) -> Tuple[int, int]:
-        """IRetainTopicIndex.findAll(): (number of topics -- the ids are 0 .. n-1, retain epoch)"""
+        """IRetainTopicIndex.findAll(): (number of retained topics, retain epoch); retain_live_ids lists the ids"""
         n, ep = C.c_uint64(), C.c_uint64()
         self._check(_lib.lib().bmq_retain_find_all(self.h, C.byref(n), C.byref(ep)))
         return n.value, ep.value

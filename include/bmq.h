@@ -472,11 +472,12 @@ int bmq_retain_range_lookup(const uint8_t* tenant, uint32_t tenant_len, const ui
                             const uint32_t* end_off, uint32_t n_ranges, uint32_t mode, uint8_t* out_keep);
 
 /* ---- retain direction (RS/index/IRetainTopicIndex.java:27-35) -------------------------------------------- */
-/* Load the retained-topic index: (tenant, topic) pairs; topic id = rank of (tenant, levels) in byte order (tenants in byte order
- * of their ids, a tenant's topics level list by level list).  Ids are RANKS: every bmq_retain_rebuild* / bmq_retain_apply* shifts
- * them (bmq_retain_find_all reports the retain epoch) -- resolve ids (bmq_retain_topic) before the next mutation, the way the
- * reference reads its index under the apply thread (RS/RetainStoreCoProc.java:240-255).
- * Replaces the full-scan rebuild in RS/RetainStoreCoProc.java:134-137,279-296.
+/* A retained-topic id is a STABLE handle, like a route id: a bulk load (bmq_retain_rebuild*, bmq_retain_compact) numbers the topics by
+ * the rank of (tenant, level list) in byte order -- tenants in byte order of their ids, a tenant's topics level list by level list, so
+ * that every subtree is one id range --; a topic added later by bmq_retain_apply* gets the next unused id; the id of a removed topic
+ * goes dead and comes back to life when the topic is retained again.  No id changes or is reused until the next bulk load
+ * (bmq_retain_info.generation counts them).
+ * Load the retained-topic index: (tenant, topic) pairs.  Replaces the full-scan rebuild in RS/RetainStoreCoProc.java:134-137,279-296.
  * _ex: with what IRetainTopicIndex.add(tenantId, topic, timestamp, expirySeconds) carries (RS/index/IRetainTopicIndex.java:28):
  * timestamp_hlc[i] = Message.timestamp (an HLC: milliseconds << 16 | counter, base-hlc HLC.java:145-151), expiry_seconds[i] =
  * Message.expiryInterval; the message expires at (timestamp_hlc >> 16) + 1000 * expiry_seconds ms (RS/RetainStoreCoProc.java:298-304).
@@ -487,25 +488,61 @@ int bmq_retain_rebuild(bmq_engine* e, const uint8_t* tenants, const uint32_t* te
 int bmq_retain_rebuild_ex(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
                           const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
                           const uint64_t* timestamp_hlc, const uint32_t* expiry_seconds);
-/* IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134); op[i]: 0 = add (an add of a topic that is there
- * replaces its timestamp / expiry: RS/RetainStoreCoProc.java:246-249), 1 = remove. */
+/* IRetainTopicIndex.add / remove (RS/index/RetainTopicIndex.java:126-134; UTIL/index/TopicLevelTrie.java:49-182) as the post-commit
+ * closures of RetainStoreCoProc.batchRetain / gc issue them (RS/RetainStoreCoProc.java:240-255,270-275); op[i]: 0 = add (an add of a
+ * topic that is there replaces its timestamp / expiry: :246-249), 1 = remove (of an absent topic: a no-op).  The index is mutated
+ * WHERE IT LIVES, by three kernels on the engine stream (bmq_retain_core.h): the batch lands behind every match batch launched before
+ * it and in front of every later one; matching is never refused while a batch is applied, and the call returns when the device has
+ * applied it.  Ops on the same topic inside one batch take effect in order (the last one decides).  A malformed op (op code, tenant
+ * index) fails the batch with BMQ_E_INVAL before anything is changed.
+ * _batch: ops of several tenants in one call -- op_tenant[i] indexes the tenant table (NULL: every op belongs to tenant 0);
+ * out_topic_ids (may be NULL) [i] = the id of op i's topic, 0xFFFFFFFF for the removal of an absent topic or an op that a later op on
+ * the same topic superseded. */
 int bmq_retain_apply(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics,
                      const uint32_t* topic_off, const uint8_t* op, uint32_t n);
 int bmq_retain_apply_ex(bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topics, const uint32_t* topic_off,
                         const uint8_t* op, const uint64_t* timestamp_hlc, const uint32_t* expiry_seconds, uint32_t n);
-/* id -> retained topic: out receives the tenant id followed by the topic (no separator), *out_tenant_len bytes of
- * tenant, *out_len bytes in total. */
+int bmq_retain_apply_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* op_tenant,
+                           const uint8_t* topics, const uint32_t* topic_off, const uint8_t* op, const uint64_t* timestamp_hlc,
+                           const uint32_t* expiry_seconds, uint32_t n, uint32_t* out_topic_ids);
+/* Maintenance: fold what bmq_retain_apply* changed into a fresh bulk load (removed topics and their ids go, added topics become ranks
+ * again: every subtree one id range, the fast path of '+' and '#').  A new generation of ids. */
+int bmq_retain_compact(bmq_engine* e);
+typedef struct bmq_retain_info {
+    uint64_t n_topics;        /* retained topics now */
+    uint64_t n_tenants;       /* tenants of the last bulk load */
+    uint64_t id_bound;        /* every id handed out in this generation is below */
+    uint64_t loaded_topics;   /* ids below are ranks of the last bulk load ... */
+    uint64_t loaded_removed;  /* ... of which that many have been removed since */
+    uint64_t added_ids;       /* ids handed out to topics added since the bulk load */
+    uint64_t overlay_nodes;   /* nodes of the overlay trie that holds them */
+    uint64_t epoch;           /* +1 per rebuild / apply / compact */
+    uint64_t generation;      /* +1 per bulk load (rebuild / compact): ids of different generations are unrelated */
+} bmq_retain_info;
+int bmq_retain_info_get(const bmq_engine* e, bmq_retain_info* out);
+/* id -> the topic the id denotes in this generation (whether or not it is retained right now: bmq_retain_topic_info tells): out
+ * receives the tenant id followed by the topic (no separator), *out_tenant_len bytes of tenant, *out_len bytes in total.
+ * bmq_retain_topics: many ids at once (bulk-loaded ids from the host's copy of the load, added ones with ONE device gather):
+ * out_off[n + 1] byte offsets into out, out_tenant_len[n]; an unknown id gives an empty string. */
 int bmq_retain_topic(const bmq_engine* e, uint32_t topic_id, uint8_t* out, uint32_t cap, uint32_t* out_len,
                      uint32_t* out_tenant_len);
-/* id -> the rest of RetainedMsgInfo (RS/index/RetainedMsgInfo.java:29-36) + the expiry instant in ms (~0: never); any out may be NULL */
+int bmq_retain_topics(const bmq_engine* e, const uint32_t* topic_ids, uint32_t n, uint8_t* out, uint64_t cap, uint64_t* out_off,
+                      uint32_t* out_tenant_len);
+/* id -> the rest of RetainedMsgInfo (RS/index/RetainedMsgInfo.java:29-36) + the expiry instant in ms (~0: never); any out may be NULL.
+ * BMQ_E_INVAL: the id was never handed out, or its topic is not retained any more. */
 int bmq_retain_topic_info(const bmq_engine* e, uint32_t topic_id, uint64_t* out_timestamp_hlc, uint32_t* out_expiry_seconds,
                           uint64_t* out_expire_at_ms);
-/* IRetainTopicIndex.findAll() (RS/index/RetainTopicIndex.java:140-143): the ids are exactly 0 .. *out_n_topics - 1.
- * *out_epoch (may be NULL) counts the retain mutations so far. */
+/* IRetainTopicIndex.findAll() (RS/index/RetainTopicIndex.java:140-143): *out_n_topics = retained topics now, *out_epoch (may be
+ * NULL) counts the retain mutations so far; bmq_retain_live_ids lists their ids, ascending -- of one tenant (every topic of it, '$'
+ * ones too) or, tenant == NULL, of all.  Writes up to cap ids, *out_n = total; BMQ_E_NOSPACE if cap was too small. */
 int bmq_retain_find_all(const bmq_engine* e, uint64_t* out_n_topics, uint64_t* out_epoch);
-/* The scan of RetainStoreCoProc's GC (RS/RetainStoreCoProc.java:257-277): ids (ascending) of the topics of `tenant` (NULL: of
- * every tenant) whose message has expired at now_ms; override_expiry_seconds >= 0 replaces the stored expiry interval as
- * GCRequest.expirySeconds does.  Writes up to cap ids, *out_n = total; BMQ_E_NOSPACE if cap was too small. */
+int bmq_retain_live_ids(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, uint32_t* out_ids, uint32_t cap, uint32_t* out_n);
+/* The scan of RetainStoreCoProc's GC (RS/RetainStoreCoProc.java:257-277): ids (ascending) of the retained topics whose message has
+ * expired at now_ms (expireTime <= now) -- of every tenant (tenant == NULL: the reference's findAll() branch), or of `tenant`: there the
+ * reference scans index.match(tenantId, "#"), which does not reach topics whose first level starts with '$'
+ * (RS/index/RetainTopicIndex.java:60,86,99), and neither does this.  override_expiry_seconds >= 0 replaces the stored expiry interval
+ * as GCRequest.expirySeconds does.  One kernel over the ids + a device select.  Writes up to cap ids, *out_n = total; BMQ_E_NOSPACE
+ * if cap was too small. */
 int bmq_retain_expired(const bmq_engine* e, const uint8_t* tenant, uint32_t tenant_len, uint64_t now_ms,
                        int64_t override_expiry_seconds, uint32_t* out_ids, uint32_t cap, uint32_t* out_n);
 /* Batch of IRetainTopicIndex.match(tenant, topicFilter) (RS/index/RetainTopicIndex.java:136-138; selector

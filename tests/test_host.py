@@ -167,11 +167,15 @@ def test_host_index_fuzz_under_sanitizers():
     for seed in ("2", "11"):  # the lock-free inserts (dictionary slots, trie slots, Bloom words) under ThreadSanitizer
         r = subprocess.run([exe + "_tsan", seed, "25", "3000", "8"], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "host_fuzz ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
-    # the retain direction's host index (tools/retain_fuzz.cpp): per-tenant add/remove, segment growth, '$' runs
+    # the retain direction (tools/retain_fuzz.cpp): the bulk load, and the mutation functions the gfx950 kernels k_r_locate / k_r_commit /
+    # k_r_rank run (bmq_retain_core.h) on host threads with minimal capacities: id stability, stamps, dead-aware image walk + overlay
+    # walk == brute force, GC scan, live-id listing; the lock-free overlay inserts under ThreadSanitizer
     exe = os.path.join(ROOT, "tools", "retain_fuzz")
-    for seed, rounds in ((1, 25), (7, 25)):
-        r = subprocess.run([exe, str(seed), str(rounds)], capture_output=True, text=True, timeout=600)
+    for seed, rounds, threads in ((1, 30, 4), (7, 30, 1)):
+        r = subprocess.run([exe, str(seed), str(rounds), str(threads)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "retain_fuzz ok" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe + "_tsan", "3", "25", "8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "retain_fuzz ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
 
 
 def test_header_is_plain_c_and_usable_from_c(tmp_path):
@@ -347,3 +351,39 @@ def test_route_detail_and_receiver_cache_cases():
         rlen = int.from_bytes(k[-2:], "big")
         bad[len(k) - 2 - rlen - 1] = 9
         assert O.parse_route_key(bytes(bad)) is None and B.decode_route_key(bytes(bad)) is None
+
+
+def test_retain_mutation_abi_on_host_only_engine():
+    """bmq_retain_apply_batch / info / live_ids / topics / expired / compact through the C ABI on a host-only engine: the same
+    bmq_retain_core.h functions the gfx950 kernels run, on host threads (matching itself needs the device)."""
+    e = B.Engine(device=-1)
+    e.retain_rebuild(["t", "u"], [0, 0, 0, 1], ["a/b", "a/c", "$s/x", "q"], timestamps=[1 << 16, 2 << 16, 3 << 16, 4 << 16], expiry=[1, 2, 3, 4])
+    assert e.retain_find_all()[0] == 4 and e.retain_live_ids() == [0, 1, 2, 3] and e.retain_live_ids("t") == [0, 1, 2]
+    ids = e.retain_apply_batch(["t", "v"], [0, 0, 1, 0, 0], [(0, "a/d", 5 << 16, 9), (1, "a/b"), (0, "x/y"), (1, "nope"), (0, "$s/z")])
+    assert ids.tolist() == [4, 1, 5, 0xFFFFFFFF, 6]  # new topics: the next unused ids; a removed topic reports its id; an absent one none
+    assert e.retain_live_ids() == [0, 2, 3, 4, 5, 6] and e.retain_find_all()[0] == 6
+    assert e.retain_topics([0, 2, 3, 4, 5, 6, 1]) == [("t", "$s/x"), ("t", "a/c"), ("u", "q"), ("t", "a/d"), ("v", "x/y"), ("t", "$s/z"), ("t", "a/b")]
+    assert e.retain_topic_info(4) == (5 << 16, 9, 9005) and e.retain_topic_info(5) == (0, 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF)
+    with pytest.raises(B.BmqError):
+        e.retain_topic_info(1)  # removed
+    # the GC scan: one tenant = what match(tenant, "#") reaches (no '$' topics), all tenants = findAll()
+    assert e.retain_expired("t", 10 ** 9) == [2, 4] and e.retain_expired(None, 10 ** 9) == [0, 2, 3, 4]
+    info = e.retain_info()
+    assert (info.n_topics, info.id_bound, info.loaded_topics, info.loaded_removed, info.added_ids, info.generation) == (6, 7, 4, 1, 3, 1)
+    # ops on one topic inside a batch take effect in order; a re-added topic gets its id back
+    ids = e.retain_apply_batch(["t"], None, [(0, "a/b"), (1, "a/d"), (0, "a/d"), (1, "a/d")])
+    assert ids.tolist() == [1, 0xFFFFFFFF, 0xFFFFFFFF, 4] and e.retain_live_ids() == [0, 1, 2, 3, 5, 6]
+    with pytest.raises(B.BmqError) as ei:
+        e.retain_apply_batch(["t"], [0, 3], [(0, "ok"), (0, "bad-tenant-index")])
+    assert ei.value.code == -1 and e.retain_find_all()[0] == 6  # nothing was changed
+    e.retain_compact()
+    live = e.retain_live_ids()
+    assert live == list(range(6)) and e.retain_topics(live) == [("t", "$s/x"), ("t", "$s/z"), ("t", "a/b"), ("t", "a/c"), ("u", "q"), ("v", "x/y")]
+    info = e.retain_info()
+    assert (info.generation, info.added_ids, info.loaded_removed, info.n_tenants) == (2, 0, 0, 3)
+    assert e.retain_topic_info(2)[0] == 0 and e.retain_topic_info(3) == (2 << 16, 2, 2002)  # stamps travel through the compaction
+    # a fresh engine: the first add creates the index
+    e2 = B.Engine(device=-1)
+    assert e2.retain_apply_batch(["z"], None, [(0, "k/l")]).tolist() == [0] and e2.retain_topics([0]) == [("z", "k/l")]
+    e2.close()
+    e.close()

@@ -1,0 +1,215 @@
+"""GPU tests of the retain direction UNDER MUTATION (TopicLevelTrie.add / remove, UTIL/index/TopicLevelTrie.java:49-182,
+driven by RS/RetainStoreCoProc.java:240-255,270-275): bmq_retain_apply* mutates the index in HBM (bmq_retain_core.h), topic ids are
+stable handles.  Oracle: the restated TopicLevelTrie + RetainMatcher (oracle.LevelTrie) fed with the engine's ids."""
+import random
+import time
+
+import numpy as np
+import pytest
+
+import bifromq_amd as B
+from bifromq_amd.workload import unpack
+from oracle import oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = B.Engine(device=0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_add_remove_match_interleave(eng, seed):
+    """batches of adds / removes over several tenants (new tenants, '$' first levels, empty levels, re-adds, duplicates inside a batch)
+    interleaved with match batches, a compaction in the middle: after every batch ids are stable, every row equals the oracle's,
+    RetainStoreCoProc.match(limit, now) and the GC scan equal their restatements."""
+    rnd = random.Random(seed)
+    tenants = ["tA", "tB", "late-tenant", "ghost"]
+    base = sorted({(rnd.randrange(2), U.rand_topic(rnd, 5)) for _ in range(4000)})
+    base_ms = 1_700_000_000_000
+    ts0 = [((base_ms + rnd.randrange(100_000)) << 16) | rnd.randrange(1 << 16) for _ in base]
+    ex0 = [rnd.choice([0, 1, 30, 60, 3600]) for _ in base]
+    eng.retain_rebuild(tenants[:2], [t for t, _ in base], [p for _, p in base], timestamps=ts0, expiry=ex0)
+    order = U.retain_order(tenants[:2], [t for t, _ in base], [p for _, p in base])
+    lt = O.LevelTrie(1)
+    ident = {}   # (tenant, topic) -> id, every topic that ever got one in this generation
+    live = {}    # retained now -> id
+    stamp = {}
+    for (t, p), a, b in zip(base, ts0, ex0):
+        stamp[(tenants[t], p)] = (a, b)
+    for i, key in enumerate(order):
+        ident[key] = live[key] = i
+        lt.add(key[0], key[1], i)
+    gen = eng.retain_info().generation
+
+    def check_matches(n_filters):
+        filters = [U.rand_filter(rnd, 6) for _ in range(n_filters)] + ["#", "+", "+/#", "+/+", "/", "", "$sys/#", "$sys/+", "a/+/#", "+/b/#"]
+        ft = [rnd.randrange(len(tenants)) for _ in filters]
+        row, ids = eng.retain_match_batch(tenants, ft, filters)
+        got = U.csr_rows(row, ids)
+        for i, f in enumerate(filters):
+            assert got[i] == sorted(lt.match(tenants[ft[i]], f)), (f, tenants[ft[i]])
+        now = base_ms + rnd.choice([0, 20_000, 90_000, 10**7])
+        limits = [rnd.choice([0, 1, 2, 10, 10, 64, 100]) for _ in filters]
+        expire = {i: O.retain_expire_at(*stamp[k]) for k, i in live.items()}
+        lrow, lids, counts = eng.retain_match_limited(tenants, ft, filters, limits, now_ms=now)
+        assert counts.tolist() == [len(r) for r in got]
+        exp = [O.retain_store_match(lt, tenants[t], f, l, now, expire.__getitem__) for t, f, l in zip(ft, filters, limits)]
+        assert U.csr_rows(lrow, lids) == exp
+        # the GC scan: one tenant ('$' topics are out of its reach: RetainStoreCoProc.java:262 scans match(tenant, "#")), all tenants
+        tn = rnd.choice(tenants)
+        assert eng.retain_expired(tn, now) == sorted(i for k, i in live.items() if k[0] == tn and not k[1].startswith("$") and expire[i] <= now)
+        assert eng.retain_expired(None, now) == sorted(i for i in live.values() if expire[i] <= now)
+        assert eng.retain_expired(None, now, 7) == sorted(i for k, i in live.items() if O.retain_expire_at(stamp[k][0], 7) <= now)
+
+    check_matches(300)
+    for step in range(14):
+        if step == 7:  # fold everything into a fresh bulk load: a new generation, ids are ranks again
+            eng.retain_compact()
+            info = eng.retain_info()
+            assert info.generation == gen + 1 and info.added_ids == 0 and info.loaded_removed == 0 and info.n_topics == len(live)
+            order = U.retain_order(tenants, [tenants.index(k[0]) for k in live], [k[1] for k in live])
+            lt = O.LevelTrie(1)
+            ident, live = {}, {}
+            for i, key in enumerate(order):
+                ident[key] = live[key] = i
+                lt.add(key[0], key[1], i)
+            assert eng.retain_topics(list(range(len(order)))) == order
+            check_matches(200)
+            continue
+        n = rnd.choice([1, 5, 60, 700])
+        ops, op_tenant = [], []
+        for _ in range(n):
+            ti = rnd.randrange(3)
+            r = rnd.random()
+            if r < 0.45 and live:
+                key = rnd.choice(list(live))
+                ti, topic, o = tenants.index(key[0]), key[1], 1
+            elif r < 0.55 and ident:
+                key = rnd.choice(list(ident))
+                ti, topic, o = tenants.index(key[0]), key[1], 0
+            elif r < 0.6:
+                topic, o = U.rand_topic(rnd, 5), 1
+            else:
+                topic, o = U.rand_topic(rnd, 5), 0
+            ops.append((o, topic, ((base_ms + rnd.randrange(100_000)) << 16) | rnd.randrange(1 << 16), rnd.choice([0, 1, 30, 60, 3600])))
+            op_tenant.append(ti)
+        untouched = {k: i for k, i in rnd.sample(sorted(live.items()), min(50, len(live)))}
+        out = eng.retain_apply_batch(tenants, op_tenant, ops)
+        last = {}
+        for j, (o, topic, _a, _b) in enumerate(ops):
+            last[(tenants[op_tenant[j]], topic)] = j
+        for j, (o, topic, a, b) in enumerate(ops):
+            key = (tenants[op_tenant[j]], topic)
+            if last[key] != j:
+                assert out[j] == 0xFFFFFFFF
+                continue
+            if o == 0:
+                assert out[j] != 0xFFFFFFFF and ident.get(key, out[j]) == out[j]
+                if key not in ident:
+                    assert out[j] not in ident.values()
+                if key in live:
+                    lt.remove(key[0], key[1], live[key])
+                ident[key] = live[key] = int(out[j])
+                lt.add(key[0], key[1], int(out[j]))
+                stamp[key] = (a, b)
+            else:
+                assert out[j] == (ident[key] if key in ident else 0xFFFFFFFF)
+                if key in live:
+                    lt.remove(key[0], key[1], live.pop(key))
+        info = eng.retain_info()
+        assert info.n_topics == len(live) and info.generation == (gen if step < 7 else gen + 1)
+        live_ids = eng.retain_live_ids()
+        assert live_ids == sorted(live.values())
+        assert dict(zip(live_ids, eng.retain_topics(live_ids))) == {i: k for k, i in live.items()}
+        for k, i in untouched.items():
+            if last.get(k) is None:
+                assert live.get(k) == i  # nobody's id moved
+        for k, i in rnd.sample(sorted(live.items()), min(30, len(live))):
+            assert eng.retain_topic_info(i) == (stamp[k][0], stamp[k][1], O.retain_expire_at(*stamp[k]))
+        check_matches(200)
+
+
+def test_full_size_config4_churn(eng):
+    """configs[3] size (1M retained topics, one tenant) under churn: ONE batch of 100k ops (half removes of retained topics, half adds of
+    new ones) applied on the device, then the 100k-filter batch.  Checked: ids of untouched topics unchanged, removed ids dead, new
+    topics resolve, counts; 20 000 rows bit-exact vs the oracle on the updated set (bulk-loaded ids thinned out by the dead bitmap +
+    overlay ids); the batch applies within the time budget of DESIGN.md."""
+    w = B.Workload(0xB1F20004, 1, 1, 0)
+    data, off, tt = w.retain(0xB1F20004, 1_000_000, filters=False)
+    tn = w.tenants()
+    eng.retain_rebuild(tn, tt, packed_topics=(data, off))
+    raw = data.tobytes()
+    order = sorted({tuple(raw[off[i]:off[i + 1]].split(b"/")) for i in range(1_000_000)})
+    n0 = len(order)
+    rnd = random.Random(11)
+    gone = sorted(rnd.sample(range(n0), 50_000))
+    new_topics = []
+    seen = set(order)
+    while len(new_topics) < 50_000:
+        j = len(new_topics)
+        lv = (b"churn", b"n%d" % (j % 977), b"x%d" % j) if j % 3 else tuple(order[rnd.randrange(n0)][:2]) + (b"fresh%d" % j,)
+        if lv not in seen:
+            seen.add(lv)
+            new_topics.append(lv)
+    topics = [b"/".join(order[i]) for i in gone] + [b"/".join(lv) for lv in new_topics]
+    codes = np.array([1] * len(gone) + [0] * len(new_topics), dtype=np.uint8)
+    perm = list(range(len(topics)))
+    rnd.shuffle(perm)
+    topics = [topics[i] for i in perm]
+    codes = codes[perm]
+    packed = O.pack(topics)
+    t0 = time.perf_counter()
+    out = eng.retain_apply_batch(tn, None, None, packed_topics=packed, op_codes=codes)
+    ms = (time.perf_counter() - t0) * 1e3
+    print(f"\n  bmq_retain_apply_batch: 100000 ops on a 1M-topic index in {ms:.2f} ms (first call: buffers are allocated)")
+    t0 = time.perf_counter()
+    out2 = eng.retain_apply_batch(tn, None, None, packed_topics=packed, op_codes=codes)  # the same batch again: all no-ops / re-stamps
+    ms2 = (time.perf_counter() - t0) * 1e3
+    print(f"  the same batch again: {ms2:.2f} ms")
+    assert ms2 < 20.0  # (generous: the budget is 2 ms; bench.py reports the measured figure)
+    inv = np.argsort(perm)
+    ids_removed = out[inv[:len(gone)]]
+    ids_added = out[inv[len(gone):]]
+    assert ids_removed.tolist() == gone                                         # a bulk-loaded topic's id is its rank
+    assert sorted(ids_added.tolist()) == list(range(n0, n0 + len(new_topics)))  # new topics: the next unused ids
+    assert (out2 == out).all()
+    info = eng.retain_info()
+    assert info.n_topics == n0 and info.loaded_removed == 50_000 and info.added_ids == 50_000 and info.id_bound == n0 + 50_000
+    lt = O.LevelTrie(1)
+    dead = set(gone)
+    for i, lv in enumerate(order):
+        if i not in dead:
+            lt.add(tn[0], b"/".join(lv), i)
+    for lv, i in zip(new_topics, ids_added.tolist()):
+        lt.add(tn[0], b"/".join(lv), i)
+    probe = rnd.sample(range(n0), 2000)
+    got = eng.retain_topics(probe + ids_added[:2000].tolist())
+    assert got[:2000] == [(tn[0], b"/".join(order[i]).decode()) for i in probe]  # untouched AND removed ids still denote their topics
+    assert got[2000:] == [(tn[0], b"/".join(lv).decode()) for lv in new_topics[:2000]]
+    fdata, foff, ft = w.retain(0xB1F20004 + 1, 100_000, filters=True)
+    row, ids = eng.retain_match_batch(tn, ft, packed_filters=(fdata, foff))
+    assert row[0] == 0 and row[-1] == len(ids) and (np.diff(row.astype(np.int64)) >= 0).all()
+    d = np.diff(ids.astype(np.int64))
+    starts = row[1:-1][row[1:-1] < len(ids)]
+    d[(starts - 1)[starts > 0]] = 1
+    assert (d > 0).all()
+    assert not np.isin(ids, np.asarray(gone, dtype=np.uint32)).any()
+    sample = sorted(rnd.sample(range(100_000), 20000)) + list(range(5))
+    fraw = fdata.tobytes()
+    filters = [fraw[foff[i]:foff[i + 1]] for i in sample] + [b"churn/+/+", b"churn/#", b"#", b"+/+/+"]
+    srow, sids = eng.retain_match_batch(tn, [0] * 4, filters[-4:])
+    res, _ = lt.match_batch(tn, np.zeros(len(filters), dtype=np.uint32), O.pack(filters), threads=U.host_threads())
+    exp = [sorted(r) for r in res.per_topic()]
+    got = [ids[row[i]:row[i + 1]].tolist() for i in sample] + U.csr_rows(srow, sids)
+    assert sum(len(g) for g in got) == sum(len(e) for e in exp)
+    assert got == exp
+    assert len(got[-4]) > 30_000  # the overlay really is walked
+    # RetainStoreCoProc.match(limit = 10) on the churned index picks from the ranges, dead ids skipped
+    lrow, lids, counts = eng.retain_match_limited(tn, np.zeros(len(sample), dtype=np.uint32), filters[:len(sample)], [10] * len(sample), now_ms=0)
+    assert counts.tolist() == [len(e) for e in exp[:len(sample)]]
+    assert U.csr_rows(lrow, lids) == [e[:10] for e in exp[:len(sample)]]

@@ -150,12 +150,20 @@ def test_match_limited_vs_retain_store_coproc_match(eng):
     lrow, lids, counts = eng.retain_match_limited(tn, [0], ["#"], [7], now_ms=0)
     everything = eng.retain_match(tn[0], "#")
     assert counts[0] == len(everything) > 7 and lids.tolist() == everything[:7]
-    # add() of a topic that is there replaces its stamp (RS/RetainStoreCoProc.java:246-249); remove() forgets it
+    # add() of a topic that is there replaces its stamp (RS/RetainStoreCoProc.java:246-249); remove() forgets it -- ids are stable
+    # handles: nobody else's id moves, the removed topic's id goes dead (and comes back with the topic)
     victim = order[first[0]][1]
     eng.retain_apply(tn[0], [(0, victim, (base_ms << 16), 1)])
     assert eng.retain_topic_info(first[0])[2] == base_ms + 1000
     eng.retain_apply(tn[0], [(1, victim)])
-    assert eng.retain_find_all()[0] == len(order) - 1 and eng.retain_topic(first[0]) == order[first[1]]
+    assert eng.retain_find_all()[0] == len(order) - 1 and eng.retain_topic(first[1]) == order[first[1]]
+    assert first[0] not in eng.retain_match(tn[0], "#") and first[0] not in eng.retain_live_ids(tn[0])
+    with pytest.raises(B.BmqError):
+        eng.retain_topic_info(first[0])
+    lrow, lids, counts = eng.retain_match_limited(tn, [0], ["#"], [7], now_ms=0)
+    assert counts[0] == len(everything) - (0 if victim.startswith("$") else 1) and first[0] not in lids.tolist()
+    assert eng.retain_apply_batch(tn, [0], [(0, victim)]).tolist() == [first[0]]  # retained again: the same id
+    assert eng.retain_topic_info(first[0])[2] == 0xFFFFFFFFFFFFFFFF and eng.retain_find_all()[0] == len(order)
 
 
 def test_edge_shapes(eng):
@@ -173,8 +181,8 @@ def test_edge_shapes(eng):
 
 
 def test_apply_is_per_tenant(eng):
-    """add/remove touch one tenant: its segment is rebuilt (and moved when it outgrows its room), other tenants keep
-    their nodes; ids stay ranks over all tenants."""
+    """add/remove of one tenant at a time -- tenants appear, disappear and come back, one grows by 500 topics --: after every step the
+    retained set and every match equal the oracle's TopicLevelTrie fed with the engine's (stable) ids."""
     rnd = random.Random(8)
     state = {"tA": {"a/b", "a/c", "x"}, "tB": {"a/b"}, "tD": {"$sys/1", "q/r/s"}}
     items = [(t, p) for t, ps in state.items() for p in ps]
@@ -184,8 +192,9 @@ def test_apply_is_per_tenant(eng):
     def check():
         lt = O.LevelTrie(1)
         n = sum(len(v) for v in state.values())
-        for i in range(n):
-            tenant, topic = eng.retain_topic(i)
+        live = eng.retain_live_ids()
+        assert len(live) == n == eng.retain_find_all()[0]
+        for i, (tenant, topic) in zip(live, eng.retain_topics(live)):
             assert topic in state[tenant]
             lt.add(tenant, topic, i)
         names = sorted(state) + ["ghost"]
@@ -217,7 +226,8 @@ def test_apply_add_remove(eng):
     assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "a/+")] == ["a/b", "a/c"]
     eng.retain_apply("t", [(1, "a/b"), (0, "a/d"), (0, "a/c"), (1, "zzz")])
     assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "a/+")] == ["a/c", "a/d"]
-    assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "#")] == ["a/c", "a/d", "x"]
+    assert sorted(eng.retain_topic(i)[1] for i in eng.retain_match("t", "#")) == ["a/c", "a/d", "x"]
+    assert eng.retain_match("t", "#") == sorted(eng.retain_match("t", "#"))
 
 
 def test_full_size_config4_properties(eng):
