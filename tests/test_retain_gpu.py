@@ -141,9 +141,12 @@ def test_match_limited_vs_retain_store_coproc_match(eng):
     # the GC scan (RS/RetainStoreCoProc.java:257-277): expired ids of one tenant / of all, with and without an expiry override
     now = base_ms + 60_000
     first = [i for i, (t, _) in enumerate(order) if t == tn[0]]
-    assert eng.retain_expired(tn[0], now) == [i for i in first if expire[i] <= now]
+    # (with a tenant the reference scans index.match(tenantId, "#"), which never reaches '$' topics; without one it scans findAll())
+    reach = [i for i in first if not order[i][1].startswith("$")]
+    assert len(reach) < len(first)
+    assert eng.retain_expired(tn[0], now) == [i for i in reach if expire[i] <= now] == [i for i in lt.match(tn[0], "#") if expire[i] <= now]
     assert eng.retain_expired(None, now) == [i for i in range(len(order)) if expire[i] <= now]
-    assert eng.retain_expired(tn[0], now, 5) == [i for i in first if O.retain_expire_at(stamp[order[i]][0], 5) <= now]
+    assert eng.retain_expired(tn[0], now, 5) == [i for i in reach if O.retain_expire_at(stamp[order[i]][0], 5) <= now]
     # a single filter, unknown tenant
     lrow, lids, counts = eng.retain_match_limited(tn + ["nobody"], [3], ["#"], [5])
     assert lrow.tolist() == [0, 0] and counts.tolist() == [0]
