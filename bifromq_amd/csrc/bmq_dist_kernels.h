@@ -180,6 +180,45 @@ __device__ __forceinline__ void load_line64(const void* p, Line64& r) {
                  : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1)
                  : "v"(p));
 }
+// two independent lines, eight loads in flight, ONE wait: the walk's rounds are latency bound, two items per lane halve their number
+__device__ __forceinline__ void load_line64_x2(const void* p, const void* q, Line64& r, Line64& t) {
+    asm volatile("global_load_dwordx4 %0, %8, off\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %8, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %9, off\n\t"
+                 "global_load_dwordx4 %5, %9, off offset:16\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:32\n\t"
+                 "global_load_dwordx4 %7, %9, off offset:48\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1), "=&v"(t.a0), "=&v"(t.a1), "=&v"(t.b0), "=&v"(t.b1)
+                 : "v"(p), "v"(q));
+}
+// the HEADERS (tag, token, len, pool_off) of both slots of four dictionary groups: eight loads, one wait
+__device__ __forceinline__ void load_dict_headers_x4(const DictSlot* g0, const DictSlot* g1, const DictSlot* g2, const DictSlot* g3, uint4 (&ha)[4],
+                                                      uint4 (&hb)[4]) {
+    asm volatile("global_load_dwordx4 %0, %8, off\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %9, off\n\t"
+                 "global_load_dwordx4 %3, %9, off offset:32\n\t"
+                 "global_load_dwordx4 %4, %10, off\n\t"
+                 "global_load_dwordx4 %5, %10, off offset:32\n\t"
+                 "global_load_dwordx4 %6, %11, off\n\t"
+                 "global_load_dwordx4 %7, %11, off offset:32\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(ha[0]), "=&v"(hb[0]), "=&v"(ha[1]), "=&v"(hb[1]), "=&v"(ha[2]), "=&v"(hb[2]), "=&v"(ha[3]), "=&v"(hb[3])
+                 : "v"(g0), "v"(g1), "v"(g2), "v"(g3));
+}
+// the 16 inline bytes of four slots (the lines were just fetched: these hit the vector L1)
+__device__ __forceinline__ void load_dict_inline_x4(const DictSlot* s0, const DictSlot* s1, const DictSlot* s2, const DictSlot* s3, uint4 (&in)[4]) {
+    asm volatile("global_load_dwordx4 %0, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %6, off offset:16\n\t"
+                 "global_load_dwordx4 %3, %7, off offset:16\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(in[0]), "=&v"(in[1]), "=&v"(in[2]), "=&v"(in[3])
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3));
+}
 // ------------------------------------------------------------------------------------------------------------
 // dictionary lookup (exact: tag + length + bytes).  ONE latency: the whole home group (one 64-byte line) is requested together.
 // byte_at(i) returns byte i of the string buffer the level lives in (LDS-staged or global).
@@ -450,6 +489,12 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantS
     resolve_item(ix, ln, true, node, tok, bk, rg.base, rg.buckets, level, nlev, sys, tok_at, o);
 }
 
+// profiling experiments only (BMQ_DEBUG=2): a time stamp behind everything this wave has requested so far
+__device__ __forceinline__ unsigned long long dbg_clock(bool on) {
+    if (!on) return 0ull;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    return __builtin_amdgcn_s_memtime();
+}
 // ------------------------------------------------------------------------------------------------------------
 // k_walk -- one wave (= one 64-thread workgroup) per 64 topics
 // ------------------------------------------------------------------------------------------------------------
@@ -469,6 +514,24 @@ __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
 #ifndef BMQ_WALK_MIN_WAVES
 #define BMQ_WALK_MIN_WAVES 4
 #endif
+#ifndef BMQ_TOK_CHUNK
+#define BMQ_TOK_CHUNK 0 // 1: tokenise four levels per dictionary round trip (headers of all four home groups in flight together); 0: one level per trip
+#endif
+#ifndef BMQ_WALK_ILP
+#define BMQ_WALK_ILP 1 // work items per lane per round of the walk (their bucket lines are requested together, one wait)
+#endif
+#ifndef BMQ_XCD_REMAP
+#define BMQ_XCD_REMAP 0 // every XCD (block b runs on XCD b % 8) works on ONE contiguous eighth of the batch: a tenant's region is cached by one L2, not by eight
+#endif
+constexpr uint32_t WALK_ILP = BMQ_WALK_ILP;
+static_assert(WALK_ILP == 1 || WALK_ILP == 2, "one or two work items per lane");
+__host__ __device__ inline uint32_t walk_grid_blocks(uint32_t n_blocks) { // blocks to launch for n_blocks 64-topic waves
+#if BMQ_XCD_REMAP
+    return ((n_blocks + 7u) / 8u) * 8u;
+#else
+    return n_blocks;
+#endif
+}
 __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(BatchArgs a) {
     extern __shared__ __align__(16) uint32_t lds_all[];
     // WALK_WAVES independent waves per workgroup: every wave owns its own slice of LDS and never synchronises with its
@@ -492,6 +555,13 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
 
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t blk = blockIdx.x * WALK_WAVES + wave;
+#if BMQ_XCD_REMAP
+    static_assert(WALK_WAVES == 1, "the XCD remap assumes one wave per workgroup");
+    { // (WALK_WAVES == 1.)  Observed, used for speed only: block b runs on XCD b % 8 -- XCD x takes the x-th eighth of the batch.
+        const uint32_t per = (a.n_blocks + 7u) / 8u;
+        blk = (blk & 7u) * per + (blk >> 3);
+    }
+#endif
     if (blk >= a.n_blocks) return;
     // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
     // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
@@ -517,6 +587,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
         for (uint32_t o = lane; o < n16; o += 64) dst[o] = src[o];
     }
     wave_sync();
+    const unsigned long long clkA = dbg_clock(dbg_w); // topic bytes staged
     const uint8_t* lbytes = reinterpret_cast<const uint8_t*>(un);
     const uint8_t* gbytes = a.topics;
     auto byte_at = [&](uint32_t i) -> uint32_t { return staged ? (uint32_t)lbytes[i - a0] : (uint32_t)gbytes[i]; };
@@ -549,6 +620,78 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
     }
     TenantQuery tq;
     uint32_t l = 0;
+    const unsigned long long clkB = dbg_clock(dbg_w); // offsets loaded, tenant resolved
+#if BMQ_TOK_CHUNK
+    // Four levels per trip to the dictionary: every lane scans its next four levels (LDS only), the headers of their four home
+    // groups are requested together (eight 16-byte loads, one wait), then the inline bytes of the slots whose tag + length fit
+    // (four loads that hit the vector L1, one wait).  A topic of up to four levels costs one dependent round trip instead of
+    // four, one of five to eight levels two: round 2 measured the level-by-level loop at 28 % of the kernel.
+    if (staged) {
+        for (; __any(more); l++) {
+            if (!uni && l < 3 && t_ok) tenant_stage(a, ti, tq, l);
+            uint32_t cstart[4], clen[4], ctag[4], cgrp[4]; // (the level's bytes stay in LDS: they are compared from there)
+            bool cval[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                cval[k] = more;
+                cstart[k] = pos;
+                clen[k] = ctag[k] = cgrp[k] = 0;
+                if (more) {
+                    LevelHash h;
+                    uint32_t inl[4];
+                    bool last;
+                    scan_level(pos, end, true, word_at, h, inl, clen[k], last);
+                    nlev++;
+                    ctag[k] = level_hash_tag(h);
+                    cgrp[k] = level_hash_slot(h, clen[k]) & a.ix.dict_group_mask;
+                    more = !last;
+                }
+            }
+            uint4 ha[4], hb[4], in[4];
+            const DictSlot* grp[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) grp[k] = a.ix.dict + DICT_GROUP * (size_t)cgrp[k];
+            load_dict_headers_x4(grp[0], grp[1], grp[2], grp[3], ha, hb);
+            const DictSlot* pick[4];
+            uint32_t verdict[4]; // 0: slot chosen, verify its bytes; 1: not in the dictionary; 2: ask the probing lookup
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const bool m0 = ha[k].x == ctag[k] && ha[k].z == clen[k], m1 = hb[k].x == ctag[k] && hb[k].z == clen[k];
+                pick[k] = grp[k] + (m1 && !m0 ? 1 : 0);
+                verdict[k] = (m0 != m1) ? 0u : ((m0 && m1) ? 2u : ((ha[k].x == 0 || hb[k].x == 0) ? 1u : 2u));
+                if (m1 && !m0) ha[k] = hb[k]; // the chosen slot's header
+            }
+            load_dict_inline_x4(pick[0], pick[1], pick[2], pick[3], in);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (!cval[k]) continue;
+                uint32_t tok = TOK_UNKNOWN;
+                if (verdict[k] == 0) {
+                    // the slot's 16 inline bytes (zero padded) against the level's bytes in LDS
+                    const uint32_t iw[4] = {in[k].x, in[k].y, in[k].z, in[k].w};
+                    bool eq = true;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        const uint32_t nb = clen[k] > 4 * j ? min(4u, clen[k] - 4 * j) : 0u;
+                        const uint32_t w = nb ? word_at(cstart[k] + 4 * j) : 0u;
+                        eq = eq && iw[j] == (nb >= 4 ? w : (w & ((1u << (8u * nb)) - 1u)));
+                    }
+                    for (uint32_t i = 16; i < clen[k] && eq; i++) eq = a.ix.pool[ha[k].w + i] == byte_at(cstart[k] + i);
+                    if (eq) tok = ha[k].y;
+                    else verdict[k] = (ha[k].x == ctag[k] && hb[k].x == ctag[k]) ? 2u : ((hb[k].x == 0 || ha[k].x == 0) ? 1u : 2u);
+                }
+                if (verdict[k] == 2) { // two candidates, or a full home group: the probing lookup (rare)
+                    LevelHash h;
+                    uint32_t inl2[4], len2, p2 = cstart[k];
+                    bool last2;
+                    scan_level(p2, end, true, word_at, h, inl2, len2, last2);
+                    tok = dict_lookup(a.ix, h, len2, inl2, cstart[k], byte_at);
+                }
+                if (4 * l + k < FAST_LEVELS) tokens[(4 * l + k) * 64 + lane] = tok;
+            }
+        }
+    } else
+#endif
     for (; __any(more); l++) {
         if (!uni && l < 3 && t_ok) tenant_stage(a, ti, tq, l);
         LevelHash h;
@@ -597,8 +740,72 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
         base = (uint32_t)sb;
         return fits;
     };
-    const unsigned long long clk1 = dbg_w ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long clk1 = dbg_clock(dbg_w);
     // Round 0 visits the tenant roots: their slot payload came with the directory entry, so no line is fetched.
+    // what a resolved item leaves behind: its matched ranges go into the LDS range buffer, its children onto the stack
+    auto sink = [&](const StepOut& o, uint32_t tl) {
+            const unsigned long long m_own = __ballot(o.emit_own), m_hash = __ballot(o.emit_hash);
+            const unsigned long long m_l = __ballot(o.push_l), m_h = __ballot(o.push_h);
+            const uint32_t n_own = (uint32_t)__popcll(m_own), n_emit = n_own + (uint32_t)__popcll(m_hash);
+            // matched ranges -> LDS buffer; when this round's matches do not fit, the buffer is flushed to the spill area first
+            if (n_emit) {
+                if (pcount + n_emit > a.pcap) {
+                    for (uint32_t i = lane; i < pcount; i += 64) { // per-topic range / id counts of what leaves the buffer
+                        atomicAdd(&cnt_pairs[p_topic[i]], 1u);
+                        atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
+                    }
+                    uint32_t cb;
+                    if (spill_alloc(pcount, cb)) {
+                        if (lane == 0) a.spill[cb] = make_uint4(fl_base, fl_len, 0u, 0u);
+                        for (uint32_t i = lane; i < pcount; i += 64) a.spill[cb + 1 + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
+                        fl_base = cb;
+                        fl_len = pcount;
+                    }
+                    pcount = 0;
+                    wave_sync();
+                }
+                if (o.emit_own) {
+                    const uint32_t p = pcount + rank_below(m_own);
+                    p_begin[p] = o.s.own_begin;
+                    p_count[p] = o.s.own_count;
+                    p_topic[p] = tl;
+                }
+                if (o.emit_hash) {
+                    const uint32_t p = pcount + n_own + rank_below(m_hash);
+                    p_begin[p] = o.s.hash_begin;
+                    p_count[p] = o.s.hash_count;
+                    p_topic[p] = tl;
+                }
+                pcount += n_emit;
+            }
+            // children -> stack; if they do not fit, the pending (older) items are parked and the walk goes on with the children
+            if (m_l | m_h) {
+                const uint32_t n_l = (uint32_t)__popcll(m_l), n_push = n_l + (uint32_t)__popcll(m_h);
+                if (tail + n_push > a.qcap) {
+                    uint32_t cb;
+                    if (spill_alloc(tail, cb)) {
+                        if (lane == 0) a.spill[cb] = make_uint4(qs_base, qs_len, 0u, 0u);
+                        for (uint32_t i = lane; i < tail; i += 64) a.spill[cb + 1 + i] = make_uint4(q_node[i], q_meta[i], 0u, 0u);
+                        qs_base = cb;
+                        qs_len = tail;
+                    }
+                    tail = 0;
+                    wave_sync();
+                }
+                if (o.push_l) {
+                    const uint32_t p = tail + rank_below(m_l);
+                    q_node[p] = o.idx;
+                    q_meta[p] = make_meta(tl, o.dl, 0);
+                }
+                if (o.push_h) {
+                    const uint32_t p = tail + n_l + rank_below(m_h);
+                    q_node[p] = o.idx;
+                    q_meta[p] = make_meta(tl, o.dl, KIND_P);
+                }
+                tail += n_push;
+            }
+            wave_sync();
+    };
     bool boot = !(a.debug_flags & 1u);
     while (boot || tail || qs_len) {
         if (!boot && tail == 0) { // the stack ran dry: take the most recently parked chunk back
@@ -627,98 +834,54 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
             o.push_l = active && t0 != TOK_UNKNOWN && ((rg.root_lit_bloom >> bloom_bit(t0)) & 1u);
             o.push_h = active && (rg.root_lit_bloom & BLOOM_PLUS) != 0 && !sys; // a first-level '+' never matches a '$' topic
         } else {
-            const uint32_t take = tail < 64u ? tail : 64u;
+            // WALK_ILP items per lane: the bucket lines of all of them are requested together and waited for once -- a round costs one
+            // memory round trip however many items it carries, and rounds are what the walk's duration consists of (profiles/r02:
+            // 19 rounds of ~49 items, ~5 k clocks each)
+            const uint32_t take = tail < WALK_ILP * 64u ? tail : WALK_ILP * 64u;
             tail -= take;
             rounds++;
             items += take;
-            const bool live = lane < take;
-            uint32_t node = 0, meta = 0, tmv = 0;
-            if (live) {
-                node = q_node[tail + lane];
-                meta = q_meta[tail + lane];
-                tmv = tmeta[meta & 63u];
-            }
-            tl = meta & 63u;
-            const bool kp = (meta & KIND_P) != 0;
-            uint2 reg = make_uint2(0u, 1u);
-            uint32_t tok = TOK_PLUS;
-            if (live) {
-                reg = t_region[tl];
-                if (!kp) tok = tokens[meta_level(meta) * 64 + tl];
-            }
-            const uint32_t bk = edge_bucket(node, tok, reg.y);
-            Line64 ln;
-            load_line64(a.ix.trie + (live ? (size_t)reg.x + 2 * (size_t)bk : (size_t)0), ln);
-            const uint32_t tlc = tl;
-            resolve_item(a.ix, ln, live, node, tok, bk, reg.x, reg.y, meta_level(meta), tmv & 0xFFu, (tmv & TM_SYS) != 0,
-                         [&](uint32_t l) { return tokens[l * 64 + tlc]; }, o);
-            my_visits += o.found ? 1u : 0u;
-        }
-        const unsigned long long m_own = __ballot(o.emit_own), m_hash = __ballot(o.emit_hash);
-        const unsigned long long m_l = __ballot(o.push_l), m_h = __ballot(o.push_h);
-        const uint32_t n_own = (uint32_t)__popcll(m_own), n_emit = n_own + (uint32_t)__popcll(m_hash);
-        // matched ranges -> LDS buffer; when this round's matches do not fit, the buffer is flushed to the spill area first
-        if (n_emit) {
-            if (pcount + n_emit > a.pcap) {
-                for (uint32_t i = lane; i < pcount; i += 64) { // per-topic range / id counts of what leaves the buffer
-                    atomicAdd(&cnt_pairs[p_topic[i]], 1u);
-                    atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
+            uint32_t node[WALK_ILP], meta[WALK_ILP], tmv[WALK_ILP], tok[WALK_ILP], bk[WALK_ILP];
+            uint2 reg[WALK_ILP];
+            bool live[WALK_ILP];
+            const TrieSlot* line[WALK_ILP];
+#pragma unroll
+            for (uint32_t k = 0; k < WALK_ILP; k++) {
+                live[k] = k * 64u + lane < take;
+                node[k] = meta[k] = tmv[k] = 0;
+                reg[k] = make_uint2(0u, 1u);
+                tok[k] = TOK_PLUS;
+                if (live[k]) {
+                    node[k] = q_node[tail + k * 64u + lane];
+                    meta[k] = q_meta[tail + k * 64u + lane];
+                    tmv[k] = tmeta[meta[k] & 63u];
+                    reg[k] = t_region[meta[k] & 63u];
+                    if (!(meta[k] & KIND_P)) tok[k] = tokens[meta_level(meta[k]) * 64 + (meta[k] & 63u)];
                 }
-                uint32_t cb;
-                if (spill_alloc(pcount, cb)) {
-                    if (lane == 0) a.spill[cb] = make_uint4(fl_base, fl_len, 0u, 0u);
-                    for (uint32_t i = lane; i < pcount; i += 64) a.spill[cb + 1 + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
-                    fl_base = cb;
-                    fl_len = pcount;
-                }
-                pcount = 0;
-                wave_sync();
+                bk[k] = edge_bucket(node[k], tok[k], reg[k].y);
+                line[k] = a.ix.trie + (live[k] ? (size_t)reg[k].x + 2 * (size_t)bk[k] : (size_t)0);
             }
-            if (o.emit_own) {
-                const uint32_t p = pcount + rank_below(m_own);
-                p_begin[p] = o.s.own_begin;
-                p_count[p] = o.s.own_count;
-                p_topic[p] = tl;
+            Line64 ln[WALK_ILP];
+            if (WALK_ILP == 2) load_line64_x2(line[0], line[WALK_ILP - 1], ln[0], ln[WALK_ILP - 1]);
+            else load_line64(line[0], ln[0]);
+            wave_sync(); // every lane holds its items in registers: the stack above `tail` may be overwritten by the pushes below
+#pragma unroll
+            for (uint32_t k = 0; k < WALK_ILP; k++) {
+                if (k && take <= 64u) break; // wave-uniform
+                StepOut ok;
+                const uint32_t tlc = meta[k] & 63u;
+                resolve_item(a.ix, ln[k], live[k], node[k], tok[k], bk[k], reg[k].x, reg[k].y, meta_level(meta[k]), tmv[k] & 0xFFu, (tmv[k] & TM_SYS) != 0,
+                             [&](uint32_t lv) { return tokens[lv * 64 + tlc]; }, ok);
+                my_visits += ok.found ? 1u : 0u;
+                sink(ok, tlc);
             }
-            if (o.emit_hash) {
-                const uint32_t p = pcount + n_own + rank_below(m_hash);
-                p_begin[p] = o.s.hash_begin;
-                p_count[p] = o.s.hash_count;
-                p_topic[p] = tl;
-            }
-            pcount += n_emit;
+            continue;
         }
-        // children -> stack; if they do not fit, the pending (older) items are parked and the walk goes on with the children
-        if (m_l | m_h) {
-            const uint32_t n_l = (uint32_t)__popcll(m_l), n_push = n_l + (uint32_t)__popcll(m_h);
-            if (tail + n_push > a.qcap) {
-                uint32_t cb;
-                if (spill_alloc(tail, cb)) {
-                    if (lane == 0) a.spill[cb] = make_uint4(qs_base, qs_len, 0u, 0u);
-                    for (uint32_t i = lane; i < tail; i += 64) a.spill[cb + 1 + i] = make_uint4(q_node[i], q_meta[i], 0u, 0u);
-                    qs_base = cb;
-                    qs_len = tail;
-                }
-                tail = 0;
-                wave_sync();
-            }
-            if (o.push_l) {
-                const uint32_t p = tail + rank_below(m_l);
-                q_node[p] = o.idx;
-                q_meta[p] = make_meta(tl, o.dl, 0);
-            }
-            if (o.push_h) {
-                const uint32_t p = tail + n_l + rank_below(m_h);
-                q_node[p] = o.idx;
-                q_meta[p] = make_meta(tl, o.dl, KIND_P);
-            }
-            tail += n_push;
-        }
-        wave_sync();
+        sink(o, tl);
     }
 
     // ---- phase 3: ranges grouped by topic -> global; per-topic bookkeeping --------------------------------------
-    const unsigned long long clk2 = dbg_w ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long clk2 = dbg_clock(dbg_w);
     for (uint32_t i = lane; i < pcount; i += 64) { // counted here, once per range, instead of two LDS atomics per match
         atomicAdd(&cnt_pairs[p_topic[i]], 1u);
         atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
@@ -793,6 +956,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
         if (dbg_w) {
             const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
             a.dbg_wave[blk] = make_uint4((uint32_t)(clk1 - clk0), (uint32_t)(clk2 - clk1), (uint32_t)(clk3 - clk2), rounds | (items << 8));
+            a.dbg_wave[a.n_blocks + blk] = make_uint4((uint32_t)(clkA - clk0), (uint32_t)(clkB - clkA), (uint32_t)(clk1 - clkB), 0u); // phase 1 in detail
         }
     }
 }

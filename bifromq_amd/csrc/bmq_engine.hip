@@ -265,7 +265,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         a.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
         a.dbg_wave = nullptr;
         if (a.debug_flags & 6u) {
-            HIPCHK(e, S.b_dbg_wave.ensure(sizeof(uint4) * std::max(a.n_blocks, 1u)));
+            HIPCHK(e, S.b_dbg_wave.ensure(sizeof(uint4) * 2 * std::max(a.n_blocks, 1u)));
             a.dbg_wave = S.b_dbg_wave.as<uint4>();
         }
     }
@@ -278,7 +278,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
-        const dim3 grid((a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
+        const dim3 grid(WALK_WAVES == 1 ? walk_grid_blocks(a.n_blocks) : (a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
         if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_walk, grid, block, lds, s, a);
     }
@@ -309,8 +309,8 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
 static void print_wave_debug(bmq_engine* e, bmq_engine::BatchSlot& S) {
     const BatchArgs& a = S.last;
     if (!a.dbg_wave || !a.n_blocks) return;
-    std::vector<uint4> h(a.n_blocks);
-    if (hipMemcpy(h.data(), a.dbg_wave, sizeof(uint4) * a.n_blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::vector<uint4> h(2 * (size_t)a.n_blocks);
+    if (hipMemcpy(h.data(), a.dbg_wave, sizeof(uint4) * 2 * a.n_blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
     if (a.debug_flags & 4u) { // k_expand: head (row pointers, wave base) | range load + order | prefix + order check | id generation
         double p[4] = {0, 0, 0, 0};
         for (uint32_t i = 0; i < a.n_blocks; i++) p[0] += h[i].x, p[1] += h[i].y, p[2] += h[i].z, p[3] += h[i].w;
@@ -327,6 +327,11 @@ static void print_wave_debug(bmq_engine* e, bmq_engine::BatchSlot& S) {
     std::sort(r.begin(), r.end());
     std::sort(c2.begin(), c2.end());
     const double n = a.n_blocks;
+    {
+        double pa = 0, pb = 0, pc = 0;
+        for (uint32_t i = 0; i < a.n_blocks; i++) pa += h[a.n_blocks + i].x, pb += h[a.n_blocks + i].y, pc += h[a.n_blocks + i].z;
+        fprintf(stderr, "[bmq] k_walk tokenise in detail: stage bytes %.0f | offsets + tenant %.0f | levels + dictionary %.0f\n", pa / n, pb / n, pc / n);
+    }
     fprintf(stderr, "[bmq] k_walk waves=%u clocks/wave: tokenise %.0f walk %.0f (p50 %u p99 %u) write %.0f | rounds mean %.1f p50 %u p99 %u max %u | items/wave %.0f\n",
             a.n_blocks, s1 / n, s2 / n, c2[a.n_blocks / 2], c2[(size_t)(a.n_blocks * 0.99)], s3 / n, sr / n, r[a.n_blocks / 2],
             r[(size_t)(a.n_blocks * 0.99)], r.back(), si / n);

@@ -11,6 +11,7 @@
 
 #include "bmq_build_core.h"
 #include "bmq_fanout_core.h"
+#include "bmq_fanout_kernels.h"
 #include "bmq_retain_core.h"
 
 namespace bmq {
@@ -298,6 +299,25 @@ struct DevExec {
     }
     bool gather_bytes(const DistIndexMut& ix, const unsigned long long* refs, const uint64_t* offs, uint32_t n, uint8_t* out) {
         hipLaunchKernelGGL(k_b_gather_bytes, grid(n, BK), dim3(BK), 0, stream, ix, refs, offs, n, out);
+        return launched();
+    }
+    // ---- fan-out grouping, fast path (bmq_fanout_kernels.h): counting sort that carries its payload ----
+    static constexpr bool has_fanout_fast = true;
+    bool fo_dense(const FanoutState& st, uint16_t* dense, uint32_t* n_used) {
+        hipLaunchKernelGGL(k_fo_dense, dim3(1), dim3(1024), 0, stream, st.gt_hash, st.gt_cap, dense, n_used);
+        return launched();
+    }
+    bool fo_fast(const DistIndexMut& ix, const FanoutState& st, const FanoutFast& f) {
+        const dim3 grid((f.n_tiles + FO_WAVES - 1) / FO_WAVES), block(FO_WAVES * 64);
+        hipLaunchKernelGGL(k_fo_hist, grid, block, 0, stream, ix, st, f);
+        if (!launched()) return false;
+        const int n = (int)((size_t)f.n_bins * f.n_tiles);
+        size_t bytes = 0;
+        if (!BMQ_X(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, f.hist, f.hist, n, stream))) return false;
+        if (!ensure_tmp(bytes)) return false;
+        if (!BMQ_X(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, f.hist, f.hist, n, stream))) return false;
+        hipLaunchKernelGGL(k_fo_scatter, grid, block, 0, stream, f);
+        hipLaunchKernelGGL(k_fo_groups2, dim3(1), dim3(1024), 0, stream, st, f);
         return launched();
     }
     // ---- retain direction (bmq_retain_core.h) ----

@@ -117,6 +117,7 @@ struct HostExec {
         return true;
     }
     // ---- fan-out grouping (bmq_fanout.h) ----
+    static constexpr bool has_fanout_fast = false; // the counting-sort path is gfx950 kernels only; host engines take the generic passes
     bool fill_bytes(void* p, int byte, size_t n) {
         if (n) memset(p, byte, n);
         return true;

@@ -43,6 +43,11 @@ public:
             grow_next = false;
             if (!reset_table(st.gt_cap * 4)) return false;
         }
+        if constexpr (Exec::has_fanout_fast) {
+            const int rc = group_fast(row_ptr, ids, n_topics, total, out_topic, out_route, group_off, group_rep, group_cap, res);
+            if (rc >= 0) return rc == 1;
+            // (-1: more deliverer keys than the fast path's LDS counters hold: the generic passes below)
+        }
         for (int attempt = 0; attempt < 12; attempt++) {
             FanoutBatch b{};
             b.row_ptr = row_ptr;
@@ -93,6 +98,11 @@ public:
     }
 
     void drop() {
+        rel(f_key16);
+        rel(f_hist);
+        rel(f_dense);
+        rel(f_ctr);
+        f_key_cap = f_hist_cap = f_dense_cap = 0;
         rel(st.dgroup);
         rel(st.gt_hash);
         rel(st.gt_rep);
@@ -114,6 +124,105 @@ private:
     bool grow_next = false;
     uint32_t *s_key = nullptr, *s_key_sorted = nullptr, *s_pos = nullptr, *s_pos_sorted = nullptr;
     size_t s_cap = 0;
+
+    // ---- fast path (device): bmq_fanout_kernels.h ----
+    uint16_t *f_key16 = nullptr, *f_dense = nullptr;
+    uint32_t *f_hist = nullptr, *f_ctr = nullptr; // f_ctr: [0] pairs without a group slot, [1] used slots
+    size_t f_key_cap = 0, f_hist_cap = 0, f_dense_cap = 0;
+    uint32_t n_used = 0;
+    bool dense_stale = true;
+
+    // 1: done, 0: failed (error set), -1: not applicable
+    int group_fast(const uint32_t* row_ptr, const uint32_t* ids, uint32_t n_topics, uint32_t total, uint32_t* out_topic, uint32_t* out_route,
+                   uint32_t* group_off, uint32_t* group_rep, uint32_t group_cap, FanoutResult& res) {
+        if constexpr (!Exec::has_fanout_fast) return -1;
+        else {
+            if (st.gt_cap > 0xFFF0u) return -1;
+            if (!f_ctr && !fresh(f_ctr, 4)) return 0;
+            for (int attempt = 0; attempt < 12; attempt++) {
+                if (f_dense_cap < st.gt_cap) {
+                    if (!x.sync()) return xfail() ? 1 : 0;
+                    if (!fresh(f_dense, (size_t)st.gt_cap + 8)) return 0;
+                    f_dense_cap = st.gt_cap;
+                    dense_stale = true;
+                }
+                if (dense_stale) {
+                    uint32_t nu = 0;
+                    if (!x.fo_dense(st, f_dense, f_ctr + 1) || !x.copy_out(&nu, f_ctr + 1, sizeof(nu))) return xfail() ? 1 : 0;
+                    n_used = nu;
+                    dense_stale = false;
+                }
+                if (n_used + 2 > FO_MAX_BINS) return -1;
+                FanoutFast f{};
+                f.row_ptr = row_ptr;
+                f.ids = ids;
+                f.n_topics = n_topics;
+                f.total = total;
+                f.id_end = ix.next_id;
+                f.n_tiles = (total + FO_TILE - 1) / FO_TILE;
+                f.n_bins = n_used + 2;
+                f.key_bits = 1;
+                while ((1u << f.key_bits) < f.n_bins) f.key_bits++;
+                const size_t hist_n = (size_t)f.n_bins * f.n_tiles;
+                if (hist_n >= 0x7FFFFFF0ull) return -1;
+                if (total > f_key_cap || hist_n > f_hist_cap) {
+                    if (!x.sync()) return xfail() ? 1 : 0;
+                    if (total > f_key_cap) {
+                        if (!fresh(f_key16, (size_t)total + total / 4 + 64)) return 0;
+                        f_key_cap = (size_t)total + total / 4 + 64;
+                    }
+                    if (hist_n > f_hist_cap) {
+                        if (!fresh(f_hist, hist_n + hist_n / 4 + 64)) return 0;
+                        f_hist_cap = hist_n + hist_n / 4 + 64;
+                    }
+                }
+                f.dense = f_dense;
+                f.key16 = f_key16;
+                f.hist = f_hist;
+                f.out_topic = out_topic;
+                f.out_route = out_route;
+                f.group_off = group_off;
+                f.group_rep = group_rep;
+                f.group_cap = group_cap;
+                f.need_fill = f_ctr;
+                const DistIndexMut m = ix.mut();
+                const uint32_t keep[4] = {0u, used_slots, 0u, 0u};
+                if (!x.copy_in_async(st.flags, keep, sizeof(keep)) || !x.zero(f_ctr, sizeof(uint32_t)) || !x.fo_fast(m, st, f)) return xfail() ? 1 : 0;
+                uint32_t fl[4] = {0, 0, 0, 0}, need = 0;
+                if (!x.copy_out(fl, st.flags, sizeof(fl)) || !x.copy_out(&need, f_ctr, sizeof(need))) return xfail() ? 1 : 0;
+                if (need == 0) {
+                    res.n_groups = fl[2];
+                    res.group_overflow = fl[2] > group_cap;
+                    res.special = fl[3];
+                    return 1;
+                }
+                // route ids without a group slot (the first batch of a generation, routes added since): map them -- the passes of
+                // bmq_fanout_core.h over all pairs, cached ids fall through at once -- and run the split again
+                FanoutBatch b{};
+                b.row_ptr = row_ptr;
+                b.ids = ids;
+                b.n_topics = n_topics;
+                b.total = total;
+                b.id_end = ix.next_id;
+                if (!x.copy_in_async(st.flags, keep, sizeof(keep)) || !x.fo_fill(m, st, b) || !x.fo_verify(m, st, b) || !x.copy_out(fl, st.flags, sizeof(fl)))
+                    return xfail() ? 1 : 0;
+                used_slots = fl[1];
+                dense_stale = true;
+                if (fl[0] & FO_ERR_COLLISION) { // two deliverer keys with one 64-bit hash: new seed, every route is mapped afresh
+                    seed++;
+                    if (!reset_table(st.gt_cap)) return 0;
+                    continue;
+                }
+                if ((fl[0] & FO_ERR_FULL) || (uint64_t)used_slots * 2 > st.gt_cap) { // keep the table at most half full
+                    if (st.gt_cap >= (1u << 29)) return fail("deliverer table too large") ? 1 : 0;
+                    if (!reset_table(st.gt_cap * 4)) return 0;
+                    if (st.gt_cap > 0xFFF0u) return -1;
+                    continue;
+                }
+            }
+            return fail("fan-out grouping did not settle") ? 1 : 0;
+        }
+    }
 
     template <class T> void rel(T*& p) {
         if (p) x.release(p);
@@ -137,6 +246,7 @@ private:
         }
         st.seed = seed;
         used_slots = 0;
+        dense_stale = true;
         if (!x.zero(st.gt_hash, sizeof(unsigned long long) * (size_t)cap) || !x.fill_bytes(st.gt_rep, 0xFF, sizeof(uint32_t) * (size_t)cap) ||
             !x.fill_bytes(st.dgroup, 0xFF, sizeof(uint32_t) * (size_t)st.id_cap))
             return xfail();

@@ -1,0 +1,210 @@
+// bmq_fanout_kernels.h -- gfx950 kernels of the fan-out grouping's fast path (bmq_fanout.h): a COUNTING SORT that carries its payload.
+//
+// The (topic, route) pairs of a match batch are born in (topic, route) order -- they ARE the CSR -- and the sort key (the group of
+// the route's DelivererKey, bmq_fanout_core.h) has a few dozen to a few hundred values.  So instead of a radix sort of (key, position)
+// pairs followed by a gather of the route ids and a binary search of row_ptr per pair (round 2: nine launches, 4x the algorithmic
+// HBM traffic), the pairs are split in three launches:
+//   k_fo_hist     every wave owns a TILE of consecutive pairs: one gather per pair (dgroup[id] -> dense group number) gives the key,
+//                 kept as 16 bits for the last pass; the wave's histogram goes out transposed (hist[key][tile]), so that
+//   (scan)        ONE exclusive prefix sum over hist[] yields, in final order, where every (key, tile) run starts;
+//   k_fo_scatter  the same waves walk their tiles again, 64 pairs at a time in order: the topic of a pair comes from a window of 64
+//                 row ends (one coalesced load, a 6-step search by shuffle); its rank among the segment's pairs of the same key from
+//                 one ballot per key BIT (the lanes whose key equals mine = AND over the bits of ballot or its complement) -- no loop
+//                 over the distinct keys, and stable, so a group's pairs stay in (topic, route) order; the key's running offset
+//                 lives in LDS, bumped once per segment by the key's first lane;
+//   k_fo_groups2  one lane per key: the non-empty keys, in key order, are the groups.
+// Group numbers are DENSE (k_fo_dense: rank of a group-table slot among the used slots; the two special groups follow), so the
+// histogram has as many columns as there are deliverer keys, not as the table has slots.
+// Ids that have no group slot yet (first batch after a rebuild, routes added since) are counted by k_fo_hist; the control then
+// runs the mapping passes of bmq_fanout_core.h (fo_fill / fo_verify) once and starts over.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bmq_dist_kernels.h" // rank_below, wave_sync
+#include "bmq_fanout_core.h"
+
+namespace bmq {
+
+constexpr uint32_t FO_TILE = 4096;     // pairs per wave
+constexpr uint32_t FO_WAVES = 4;       // waves per workgroup (independent: each owns its LDS slice)
+constexpr uint32_t FO_MAX_BINS = 1026; // dense groups + the two special ones must fit the per-wave LDS counters
+
+struct FanoutFast {
+    const uint32_t* row_ptr;
+    const uint32_t* ids;
+    uint32_t n_topics, total, id_end;
+    uint32_t n_tiles, n_bins; // n_bins = used group slots + 2; key n_bins - 2 = shared subscriptions, n_bins - 1 = dead ids
+    uint32_t key_bits;        // bits needed for keys < n_bins
+    const uint16_t* dense;    // [gt_cap] group-table slot -> dense group number
+    uint16_t* key16;          // [total]
+    uint32_t* hist;           // [n_bins * n_tiles] counts, then (after the scan) start offsets
+    uint32_t *out_topic, *out_route;
+    uint32_t *group_off, *group_rep;
+    uint32_t group_cap;
+    uint32_t* need_fill;      // [1] pairs whose route id has no group slot yet
+};
+
+// dense[s] = number of used slots in front of slot s (one workgroup; the table has at most 2^29 slots but in practice a few thousand)
+__global__ __launch_bounds__(1024) void k_fo_dense(const unsigned long long* gt_hash, uint32_t gt_cap, uint16_t* dense, uint32_t* n_used) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (gt_cap + 1023) / 1024, lo = min(gt_cap, tid * per), hi = min(gt_cap, lo + per);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += gt_hash[i] != 0ull ? 1u : 0u;
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t i = lo; i < hi; i++) {
+        dense[i] = (uint16_t)min(run, 0xFFFFu);
+        run += gt_hash[i] != 0ull ? 1u : 0u;
+    }
+    if (tid == 1023) *n_used = part[1023];
+}
+
+__global__ __launch_bounds__(FO_WAVES * 64) void k_fo_hist(DistIndexMut ix, FanoutState st, FanoutFast f) {
+    __shared__ uint32_t cnt_all[FO_WAVES][FO_MAX_BINS];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * FO_WAVES + wave;
+    if (tile >= f.n_tiles) return;
+    uint32_t* cnt = cnt_all[wave];
+    for (uint32_t b = lane; b < f.n_bins; b += 64) cnt[b] = 0;
+    wave_sync();
+    const uint32_t p0 = tile * FO_TILE, p1 = min(f.total, p0 + FO_TILE);
+    uint32_t unset = 0;
+    for (uint32_t p = p0 + lane; p < p1; p += 64) {
+        const uint32_t id = f.ids[p];
+        uint32_t key = f.n_bins - 1; // dead: never handed out, or deleted since the match
+        if (id < f.id_end && id < st.id_cap && ix.kref[id] != 0) {
+            const uint32_t g = st.dgroup[id];
+            if (g == FO_UNSET || (g & FO_NEW)) unset++;
+            else key = g == st.gt_cap ? f.n_bins - 2 : (uint32_t)f.dense[g];
+        }
+        f.key16[p] = (uint16_t)key;
+        atomicAdd(&cnt[key], 1u);
+    }
+    wave_sync();
+    for (uint32_t b = lane; b < f.n_bins; b += 64) f.hist[(size_t)b * f.n_tiles + tile] = cnt[b];
+    if (__any(unset != 0)) {
+        uint32_t s = unset;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+        if (lane == 0) atomicAdd(f.need_fill, s);
+    }
+}
+
+__global__ __launch_bounds__(FO_WAVES * 64) void k_fo_scatter(FanoutFast f) {
+    __shared__ uint32_t off_all[FO_WAVES][FO_MAX_BINS];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * FO_WAVES + wave;
+    if (tile >= f.n_tiles) return;
+    uint32_t* off = off_all[wave];
+    for (uint32_t b = lane; b < f.n_bins; b += 64) off[b] = f.hist[(size_t)b * f.n_tiles + tile];
+    const uint32_t p0 = tile * FO_TILE, p1 = min(f.total, p0 + FO_TILE);
+    uint32_t r; // the row of the tile's first pair: the last r with row_ptr[r] <= p0 (rows may be empty)
+    {
+        uint32_t lo = 0, hi = f.n_topics;
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (f.row_ptr[mid] <= p0) lo = mid;
+            else hi = mid;
+        }
+        r = lo;
+    }
+    wave_sync();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t s = p0; s < p1; s += 64) {
+        const uint32_t p = s + lane;
+        const bool in = p < p1;
+        const uint32_t id = in ? f.ids[p] : 0u;
+        const uint32_t key = in ? (uint32_t)f.key16[p] : 0u;
+        // ---- topic of every pair: rows base, base + 1, ... end at row_ptr[base + 1], row_ptr[base + 2], ...: a window of 64 row ends,
+        // searched by shuffle; a lane whose pair lies behind the whole window makes the wave move the window on
+        uint32_t topic = r;
+        bool placed = !in;
+        for (uint32_t base = r; !__all(placed); base += 64) {
+            const uint32_t idx = base + 1 + lane;
+            const uint32_t e = idx <= f.n_topics ? f.row_ptr[idx] : 0xFFFFFFFFu; // end of row base + lane (behind the last row: never reached)
+            uint32_t lo = 0, hi = 63;                                            // first j with e_j > p, if e_63 > p
+#pragma unroll
+            for (int step = 0; step < 6; step++) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t em = __shfl(e, (int)mid);
+                if (em <= p) lo = mid + 1;
+                else hi = mid;
+            }
+            const uint32_t e_last = __shfl(e, 63);
+            if (!placed && e_last > p) {
+                topic = base + min(lo, 63u);
+                placed = true;
+            }
+        }
+        r = __shfl(topic, (int)(min(p1 - s, 64u) - 1u)); // the next segment starts in (or behind) the row of this segment's last pair
+        // ---- stable rank among the segment's pairs of the same key: `same` = lanes whose key equals mine
+        const unsigned long long m_in = __ballot(in);
+        unsigned long long same = m_in;
+        for (uint32_t b = 0; b < f.key_bits; b++) {
+            const unsigned long long mb = __ballot((key >> b) & 1u);
+            same &= ((key >> b) & 1u) ? mb : ~mb;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & below), cnt = (uint32_t)__popcll(same);
+        const int leader = __ffsll((long long)same) - 1;
+        uint32_t base_off = 0;
+        if (in && (int)lane == leader) { // one lane per distinct key: no two leaders share a counter
+            base_off = off[key];
+            off[key] = base_off + cnt;
+        }
+        base_off = __shfl(base_off, in ? leader : 0);
+        if (in) {
+            const uint32_t dst = base_off + rank;
+            f.out_topic[dst] = topic;
+            f.out_route[dst] = id;
+        }
+        wave_sync();
+    }
+}
+
+// one lane per key: group g = the g-th non-empty key; its pairs start where the key's first tile run starts
+__global__ __launch_bounds__(1024) void k_fo_groups2(FanoutState st, FanoutFast f) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (f.n_bins + 1023) / 1024, lo = min(f.n_bins, tid * per), hi = min(f.n_bins, lo + per);
+    auto start_of = [&](uint32_t b) { return f.hist[(size_t)b * f.n_tiles]; };
+    auto end_of = [&](uint32_t b) { return b + 1 < f.n_bins ? f.hist[(size_t)(b + 1) * f.n_tiles] : f.total; };
+    uint32_t s = 0;
+    for (uint32_t b = lo; b < hi; b++) s += end_of(b) > start_of(b) ? 1u : 0u;
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t g = part[tid] - s;
+    for (uint32_t b = lo; b < hi; b++) {
+        const uint32_t b0 = start_of(b), b1 = end_of(b);
+        if (b1 == b0) continue;
+        if (g < f.group_cap) {
+            f.group_off[g] = b0;
+            // a normal group is named by one of ITS routes of this batch (alive as of the match; the slot's first route may be gone by now)
+            f.group_rep[g] = b + 2 < f.n_bins ? f.out_route[b0] : (b + 2 == f.n_bins ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+        }
+        g++;
+    }
+    if (tid == 1023) {
+        const uint32_t n = part[1023];
+        st.flags[2] = n;
+        if (n <= f.group_cap) f.group_off[n] = f.total;
+        // which special groups are present (they sort last): bit 0 shared subscriptions, bit 1 dead ids
+        const uint32_t sh0 = start_of(f.n_bins - 2), d0 = start_of(f.n_bins - 1);
+        st.flags[3] = (d0 > sh0 ? 1u : 0u) | (f.total > d0 ? 2u : 0u);
+    }
+}
+
+} // namespace bmq
