@@ -180,6 +180,43 @@ __device__ __forceinline__ void load_line64(const void* p, Line64& r) {
                  : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1)
                  : "v"(p));
 }
+// The same line fetched by the lane's QUAD.  A vector load whose 64 lanes address 64 different cache lines occupies the CU's address /
+// tag pipeline for 64 cycles, and load_line64 issues four of them per line: with 16 resident waves the vector L1 -- not the latency
+// of L2 / HBM -- sets the duration of a walk round (measured, profiles/r03: two lines per lane and round left the phase's duration
+// unchanged; a round costs ~5 k clocks ~= 16 waves x 256 cycles).  Here lane 4q + j asks for bytes 16 j .. 16 j + 15 of the line of
+// lane 4q + r in request r = 0..3: every request touches 16 lines instead of 64, the four lanes of a quad share one.  The 4 x 4
+// (request x lane) block a quad holds afterwards is transposed with two DPP butterfly stages, so that every lane ends up with ITS
+// line as before.  All 64 lanes must call it together (inactive work passes any readable address).
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_quad(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ void quad_swap(uint4& lo, uint4& hi, bool upper) { // 2 x 2 block transpose across lanes differing in one quad bit
+    const uint4 x = make_uint4(dpp_quad<CTRL>(lo.x), dpp_quad<CTRL>(lo.y), dpp_quad<CTRL>(lo.z), dpp_quad<CTRL>(lo.w));
+    const uint4 y = make_uint4(dpp_quad<CTRL>(hi.x), dpp_quad<CTRL>(hi.y), dpp_quad<CTRL>(hi.z), dpp_quad<CTRL>(hi.w));
+    if (upper) lo = y; // the upper lane of the pair takes the lower lane's `hi` ...
+    else hi = x;       // ... the lower lane the upper lane's `lo`
+}
+__device__ __forceinline__ void load_line64_quad(const void* p, Line64& r) {
+    const uint32_t sub = threadIdx.x & 3u;
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32);
+    const uint64_t p0 = (((uint64_t)dpp_quad<0x00>(ahi) << 32) | dpp_quad<0x00>(alo)) + 16u * sub;
+    const uint64_t p1 = (((uint64_t)dpp_quad<0x55>(ahi) << 32) | dpp_quad<0x55>(alo)) + 16u * sub;
+    const uint64_t p2 = (((uint64_t)dpp_quad<0xAA>(ahi) << 32) | dpp_quad<0xAA>(alo)) + 16u * sub;
+    const uint64_t p3 = (((uint64_t)dpp_quad<0xFF>(ahi) << 32) | dpp_quad<0xFF>(alo)) + 16u * sub;
+    uint4 v0, v1, v2, v3;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                 "global_load_dwordx4 %1, %5, off\n\t"
+                 "global_load_dwordx4 %2, %6, off\n\t"
+                 "global_load_dwordx4 %3, %7, off\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+    // v_r of lane 4q + j = part j of the line of lane 4q + r: transpose the quad's 4 x 4 block
+    quad_swap<0xB1>(v0, v1, (sub & 1u) != 0); // quad_perm [1,0,3,2]
+    quad_swap<0xB1>(v2, v3, (sub & 1u) != 0);
+    quad_swap<0x4E>(v0, v2, (sub & 2u) != 0); // quad_perm [2,3,0,1]
+    quad_swap<0x4E>(v1, v3, (sub & 2u) != 0);
+    r.a0 = v0, r.a1 = v1, r.b0 = v2, r.b1 = v3;
+}
 // two independent lines, eight loads in flight, ONE wait: the walk's rounds are latency bound, two items per lane halve their number
 __device__ __forceinline__ void load_line64_x2(const void* p, const void* q, Line64& r, Line64& t) {
     asm volatile("global_load_dwordx4 %0, %8, off\n\t"
@@ -246,6 +283,29 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
         g = (g + 1) & ix.dict_group_mask;
     }
     return TOK_UNKNOWN;
+}
+
+// The same with the home group fetched by the lane's quad (load_line64_quad): ALL 64 lanes call it together, `active` says whose level
+// is real.  A home group full of other strings (rare at load factor 1/4) falls back to the probing lookup above.
+template <class ByteAt>
+__device__ __forceinline__ uint32_t dict_lookup_quad(const DistIndexView& ix, bool active, const LevelHash& h, uint32_t len, const uint32_t inl[4],
+                                                     uint32_t start, ByteAt&& byte_at) {
+    const uint32_t tag = level_hash_tag(h);
+    const uint32_t g = active ? (level_hash_slot(h, len) & ix.dict_group_mask) : 0u;
+    Line64 ln;
+    load_line64_quad(ix.dict + DICT_GROUP * (size_t)g, ln);
+    if (!active) return TOK_UNKNOWN;
+    auto tail_eq = [&](uint32_t pool_off) {
+        bool eq = true;
+        for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[pool_off + i] == byte_at(start + i);
+        return eq;
+    };
+    const bool h0 = ln.a0.x == tag && ln.a0.z == len && ln.a1.x == inl[0] && ln.a1.y == inl[1] && ln.a1.z == inl[2] && ln.a1.w == inl[3];
+    const bool h1 = ln.b0.x == tag && ln.b0.z == len && ln.b1.x == inl[0] && ln.b1.y == inl[1] && ln.b1.z == inl[2] && ln.b1.w == inl[3];
+    if (h0 && (len <= 16 || tail_eq(ln.a0.w))) return ln.a0.y;
+    if (h1 && (len <= 16 || tail_eq(ln.b0.w))) return ln.b0.y;
+    if (ln.a0.x == 0 || ln.b0.x == 0) return TOK_UNKNOWN;
+    return dict_lookup(ix, h, len, inl, start, byte_at);
 }
 
 // Scans one level starting at pos: bytes up to the next '/' (split) or to `end`, FOUR BYTES PER STEP.
@@ -520,6 +580,9 @@ __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
 #ifndef BMQ_WALK_ILP
 #define BMQ_WALK_ILP 1 // work items per lane per round of the walk (their bucket lines are requested together, one wait)
 #endif
+#ifndef BMQ_QUAD_LOAD
+#define BMQ_QUAD_LOAD 0 // 1: a bucket / dictionary line is fetched by the lane's quad (16 lines per request instead of 64): see load_line64_quad
+#endif
 #ifndef BMQ_XCD_REMAP
 #define BMQ_XCD_REMAP 0 // every XCD (block b runs on XCD b % 8) works on ONE contiguous eighth of the batch: a tenant's region is cached by one L2, not by eight
 #endif
@@ -694,16 +757,22 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
 #endif
     for (; __any(more); l++) {
         if (!uni && l < 3 && t_ok) tenant_stage(a, ti, tq, l);
-        LevelHash h;
-        uint32_t inl[4], len = 0;
+        LevelHash h = level_hash_init();
+        uint32_t inl[4] = {0, 0, 0, 0}, len = 0;
         const uint32_t start = pos;
+        const bool mine = more;
         if (more) {
             bool last;
             scan_level(pos, end, true, word_at, h, inl, len, last);
             nlev++;
-            if (l < FAST_LEVELS) tokens[l * 64 + lane] = dict_lookup(a.ix, h, len, inl, start, byte_at);
             more = !last;
         }
+#if BMQ_QUAD_LOAD
+        const uint32_t tok = dict_lookup_quad(a.ix, mine, h, len, inl, start, byte_at); // (all lanes: the quads fetch their lines together)
+#else
+        const uint32_t tok = mine ? dict_lookup(a.ix, h, len, inl, start, byte_at) : TOK_UNKNOWN;
+#endif
+        if (mine && l < FAST_LEVELS) tokens[l * 64 + lane] = tok;
     }
     if (!uni) {
         for (uint32_t st = l; st < 3; st++) // a wave of topics with fewer than three levels
@@ -863,6 +932,7 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
             }
             Line64 ln[WALK_ILP];
             if (WALK_ILP == 2) load_line64_x2(line[0], line[WALK_ILP - 1], ln[0], ln[WALK_ILP - 1]);
+            else if (BMQ_QUAD_LOAD) load_line64_quad(line[0], ln[0]);
             else load_line64(line[0], ln[0]);
             wave_sync(); // every lane holds its items in registers: the stack above `tail` may be overwritten by the pushes below
 #pragma unroll
