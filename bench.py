@@ -45,15 +45,21 @@ def main():
     ap.add_argument("--exchange", default="fanout", choices=["fanout", "ids", "none"],
                     help="N>1 exchange step: per-topic fan-out counts (what the reference sends upstream, DistWorkerCoProc.java:535-538) "
                          "or the complete CSR as an all-gatherv of route ids")
-    ap.add_argument("--exchange-impl", default="torch", choices=["torch", "lib"],
-                    help="who issues the collectives: torch.distributed (RCCL through PyTorch) or libbmq itself (bmq_exchange_*: RCCL "
-                         "loaded by the library; validated at world size 1 only on this pool, hence not the default)")
+    ap.add_argument("--exchange-impl", default="lib", choices=["torch", "lib"],
+                    help="who issues the collectives: libbmq itself (bmq_exchange_*: RCCL loaded by the library, on the engine's exchange "
+                         "stream) or torch.distributed (RCCL through PyTorch)")
+    ap.add_argument("--csr-exchange-steps", type=int, default=5,
+                    help="N>1: extra steps, outside the timed region, with the OTHER exchange form (the all-gatherv of the complete CSR that "
+                         "north_star names when --exchange is fanout, and vice versa): reported as exchange.csr_ms / exchange.fanout_ms")
     ap.add_argument("--node-batch-steps", type=int, default=10,
                     help="N>1: steps of the extra node-wide measurement (one shared Zipf batch, device-side partition, hot tenants "
                          "split by filter, fan-out all-reduce); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1: skip the compact extra legs (configs[4] churn on this index, the batching front at 64 threads, C2 and C4 as "
+                         "child runs) that the default run appends under `extra`")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-visible (PCIe-inclusive) measurement")
-    ap.add_argument("--batcher-threads", type=int, default=0,
+    ap.add_argument("--batcher-threads", type=int, default=-1,
                     help="also measure the batching front (bmq_batcher_*, SURVEY 8f-1): N native threads issue single-topic calls")
     ap.add_argument("--batcher-topics", type=int, default=200_000)
     ap.add_argument("--cpu-sample-tenants", type=int, default=128)
@@ -154,9 +160,11 @@ def main():
             raise RuntimeError("bmq_comm_init failed: %s" % B._lib.lib().bmq_last_error(eng.h))
         d_counts_all = [torch.zeros(world * n, dtype=torch.int32, device=dev) for _ in range(NBUF)]
         d_rows_all = [torch.zeros(world * (n + 1), dtype=torch.int32, device=dev) for _ in range(NBUF)]
-        d_ids_all = [torch.zeros(world * cap, dtype=torch.int32, device=dev) for _ in range(NBUF)] if args.exchange == "ids" else None
+        d_ids_all = [torch.zeros(world * cap, dtype=torch.int32, device=dev) for _ in range(NBUF)]
         h_totals = np.zeros(world, dtype=np.uint64)
     torch.cuda.synchronize()
+
+    ex_mode = [args.exchange]  # the exchange form of the steps being run (the extra pass below switches it)
 
     def step(i):
         nonlocal cap
@@ -180,13 +188,13 @@ def main():
                     raise
                 cap = int(d_total.item()) * 2  # only during warm-up in practice
                 d_ids[k] = torch.zeros(cap, dtype=torch.int32, device=dev)
-        if dist is not None and args.exchange != "none":  # the one exchange step over RCCL/xGMI, on its own stream
+        if dist is not None and ex_mode[0] != "none":  # the one exchange step over RCCL/xGMI, on its own stream
             from bifromq_amd import shard
             if d_ids[k].numel() < total:
                 raise RuntimeError("id buffer smaller than the batch result")
             if use_lib_ex:  # asynchronous on the engine's exchange stream, behind this batch, overlapping the next one
                 L = B._lib.lib()
-                if args.exchange == "fanout":
+                if ex_mode[0] == "fanout":
                     rc = L.bmq_exchange_fanout(eng.h, d_row[k].data_ptr(), n, d_counts_all[k].data_ptr())
                 else:
                     if d_ids_all[k].numel() < world * d_ids[k].numel():  # the result buffer grew during warm-up
@@ -198,7 +206,7 @@ def main():
                 ex_done[k] = True
                 return total
             with torch.cuda.stream(ex_stream):  # results are complete (finish() synchronised the engine stream)
-                if args.exchange == "fanout":  # 4 B per topic: every rank learns every topic's fan-out
+                if ex_mode[0] == "fanout":  # 4 B per topic: every rank learns every topic's fan-out
                     shard.exchange_counts_weak(dist, d_row[k], world)
                 else:  # all-gatherv of the complete CSR: exact sizes, one grouped broadcast per rank
                     shard.exchange_csr_v(dist, d_row[k], d_ids[k], total, world)
@@ -284,6 +292,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # the OTHER exchange form, a few steps outside the timed region: north_star's "all-gatherv of (topic -> matched-route) pairs" next to
+    # the fan-out counts the reference really sends upstream
+    other_ms = None
+    if dist is not None and args.exchange != "none" and args.csr_exchange_steps > 0:
+        ex_mode[0] = "ids" if args.exchange == "fanout" else "fanout"
+        step(0)
+        barrier()
+        t_o = time.perf_counter()
+        for i in range(args.csr_exchange_steps):
+            step(i)
+        barrier()
+        t_other = time.perf_counter() - t_o
+        tmax = torch.tensor([t_other], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        other_ms = float(tmax.item()) / args.csr_exchange_steps * 1e3
+        ex_mode[0] = args.exchange
     node = None
     if dist is not None and args.node_batch_steps > 0 and args.workload == "c3":
         node = node_batch(args, rank, world, local_rank, dev, dist, total_tenants, per_tenant, mode, seed)
@@ -339,6 +363,12 @@ def main():
                                 if args.exchange == "fanout" else
                                 "RCCL all-gatherv of the complete CSR (row_ptr + route ids, exact sizes, grouped per-rank broadcasts), "
                                 "overlapped with the next batch's match")},
+        "exchange": None if dist is None or args.exchange == "none" else {
+            ("fanout_ms" if args.exchange == "fanout" else "csr_ms"): elapsed / steps * 1e3,
+            ("csr_ms" if args.exchange == "fanout" else "fanout_ms"): other_ms,
+            "note": "ms per step (match + exchange, max over ranks) with the fan-out exchange (all-gather of 4 B per topic) and with the "
+                    "all-gatherv of the complete CSR (totals, row pointers, then one exact-size broadcast per rank in one group); the first "
+                    "is the timed region of `value`, the second a few extra steps"},
         "value_without_kernel_timing": world * n * steps / elapsed_plain if not args.churn else None,
         "ms_per_step_without_kernel_timing": elapsed_plain / steps * 1e3 if not args.churn else None,
         "p99_batch_ms": float(np.percentile(lat, 99)),
@@ -386,6 +416,8 @@ def main():
             out["host_visible"] = host_visible(args, eng, w, batches, n, seed, rank, int(ids_per_batch * 1.25) + 4096)
         else:
             out["host_visible"] = {"skipped": "a batch returns %.1f GB of route ids: the host-visible rate is PCIe bandwidth / that" % (ids_per_batch * 4 / 1e9)}
+    if args.batcher_threads < 0:  # default: the batching front at 64 threads is part of the N = 1 line (unless the extras are off)
+        args.batcher_threads = 64 if (world == 1 and not args.no_extras and not args.no_host_path and args.workload == "c3") else 0
     if args.batcher_threads and world == 1:  # the production call pattern (one topic per call, many threads) through the collector
         hdata, hoff, htt = batches[0][3]
         m = min(args.batcher_topics, n)
@@ -432,9 +464,88 @@ def main():
             out["batching_front"]["route_cache"] = {"error": repr(ex)}
     if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n)
+    if world == 1 and not args.no_extras and not args.churn and args.workload == "c3":
+        out["extra"] = extra_legs(args, eng, w, step, torch, np)
     if dist is not None:
         dist.destroy_process_group()
     emit_json(out)
+
+
+def extra_legs(args, eng, w, step, torch, np):
+    """Compact legs the default N = 1 run appends, so that the driver's own command exercises them: configs[4] (100 k route mutations
+    before every batch) on THIS index, and configs[1] / configs[3] as child runs of this script (3 steps each)."""
+    import subprocess
+
+    import bifromq_amd as B
+    from bifromq_amd.engine import pack
+
+    extra = {}
+    t_all = time.perf_counter()
+    for wl in ("c2", "c4"):  # child runs: their own index, their own roofline
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                                "--no-host-path", "--no-extras"], capture_output=True, text=True, timeout=240)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            keep = ("metric", "value", "unit", "ms_per_step", "kernel_ms", "roofline", "routes_per_topic", "topics_per_filter", "churn")
+            extra[wl] = {k: d[k] for k in keep if k in d}
+            extra[wl]["workload"] = d["config"]["workload"]
+            extra[wl]["wall_s"] = time.perf_counter() - t0
+        except Exception as ex:  # noqa: BLE001
+            extra[wl] = {"error": repr(ex)}
+    # configs[4] on the C3 index of this run: 5 steps, each = bmq_routes_apply(100 k ops from pinned memory) + the 1 M-publish batch
+    try:
+        n_ops, n_steps = 100_000, 5
+        rng = np.random.default_rng(4321)
+        kb_h, ko_h = w.keys_packed()
+        mv = memoryview(kb_h)
+        perm = rng.permutation(w.n_keys)[:(n_steps + 1) * (n_ops // 2)]
+        tenants_l = w.tenants()
+        cb = []
+        q = 0
+        for b in range(n_steps + 1):
+            dels = perm[b * (n_ops // 2):(b + 1) * (n_ops // 2)]
+            keys_b = [bytes(mv[int(ko_h[i]):int(ko_h[i + 1])]) for i in dels]
+            ops_b = [1] * len(keys_b)
+            for _ in range(n_ops - n_ops // 2):
+                q += 1
+                t = tenants_l[int(rng.integers(0, len(tenants_l)))]
+                keys_b.append(B.route_key(t, "churn/l1_%d/+/l3_%d" % (q % 64, q % 4096), 1, "0\0c%d\0d%d" % (q, q % 64)))
+                ops_b.append(0)
+            order = rng.permutation(len(keys_b))
+            data, off = pack([keys_b[i] for i in order])
+            cb.append(tuple(torch.from_numpy(x).pin_memory() for x in (data, off, np.array([ops_b[i] for i in order], dtype=np.uint8))))
+        lib = B._lib.lib()
+
+        def apply(i):
+            data, off, opb = cb[i]
+            t0c = time.perf_counter()
+            rc = lib.bmq_routes_apply(eng.h, data.data_ptr(), off.data_ptr(), opb.data_ptr(), len(opb))
+            if rc:
+                raise RuntimeError("bmq_routes_apply failed: %d" % rc)
+            return (time.perf_counter() - t0c) * 1e3
+
+        apply(0)
+        step(0)
+        torch.cuda.synchronize()
+        ams, t0 = [], time.perf_counter()
+        for i in range(n_steps):
+            ams.append(apply(i + 1))
+            step(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st = eng.stats()
+        alg = st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit + 4 * st.n_match
+        extra["c5"] = {"workload": "C5 = C3 + %d route mutations (50 %% unsubscribe / 50 %% subscribe) before every 1 M-publish batch" % n_ops,
+                       "value": args.topics * n_steps / el, "unit": "topics/s", "steps": n_steps, "ms_per_step": el / n_steps * 1e3,
+                       "apply_ms_mean": float(np.mean(ams)), "apply_ms_max": float(np.max(ams)),
+                       "kernel_ms": {"k_walk": st.ms_walk, "k_expand": st.ms_expand, "all_kernels": st.ms_total},
+                       "roofline": {"bound": "hbm", "kernel": "k_walk", "achieved": alg / (st.ms_walk * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": alg / (st.ms_walk * 1e-3) / 8e12}}
+    except Exception as ex:  # noqa: BLE001
+        extra["c5"] = {"error": repr(ex)}
+    extra["wall_s"] = time.perf_counter() - t_all
+    return extra
 
 
 def node_batch(args, rank, world, local_rank, dev, dist, total_tenants, per_tenant, mode, seed):
@@ -518,13 +629,12 @@ def _node_batch_run(args, rank, world, dev, dist, n, eng, tn, tt, hot, n_split_k
     from bifromq_amd import shard
 
     m_sel = 0
+    part = shard.DevicePartition(eng, d_owner, n, int(d_data.numel()), dev)  # bmq_partition_batch_dev: kernels on the engine stream
 
     def step():
         nonlocal m_sel, d_ids
-        sel, pd, po, ptt = shard.partition_batch(d_owner, d_tt, d_data, d_off, rank)
-        m = int(sel.numel())
+        sel, pd, po, ptt, m = part(d_tt, d_data, d_off, rank)
         m_sel = m
-        torch.cuda.current_stream().synchronize()  # the engine launches on its own stream: the partition must have landed
         if m:
             while True:
                 eng.match_batch_device(d_tenants.data_ptr(), d_tenant_off.data_ptr(), len(tn), ptt.data_ptr(), pd.data_ptr(), po.data_ptr(), m,
@@ -565,7 +675,7 @@ def _node_batch_run(args, rank, world, dev, dist, n, eng, tn, tt, hot, n_split_k
             "split_tenants": [tn[h] for h in hot], "split_route_keys_this_rank": n_split_keys,
             "publishes_per_rank": [int(x) for x in per_rank], "imbalance_max_over_mean": float(per_rank.max() / per_rank.mean()),
             "imbalance_without_split": float(plain.max() / plain.mean()),
-            "note": "one shared batch: device-side partition by hash(tenantId) mod N (hot tenants split by filter, publishes to all ranks) "
+            "note": "one shared batch: device-side partition (bmq_partition_batch_dev) by hash(tenantId) mod N (hot tenants split by filter, publishes to all ranks) "
                     "-> match -> all-reduce of per-topic fan-out; includes the partition and the exchange"}
 
 
@@ -662,8 +772,11 @@ def kernel_sources_sha():
     """hash of the sources the match kernels are built from: ties a PMC traffic measurement to the code it was taken with"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("bmq_layout.h", "bmq_dist_kernels.h", "bmq_retain_kernels.h"):
-        h.update(open(os.path.join(ROOT, "bifromq_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "bifromq_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):  # everything bmq_engine.o is built from: kernels AND the launch geometry in bmq_engine.hip
+        if f.endswith((".h", ".inc", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -754,7 +867,12 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
             return
     kw, ke = float(np.mean(walk_ms)), float(np.mean(expand_ms))
     dom_name, k_ms = ("k_retain_walk", kw) if kw >= ke else ("k_expand", ke)
-    achieved = float(np.mean(alg)) / (k_ms * 1e-3) / 1e9  # the batch's algorithmic bytes / the dominant kernel
+    # ONE dominant kernel and ITS share of the algorithmic bytes: the walk reads the filters and touches the nodes
+    # (len + 8 + 32 N_visit), the expansion writes the ids (4 N_match)
+    walk_bytes = float(np.mean(alg)) - 4.0 * n_match / args.steps
+    exp_bytes = 4.0 * n_match / args.steps
+    achieved = (walk_bytes if dom_name == "k_retain_walk" else exp_bytes) / (k_ms * 1e-3) / 1e9
+    churn = retain_churn_leg(eng, w, data, off, n_topics, step, torch, np) if world == 1 else None
     out = {"metric": "retain-direction filter matches/sec (whole node)", "value": world * n * args.steps / elapsed,
            "unit": "filters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -769,7 +887,9 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0,
                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                         "frac_pipeline": float(np.mean(alg)) / ((kw + ke) * 1e-3) / 8e12,
-                        "algorithmic_bytes_per_launch": float(np.mean(alg))}}
+                        "algorithmic_bytes_per_launch": walk_bytes if dom_name == "k_retain_walk" else exp_bytes,
+                        "algorithmic_bytes_per_batch": float(np.mean(alg))},
+           "churn": churn}
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
         lt = O.LevelTrie(1)
@@ -787,6 +907,57 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
     if world > 1:
         dist.destroy_process_group()
     emit_json(out)
+
+
+def retain_churn_leg(eng, w, data, off, n_topics, step, torch, np, n_ops=100_000, reps=6):
+    """SURVEY row a10 at configs[3] size: batches of 100 k IRetainTopicIndex.add / remove (half removes of retained topics, half adds of
+    new ones; every other batch undoes the one before it) through bmq_retain_apply_batch from page-locked buffers -- three kernels on the
+    engine stream -- and the 100 k-filter batch on the churned index (dead-aware expansion + overlay walk)."""
+    import ctypes as C
+
+    import bifromq_amd as B
+    from bifromq_amd.engine import pack
+
+    rng = np.random.default_rng(99)
+    raw = data.tobytes()
+    pick = rng.choice(n_topics, n_ops // 2, replace=False)
+    old = sorted({raw[off[i]:off[i + 1]] for i in pick})
+    new = [b"churn/n%d/x%d" % (j % 977, j) for j in range(n_ops - len(old))]
+    tdata, toff = w.tenants_packed()
+    lib = B._lib.lib()
+
+    def batch(removes, adds):
+        topics = list(removes) + list(adds)
+        codes = np.array([1] * len(removes) + [0] * len(adds), dtype=np.uint8)
+        order = rng.permutation(len(topics))
+        d, o = pack([topics[i] for i in order])
+        return tuple(torch.from_numpy(x).pin_memory() for x in (d, o, codes[order]))
+
+    fwd, back = batch(old, new), batch(new, old)
+    t_tenants, t_toff = torch.from_numpy(tdata.copy()).pin_memory(), torch.from_numpy(toff.astype(np.uint32).view(np.int32)).pin_memory()
+    ms = []
+    for r in range(reps):
+        d, o, c = fwd if r % 2 == 0 else back
+        t0 = time.perf_counter()
+        rc = lib.bmq_retain_apply_batch(eng.h, t_tenants.data_ptr(), t_toff.data_ptr(), 1, None, d.data_ptr(), o.data_ptr(), c.data_ptr(), None, None, len(c), None)
+        ms.append((time.perf_counter() - t0) * 1e3)
+        if rc:
+            raise RuntimeError("bmq_retain_apply_batch failed: %d %s" % (rc, lib.bmq_last_error(eng.h)))
+    d, o, c = fwd  # leave the index churned: 50 k bulk-loaded ids dead, 50 k overlay topics live
+    lib.bmq_retain_apply_batch(eng.h, t_tenants.data_ptr(), t_toff.data_ptr(), 1, None, d.data_ptr(), o.data_ptr(), c.data_ptr(), None, None, len(c), None)
+    step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    match_ms = (time.perf_counter() - t0) / 3 * 1e3
+    st = eng.stats()
+    info = eng.retain_info()
+    return {"ops_per_batch": n_ops, "apply_ms": [round(x, 3) for x in ms], "apply_ms_median_warm": float(np.median(ms[1:])),
+            "match_ms_per_step_on_churned_index": match_ms, "kernel_ms_on_churned_index": {"k_retain_walk": st.ms_walk, "k_retain_expand_dyn": st.ms_expand},
+            "index": {"retained": int(info.n_topics), "loaded_removed": int(info.loaded_removed), "added_ids": int(info.added_ids), "overlay_nodes": int(info.overlay_nodes)},
+            "note": "wall time of the C-ABI call (upload from pinned memory + locate x2, commit, rank kernels + read-back); the first call allocates"}
 
 
 def effective_cpus():

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "bmq_index_info_get", "bmq_route_key", "bmq_route_keys", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
     "bmq_match_finish", "bmq_set_kernel_timing", "bmq_match_submit", "bmq_match_wait", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_range_lookup", "bmq_comm_unique_id", "bmq_comm_init", "bmq_comm_destroy", "bmq_exchange_fanout",
-    "bmq_exchange_csr", "bmq_exchange_wait", "bmq_retain_message_key", "bmq_retain_filter_route", "bmq_retain_rebuild", "bmq_retain_rebuild_ex", "bmq_retain_apply", "bmq_retain_apply_ex", "bmq_retain_topic",
+    "bmq_exchange_csr", "bmq_exchange_wait", "bmq_partition_batch_dev", "bmq_retain_message_key", "bmq_retain_filter_route", "bmq_retain_rebuild", "bmq_retain_rebuild_ex", "bmq_retain_apply", "bmq_retain_apply_ex", "bmq_retain_topic",
     "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired", "bmq_retain_apply_batch", "bmq_retain_compact", "bmq_retain_info_get",
     "bmq_retain_live_ids", "bmq_retain_topics",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
             "bmq_exchange_fanout": (C.c_int, [vp, vp, u32, vp]),
             "bmq_exchange_csr": (C.c_int, [vp, vp, vp, u32, u64, vp, vp, u64, vp]),
             "bmq_exchange_wait": (C.c_int, [vp]),
+            "bmq_partition_batch_dev": (C.c_int, [vp, vp, u32, i32, vp, vp, vp, u32, vp, vp, vp, vp, P(u32), P(u64)]),
             "bmq_retain_message_key": (u32, [C.c_char_p, u32, C.c_char_p, u32, C.c_char_p, u32]),
             "bmq_retain_filter_route": (C.c_int, [C.c_char_p, u32, C.c_char_p, u32, C.c_char_p, u32, P(u32), C.c_char_p, u32, P(u32), P(u32)]),
             "bmq_range_lookup": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, vp, vp, vp, vp, vp, u32, vp]),

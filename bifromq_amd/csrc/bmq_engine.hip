@@ -160,6 +160,7 @@ struct bmq_engine {
     hipStream_t s_ex = nullptr;
     hipEvent_t ev_ex = nullptr;
     DevBuf ex_buf;
+    DevBuf part_buf; // bmq_partition_batch_dev: flags, lengths and their prefix sums
     uint32_t rgcap = 0;
 };
 

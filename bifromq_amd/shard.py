@@ -125,6 +125,38 @@ def partition_batch(owner, topic_tenant, data, off, rank: int):
     return sel, new_data, new_off.to(torch.int32), topic_tenant[sel].contiguous()
 
 
+class DevicePartition:
+    """bmq_partition_batch_dev (include/bmq.h): the same partition as partition_batch, by kernels of the library on the engine stream
+    -- mask, two prefix sums, scatter; one host read (the sizes) per batch instead of a chain of tensor ops with a .item() in the middle.
+    Buffers are allocated once for batches of up to n topics / `nbytes` topic bytes."""
+
+    def __init__(self, eng, owner, n: int, nbytes: int, device):
+        import torch
+
+        self.eng = eng
+        self.owner = owner.to(torch.int32).contiguous()
+        self.sel = torch.zeros(n, dtype=torch.int32, device=device)
+        self.data = torch.zeros(nbytes + 64, dtype=torch.uint8, device=device)
+        self.off = torch.zeros(n + 1, dtype=torch.int32, device=device)
+        self.tt = torch.zeros(n, dtype=torch.int32, device=device)
+
+    def __call__(self, topic_tenant, data, off, rank: int):
+        """-> (sel [m], data', off' [m + 1], topic_tenant' [m]) views of the internal buffers, m"""
+        import ctypes as C
+
+        from . import _lib
+
+        n = int(topic_tenant.numel())
+        m, nb = C.c_uint32(), C.c_uint64()
+        rc = _lib.lib().bmq_partition_batch_dev(self.eng.h, self.owner.data_ptr(), int(self.owner.numel()), rank, topic_tenant.data_ptr(), data.data_ptr(),
+                                                off.data_ptr(), n, self.sel.data_ptr(), self.data.data_ptr(), self.off.data_ptr(), self.tt.data_ptr(),
+                                                C.byref(m), C.byref(nb))
+        if rc:
+            raise RuntimeError("bmq_partition_batch_dev failed: %d %s" % (rc, _lib.lib().bmq_last_error(self.eng.h)))
+        m = int(m.value)
+        return self.sel[:m], self.data, self.off[:m + 1], self.tt[:m], m
+
+
 def exchange_fanout(dist, counts_local, sel, n_global: int):
     """Node-wide per-topic fan-out: every rank adds the fan-outs of the topics it matched into a vector over the whole batch
     (one all-reduce SUM of 4 B per topic -- split tenants are matched by every rank against its share of the filters, so their
@@ -133,7 +165,7 @@ def exchange_fanout(dist, counts_local, sel, n_global: int):
 
     v = torch.zeros(n_global, dtype=torch.int32, device=counts_local.device)
     if sel.numel():
-        v[sel] = counts_local.to(torch.int32)
+        v[sel.long()] = counts_local.to(torch.int32)
     if dist is not None:
         dist.all_reduce(v)
     return v

@@ -204,6 +204,21 @@ int bmq_exchange_fanout(bmq_engine* e, const uint32_t* d_row_ptr, uint32_t n, ui
 int bmq_exchange_csr(bmq_engine* e, const uint32_t* d_row_ptr, const uint32_t* d_ids, uint32_t n, uint64_t total,
                      uint32_t* d_rows_all, uint32_t* d_ids_all, uint64_t ids_cap, uint64_t* out_totals);
 int bmq_exchange_wait(bmq_engine* e);
+/* The ids bmq_exchange_csr gathers are rank-local handles: rank r's rows are d_rows_all[r * (n + 1) ...], its ids the stretch of
+ * d_ids_all behind sum(out_totals[0 .. r)) -- the position frames them as (rank, id); a consumer resolves an id on the rank that owns it.
+ *
+ * The node-wide batch: ONE publish batch for all tenants arrives on every GPU; a rank matches the topics whose tenant
+ * it owns (d_owner[tenant index] == rank) and those of tenants split by filter over all ranks (d_owner < 0: the reference's analogue is
+ * a hot range split by DW/hinter/FanoutSplitHinter.java:49, dist-server sums the per-range fan-outs, BatchDistServerCall.java:186-205).
+ * All pointers are device pointers; the part is picked by kernels on the engine stream (mask, two prefix sums, scatter):
+ *   d_out_sel[m]        global topic index of the part's k-th topic
+ *   d_out_topics/_off   the part's topics packed (the buffer must hold the batch's bytes + 32 and be 16-byte aligned: it is handed to
+ *                       bmq_match_batch_dev as is), d_out_off[m + 1]
+ *   d_out_tenant[m]     tenant index of every topic (the batch's tenant table stays as it is)
+ * *out_n = m, *out_bytes = bytes of the part: the one host read of the step. */
+int bmq_partition_batch_dev(bmq_engine* e, const int32_t* d_owner, uint32_t n_tenants, int32_t rank, const uint32_t* d_topic_tenant,
+                            const uint8_t* d_topics, const uint32_t* d_topic_off, uint32_t n_topics, uint32_t* d_out_sel, uint8_t* d_out_topics,
+                            uint32_t* d_out_off, uint32_t* d_out_tenant, uint32_t* out_n, uint64_t* out_bytes);
 
 /* ---- batching front ------------------------------------------------------------------- */
 /* Production asks for one topic per call: TenantRouteCache issues matchAll(singleton(topic)) per cache miss from

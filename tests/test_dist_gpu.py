@@ -741,3 +741,68 @@ def test_in_library_rccl_exchange_world_size_one(eng):
     for p in bufs:
         hip.hipFree(p)
     e2.close()
+
+
+def test_node_wide_path_two_shards_on_one_gpu():
+    """The node-wide shape of SURVEY 8e without a second GPU: two engines hold the shards ranks 0 and 1 of a 2-GPU node would hold
+    (tenants by hash(tenantId) mod 2, the hottest tenant split by filter: its route keys by hash(route key) mod 2), ONE publish batch
+    for all tenants lies in HBM, each "rank" picks its part with bmq_partition_batch_dev (kernels of the library), matches it, and the
+    per-topic fan-outs add up.  The sum must equal the fan-out of an unsharded engine -- and the oracle's."""
+    import torch
+
+    from bifromq_amd import shard
+
+    W = 2
+    w = B.Workload(0xB1F20077, 24, 800, 1)
+    keys, tn = w.keys(), w.tenants()
+    n = 30000
+    data, off, tt = w.topics(5, n)
+    share = np.bincount(tt, minlength=len(tn)) / float(n)
+    hot = [int(np.argmax(share))]
+    owner = shard.topic_targets(tn, hot, W)
+    assert (owner < 0).sum() == 1 and set(owner[owner >= 0].tolist()) == {0, 1}
+    tidx = {t: i for i, t in enumerate(tn)}
+    key_tenant = [tidx[B.decode_route_key(k)[1]] for k in keys]
+    dev = torch.device("cuda", 0)
+    d_data = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+    d_data[:len(data)] = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
+    d_tt = torch.from_numpy(tt.astype(np.int32)).to(dev)
+    d_owner = torch.from_numpy(owner).to(dev)
+    tdata, toff = w.tenants_packed()
+    d_tenants = torch.from_numpy(tdata.copy()).to(dev)
+    d_tenant_off = torch.from_numpy(toff.astype(np.int32)).to(dev)
+    total = torch.zeros(n, dtype=torch.int64, device=dev)
+    parts = []
+    for rank in range(W):
+        eng = B.Engine(device=0).rebuild(sorted(shard.shard_keys(keys, key_tenant, tn, hot, W, rank)))
+        part = shard.DevicePartition(eng, d_owner, n, len(data), dev)
+        sel, pd, po, ptt, m = part(d_tt, d_data, d_off, rank)
+        parts.append(sel.cpu().numpy().copy())
+        d_row = torch.zeros(m + 1, dtype=torch.int32, device=dev)
+        d_ids = torch.zeros(64 * n, dtype=torch.int32, device=dev)
+        d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        eng.match_batch_device(d_tenants.data_ptr(), d_tenant_off.data_ptr(), len(tn), ptt.data_ptr(), pd.data_ptr(), po.data_ptr(), m, d_row.data_ptr(),
+                               d_ids.data_ptr(), d_ids.numel(), d_total.data_ptr())
+        eng.finish()
+        counts = (d_row[1:] - d_row[:-1]).to(torch.int64)
+        total.index_add_(0, sel.long(), counts)
+        # the part is exactly the topics of the rank's tenants and of the split tenant, in batch order, bytes intact
+        want_sel = np.nonzero((owner[tt] == rank) | (owner[tt] < 0))[0]
+        assert np.array_equal(parts[-1], want_sel)
+        po_h, pd_h = po.cpu().numpy(), pd.cpu().numpy()
+        raw = data.tobytes()
+        for j in (0, 1, m // 2, m - 1):
+            g = int(want_sel[j])
+            assert pd_h[po_h[j]:po_h[j + 1]].tobytes() == raw[off[g]:off[g + 1]]
+        assert np.array_equal(ptt.cpu().numpy(), tt[want_sel].astype(np.int32))
+        eng.close()
+    assert len(np.intersect1d(parts[0], parts[1])) == int((owner[tt] < 0).sum())  # only the split tenant's publishes go to both
+    whole = B.Engine(device=0).rebuild(keys)
+    row, ids = whole.match_batch(tn, tt, packed_topics=(data, off))
+    assert np.array_equal(total.cpu().numpy(), np.diff(row.astype(np.int64)))
+    kv = O.KV(keys)
+    topics = unpack(data, off)
+    for i in range(0, n, 997):
+        assert int(total[i]) == len(kv.match_bruteforce(tn[int(tt[i])], [topics[i]]).per_topic()[0])
+    whole.close()

@@ -4,7 +4,7 @@ out=gpurun_out/ab_walk.txt
 : > $out
 run() { # name, env...
   name=$1; shift
-  r=$(env "$@" python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path 2>gpurun_out/ab_$name.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['kernel_ms'], 'step', round(d['ms_per_step'],4), 'novt', round(d['ms_per_step_without_kernel_timing'],4), 'fanout', (d.get('fanout_group') or {}).get('ms'))")
+  r=$(env "$@" python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-extras 2>gpurun_out/ab_$name.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['kernel_ms'], 'step', round(d['ms_per_step'],4), 'novt', round(d['ms_per_step_without_kernel_timing'],4), 'fanout', (d.get('fanout_group') or {}).get('ms'))")
   echo "$name: $r" >> $out
   grep "k_walk" gpurun_out/ab_$name.err | tail -2 >> $out
 }
