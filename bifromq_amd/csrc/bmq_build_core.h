@@ -127,7 +127,12 @@ struct DistIndexMut {
     uint32_t id_cap;
     const uint8_t* kpool;     // key bytes; readable 16 bytes past the end
     BuildCounters* bc;
+    // the fan-out grouping's per-id cache (bmq_fanout_core.h: dgroup[id] = group slot of the route), or null: a deleted route is
+    // marked there by the very lane that deletes it, so the grouping learns about it with the one gather it does anyway
+    uint32_t* fo_dgroup;
+    uint32_t fo_cap;
 };
+constexpr uint32_t FO_DEAD_ID = 0xFFFFFFFEu; // fo_dgroup[id]: the route has been deleted (ids are not reused before the next rebuild)
 constexpr unsigned KREF_LEN_SHIFT = 40;
 constexpr unsigned long long KREF_OFF_MASK = (1ull << KREF_LEN_SHIFT) - 1;
 
@@ -755,7 +760,10 @@ BMQ_HD void group_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t p) {
     if (blk != 0 && !s.indirect()) garbage += (unsigned long long)blk_cap + 1;
     for (uint32_t q = p; q < e; q++) {
         const uint32_t dead = ob.nn[ob.order[q]];
-        if (dead != NONE && dead < ix.id_cap) ix.kref[dead] = 0;
+        if (dead != NONE && dead < ix.id_cap) {
+            ix.kref[dead] = 0;
+            if (ix.fo_dgroup && dead < ix.fo_cap) ix.fo_dgroup[dead] = FO_DEAD_ID;
+        }
     }
     *pb = s.begin;
     *pc = s.cf;

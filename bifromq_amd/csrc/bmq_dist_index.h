@@ -93,6 +93,8 @@ public:
     uint64_t kpool_cap = 0, kpool_used = 0;
     BuildCounters* bc = nullptr;
     BuildCounters hbc{}; // last read-back
+    uint32_t* fo_dgroup = nullptr; // registered by the fan-out grouping (bmq_fanout.h): deletes mark their ids dead in its per-id cache
+    uint32_t fo_cap = 0;
 
     // ---- host bookkeeping ----
     std::unordered_map<std::string, uint32_t> tenant_slot; // tenant id -> directory slot
@@ -128,6 +130,8 @@ public:
         m.id_cap = id_cap;
         m.kpool = kpool;
         m.bc = bc;
+        m.fo_dgroup = fo_dgroup;
+        m.fo_cap = fo_cap;
         return m;
     }
 

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "bmq_build_core.h"
@@ -309,15 +311,32 @@ struct DevExec {
     }
     bool fo_fast(const DistIndexMut& ix, const FanoutState& st, const FanoutFast& f) {
         const dim3 grid((f.n_tiles + FO_WAVES - 1) / FO_WAVES), block(FO_WAVES * 64);
+        static const bool timing = getenv("BMQ_TIMING") != nullptr; // profiling experiments only: per-kernel HIP-event times on stderr
+        hipEvent_t ev[5] = {};
+        if (timing)
+            for (auto& e : ev) (void)hipEventCreate(&e);
+        if (timing) (void)hipEventRecord(ev[0], stream);
         hipLaunchKernelGGL(k_fo_hist, grid, block, 0, stream, ix, st, f);
         if (!launched()) return false;
+        if (timing) (void)hipEventRecord(ev[1], stream);
         const int n = (int)((size_t)f.n_bins * f.n_tiles);
         size_t bytes = 0;
         if (!BMQ_X(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, f.hist, f.hist, n, stream))) return false;
         if (!ensure_tmp(bytes)) return false;
         if (!BMQ_X(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, f.hist, f.hist, n, stream))) return false;
+        if (timing) (void)hipEventRecord(ev[2], stream);
         hipLaunchKernelGGL(k_fo_scatter, grid, block, 0, stream, f);
+        if (timing) (void)hipEventRecord(ev[3], stream);
         hipLaunchKernelGGL(k_fo_groups2, dim3(1), dim3(1024), 0, stream, st, f);
+        if (timing) {
+            (void)hipEventRecord(ev[4], stream);
+            (void)hipEventSynchronize(ev[4]);
+            float t[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
+            fprintf(stderr, "[bmq] fan-out grouping (%u pairs, %u keys, %u tiles): hist %.3f ms, scan %.3f, scatter %.3f, groups %.3f\n", f.total, f.n_bins,
+                    f.n_tiles, t[0], t[1], t[2], t[3]);
+            for (auto& e : ev) (void)hipEventDestroy(e);
+        }
         return launched();
     }
     // ---- retain direction (bmq_retain_core.h) ----

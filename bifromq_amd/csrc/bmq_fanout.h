@@ -103,6 +103,8 @@ public:
         rel(f_dense);
         rel(f_ctr);
         f_key_cap = f_hist_cap = f_dense_cap = 0;
+        ix.fo_dgroup = nullptr;
+        ix.fo_cap = 0;
         rel(st.dgroup);
         rel(st.gt_hash);
         rel(st.gt_rep);
@@ -260,9 +262,14 @@ private:
         if (!x.sync()) return xfail();
         const uint32_t cap = ix.id_cap ? ix.id_cap : 1;
         if (!st.dgroup || st.id_cap < cap) {
+            ix.fo_dgroup = nullptr;
             if (!fresh(st.dgroup, cap)) return false;
             st.id_cap = cap;
         }
+        // from here on the index builder marks the ids it deletes in dgroup[] itself (DistIndexMut::fo_dgroup): ids it deleted before
+        // are found by pass 1 (their key reference is 0)
+        ix.fo_dgroup = st.dgroup;
+        ix.fo_cap = st.id_cap;
         generation = ix.generation;
         // a grown id space keeps the table (hash -> slot stays valid); the per-id cache simply refills
         if (regen || !st.gt_hash) return reset_table(st.gt_hash && !regen ? st.gt_cap : initial_table);

@@ -28,7 +28,7 @@ template <class T> BMQ_HD void fo_store(T* p, T v) { shared_store(p, v); }
 template <class T> BMQ_HD void fo_store(T* p, T v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 #endif
 
-constexpr uint32_t FO_UNSET = 0xFFFFFFFFu; // dgroup[id]: not computed yet
+constexpr uint32_t FO_UNSET = 0xFFFFFFFFu; // dgroup[id]: not computed yet (FO_DEAD_ID, bmq_build_core.h: the route has been deleted)
 constexpr uint32_t FO_NEW = 0x80000000u;   // dgroup[id] flag: mapped in this pass, bytes not verified against the slot's first route yet
 enum : uint32_t { FO_ERR_FULL = 1u, FO_ERR_COLLISION = 2u, FO_ERR_CSR = 4u };
 
@@ -53,6 +53,26 @@ struct FanoutBatch {
     uint32_t *out_topic, *out_route; // [total] the pairs, ordered by (group, topic, route id)
     uint32_t *group_off, *group_rep; // [group_cap (+1)]
     uint32_t group_cap;
+};
+
+// ---- the fast path (gfx950 kernels: bmq_fanout_kernels.h; the host executor has none and takes the generic passes) ----
+constexpr uint32_t FO_TILE = 4096;     // pairs per wave
+constexpr uint32_t FO_WAVES = 4;       // waves per workgroup (independent: each owns its LDS slice)
+constexpr uint32_t FO_MAX_BINS = 1026; // dense groups + the two special ones must fit the per-wave LDS counters
+
+struct FanoutFast {
+    const uint32_t* row_ptr;
+    const uint32_t* ids;
+    uint32_t n_topics, total, id_end;
+    uint32_t n_tiles, n_bins; // n_bins = used group slots + 2; key n_bins - 2 = shared subscriptions, n_bins - 1 = dead ids
+    uint32_t key_bits;        // bits needed for keys < n_bins
+    const uint16_t* dense;    // [gt_cap] group-table slot -> dense group number
+    uint16_t* key16;          // [total]
+    uint32_t* hist;           // [n_bins * n_tiles] counts, then (after the scan) start offsets
+    uint32_t *out_topic, *out_route;
+    uint32_t *group_off, *group_rep;
+    uint32_t group_cap;
+    uint32_t* need_fill;      // [1] pairs whose route id has no group slot yet
 };
 
 // (subBrokerId, delivererKey) of the route key at kp[off, off+len): byte spans of receiverUrl part 0 and part 2.  false = a route of a
@@ -96,7 +116,10 @@ BMQ_HD void fo_fill_one(const DistIndexMut& ix, const FanoutState& st, const Fan
     if (id >= b.id_end || id >= st.id_cap) return; // counted as dead in pass 3
     if (atom_load(st.dgroup + id) != FO_UNSET) return;
     const unsigned long long r = ix.kref[id];
-    if (r == 0) return; // deleted meanwhile: not cached (the id is never handed out again before the next rebuild, but stays dead)
+    if (r == 0) { // deleted before it was ever mapped: remembered as dead
+        fo_store(st.dgroup + id, FO_DEAD_ID);
+        return;
+    }
     DelivererSpan s;
     if (!fo_deliverer_span(ix.kpool, r & KREF_OFF_MASK, r >> KREF_LEN_SHIFT, s)) {
         fo_store(st.dgroup + id, st.gt_cap); // shared subscription
@@ -127,7 +150,7 @@ BMQ_HD void fo_verify_one(const DistIndexMut& ix, const FanoutState& st, const F
     const uint32_t id = b.ids[i];
     if (id >= b.id_end || id >= st.id_cap) return;
     const uint32_t g = atom_load(st.dgroup + id);
-    if (g == FO_UNSET || !(g & FO_NEW)) return;
+    if (g == FO_UNSET || g == FO_DEAD_ID || !(g & FO_NEW)) return;
     const uint32_t slot = g & ~FO_NEW;
     const uint32_t rep = st.gt_rep[slot];
     const unsigned long long r = ix.kref[id], rr = rep < st.id_cap ? ix.kref[rep] : 0ull;
@@ -143,8 +166,8 @@ BMQ_HD void fo_verify_one(const DistIndexMut& ix, const FanoutState& st, const F
 // (a route deleted since the match is dead whatever the cache remembers of it)
 BMQ_HD void fo_key_one(const DistIndexMut& ix, const FanoutState& st, const FanoutBatch& b, uint32_t i) {
     const uint32_t id = b.ids[i];
-    uint32_t g = id < b.id_end && id < st.id_cap && ix.kref[id] != 0 ? st.dgroup[id] : FO_UNSET;
-    if (g == FO_UNSET) g = st.gt_cap + 1;
+    uint32_t g = id < b.id_end && id < st.id_cap ? st.dgroup[id] : FO_UNSET; // (a deleted route: FO_DEAD_ID, from the builder or pass 1)
+    if (g == FO_UNSET || g == FO_DEAD_ID) g = st.gt_cap + 1;
     b.key[i] = g & ~FO_NEW;
     b.pos[i] = i;
 }

@@ -25,25 +25,6 @@
 
 namespace bmq {
 
-constexpr uint32_t FO_TILE = 4096;     // pairs per wave
-constexpr uint32_t FO_WAVES = 4;       // waves per workgroup (independent: each owns its LDS slice)
-constexpr uint32_t FO_MAX_BINS = 1026; // dense groups + the two special ones must fit the per-wave LDS counters
-
-struct FanoutFast {
-    const uint32_t* row_ptr;
-    const uint32_t* ids;
-    uint32_t n_topics, total, id_end;
-    uint32_t n_tiles, n_bins; // n_bins = used group slots + 2; key n_bins - 2 = shared subscriptions, n_bins - 1 = dead ids
-    uint32_t key_bits;        // bits needed for keys < n_bins
-    const uint16_t* dense;    // [gt_cap] group-table slot -> dense group number
-    uint16_t* key16;          // [total]
-    uint32_t* hist;           // [n_bins * n_tiles] counts, then (after the scan) start offsets
-    uint32_t *out_topic, *out_route;
-    uint32_t *group_off, *group_rep;
-    uint32_t group_cap;
-    uint32_t* need_fill;      // [1] pairs whose route id has no group slot yet
-};
-
 // dense[s] = number of used slots in front of slot s (one workgroup; the table has at most 2^29 slots but in practice a few thousand)
 __global__ __launch_bounds__(1024) void k_fo_dense(const unsigned long long* gt_hash, uint32_t gt_cap, uint16_t* dense, uint32_t* n_used) {
     __shared__ uint32_t part[1024];
@@ -80,9 +61,11 @@ __global__ __launch_bounds__(FO_WAVES * 64) void k_fo_hist(DistIndexMut ix, Fano
     for (uint32_t p = p0 + lane; p < p1; p += 64) {
         const uint32_t id = f.ids[p];
         uint32_t key = f.n_bins - 1; // dead: never handed out, or deleted since the match
-        if (id < f.id_end && id < st.id_cap && ix.kref[id] != 0) {
+        if (id < f.id_end && id < st.id_cap) {
+            // one gather per pair: a deleted route carries FO_DEAD_ID here (written by the lane that deleted it, bmq_build_core.h group_one)
             const uint32_t g = st.dgroup[id];
-            if (g == FO_UNSET || (g & FO_NEW)) unset++;
+            if (g == FO_DEAD_ID) {
+            } else if (g == FO_UNSET || (g & FO_NEW)) unset++;
             else key = g == st.gt_cap ? f.n_bins - 2 : (uint32_t)f.dense[g];
         }
         f.key16[p] = (uint16_t)key;
