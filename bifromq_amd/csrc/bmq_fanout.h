@@ -134,6 +134,14 @@ private:
     uint32_t n_used = 0;
     bool dense_stale = true;
 
+    static uint32_t fast_tile() { // BMQ_FO_TILE: experiments only
+        static const uint32_t t = [] {
+            const char* v = getenv("BMQ_FO_TILE");
+            const long n = v ? atol(v) : 0;
+            return n >= 64 && n <= (1 << 20) ? (uint32_t)(n / 64 * 64) : FO_TILE;
+        }();
+        return t;
+    }
     // 1: done, 0: failed (error set), -1: not applicable
     int group_fast(const uint32_t* row_ptr, const uint32_t* ids, uint32_t n_topics, uint32_t total, uint32_t* out_topic, uint32_t* out_route,
                    uint32_t* group_off, uint32_t* group_rep, uint32_t group_cap, FanoutResult& res) {
@@ -161,7 +169,8 @@ private:
                 f.n_topics = n_topics;
                 f.total = total;
                 f.id_end = ix.next_id;
-                f.n_tiles = (total + FO_TILE - 1) / FO_TILE;
+                f.tile = fast_tile();
+                f.n_tiles = (total + f.tile - 1) / f.tile;
                 f.n_bins = n_used + 2;
                 f.key_bits = 1;
                 while ((1u << f.key_bits) < f.n_bins) f.key_bits++;

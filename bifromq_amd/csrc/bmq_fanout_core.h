@@ -64,6 +64,7 @@ struct FanoutFast {
     const uint32_t* row_ptr;
     const uint32_t* ids;
     uint32_t n_topics, total, id_end;
+    uint32_t tile;            // pairs per wave (FO_TILE; a multiple of 64)
     uint32_t n_tiles, n_bins; // n_bins = used group slots + 2; key n_bins - 2 = shared subscriptions, n_bins - 1 = dead ids
     uint32_t key_bits;        // bits needed for keys < n_bins
     const uint16_t* dense;    // [gt_cap] group-table slot -> dense group number

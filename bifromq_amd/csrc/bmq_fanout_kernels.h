@@ -56,7 +56,7 @@ __global__ __launch_bounds__(FO_WAVES * 64) void k_fo_hist(DistIndexMut ix, Fano
     uint32_t* cnt = cnt_all[wave];
     for (uint32_t b = lane; b < f.n_bins; b += 64) cnt[b] = 0;
     wave_sync();
-    const uint32_t p0 = tile * FO_TILE, p1 = min(f.total, p0 + FO_TILE);
+    const uint32_t p0 = tile * f.tile, p1 = min(f.total, p0 + f.tile);
     uint32_t unset = 0;
     for (uint32_t p = p0 + lane; p < p1; p += 64) {
         const uint32_t id = f.ids[p];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(FO_WAVES * 64) void k_fo_scatter(FanoutFast f) {
     if (tile >= f.n_tiles) return;
     uint32_t* off = off_all[wave];
     for (uint32_t b = lane; b < f.n_bins; b += 64) off[b] = f.hist[(size_t)b * f.n_tiles + tile];
-    const uint32_t p0 = tile * FO_TILE, p1 = min(f.total, p0 + FO_TILE);
+    const uint32_t p0 = tile * f.tile, p1 = min(f.total, p0 + f.tile);
     uint32_t r; // the row of the tile's first pair: the last r with row_ptr[r] <= p0 (rows may be empty)
     {
         uint32_t lo = 0, hi = f.n_topics;
@@ -101,19 +101,32 @@ __global__ __launch_bounds__(FO_WAVES * 64) void k_fo_scatter(FanoutFast f) {
     }
     wave_sync();
     const unsigned long long below = (1ull << lane) - 1ull;
+    // The window of row ends: e = row_ptr[wbase + 1 + lane] = end of row wbase + lane, kept in registers ACROSS segments -- a segment of
+    // 64 pairs spans only a few rows, so the window moves on (one dependent load) every few segments, not in every one; row_ptr[wbase] <= p
+    // holds for every pair still to come.
+    uint32_t wbase = r;
+    auto load_window = [&](uint32_t base) {
+        const uint32_t idx = base + 1 + lane;
+        return idx <= f.n_topics ? f.row_ptr[idx] : 0xFFFFFFFFu; // (behind the last row: never reached)
+    };
+    uint32_t e = load_window(wbase);
+    uint32_t id_next = p0 + lane < p1 ? f.ids[p0 + lane] : 0u;
+    uint32_t key_next = p0 + lane < p1 ? (uint32_t)f.key16[p0 + lane] : 0u;
     for (uint32_t s = p0; s < p1; s += 64) {
         const uint32_t p = s + lane;
         const bool in = p < p1;
-        const uint32_t id = in ? f.ids[p] : 0u;
-        const uint32_t key = in ? (uint32_t)f.key16[p] : 0u;
-        // ---- topic of every pair: rows base, base + 1, ... end at row_ptr[base + 1], row_ptr[base + 2], ...: a window of 64 row ends,
-        // searched by shuffle; a lane whose pair lies behind the whole window makes the wave move the window on
-        uint32_t topic = r;
+        const uint32_t id = id_next, key = key_next;
+        {   // the next segment's pair is on its way while this one is ranked
+            const uint32_t pn = p + 64;
+            id_next = pn < p1 ? f.ids[pn] : 0u;
+            key_next = pn < p1 ? (uint32_t)f.key16[pn] : 0u;
+        }
+        // ---- topic of every pair: the first row of the window that ends behind the pair (6-step search by shuffle); a lane whose pair
+        // lies behind the whole window makes the wave move the window on
+        uint32_t topic = wbase;
         bool placed = !in;
-        for (uint32_t base = r; !__all(placed); base += 64) {
-            const uint32_t idx = base + 1 + lane;
-            const uint32_t e = idx <= f.n_topics ? f.row_ptr[idx] : 0xFFFFFFFFu; // end of row base + lane (behind the last row: never reached)
-            uint32_t lo = 0, hi = 63;                                            // first j with e_j > p, if e_63 > p
+        for (;;) {
+            uint32_t lo = 0, hi = 63; // first j with e_j > p, if e_63 > p
 #pragma unroll
             for (int step = 0; step < 6; step++) {
                 const uint32_t mid = (lo + hi) >> 1;
@@ -123,11 +136,13 @@ __global__ __launch_bounds__(FO_WAVES * 64) void k_fo_scatter(FanoutFast f) {
             }
             const uint32_t e_last = __shfl(e, 63);
             if (!placed && e_last > p) {
-                topic = base + min(lo, 63u);
+                topic = wbase + min(lo, 63u);
                 placed = true;
             }
+            if (__all(placed)) break;
+            wbase += 64; // the pairs not placed yet start at or behind row_ptr[wbase + 64]
+            e = load_window(wbase);
         }
-        r = __shfl(topic, (int)(min(p1 - s, 64u) - 1u)); // the next segment starts in (or behind) the row of this segment's last pair
         // ---- stable rank among the segment's pairs of the same key: `same` = lanes whose key equals mine
         const unsigned long long m_in = __ballot(in);
         unsigned long long same = m_in;
