@@ -319,13 +319,14 @@ struct DevExec {
         hipLaunchKernelGGL(k_fo_hist, grid, block, 0, stream, ix, st, f);
         if (!launched()) return false;
         if (timing) (void)hipEventRecord(ev[1], stream);
-        const int n = (int)((size_t)f.n_bins * f.n_tiles);
+        const int n = (int)((size_t)f.n_bins * f.n_tiles) + 1; // + the end mark
         size_t bytes = 0;
         if (!BMQ_X(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, f.hist, f.hist, n, stream))) return false;
         if (!ensure_tmp(bytes)) return false;
         if (!BMQ_X(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, f.hist, f.hist, n, stream))) return false;
         if (timing) (void)hipEventRecord(ev[2], stream);
-        hipLaunchKernelGGL(k_fo_scatter, grid, block, 0, stream, f);
+        hipLaunchKernelGGL(k_fo_scatter, dim3((f.n_tiles + FO_SC_WAVES - 1) / FO_SC_WAVES), dim3(FO_SC_WAVES * 64), FO_SC_WAVES * fo_scatter_lds(f.n_bins, f.tile),
+                           stream, f);
         if (timing) (void)hipEventRecord(ev[3], stream);
         hipLaunchKernelGGL(k_fo_groups2, dim3(1), dim3(1024), 0, stream, st, f);
         if (timing) {

@@ -138,7 +138,7 @@ private:
         static const uint32_t t = [] {
             const char* v = getenv("BMQ_FO_TILE");
             const long n = v ? atol(v) : 0;
-            return n >= 64 && n <= (1 << 20) ? (uint32_t)(n / 64 * 64) : FO_TILE;
+            return n >= 64 && n <= 2048 ? (uint32_t)(n / 64 * 64) : FO_TILE;
         }();
         return t;
     }

@@ -56,7 +56,8 @@ struct FanoutBatch {
 };
 
 // ---- the fast path (gfx950 kernels: bmq_fanout_kernels.h; the host executor has none and takes the generic passes) ----
-constexpr uint32_t FO_TILE = 4096;     // pairs per wave
+constexpr uint32_t FO_TILE = 1024;     // pairs per wave (k_fo_scatter holds a tile in LDS: 10 bytes per pair)
+constexpr uint32_t FO_SC_WAVES = 2;    // waves per workgroup of k_fo_scatter (LDS: 2 x (10 KB + 8 bytes per key) <= 64 KB)
 constexpr uint32_t FO_WAVES = 4;       // waves per workgroup (independent: each owns its LDS slice)
 constexpr uint32_t FO_MAX_BINS = 1026; // dense groups + the two special ones must fit the per-wave LDS counters
 

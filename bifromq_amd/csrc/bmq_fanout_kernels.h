@@ -73,6 +73,7 @@ __global__ __launch_bounds__(FO_WAVES * 64) void k_fo_hist(DistIndexMut ix, Fano
     }
     wave_sync();
     for (uint32_t b = lane; b < f.n_bins; b += 64) f.hist[(size_t)b * f.n_tiles + tile] = cnt[b];
+    if (tile == 0 && lane == 0) f.hist[(size_t)f.n_bins * f.n_tiles] = 0; // scanned along: becomes the total, the end of the last run
     if (__any(unset != 0)) {
         uint32_t s = unset;
 #pragma unroll
@@ -81,14 +82,46 @@ __global__ __launch_bounds__(FO_WAVES * 64) void k_fo_hist(DistIndexMut ix, Fano
     }
 }
 
-__global__ __launch_bounds__(FO_WAVES * 64) void k_fo_scatter(FanoutFast f) {
-    __shared__ uint32_t off_all[FO_WAVES][FO_MAX_BINS];
+// LDS of one wave of k_fo_scatter: delta[nb] | loff[nb] | topic[tile] | route[tile] | key[tile] (16 bits)
+__host__ __device__ inline uint32_t fo_scatter_bins(uint32_t n_bins) { return (n_bins + 63u) & ~63u; }
+__host__ __device__ inline uint32_t fo_scatter_lds(uint32_t n_bins, uint32_t tile) { return fo_scatter_bins(n_bins) * 8u + tile * 10u; }
+
+__global__ __launch_bounds__(FO_SC_WAVES * 64) void k_fo_scatter(FanoutFast f) {
+    extern __shared__ __align__(16) unsigned char fo_lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t tile = blockIdx.x * FO_WAVES + wave;
+    const uint32_t tile = blockIdx.x * FO_SC_WAVES + wave;
     if (tile >= f.n_tiles) return;
-    uint32_t* off = off_all[wave];
-    for (uint32_t b = lane; b < f.n_bins; b += 64) off[b] = f.hist[(size_t)b * f.n_tiles + tile];
+    const uint32_t nb = fo_scatter_bins(f.n_bins);
+    uint32_t* delta = reinterpret_cast<uint32_t*>(fo_lds + (size_t)wave * fo_scatter_lds(f.n_bins, f.tile));
+    uint32_t* loff = delta + nb;
+    uint32_t* s_topic = loff + nb;
+    uint32_t* s_route = s_topic + f.tile;
+    uint16_t* s_key = reinterpret_cast<uint16_t*>(s_route + f.tile);
     const uint32_t p0 = tile * f.tile, p1 = min(f.total, p0 + f.tile);
+    // ---- where the tile's run of every key starts: in the output (scanned histogram; the next entry of the flat array is the end of
+    // the run, hist[n_bins * n_tiles] = total) and inside the tile (prefix sum of the run lengths over the keys)
+    {
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            uint32_t g = 0, c = 0;
+            if (b < f.n_bins) {
+                const size_t at = (size_t)b * f.n_tiles + tile;
+                g = f.hist[at];
+                c = f.hist[at + 1] - g;
+            }
+            uint32_t inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(inc, d);
+                if ((int)lane >= d) inc += v;
+            }
+            const uint32_t l = carry + inc - c;
+            loff[b] = l;
+            delta[b] = g - l;
+            carry += __shfl(inc, 63);
+        }
+    }
     uint32_t r; // the row of the tile's first pair: the last r with row_ptr[r] <= p0 (rows may be empty)
     {
         uint32_t lo = 0, hi = f.n_topics;
@@ -154,16 +187,25 @@ __global__ __launch_bounds__(FO_WAVES * 64) void k_fo_scatter(FanoutFast f) {
         const int leader = __ffsll((long long)same) - 1;
         uint32_t base_off = 0;
         if (in && (int)lane == leader) { // one lane per distinct key: no two leaders share a counter
-            base_off = off[key];
-            off[key] = base_off + cnt;
+            base_off = loff[key];
+            loff[key] = base_off + cnt;
         }
         base_off = __shfl(base_off, in ? leader : 0);
-        if (in) {
-            const uint32_t dst = base_off + rank;
-            f.out_topic[dst] = topic;
-            f.out_route[dst] = id;
+        if (in) { // into the tile's LDS copy, sorted by key: the runs leave for HBM in whole pieces below
+            const uint32_t at = base_off + rank;
+            s_topic[at] = topic;
+            s_route[at] = id;
+            s_key[at] = (uint16_t)key;
         }
         wave_sync();
+    }
+    // ---- the tile, now ordered by (key, topic, route): position j of the tile goes to delta[key] + j -- neighbouring lanes write
+    // neighbouring words of a run (the scattered 4-byte stores of a direct scatter cost 3x the time: partial lines thrash L2)
+    const uint32_t n = p1 - p0;
+    for (uint32_t j = lane; j < n; j += 64) {
+        const uint32_t dst = delta[s_key[j]] + j;
+        f.out_topic[dst] = s_topic[j];
+        f.out_route[dst] = s_route[j];
     }
 }
 
