@@ -684,7 +684,7 @@ def host_visible(args, eng, w, batches, n, seed, rank, cap):
     """SURVEY 8d's latency definition: host enqueue -> results visible on host.  Inputs and outputs live in page-locked host
     memory (bmq_host_alloc: what a JNI binding hands over as direct buffers).
       * p99 / p50 latency of ONE blocking bmq_match_batch call (upload + kernels + download, nothing overlapped);
-      * throughput with two batches in flight (bmq_match_submit / bmq_match_wait): the upload of batch i+1 and the download of
+      * throughput with three batches in flight (bmq_match_submit / bmq_match_wait): the upload of batch i+1 and the download of
         batch i-1 overlap the kernels of batch i."""
     import numpy as np
 
@@ -703,8 +703,9 @@ def host_visible(args, eng, w, batches, n, seed, rank, cap):
         pd, po, pt = pinned(len(data), np.uint8), pinned(len(off), np.uint32), pinned(len(tt), np.uint32)
         pd[:], po[:], pt[:] = data, off, tt
         hb.append((pd, po, pt))
-    rows = [pinned(n + 1, np.uint32) for _ in range(2)]
-    ids = [pinned(cap, np.uint32) for _ in range(2)]
+    D = 3  # BMQ_MAX_TICKETS: one batch on its way up, one on the GPU, one on its way down
+    rows = [pinned(n + 1, np.uint32) for _ in range(D)]
+    ids = [pinned(cap, np.uint32) for _ in range(D)]
     L = B._lib.lib()
     need = C.c_uint64()
     lat = []
@@ -720,23 +721,84 @@ def host_visible(args, eng, w, batches, n, seed, rank, cap):
     total_ids = need.value
     # pipelined
     K = args.steps
-    tickets = [None, None]
+    tickets = [None] * D
+
+    def pipelined(k):
+        for i in range(k + D - 1):
+            if i < k:
+                pd, po, pt = hb[i % 2]
+                tickets[i % D] = eng.match_submit(p_t, p_to, w.n_tenants, pt, pd, po, n)
+            if i >= D - 1:
+                j = (i - (D - 1)) % D
+                got = eng.match_wait(tickets[j], rows[j], ids[j])
+                assert got == total_ids or len(hb) > 1
+
+    pipelined(D)  # untimed: every ticket's slot allocates its buffers on first use
     t0 = time.perf_counter()
-    for i in range(K + 1):
-        if i < K:
-            pd, po, pt = hb[i % 2]
-            tickets[i % 2] = eng.match_submit(p_t, p_to, w.n_tenants, pt, pd, po, n)
-        if i >= 1:
-            j = (i - 1) % 2
-            got = eng.match_wait(tickets[j], rows[j], ids[j])
-            assert got == total_ids or len(hb) > 1
+    pipelined(K)
     sec = time.perf_counter() - t0
     in_bytes = sum(int(x.nbytes) for x in hb[0])
+    # ---- the formats that fit the wire (include/bmq.h BMQ_FMT_*): the same two measurements per format
+    formats = {}
+    try:
+        rptr = [pinned(n + 1, np.uint32) for _ in range(D)]
+        ranges = [pinned((max(total_ids // 2, 1024), 2), np.uint32) for _ in range(D)]
+        side = [pinned(1 << 20, np.uint32) for _ in range(D)]
+        goff, grep_ = pinned(4097, np.uint32), pinned(4096, np.uint32)
+        state = {}
+
+        def wait(fmt, ticket, j):
+            if fmt == eng.FMT_COUNTS:
+                eng.match_wait_counts(ticket, rows[j])
+                return 4 * (n + 1)
+            if fmt == eng.FMT_RANGES:
+                info = eng.match_wait_ranges(ticket, rptr[j], ranges[j], side[j], rows[j])
+                state["ranges"] = int(info.n_ranges)
+                return 8 * (n + 1) + 8 * int(info.n_ranges) + 4 * int(info.n_side_ids)
+            tot, ng, _ = eng.match_wait_grouped(ticket, ids[0], ids[1], goff, grep_)  # (one pair of big buffers: no second batch in flight)
+            return 8 * int(tot) + 8 * int(ng)
+
+        for name, fmt in (("counts", eng.FMT_COUNTS), ("ranges", eng.FMT_RANGES), ("grouped", eng.FMT_GROUPED)):
+            lat_f, out_bytes = [], 0
+            for i in range(args.steps + 2):
+                pd, po, pt = hb[i % 2]
+                t1 = time.perf_counter()
+                out_bytes = wait(fmt, eng.match_submit_fmt(p_t, p_to, w.n_tenants, pt, pd, po, n, fmt), 0)
+                if i >= 2:
+                    lat_f.append((time.perf_counter() - t1) * 1e3)
+            depth = 1 if fmt == eng.FMT_GROUPED else D
+            tk = [None] * D
+
+            def run(k):
+                for i in range(k + depth - 1):
+                    if i < k:
+                        pd, po, pt = hb[i % 2]
+                        if depth == 1:
+                            wait(fmt, eng.match_submit_fmt(p_t, p_to, w.n_tenants, pt, pd, po, n, fmt), 0)
+                            continue
+                        tk[i % D] = eng.match_submit_fmt(p_t, p_to, w.n_tenants, pt, pd, po, n, fmt)
+                    if i >= depth - 1:
+                        wait(fmt, tk[(i - (depth - 1)) % D], (i - (depth - 1)) % D)
+
+            run(D)
+            t1 = time.perf_counter()
+            run(K)
+            sec_f = time.perf_counter() - t1
+            formats[name] = {"value_host_visible": n * K / sec_f, "ms_per_batch_pipelined": sec_f / K * 1e3,
+                             "p50_host_visible_ms": float(np.percentile(lat_f, 50)), "p99_host_visible_ms": float(np.percentile(lat_f, 99)),
+                             "bytes_out_per_batch": int(out_bytes), "in_flight": depth}
+            if name == "ranges":
+                formats[name]["ranges_per_batch"] = state.get("ranges")
+    except Exception as ex:  # never fails the bench line
+        formats["error"] = repr(ex)
     return {"value_host_visible": n * K / sec, "unit": "topics/s", "ms_per_batch_pipelined": sec / K * 1e3,
+            "formats": formats,
             "p50_host_visible_ms": float(np.percentile(lat, 50)), "p99_host_visible_ms": float(np.percentile(lat, 99)),
             "bytes_in_per_batch": in_bytes, "bytes_out_per_batch": int(4 * (n + 1) + 4 * total_ids),
             "note": "host buffers in, CSR out, page-locked memory; latency = one blocking bmq_match_batch (upload + kernels + download); "
-                    "throughput = bmq_match_submit/bmq_match_wait with two batches in flight"}
+                    "throughput = bmq_match_submit/bmq_match_wait with three batches in flight (one caller thread); formats: the same with bmq_match_submit_fmt -- "
+                    "counts = row pointers only (all BatchDistReply carries), ranges = matched (begin, count) id ranges the consumer expands, "
+                    "grouped = (topic, route) pairs by DelivererKey; every rate is bounded by the %.1f MB of topics that go IN over PCIe" % (in_bytes / 1e6)}
 
 
 def fanout_group_leg(eng, d_row, d_ids, n, dev, torch, np, reps=10):

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ABI_SYMBOLS = [
     "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_compact", "bmq_routes_apply",
     "bmq_index_info_get", "bmq_route_key", "bmq_route_keys", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
-    "bmq_match_finish", "bmq_set_kernel_timing", "bmq_match_submit", "bmq_match_wait", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
+    "bmq_match_finish", "bmq_set_kernel_timing", "bmq_match_submit", "bmq_match_wait", "bmq_match_submit_fmt", "bmq_match_wait_counts", "bmq_match_wait_ranges", "bmq_match_wait_grouped", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_range_lookup", "bmq_comm_unique_id", "bmq_comm_init", "bmq_comm_destroy", "bmq_exchange_fanout",
     "bmq_exchange_csr", "bmq_exchange_wait", "bmq_partition_batch_dev", "bmq_retain_message_key", "bmq_retain_filter_route", "bmq_retain_rebuild", "bmq_retain_rebuild_ex", "bmq_retain_apply", "bmq_retain_apply_ex", "bmq_retain_topic",
     "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired", "bmq_retain_apply_batch", "bmq_retain_compact", "bmq_retain_info_get",
@@ -88,6 +88,10 @@ class RetainInfo(C.Structure):
                 ("generation", C.c_uint64)]
 
 
+class RangesInfo(C.Structure):
+    _fields_ = [("n_ranges", C.c_uint64), ("n_side_ids", C.c_uint64), ("n_ids", C.c_uint64), ("n_overlapping_rows", C.c_uint64)]
+
+
 class RouteCacheTenantStats(C.Structure):
     _fields_ = [("hits", C.c_uint64), ("misses", C.c_uint64), ("evictions", C.c_uint64), ("entries", C.c_uint64), ("cached_routes", C.c_uint64),
                 ("last_get_ms", C.c_uint64), ("max_persistent_fanout", C.c_int32), ("max_group_fanout", C.c_int32)]
@@ -124,6 +128,10 @@ def lib() -> C.CDLL:
             "bmq_set_kernel_timing": (C.c_int, [vp, C.c_int]),
             "bmq_match_submit": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, P(C.c_int)]),
             "bmq_match_wait": (C.c_int, [vp, C.c_int, vp, vp, u64, P(u64)]),
+            "bmq_match_submit_fmt": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, C.c_int, P(C.c_int)]),
+            "bmq_match_wait_counts": (C.c_int, [vp, C.c_int, vp, P(u64)]),
+            "bmq_match_wait_ranges": (C.c_int, [vp, C.c_int, vp, vp, vp, u64, vp, u64, P(RangesInfo)]),
+            "bmq_match_wait_grouped": (C.c_int, [vp, C.c_int, vp, vp, u64, vp, vp, u32, P(u32), P(u32), P(u64)]),
             "bmq_host_alloc": (vp, [C.c_size_t]),
             "bmq_host_free": (None, [vp]),
             "bmq_sync": (C.c_int, [vp]),

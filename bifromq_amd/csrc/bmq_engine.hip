@@ -27,6 +27,7 @@
 #include "bmq_exec_dev.h"
 #include "bmq_exec_host.h"
 #include "bmq_fanout.h"
+#include "bmq_format_kernels.h"
 #include "bmq_range_core.h"
 #include "bmq_retain.h"
 #include "bmq_retain_dyn.h"
@@ -130,10 +131,17 @@ struct bmq_engine {
         uint32_t n_rows = 0;
         BatchArgs last{};
         RetainArgs rlast{};
+        // result formats of bmq_match_submit_fmt (bmq_formats.inc)
+        int format = 0;                                 // BMQ_FMT_*
+        DevBuf f_cnt, f_ptr, f_ranges, f_side, f_sums;  // RANGES: counts, their prefix sums, the ranges, the side ids, sizes / flags
+        uint64_t range_cap = 0, side_cap = 0;
+        unsigned long long* h_fsums = nullptr;          // pinned copy of f_sums
+        hipEvent_t ev_fmt = nullptr;                    // the format kernels (and the read-back of their sizes) are complete
+        DevBuf g_pairs, g_groups;                       // GROUPED: out_topic | out_route, group_off | group_rep
     };
-    // slots[0] (== cur, never re-pointed) serves the blocking / *_dev entry points; slots[1], slots[2] are the two tickets of
+    // slots[0] (== cur, never re-pointed) serves the blocking / *_dev entry points; slots[1 ..] are the BMQ_MAX_TICKETS tickets of
     // bmq_match_submit / bmq_match_wait, so that a ticket in flight is never staged over by another thread's blocking call.
-    BatchSlot slots[3];
+    BatchSlot slots[1 + BMQ_MAX_TICKETS];
     BatchSlot* const cur = &slots[0];
     hipStream_t s_in = nullptr, s_out = nullptr; // copy streams of the asynchronous host API
     bmq_stats stats{};
@@ -239,6 +247,47 @@ void reset_slot(bmq_engine* e, bmq_engine::BatchSlot& S, hipStream_t s) {
     S.clean = true;
 }
 
+// RANGES format: k_fmt_count -> two prefix sums -> k_fmt_emit on the engine stream (bmq_format_kernels.h); sizes into S.h_fsums
+int enqueue_ranges(bmq_engine* e, bmq_engine::BatchSlot& S, const BatchArgs& a) {
+    const size_t n1 = (size_t)a.n_topics + 1;
+    HIPCHK(e, S.f_cnt.ensure(sizeof(uint32_t) * 2 * n1));
+    HIPCHK(e, S.f_ptr.ensure(sizeof(uint32_t) * 2 * n1));
+    HIPCHK(e, S.f_sums.ensure(4 * sizeof(unsigned long long)));
+    if (S.range_cap < (uint64_t)a.n_topics * 8 + 1024) S.range_cap = (uint64_t)a.n_topics * 8 + 1024;
+    if (S.side_cap < 65536) S.side_cap = 65536;
+    HIPCHK(e, S.f_ranges.ensure(sizeof(MatchRange) * S.range_cap));
+    HIPCHK(e, S.f_side.ensure(sizeof(uint32_t) * S.side_cap));
+    FmtArgs f{};
+    f.ix = a.ix;
+    f.pair_off = a.pair_off;
+    f.pair_cnt = a.pair_cnt;
+    f.pairs = a.pairs;
+    f.ctr = a.ctr;
+    f.n_topics = a.n_topics;
+    f.cnt_r = S.f_cnt.as<uint32_t>();
+    f.cnt_s = f.cnt_r + n1;
+    f.range_ptr = S.f_ptr.as<uint32_t>();
+    f.side_ptr = f.range_ptr + n1;
+    f.out_ranges = S.f_ranges.as<MatchRange>();
+    f.range_cap = S.range_cap;
+    f.out_side = S.f_side.as<uint32_t>();
+    f.side_cap = S.side_cap;
+    f.sums = S.f_sums.as<unsigned long long>();
+    hipStream_t s = e->stream;
+    const dim3 grid((unsigned)((n1 + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_fmt_count, grid, block, 0, s, f);
+    size_t bytes = 0;
+    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, f.cnt_r, f.range_ptr, (int)n1, s));
+    if (!e->dx.ensure_tmp(bytes)) return set_err(e, BMQ_E_NOMEM, e->dx.err);
+    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(e->dx.tmp, bytes, f.cnt_r, f.range_ptr, (int)n1, s));
+    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(e->dx.tmp, bytes, f.cnt_s, f.side_ptr, (int)n1, s));
+    hipLaunchKernelGGL(k_fmt_emit, grid, block, 0, s, f);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(S.h_fsums, f.sums, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipEventRecord(S.ev_fmt, s));
+    return BMQ_OK;
+}
+
 int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     a.ix = e->dix->view();
     a.tpw_shift = tpw_shift_for(a.n_topics);
@@ -295,6 +344,10 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
     if (e->sort_on) hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
     HIPCHK(e, hipEventRecord(S.ev[5], s));
+    if (S.format == BMQ_FMT_RANGES) { // the compact range lists, while the slot's counters still say whether the batch is complete
+        const int frc = enqueue_ranges(e, S, a);
+        if (frc) return frc;
+    }
     HIPCHK(e, hipMemcpyAsync(S.h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipEventRecord(S.ev_done, s));
     reset_slot(e, S, s); // behind the batch: the counters / allocators are clean again when the next batch arrives
@@ -477,6 +530,9 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
                 return BMQ_E_HIP;
             if (hipHostMalloc((void**)&sl.h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) return BMQ_E_NOMEM;
             memset(sl.h_ctr, 0, sizeof(Counters));
+            if (hipEventCreateWithFlags(&sl.ev_fmt, hipEventDisableTiming) != hipSuccess) return BMQ_E_HIP;
+            if (hipHostMalloc((void**)&sl.h_fsums, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return BMQ_E_NOMEM;
+            memset(sl.h_fsums, 0, 4 * sizeof(unsigned long long));
         }
         e->dx.device = c.device;
         e->dx.stream = e->stream;
@@ -503,6 +559,8 @@ void bmq_engine_destroy(bmq_engine* e) {
             if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
             if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
             if (sl.h_ctr) (void)hipHostFree(sl.h_ctr);
+            if (sl.ev_fmt) (void)hipEventDestroy(sl.ev_fmt);
+            if (sl.h_fsums) (void)hipHostFree(sl.h_fsums);
         }
         if (e->s_in) (void)hipStreamDestroy(e->s_in);
         if (e->s_out) (void)hipStreamDestroy(e->s_out);
@@ -832,19 +890,25 @@ void bmq_host_free(void* p) {
 
 int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
                      const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, int* out_ticket) {
+    return bmq_match_submit_fmt(e, tenants, tenant_off, n_tenants, topic_tenant, topics, topic_off, n_topics, BMQ_FMT_IDS, out_ticket);
+}
+
+int bmq_match_submit_fmt(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                         const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, int format, int* out_ticket) {
     int rc = check_dist_ready(e);
     if (rc) return rc;
+    if (format < BMQ_FMT_IDS || format > BMQ_FMT_GROUPED) return set_err(e, BMQ_E_INVAL, "unknown result format");
     if (!out_ticket || n_topics == 0 || !topics || !topic_off || !topic_tenant || (n_tenants && (!tenants || !tenant_off)))
         return set_err(e, BMQ_E_INVAL, "null pointer or empty batch");
     std::lock_guard<std::mutex> g(e->mu);
     HIPCHK(e, hipSetDevice(e->device));
     int k = -1;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < BMQ_MAX_TICKETS; i++)
         if (!e->slots[1 + i].pending && !e->slots[1 + i].submitted) {
             k = i;
             break;
         }
-    if (k < 0) return set_err(e, BMQ_E_STATE, "two batches are already in flight: call bmq_match_wait first");
+    if (k < 0) return set_err(e, BMQ_E_STATE, "every ticket is in flight: call bmq_match_wait first");
     bmq_engine::BatchSlot& S = e->slots[1 + k]; // ticket k: never the slot the blocking entry points stage into
     const size_t tb = n_tenants ? tenant_off[n_tenants] : 0, pb = topic_off[n_topics];
     HIPCHK(e, S.s_tenants.ensure(tb + 16));
@@ -854,8 +918,11 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
     HIPCHK(e, S.s_topic_off.ensure(sizeof(uint32_t) * ((size_t)n_topics + 1)));
     HIPCHK(e, S.s_row_ptr.ensure(sizeof(uint32_t) * ((size_t)n_topics + 1)));
     HIPCHK(e, S.b_total.ensure(sizeof(unsigned long long)));
-    S.dev_cap = std::max<uint64_t>(S.s_ids.cap / 4, std::max<uint64_t>((uint64_t)n_topics * 24, 1024));
-    HIPCHK(e, S.s_ids.ensure(S.dev_cap * 4));
+    const bool with_ids = format == BMQ_FMT_IDS || format == BMQ_FMT_GROUPED;
+    if (with_ids) {
+        S.dev_cap = std::max<uint64_t>(S.s_ids.cap / 4, std::max<uint64_t>((uint64_t)n_topics * 24, 1024));
+        HIPCHK(e, S.s_ids.ensure(S.dev_cap * 4));
+    }
     if ((rc = ensure_batch_scratch(e, S, n_tenants, n_topics))) return rc;
     // upload on the copy-in stream: it overlaps the kernels of the batch submitted before (pinned sources: bmq_host_alloc)
     if (n_tenants) {
@@ -876,10 +943,16 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
     a.topic_off = S.s_topic_off.as<uint32_t>();
     a.n_topics = n_topics;
     a.out_row_ptr = S.s_row_ptr.as<uint32_t>();
-    a.out_ids = S.s_ids.as<uint32_t>();
-    a.out_capacity = S.dev_cap;
+    // COUNTS / RANGES: no id is written -- k_expand still lays down the row pointers (= the fan-out of every topic) and the totals,
+    // sees that nothing fits a buffer of 0 ids, and leaves (ST_NOSPACE, which these formats expect)
+    a.out_ids = with_ids ? S.s_ids.as<uint32_t>() : nullptr;
+    a.out_capacity = with_ids ? S.dev_cap : 0;
     a.out_total = S.b_total.as<unsigned long long>();
-    if ((rc = launch_dist(e, S, a))) return rc;
+    S.format = format;
+    if ((rc = launch_dist(e, S, a))) {
+        S.format = BMQ_FMT_IDS;
+        return rc;
+    }
     S.submitted = true;
     S.n_rows = n_topics;
     *out_ticket = k;
@@ -887,13 +960,14 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
 }
 
 int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed) {
-    if (!e || ticket < 0 || ticket > 1 || !out_row_ptr || !out_needed) return BMQ_E_INVAL;
+    if (!e || ticket < 0 || ticket >= BMQ_MAX_TICKETS || !out_row_ptr || !out_needed) return BMQ_E_INVAL;
     if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only");
     bmq_engine::BatchSlot& S = e->slots[1 + ticket];
     uint64_t total = 0;
     {
         std::lock_guard<std::mutex> g(e->mu);
         if (!S.submitted) return set_err(e, BMQ_E_STATE, "no such ticket in flight");
+        if (S.format != BMQ_FMT_IDS) return set_err(e, BMQ_E_STATE, "the ticket was submitted with another result format");
         HIPCHK(e, hipSetDevice(e->device));
     }
     (void)hipEventSynchronize(S.ev_done); // outside the lock: other threads may submit / apply meanwhile
@@ -1190,3 +1264,4 @@ int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len) { return java_st
 #include "bmq_range_engine.inc"
 #include "bmq_exchange.inc"
 #include "bmq_fanout_engine.inc"
+#include "bmq_formats.inc"

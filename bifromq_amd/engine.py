@@ -270,7 +270,7 @@ class Engine:
             self._check(rc)
             return row, ids[:need.value]
 
-    # ---- asynchronous host-buffer match: two batches in flight (bmq_match_submit / bmq_match_wait) ------------------------
+    # ---- asynchronous host-buffer match: up to three batches in flight (bmq_match_submit / bmq_match_wait) ------------------------
     def match_submit(self, tdata, toff, n_tenants, tt, pdata, poff, n_topics) -> int:
         """numpy arrays (ideally views of bmq_host_alloc memory, see pinned()); they must stay alive until match_wait."""
         k = C.c_int()
@@ -287,6 +287,62 @@ class Engine:
             err.needed = need.value
             raise err
         return need.value
+
+    # ---- result formats that fit the wire (include/bmq.h: BMQ_FMT_*) ------------------------------------------------------------
+    FMT_IDS, FMT_COUNTS, FMT_RANGES, FMT_GROUPED = 0, 1, 2, 3
+    RANGE_SIDE = 0x80000000
+
+    def match_submit_fmt(self, tdata, toff, n_tenants, tt, pdata, poff, n_topics, fmt: int) -> int:
+        k = C.c_int()
+        self._check(_lib.lib().bmq_match_submit_fmt(self.h, _ptr(tdata), _ptr(toff), n_tenants, _ptr(tt), _ptr(pdata), _ptr(poff), n_topics, fmt,
+                                                    C.byref(k)))
+        return k.value
+
+    def match_wait_counts(self, ticket: int, row: np.ndarray) -> int:
+        """row[n + 1] <- the id row pointers (fan-out of topic i = row[i + 1] - row[i]); -> total ids"""
+        tot = C.c_uint64()
+        self._check(_lib.lib().bmq_match_wait_counts(self.h, ticket, _ptr(row), C.byref(tot)))
+        return tot.value
+
+    def match_wait_ranges(self, ticket: int, range_ptr: np.ndarray, ranges: np.ndarray, side: np.ndarray, row: Optional[np.ndarray] = None):
+        """ranges: uint32 [cap, 2] (begin, count); side: uint32 [cap]; -> RangesInfo (BmqError -3 carries .info with the sizes)"""
+        info = _lib.RangesInfo()
+        rc = _lib.lib().bmq_match_wait_ranges(self.h, ticket, _ptr(row) if row is not None else None, _ptr(range_ptr), _ptr(ranges), len(ranges),
+                                              _ptr(side), len(side), C.byref(info))
+        if rc:
+            err = BmqError(rc, (_lib.lib().bmq_last_error(self.h) or b"").decode())
+            err.info = info
+            raise err
+        return info
+
+    def match_wait_grouped(self, ticket: int, out_topic: np.ndarray, out_route: np.ndarray, group_off: np.ndarray, group_rep: np.ndarray):
+        """-> (total pairs, n_groups, special)"""
+        ng, sp, tot = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        rc = _lib.lib().bmq_match_wait_grouped(self.h, ticket, _ptr(out_topic), _ptr(out_route), len(out_topic), _ptr(group_off), _ptr(group_rep),
+                                               len(group_rep), C.byref(ng), C.byref(sp), C.byref(tot))
+        if rc:
+            err = BmqError(rc, (_lib.lib().bmq_last_error(self.h) or b"").decode())
+            err.needed = tot.value
+            raise err
+        return tot.value, ng.value, sp.value
+
+    @staticmethod
+    def expand_ranges(range_ptr: np.ndarray, ranges: np.ndarray, side: np.ndarray, n: int) -> List[np.ndarray]:
+        """What a consumer of BMQ_FMT_RANGES does: the id row of every topic (ordered where ranges overlap)."""
+        out = []
+        for i in range(n):
+            parts, last, overlap = [], -1, False
+            for b, c in ranges[range_ptr[i]:range_ptr[i + 1]]:
+                b, c = int(b), int(c)
+                ids = side[b:b + (c & 0x7FFFFFFF)] if c & 0x80000000 else np.arange(b, b + c, dtype=np.uint32)
+                if len(ids) == 0:
+                    continue
+                overlap |= int(ids[0]) <= last
+                last = int(ids[-1])
+                parts.append(ids)
+            row = np.concatenate(parts).astype(np.uint32) if parts else np.zeros(0, dtype=np.uint32)
+            out.append(np.sort(row) if overlap else row)
+        return out
 
     def batcher(self, max_batch_topics: int = 0) -> "Batcher":
         """The batching front of SURVEY.md 8f-1 over this engine (close it before the engine)."""

@@ -27,7 +27,7 @@
  *     ForkJoinPool, DW/DistWorkerCoProcFactory.java:74-88, may all call into it); ONE device batch may be in flight
  *     per engine through the *_dev protocol: bmq_match_batch_dev / bmq_retain_match_batch_dev take the engine for their caller
  *     until the SAME thread calls bmq_match_finish (other threads' calls wait; another thread's *_dev launch gets BMQ_E_STATE).
- *     bmq_match_submit / bmq_match_wait keep two host batches in flight.  Use one engine per KV range replica.
+ *     bmq_match_submit / bmq_match_wait keep up to BMQ_MAX_TICKETS host batches in flight.  Use one engine per KV range replica.
  *   - the engine REQUIRES a gfx950 device for every match call.  There is no CPU fallback: without a
  *     device bmq_engine_create(device >= 0) fails with BMQ_E_NODEVICE.
  */
@@ -171,18 +171,66 @@ void* bmq_stream(const bmq_engine* e);
  * them with NewDirectByteBuffer.  (Any host pointer is accepted everywhere; pageable memory is staged by the HIP runtime.) */
 void* bmq_host_alloc(size_t bytes);
 void bmq_host_free(void* p);
-/* bmq_match_batch split in two so that TWO batches can be in flight: the upload of batch i+1 (copy-in stream) and the download
+/* bmq_match_batch split in two so that several batches can be in flight: the upload of batch i+1 (copy-in stream) and the download
  * of batch i-1 (copy-out stream, inside bmq_match_wait) overlap the kernels of batch i (engine stream).  Steady state: one batch
  * costs max(upload, kernels, download) instead of their sum.  Input buffers must stay valid and unchanged until the matching
- * bmq_match_wait returns.  *out_ticket is 0 or 1; BMQ_E_STATE when both are taken.  bmq_match_wait blocks until the batch is
+ * bmq_match_wait returns.  *out_ticket is 0 .. BMQ_MAX_TICKETS - 1; BMQ_E_STATE when all are taken (three, so that a single caller thread
+ * that blocks in the download of batch i still has batch i + 1 on the GPU and batch i + 2 on its way up).  bmq_match_wait blocks until the batch is
  * done, copies row_ptr[n_topics + 1] and the ids out (same NOSPACE protocol as bmq_match_batch) and frees the ticket.
  * Tickets may be waited for from any thread; bmq_routes_apply between a submit and its wait is applied BEHIND the submitted batch
  * (stream order). */
+#define BMQ_MAX_TICKETS 3
 int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
                      const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
                      int* out_ticket);
 int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
                    uint64_t* out_needed);
+
+/* ---- host-visible result formats ------------------------------------------------------------------------------ */
+/* The id CSR of a million-topic batch is ~77 MB over PCIe -- more than twice the topics that went in.  What the callers of the
+ * reference's match path do next needs less, so a ticket can be submitted for one of these formats instead (bmq_match_submit_fmt takes the
+ * arguments of bmq_match_submit + the format; every format has its own wait; waiting with another format's call is BMQ_E_STATE and
+ * leaves the ticket in flight):
+ *   BMQ_FMT_IDS      bmq_match_wait: row_ptr + ids.
+ *   BMQ_FMT_COUNTS   bmq_match_wait_counts: out_row_ptr[n + 1] only -- the fan-out of topic i is row_ptr[i + 1] - row_ptr[i].  This is
+ *                    all DistWorkerCoProc.batchDist replies with (DW/DistWorkerCoProc.java:535-538: BatchDistReply carries the fan-out per
+ *                    topic).  4 bytes per topic come back; no id is ever written (the expansion kernel lays down the row pointers and leaves).
+ *   BMQ_FMT_RANGES   bmq_match_wait_ranges: the MATCHED RANGES.  Every matched filter owns a run of route ids begin .. begin + count - 1
+ *                    (its routes are neighbours in KV key order, SCHEMA/KVSchemaUtil.java:91-117), so a row is a handful of (begin, count)
+ *                    pairs -- ~6 per topic where the id row has 18 entries.  out_range_ptr[n + 1] delimits the rows in out_ranges.  A range
+ *                    whose count has BMQ_RANGE_SIDE set (filters touched by bmq_routes_apply since the last rebuild) lists its ids
+ *                    explicitly: out_side_ids[begin .. begin + (count & ~BMQ_RANGE_SIDE)).  The result is self-contained: expanding
+ *                    needs nothing of the index.  The ranges of a row come in ascending order of their first id (rows of more than 32
+ *                    ranges: as matched); expanding them in that order yields the row's ids in ascending order -- exactly the row of
+ *                    BMQ_FMT_IDS -- unless ranges overlap (interleaved id sets: only after churn), which the consumer sees while expanding
+ *                    (first id <= last id of the range before it) and repairs by ordering that row's ids;
+ *                    out_info->n_overlapping_rows says how many such rows the batch has (0 after a rebuild).  out_row_ptr (may be NULL)
+ *                    receives the id row pointers as well, so that the consumer knows where every expanded row goes.
+ *                    BMQ_E_NOSPACE when range_cap / side_cap are too small: out_info holds the sizes, row pointers are written, the ticket
+ *                    is released (as with bmq_match_wait).
+ *   BMQ_FMT_GROUPED  bmq_match_wait_grouped: the (topic, route) pairs of the batch regrouped by DelivererKey -- the output of
+ *                    bmq_fanout_group (see there for the meaning of every array) without the CSR ever leaving the GPU. */
+#define BMQ_FMT_IDS 0
+#define BMQ_FMT_COUNTS 1
+#define BMQ_FMT_RANGES 2
+#define BMQ_FMT_GROUPED 3
+#define BMQ_RANGE_SIDE 0x80000000u
+typedef struct bmq_id_range {
+    uint32_t begin, count;
+} bmq_id_range;
+typedef struct bmq_ranges_info {
+    uint64_t n_ranges, n_side_ids;
+    uint64_t n_ids;              /* what the id CSR of the batch would hold */
+    uint64_t n_overlapping_rows; /* rows whose expanded ids the consumer has to order */
+} bmq_ranges_info;
+int bmq_match_submit_fmt(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants,
+                         const uint32_t* topic_tenant, const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics,
+                         int format, int* out_ticket);
+int bmq_match_wait_counts(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint64_t* out_total /* may be NULL */);
+int bmq_match_wait_ranges(bmq_engine* e, int ticket, uint32_t* out_row_ptr /* may be NULL */, uint32_t* out_range_ptr, bmq_id_range* out_ranges,
+                          uint64_t range_cap, uint32_t* out_side_ids, uint64_t side_cap, bmq_ranges_info* out_info);
+int bmq_match_wait_grouped(bmq_engine* e, int ticket, uint32_t* out_topic, uint32_t* out_route, uint64_t pair_cap, uint32_t* out_group_off,
+                           uint32_t* out_group_rep, uint32_t group_cap, uint32_t* out_n_groups, uint32_t* out_special, uint64_t* out_total);
 
 /* ---- multi-GPU exchange -------------------------------------------------------------------------------------- */
 /* One process per GPU, tenants sharded by hash(tenantId) mod N; after the per-rank match ONE exchange step over RCCL / xGMI.

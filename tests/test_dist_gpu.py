@@ -617,15 +617,17 @@ def test_submit_wait_two_batches_in_flight(eng):
             assert got == len(eids) and (rows[j][:n + 1] == erow).all() and (ids[j][:got] == eids).all()
     with pytest.raises(B.BmqError):
         eng.match_wait(0, rows[0], ids[0])  # nothing in flight under that ticket
-    # a third submit while two are in flight is refused; an apply between submit and wait lands behind the submitted batch
+    # a submit while every ticket is in flight is refused; an apply between submit and wait lands behind the submitted batch
     pd, po, pt, n = batches[0]
     t0 = eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
     t1 = eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
+    t2 = eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
+    assert sorted((t0, t1, t2)) == [0, 1, 2]  # BMQ_MAX_TICKETS
     with pytest.raises(B.BmqError):
         eng.match_submit(p_t, p_to, len(tn), pt, pd, po, n)
     extra = _normal(tn[0], "#", 0, "late", "d")
     eng.apply([(0, extra)])
-    for t in (t0, t1):
+    for t in (t0, t1, t2):
         got = eng.match_wait(t, rows[0], ids[0])
         assert got == len(expect[0][1]) and (ids[0][:got] == expect[0][1]).all()  # submitted before the apply
     row2, ids2 = eng.match_batch(tn, pt, packed_topics=(pd, po))
