@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ABI_SYMBOLS = [
     "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_compact", "bmq_routes_apply",
     "bmq_index_info_get", "bmq_route_key", "bmq_route_keys", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
-    "bmq_match_finish", "bmq_set_kernel_timing", "bmq_match_submit", "bmq_match_wait", "bmq_match_submit_fmt", "bmq_match_wait_counts", "bmq_match_wait_ranges", "bmq_match_wait_grouped", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
+    "bmq_match_finish", "bmq_set_kernel_timing", "bmq_match_submit", "bmq_match_wait", "bmq_match_submit_fmt", "bmq_match_submit_dev", "bmq_match_wait_dev", "bmq_match_wait_counts", "bmq_match_wait_ranges", "bmq_match_wait_grouped", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_range_lookup", "bmq_comm_unique_id", "bmq_comm_init", "bmq_comm_destroy", "bmq_exchange_fanout",
     "bmq_exchange_csr", "bmq_exchange_wait", "bmq_partition_batch_dev", "bmq_retain_message_key", "bmq_retain_filter_route", "bmq_retain_rebuild", "bmq_retain_rebuild_ex", "bmq_retain_apply", "bmq_retain_apply_ex", "bmq_retain_topic",
     "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired", "bmq_retain_apply_batch", "bmq_retain_compact", "bmq_retain_info_get",
@@ -130,6 +130,8 @@ def lib() -> C.CDLL:
             "bmq_match_wait": (C.c_int, [vp, C.c_int, vp, vp, u64, P(u64)]),
             "bmq_match_submit_fmt": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, C.c_int, P(C.c_int)]),
             "bmq_match_wait_counts": (C.c_int, [vp, C.c_int, vp, P(u64)]),
+            "bmq_match_submit_dev": (C.c_int, [vp, vp, vp, u32, vp, vp, vp, u32, vp, vp, u64, vp, P(C.c_int)]),
+            "bmq_match_wait_dev": (C.c_int, [vp, C.c_int, P(u64)]),
             "bmq_match_wait_ranges": (C.c_int, [vp, C.c_int, vp, vp, vp, u64, vp, u64, P(RangesInfo)]),
             "bmq_match_wait_grouped": (C.c_int, [vp, C.c_int, vp, vp, u64, vp, vp, u32, P(u32), P(u32), P(u64)]),
             "bmq_host_alloc": (vp, [C.c_size_t]),

@@ -124,6 +124,7 @@ struct bmq_engine {
         bool clean = false; // counters / allocators / super sums are zero (k_reset ran behind the last batch of the slot)
         bool ran_slow = false, ran_sort = false; // k_walk_slow / k_sort_rows were part of this batch's launch
         bool timed = false; // this batch was launched with the per-kernel events (bmq_config.kernel_timing)
+        bool total_timed = false; // ... with the two events around the whole batch (bmq_stats.ms_total)
         int pending_kind = 0; // 0 dist, 1 retain
         bool submitted = false; // owned by a bmq_match_submit ticket
         bool api_held = false;  // the *_dev launch took the engine's api lock; bmq_match_finish gives it back
@@ -133,6 +134,7 @@ struct bmq_engine {
         RetainArgs rlast{};
         // result formats of bmq_match_submit_fmt (bmq_formats.inc)
         int format = 0;                                 // BMQ_FMT_*
+        bool devptr = false;                            // a bmq_match_submit_dev ticket: the caller's buffers, nothing staged
         DevBuf f_cnt, f_ptr, f_ranges, f_side, f_sums;  // RANGES: counts, their prefix sums, the ranges, the side ids, sizes / flags
         uint64_t range_cap = 0, side_cap = 0;
         unsigned long long* h_fsums = nullptr;          // pinned copy of f_sums
@@ -324,7 +326,9 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     hipStream_t s = e->stream;
     S.timed = e->kernel_events;
     if (!S.clean) reset_slot(e, S, s); // first batch of the slot, buffers regrown, or a retain batch ran on it
-    HIPCHK(e, hipEventRecord(S.ev[0], s));
+    // ms_total: two more events per batch -- ~8 us of host time, which a launch of a few hundred topics (the batching front's) feels
+    S.total_timed = e->kernel_events || a.n_topics >= 4096;
+    if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[0], s));
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
@@ -343,7 +347,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
     if (e->sort_on) hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
-    HIPCHK(e, hipEventRecord(S.ev[5], s));
+    if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[5], s));
     if (S.format == BMQ_FMT_RANGES) { // the compact range lists, while the slot's counters still say whether the batch is complete
         const int frc = enqueue_ranges(e, S, a);
         if (frc) return frc;
@@ -455,7 +459,7 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
         st.n_slow_topics = c.slow_count;
         st.n_sorted_rows = c.sort_count;
         st.topic_bytes = c.topic_bytes;
-        (void)hipEventElapsedTime(&st.ms_total, S.ev[0], S.ev[5]);
+        if (S.total_timed) (void)hipEventElapsedTime(&st.ms_total, S.ev[0], S.ev[5]);
         if (S.timed) {
             (void)hipEventElapsedTime(&st.ms_walk, S.ev[1], S.ev[2]);
             (void)hipEventElapsedTime(&st.ms_expand, S.ev[3], S.ev[4]);
@@ -967,7 +971,7 @@ int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* o
     {
         std::lock_guard<std::mutex> g(e->mu);
         if (!S.submitted) return set_err(e, BMQ_E_STATE, "no such ticket in flight");
-        if (S.format != BMQ_FMT_IDS) return set_err(e, BMQ_E_STATE, "the ticket was submitted with another result format");
+        if (S.format != BMQ_FMT_IDS || S.devptr) return set_err(e, BMQ_E_STATE, "the ticket was submitted with another result format");
         HIPCHK(e, hipSetDevice(e->device));
     }
     (void)hipEventSynchronize(S.ev_done); // outside the lock: other threads may submit / apply meanwhile
@@ -1006,6 +1010,68 @@ int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* o
     if (rc) return rc;
     if (he != hipSuccess) return set_err(e, BMQ_E_HIP, std::string("result download: ") + hipGetErrorString(he));
     return fits ? BMQ_OK : set_err(e, BMQ_E_NOSPACE, "output buffer too small");
+}
+
+// Tickets over device-accessible buffers (include/bmq.h): nothing is staged and nothing copied -- the kernels read the caller's
+// inputs and write the caller's outputs in place (HBM, or page-locked host memory over PCIe).
+int bmq_match_submit_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t* d_tenant_off, uint32_t n_tenants, const uint32_t* d_topic_tenant,
+                         const uint8_t* d_topics, const uint32_t* d_topic_off, uint32_t n_topics, uint32_t* d_out_row_ptr, uint32_t* d_out_route_ids,
+                         uint64_t out_capacity, uint64_t* d_out_total, int* out_ticket) {
+    int rc = check_dist_ready(e);
+    if (rc) return rc;
+    if (!out_ticket || n_topics == 0 || !d_out_row_ptr || !d_topic_off || !d_topics || !d_topic_tenant || !d_out_total || (n_tenants && (!d_tenants || !d_tenant_off)))
+        return set_err(e, BMQ_E_INVAL, "null pointer or empty batch");
+    if ((uintptr_t)d_topics & 15) return set_err(e, BMQ_E_INVAL, "the topic byte buffer must be 16-byte aligned");
+    std::lock_guard<std::mutex> g(e->mu);
+    HIPCHK(e, hipSetDevice(e->device));
+    int k = -1;
+    for (int i = 0; i < BMQ_MAX_TICKETS; i++)
+        if (!e->slots[1 + i].pending && !e->slots[1 + i].submitted) {
+            k = i;
+            break;
+        }
+    if (k < 0) return set_err(e, BMQ_E_STATE, "every ticket is in flight: call bmq_match_wait first");
+    bmq_engine::BatchSlot& S = e->slots[1 + k];
+    if ((rc = ensure_batch_scratch(e, S, n_tenants, n_topics))) return rc;
+    BatchArgs a{};
+    a.tenants = d_tenants;
+    a.tenant_off = d_tenant_off;
+    a.n_tenants = n_tenants;
+    a.topic_tenant = d_topic_tenant;
+    a.topics = d_topics;
+    a.topic_off = d_topic_off;
+    a.n_topics = n_topics;
+    a.out_row_ptr = d_out_row_ptr;
+    a.out_ids = d_out_route_ids;
+    a.out_capacity = d_out_route_ids ? out_capacity : 0;
+    a.out_total = (unsigned long long*)d_out_total;
+    S.format = BMQ_FMT_IDS;
+    if ((rc = launch_dist(e, S, a))) return rc;
+    S.submitted = true;
+    S.devptr = true;
+    S.n_rows = n_topics;
+    *out_ticket = k;
+    return BMQ_OK;
+}
+
+int bmq_match_wait_dev(bmq_engine* e, int ticket, uint64_t* out_total) {
+    if (!e || ticket < 0 || ticket >= BMQ_MAX_TICKETS) return BMQ_E_INVAL;
+    if (e->device < 0) return set_err(e, BMQ_E_NODEVICE, "engine is host-only");
+    bmq_engine::BatchSlot& S = e->slots[1 + ticket];
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        if (!S.submitted || !S.devptr) return set_err(e, BMQ_E_STATE, "no such device-buffer ticket in flight");
+        HIPCHK(e, hipSetDevice(e->device));
+    }
+    (void)hipEventSynchronize(S.ev_done); // outside the lock: other threads may submit / apply meanwhile
+    std::lock_guard<std::mutex> g(e->mu);
+    uint64_t total = 0;
+    const int rc = finish_dist(e, S, &total); // grows internal scratch and re-runs if a kernel asked for it
+    if (out_total) *out_total = total;
+    S.submitted = false;
+    S.pending = false;
+    S.devptr = false;
+    return rc;
 }
 
 // ---- MatchedRoutes caps (DW/cache/MatchedRoutes.java:87-141) over rows of route ids ----------------------------------------

@@ -77,7 +77,8 @@ typedef struct bmq_stats {
     uint64_t n_slow_topics;  /* topics resolved by the slow path (more than 16 levels)                     */
     uint64_t n_sorted_rows;  /* rows that needed the element-level fix-up sort                              */
     uint64_t topic_bytes;    /* sum of topic lengths                                                        */
-    float ms_total;          /* HIP-event time of the whole batch on the engine stream                      */
+    float ms_total;          /* HIP-event time of the whole batch on the engine stream (0 for batches of fewer */
+                             /* than 4096 topics unless bmq_config.kernel_timing: the two events cost ~8 us)  */
     float ms_walk;           /* ... of the tokenise+walk kernel alone (0 unless bmq_config.kernel_timing)   */
     float ms_expand;         /* ... of the expand kernel alone (0 unless bmq_config.kernel_timing)          */
     float ms_reserved;
@@ -185,6 +186,18 @@ int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tena
                      int* out_ticket);
 int bmq_match_wait(bmq_engine* e, int ticket, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity,
                    uint64_t* out_needed);
+
+/* Tickets over DEVICE-ACCESSIBLE buffers: every pointer is HBM or page-locked host memory from bmq_host_alloc, which the GPU reads and
+ * writes in place over PCIe (same alignment / padding duties as bmq_match_batch_dev).  Nothing is staged, nothing copied: for small
+ * launches -- the batching front's: tens to thousands of topics -- the five uploads, three downloads and their synchronisation cost
+ * more than the kernels.  The results (d_out_row_ptr[n + 1], d_out_route_ids, *d_out_total) are complete when bmq_match_wait_dev
+ * returns; BMQ_E_NOSPACE + *out_total if out_capacity was short (row pointers are written).  Unlike bmq_match_batch_dev the engine is
+ * not taken for the caller: BMQ_MAX_TICKETS such launches may be in flight, from any threads. */
+int bmq_match_submit_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t* d_tenant_off, uint32_t n_tenants,
+                         const uint32_t* d_topic_tenant, const uint8_t* d_topics, const uint32_t* d_topic_off, uint32_t n_topics,
+                         uint32_t* d_out_row_ptr, uint32_t* d_out_route_ids, uint64_t out_capacity, uint64_t* d_out_total,
+                         int* out_ticket);
+int bmq_match_wait_dev(bmq_engine* e, int ticket, uint64_t* out_total /* may be NULL */);
 
 /* ---- host-visible result formats ------------------------------------------------------------------------------ */
 /* The id CSR of a million-topic batch is ~77 MB over PCIe -- more than twice the topics that went in.  What the callers of the

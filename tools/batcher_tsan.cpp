@@ -69,12 +69,15 @@ extern "C" int bmq_match_batch(bmq_engine* e, const uint8_t* tenants, const uint
     return BMQ_OK;
 }
 
-// bmq_match_submit / bmq_match_wait of the stand-in: three tickets; a launch is ready launch_us after its submit, except that the "GPU"
-// works on one launch at a time for 40% of that (the kernels; upload, download and the synchronisation overlap with the neighbours)
+// bmq_match_submit_dev / bmq_match_wait_dev of the stand-in: three tickets over the caller's buffers; a launch is ready launch_us after its
+// submit, except that the "GPU" works on one launch at a time for 40% of that (the kernels; the rest overlaps with the neighbours)
 struct FakeTicket {
     bool used = false;
-    std::vector<uint8_t> tenants, topics;
-    std::vector<uint32_t> tenant_off, topic_tenant, topic_off;
+    const uint8_t *tenants, *topics;
+    const uint32_t *tenant_off, *topic_tenant, *topic_off;
+    uint32_t n_tenants, n_topics;
+    uint32_t *row, *ids;
+    uint64_t cap;
     std::chrono::steady_clock::time_point ready;
 };
 static FakeTicket g_tk[BMQ_MAX_TICKETS];
@@ -82,20 +85,21 @@ static std::mutex g_tk_mu;
 static std::chrono::steady_clock::time_point g_gpu_free;
 static std::atomic<int> g_ticket_refusals{0}; // test knob: the next n submits are refused (BMQ_E_STATE), as when other users hold every ticket
 
-extern "C" int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
-                                const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, int* out_ticket) {
+extern "C" void* bmq_host_alloc(size_t n) { return malloc(n); }
+extern "C" void bmq_host_free(void* p) { free(p); }
+extern "C" int bmq_match_submit_dev(bmq_engine* e, const uint8_t* tenants, const uint32_t* tenant_off, uint32_t n_tenants, const uint32_t* topic_tenant,
+                                    const uint8_t* topics, const uint32_t* topic_off, uint32_t n_topics, uint32_t* row, uint32_t* ids, uint64_t cap,
+                                    uint64_t* total, int* out_ticket) {
     std::unique_lock<std::recursive_mutex> lk(e->api);
+    if (((uintptr_t)topics & 15) || !total) return BMQ_E_INVAL;
     if (g_ticket_refusals.load() > 0 && g_ticket_refusals.fetch_sub(1) > 0) return BMQ_E_STATE;
     std::lock_guard<std::mutex> g(g_tk_mu);
     for (int k = 0; k < BMQ_MAX_TICKETS; k++) {
         FakeTicket& t = g_tk[k];
         if (t.used) continue;
         t.used = true;
-        t.tenants.assign(tenants, tenants + tenant_off[n_tenants]);
-        t.tenant_off.assign(tenant_off, tenant_off + n_tenants + 1);
-        t.topic_tenant.assign(topic_tenant, topic_tenant + n_topics);
-        t.topics.assign(topics, topics + topic_off[n_topics]);
-        t.topic_off.assign(topic_off, topic_off + n_topics + 1);
+        t.tenants = tenants, t.tenant_off = tenant_off, t.n_tenants = n_tenants, t.topic_tenant = topic_tenant, t.topics = topics, t.topic_off = topic_off;
+        t.n_topics = n_topics, t.row = row, t.ids = ids, t.cap = cap;
         const auto now = std::chrono::steady_clock::now();
         const auto L = std::chrono::microseconds(g_launch_us.load());
         t.ready = std::max(now + L * 6 / 10, g_gpu_free) + L * 4 / 10;
@@ -105,7 +109,7 @@ extern "C" int bmq_match_submit(bmq_engine* e, const uint8_t* tenants, const uin
     }
     return BMQ_E_STATE;
 }
-extern "C" int bmq_match_wait(bmq_engine*, int ticket, uint32_t* out_row_ptr, uint32_t* out_route_ids, uint64_t out_capacity, uint64_t* out_needed) {
+extern "C" int bmq_match_wait_dev(bmq_engine*, int ticket, uint64_t* out_total) {
     FakeTicket* t;
     {
         std::lock_guard<std::mutex> g(g_tk_mu);
@@ -116,33 +120,30 @@ extern "C" int bmq_match_wait(bmq_engine*, int ticket, uint32_t* out_row_ptr, ui
         while (std::chrono::steady_clock::now() < t->ready) std::this_thread::yield();
     else std::this_thread::sleep_until(t->ready);
     g_batches++;
-    const uint32_t n_topics = (uint32_t)t->topic_tenant.size(), n_tenants = (uint32_t)t->tenant_off.size() - 1;
     uint64_t total = 0;
     int rc = BMQ_OK;
-    for (uint32_t i = 0; i < n_topics && rc == BMQ_OK; i++) {
-        if (t->topic_tenant[i] >= n_tenants) rc = BMQ_E_INVAL;
+    auto tenant_of = [&](uint32_t i) { return std::string_view((const char*)t->tenants + t->tenant_off[t->topic_tenant[i]], t->tenant_off[t->topic_tenant[i] + 1] - t->tenant_off[t->topic_tenant[i]]); };
+    auto topic_of = [&](uint32_t i) { return std::string_view((const char*)t->topics + t->topic_off[i], t->topic_off[i + 1] - t->topic_off[i]); };
+    for (uint32_t i = 0; i < t->n_topics && rc == BMQ_OK; i++) {
+        if (t->topic_tenant[i] >= t->n_tenants) rc = BMQ_E_INVAL;
         else {
-            const std::string_view tn((const char*)t->tenants.data() + t->tenant_off[t->topic_tenant[i]], t->tenant_off[t->topic_tenant[i] + 1] - t->tenant_off[t->topic_tenant[i]]);
-            const std::string_view tp((const char*)t->topics.data() + t->topic_off[i], t->topic_off[i + 1] - t->topic_off[i]);
-            out_row_ptr[i] = (uint32_t)total;
-            total += fake_count(tn, tp);
+            t->row[i] = (uint32_t)total;
+            total += fake_count(tenant_of(i), topic_of(i));
         }
     }
     if (rc == BMQ_OK) {
-        out_row_ptr[n_topics] = (uint32_t)total;
-        *out_needed = total;
-        if (total > out_capacity) rc = BMQ_E_NOSPACE;
+        t->row[t->n_topics] = (uint32_t)total;
+        if (out_total) *out_total = total;
+        if (total > t->cap) rc = BMQ_E_NOSPACE;
     }
-    for (uint32_t i = 0; i < n_topics && rc == BMQ_OK; i++) {
-        const std::string_view tn((const char*)t->tenants.data() + t->tenant_off[t->topic_tenant[i]], t->tenant_off[t->topic_tenant[i] + 1] - t->tenant_off[t->topic_tenant[i]]);
-        const std::string_view tp((const char*)t->topics.data() + t->topic_off[i], t->topic_off[i + 1] - t->topic_off[i]);
-        for (uint32_t k = 0; k < out_row_ptr[i + 1] - out_row_ptr[i]; k++) out_route_ids[out_row_ptr[i] + k] = fake_id(tn, tp, k);
-    }
+    for (uint32_t i = 0; i < t->n_topics && rc == BMQ_OK; i++)
+        for (uint32_t k = 0; k < t->row[i + 1] - t->row[i]; k++) t->ids[t->row[i] + k] = fake_id(tenant_of(i), topic_of(i), k);
     std::lock_guard<std::mutex> g(g_tk_mu);
     t->used = false;
     return rc;
 }
 
+#define BMQ_BATCHER_INITIAL_IDS 4
 #include "../bifromq_amd/csrc/bmq_batcher.inc"
 
 static std::atomic<int> g_fail{0};
