@@ -143,3 +143,46 @@ def test_formats_on_edge_shapes(eng):
         ot, orr, goff, grep = (np.zeros(8, dtype=np.uint32) for _ in range(4))
         total, ng, special = eng.match_wait_grouped(t, ot, orr, goff, grep)
         assert total == len(eids) and ng == (1 if len(eids) else 0) and sorted(orr[:total].tolist()) == sorted(eids.tolist())
+
+
+def test_tickets_over_page_locked_buffers_in_place(eng):
+    """bmq_match_submit_dev / bmq_match_wait_dev: the kernels read the inputs and write the CSR in place in page-locked host memory (what
+    the batching front launches through); several in flight; too small an id buffer is NOSPACE with the size."""
+    import ctypes as C
+
+    from bifromq_amd.engine import _ptr
+    L = B._lib.lib()
+    w = B.Workload(0xF0A9, 9, 2000, 1)
+    eng.rebuild(w.keys())
+    tn = w.tenants()
+    tdata, toff = w.tenants_packed()
+    p_t, p_to = pinned(len(tdata) + 32, np.uint8), pinned(len(toff), np.uint32)
+    p_t[:] = 0
+    p_t[:len(tdata)], p_to[:] = tdata, toff
+    runs = []
+    for k, n in enumerate((1, 257, 5000)):
+        data, off, tt = w.topics(40 + k, n)
+        pd, po, pt = pinned(len(data) + 32, np.uint8), pinned(len(off), np.uint32), pinned(len(tt), np.uint32)
+        pd[:] = 0
+        pd[:len(data)], po[:], pt[:] = data, off, tt
+        erow, eids = eng.match_batch(tn, tt, packed_topics=(data, off))
+        row, ids, tot = pinned(n + 1, np.uint32), pinned(len(eids) + 8, np.uint32), pinned(1, np.uint64)
+        row[:], ids[:] = 0, 0xFFFFFFFF
+        t = C.c_int()
+        assert L.bmq_match_submit_dev(eng.h, _ptr(p_t), _ptr(p_to), len(tn), _ptr(pt), _ptr(pd), _ptr(po), n, _ptr(row), _ptr(ids), len(ids), _ptr(tot),
+                                      C.byref(t)) == 0
+        runs.append((t.value, n, erow, eids, row, ids, tot, (pd, po, pt)))
+    assert sorted(r[0] for r in runs) == [0, 1, 2]
+    for t, n, erow, eids, row, ids, tot, _ in reversed(runs):
+        need = C.c_uint64()
+        assert L.bmq_match_wait_dev(eng.h, t, C.byref(need)) == 0
+        assert need.value == len(eids) == int(tot[0]) and (row == erow).all() and (ids[:len(eids)] == eids).all()
+    # short id buffer
+    t, n, erow, eids, row, ids, tot, (pd, po, pt) = runs[1]
+    row[:] = 0
+    tk, need = C.c_int(), C.c_uint64()
+    assert L.bmq_match_submit_dev(eng.h, _ptr(p_t), _ptr(p_to), len(tn), _ptr(pt), _ptr(pd), _ptr(po), n, _ptr(row), _ptr(ids), 3, _ptr(tot), C.byref(tk)) == 0
+    with pytest.raises(B.BmqError):
+        eng.match_wait(tk.value, row, ids)  # the host-buffer wait does not take a device-buffer ticket
+    assert L.bmq_match_wait_dev(eng.h, tk.value, C.byref(need)) == -3 and need.value == len(eids) and (row == erow).all()
+    assert L.bmq_match_wait_dev(eng.h, tk.value, C.byref(need)) == -7  # released: BMQ_E_STATE

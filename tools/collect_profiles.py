@@ -5,10 +5,10 @@ usage: python tools/collect_profiles.py r02"""
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = os.path.join("gpurun_out", R), os.path.join("profiles", R)
 os.makedirs(dst, exist_ok=True)
-for name in ("pytest_gpu.log", "bench_c3.json", "bench_c2.json", "bench_c4.json"):
+for name in ("pytest_gpu.log", "bench_c3.json", "bench_c2.json", "bench_c4.json", "bench_c3.err"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))
@@ -16,46 +16,59 @@ for w in ("c3", "c2", "c4"):
     hits = glob.glob(os.path.join(src, "kt_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, w + "_kernel_stats.csv"))
-rows, per = [], {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    hits = glob.glob(os.path.join(src, "pmc_" + c, "**", "*counter_collection.csv"), recursive=True)
-    if not hits:
+sys.path.insert(0, os.getcwd())
+from bench import kernel_sources_sha  # the same hash bench.py checks before it quotes a traffic file
+
+traffic_out = {}
+for w in ("c3", "c2", "c4"):
+    rows, per = [], {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        hits = glob.glob(os.path.join(src, "pmc_%s_%s" % (w, c), "**", "*counter_collection.csv"), recursive=True)
+        if not hits:
+            continue
+        acc = defaultdict(list)
+        with open(hits[0]) as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] == c:
+                    acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        for k in sorted(acc):
+            v = acc[k][1:] if len(acc[k]) > 1 else acc[k]  # the first dispatch of a kernel includes cold-start effects
+            rows.append((k, c, len(v), sum(v) / len(v)))
+            per[(k, c)] = sum(v) / len(v)
+    if not rows:
         continue
-    acc = defaultdict(list)
-    with open(hits[0]) as f:
-        for r in csv.DictReader(f):
-            if r["Counter_Name"] == c:
-                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    for k in sorted(acc):
-        v = acc[k][1:] if len(acc[k]) > 1 else acc[k]  # the first dispatch of a kernel includes cold-start effects
-        rows.append((k, c, len(v), sum(v) / len(v)))
-        per[(k, c)] = sum(v) / len(v)
-if rows:
-    with open(os.path.join(dst, "c3_pmc_hbm.csv"), "w") as f:
-        f.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline ; KiB per dispatch, averaged\n")
+    with open(os.path.join(dst, w + "_pmc_hbm.csv"), "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --workload %s --steps 4 --warmup 1 --no-cpu-baseline "
+                "--no-extras --batcher-threads 0 ; KiB per dispatch, averaged\n" % w)
         f.write("kernel,counter,dispatches,avg_KiB_per_dispatch\n")
         for k, c, n, v in rows:
             f.write("%s,%s,%d,%.1f\n" % (k, c, n, v))
-    fk, wk = per.get(("bmq::k_walk", "FETCH_SIZE")), per.get(("bmq::k_walk", "WRITE_SIZE"))
-    if fk is not None and wk is not None:
-        traffic = fk * 1024 * 0.992 + wk * 1024
-        with open(os.path.join("profiles", "traffic_%s.json" % R), "w") as f:
-            import hashlib
-            hs = hashlib.sha256()
-            for fn in ("bmq_layout.h", "bmq_dist_kernels.h", "bmq_retain_kernels.h"):
-                hs.update(open(os.path.join("bifromq_amd", "csrc", fn), "rb").read())
-            json.dump({"c3": traffic, "kernel_sources_sha": hs.hexdigest()[:16], "_note": "HBM bytes per k_walk launch = FETCH_SIZE*1024*0.992 (calibrated on random 64-byte line "
-                       "fetches, tools/ubench_lines.hip) + WRITE_SIZE*1024 (uncalibrated); profiles/%s/c3_pmc_hbm.csv" % R}, f)
-        print("k_walk traffic per launch: %.1f MB" % (traffic / 1e6))
-        # the round's C3 bench line ran before the counter passes: its roofline.traffic is filled in from them here
-        bj = os.path.join(dst, "bench_c3.json")
-        if os.path.exists(bj):
-            d = json.loads(open(bj).read().strip().splitlines()[-1])
-            if d["roofline"].get("traffic") is None and d["roofline"].get("kernel") == "k_walk":
-                d["roofline"]["traffic"] = traffic
-                d["roofline"]["traffic_source"] = ("profiles/traffic_%s.json: PMC passes of the same profile round (tools/profile_round.sh), "
-                                                   "filled in by tools/collect_profiles.py" % R)
-                open(bj, "w").write(json.dumps(d) + "\n")
+    # the workload's dominant kernel is the one its bench line names
+    bj = os.path.join(dst, "bench_%s.json" % w)
+    kernel = "k_walk"
+    d = None
+    if os.path.exists(bj):
+        d = json.loads(open(bj).read().strip().splitlines()[-1])
+        kernel = d["roofline"].get("kernel", kernel)
+    fk, wk = per.get(("bmq::" + kernel, "FETCH_SIZE")), per.get(("bmq::" + kernel, "WRITE_SIZE"))
+    if fk is None or wk is None:
+        continue
+    traffic = fk * 1024 * 0.992 + wk * 1024
+    traffic_out[w] = traffic
+    traffic_out[w + "_kernel"] = kernel
+    print("%s: %s traffic per launch: %.1f MB" % (w, kernel, traffic / 1e6))
+    # the round's bench line ran before the counter passes: its roofline.traffic is filled in from them here
+    if d is not None and d["roofline"].get("traffic") is None:
+        d["roofline"]["traffic"] = traffic
+        d["roofline"]["traffic_source"] = ("profiles/traffic_%s.json: PMC passes of the same profile round (tools/profile_round.sh), "
+                                           "filled in by tools/collect_profiles.py" % R)
+        open(bj, "w").write(json.dumps(d) + "\n")
+if traffic_out:
+    traffic_out["kernel_sources_sha"] = kernel_sources_sha()
+    traffic_out["_note"] = ("HBM bytes per launch of the workload's dominant kernel = FETCH_SIZE*1024*0.992 (calibrated on random 64-byte line "
+                            "fetches, tools/ubench_lines.hip) + WRITE_SIZE*1024 (uncalibrated); profiles/%s/<workload>_pmc_hbm.csv" % R)
+    with open(os.path.join("profiles", "traffic_%s.json" % R), "w") as f:
+        json.dump(traffic_out, f)
 ex = os.path.join(src, "extras")
 if os.path.isdir(ex):  # tools/measure_extras.sh
     os.makedirs(os.path.join(dst, "extras"), exist_ok=True)
