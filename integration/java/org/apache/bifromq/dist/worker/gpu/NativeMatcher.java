@@ -41,12 +41,27 @@ final class NativeMatcher {
 
     static native void hostFree(ByteBuffer buf);
 
-    /** Two batches in flight: upload of batch i+1 and download of batch i-1 overlap the kernels of batch i. @return ticket */
+    /** Up to three batches in flight: upload of batch i+1 and download of batch i-1 overlap the kernels of batch i. @return ticket */
     static native int matchSubmit(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant,
                                   ByteBuffer topics, IntBuffer topicOff, int nTopics);
 
     /** @return number of ids, or -(needed) when outIds is too small (the ticket is consumed either way: re-submit) */
     static native long matchWait(long engine, int ticket, IntBuffer outRowPtr, IntBuffer outIds);
+
+    /** Result formats that fit the wire (bmq.h BMQ_FMT_*): 0 ids, 1 fan-out counts, 2 matched id ranges, 3 pairs grouped by DelivererKey. */
+    static native int matchSubmitFmt(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant,
+                                     ByteBuffer topics, IntBuffer topicOff, int nTopics, int format);
+
+    /** Fan-out of topic i = outRowPtr[i + 1] - outRowPtr[i] (all a BatchDistReply carries). @return total fan-out */
+    static native long matchWaitCounts(long engine, int ticket, IntBuffer outRowPtr);
+
+    /** @return number of ranges, or -(needed); info4 = {ranges, side ids, ids, rows whose expanded ids must be ordered} */
+    static native long matchWaitRanges(long engine, int ticket, IntBuffer outRowPtr, IntBuffer outRangePtr, IntBuffer outRanges,
+                                       IntBuffer outSideIds, long[] info4);
+
+    /** @return number of (topic, route) pairs, or -(needed); groups2 = {groups, special bits} */
+    static native long matchWaitGrouped(long engine, int ticket, IntBuffer outTopic, IntBuffer outRoute, IntBuffer outGroupOff,
+                                        IntBuffer outGroupRep, int[] groups2);
 
     /** @return key length, or -(needed) when out is too small */
     static native int routeKey(long engine, int routeId, ByteBuffer out);

@@ -114,7 +114,7 @@ JNIEXPORT void JNICALL NM(hostFree)(JNIEnv* env, jclass c, jobject buf) {
     bmq_host_free(ADDR(buf));
 }
 /* int matchSubmit(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer topicTenant, ByteBuffer topics,
- *                 IntBuffer topicOff, int nTopics)      -> ticket (0 / 1); two batches may be in flight */
+ *                 IntBuffer topicOff, int nTopics)      -> ticket (0 .. BMQ_MAX_TICKETS - 1): three batches may be in flight */
 JNIEXPORT jint JNICALL NM(matchSubmit)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants, jobject topicTenant,
                                        jobject topics, jobject topicOff, jint nTopics) {
     (void)c;
@@ -131,6 +131,54 @@ JNIEXPORT jlong JNICALL NM(matchWait)(JNIEnv* env, jclass c, jlong h, jint ticke
     uint64_t need = 0;
     const int rc = bmq_match_wait(ENGINE(h), ticket, (uint32_t*)ADDR(outRowPtr), (uint32_t*)ADDR(outIds), CAP(outIds), &need);
     return result_of(env, ENGINE(h), "bmq_match_wait", rc, need);
+}
+/* ---- result formats that fit the wire (include/bmq.h BMQ_FMT_*) ---- */
+/* int matchSubmitFmt(long engine, ..., int nTopics, int format)   -> ticket (0 .. BMQ_MAX_TICKETS - 1) */
+JNIEXPORT jint JNICALL NM(matchSubmitFmt)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants, jobject topicTenant,
+                                          jobject topics, jobject topicOff, jint nTopics, jint format) {
+    (void)c;
+    int ticket = -1;
+    const int rc = bmq_match_submit_fmt(ENGINE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
+                                        (const uint32_t*)ADDR(topicTenant), (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                        (uint32_t)nTopics, (int)format, &ticket);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_match_submit_fmt", rc);
+    return ticket;
+}
+/* long matchWaitCounts(long engine, int ticket, IntBuffer outRowPtr)   -> total fan-out of the batch; fan-out of topic i =
+ * outRowPtr[i + 1] - outRowPtr[i]: all a BatchDistReply carries (DW/DistWorkerCoProc.java:535-538) */
+JNIEXPORT jlong JNICALL NM(matchWaitCounts)(JNIEnv* env, jclass c, jlong h, jint ticket, jobject outRowPtr) {
+    (void)c;
+    uint64_t total = 0;
+    const int rc = bmq_match_wait_counts(ENGINE(h), ticket, (uint32_t*)ADDR(outRowPtr), &total);
+    return result_of(env, ENGINE(h), "bmq_match_wait_counts", rc, total);
+}
+/* long matchWaitRanges(long engine, int ticket, IntBuffer outRowPtr (may be null), IntBuffer outRangePtr, IntBuffer outRanges (begin, count pairs),
+ *                      IntBuffer outSideIds, long[] info4)   -> number of ranges, or -(needed ranges) when a buffer is too small;
+ * info4 = {ranges, side ids, ids of the batch, rows whose expanded ids the consumer must order} */
+JNIEXPORT jlong JNICALL NM(matchWaitRanges)(JNIEnv* env, jclass c, jlong h, jint ticket, jobject outRowPtr, jobject outRangePtr, jobject outRanges,
+                                            jobject outSideIds, jlongArray info4) {
+    (void)c;
+    bmq_ranges_info info;
+    const int rc = bmq_match_wait_ranges(ENGINE(h), ticket, outRowPtr ? (uint32_t*)ADDR(outRowPtr) : NULL, (uint32_t*)ADDR(outRangePtr),
+                                         (bmq_id_range*)ADDR(outRanges), CAP(outRanges) / 2, (uint32_t*)ADDR(outSideIds), CAP(outSideIds), &info);
+    if (rc == BMQ_OK || rc == BMQ_E_NOSPACE) {
+        const jlong v[4] = {(jlong)info.n_ranges, (jlong)info.n_side_ids, (jlong)info.n_ids, (jlong)info.n_overlapping_rows};
+        (*env)->SetLongArrayRegion(env, info4, 0, 4, v);
+    }
+    return result_of(env, ENGINE(h), "bmq_match_wait_ranges", rc, info.n_ranges);
+}
+/* long matchWaitGrouped(long engine, int ticket, IntBuffer outTopic, IntBuffer outRoute, IntBuffer outGroupOff, IntBuffer outGroupRep, int[] groups2)
+ *   -> number of (topic, route) pairs, or -(needed); groups2 = {groups, special bits}: what DeliverExecutorGroup.submit builds next */
+JNIEXPORT jlong JNICALL NM(matchWaitGrouped)(JNIEnv* env, jclass c, jlong h, jint ticket, jobject outTopic, jobject outRoute, jobject outGroupOff,
+                                             jobject outGroupRep, jintArray groups2) {
+    (void)c;
+    uint32_t ng = 0, special = 0;
+    uint64_t total = 0;
+    const int rc = bmq_match_wait_grouped(ENGINE(h), ticket, (uint32_t*)ADDR(outTopic), (uint32_t*)ADDR(outRoute), CAP(outTopic), (uint32_t*)ADDR(outGroupOff),
+                                          (uint32_t*)ADDR(outGroupRep), (uint32_t)CAP(outGroupRep), &ng, &special, &total);
+    const jint g[2] = {(jint)ng, (jint)special};
+    (*env)->SetIntArrayRegion(env, groups2, 0, 2, g);
+    return result_of(env, ENGINE(h), "bmq_match_wait_grouped", rc, total);
 }
 /* int routeKey(long engine, int routeId, ByteBuffer out)    -> key length; the adapter turns it into a Matching
  *                                                              (KVSchemaUtil.buildMatchRoute(routeKey, value)) */

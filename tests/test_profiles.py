@@ -6,7 +6,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, "profiles", "r02")
+R = os.path.join(ROOT, "profiles", "r03")
 
 
 def _bench(name):
@@ -42,7 +42,7 @@ def test_rocprof_trace_agrees_with_the_bench_line():
 
 def test_traffic_comes_from_the_pmc_passes():
     d = _bench("bench_c3.json")
-    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))
     t = tj["c3"]
     per = {}
     with open(os.path.join(R, "c3_pmc_hbm.csv")) as f:
@@ -55,12 +55,15 @@ def test_traffic_comes_from_the_pmc_passes():
     # the measurement is tied to the kernel sources it was taken with; bench.py reports it only while they are unchanged
     # (roofline.traffic = null + a "stale" traffic_source otherwise).  A mismatch here is therefore not an inconsistency of the
     # committed evidence, only a reminder to re-run tools/profile_round.sh + tools/collect_profiles.py before the round ends.
-    import hashlib
     import re
+    import sys
     import warnings
     assert re.fullmatch(r"[0-9a-f]{16}", tj["kernel_sources_sha"])
-    h = hashlib.sha256()
-    for fn in ("bmq_layout.h", "bmq_dist_kernels.h", "bmq_retain_kernels.h"):
-        h.update(open(os.path.join(ROOT, "bifromq_amd", "csrc", fn), "rb").read())
-    if tj["kernel_sources_sha"] != h.hexdigest()[:16]:
-        warnings.warn("profiles/traffic_r02.json was measured with older kernel sources: bench.py will not report it")
+    sys.path.insert(0, ROOT)
+    from bench import kernel_sources_sha
+    if tj["kernel_sources_sha"] != kernel_sources_sha():
+        warnings.warn("profiles/traffic_r03.json was measured with older kernel sources: bench.py will not report it")
+    # every workload's dominant kernel has its traffic (C2 / C4 were null)
+    for w in ("c2", "c4"):
+        dw = _bench("bench_%s.json" % w)
+        assert tj[w] > 0 and tj[w + "_kernel"] == dw["roofline"]["kernel"]

@@ -15,7 +15,9 @@ timeout 300 python bench.py --workload c2 --cpu-sample-topics 20000 --no-extras 
 timeout 300 python bench.py --workload c4 --no-extras > $O/bench_c4.json 2> $O/bench_c4.err
 P="--no-cpu-baseline --no-extras --batcher-threads 0"
 for w in c3 c2 c4; do
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o $w -- python bench.py --workload $w --steps 20 --warmup 5 $P > $O/kt_$w.log 2>&1
+  # (--no-host-path: only the timed loop launches the match kernels, so that the trace's AVERAGE is the average of the same launches the
+  # bench line times -- the host-visible legs run the kernels next to PCIe copies and other result formats)
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o $w -- python bench.py --workload $w --steps 20 --warmup 5 $P --no-host-path > $O/kt_$w.log 2>&1
 done
 # HBM traffic: separate counter passes, nothing else enabled (MI355X_MICROARCH.md, HBM / rocprofv3 section)
 for w in c3 c2 c4; do
