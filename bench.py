@@ -152,12 +152,35 @@ def main():
     if use_lib_ex:  # the library's own RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes
         import ctypes as C
         uid = C.create_string_buffer(128)
-        if rank == 0 and B._lib.lib().bmq_comm_unique_id(uid):
-            raise RuntimeError("bmq_comm_unique_id failed")
-        box = [uid.raw]
+        have_id = rank != 0 or B._lib.lib().bmq_comm_unique_id(uid) == 0
+        box = [uid.raw if have_id else b""]  # (no id on rank 0, e.g. no librccl: every rank learns it and takes the torch path)
         dist.broadcast_object_list(box, src=0)
-        if B._lib.lib().bmq_comm_init(eng.h, world, rank, box[0]):
-            raise RuntimeError("bmq_comm_init failed: %s" % B._lib.lib().bmq_last_error(eng.h))
+    if use_lib_ex and len(box[0]) != 128:
+        use_lib_ex = False
+    if use_lib_ex:
+        # ncclCommInitRank is collective: it runs in a helper thread so that a rank that cannot reach the others ends the run with a
+        # message instead of hanging it; a failure on ANY rank sends ALL ranks to the torch.distributed path (agreed by an all-reduce)
+        import threading
+        init_rc = [None]
+
+        def _init():
+            init_rc[0] = B._lib.lib().bmq_comm_init(eng.h, world, rank, box[0])
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(180)
+        if th.is_alive():
+            sys.stderr.write("bench.py: bmq_comm_init (ncclCommInitRank of the library's communicator) did not return within 180 s on rank %d\n" % rank)
+            sys.stderr.flush()
+            os._exit(3)
+        ok = torch.tensor([1 if init_rc[0] == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if rank == 0:
+                sys.stderr.write("bench.py: the in-library RCCL communicator could not be set up (rc %s: %s) -- exchange through torch.distributed instead\n"
+                                 % (init_rc[0], B._lib.lib().bmq_last_error(eng.h)))
+            use_lib_ex = False
+    if use_lib_ex:
         d_counts_all = [torch.zeros(world * n, dtype=torch.int32, device=dev) for _ in range(NBUF)]
         d_rows_all = [torch.zeros(world * (n + 1), dtype=torch.int32, device=dev) for _ in range(NBUF)]
         d_ids_all = [torch.zeros(world * cap, dtype=torch.int32, device=dev) for _ in range(NBUF)]
@@ -632,7 +655,17 @@ def _node_batch_run(args, rank, world, dev, dist, n, eng, tn, tt, hot, n_split_k
     m_sel = 0
     part = shard.DevicePartition(eng, d_owner, n, int(d_data.numel()), dev)  # bmq_partition_batch_dev: kernels on the engine stream
 
+    step_error = [None]
+
     def step():
+        # a rank that fails here must not leave the others waiting in the all-reduce: it contributes nothing and reports afterwards
+        try:
+            return step_body()
+        except Exception as ex:  # noqa: BLE001
+            step_error[0] = repr(ex)
+            return shard.exchange_fanout(dist, torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int64, device=dev), n)
+
+    def step_body():
         nonlocal m_sel, d_ids
         sel, pd, po, ptt, m = part(d_tt, d_data, d_off, rank)
         m_sel = m
@@ -667,6 +700,11 @@ def _node_batch_run(args, rank, world, dev, dist, n, eng, tn, tt, hot, n_split_k
     dist.all_gather_into_tensor(sel_all, tmax)
     per_rank = sel_all.view(world, 2)[:, 1].cpu().numpy()
     elapsed = float(sel_all.view(world, 2)[:, 0].max().item())
+    flag = torch.tensor([0 if step_error[0] is None else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        eng.close()
+        return {"skipped": "a step failed on at least one rank" + ("" if step_error[0] is None else ": " + step_error[0])}
     # what the imbalance would be WITHOUT the split (every publish to its tenant's owner)
     plain_owner = np.array([shard.tenant_rank(t, world) for t in tn])
     plain = np.bincount(plain_owner[tt], minlength=world)
