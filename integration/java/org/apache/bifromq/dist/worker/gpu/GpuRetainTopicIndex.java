@@ -3,9 +3,12 @@
  * (bifromq-retain/bifromq-retain-store/src/main/java/org/apache/bifromq/retain/store/index/IRetainTopicIndex.java:27-35).
  * NOT compiled in this repository (no JDK in its build image).
  *
- * The engine's retained-topic ids are RANKS of (tenant, level list): every add/remove shifts them.  The adapter therefore takes
- * a read lock around "match + resolve ids" and the write lock around add/remove -- the reference's callers already behave that
- * way: add/remove run on the range's apply thread post-commit (RetainStoreCoProc.java:240-255), match on query threads.
+ * The engine's retained-topic ids are STABLE handles (include/bmq.h): an id names the same (tenant, topic) until the next bulk load
+ * (retainInfo: generation), whatever add / remove does meanwhile -- so "match, then resolve the ids" needs no lock against the
+ * range's apply thread (RetainStoreCoProc.java:240-255), exactly as the reference's concurrent trie needs none.  A topic removed
+ * between the match and the resolution is skipped (retainTopicInfo says it is gone), which is one of the orders the reference's
+ * own race allows.  The apply loop of the coproc should hand a whole pass over as ONE NativeMatcher.retainApplyBatch; add / remove
+ * below are the single-op forms the interface asks for.
  * RetainStoreCoProc.match(limit, now) itself (RetainStoreCoProc.java:167-190) is better served by matchLimited(): the engine
  * returns the first `limit` topics that have NOT expired, so the coproc only point-gets messages it will actually return.
  */
@@ -18,13 +21,11 @@ import java.nio.LongBuffer;
 import java.nio.charset.StandardCharsets;
 import java.util.HashSet;
 import java.util.Set;
-import java.util.concurrent.locks.ReentrantReadWriteLock;
 import org.apache.bifromq.retain.store.index.IRetainTopicIndex;
 import org.apache.bifromq.retain.store.index.RetainedMsgInfo;
 
 final class GpuRetainTopicIndex implements IRetainTopicIndex {
     private final long engine;
-    private final ReentrantReadWriteLock lock = new ReentrantReadWriteLock();
 
     GpuRetainTopicIndex(long engine) {
         this.engine = engine;
@@ -41,12 +42,7 @@ final class GpuRetainTopicIndex implements IRetainTopicIndex {
         ByteBuffer ops = direct(1).put(0, op);
         LongBuffer ts = direct(8).asLongBuffer().put(0, timestamp);
         IntBuffer ex = direct(4).asIntBuffer().put(0, expirySeconds);
-        lock.writeLock().lock();
-        try {
-            NativeMatcher.retainApplyEx(engine, tenantId.getBytes(StandardCharsets.UTF_8), topics, off, ops, ts, ex, 1);
-        } finally {
-            lock.writeLock().unlock();
-        }
+        NativeMatcher.retainApplyEx(engine, tenantId.getBytes(StandardCharsets.UTF_8), topics, off, ops, ts, ex, 1);
     }
 
     @Override
@@ -71,7 +67,11 @@ final class GpuRetainTopicIndex implements IRetainTopicIndex {
         out.get(0, raw);
         int tl = (int) tenantLen[0];
         long[] stamp = new long[3];
-        NativeMatcher.retainTopicInfo(engine, id, stamp);
+        try {
+            NativeMatcher.retainTopicInfo(engine, id, stamp);
+        } catch (IllegalStateException gone) {
+            return null; // removed since the match
+        }
         return new RetainedMsgInfo(new String(raw, 0, tl, StandardCharsets.UTF_8), new String(raw, tl, len - tl, StandardCharsets.UTF_8),
             stamp[0], (int) stamp[1]);
     }
@@ -88,18 +88,16 @@ final class GpuRetainTopicIndex implements IRetainTopicIndex {
         IntBuffer row = direct(8).asIntBuffer(), counts = direct(4).asIntBuffer();
         IntBuffer ids = direct(4 * Math.max(64, limit < 0 ? 4096 : limit)).asIntBuffer();
         Set<RetainedMsgInfo> out = new HashSet<>();
-        lock.readLock().lock(); // ids are ranks: resolve them before the next add/remove can shift them
-        try {
-            long got = NativeMatcher.retainMatchLimited(engine, tenants, tenantOff, 1, ft, filters, filterOff, 1, lim, nowMs, row, ids, counts);
-            while (got < 0) {
-                ids = direct((int) (4 * -got)).asIntBuffer();
-                got = NativeMatcher.retainMatchLimited(engine, tenants, tenantOff, 1, ft, filters, filterOff, 1, lim, nowMs, row, ids, counts);
+        long got = NativeMatcher.retainMatchLimited(engine, tenants, tenantOff, 1, ft, filters, filterOff, 1, lim, nowMs, row, ids, counts);
+        while (got < 0) {
+            ids = direct((int) (4 * -got)).asIntBuffer();
+            got = NativeMatcher.retainMatchLimited(engine, tenants, tenantOff, 1, ft, filters, filterOff, 1, lim, nowMs, row, ids, counts);
+        }
+        for (int k = 0; k < got; k++) {
+            RetainedMsgInfo m = info(ids.get(k));
+            if (m != null) {
+                out.add(m);
             }
-            for (int k = 0; k < got; k++) {
-                out.add(info(ids.get(k)));
-            }
-        } finally {
-            lock.readLock().unlock();
         }
         return out;
     }
@@ -112,15 +110,19 @@ final class GpuRetainTopicIndex implements IRetainTopicIndex {
     @Override
     public Set<RetainedMsgInfo> findAll() {
         Set<RetainedMsgInfo> out = new HashSet<>();
-        lock.readLock().lock();
-        try {
-            long[] n = new long[2];
-            NativeMatcher.retainFindAll(engine, n); // the ids are 0 .. n-1
-            for (int id = 0; id < n[0]; id++) {
-                out.add(info(id));
+        long[] n = new long[2];
+        NativeMatcher.retainFindAll(engine, n);
+        IntBuffer ids = direct(4 * (int) Math.max(64, n[0] + 1024)).asIntBuffer();
+        long got = NativeMatcher.retainLiveIds(engine, null, ids); // ids are handles, not 0 .. n-1
+        while (got < 0) {
+            ids = direct((int) (4 * -got)).asIntBuffer();
+            got = NativeMatcher.retainLiveIds(engine, null, ids);
+        }
+        for (int k = 0; k < got; k++) {
+            RetainedMsgInfo m = info(ids.get(k));
+            if (m != null) {
+                out.add(m);
             }
-        } finally {
-            lock.readLock().unlock();
         }
         return out;
     }

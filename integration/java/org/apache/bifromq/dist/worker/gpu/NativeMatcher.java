@@ -90,6 +90,20 @@ final class NativeMatcher {
 
     static native void retainApply(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, ByteBuffer ops, int n);
 
+    /** Adds / removes of several tenants in one call, applied by kernels behind the batches in flight; outTopicIds may be null. */
+    static native void retainApplyBatch(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer opTenant,
+                                        ByteBuffer topics, IntBuffer topicOff, ByteBuffer ops, LongBuffer timestampHlc,
+                                        IntBuffer expirySeconds, int n, IntBuffer outTopicIds);
+
+    /** Maintenance: a fresh bulk load of the live topics (a new generation of ids). */
+    static native void retainCompact(long engine);
+
+    /** out9 = {topics, tenants, idBound, loaded, loadedRemoved, addedIds, overlayNodes, epoch, generation} */
+    static native void retainInfo(long engine, long[] out9);
+
+    /** Ids of the retained topics (of one tenant, or of all: tenant == null), ascending. @return count, or -(needed) */
+    static native long retainLiveIds(long engine, byte[] tenant, IntBuffer outIds);
+
     /** IRetainTopicIndex.add(tenantId, topic, timestamp, expirySeconds) / remove: ops[i] 0 = add, 1 = remove. */
     static native void retainApplyEx(long engine, byte[] tenant, ByteBuffer topics, IntBuffer topicOff, ByteBuffer ops,
                                      LongBuffer timestampHlc, IntBuffer expirySeconds, int n);

@@ -295,6 +295,48 @@ JNIEXPORT void JNICALL NM(retainApplyEx)(JNIEnv* env, jclass c, jlong h, jbyteAr
     (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
     if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_apply_ex", rc);
 }
+/* void retainApplyBatch(long engine, ByteBuffer tenants, IntBuffer tenantOff, int nTenants, IntBuffer opTenant, ByteBuffer topics, IntBuffer topicOff,
+ *                       ByteBuffer ops, LongBuffer timestampHlc, IntBuffer expirySeconds, int n, IntBuffer outTopicIds (may be null))
+ * the adds / removes of one pass of the coproc's apply loop (RS/RetainStoreCoProc.java:240-255), all tenants, as kernels behind the batches in flight */
+JNIEXPORT void JNICALL NM(retainApplyBatch)(JNIEnv* env, jclass c, jlong h, jobject tenants, jobject tenantOff, jint nTenants, jobject opTenant,
+                                            jobject topics, jobject topicOff, jobject ops, jobject timestampHlc, jobject expirySeconds, jint n,
+                                            jobject outTopicIds) {
+    (void)c;
+    const int rc = bmq_retain_apply_batch(ENGINE(h), (const uint8_t*)ADDR(tenants), (const uint32_t*)ADDR(tenantOff), (uint32_t)nTenants,
+                                          (const uint32_t*)ADDR(opTenant), (const uint8_t*)ADDR(topics), (const uint32_t*)ADDR(topicOff),
+                                          (const uint8_t*)ADDR(ops), (const uint64_t*)ADDR(timestampHlc), (const uint32_t*)ADDR(expirySeconds), (uint32_t)n,
+                                          outTopicIds ? (uint32_t*)ADDR(outTopicIds) : NULL);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_apply_batch", rc);
+}
+/* void retainCompact(long engine)     maintenance: a fresh bulk load of the live topics (a new generation of ids) */
+JNIEXPORT void JNICALL NM(retainCompact)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    const int rc = bmq_retain_compact(ENGINE(h));
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_compact", rc);
+}
+/* void retainInfo(long engine, long[] out9)   out = bmq_retain_info {topics, tenants, idBound, loaded, loadedRemoved, addedIds, overlayNodes, epoch, generation} */
+JNIEXPORT void JNICALL NM(retainInfo)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
+    (void)c;
+    bmq_retain_info ri;
+    const int rc = bmq_retain_info_get(ENGINE(h), &ri);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_retain_info_get", rc);
+        return;
+    }
+    const jlong v[9] = {(jlong)ri.n_topics, (jlong)ri.n_tenants, (jlong)ri.id_bound, (jlong)ri.loaded_topics, (jlong)ri.loaded_removed,
+                        (jlong)ri.added_ids, (jlong)ri.overlay_nodes, (jlong)ri.epoch, (jlong)ri.generation};
+    (*env)->SetLongArrayRegion(env, out, 0, 9, v);
+}
+/* long retainLiveIds(long engine, byte[] tenant (null: all tenants), IntBuffer outIds)    -> number of retained topics, or -(needed) */
+JNIEXPORT jlong JNICALL NM(retainLiveIds)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jobject outIds) {
+    (void)c;
+    jsize tl = tenant ? (*env)->GetArrayLength(env, tenant) : 0;
+    jbyte* tn = tenant ? (*env)->GetByteArrayElements(env, tenant, NULL) : NULL;
+    uint32_t n = 0;
+    const int rc = bmq_retain_live_ids(ENGINE(h), (const uint8_t*)tn, (uint32_t)tl, (uint32_t*)ADDR(outIds), (uint32_t)CAP(outIds), &n);
+    if (tenant) (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    return result_of(env, ENGINE(h), "bmq_retain_live_ids", rc, n);
+}
 /* void retainTopicInfo(long engine, int topicId, long[] out)     out = {timestampHlc, expirySeconds, expireAtMs} */
 JNIEXPORT void JNICALL NM(retainTopicInfo)(JNIEnv* env, jclass c, jlong h, jint id, jlongArray out) {
     (void)c;
@@ -308,7 +350,7 @@ JNIEXPORT void JNICALL NM(retainTopicInfo)(JNIEnv* env, jclass c, jlong h, jint 
     const jlong v[3] = {(jlong)ts, (jlong)ex, (jlong)at};
     (*env)->SetLongArrayRegion(env, out, 0, 3, v);
 }
-/* void retainFindAll(long engine, long[] out)      out = {number of topics (ids 0 .. n-1), retain epoch} */
+/* void retainFindAll(long engine, long[] out)      out = {number of retained topics (their ids: retainLiveIds), retain epoch} */
 JNIEXPORT void JNICALL NM(retainFindAll)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
     (void)c;
     uint64_t n = 0, ep = 0;
