@@ -328,8 +328,10 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     if (!S.clean) reset_slot(e, S, s); // first batch of the slot, buffers regrown, or a retain batch ran on it
     // ms_total: two more events per batch -- ~8 us of host time, which a launch of a few hundred topics (the batching front's) feels
     S.total_timed = e->kernel_events || a.n_topics >= 4096;
+    // Per-kernel times (bmq_config.kernel_timing) need no event of their own where a neighbouring one marks the same instant: ev[0] stands
+    // in front of k_walk, ev[5] behind k_expand unless a repair kernel runs in between -- three events per batch instead of six (~4 us each
+    // on the stream, measured).
     if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[0], s));
-    if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
         const dim3 grid(WALK_WAVES == 1 ? walk_grid_blocks(a.n_blocks) : (a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
@@ -342,11 +344,15 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     // ranges do not come out in ascending id order.  A launch that finds nothing to do still costs its slot in the stream.
     S.ran_slow = e->slow_on;
     S.ran_sort = e->sort_on;
-    if (e->slow_on) hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
-    if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[3], s));
+    if (e->slow_on) {
+        hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
+        if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[3], s));
+    }
     hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
-    if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
-    if (e->sort_on) hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
+    if (e->sort_on) {
+        if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
+        hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
+    }
     if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[5], s));
     if (S.format == BMQ_FMT_RANGES) { // the compact range lists, while the slot's counters still say whether the batch is complete
         const int frc = enqueue_ranges(e, S, a);
@@ -461,8 +467,8 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
         st.topic_bytes = c.topic_bytes;
         if (S.total_timed) (void)hipEventElapsedTime(&st.ms_total, S.ev[0], S.ev[5]);
         if (S.timed) {
-            (void)hipEventElapsedTime(&st.ms_walk, S.ev[1], S.ev[2]);
-            (void)hipEventElapsedTime(&st.ms_expand, S.ev[3], S.ev[4]);
+            (void)hipEventElapsedTime(&st.ms_walk, S.ev[0], S.ev[2]);
+            (void)hipEventElapsedTime(&st.ms_expand, S.ev[S.ran_slow ? 3 : 2], S.ev[S.ran_sort ? 4 : 5]);
         }
         if (out_total) *out_total = c.total_ids;
         if (c.status & ST_RANGE) return set_err(e, BMQ_E_RANGE, "batch produced >= 2^32 route ids");

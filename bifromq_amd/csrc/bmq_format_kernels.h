@@ -1,4 +1,4 @@
-// bmq_format_kernels.h -- gfx950 kernels of the RANGES result format (include/bmq.h: bmq_match_wait_ranges; SURVEY.md 8f-3).
+// bmq_format_kernels.h -- gfx950 kernels of the RANGES result format (include/bmq.h: bmq_match_wait_ranges; SURVEY.md 8d).
 //
 // What k_walk leaves behind for a topic is a short list of MATCHED RANGES: every matched filter node owns the route ids
 // begin .. begin + count - 1 (its routes are neighbours in KV key order, SCHEMA/KVSchemaUtil.java:91-117), or -- for nodes touched by

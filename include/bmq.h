@@ -64,7 +64,7 @@ typedef struct bmq_config {
     uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 160; 128..4096, x4)  */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t kernel_timing;    /* 1: HIP events around k_walk / k_expand of every batch -> bmq_stats.ms_walk /  */
-                               /* ms_expand (costs ~4 us per event: 16 us per batch, measured); 0: only ms_total */
+                               /* ms_expand (one extra event per batch, ~4 us on the stream); 0: only ms_total  */
     uint32_t reserved[7];
 } bmq_config;
 
@@ -199,7 +199,7 @@ int bmq_match_submit_dev(bmq_engine* e, const uint8_t* d_tenants, const uint32_t
                          int* out_ticket);
 int bmq_match_wait_dev(bmq_engine* e, int ticket, uint64_t* out_total /* may be NULL */);
 
-/* ---- host-visible result formats ------------------------------------------------------------------------------ */
+/* ---- host-visible result formats (host enqueue -> results visible on host) ------------------------------------------------------------------------------ */
 /* The id CSR of a million-topic batch is ~77 MB over PCIe -- more than twice the topics that went in.  What the callers of the
  * reference's match path do next needs less, so a ticket can be submitted for one of these formats instead (bmq_match_submit_fmt takes the
  * arguments of bmq_match_submit + the format; every format has its own wait; waiting with another format's call is BMQ_E_STATE and

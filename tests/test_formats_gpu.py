@@ -1,4 +1,4 @@
-"""Host-visible result formats of the asynchronous match (include/bmq.h BMQ_FMT_*; SURVEY.md 8f-3): fan-out counts only (what
+"""Host-visible result formats of the asynchronous match (include/bmq.h BMQ_FMT_*; SURVEY.md 8d): fan-out counts only (what
 DistWorkerCoProc.batchDist replies with, DW/DistWorkerCoProc.java:535-538), matched id ranges, pairs grouped by DelivererKey
 (DW/DeliverExecutorGroup.java:112-241).  Every format must carry exactly the information of the id CSR it stands in for."""
 import numpy as np

@@ -387,3 +387,17 @@ def test_retain_mutation_abi_on_host_only_engine():
     assert e2.retain_apply_batch(["z"], None, [(0, "k/l")]).tolist() == [0] and e2.retain_topics([0]) == [("z", "k/l")]
     e2.close()
     e.close()
+
+
+def test_expand_ranges_orders_rows_whose_ranges_interleave():
+    """The consumer side of BMQ_FMT_RANGES (bifromq_amd.Engine.expand_ranges): direct ranges, side lists, empty ranges, and a row whose ranges
+    overlap (only possible after churn) comes out ascending -- what the id CSR of the same batch holds."""
+    import bifromq_amd as B
+    S = B.Engine.RANGE_SIDE
+    side = np.array([7, 9, 40, 41, 5], dtype=np.uint32)
+    ranges = np.array([[10, 3], [0, 2 | S], [20, 0], [30, 2],      # row 0: 10..12, side[0:2] = 7, 9 -> overlap: ordered
+                       [2, 2 | S], [50, 1],                          # row 1: 40, 41, 50
+                       [4, 1 | S]], dtype=np.uint32)                 # row 3 (row 2 is empty): 5
+    rptr = np.array([0, 4, 6, 6, 7], dtype=np.uint32)
+    rows = B.Engine.expand_ranges(rptr, ranges, side, 4)
+    assert [r.tolist() for r in rows] == [[7, 9, 10, 11, 12, 30, 31], [40, 41, 50], [], [5]]
