@@ -328,10 +328,12 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     if (!S.clean) reset_slot(e, S, s); // first batch of the slot, buffers regrown, or a retain batch ran on it
     // ms_total: two more events per batch -- ~8 us of host time, which a launch of a few hundred topics (the batching front's) feels
     S.total_timed = e->kernel_events || a.n_topics >= 4096;
-    // Per-kernel times (bmq_config.kernel_timing) need no event of their own where a neighbouring one marks the same instant: ev[0] stands
-    // in front of k_walk, ev[5] behind k_expand unless a repair kernel runs in between -- three events per batch instead of six (~4 us each
-    // on the stream, measured).
+    // Per-kernel times (bmq_config.kernel_timing) need no event of their own where a neighbouring one marks the same instant: ev[5] stands
+    // behind k_expand unless a repair kernel runs in between, ev[2] in front of it -- four events per batch instead of six (~4 us each on
+    // the stream, measured).  k_walk keeps its own start event BEHIND ev[0]: the first packet after an idle stream is stamped before the
+    // queue has woken up, and ev[0] -> ev[2] read 6 us more than the kernel's own duration (rocprofv3), ev[1] -> ev[2] agrees with it.
     if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[0], s));
+    if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
         const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
         const dim3 grid(WALK_WAVES == 1 ? walk_grid_blocks(a.n_blocks) : (a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
@@ -467,7 +469,7 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
         st.topic_bytes = c.topic_bytes;
         if (S.total_timed) (void)hipEventElapsedTime(&st.ms_total, S.ev[0], S.ev[5]);
         if (S.timed) {
-            (void)hipEventElapsedTime(&st.ms_walk, S.ev[0], S.ev[2]);
+            (void)hipEventElapsedTime(&st.ms_walk, S.ev[1], S.ev[2]);
             (void)hipEventElapsedTime(&st.ms_expand, S.ev[S.ran_slow ? 3 : 2], S.ev[S.ran_sort ? 4 : 5]);
         }
         if (out_total) *out_total = c.total_ids;

@@ -64,7 +64,7 @@ typedef struct bmq_config {
     uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 160; 128..4096, x4)  */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t kernel_timing;    /* 1: HIP events around k_walk / k_expand of every batch -> bmq_stats.ms_walk /  */
-                               /* ms_expand (one extra event per batch, ~4 us on the stream); 0: only ms_total  */
+                               /* ms_expand (two extra events per batch, ~4 us each on the stream); 0: ms_total  */
     uint32_t reserved[7];
 } bmq_config;
 
