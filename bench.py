@@ -79,6 +79,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dist = None
+    # BMQ_BENCH_ONE_GPU=1 (self-test of the N > 1 code path on a 1-GPU box, tools/selftest_two_ranks.sh): every rank works on GPU 0 and the
+    # collectives go through gloo (two ranks on one GPU cannot share an RCCL communicator) -- the numbers mean nothing, the code path is the point
+    one_gpu = os.environ.get("BMQ_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
+        args.exchange_impl = "torch"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.exchange_selftest:
@@ -87,6 +93,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        elif one_gpu:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
@@ -422,7 +430,9 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
         except Exception:
             continue
-        if tj.get("kernel_sources_sha") == kernel_sources_sha():
+        if world > 1:  # the counter passes ran the single-GPU configuration (a rank of N holds 1/N of the index)
+            out["roofline"]["traffic_source"] = "profiles/%s was measured at n_gpus = 1: not reported for a shard" % tf
+        elif tj.get("kernel_sources_sha") == kernel_sources_sha():
             out["roofline"]["traffic"] = tj.get(args.workload)
             out["roofline"]["traffic_source"] = "profiles/" + tf
         else:
