@@ -30,6 +30,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "bmq_layout.h"
 
 namespace bmq {
@@ -179,6 +181,16 @@ __device__ __forceinline__ void load_line64(const void* p, Line64& r) {
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1)
                  : "v"(p));
+}
+// ... with a wave-uniform base (SGPR pair) and a 32-bit byte offset per lane: no 64-bit address arithmetic on the vector unit
+__device__ __forceinline__ void load_line64_s(const void* sbase, uint32_t voff, Line64& r) {
+    asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                 "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
+                 "global_load_dwordx4 %3, %4, %5 offset:48\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1)
+                 : "v"(voff), "s"(sbase));
 }
 // The same line fetched by the lane's QUAD.  A vector load whose 64 lanes address 64 different cache lines occupies the CU's address /
 // tag pipeline for 64 cycles, and load_line64 issues four of them per line: with 16 resident waves the vector L1 -- not the latency
@@ -583,6 +595,9 @@ __host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
 #ifndef BMQ_QUAD_LOAD
 #define BMQ_QUAD_LOAD 0 // 1: a bucket / dictionary line is fetched by the lane's quad (16 lines per request instead of 64): see load_line64_quad
 #endif
+#ifndef BMQ_WALK_UNI
+#define BMQ_WALK_UNI 1 // 1: a wave whose topics share one tenant (the normal case: batches arrive grouped by tenant) keeps the tenant's region in SGPRs
+#endif
 #ifndef BMQ_XCD_REMAP
 #define BMQ_XCD_REMAP 0 // every XCD (block b runs on XCD b % 8) works on ONE contiguous eighth of the batch: a tenant's region is cached by one L2, not by eight
 #endif
@@ -876,6 +891,13 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
             wave_sync();
     };
     bool boot = !(a.debug_flags & 1u);
+    // The tenant's region (base, bucket count): per topic in LDS -- or, when the whole wave belongs to ONE tenant, in two scalar registers:
+    // the bucket index is then one v_mul_hi against an SGPR and the line's address an SGPR base + a 32-bit lane offset.
+    const uint32_t s_rbase = __builtin_amdgcn_readfirstlane(rg.base), s_rbuckets = __builtin_amdgcn_readfirstlane(rg.buckets);
+    const bool uni_region = BMQ_WALK_UNI && WALK_ILP == 1 && !BMQ_QUAD_LOAD && uni && s_rbuckets < (1u << 25);
+    const TrieSlot* const s_rptr = a.ix.trie + s_rbase;
+    auto drain = [&](auto uni_tag) {
+    constexpr bool UNI = decltype(uni_tag)::value;
     while (boot || tail || qs_len) {
         if (!boot && tail == 0) { // the stack ran dry: take the most recently parked chunk back
             const uint4 hd = a.spill[qs_base];
@@ -924,14 +946,16 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
                     node[k] = q_node[tail + k * 64u + lane];
                     meta[k] = q_meta[tail + k * 64u + lane];
                     tmv[k] = tmeta[meta[k] & 63u];
-                    reg[k] = t_region[meta[k] & 63u];
+                    if (!UNI) reg[k] = t_region[meta[k] & 63u];
                     if (!(meta[k] & KIND_P)) tok[k] = tokens[meta_level(meta[k]) * 64 + (meta[k] & 63u)];
                 }
-                bk[k] = edge_bucket(node[k], tok[k], reg[k].y);
-                line[k] = a.ix.trie + (live[k] ? (size_t)reg[k].x + 2 * (size_t)bk[k] : (size_t)0);
+                if (UNI) reg[k] = make_uint2(s_rbase, s_rbuckets);
+                bk[k] = edge_bucket(node[k], tok[k], UNI ? s_rbuckets : reg[k].y);
+                line[k] = UNI ? nullptr : a.ix.trie + (live[k] ? (size_t)reg[k].x + 2 * (size_t)bk[k] : (size_t)0);
             }
             Line64 ln[WALK_ILP];
-            if (WALK_ILP == 2) load_line64_x2(line[0], line[WALK_ILP - 1], ln[0], ln[WALK_ILP - 1]);
+            if (UNI) load_line64_s(s_rptr, bk[0] * 64u, ln[0]); // (a lane without an item fetches some bucket of the region: harmless)
+            else if (WALK_ILP == 2) load_line64_x2(line[0], line[WALK_ILP - 1], ln[0], ln[WALK_ILP - 1]);
             else if (BMQ_QUAD_LOAD) load_line64_quad(line[0], ln[0]);
             else load_line64(line[0], ln[0]);
             wave_sync(); // every lane holds its items in registers: the stack above `tail` may be overwritten by the pushes below
@@ -949,6 +973,9 @@ __global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(Ba
         }
         sink(o, tl);
     }
+    };
+    if (uni_region) drain(std::true_type{});
+    else drain(std::false_type{});
 
     // ---- phase 3: ranges grouped by topic -> global; per-topic bookkeeping --------------------------------------
     const unsigned long long clk2 = dbg_clock(dbg_w);
