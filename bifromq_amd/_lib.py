@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get",
     "bmq_route_cache_create", "bmq_route_cache_destroy", "bmq_route_cache_get", "bmq_route_cache_get_async", "bmq_route_cache_get_batch", "bmq_batcher_match_batch", "bmq_route_cache_is_cached", "bmq_route_cache_apply",
     "bmq_route_cache_rebuild", "bmq_route_cache_reset", "bmq_route_cache_expire", "bmq_route_cache_stats_get", "bmq_route_cache_tenant_stats_get",
-    "bmq_route_cache_set_caps", "bmq_route_cache_set_event_sink", "bmq_routes_cap", "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup",
+    "bmq_route_cache_set_caps", "bmq_route_cache_set_event_sink", "bmq_routes_cap", "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup", "bmq_router_create", "bmq_router_destroy", "bmq_router_lookup_key", "bmq_router_lookup_boundary", "bmq_router_retain_lookup",
 ]
 
 
@@ -195,6 +195,11 @@ def lib() -> C.CDLL:
             "bmq_router_find_by_key": (C.c_int, [vp, vp, vp, vp, vp, u32, C.c_char_p, u32, P(i32)]),
             "bmq_router_find_by_boundary": (C.c_int, [vp, vp, vp, vp, vp, u32, C.c_uint8, C.c_char_p, u32, C.c_char_p, u32, P(u32), P(u32)]),
             "bmq_retain_range_lookup": (C.c_int, [C.c_char_p, u32, vp, vp, u32, vp, vp, vp, vp, vp, u32, u32, vp]),
+            "bmq_router_create": (C.c_int, [vp, vp, vp, vp, vp, u32, P(vp)]),
+            "bmq_router_destroy": (None, [vp]),
+            "bmq_router_lookup_key": (C.c_int, [vp, C.c_char_p, u32, P(i32)]),
+            "bmq_router_lookup_boundary": (C.c_int, [vp, C.c_uint8, C.c_char_p, u32, C.c_char_p, u32, P(u32), P(u32)]),
+            "bmq_router_retain_lookup": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, u32, vp]),
         }
         assert sorted(sig) == sorted(ABI_SYMBOLS)
         for name, (res, args) in sig.items():

@@ -11,6 +11,7 @@
 #include "bmq_codec.h"
 
 #include <cstring>
+#include <memory>
 #include <optional>
 #include <string>
 #include <string_view>
@@ -171,13 +172,11 @@ int bmq_router_find_by_boundary(const uint8_t* range_flags, const uint8_t* start
     return BMQ_OK;
 }
 
-int bmq_retain_range_lookup(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filters, const uint32_t* filter_off, uint32_t n_filters,
-                            const uint8_t* range_flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end,
-                            const uint32_t* end_off, uint32_t n_ranges, uint32_t mode, uint8_t* out_keep) {
+static int retain_range_lookup(const Router& r, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filters, const uint32_t* filter_off,
+                               uint32_t n_filters, uint32_t mode, uint8_t* out_keep) {
+    const uint32_t n_ranges = (uint32_t)r.b.size();
     if (mode > BMQ_ROUTER_EXACT) return BMQ_E_INVAL;
     if ((n_filters && (!filters || !filter_off)) || (n_filters && n_ranges && !out_keep)) return BMQ_E_INVAL;
-    Router r;
-    if (int rc = load_router(r, range_flags, start, start_off, end, end_off, n_ranges)) return rc;
     const std::string_view tn((const char*)tenant, tenant_len);
     std::string tenant_begin; // KVSchemaUtil.tenantBeginKey
     tenant_begin.push_back('\0');
@@ -271,6 +270,62 @@ int bmq_retain_range_lookup(const uint8_t* tenant, uint32_t tenant_len, const ui
         }
     }
     return BMQ_OK;
+}
+
+int bmq_retain_range_lookup(const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filters, const uint32_t* filter_off, uint32_t n_filters,
+                            const uint8_t* range_flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end,
+                            const uint32_t* end_off, uint32_t n_ranges, uint32_t mode, uint8_t* out_keep) {
+    Router r;
+    if (int rc = load_router(r, range_flags, start, start_off, end, end_off, n_ranges)) return rc;
+    return retain_range_lookup(r, tenant, tenant_len, filters, filter_off, n_filters, mode, out_keep);
+}
+
+// ---- the router as an object: the boundaries are copied, checked and indexed ONCE (the reference keeps its TreeMap between calls too:
+// KVRangeRouter is rebuilt only when the range landscape changes, base-kv/base-kv-store-client/.../KVRangeRouter.java) ----
+struct bmq_router {
+    std::string start_bytes, end_bytes; // own copies: the views of `r` point into them
+    Router r;
+};
+
+int bmq_router_create(const uint8_t* range_flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end, const uint32_t* end_off,
+                      uint32_t n_ranges, bmq_router** out) {
+    if (!out) return BMQ_E_INVAL;
+    *out = nullptr;
+    if (n_ranges && (!range_flags || !start_off || !end_off)) return BMQ_E_INVAL;
+    auto h = std::make_unique<bmq_router>();
+    if (n_ranges) {
+        if (start_off[n_ranges] && !start) return BMQ_E_INVAL;
+        if (end_off[n_ranges] && !end) return BMQ_E_INVAL;
+        h->start_bytes.assign((const char*)start, start_off[n_ranges]);
+        h->end_bytes.assign((const char*)end, end_off[n_ranges]);
+    }
+    if (int rc = load_router(h->r, range_flags, (const uint8_t*)h->start_bytes.data(), start_off, (const uint8_t*)h->end_bytes.data(), end_off, n_ranges))
+        return rc;
+    *out = h.release();
+    return BMQ_OK;
+}
+void bmq_router_destroy(bmq_router* h) { delete h; }
+int bmq_router_lookup_key(const bmq_router* h, const uint8_t* key, uint32_t key_len, int32_t* out_index) {
+    if (!h || !out_index || (key_len && !key)) return BMQ_E_INVAL;
+    *out_index = (int32_t)h->r.find_by_key(std::string_view((const char*)key, key_len));
+    return BMQ_OK;
+}
+int bmq_router_lookup_boundary(const bmq_router* h, uint8_t query_flags, const uint8_t* q_start, uint32_t q_start_len, const uint8_t* q_end,
+                               uint32_t q_end_len, uint32_t* out_first, uint32_t* out_count) {
+    if (!h || !out_first || !out_count) return BMQ_E_INVAL;
+    Bnd q;
+    if (query_flags & 1) q.start = std::string_view((const char*)q_start, q_start_len);
+    if (query_flags & 2) q.end = std::string_view((const char*)q_end, q_end_len);
+    size_t lo, hi;
+    h->r.find_by_boundary(q, lo, hi);
+    *out_first = (uint32_t)lo;
+    *out_count = (uint32_t)(hi - lo);
+    return BMQ_OK;
+}
+int bmq_router_retain_lookup(const bmq_router* h, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filters, const uint32_t* filter_off,
+                             uint32_t n_filters, uint32_t mode, uint8_t* out_keep) {
+    if (!h || (tenant_len && !tenant)) return BMQ_E_INVAL;
+    return retain_range_lookup(h->r, tenant, tenant_len, filters, filter_off, n_filters, mode, out_keep);
 }
 
 } // extern "C"

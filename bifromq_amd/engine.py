@@ -118,9 +118,33 @@ class RangeRouter:
     def _args(self):
         return (_ptr(self.flags), _ptr(self.start), _ptr(self.start_off), _ptr(self.end), _ptr(self.end_off), self.n)
 
+    def build(self):
+        """bmq_router_create: copy, check and index the boundaries once; the lookups below then go through the object."""
+        if getattr(self, "h", None) is None:
+            h = C.c_void_p()
+            rc = _lib.lib().bmq_router_create(*self._args(), C.byref(h))
+            if rc < 0:
+                raise BmqError(rc, "bmq_router_create")
+            self.h = h
+        return self
+
+    def close(self):
+        if getattr(self, "h", None) is not None:
+            _lib.lib().bmq_router_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def find_by_key(self, key: bytes):
         out = C.c_int32()
-        rc = _lib.lib().bmq_router_find_by_key(*self._args(), key, len(key), C.byref(out))
+        if getattr(self, "h", None) is not None:
+            rc = _lib.lib().bmq_router_lookup_key(self.h, key, len(key), C.byref(out))
+        else:
+            rc = _lib.lib().bmq_router_find_by_key(*self._args(), key, len(key), C.byref(out))
         if rc < 0:
             raise BmqError(rc, "bmq_router_find_by_key")
         return None if out.value < 0 else out.value
@@ -128,8 +152,11 @@ class RangeRouter:
     def find_by_boundary(self, start, end):
         first, count = C.c_uint32(), C.c_uint32()
         fl = (1 if start is not None else 0) | (2 if end is not None else 0)
-        rc = _lib.lib().bmq_router_find_by_boundary(*self._args(), fl, start or b"", len(start or b""), end or b"", len(end or b""),
-                                                    C.byref(first), C.byref(count))
+        q = (fl, start or b"", len(start or b""), end or b"", len(end or b""), C.byref(first), C.byref(count))
+        if getattr(self, "h", None) is not None:
+            rc = _lib.lib().bmq_router_lookup_boundary(self.h, *q)
+        else:
+            rc = _lib.lib().bmq_router_find_by_boundary(*self._args(), *q)
         if rc < 0:
             raise BmqError(rc, "bmq_router_find_by_boundary")
         return list(range(first.value, first.value + count.value))
@@ -139,7 +166,10 @@ class RangeRouter:
         t = _b(tenant)
         fb, fo = pack(topic_filters)
         keep = np.zeros((len(topic_filters), self.n), dtype=np.uint8)
-        rc = _lib.lib().bmq_retain_range_lookup(t, len(t), _ptr(fb), _ptr(fo), len(topic_filters), *self._args(), 1 if exact else 0, _ptr(keep))
+        if getattr(self, "h", None) is not None:
+            rc = _lib.lib().bmq_router_retain_lookup(self.h, t, len(t), _ptr(fb), _ptr(fo), len(topic_filters), 1 if exact else 0, _ptr(keep))
+        else:
+            rc = _lib.lib().bmq_retain_range_lookup(t, len(t), _ptr(fb), _ptr(fo), len(topic_filters), *self._args(), 1 if exact else 0, _ptr(keep))
         if rc < 0:
             raise BmqError(rc, "bmq_retain_range_lookup")
         return [np.nonzero(keep[i])[0].tolist() for i in range(len(topic_filters))]

@@ -547,6 +547,19 @@ int bmq_retain_range_lookup(const uint8_t* tenant, uint32_t tenant_len, const ui
                             const uint8_t* range_flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end,
                             const uint32_t* end_off, uint32_t n_ranges, uint32_t mode, uint8_t* out_keep);
 
+/* The same three lookups over a router OBJECT: the boundaries are copied, checked and indexed once and asked many times (the reference
+ * keeps its TreeMap between calls as well and rebuilds it only when the range landscape changes).  n_ranges of bmq_router_retain_lookup's
+ * out_keep rows = the n_ranges the router was created with.  A router is immutable: any number of threads may ask it. */
+typedef struct bmq_router bmq_router;
+int bmq_router_create(const uint8_t* range_flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end,
+                      const uint32_t* end_off, uint32_t n_ranges, bmq_router** out);
+void bmq_router_destroy(bmq_router* r);
+int bmq_router_lookup_key(const bmq_router* r, const uint8_t* key, uint32_t key_len, int32_t* out_index);
+int bmq_router_lookup_boundary(const bmq_router* r, uint8_t query_flags, const uint8_t* q_start, uint32_t q_start_len, const uint8_t* q_end,
+                               uint32_t q_end_len, uint32_t* out_first, uint32_t* out_count);
+int bmq_router_retain_lookup(const bmq_router* r, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* filters,
+                             const uint32_t* filter_off, uint32_t n_filters, uint32_t mode, uint8_t* out_keep);
+
 /* ---- retain direction (RS/index/IRetainTopicIndex.java:27-35) -------------------------------------------- */
 /* A retained-topic id is a STABLE handle, like a route id: a bulk load (bmq_retain_rebuild*, bmq_retain_compact) numbers the topics by
  * the rank of (tenant, level list) in byte order -- tenants in byte order of their ids, a tenant's topics level list by level list, so

@@ -131,6 +131,14 @@ final class NativeMatcher {
                                          ByteBuffer start, IntBuffer startOff, ByteBuffer end, IntBuffer endOff, int nRanges, int mode,
                                          ByteBuffer outKeep);
 
+    /** The effective router as an object (built when the range landscape changes, asked per request). */
+    static native long routerCreate(ByteBuffer rangeFlags, ByteBuffer start, IntBuffer startOff, ByteBuffer end, IntBuffer endOff, int nRanges);
+
+    static native void routerDestroy(long router);
+
+    static native void routerRetainLookup(long router, byte[] tenant, ByteBuffer filters, IntBuffer filterOff, int nFilters, int mode,
+                                          ByteBuffer outKeep);
+
     // ---- fan-out grouping ----
     /** (topic, route) pairs of a match batch regrouped by DelivererKey; out = {nGroups, special}. @return pairs, or -(groups needed) */
     static native long fanoutGroup(long engine, IntBuffer rowPtr, IntBuffer routeIds, int nTopics, IntBuffer outTopic, IntBuffer outRoute,

@@ -425,6 +425,34 @@ JNIEXPORT void JNICALL NM(retainRangeLookup)(JNIEnv* env, jclass c, jbyteArray t
     if (rc != BMQ_OK) throw_state(env, NULL, "bmq_retain_range_lookup", rc);
 }
 
+/* long routerCreate(ByteBuffer rangeFlags, ByteBuffer start, IntBuffer startOff, ByteBuffer end, IntBuffer endOff, int nRanges)
+ * the effective router as an object: built when the range landscape changes (as the reference rebuilds its TreeMap), asked per request */
+JNIEXPORT jlong JNICALL NM(routerCreate)(JNIEnv* env, jclass c, jobject rangeFlags, jobject start, jobject startOff, jobject end, jobject endOff,
+                                         jint nRanges) {
+    (void)c;
+    bmq_router* r = NULL;
+    const int rc = bmq_router_create((const uint8_t*)ADDR(rangeFlags), (const uint8_t*)ADDR(start), (const uint32_t*)ADDR(startOff),
+                                     (const uint8_t*)ADDR(end), (const uint32_t*)ADDR(endOff), (uint32_t)nRanges, &r);
+    if (rc != BMQ_OK) throw_state(env, NULL, "bmq_router_create", rc);
+    return (jlong)(intptr_t)r;
+}
+JNIEXPORT void JNICALL NM(routerDestroy)(JNIEnv* env, jclass c, jlong router) {
+    (void)env;
+    (void)c;
+    bmq_router_destroy((bmq_router*)(intptr_t)router);
+}
+/* void routerRetainLookup(long router, byte[] tenant, ByteBuffer filters, IntBuffer filterOff, int nFilters, int mode, ByteBuffer outKeep) */
+JNIEXPORT void JNICALL NM(routerRetainLookup)(JNIEnv* env, jclass c, jlong router, jbyteArray tenant, jobject filters, jobject filterOff,
+                                              jint nFilters, jint mode, jobject outKeep) {
+    (void)c;
+    const jsize tl = (*env)->GetArrayLength(env, tenant);
+    jbyte* tn = (*env)->GetByteArrayElements(env, tenant, NULL);
+    const int rc = bmq_router_retain_lookup((const bmq_router*)(intptr_t)router, (const uint8_t*)tn, (uint32_t)tl, (const uint8_t*)ADDR(filters),
+                                            (const uint32_t*)ADDR(filterOff), (uint32_t)nFilters, (uint32_t)mode, (uint8_t*)ADDR(outKeep));
+    (*env)->ReleaseByteArrayElements(env, tenant, tn, JNI_ABORT);
+    if (rc != BMQ_OK) throw_state(env, NULL, "bmq_router_retain_lookup", rc);
+}
+
 /* ---- fan-out grouping ---- */
 /* long fanoutGroup(long engine, IntBuffer rowPtr, IntBuffer routeIds, int nTopics, IntBuffer outTopic, IntBuffer outRoute,
  *                  IntBuffer outGroupOff, IntBuffer outGroupRep, long[] out)       out = {nGroups, special}

@@ -16,6 +16,21 @@ NULL_BOUNDARY = (None, b"")
 TENANT = "testTenant"
 
 
+@pytest.fixture(autouse=True, params=["arrays", "object"])
+def router_form(request, monkeypatch):
+    """Every test runs twice: lookups over the caller's arrays (the router is indexed per call) and over a router OBJECT built once
+    (bmq_router_create: the boundaries are copied, checked and indexed once) -- the two forms must agree with the oracle alike."""
+    if request.param == "object":
+        plain_init = RangeRouter.__init__
+
+        def init_and_build(self, boundaries):
+            plain_init(self, boundaries)
+            self.build()
+
+        monkeypatch.setattr(RangeRouter, "__init__", init_and_build)
+    return request.param
+
+
 def _abcd_router():
     # (null,"b") ["b","c") ["c","d") ["d",null)   KVRangeRouterUtilTest.java:66-117
     return [(None, b"b"), (b"b", b"c"), (b"c", b"d"), (b"d", None)]
