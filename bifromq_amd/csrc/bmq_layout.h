@@ -33,7 +33,10 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;        // empty slot / no child / node id
 constexpr uint32_t TOK_UNKNOWN = 0;           // level string not in the dictionary
 constexpr uint32_t TOK_PLUS = 1;              // the '+' edge
 constexpr uint32_t TOK_FIRST = 2;             // first dictionary token
-constexpr int FAST_LEVELS = 16;               // topics with more levels take the slow path
+#ifndef BMQ_FAST_LEVELS
+#define BMQ_FAST_LEVELS 16
+#endif
+constexpr int FAST_LEVELS = BMQ_FAST_LEVELS;  // topics with more levels take the slow path
                                               // (Setting.MaxTopicLevels default, Setting.java:45)
 constexpr uint32_t RANGE_INDIRECT = 0x80000000u; // count flag: begin indexes route_pos[] instead of being the first id
 constexpr uint32_t BLOOM_PLUS = 0x80000000u;     // lit_bloom bit 31: the node has a '+' child

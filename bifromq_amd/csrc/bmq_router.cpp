@@ -118,6 +118,12 @@ struct Router {
 int load_router(Router& r, const uint8_t* flags, const uint8_t* start, const uint32_t* start_off, const uint8_t* end, const uint32_t* end_off,
                 uint32_t n) {
     if (n && (!flags || !start_off || !end_off)) return BMQ_E_INVAL;
+    // offsets: start at 0 and never decrease, so that every view below lies inside [0, off[n]) of its byte array (the router object
+    // copies exactly off[n] bytes: a decreasing or oversized offset would build views outside the copy and underflow their lengths)
+    if (n && (start_off[0] != 0 || end_off[0] != 0)) return BMQ_E_INVAL;
+    for (uint32_t i = 0; i < n; i++)
+        if (start_off[i] > start_off[i + 1] || end_off[i] > end_off[i + 1]) return BMQ_E_INVAL;
+    if (n && ((start_off[n] && !start) || (end_off[n] && !end))) return BMQ_E_INVAL;
     r.b.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         if (flags[i] & 1) r.b[i].start = std::string_view((const char*)start + start_off[i], start_off[i + 1] - start_off[i]);
@@ -160,6 +166,7 @@ int bmq_router_find_by_boundary(const uint8_t* range_flags, const uint8_t* start
                                 const uint32_t* end_off, uint32_t n_ranges, uint8_t query_flags, const uint8_t* q_start, uint32_t q_start_len,
                                 const uint8_t* q_end, uint32_t q_end_len, uint32_t* out_first, uint32_t* out_count) {
     if (!out_first || !out_count) return BMQ_E_INVAL;
+    if (((query_flags & 1) && q_start_len && !q_start) || ((query_flags & 2) && q_end_len && !q_end)) return BMQ_E_INVAL;
     Router r;
     if (int rc = load_router(r, range_flags, start, start_off, end, end_off, n_ranges)) return rc;
     Bnd q;
@@ -313,6 +320,7 @@ int bmq_router_lookup_key(const bmq_router* h, const uint8_t* key, uint32_t key_
 int bmq_router_lookup_boundary(const bmq_router* h, uint8_t query_flags, const uint8_t* q_start, uint32_t q_start_len, const uint8_t* q_end,
                                uint32_t q_end_len, uint32_t* out_first, uint32_t* out_count) {
     if (!h || !out_first || !out_count) return BMQ_E_INVAL;
+    if (((query_flags & 1) && q_start_len && !q_start) || ((query_flags & 2) && q_end_len && !q_end)) return BMQ_E_INVAL;
     Bnd q;
     if (query_flags & 1) q.start = std::string_view((const char*)q_start, q_start_len);
     if (query_flags & 2) q.end = std::string_view((const char*)q_end, q_end_len);

@@ -493,9 +493,11 @@ JNIEXPORT jlong JNICALL NM(routeCacheCreate)(JNIEnv* env, jclass c, jlong h, jlo
     return (jlong)(intptr_t)rc_;
 }
 /* void routeCacheDestroy(long cache) */
+static void sink_drop(JNIEnv* env, bmq_route_cache* cache);
 JNIEXPORT void JNICALL NM(routeCacheDestroy)(JNIEnv* env, jclass c, jlong h) {
-    (void)env, (void)c;
-    bmq_route_cache_destroy(CACHE(h));
+    (void)c;
+    bmq_route_cache_destroy(CACHE(h)); /* no getter is inside any more (the caller's contract): nobody calls the sink from here on */
+    sink_drop(env, CACHE(h));
 }
 /* long routeCacheGet(long cache, byte[] tenant, byte[] topic, long nowMs, IntBuffer outIds, long[] epochOut)
  * ISubscriptionCache.get(tenantId, topic): -> number of route ids, or -(needed); a hit never leaves the host */
@@ -664,41 +666,87 @@ JNIEXPORT void JNICALL NM(routeCacheSetCaps)(JNIEnv* env, jclass c, jlong h, jby
 /* void routeCacheSetEventSink(long cache, ThrottleSink sink)
  * sink.onThrottle(byte[] tenant, byte[] topic, int type, int routeId, int maxCount) is IEventCollector.report(PersistentFanoutThrottled
  * (type 0) / GroupFanoutThrottled (type 1)), MatchedRoutes.java:95-101,124-130; it runs on the thread that completes the load (a Java
- * matcher thread, or the dispatcher thread of the batching front).  One sink per process (a global ref that lives as long as the JVM). */
-static jobject g_sink;
-static jmethodID g_on_throttle;
+ * matcher thread, or the dispatcher thread of the batching front).  One sink PER CACHE: a dist worker hosts one GpuSubscriptionCache per
+ * range and each installs a lambda that resolves route ids against ITS range's index -- the sink object travels as the `user` pointer of
+ * bmq_route_cache_set_event_sink (a global ref held in a registry entry of the cache), it is deleted when the sink is replaced or cleared
+ * and when the cache is destroyed.  (Round 3 kept one global sink per process: the events of the second and later caches went to the
+ * first cache's lambda.) */
+typedef struct sink_entry {
+    struct sink_entry* next;
+    bmq_route_cache* cache;
+    jobject ref; /* global ref of the cache's ThrottleSink */
+} sink_entry;
+static sink_entry* g_sinks;
+static pthread_mutex_t g_sinks_mu = PTHREAD_MUTEX_INITIALIZER;
+static jmethodID g_on_throttle; /* ThrottleSink.onThrottle([B[BIII)V, looked up once (all sinks implement the one interface) */
 static void throttle_event(void* user, const uint8_t* tenant, uint32_t tl, const uint8_t* topic, uint32_t pl, int32_t type, uint32_t route_id,
                            int32_t max_count) {
-    (void)user;
+    sink_entry* se = (sink_entry*)user;
     JNIEnv* env = env_of_this_thread();
-    if (!env || !g_sink || !g_on_throttle) return;
+    if (!env || !se || !se->ref || !g_on_throttle) return;
     jbyteArray jt = (*env)->NewByteArray(env, (jsize)tl), jp = (*env)->NewByteArray(env, (jsize)pl);
     if (jt && jp) {
         if (tl) (*env)->SetByteArrayRegion(env, jt, 0, (jsize)tl, (const jbyte*)tenant);
         if (pl) (*env)->SetByteArrayRegion(env, jp, 0, (jsize)pl, (const jbyte*)topic);
-        (*env)->CallVoidMethod(env, g_sink, g_on_throttle, jt, jp, (jint)type, (jint)route_id, (jint)max_count);
+        (*env)->CallVoidMethod(env, se->ref, g_on_throttle, jt, jp, (jint)type, (jint)route_id, (jint)max_count);
     }
     if ((*env)->ExceptionCheck(env)) (*env)->ExceptionClear(env);
     if (jt) (*env)->DeleteLocalRef(env, jt);
     if (jp) (*env)->DeleteLocalRef(env, jp);
 }
+/* unlinks the cache's registry entry (the cache no longer calls it: its sink was replaced, cleared, or the cache is gone) and frees its ref */
+static void sink_drop(JNIEnv* env, bmq_route_cache* cache) {
+    sink_entry* dead = NULL;
+    pthread_mutex_lock(&g_sinks_mu);
+    for (sink_entry** pp = &g_sinks; *pp; pp = &(*pp)->next)
+        if ((*pp)->cache == cache) {
+            dead = *pp;
+            *pp = dead->next;
+            break;
+        }
+    pthread_mutex_unlock(&g_sinks_mu);
+    if (dead) {
+        if (dead->ref) (*env)->DeleteGlobalRef(env, dead->ref);
+        free(dead);
+    }
+}
 JNIEXPORT void JNICALL NM(routeCacheSetEventSink)(JNIEnv* env, jclass c, jlong h, jobject sink) {
     (void)c;
     if (!g_vm) (*env)->GetJavaVM(env, &g_vm);
-    if (!sink) {
+    if (!sink) { /* reporting off: first the cache stops calling, then the reference goes */
         (void)bmq_route_cache_set_event_sink(CACHE(h), NULL, NULL);
+        sink_drop(env, CACHE(h));
         return;
     }
-    if (!g_sink) {
+    if (!g_on_throttle) {
         jclass cls = (*env)->GetObjectClass(env, sink);
         g_on_throttle = (*env)->GetMethodID(env, cls, "onThrottle", "([B[BIII)V");
         (*env)->DeleteLocalRef(env, cls);
         if (!g_on_throttle) return; /* NoSuchMethodError is pending */
-        g_sink = (*env)->NewGlobalRef(env, sink);
-        if (!g_sink) return; /* OutOfMemoryError is pending */
     }
-    const int rc = bmq_route_cache_set_event_sink(CACHE(h), throttle_event, NULL);
-    if (rc != BMQ_OK) throw_state(env, NULL, "bmq_route_cache_set_event_sink", rc);
+    sink_entry* se = (sink_entry*)calloc(1, sizeof *se);
+    if (!se) {
+        throw_state(env, NULL, "routeCacheSetEventSink: out of memory", BMQ_E_NOMEM);
+        return;
+    }
+    se->cache = CACHE(h);
+    se->ref = (*env)->NewGlobalRef(env, sink);
+    if (!se->ref) { /* OutOfMemoryError is pending */
+        free(se);
+        return;
+    }
+    const int rc = bmq_route_cache_set_event_sink(CACHE(h), throttle_event, se); /* from here on the cache calls the NEW entry only */
+    if (rc != BMQ_OK) {
+        (*env)->DeleteGlobalRef(env, se->ref);
+        free(se);
+        throw_state(env, NULL, "bmq_route_cache_set_event_sink", rc);
+        return;
+    }
+    sink_drop(env, CACHE(h)); /* the entry this one replaces, if any */
+    pthread_mutex_lock(&g_sinks_mu);
+    se->next = g_sinks;
+    g_sinks = se;
+    pthread_mutex_unlock(&g_sinks_mu);
 }
 /* boolean routeCacheTenantStats(long cache, byte[] tenant, long[] out)     out[0..4] = hits, misses, evictions, entries, cached routes --
  * the MqttRouteCacheHitCount / MissCount / EvictCount counters and the MqttRouteCacheSize gauge of TenantRouteCache.java:141-147;

@@ -199,6 +199,45 @@ def test_router_argument_checks():
     assert O.router_find_by_boundary((b"a", b"b"), [(b"x", b"y")]) == []
 
 
+def test_router_rejects_hostile_offsets(router_form):
+    """Offsets that decrease, do not start at 0, or reach beyond the byte arrays are refused (BMQ_E_INVAL) instead of building views
+    outside the router object's own copy of the boundaries; a query boundary flagged present with a NULL pointer is refused too."""
+    import ctypes as C
+
+    from bifromq_amd import _lib
+
+    for damage in ("decreasing", "nonzero_first", "end_decreasing"):
+        r = object.__new__(RangeRouter)
+        bs = _abcd_router()
+        r.n = len(bs)
+        import numpy as np
+
+        from bifromq_amd.engine import pack
+        r.flags = np.array([(1 if s is not None else 0) | (2 if e is not None else 0) for s, e in bs], dtype=np.uint8)
+        r.start, r.start_off = pack([s or b"" for s, _ in bs])
+        r.end, r.end_off = pack([e or b"" for _, e in bs])
+        r.h = None
+        if damage == "decreasing":
+            r.start_off[2] = 0xFFFFFFF0
+        elif damage == "nonzero_first":
+            r.start_off[0] = 1
+        else:
+            r.end_off[1], r.end_off[2] = r.end_off[2] + 1, r.end_off[1]
+        with pytest.raises(BmqError):
+            if router_form == "object":
+                r.build()
+            else:
+                r.find_by_key(b"a")
+    good = RangeRouter(_abcd_router())
+    first, count = C.c_uint32(), C.c_uint32()
+    L = _lib.lib()
+    if router_form == "object":
+        rc = L.bmq_router_lookup_boundary(good.h, 1, None, 3, b"", 0, C.byref(first), C.byref(count))
+    else:
+        rc = L.bmq_router_find_by_boundary(*good._args(), 1, None, 3, b"", 0, C.byref(first), C.byref(count))
+    assert rc < 0
+
+
 def test_router_under_sanitizers():
     """tools/router_fuzz.cpp: bmq_router.cpp under ASan + UBSan with hostile boundary keys (empty, truncated inside the key header,
     all 0xFF, other tenants'): a lookup succeeds or reports BMQ_E_INVAL, find_by_boundary returns exactly the overlapping ranges, EXACT
