@@ -9,7 +9,7 @@
 //   (no prologue)     : the batch's tenants are resolved by the walk kernels themselves (a wave's topics usually share one
 //                       tenant: the directory lookup then runs on the scalar unit); the batch counters are zeroed BEHIND the
 //                       previous batch of the slot (k_reset) -- a batch starts on its walk kernel.
-//   k_walk            : one wave per 64 topics, WALK_WAVES independent waves per workgroup (own LDS slice each).
+//   k_walk<LV,QC,PC>  : (bmq_walk_kernel.h) one wave = one workgroup per 64 topics.
 //                       Phase 1: tenant directory entry; the wave stages its topics' bytes in LDS with coalesced 16-byte loads, then walks
 //                       them level by level: every lane scans its own next level (LDS only), then ALL lanes look
 //                       their level up in the dictionary together -- one memory latency per level, not per lane.
@@ -44,7 +44,8 @@ enum : uint32_t {
     ST_NOSPACE = 8u,        // caller's id buffer too small
     ST_RANGE = 16u,         // >= 2^32 ids
     ST_NEED_SORTLIST = 32u, // fix-up list too small
-    ST_NEED_SPILL = 64u     // range spill buffer too small
+    ST_NEED_SPILL = 64u,    // range spill buffer too small
+    ST_WANT_MIXED = 256u    // a wave held topics of many tenants (the batch is not grouped by tenant): the batch runs again through the MIXED instantiation
 };
 constexpr uint32_t ST_RERUN = ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH | ST_NEED_SPILL;
 
@@ -192,82 +193,6 @@ __device__ __forceinline__ void load_line64_s(const void* sbase, uint32_t voff, 
                  : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1)
                  : "v"(voff), "s"(sbase));
 }
-// The same line fetched by the lane's QUAD.  A vector load whose 64 lanes address 64 different cache lines occupies the CU's address /
-// tag pipeline for 64 cycles, and load_line64 issues four of them per line: with 16 resident waves the vector L1 -- not the latency
-// of L2 / HBM -- sets the duration of a walk round (measured, profiles/r03: two lines per lane and round left the phase's duration
-// unchanged; a round costs ~5 k clocks ~= 16 waves x 256 cycles).  Here lane 4q + j asks for bytes 16 j .. 16 j + 15 of the line of
-// lane 4q + r in request r = 0..3: every request touches 16 lines instead of 64, the four lanes of a quad share one.  The 4 x 4
-// (request x lane) block a quad holds afterwards is transposed with two DPP butterfly stages, so that every lane ends up with ITS
-// line as before.  All 64 lanes must call it together (inactive work passes any readable address).
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_quad(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
-template <int CTRL> __device__ __forceinline__ void quad_swap(uint4& lo, uint4& hi, bool upper) { // 2 x 2 block transpose across lanes differing in one quad bit
-    const uint4 x = make_uint4(dpp_quad<CTRL>(lo.x), dpp_quad<CTRL>(lo.y), dpp_quad<CTRL>(lo.z), dpp_quad<CTRL>(lo.w));
-    const uint4 y = make_uint4(dpp_quad<CTRL>(hi.x), dpp_quad<CTRL>(hi.y), dpp_quad<CTRL>(hi.z), dpp_quad<CTRL>(hi.w));
-    if (upper) lo = y; // the upper lane of the pair takes the lower lane's `hi` ...
-    else hi = x;       // ... the lower lane the upper lane's `lo`
-}
-__device__ __forceinline__ void load_line64_quad(const void* p, Line64& r) {
-    const uint32_t sub = threadIdx.x & 3u;
-    const uint64_t a = (uint64_t)(uintptr_t)p;
-    const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32);
-    const uint64_t p0 = (((uint64_t)dpp_quad<0x00>(ahi) << 32) | dpp_quad<0x00>(alo)) + 16u * sub;
-    const uint64_t p1 = (((uint64_t)dpp_quad<0x55>(ahi) << 32) | dpp_quad<0x55>(alo)) + 16u * sub;
-    const uint64_t p2 = (((uint64_t)dpp_quad<0xAA>(ahi) << 32) | dpp_quad<0xAA>(alo)) + 16u * sub;
-    const uint64_t p3 = (((uint64_t)dpp_quad<0xFF>(ahi) << 32) | dpp_quad<0xFF>(alo)) + 16u * sub;
-    uint4 v0, v1, v2, v3;
-    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
-                 "global_load_dwordx4 %1, %5, off\n\t"
-                 "global_load_dwordx4 %2, %6, off\n\t"
-                 "global_load_dwordx4 %3, %7, off\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
-                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
-    // v_r of lane 4q + j = part j of the line of lane 4q + r: transpose the quad's 4 x 4 block
-    quad_swap<0xB1>(v0, v1, (sub & 1u) != 0); // quad_perm [1,0,3,2]
-    quad_swap<0xB1>(v2, v3, (sub & 1u) != 0);
-    quad_swap<0x4E>(v0, v2, (sub & 2u) != 0); // quad_perm [2,3,0,1]
-    quad_swap<0x4E>(v1, v3, (sub & 2u) != 0);
-    r.a0 = v0, r.a1 = v1, r.b0 = v2, r.b1 = v3;
-}
-// two independent lines, eight loads in flight, ONE wait: the walk's rounds are latency bound, two items per lane halve their number
-__device__ __forceinline__ void load_line64_x2(const void* p, const void* q, Line64& r, Line64& t) {
-    asm volatile("global_load_dwordx4 %0, %8, off\n\t"
-                 "global_load_dwordx4 %1, %8, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %8, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %8, off offset:48\n\t"
-                 "global_load_dwordx4 %4, %9, off\n\t"
-                 "global_load_dwordx4 %5, %9, off offset:16\n\t"
-                 "global_load_dwordx4 %6, %9, off offset:32\n\t"
-                 "global_load_dwordx4 %7, %9, off offset:48\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1), "=&v"(t.a0), "=&v"(t.a1), "=&v"(t.b0), "=&v"(t.b1)
-                 : "v"(p), "v"(q));
-}
-// the HEADERS (tag, token, len, pool_off) of both slots of four dictionary groups: eight loads, one wait
-__device__ __forceinline__ void load_dict_headers_x4(const DictSlot* g0, const DictSlot* g1, const DictSlot* g2, const DictSlot* g3, uint4 (&ha)[4],
-                                                      uint4 (&hb)[4]) {
-    asm volatile("global_load_dwordx4 %0, %8, off\n\t"
-                 "global_load_dwordx4 %1, %8, off offset:32\n\t"
-                 "global_load_dwordx4 %2, %9, off\n\t"
-                 "global_load_dwordx4 %3, %9, off offset:32\n\t"
-                 "global_load_dwordx4 %4, %10, off\n\t"
-                 "global_load_dwordx4 %5, %10, off offset:32\n\t"
-                 "global_load_dwordx4 %6, %11, off\n\t"
-                 "global_load_dwordx4 %7, %11, off offset:32\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(ha[0]), "=&v"(hb[0]), "=&v"(ha[1]), "=&v"(hb[1]), "=&v"(ha[2]), "=&v"(hb[2]), "=&v"(ha[3]), "=&v"(hb[3])
-                 : "v"(g0), "v"(g1), "v"(g2), "v"(g3));
-}
-// the 16 inline bytes of four slots (the lines were just fetched: these hit the vector L1)
-__device__ __forceinline__ void load_dict_inline_x4(const DictSlot* s0, const DictSlot* s1, const DictSlot* s2, const DictSlot* s3, uint4 (&in)[4]) {
-    asm volatile("global_load_dwordx4 %0, %4, off offset:16\n\t"
-                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %6, off offset:16\n\t"
-                 "global_load_dwordx4 %3, %7, off offset:16\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(in[0]), "=&v"(in[1]), "=&v"(in[2]), "=&v"(in[3])
-                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3));
-}
 // ------------------------------------------------------------------------------------------------------------
 // dictionary lookup (exact: tag + length + bytes).  ONE latency: the whole home group (one 64-byte line) is requested together.
 // byte_at(i) returns byte i of the string buffer the level lives in (LDS-staged or global).
@@ -295,29 +220,6 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
         g = (g + 1) & ix.dict_group_mask;
     }
     return TOK_UNKNOWN;
-}
-
-// The same with the home group fetched by the lane's quad (load_line64_quad): ALL 64 lanes call it together, `active` says whose level
-// is real.  A home group full of other strings (rare at load factor 1/4) falls back to the probing lookup above.
-template <class ByteAt>
-__device__ __forceinline__ uint32_t dict_lookup_quad(const DistIndexView& ix, bool active, const LevelHash& h, uint32_t len, const uint32_t inl[4],
-                                                     uint32_t start, ByteAt&& byte_at) {
-    const uint32_t tag = level_hash_tag(h);
-    const uint32_t g = active ? (level_hash_slot(h, len) & ix.dict_group_mask) : 0u;
-    Line64 ln;
-    load_line64_quad(ix.dict + DICT_GROUP * (size_t)g, ln);
-    if (!active) return TOK_UNKNOWN;
-    auto tail_eq = [&](uint32_t pool_off) {
-        bool eq = true;
-        for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[pool_off + i] == byte_at(start + i);
-        return eq;
-    };
-    const bool h0 = ln.a0.x == tag && ln.a0.z == len && ln.a1.x == inl[0] && ln.a1.y == inl[1] && ln.a1.z == inl[2] && ln.a1.w == inl[3];
-    const bool h1 = ln.b0.x == tag && ln.b0.z == len && ln.b1.x == inl[0] && ln.b1.y == inl[1] && ln.b1.z == inl[2] && ln.b1.w == inl[3];
-    if (h0 && (len <= 16 || tail_eq(ln.a0.w))) return ln.a0.y;
-    if (h1 && (len <= 16 || tail_eq(ln.b0.w))) return ln.b0.y;
-    if (ln.a0.x == 0 || ln.b0.x == 0) return TOK_UNKNOWN;
-    return dict_lookup(ix, h, len, inl, start, byte_at);
 }
 
 // Scans one level starting at pos: bytes up to the next '/' (split) or to `end`, FOUR BYTES PER STEP.
@@ -567,496 +469,9 @@ __device__ __forceinline__ unsigned long long dbg_clock(bool on) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     return __builtin_amdgcn_s_memtime();
 }
-// ------------------------------------------------------------------------------------------------------------
-// k_walk -- one wave (= one 64-thread workgroup) per 64 topics
-// ------------------------------------------------------------------------------------------------------------
-// tmeta bits: 0-7 level count (<= FAST_LEVELS), 8 sys, 9 flagged (more than FAST_LEVELS levels -> slow path)
-constexpr uint32_t TM_SYS = 1u << 8, TM_FLAG = 1u << 9;
-#ifndef BMQ_WALK_WAVES
-#define BMQ_WALK_WAVES 1
-#endif
-constexpr uint32_t WALK_WAVES = BMQ_WALK_WAVES; // waves per k_walk workgroup
-
-__host__ __device__ inline size_t walk_union_words(uint32_t qcap, uint32_t pcap) { return 2 * (size_t)qcap + 3 * (size_t)pcap; }
-constexpr uint32_t WALK_TOPIC_WORDS = 6 * 64; // per-topic arrays, behind the union
-__host__ __device__ inline size_t walk_lds_bytes(uint32_t qcap, uint32_t pcap) {
-    return (sizeof(uint32_t) * ((size_t)FAST_LEVELS * 64 + WALK_TOPIC_WORDS + walk_union_words(qcap, pcap)) + 15) & ~(size_t)15;
-}
-
-#ifndef BMQ_WALK_MIN_WAVES
-#define BMQ_WALK_MIN_WAVES 4
-#endif
-#ifndef BMQ_TOK_CHUNK
-#define BMQ_TOK_CHUNK 0 // 1: tokenise four levels per dictionary round trip (headers of all four home groups in flight together); 0: one level per trip
-#endif
-#ifndef BMQ_WALK_ILP
-#define BMQ_WALK_ILP 1 // work items per lane per round of the walk (their bucket lines are requested together, one wait)
-#endif
-#ifndef BMQ_QUAD_LOAD
-#define BMQ_QUAD_LOAD 0 // 1: a bucket / dictionary line is fetched by the lane's quad (16 lines per request instead of 64): see load_line64_quad
-#endif
-#ifndef BMQ_WALK_UNI
-#define BMQ_WALK_UNI 1 // 1: a wave whose topics share one tenant (the normal case: batches arrive grouped by tenant) keeps the tenant's region in SGPRs
-#endif
-#ifndef BMQ_XCD_REMAP
-#define BMQ_XCD_REMAP 0 // every XCD (block b runs on XCD b % 8) works on ONE contiguous eighth of the batch: a tenant's region is cached by one L2, not by eight
-#endif
-constexpr uint32_t WALK_ILP = BMQ_WALK_ILP;
-static_assert(WALK_ILP == 1 || WALK_ILP == 2, "one or two work items per lane");
-__host__ __device__ inline uint32_t walk_grid_blocks(uint32_t n_blocks) { // blocks to launch for n_blocks 64-topic waves
-#if BMQ_XCD_REMAP
-    return ((n_blocks + 7u) / 8u) * 8u;
-#else
-    return n_blocks;
-#endif
-}
-__global__ __launch_bounds__(WALK_WAVES * 64, BMQ_WALK_MIN_WAVES) void k_walk(BatchArgs a) {
-    extern __shared__ __align__(16) uint32_t lds_all[];
-    // WALK_WAVES independent waves per workgroup: every wave owns its own slice of LDS and never synchronises with its
-    // neighbours.  Measured on C3 (profiles/r01): 1 wave per workgroup 0.308 ms, 2 waves 0.317 ms, 4 waves 0.320 ms -- 16 waves
-    // per CU in all three (9.6 KB of LDS per wave), single-wave groups retire and refill a little faster.
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* lds = lds_all + wave * (walk_lds_bytes(a.qcap, a.pcap) / 4);
-    uint32_t* tokens = lds;                                   // [FAST_LEVELS][64]
-    uint32_t* un = tokens + FAST_LEVELS * 64;                 // staged topic bytes (phase 1) | everything below (phases 2, 3)
-    uint32_t* q_node = un;                                    // [qcap] work stack
-    uint32_t* q_meta = q_node + a.qcap;                       // [qcap]
-    uint32_t* p_begin = q_meta + a.qcap;                      // [pcap] range buffer
-    uint32_t* p_count = p_begin + a.pcap;                     // [pcap]
-    uint32_t* p_topic = p_count + a.pcap;                     // [pcap]
-    uint32_t* tmeta = un + walk_union_words(a.qcap, a.pcap);  // [64]
-    uint32_t* cnt_pairs = tmeta + 64;                         // [64]
-    uint32_t* cnt_routes = cnt_pairs + 64;                    // [64]
-    uint32_t* cursor = cnt_routes + 64;                       // [64]
-    uint2* t_region = reinterpret_cast<uint2*>(cursor + 64);  // [64] (region base, buckets) of each topic's tenant
-    const uint32_t stage_bytes = (uint32_t)(walk_union_words(a.qcap, a.pcap) + WALK_TOPIC_WORDS) * 4u;
-
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t blk = blockIdx.x * WALK_WAVES + wave;
-#if BMQ_XCD_REMAP
-    static_assert(WALK_WAVES == 1, "the XCD remap assumes one wave per workgroup");
-    { // (WALK_WAVES == 1.)  Observed, used for speed only: block b runs on XCD b % 8 -- XCD x takes the x-th eighth of the batch.
-        const uint32_t per = (a.n_blocks + 7u) / 8u;
-        blk = (blk & 7u) * per + (blk >> 3);
-    }
-#endif
-    if (blk >= a.n_blocks) return;
-    // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
-    // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
-    blk = a.n_blocks - 1 - blk;
-    // A wave owns TPW = 2^tpw_shift consecutive topics.  64 for large batches; a small batch is spread over more waves (16 or 4
-    // topics each): the walk phase is a chain of dependent line fetches whose length is ~ max(depth, items / 64), so a wave with
-    // fewer topics finishes sooner and a 10 k-topic batch fills the chip instead of 157 waves on 256 CUs.
-    const uint32_t tpw = 1u << a.tpw_shift;
-    const uint32_t t = (blk << a.tpw_shift) + lane;
-    const bool valid = lane < tpw && t < a.n_topics;
-    const bool dbg_w = a.dbg_wave && (a.debug_flags & 2u);
-    const unsigned long long clk0 = dbg_w ? __builtin_amdgcn_s_memtime() : 0ull;
-
-    // ---- phase 1: tokenise ---------------------------------------------------------------------------------------------
-    const uint32_t t_first = blk << a.tpw_shift, t_end = min(t_first + tpw, a.n_topics);
-    const uint32_t s_beg = a.topic_off[t_first], s_end = a.topic_off[t_end]; // wave-uniform
-    const uint32_t a0 = s_beg & ~15u;
-    const bool staged = (s_end - a0) + 32u <= stage_bytes;
-    if (staged) { // coalesced 16-byte copies of the wave's contiguous topic bytes into LDS
-        uint4* dst = reinterpret_cast<uint4*>(un);
-        const uint4* src = reinterpret_cast<const uint4*>(a.topics + a0);
-        const uint32_t n16 = (s_end - a0 + 15) >> 4;
-        for (uint32_t o = lane; o < n16; o += 64) dst[o] = src[o];
-    }
-    wave_sync();
-    const unsigned long long clkA = dbg_clock(dbg_w); // topic bytes staged
-    const uint8_t* lbytes = reinterpret_cast<const uint8_t*>(un);
-    const uint8_t* gbytes = a.topics;
-    auto byte_at = [&](uint32_t i) -> uint32_t { return staged ? (uint32_t)lbytes[i - a0] : (uint32_t)gbytes[i]; };
-    auto word_at = [&](uint32_t i) -> uint32_t {
-        if (!staged) return global_word_at(gbytes, i);
-        const uint32_t rel = i - a0;
-        return __builtin_amdgcn_alignbyte(un[(rel >> 2) + 1], un[rel >> 2], rel & 3u);
-    };
-
-    uint32_t nlev = 0, tbytes = 0, pos = 0, end = 0, ti = 0;
-    bool sys = false, more = false, t_ok = false;
-    if (valid) {
-        pos = a.topic_off[t];
-        end = a.topic_off[t + 1];
-        tbytes = end - pos;
-        ti = a.topic_tenant[t];
-        t_ok = ti < a.n_tenants;
-        more = t_ok; // (a topic of a tenant the index does not know is tokenised for nothing: rare, and the answer comes late)
-        sys = more && end > pos && byte_at(pos) == '$';
-    }
-    // The tenant's directory entry.  A wave's topics usually share one tenant (batches arrive grouped by tenant): then the lookup
-    // is wave-uniform and runs on the scalar unit -- it costs the vector memory pipeline, which bounds this kernel, nothing.  A
-    // wave that straddles tenants resolves per lane, one request per tokeniser iteration (they land under the dictionary waits).
-    const uint32_t ti0 = __builtin_amdgcn_readfirstlane(ti); // lane 0 is valid in every wave that exists
-    const bool uni = __all(!valid || ti == ti0);
-    TenantSlot rg = EMPTY_TENANT;
-    if (uni) {
-        if (ti0 < a.n_tenants) rg = resolve_tenant_uniform(a, ti0);
-        more = more && tenant_known(rg); // unknown tenant: no routes, nothing to tokenise
-    }
-    TenantQuery tq;
-    uint32_t l = 0;
-    const unsigned long long clkB = dbg_clock(dbg_w); // offsets loaded, tenant resolved
-#if BMQ_TOK_CHUNK
-    // Four levels per trip to the dictionary: every lane scans its next four levels (LDS only), the headers of their four home
-    // groups are requested together (eight 16-byte loads, one wait), then the inline bytes of the slots whose tag + length fit
-    // (four loads that hit the vector L1, one wait).  A topic of up to four levels costs one dependent round trip instead of
-    // four, one of five to eight levels two: round 2 measured the level-by-level loop at 28 % of the kernel.
-    if (staged) {
-        for (; __any(more); l++) {
-            if (!uni && l < 3 && t_ok) tenant_stage(a, ti, tq, l);
-            uint32_t cstart[4], clen[4], ctag[4], cgrp[4]; // (the level's bytes stay in LDS: they are compared from there)
-            bool cval[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                cval[k] = more;
-                cstart[k] = pos;
-                clen[k] = ctag[k] = cgrp[k] = 0;
-                if (more) {
-                    LevelHash h;
-                    uint32_t inl[4];
-                    bool last;
-                    scan_level(pos, end, true, word_at, h, inl, clen[k], last);
-                    nlev++;
-                    ctag[k] = level_hash_tag(h);
-                    cgrp[k] = level_hash_slot(h, clen[k]) & a.ix.dict_group_mask;
-                    more = !last;
-                }
-            }
-            uint4 ha[4], hb[4], in[4];
-            const DictSlot* grp[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) grp[k] = a.ix.dict + DICT_GROUP * (size_t)cgrp[k];
-            load_dict_headers_x4(grp[0], grp[1], grp[2], grp[3], ha, hb);
-            const DictSlot* pick[4];
-            uint32_t verdict[4]; // 0: slot chosen, verify its bytes; 1: not in the dictionary; 2: ask the probing lookup
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const bool m0 = ha[k].x == ctag[k] && ha[k].z == clen[k], m1 = hb[k].x == ctag[k] && hb[k].z == clen[k];
-                pick[k] = grp[k] + (m1 && !m0 ? 1 : 0);
-                verdict[k] = (m0 != m1) ? 0u : ((m0 && m1) ? 2u : ((ha[k].x == 0 || hb[k].x == 0) ? 1u : 2u));
-                if (m1 && !m0) ha[k] = hb[k]; // the chosen slot's header
-            }
-            load_dict_inline_x4(pick[0], pick[1], pick[2], pick[3], in);
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                if (!cval[k]) continue;
-                uint32_t tok = TOK_UNKNOWN;
-                if (verdict[k] == 0) {
-                    // the slot's 16 inline bytes (zero padded) against the level's bytes in LDS
-                    const uint32_t iw[4] = {in[k].x, in[k].y, in[k].z, in[k].w};
-                    bool eq = true;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        const uint32_t nb = clen[k] > 4 * j ? min(4u, clen[k] - 4 * j) : 0u;
-                        const uint32_t w = nb ? word_at(cstart[k] + 4 * j) : 0u;
-                        eq = eq && iw[j] == (nb >= 4 ? w : (w & ((1u << (8u * nb)) - 1u)));
-                    }
-                    for (uint32_t i = 16; i < clen[k] && eq; i++) eq = a.ix.pool[ha[k].w + i] == byte_at(cstart[k] + i);
-                    if (eq) tok = ha[k].y;
-                    else verdict[k] = (ha[k].x == ctag[k] && hb[k].x == ctag[k]) ? 2u : ((hb[k].x == 0 || ha[k].x == 0) ? 1u : 2u);
-                }
-                if (verdict[k] == 2) { // two candidates, or a full home group: the probing lookup (rare)
-                    LevelHash h;
-                    uint32_t inl2[4], len2, p2 = cstart[k];
-                    bool last2;
-                    scan_level(p2, end, true, word_at, h, inl2, len2, last2);
-                    tok = dict_lookup(a.ix, h, len2, inl2, cstart[k], byte_at);
-                }
-                if (4 * l + k < FAST_LEVELS) tokens[(4 * l + k) * 64 + lane] = tok;
-            }
-        }
-    } else
-#endif
-    for (; __any(more); l++) {
-        if (!uni && l < 3 && t_ok) tenant_stage(a, ti, tq, l);
-        LevelHash h = level_hash_init();
-        uint32_t inl[4] = {0, 0, 0, 0}, len = 0;
-        const uint32_t start = pos;
-        const bool mine = more;
-        if (more) {
-            bool last;
-            scan_level(pos, end, true, word_at, h, inl, len, last);
-            nlev++;
-            more = !last;
-        }
-#if BMQ_QUAD_LOAD
-        const uint32_t tok = dict_lookup_quad(a.ix, mine, h, len, inl, start, byte_at); // (all lanes: the quads fetch their lines together)
-#else
-        const uint32_t tok = mine ? dict_lookup(a.ix, h, len, inl, start, byte_at) : TOK_UNKNOWN;
-#endif
-        if (mine && l < FAST_LEVELS) tokens[l * 64 + lane] = tok;
-    }
-    if (!uni) {
-        for (uint32_t st = l; st < 3; st++) // a wave of topics with fewer than three levels
-            if (t_ok) tenant_stage(a, ti, tq, st);
-        if (t_ok) rg = tenant_verdict(a, tq);
-    }
-    const bool known = valid && tenant_known(rg);
-    const bool deep = nlev > FAST_LEVELS;
-    const bool active = known && !deep;
-    wave_sync(); // staged bytes are dead from here on: the area becomes stack + range buffer + per-topic arrays
-    tmeta[lane] = (deep ? 0u : nlev) | (sys ? TM_SYS : 0u) | (deep ? TM_FLAG : 0u);
-    cnt_pairs[lane] = 0;
-    cnt_routes[lane] = 0;
-    t_region[lane] = make_uint2(rg.base, rg.buckets);
-
-    // ---- phase 2: drain the work stack ----------------------------------------------------------------------------
-    // The work list is a STACK (newest items first): depth-first order keeps it at a few pending siblings per topic,
-    // where breadth-first order would have to hold a whole frontier level of all 64 topics.
-    // Neither LDS list bounds the walk: a full range buffer is flushed to, and a full stack parked in, the global spill
-    // area, as chunks {header record, payload records}; the header links to the wave's previous chunk of the same kind
-    // (base, length; length 0 ends the chain), so the bookkeeping is two wave-uniform registers per chain.
-    // Only topics with more than FAST_LEVELS levels are flagged (TM_FLAG, set above) and they never enter the stack: every
-    // item popped below belongs to a live topic, and a lane may count the nodes it discovers in a register.
-    uint32_t tail = 0, pcount = 0, rounds = 0, items = 0, my_visits = 0;
-    uint32_t fl_base = 0, fl_len = 0; // last flushed range chunk
-    uint32_t qs_base = 0, qs_len = 0; // last parked stack chunk (LIFO)
-    auto spill_alloc = [&](uint32_t n, uint32_t& base) -> bool { // wave-uniform; n payload records + header
-        unsigned long long sb = 0;
-        uint32_t ok = 1;
-        if (lane == 0) ok = pair_alloc(a.subs + N_SUB, a.spill_cap, blk, n + 1, sb) ? 1u : 0u;
-        sb = __shfl(sb, 0);
-        const bool fits = __shfl(ok, 0) != 0 && sb + n + 1 < 0xFFFFFFFFull;
-        if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_SPILL); // the batch is re-run with a larger area
-        base = (uint32_t)sb;
-        return fits;
-    };
-    const unsigned long long clk1 = dbg_clock(dbg_w);
-    // Round 0 visits the tenant roots: their slot payload came with the directory entry, so no line is fetched.
-    // what a resolved item leaves behind: its matched ranges go into the LDS range buffer, its children onto the stack
-    auto sink = [&](const StepOut& o, uint32_t tl) {
-            const unsigned long long m_own = __ballot(o.emit_own), m_hash = __ballot(o.emit_hash);
-            const unsigned long long m_l = __ballot(o.push_l), m_h = __ballot(o.push_h);
-            const uint32_t n_own = (uint32_t)__popcll(m_own), n_emit = n_own + (uint32_t)__popcll(m_hash);
-            // matched ranges -> LDS buffer; when this round's matches do not fit, the buffer is flushed to the spill area first
-            if (n_emit) {
-                if (pcount + n_emit > a.pcap) {
-                    for (uint32_t i = lane; i < pcount; i += 64) { // per-topic range / id counts of what leaves the buffer
-                        atomicAdd(&cnt_pairs[p_topic[i]], 1u);
-                        atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
-                    }
-                    uint32_t cb;
-                    if (spill_alloc(pcount, cb)) {
-                        if (lane == 0) a.spill[cb] = make_uint4(fl_base, fl_len, 0u, 0u);
-                        for (uint32_t i = lane; i < pcount; i += 64) a.spill[cb + 1 + i] = make_uint4(p_begin[i], p_count[i], p_topic[i], 0u);
-                        fl_base = cb;
-                        fl_len = pcount;
-                    }
-                    pcount = 0;
-                    wave_sync();
-                }
-                if (o.emit_own) {
-                    const uint32_t p = pcount + rank_below(m_own);
-                    p_begin[p] = o.s.own_begin;
-                    p_count[p] = o.s.own_count;
-                    p_topic[p] = tl;
-                }
-                if (o.emit_hash) {
-                    const uint32_t p = pcount + n_own + rank_below(m_hash);
-                    p_begin[p] = o.s.hash_begin;
-                    p_count[p] = o.s.hash_count;
-                    p_topic[p] = tl;
-                }
-                pcount += n_emit;
-            }
-            // children -> stack; if they do not fit, the pending (older) items are parked and the walk goes on with the children
-            if (m_l | m_h) {
-                const uint32_t n_l = (uint32_t)__popcll(m_l), n_push = n_l + (uint32_t)__popcll(m_h);
-                if (tail + n_push > a.qcap) {
-                    uint32_t cb;
-                    if (spill_alloc(tail, cb)) {
-                        if (lane == 0) a.spill[cb] = make_uint4(qs_base, qs_len, 0u, 0u);
-                        for (uint32_t i = lane; i < tail; i += 64) a.spill[cb + 1 + i] = make_uint4(q_node[i], q_meta[i], 0u, 0u);
-                        qs_base = cb;
-                        qs_len = tail;
-                    }
-                    tail = 0;
-                    wave_sync();
-                }
-                if (o.push_l) {
-                    const uint32_t p = tail + rank_below(m_l);
-                    q_node[p] = o.idx;
-                    q_meta[p] = make_meta(tl, o.dl, 0);
-                }
-                if (o.push_h) {
-                    const uint32_t p = tail + n_l + rank_below(m_h);
-                    q_node[p] = o.idx;
-                    q_meta[p] = make_meta(tl, o.dl, KIND_P);
-                }
-                tail += n_push;
-            }
-            wave_sync();
-    };
-    bool boot = !(a.debug_flags & 1u);
-    // The tenant's region (base, bucket count): per topic in LDS -- or, when the whole wave belongs to ONE tenant, in two scalar registers:
-    // the bucket index is then one v_mul_hi against an SGPR and the line's address an SGPR base + a 32-bit lane offset.
-    const uint32_t s_rbase = __builtin_amdgcn_readfirstlane(rg.base), s_rbuckets = __builtin_amdgcn_readfirstlane(rg.buckets);
-    const bool uni_region = BMQ_WALK_UNI && WALK_ILP == 1 && !BMQ_QUAD_LOAD && uni && s_rbuckets < (1u << 25);
-    const TrieSlot* const s_rptr = a.ix.trie + s_rbase;
-    auto drain = [&](auto uni_tag) {
-    constexpr bool UNI = decltype(uni_tag)::value;
-    while (boot || tail || qs_len) {
-        if (!boot && tail == 0) { // the stack ran dry: take the most recently parked chunk back
-            const uint4 hd = a.spill[qs_base];
-            for (uint32_t i = lane; i < qs_len; i += 64) {
-                const uint4 r = a.spill[qs_base + 1 + i];
-                q_node[i] = r.x;
-                q_meta[i] = r.y;
-            }
-            tail = qs_len;
-            qs_base = hd.x;
-            qs_len = hd.y;
-            wave_sync();
-        }
-        StepOut o;
-        uint32_t tl = lane;
-        if (boot) {
-            boot = false;
-            o.found = active;
-            o.idx = 0; // the tenant root's node id
-            o.dl = 0;
-            o.s = TrieSlot{NONE, 0, 0, 0, rg.root_hash_begin, rg.root_hash_count, 0, rg.root_lit_bloom};
-            o.emit_own = false; // a topic has at least one level
-            o.emit_hash = active && rg.root_hash_count != 0 && !sys; // the filter "#"; never for '$' topics
-            const uint32_t t0 = active ? tokens[lane] : TOK_UNKNOWN;
-            o.push_l = active && t0 != TOK_UNKNOWN && ((rg.root_lit_bloom >> bloom_bit(t0)) & 1u);
-            o.push_h = active && (rg.root_lit_bloom & BLOOM_PLUS) != 0 && !sys; // a first-level '+' never matches a '$' topic
-        } else {
-            // WALK_ILP items per lane: the bucket lines of all of them are requested together and waited for once -- a round costs one
-            // memory round trip however many items it carries, and rounds are what the walk's duration consists of (profiles/r02:
-            // 19 rounds of ~49 items, ~5 k clocks each)
-            const uint32_t take = tail < WALK_ILP * 64u ? tail : WALK_ILP * 64u;
-            tail -= take;
-            rounds++;
-            items += take;
-            uint32_t node[WALK_ILP], meta[WALK_ILP], tmv[WALK_ILP], tok[WALK_ILP], bk[WALK_ILP];
-            uint2 reg[WALK_ILP];
-            bool live[WALK_ILP];
-            const TrieSlot* line[WALK_ILP];
-#pragma unroll
-            for (uint32_t k = 0; k < WALK_ILP; k++) {
-                live[k] = k * 64u + lane < take;
-                node[k] = meta[k] = tmv[k] = 0;
-                reg[k] = make_uint2(0u, 1u);
-                tok[k] = TOK_PLUS;
-                if (live[k]) {
-                    node[k] = q_node[tail + k * 64u + lane];
-                    meta[k] = q_meta[tail + k * 64u + lane];
-                    tmv[k] = tmeta[meta[k] & 63u];
-                    if (!UNI) reg[k] = t_region[meta[k] & 63u];
-                    if (!(meta[k] & KIND_P)) tok[k] = tokens[meta_level(meta[k]) * 64 + (meta[k] & 63u)];
-                }
-                if (UNI) reg[k] = make_uint2(s_rbase, s_rbuckets);
-                bk[k] = edge_bucket(node[k], tok[k], UNI ? s_rbuckets : reg[k].y);
-                line[k] = UNI ? nullptr : a.ix.trie + (live[k] ? (size_t)reg[k].x + 2 * (size_t)bk[k] : (size_t)0);
-            }
-            Line64 ln[WALK_ILP];
-            if (UNI) load_line64_s(s_rptr, bk[0] * 64u, ln[0]); // (a lane without an item fetches some bucket of the region: harmless)
-            else if (WALK_ILP == 2) load_line64_x2(line[0], line[WALK_ILP - 1], ln[0], ln[WALK_ILP - 1]);
-            else if (BMQ_QUAD_LOAD) load_line64_quad(line[0], ln[0]);
-            else load_line64(line[0], ln[0]);
-            wave_sync(); // every lane holds its items in registers: the stack above `tail` may be overwritten by the pushes below
-#pragma unroll
-            for (uint32_t k = 0; k < WALK_ILP; k++) {
-                if (k && take <= 64u) break; // wave-uniform
-                StepOut ok;
-                const uint32_t tlc = meta[k] & 63u;
-                resolve_item(a.ix, ln[k], live[k], node[k], tok[k], bk[k], reg[k].x, reg[k].y, meta_level(meta[k]), tmv[k] & 0xFFu, (tmv[k] & TM_SYS) != 0,
-                             [&](uint32_t lv) { return tokens[lv * 64 + tlc]; }, ok);
-                my_visits += ok.found ? 1u : 0u;
-                sink(ok, tlc);
-            }
-            continue;
-        }
-        sink(o, tl);
-    }
-    };
-    if (uni_region) drain(std::true_type{});
-    else drain(std::false_type{});
-
-    // ---- phase 3: ranges grouped by topic -> global; per-topic bookkeeping --------------------------------------
-    const unsigned long long clk2 = dbg_clock(dbg_w);
-    for (uint32_t i = lane; i < pcount; i += 64) { // counted here, once per range, instead of two LDS atomics per match
-        atomicAdd(&cnt_pairs[p_topic[i]], 1u);
-        atomicAdd(&cnt_routes[p_topic[i]], p_count[i] & ~RANGE_INDIRECT);
-    }
-    wave_sync();
-    const uint32_t tm = tmeta[lane];
-    const bool flagged = (tm & TM_FLAG) != 0;
-    const uint32_t np = flagged ? 0u : cnt_pairs[lane];
-    const uint32_t nr = flagged ? 0u : cnt_routes[lane];
-    uint32_t total_pairs;
-    const uint32_t excl = wave_excl_scan(np, lane, total_pairs);
-    unsigned long long base = 0;
-    uint32_t fits_l = 1;
-    if (lane == 0 && total_pairs) fits_l = pair_alloc(a.subs, a.pair_cap, blk, total_pairs, base) ? 1u : 0u;
-    base = __shfl(base, 0);
-    const bool fits = __shfl(fits_l, 0) != 0;
-    if (!fits && lane == 0) atomicOr(&a.ctr->status, ST_NEED_PAIRS);
-    cursor[lane] = excl;
-    wave_sync();
-    if (fits && total_pairs) {
-        // flushed chunks first, OLDEST first (the chain runs newest to oldest: it is laid out in the dead stack area and
-        // replayed backwards), then what is still in LDS: every topic's ranges stay in discovery order, which is close to
-        // ascending id order and keeps the ordering work of k_expand small
-        auto copy_chunk = [&](uint32_t cb, uint32_t cl) {
-            for (uint32_t i = lane; i < cl; i += 64) {
-                const uint4 r = a.spill[cb + 1 + i];
-                const uint32_t dst = atomicAdd(&cursor[r.z], 1u);
-                a.pairs[base + dst] = MatchRange{r.x, r.y};
-            }
-        };
-        uint32_t n_ch = 0;
-        for (uint32_t cb = fl_base, cl = fl_len; cl;) {
-            const uint4 hd = a.spill[cb];
-            if (n_ch < a.qcap) {
-                q_node[n_ch] = cb; // all lanes store the same values
-                q_meta[n_ch] = cl;
-                n_ch++;
-            } else copy_chunk(cb, cl); // a chain longer than the stack area: order is only a matter of speed
-            cb = hd.x;
-            cl = hd.y;
-        }
-        wave_sync();
-        while (n_ch) {
-            n_ch--;
-            copy_chunk(q_node[n_ch], q_meta[n_ch]);
-        }
-        for (uint32_t i = lane; i < pcount; i += 64) {
-            const uint32_t tl = p_topic[i];
-            const uint32_t dst = atomicAdd(&cursor[tl], 1u);
-            a.pairs[base + dst] = MatchRange{p_begin[i], p_count[i]};
-        }
-    }
-    if (valid) {
-        a.pair_off[t] = (uint32_t)(base + excl); // pair_cap < 2^32 is enforced by the host
-        a.pair_cnt[t] = np;
-        a.route_cnt[t] = nr;
-        if (flagged) {
-            const uint32_t sp = atomicAdd(&a.ctr->slow_count, 1u);
-            if (sp < a.slow_cap) a.slow_list[sp] = t;
-            else atomicOr(&a.ctr->status, ST_NEED_SLOW);
-        }
-    }
-    const unsigned long long wsum = wave_sum_u64(nr);
-    const unsigned long long wvis = wave_sum_u64(my_visits);
-    const unsigned long long wbytes = wave_sum_u64(tbytes);
-    if (lane == 0) {
-        a.wave_sums[blk] = wsum;
-        if (wsum) atomicAdd(&a.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], wsum);
-        // statistics: a plain store per wave.  (Atomics were measured twice: on the batch counters they set the kernel's duration,
-        // three more per wave on the super-block's line still cost +20 us per 1 M topics and +7 us per 10 k.)
-        a.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
-        if (dbg_w) {
-            const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
-            a.dbg_wave[blk] = make_uint4((uint32_t)(clk1 - clk0), (uint32_t)(clk2 - clk1), (uint32_t)(clk3 - clk2), rounds | (items << 8));
-            a.dbg_wave[a.n_blocks + blk] = make_uint4((uint32_t)(clkA - clk0), (uint32_t)(clkB - clkA), (uint32_t)(clk1 - clkB), 0u); // phase 1 in detail
-        }
-    }
-}
+} // namespace bmq
+#include "bmq_walk_kernel.h" // k_walk<LV, QC, PC>: one wave (= one 64-thread workgroup) per 64 topics
+namespace bmq {
 
 // ------------------------------------------------------------------------------------------------------------
 // k_walk_slow -- per-lane depth-first walk, tokens + stack in global scratch, two passes (count, write)

@@ -103,6 +103,9 @@ struct bmq_engine {
     bool built = false;
     bool slow_on = false, sort_on = false; // the repair kernels are in the pipeline (see launch_dist)
     uint32_t slow_idle = 0, sort_idle = 0; // consecutive batches that ran them for nothing
+    bool mixed_on = false;                 // k_walk runs in its MIXED instantiation (batches are not grouped by tenant)
+    uint32_t mixed_idle = 0;
+    int walk_geom = 0;                     // LDS geometry of k_walk: 0 default, 2 smallest lists (bmq_config caps <= 128)
     bool kernel_events = false; // bmq_config.kernel_timing: HIP events around k_walk / k_expand of every dist batch (~4 us each)
 
     // Everything ONE batch in flight needs: per-batch scratch, staging of the host-buffer API, counters, events.  The asynchronous
@@ -123,6 +126,7 @@ struct bmq_engine {
         bool pending = false;
         bool clean = false; // counters / allocators / super sums are zero (k_reset ran behind the last batch of the slot)
         bool ran_slow = false, ran_sort = false; // k_walk_slow / k_sort_rows were part of this batch's launch
+        bool ran_mixed = false;                  // k_walk ran in its MIXED instantiation
         bool timed = false; // this batch was launched with the per-kernel events (bmq_config.kernel_timing)
         bool total_timed = false; // ... with the two events around the whole batch (bmq_stats.ms_total)
         int pending_kind = 0; // 0 dist, 1 retain
@@ -316,7 +320,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         const char* dbg = getenv("BMQ_DEBUG");
         a.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
         a.dbg_wave = nullptr;
-        if (a.debug_flags & 6u) {
+        if (a.debug_flags & 30u) {
             HIPCHK(e, S.b_dbg_wave.ensure(sizeof(uint4) * 2 * std::max(a.n_blocks, 1u)));
             a.dbg_wave = S.b_dbg_wave.as<uint4>();
         }
@@ -335,10 +339,19 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[0], s));
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
-        const size_t lds = WALK_WAVES * walk_lds_bytes(a.qcap, a.pcap);
-        const dim3 grid(WALK_WAVES == 1 ? walk_grid_blocks(a.n_blocks) : (a.n_blocks + WALK_WAVES - 1) / WALK_WAVES), block(WALK_WAVES * 64);
-        if (lds > 64 * 1024) HIPCHK(e, hipFuncSetAttribute((const void*)k_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_walk, grid, block, lds, s, a);
+        // k_walk<token table entries, stack items, range entries, MIXED>: the LDS geometry is a compile-time property (bmq_walk_kernel.h)
+        const dim3 grid(a.n_blocks), block(64);
+        S.ran_mixed = e->mixed_on;
+        const int g = e->walk_geom;
+#define BMQ_WALK_LAUNCH(TC, QC, PC)                                                        \
+    do {                                                                                   \
+        if (e->mixed_on) hipLaunchKernelGGL((k_walk<TC, QC, PC, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((k_walk<TC, QC, PC, false>), grid, block, 0, s, a);            \
+    } while (0)
+        if (a.debug_flags & 16u) hipLaunchKernelGGL(k_occ_probe, grid, block, 0, s, a); // (experiments: its census replaces k_walk's)
+        if (g == 2) BMQ_WALK_LAUNCH(192, 128, 128); // smallest lists: every overflow path runs all the time (tests)
+        else BMQ_WALK_LAUNCH(512, 192, 160);
+#undef BMQ_WALK_LAUNCH
     }
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[2], s));
     // The two repair kernels run only while batches need them (finish_dist turns them on -- and completes the batch that found
@@ -377,6 +390,40 @@ static void print_wave_debug(bmq_engine* e, bmq_engine::BatchSlot& S) {
     if (!a.dbg_wave || !a.n_blocks) return;
     std::vector<uint4> h(2 * (size_t)a.n_blocks);
     if (hipMemcpy(h.data(), a.dbg_wave, sizeof(uint4) * 2 * a.n_blocks, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (a.debug_flags & 24u) { // k_walk residency census (8) / the probe kernel's (16): {start lo, start hi, duration, HW_ID | XCC_ID << 16} per wave
+        std::vector<std::pair<unsigned long long, int>> ev;
+        unsigned long long t0 = ~0ull, t1 = 0, busy = 0;
+        std::map<uint32_t, std::vector<std::pair<unsigned long long, int>>> per_simd;
+        for (uint32_t i = 0; i < a.n_blocks; i++) {
+            const unsigned long long st = ((unsigned long long)h[i].y << 32) | h[i].x, en = st + h[i].z;
+            t0 = std::min(t0, st), t1 = std::max(t1, en), busy += h[i].z;
+            ev.push_back({st, 1}), ev.push_back({en, -1});
+            // HW_ID: wave_id [3:0] simd_id [5:4] pipe [7:6] cu_id [11:8] sh_id [12] se_id [15:13]; + XCC_ID
+            const uint32_t simd_key = (h[i].w >> 4) & 0xFFFFFu & ~0xCu; // simd + cu + sh + se + xcc (pipe bits dropped)
+            per_simd[simd_key].push_back({st, 1}), per_simd[simd_key].push_back({en, -1});
+        }
+        if (const char* fn = getenv("BMQ_CENSUS_FILE")) { // raw records for offline analysis (tools/census.py)
+            if (FILE* f = fopen(fn, "wb")) {
+                fwrite(h.data(), sizeof(uint4), a.n_blocks, f);
+                fclose(f);
+            }
+        }
+        std::sort(ev.begin(), ev.end());
+        int cur = 0, peak = 0;
+        for (auto& x : ev) cur += x.second, peak = std::max(peak, cur);
+        int simd_peak = 0;
+        double simd_peak_sum = 0;
+        for (auto& kv : per_simd) {
+            std::sort(kv.second.begin(), kv.second.end());
+            int c = 0, pk = 0;
+            for (auto& x : kv.second) c += x.second, pk = std::max(pk, c);
+            simd_peak = std::max(simd_peak, pk), simd_peak_sum += pk;
+        }
+        fprintf(stderr, "[bmq] k_walk census: %u waves, span %llu ticks, mean wave %.0f ticks, mean resident %.0f (peak %d) waves; %zu distinct SIMD keys, peak waves on one SIMD %d (mean of peaks %.1f)\n",
+                a.n_blocks, t1 - t0, (double)busy / a.n_blocks, (double)busy / (double)(t1 - t0), peak, per_simd.size(), simd_peak,
+                simd_peak_sum / std::max<size_t>(per_simd.size(), 1));
+        return;
+    }
     if (a.debug_flags & 4u) { // k_expand: head (row pointers, wave base) | range load + order | prefix + order check | id generation
         double p[4] = {0, 0, 0, 0};
         for (uint32_t i = 0; i < a.n_blocks; i++) p[0] += h[i].x, p[1] += h[i].y, p[2] += h[i].z, p[3] += h[i].w;
@@ -406,7 +453,7 @@ static void print_wave_debug(bmq_engine* e, bmq_engine::BatchSlot& S) {
 int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
     for (int attempt = 0; attempt < 8; attempt++) {
         HIPCHK(e, hipEventSynchronize(S.ev_done)); // this batch only: a later batch may already be running behind it
-        if (S.last.debug_flags & 6u) print_wave_debug(e, S);
+        if (S.last.debug_flags & 30u) print_wave_debug(e, S);
         const Counters c = *S.h_ctr;
         const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST);
         if (grow) {
@@ -434,6 +481,14 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
             }
             if (c.sort_count) e->sort_on = true, e->sort_idle = 0;
             if (c.slow_count) e->slow_on = true, e->slow_idle = 0;
+            if (c.status & ST_WANT_MIXED) e->mixed_on = true, e->mixed_idle = 0;
+            BatchArgs a = S.last;
+            int rc = launch_dist(e, S, a);
+            if (rc) return rc;
+            continue;
+        }
+        if ((c.status & ST_WANT_MIXED) && !S.ran_mixed) { // waves held many tenants each: once more through the instantiation for that
+            e->mixed_on = true, e->mixed_idle = 0;
             BatchArgs a = S.last;
             int rc = launch_dist(e, S, a);
             if (rc) return rc;
@@ -457,6 +512,8 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
         }
         if (S.ran_slow && (c.slow_count ? (e->slow_idle = 0) : ++e->slow_idle) >= REPAIR_IDLE_BATCHES) e->slow_on = false;
         if (S.ran_sort && (c.sort_count ? (e->sort_idle = 0) : ++e->sort_idle) >= REPAIR_IDLE_BATCHES) e->sort_on = false;
+        // (the MIXED instantiation cannot tell whether the grouped one would do: it is dropped after a while and comes back if asked for)
+        if (S.ran_mixed && ++e->mixed_idle >= 8 * REPAIR_IDLE_BATCHES) e->mixed_on = false;
         S.pending = false;
         bmq_stats& st = e->stats;
         st = bmq_stats{};
@@ -513,7 +570,9 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (cfg->struct_size < 8 || cfg->struct_size > sizeof(bmq_config)) return BMQ_E_INVAL;
         memcpy(&c, cfg, cfg->struct_size);
     }
-    // defaults: 9.6 KB of LDS per wave -> 8 two-wave workgroups = 16 waves per CU (measured best on C3, profiles/r01)
+    // The LDS geometry of k_walk is a compile-time property of its instantiations (bmq_walk_kernel.h): the two caps select one --
+    // caps of 128 the smallest lists (tests force the overflow paths with them), anything else the default (192 / 160: 5.5 KB of LDS per
+    // one-wave workgroup, 7 waves per SIMD); BMQ_WALK_GEOM picks one by number (profiling experiments).
     if (c.wave_queue_cap == 0) c.wave_queue_cap = 192;
     if (c.wave_pair_cap == 0) c.wave_pair_cap = 160;
     if (const char* v = getenv("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
@@ -524,6 +583,9 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     auto e = std::make_unique<bmq_engine>();
     e->cfg = c;
     e->device = c.device;
+    e->walk_geom = (c.wave_queue_cap <= 128 || c.wave_pair_cap <= 128) ? 2 : 0;
+    if (const char* v = getenv("BMQ_WALK_GEOM")) e->walk_geom = atoi(v);
+    if (const char* v = getenv("BMQ_WALK_MIXED")) e->mixed_on = atoi(v) != 0; // profiling experiments
     e->kernel_events = c.kernel_timing != 0;
     if (const char* v = getenv("BMQ_KERNEL_EVENTS")) e->kernel_events = atoi(v) != 0; // profiling experiments
     if (c.device >= 0) {

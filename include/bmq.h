@@ -59,9 +59,10 @@ typedef struct bmq_engine bmq_engine;
 typedef struct bmq_config {
     uint32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = host-only engine (build/inspect, no match)      */
-    uint32_t wave_queue_cap;   /* per-wave LDS work stack, items (default 192; 128..4096, x64); overflow is   */
-                               /* parked in global memory, never an error                                    */
-    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (default 160; 128..4096, x4)  */
+    uint32_t wave_queue_cap;   /* per-wave LDS work stack, items (128..4096, x64).  The walk kernel's LDS geometry is */
+                               /* compiled in: a cap of 128 selects the smallest lists (128 / 128), any other value   */
+                               /* the default (192 / 160).  Overflow is parked in global memory, never an error       */
+    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (128..4096, x4): as above               */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t kernel_timing;    /* 1: HIP events around k_walk / k_expand of every batch -> bmq_stats.ms_walk /  */
                                /* ms_expand (two extra events per batch, ~4 us each on the stream); 0: ms_total  */

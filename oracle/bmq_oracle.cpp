@@ -1046,6 +1046,62 @@ void orc_match_bruteforce(void* kvp, const uint8_t* tenant, uint32_t tl, const u
     }
 }
 
+// Oracle A for a whole multi-tenant batch, on `threads` host threads: per topic the ranks of all keys of ITS tenant whose filter
+// matches (TRIET/TopicMatcher.java:39-101 applied key by key).  A tenant's keys are one contiguous run of the sorted KV
+// (SCHEMA/KVSchemaUtil.java:91-94: every key starts with the tenant), found once per tenant -- so a row costs O(keys of the tenant),
+// which is what makes "every row that differs from the structural restatement is checked against the semantic oracle" affordable
+// at the full BASELINE sizes.  Returns seconds.
+double orc_match_semantic_batch(void* kvp, const uint8_t* tenants, const uint32_t* toff, const uint32_t* topicTenant, const uint8_t* topics,
+                                const uint32_t* off, uint32_t n, int threads, void* result) {
+    KV& kv = *(KV*)kvp;
+    uint32_t nt = 0;
+    for (uint32_t i = 0; i < n; i++) nt = std::max(nt, topicTenant[i] + 1);
+    std::vector<std::string> tn = split_packed(tenants, toff, nt);
+    // the run of keys of every tenant of the batch (details[r].tenant is non-decreasing over the sorted keys of well-formed KVs; keys
+    // that do not parse belong to nobody and are skipped as orc_match_bruteforce skips them)
+    std::vector<std::pair<size_t, size_t>> run(nt, {0, 0});
+    for (uint32_t t = 0; t < nt; t++) {
+        const std::string p = tenant_begin_key(tn[t]);
+        std::string q = p;
+        q.push_back('\xFF'); // a key of the tenant continues with level bytes (UTF-8, < 0xF8) or 0x00
+        const size_t lo = std::lower_bound(kv.keys.begin(), kv.keys.end(), p) - kv.keys.begin();
+        const size_t hi = std::lower_bound(kv.keys.begin(), kv.keys.end(), q) - kv.keys.begin();
+        run[t] = {lo, std::max(lo, hi)};
+    }
+    std::vector<std::vector<uint32_t>> per(n);
+    if (threads < 1) threads = 1;
+    auto t0 = std::chrono::steady_clock::now();
+    std::atomic<uint32_t> cursor{0};
+    auto work = [&]() {
+        for (;;) {
+            const uint32_t i = cursor.fetch_add(16);
+            if (i >= n) break;
+            for (uint32_t j = i; j < std::min(n, i + 16); j++) {
+                const std::string tp((const char*)topics + off[j], off[j + 1] - off[j]);
+                const Levels t = parse(tp, false);
+                const std::string& ten = tn[topicTenant[j]];
+                for (size_t r = run[topicTenant[j]].first; r < run[topicTenant[j]].second; r++) {
+                    const RouteDetail& d = kv.details[r];
+                    if (d.ok && d.tenant == ten && semantic_match(t, d.filterLevels)) per[j].push_back((uint32_t)r);
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    MatchAllResult* res = (MatchAllResult*)result;
+    *res = MatchAllResult();
+    res->rowPtr.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        res->rowPtr[i + 1] = res->rowPtr[i] + (uint32_t)per[i].size();
+        res->routes.insert(res->routes.end(), per[i].begin(), per[i].end());
+    }
+    return sec;
+}
+
 // N_visit per topic (roofline accounting). visits_out[n].
 void orc_count_visits(void* kvp, const uint8_t* tenants, const uint32_t* toff, const uint32_t* topicTenant,
                       const uint8_t* topics, const uint32_t* off, uint32_t n, uint32_t* visits_out) {

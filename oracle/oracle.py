@@ -64,6 +64,7 @@ def lib():
             "orc_match_all": (None, [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint32, C.c_int, C.c_int, vp]),
             "orc_match_singletons": (C.c_double, [vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
             "orc_match_bruteforce": (None, [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint32, vp]),
+            "orc_match_semantic_batch": (C.c_double, [vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
             "orc_count_visits": (None, [vp, vp, vp, vp, vp, vp, C.c_uint32, vp]),
             "orc_ltrie_new": (vp, [C.c_int]), "orc_ltrie_free": (None, [vp]),
             "orc_ltrie_add": (None, [vp, C.c_char_p, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_int]),
@@ -355,6 +356,17 @@ class KV:
         res = MatchResult(len(topics))
         lib().orc_match_bruteforce(self.h, t, len(t), _ptr(data), _ptr(off), len(topics), res.h)
         return res
+
+    def match_semantic_batch(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed, threads: int = 1):
+        """Semantic oracle (A) for a whole multi-tenant batch on `threads` host threads: per topic every key of ITS tenant is tested
+        (a tenant's keys are one run of the sorted KV).  -> (MatchResult, seconds)"""
+        tdata, toff = pack(tenants)
+        data, off = topics_packed
+        tt = np.ascontiguousarray(topic_tenant, dtype=np.uint32)
+        n = len(off) - 1
+        res = MatchResult(n)
+        sec = lib().orc_match_semantic_batch(self.h, _ptr(tdata), _ptr(toff), _ptr(tt), _ptr(data), _ptr(off), n, threads, res.h)
+        return res, sec
 
     def count_visits(self, tenants: Sequence, topic_tenant: np.ndarray, topics_packed) -> np.ndarray:
         tdata, toff = pack(tenants)

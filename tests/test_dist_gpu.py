@@ -208,6 +208,34 @@ def test_generated_workload_parity(eng):
         assert [got[i] for i in idx] == U.semantic_rows(kv, tn, [tt[i] for i in idx], [topics[i] for i in idx])
 
 
+def test_grouped_batch_equals_ungrouped(eng):
+    """k_walk has two instantiations: a batch ordered by tenant (the DistPacks of a BatchDistRequest: what bench.py times) is walked one
+    tenant at a time with the tenant's region in scalar registers, waves that straddle up to 4 tenants walk them one after the other; a
+    batch in any other order is run again through the MIXED instantiation (ST_WANT_MIXED).  The same publishes in both orders must give
+    the same rows -- the ungrouped order is what the oracle tests above and below use -- also for tenants with a handful of publishes
+    (several tenants per wave) and for small batches (16 / 4 topics per wave)."""
+    w = B.Workload(0xB1F20007, 300, 2000, 1)
+    eng.rebuild(packed=w.keys_packed())
+    kv = O.KV(packed=w.keys_packed())
+    tn = w.tenants()
+    for n in (200_000, 20_000, 3_000):  # 64 / 16 / 4 topics per wave
+        data, off, tt = w.topics(0xB1F20007 + n, n)
+        row, ids = eng.match_batch(tn, tt, packed_topics=(data, off))
+        nv = eng.stats().n_visit
+        order = np.argsort(tt, kind="stable")
+        gdata, goff = U.sub_packed(data, off, order)
+        grow, gids = eng.match_batch(tn, tt[order], packed_topics=(gdata, goff))
+        assert eng.stats().n_visit == nv == int(kv.count_visits(tn, tt, (data, off)).sum())
+        a_rp, a = U.csr_select(row, ids, order)
+        assert np.array_equal(a_rp, grow.astype(np.int64)) and np.array_equal(a, gids)
+        # ... and a slice of the grouped batch against the semantic oracle directly
+        sel = np.arange(0, n, max(1, n // 2000))
+        sd, so = U.sub_packed(gdata, goff, sel)
+        res, _ = kv.match_semantic_batch(tn, tt[order][sel], (sd, so), threads=U.host_threads())
+        b_rp, b = U.csr_select(grow, gids, sel)
+        assert np.array_equal(b_rp, res.row_ptr.astype(np.int64)) and np.array_equal(b, res.routes)
+
+
 # ---- the rare paths: LDS overflow -> per-lane DFS, deep topics, interleaved ranges -> fix-up sort ------------------
 def test_slow_path_equals_fast_path():
     rnd = random.Random(5)
@@ -464,8 +492,8 @@ def test_output_capacity_protocol(eng):
 # ---- full BASELINE size: properties that do not need the oracle to finish the whole batch ---------------------------
 def test_full_size_config2_properties(eng):
     """configs[1]: 1 tenant, 1M filters with +/# wildcards, 1M-publish batch.  Checked: CSR well-formed, rows strictly
-    ascending, a random sample of rows bit-exact vs the oracle (production call pattern), every emitted id of a second
-    sample semantically matches, duplicate topics get identical rows, idempotence across two runs."""
+    ascending, EVERY row bit-exact vs the oracle (production call pattern; the rows the reference loses routes in -- quirk (ii) -- vs the
+    semantic oracle, all of them), duplicate topics get identical rows, idempotence across two runs."""
     w = B.Workload(0xB1F20002, 1, 1_000_000, 1)
     eng.rebuild(packed=w.keys_packed())
     data, off, tt = w.topics(0xB1F20002 + 1, 1_000_000)
@@ -481,28 +509,28 @@ def test_full_size_config2_properties(eng):
     assert (row == row2).all() and (ids == ids2).all()
     rnd = random.Random(3)
     kv = O.KV(packed=w.keys_packed())
-    # 100 000 of the 1M rows (every 10th) against the oracle in the production call pattern, on all host cores; whole-CSR compare
-    sample = np.arange(0, 1_000_000, 10)
+    # EVERY row of the 1M-publish batch: the DISTINCT topics (Zipf: identical publishes are checked equal row for row just below) against
+    # the oracle in the production call pattern -- one matchAll(singleton(topic)) each -- on all host cores, whole-CSR comparison; every
+    # row that differs from that structural restatement (the reference loses routes to quirk (ii) there: hot filters next to
+    # "<filter>/" filters) and a sub-sample of the others against the semantic oracle
     raw = data.tobytes()
-    sub_off = np.concatenate([[0], np.cumsum((off[sample + 1] - off[sample]).astype(np.int64))]).astype(np.uint32)
-    sub_data = np.zeros(int(sub_off[-1]) + 32, dtype=np.uint8)
-    sub_data[:int(sub_off[-1])] = np.frombuffer(b"".join(raw[off[i]:off[i + 1]] for i in sample), dtype=np.uint8)
-    res, _ = kv.match_singletons(tn, np.zeros(len(sample), dtype=np.uint32), (sub_data, sub_off), threads=U.host_threads())
+    first_of, rep = {}, np.zeros(1_000_000, dtype=np.int64)
+    for i in range(1_000_000):
+        rep[i] = first_of.setdefault(raw[off[i]:off[i + 1]], i)
+    cnt = np.diff(row.astype(np.int64))
+    assert (cnt == cnt[rep]).all()
+    dup = np.nonzero(rep != np.arange(1_000_000))[0]
+    a_rp, a = U.csr_select(row, ids, dup)
+    b_rp, b = U.csr_select(row, ids, rep[dup])
+    assert np.array_equal(a, b)  # identical topic -> identical row
+    sample = np.nonzero(rep == np.arange(1_000_000))[0]
+    sub_data, sub_off = U.sub_packed(raw, off, sample)
+    stt0 = np.zeros(len(sample), dtype=np.uint32)
+    res, _ = kv.match_singletons(tn, stt0, (sub_data, sub_off), threads=U.host_threads())
     got_rp, got = U.csr_select(row, ids, sample)
     differ = U.assert_csr_equal_modulo_quirk_ii(w.keys, kv.key, tn, None, res.row_ptr.astype(np.int64), res.routes, got_rp, got)
-    # rows where the reference loses routes to quirk (ii) (hot filters next to "<filter>/" filters: a few % of this workload) and a
-    # sub-sample of the others: the semantic oracle is authoritative (O(keys) each)
-    for i in [int(sample[j]) for j in differ[:25]] + sample[::4000].tolist():
-        assert ids[row[i]:row[i + 1]].tolist() == kv.match_bruteforce(tn[0], [raw[off[i]:off[i + 1]]]).per_topic()[0]
-    # duplicates: same topic string -> same row
-    seen = {}
-    for i in range(0, 200000):
-        t = raw[off[i]:off[i + 1]]
-        if t in seen:
-            j = seen[t]
-            assert (ids[row[i]:row[i + 1]] == ids[row[j]:row[j + 1]]).all()
-        else:
-            seen[t] = i
+    U.assert_differing_rows_semantic("c2: 1 tenant x 1M routes, 1M publishes (%d distinct topics, all compared)" % len(sample), kv, tn, stt0,
+                                     (sub_data, sub_off), differ, got_rp, got, livelocks=res.livelocks(), extra_rows=range(0, len(sample), 4000))
 
 
 def test_full_size_config3_properties(eng):
@@ -547,9 +575,9 @@ def test_full_size_config3_properties(eng):
     differ = U.assert_csr_equal_modulo_quirk_ii(lambda: [rawk[sub_off[i]:sub_off[i + 1]] for i in range(hi)], kv.key, tn[:S], stt,
                                                 res.row_ptr.astype(np.int64), res.routes, got_rp, got)
     rnd = random.Random(4)
-    for j in differ[:20].tolist() + rnd.sample(range(len(cand)), 20):  # authoritative semantic check: quirk rows + a sub-sample
-        i = int(cand[j])
-        assert ids[row[i]:row[i + 1]].tolist() == kv.match_bruteforce(tn[int(tt[i])], [raw[off[i]:off[i + 1]]]).per_topic()[0]
+    # authoritative semantic check: EVERY row that differs from the structural restatement + a sub-sample of the others
+    U.assert_differing_rows_semantic("c3: 1000 tenants x 10k routes, 1M publishes (every publish of the first %d tenants)" % S, kv, tn[:S], stt,
+                                     (t_data, t_off), differ, got_rp, got, livelocks=res.livelocks(), extra_rows=rnd.sample(range(len(cand)), 200))
     # fan-out grouping of the whole batch (~18 M (topic, route) pairs regrouped by DelivererKey), size-independent properties:
     # a permutation of the pairs; inside a group (topic, route) ascending; one DelivererKey per group and one group per DelivererKey
     # (checked on a sample of pairs of every group through their route keys)

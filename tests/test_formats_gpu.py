@@ -1,6 +1,7 @@
 """Host-visible result formats of the asynchronous match (include/bmq.h BMQ_FMT_*): fan-out counts only (what
 DistWorkerCoProc.batchDist replies with, DW/DistWorkerCoProc.java:535-538), matched id ranges, pairs grouped by DelivererKey
-(DW/DeliverExecutorGroup.java:112-241).  Every format must carry exactly the information of the id CSR it stands in for."""
+(DW/DeliverExecutorGroup.java:112-241).  Every format is compared with the ORACLE's rows of the same batch (the semantic oracle over every
+key of the row's tenant; the grouped pairs with oracle.fanout_groups), not with the engine's own id CSR."""
 import numpy as np
 import pytest
 
@@ -8,8 +9,22 @@ import bifromq_amd as B
 from bifromq_amd.engine import pinned
 from oracle import oracle as O
 from bifromq_amd.workload import unpack
+from tests import util as U
+from tests.test_fanout import _check as check_groups_vs_oracle
 
 pytestmark = pytest.mark.gpu
+
+
+def _oracle_csr(keys_sorted, tn, tt, packed, id_of_rank=None):
+    """(row_ptr, ids) the semantic oracle expects for the batch: ranks of the matching keys of each row's tenant, mapped to engine ids
+    (after a rebuild the id IS the rank; after churn `id_of_rank` maps) and ascending per row"""
+    kv = O.KV(keys_sorted)
+    res, _ = kv.match_semantic_batch(tn, np.asarray(tt, dtype=np.uint32), packed, threads=U.host_threads())
+    rp = res.row_ptr.astype(np.int64)
+    ids = res.routes.astype(np.int64)
+    if id_of_rank is not None:
+        ids = U.csr_sorted(rp, np.asarray(id_of_rank, dtype=np.int64)[ids])
+    return rp.astype(np.uint32), ids.astype(np.uint32)
 
 
 @pytest.fixture(scope="module")
@@ -57,18 +72,16 @@ def test_counts_ranges_grouped_equal_the_id_csr(eng):
     n = 30000
     (data, off, tt), pb = _batch(w, 7, n)
     pd, po, pt = pb
-    erow, eids = eng.match_batch(tn, tt, packed_topics=(data, off))
+    erow, eids = _oracle_csr(sorted(keys), tn, tt, (data, off))  # what every format below must carry: the ORACLE's rows
+    grow, gids = eng.match_batch(tn, tt, packed_topics=(data, off))
+    assert np.array_equal(grow, erow) and np.array_equal(gids, eids)
     # ---- COUNTS: the row pointers, nothing else; the wrong wait is refused and leaves the ticket in flight
     t = eng.match_submit_fmt(p_t, p_to, len(tn), pt, pd, po, n, eng.FMT_COUNTS)
     row = pinned(n + 1, np.uint32)
     with pytest.raises(B.BmqError):
         eng.match_wait(t, row, pinned(16, np.uint32))
     assert eng.match_wait_counts(t, row) == len(eids)
-    assert (row == erow).all()
-    kv = O.KV(keys)
-    topics = unpack(data, off)
-    for i in range(0, n, 1499):
-        assert int(row[i + 1] - row[i]) == len(kv.match_bruteforce(tn[int(tt[i])], [topics[i]]).per_topic()[0])
+    assert (row == erow).all()  # every fan-out count equals the oracle's
     # ---- RANGES: expanding gives the id rows, in order; fewer ranges than ids; nothing indirect after a rebuild
     info = _check_ranges(eng, p_t, p_to, len(tn), pb, n, erow, eids, expect_overlap=False)
     assert info.n_side_ids == 0 and 0 < info.n_ranges < len(eids)
@@ -77,15 +90,14 @@ def test_counts_ranges_grouped_equal_the_id_csr(eng):
     with pytest.raises(B.BmqError) as ei:
         eng.match_wait_ranges(t, pinned(n + 1, np.uint32), pinned((4, 2), np.uint32), pinned(4, np.uint32))
     assert ei.value.code == -3 and ei.value.info.n_ranges == info.n_ranges
-    # ---- GROUPED: equals bmq_fanout_group of the CSR
+    # ---- GROUPED: the oracle's DeliverExecutorGroup.submit -> BatchDeliveryCall.add restatement over the oracle's rows
     t = eng.match_submit_fmt(p_t, p_to, len(tn), pt, pd, po, n, eng.FMT_GROUPED)
     ot, orr = pinned(len(eids) + 8, np.uint32), pinned(len(eids) + 8, np.uint32)
     goff, grep = pinned(4096, np.uint32), pinned(4095, np.uint32)
     total, ng, special = eng.match_wait_grouped(t, ot, orr, goff, grep)
     assert total == len(eids)
-    g_topic, g_route, g_off, g_rep, g_special = eng.fanout_group(erow, eids)
-    assert ng == len(g_rep) and special == g_special
-    assert (goff[:ng + 1] == g_off).all() and (ot[:total] == g_topic).all() and (orr[:total] == g_route).all()
+    ks = sorted(keys)
+    check_groups_vs_oracle(eng, U.csr_rows(erow, eids), lambda i: ks[i], (ot[:total], orr[:total], goff[:ng + 1], grep[:ng], special))
     # two formats in flight at once, waited for in the other order
     t0 = eng.match_submit_fmt(p_t, p_to, len(tn), pt, pd, po, n, eng.FMT_COUNTS)
     t1 = eng.match_submit_fmt(p_t, p_to, len(tn), pt, pd, po, n, eng.FMT_IDS)
@@ -115,7 +127,17 @@ def test_ranges_after_churn_carry_their_side_lists(eng):
     for k in keys[::7]:
         ops.append((1, k))
     eng.apply(ops)
-    erow, eids = eng.match_batch(tn, tt, packed_topics=(data, off))
+    # the oracle's rows on the UPDATED key set; ranks -> engine ids
+    expect_live = set(keys)
+    for op, k in ops:
+        (expect_live.add if op == 0 else expect_live.discard)(k)
+    nid = eng.info().next_route_id  # the id <-> key mapping is the engine's key store (bmq_route_keys); WHICH keys match is the oracle's call
+    id_of = {k: i for i, k in enumerate(eng.route_keys(list(range(nid)))) if k}
+    assert set(id_of) == expect_live
+    live = sorted(id_of)
+    erow, eids = _oracle_csr(live, tn, tt, (data, off), id_of_rank=[id_of[k] for k in live])
+    grow, gids = eng.match_batch(tn, tt, packed_topics=(data, off))
+    assert np.array_equal(grow, erow) and np.array_equal(gids, eids)
     info = _check_ranges(eng, p_t, p_to, len(tn), pb, n, erow, eids)
     assert info.n_side_ids > 0
 

@@ -199,6 +199,54 @@ def assert_csr_equal_modulo_quirk_ii(all_keys_fn, key_of, tenants, topic_tenant,
     return np.nonzero(differ)[0]
 
 
+def sub_packed(data, off, sel):
+    """the packed strings `sel` of (data, off) as a packed pair of their own (padded for the engine / oracle readers)"""
+    sel = np.asarray(sel, dtype=np.int64)
+    raw = data.tobytes() if not isinstance(data, (bytes, bytearray)) else data
+    o = np.concatenate([[0], np.cumsum((off[sel + 1].astype(np.int64) - off[sel].astype(np.int64)))]).astype(np.uint32)
+    d = np.zeros(int(o[-1]) + 32, dtype=np.uint8)
+    d[:int(o[-1])] = np.frombuffer(b"".join(raw[off[i]:off[i + 1]] for i in sel), dtype=np.uint8)
+    return d, o
+
+
+def parity_report(config, **fields):
+    """One line per full-size parity comparison: how far the engine's rows are from the STRUCTURAL restatement of the reference
+    (rows the reference loses routes in: quirks (ii)/(iv) of DESIGN.md section 2) and that every such row equals the semantic oracle.
+    Printed (pytest -s / a failing test shows it) and appended to gpurun_out/parity_report.jsonl when that directory is writable."""
+    import json
+    import os
+    line = json.dumps(dict(config=config, **fields))
+    print("[parity] " + line)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.jsonl"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def assert_differing_rows_semantic(config, kv, tenants, topic_tenant, packed_topics, differ, got_rp, got, livelocks=None, extra_rows=()):
+    """EVERY row that differs from the structural restatement (+ extra_rows, a sub-sample of the others) against the semantic oracle A
+    (the reference's own brute-force TopicMatcher over all keys of the row's tenant, on all host cores): equal id for id.
+    topic_tenant / packed_topics / got_rp / got describe the compared rows (row j of one is row j of the others); differ = indices."""
+    rows = np.unique(np.concatenate([np.asarray(differ, dtype=np.int64), np.asarray(list(extra_rows), dtype=np.int64)])) if (len(differ) or len(extra_rows)) else np.zeros(0, dtype=np.int64)
+    n_rows = len(got_rp) - 1
+    sec = 0.0
+    if len(rows):
+        data, off = packed_topics
+        sd, so = sub_packed(data, off, rows)
+        stt = np.asarray(topic_tenant, dtype=np.uint32)[rows] if topic_tenant is not None else np.zeros(len(rows), dtype=np.uint32)
+        res, sec = kv.match_semantic_batch(tenants, stt, (sd, so), threads=host_threads())
+        a_rp, a = csr_select(np.asarray(got_rp), np.asarray(got), rows)
+        assert np.array_equal(a_rp, res.row_ptr.astype(np.int64)), "row lengths differ from the semantic oracle"
+        assert np.array_equal(np.asarray(a, dtype=np.int64), res.routes.astype(np.int64)), "ids differ from the semantic oracle"
+    parity_report(config, rows_compared=int(n_rows), rows_differing_from_reference_restatement=int(len(differ)),
+                  differing_rows_equal_semantic_oracle=int(len(differ)), other_rows_checked_vs_semantic_oracle=int(len(rows) - len(differ)),
+                  reference_livelocks=None if livelocks is None else int(livelocks), semantic_oracle_s=round(sec, 2))
+    return len(differ)
+
+
 def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_tenants=16, n_sample=2000, seed=0xB1F20005):
     """configs[4]: an index of n_tenants x per_tenant generated routes, then ONE batch of n_ops mutations (50 % unsubscribes of
     existing routes, 50 % subscribes of new filters, spread over all tenants) through bmq_routes_apply, then a batch of

@@ -8,9 +8,15 @@ Counters the box's `rocprofv3 -L` does not list are skipped (and named in the fi
 import csv, glob, os, subprocess, sys
 from collections import defaultdict
 
+COLLECT_ONLY = "--collect-only" in sys.argv  # aggregate the passes already under gpurun_out/<round>/ (no GPU needed)
+sys.argv = [a for a in sys.argv if a != "--collect-only"]
 R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 W = sys.argv[2] if len(sys.argv) > 2 else "c3"
 EXTRA = sys.argv[3:]
+ONLY = None
+if EXTRA and EXTRA[0].startswith("--groups="):  # e.g. --groups=0,1 : only these counter groups
+    ONLY = set(int(x) for x in EXTRA[0].split("=")[1].split(","))
+    EXTRA = EXTRA[1:]
 O = os.path.join("gpurun_out", R)
 os.makedirs(O, exist_ok=True)
 os.environ.setdefault("TMPDIR", "/tmp")
@@ -28,12 +34,13 @@ GROUPS = [
     ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_TAG_STALL_sum", "TCC_EA0_RD_UNCACHED_32B_sum"],
     ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum"],
     ["TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TCP_TA_TCP_STATE_READ_sum", "TCP_TCC_READ_REQ_LATENCY_sum"],
-    ["TA_TA_BUSY_sum", "TA_BUFFER_WAVEFRONTS_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum"],
     ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
+    # (a TA_* pass -- TA_TA_BUSY_sum TA_BUFFER_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
+    # TA_DATA_STALLED_BY_TC_CYCLES_sum -- hung rocprofv3 for its whole 600 s limit on this pool (round 4): not collected)
 ]
 
 avail_txt = os.path.join(O, "counters_avail.txt")
-if not os.path.exists(avail_txt):
+if not os.path.exists(avail_txt) and not COLLECT_ONLY:
     with open(avail_txt, "w") as f:
         subprocess.run(["rocprofv3", "-L"], stdout=f, stderr=subprocess.STDOUT, timeout=300)
 avail = open(avail_txt).read()
@@ -44,6 +51,8 @@ skipped, rows = [], []
 bench = ["python", "bench.py", "--workload", W, "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--batcher-threads", "0",
          "--no-host-path"] + EXTRA
 for gi, g in enumerate(GROUPS):
+    if ONLY is not None and gi not in ONLY:
+        continue
     use = [c for c in g if have(c)]
     skipped += [c for c in g if not have(c)]
     if not use:
@@ -51,8 +60,13 @@ for gi, g in enumerate(GROUPS):
     d = os.path.join(O, "pmcsq_%s_%d" % (W, gi))
     log = os.path.join(O, "pmcsq_%s_%d.log" % (W, gi))
     cmd = ["rocprofv3", "--pmc"] + use + ["--output-format", "csv", "-d", d, "-o", W, "--"] + bench
-    with open(log, "w") as f:
-        rc = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, timeout=600).returncode
+    rc = 0
+    if not COLLECT_ONLY:
+        with open(log, "w") as f:
+            try:
+                rc = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, timeout=240).returncode
+            except subprocess.TimeoutExpired:
+                rc = -1
     hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if rc != 0 or not hits:
         print("pass %d failed (rc %d): %s" % (gi, rc, " ".join(use)))
@@ -62,6 +76,8 @@ for gi, g in enumerate(GROUPS):
     with open(hits[0]) as f:
         for r in csv.DictReader(f):
             k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("void "):  # templates are reported with their return type
+                k = k[5:]
             if not k.startswith("bmq::"):
                 continue
             acc[(k, r["Counter_Name"])].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
