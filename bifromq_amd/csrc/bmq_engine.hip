@@ -340,7 +340,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
         // k_walk<token table entries, stack items, range entries, MIXED>: the LDS geometry is a compile-time property (bmq_walk_kernel.h)
-        const dim3 grid(a.n_blocks), block(64);
+        const dim3 grid((a.debug_flags & 32u) ? ((a.n_blocks + 7u) / 8u) * 8u : a.n_blocks), block(64);
         S.ran_mixed = e->mixed_on;
         const int g = e->walk_geom;
 #define BMQ_WALK_LAUNCH(TC, QC, PC)                                                        \

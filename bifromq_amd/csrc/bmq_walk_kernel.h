@@ -46,7 +46,10 @@ template <int TC, int QC, int PC, bool MIXED> struct WalkLds { // byte offsets i
     static constexpr uint32_t STAGE = BYTES - STK;        // bytes available for staging
     // waves per SIMD the LDS slice allows (160 KB per CU, one wave per workgroup, 512-byte allocation granules assumed), at most 8
     static constexpr uint32_t ALLOC = (BYTES + 511) & ~511u;
-    static constexpr uint32_t WAVES = (163840 / ALLOC) / 4 > 8 ? 8 : (163840 / ALLOC) / 4;
+    // (the MIXED instantiation carries 64-bit addresses and per-topic regions through the loop: at more than 5 waves -- <= 96 VGPRs --
+    // the compiler spills 50-80 registers to scratch)
+    static constexpr uint32_t WAVES_LDS = (163840 / ALLOC) / 4 > 8 ? 8 : (163840 / ALLOC) / 4;
+    static constexpr uint32_t WAVES = MIXED && WAVES_LDS > 5 ? 5 : WAVES_LDS;
     static_assert(3 * 64 * 4 <= STK && PC % 8 == 0 && QC % 8 == 0 && STK % 16 == 0 && WAVES >= 1 && TC >= 2 * FAST_LEVELS && TC <= 1023, "layout");
     static_assert(STK + (QC + 64) * 8 <= BYTES, "a round reads 64 stack slots from `tail` on, whatever is there");
 };
@@ -78,10 +81,17 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     uint32_t* const cursor = cnt_routes + 64;
 
     const uint32_t lane = threadIdx.x;
-    if (blockIdx.x >= a.n_blocks) return;
-    // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
-    // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
-    const uint32_t blk = a.n_blocks - 1 - blockIdx.x;
+    uint32_t blk;
+    if (a.debug_flags & 32u) { // (experiment) every XCD -- workgroup b runs on XCD b % 8 -- takes ONE contiguous eighth of the batch: a tenant's region is cached by one L2, not by eight
+        const uint32_t per = (a.n_blocks + 7u) >> 3;
+        blk = (blockIdx.x & 7u) * per + (per - 1u - (blockIdx.x >> 3));
+        if ((blockIdx.x >> 3) >= per || blk >= a.n_blocks) return;
+    } else {
+        if (blockIdx.x >= a.n_blocks) return;
+        // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
+        // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
+        blk = a.n_blocks - 1 - blockIdx.x;
+    }
     // A wave owns TPW = 2^tpw_shift consecutive topics.  64 for large batches; a small batch is spread over more waves (16 or 4
     // topics each): the walk phase is a chain of dependent line fetches whose length is ~ max(depth, items / 64), so a wave with
     // fewer topics finishes sooner and a 10 k-topic batch fills the chip instead of 157 waves on 256 CUs.
@@ -179,13 +189,18 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     };
     const unsigned long long clk1 = dbg_clock(dbg_w);
     // what a resolved item leaves behind: its matched ranges go into the LDS range buffer, its children onto the stack
-    auto sink = [&](bool emit_own, bool emit_hash, bool push_l, bool push_h, uint32_t own_begin, uint32_t own_count, uint32_t hash_begin,
-                    uint32_t hash_count, uint32_t child, uint32_t cmeta /* the children's meta, kind L */, uint32_t tl, uint32_t ln /* lane_here() */) {
+    // (The four predicates arrive as INTEGERS -- a count that is zero unless its range is to be emitted, a flag, the Bloom word's sign --
+    // so that every ballot below is one v_cmp on a vector register: a ballot of a boolean that was combined on the scalar unit costs a
+    // v_cndmask + v_cmp to bring it back.)
+    auto sink = [&](uint32_t own_begin, uint32_t own_count /* 0: no such range */, uint32_t hash_begin, uint32_t hash_count /* 0: none */,
+                    uint32_t lit /* != 0: push the literal child probe */, uint32_t bloom /* bit 31: push the '+' child probe */, uint32_t child,
+                    uint32_t cmeta /* the children's meta, kind L */, uint32_t tl, uint32_t ln /* lane_here() */) {
+        const bool emit_own = own_count != 0, emit_hash = hash_count != 0, push_l = lit != 0, push_h = (int32_t)bloom < 0;
         const unsigned long long m_own = ballot64(emit_own), m_hash = ballot64(emit_hash);
         const unsigned long long m_l = ballot64(push_l), m_h = ballot64(push_h);
         if ((m_own | m_hash) != 0) {
             const uint32_t n_own = (uint32_t)__popcll(m_own), n_emit = n_own + (uint32_t)__popcll(m_hash);
-            if (pcount + n_emit > (uint32_t)PC) { // (cold) this round's matches do not fit: the buffer is flushed to the spill area first
+            if (__builtin_expect(pcount + n_emit > (uint32_t)PC, 0)) { // (cold) this round's matches do not fit: the buffer is flushed to the spill area first
                 const BatchArgs& c = a;
                 uint32_t cb;
                 if (spill_alloc(c, ln, pcount, cb)) {
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
         // children -> stack; if they do not fit, the pending (older) items are parked and the walk goes on with the children
         if ((m_l | m_h) != 0) {
             const uint32_t n_l = (uint32_t)__popcll(m_l), n_push = n_l + (uint32_t)__popcll(m_h);
-            if (tail + n_push > (uint32_t)QC) { // (cold)
+            if (__builtin_expect(tail + n_push > (uint32_t)QC, 0)) { // (cold)
                 const BatchArgs& c = a;
                 uint32_t cb;
                 if (spill_alloc(c, ln, tail, cb)) {
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
         constexpr int MODE = decltype(mode_tag)::value;
         while ((tail | qs_len) != 0) {
             const uint32_t ln = lane_here();
-            if (tail == 0) { // (cold) the stack ran dry: take the most recently parked chunk back
+            if (__builtin_expect(tail == 0, 0)) { // (cold) the stack ran dry: take the most recently parked chunk back
                 const BatchArgs& c = a;
                 const uint32_t hx = sgpr(c.spill[qs_base].x), hy = sgpr(c.spill[qs_base].y);
                 for (uint32_t i = ln; i < qs_len; i += 64) {
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
             wave_sync(); // every ln holds its item in registers: the stack above `tail` may be overwritten by the pushes below
             bool m0 = line.a0.x == node && line.a0.y == tok;
             bool m1 = line.b0.x == node && line.b0.y == tok;
-            if (ballot64(live && !m0 && !m1 && line.a0.x != NONE && line.b0.x != NONE) != 0) {
+            if (__builtin_expect(ballot64(live && !m0 && !m1 && line.a0.x != NONE && line.b0.x != NONE) != 0, 0)) {
                 // (cold) a home bucket full of other edges (rare at load factor 1/2): first-free probing continues.  Bounded by the region
                 // size so that not even a damaged image can hang the GPU.
                 const uint32_t nb = MODE == 2 ? reg.y : s_rbuckets;
@@ -291,12 +306,13 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
             const uint32_t hash_begin = m1 ? line.b1.x : line.a1.x, hash_count = m1 ? line.b1.y : line.a1.y;
             const uint32_t child = m1 ? line.b1.z : line.a1.z, bloom = m1 ? line.b1.w : line.a1.w;
             const uint32_t cmeta = (meta & ~KIND_P) + WALK_META_CHILD; // the same topic, one level on
-            const uint32_t rem = (meta >> 16) & 31u;                   // levels of the topic behind this item's
+            const bool last = ((meta >> 16) & 31u) == 0;               // no level of the topic behind this item's
             my_visits += found ? 1u : 0u;
-            const bool inner = found && rem != 0;
-            sink(found && rem == 0 && own_count != 0, found && hash_count != 0 /* "<path>/#" matches whatever follows, also nothing */,
-                 inner && tnext != TOK_UNKNOWN && ((bloom >> bloom_bit(tnext)) & 1u), inner && (bloom & BLOOM_PLUS) != 0, own_begin, own_count,
-                 hash_begin, hash_count, child, cmeta, tl, ln);
+            const uint32_t bloom_in = (found && !last) ? bloom : 0u;   // children only below an inner level
+            // the literal child: the next token is known to the dictionary (TOK_UNKNOWN = 0: min() drops it) and the node's Bloom word has its bit
+            const uint32_t lit = min((bloom_in >> bloom_bit(tnext)) & 1u, tnext);
+            sink(own_begin, (found && last) ? own_count : 0u, hash_begin, found ? hash_count : 0u /* "<path>/#" matches whatever follows, also nothing */,
+                 lit, bloom_in, child, cmeta, tl, ln);
         }
     };
     // Round 0 visits the tenant roots: their slot payload comes with the directory entry, no line is fetched.
@@ -304,18 +320,27 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
         const bool act = mine;
         const uint32_t ln = lane_here();
         const uint32_t t0 = tokens[tok_base]; // (a lane that is not `mine` reads some entry of the table)
-        sink(false,                                                          // a topic has at least one level
-             act && r_hash_count != 0 && !sys,                               // the filter "#"; never for '$' topics
-             act && t0 != TOK_UNKNOWN && ((r_bloom >> bloom_bit(t0)) & 1u),
-             act && (r_bloom & BLOOM_PLUS) != 0 && !sys,                     // a first-level '+' never matches a '$' topic
-             0u, 0u, r_hash_begin, r_hash_count, 0u /* the tenant root's node id */, walk_meta(ln, tok_base, nlev - 1), ln, ln);
+        const uint32_t bloom_in = act ? r_bloom : 0u;
+        sink(0u, 0u,                                                        // a topic has at least one level: nothing ends at the root
+             r_hash_begin, (act && !sys) ? r_hash_count : 0u,               // the filter "#"; never for '$' topics
+             min((bloom_in >> bloom_bit(t0)) & 1u, t0),
+             sys ? (bloom_in & ~BLOOM_PLUS) : bloom_in,                      // a first-level '+' never matches a '$' topic
+             0u /* the tenant root's node id */, walk_meta(ln, tok_base, nlev - 1), ln, ln);
     };
     {
     const BatchArgs& b = a;
     const bool run = !(b.debug_flags & 1u);
-    TenantSlot mrg = EMPTY_TENANT; // MIXED: every topic resolves its own tenant (three dependent requests per lane), the region goes to LDS
+    uint2 t_region_early = make_uint2(0u, 1u);
+    // MIXED: every topic resolves its own tenant (three dependent requests per lane); the region goes to LDS, the root's payload stays in
+    // three registers (a topic of a tenant the index does not know: an empty root, nothing is pushed)
+    uint32_t m_hash_begin = 0, m_hash_count = 0, m_bloom = 0;
     if (MIXED) {
-        if (asked) mrg = resolve_tenant(b, ti);
+        uint2 reg = make_uint2(0u, 1u);
+        if (asked) {
+            const TenantSlot rg = resolve_tenant(b, ti);
+            if (tenant_known(rg)) reg = make_uint2(rg.base, rg.buckets), m_hash_begin = rg.root_hash_begin, m_hash_count = rg.root_hash_count, m_bloom = rg.root_lit_bloom;
+        }
+        t_region_early = reg;
     }
     // The wave's topics in CHUNKS that fit the token table -- one chunk unless the depths of the 64 topics add up to more than TC levels.
     // A chunk = the longest prefix of the topics still to be walked whose tokens fit; its topics are tokenised (the first chunk from the
@@ -332,11 +357,11 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
         wave_sync(); // (first chunk: the staged bytes are dead from here on: the area becomes stack + range buffer)
         if (!run) continue;
         if (MIXED) {
-            if (first) {
-                t_region[lane] = make_uint2(mrg.base, mrg.buckets);
+            if (first) { // (the staging area is free now)
+                t_region[lane] = t_region_early;
                 wave_sync();
             }
-            boot(mine && tenant_known(mrg), mrg.root_hash_begin, mrg.root_hash_count, mrg.root_lit_bloom);
+            boot(mine, m_hash_begin, m_hash_count, m_bloom);
             drain(std::integral_constant<int, 2>{}, b.ix.trie, 1u);
         } else {
             // the chunk's tenants, one after the other (batches arrive grouped by tenant: one, sometimes two)

@@ -8,7 +8,7 @@ from collections import defaultdict
 R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = os.path.join("gpurun_out", R), os.path.join("profiles", R)
 os.makedirs(dst, exist_ok=True)
-for name in ("pytest_gpu.log", "bench_c3.json", "bench_c2.json", "bench_c4.json", "bench_c3.err"):
+for name in ("pytest_gpu.log", "bench_c3.json", "bench_c2.json", "bench_c4.json", "bench_c3.err", "c3_pmc_sq.csv", "parity_report.jsonl"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))
@@ -19,6 +19,14 @@ for w in ("c3", "c2", "c4"):
 sys.path.insert(0, os.getcwd())
 from bench import kernel_sources_sha  # the same hash bench.py checks before it quotes a traffic file
 
+def kernel_base_name(n):
+    """'void bmq::k_walk<512, 192, 160, false>(bmq::BatchArgs)' -> 'bmq::k_walk' (template instantiations are summed under their template)"""
+    n = n.split("(")[0]
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
+
+
 traffic_out = {}
 for w in ("c3", "c2", "c4"):
     rows, per = [], {}
@@ -26,20 +34,24 @@ for w in ("c3", "c2", "c4"):
         hits = glob.glob(os.path.join(src, "pmc_%s_%s" % (w, c), "**", "*counter_collection.csv"), recursive=True)
         if not hits:
             continue
-        acc = defaultdict(list)
+        acc = defaultdict(list)  # kernel -> [(grid, value)]
         with open(hits[0]) as f:
             for r in csv.DictReader(f):
                 if r["Counter_Name"] == c:
-                    acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+                    acc[kernel_base_name(r["Kernel_Name"])].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
         for k in sorted(acc):
-            v = acc[k][1:] if len(acc[k]) > 1 else acc[k]  # the first dispatch of a kernel includes cold-start effects
+            # only the dispatches of the kernel's LARGEST grid = the timed launches (a run also launches smaller batches: warm-up
+            # probes, the host-path legs), and not the first of them (cold start)
+            gmax = max(g for g, _ in acc[k])
+            v = [x for g, x in acc[k] if g == gmax]
+            v = v[1:] if len(v) > 1 else v
             rows.append((k, c, len(v), sum(v) / len(v)))
             per[(k, c)] = sum(v) / len(v)
     if not rows:
         continue
     with open(os.path.join(dst, w + "_pmc_hbm.csv"), "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --workload %s --steps 4 --warmup 1 --no-cpu-baseline "
-                "--no-extras --batcher-threads 0 ; KiB per dispatch, averaged\n" % w)
+                "--no-extras --batcher-threads 0 ; KiB per dispatch, averaged over the dispatches of the kernel's largest grid (the timed launches), the first dropped\n" % w)
         f.write("kernel,counter,dispatches,avg_KiB_per_dispatch\n")
         for k, c, n, v in rows:
             f.write("%s,%s,%d,%.1f\n" % (k, c, n, v))

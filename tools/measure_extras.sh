@@ -1,6 +1,6 @@
 #!/bin/bash
 # Secondary measurements quoted in DESIGN.md section 5 (run through gpurun from the repo root; results under gpurun_out/<round>/extras).
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/$R/extras
 mkdir -p $O
 for n in 10000 100000 4000000; do

@@ -2,7 +2,7 @@
 # Regenerates the evidence kept under profiles/<round>/ on a GPU box (run through gpurun from the repo root):
 #   bash tools/profile_round.sh r03
 # Writes under gpurun_out/<round>/ (scratch); tools/collect_profiles.py then copies the summaries into profiles/<round>/.
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -25,4 +25,6 @@ for w in c3 c2 c4; do
     timeout 400 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -o $w -- python bench.py --workload $w --steps 4 --warmup 1 $P > $O/pmc_${w}_$c.log 2>&1
   done
 done
+# SQ / TCC / TCP counters of the C3 kernels (one pass per counter group; tools/pmc_sq.py writes $O/c3_pmc_sq.csv)
+timeout 900 python tools/pmc_sq.py $R c3 > $O/pmc_sq.log 2>&1; tail -2 $O/pmc_sq.log
 find $O -name "*.csv" | head -60
