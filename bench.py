@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--node-batch-steps", type=int, default=10,
                     help="N>1: steps of the extra node-wide measurement (one shared Zipf batch, device-side partition, hot tenants "
                          "split by filter, fan-out all-reduce); 0 = skip")
+    ap.add_argument("--dedup", action="store_true", help="de-duplicate every batch on the device first (bmq_config.dedup_min_topics = 1; default: never)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1: skip the compact extra legs (configs[4] churn on this index, the batching front at 64 threads, C2 and C4 as "
@@ -120,7 +121,8 @@ def main():
     else:  # one GPU, or a single-tenant config on several GPUs: replicas (documented in DESIGN.md)
         w = B.Workload(seed, total_tenants, per_tenant, mode)
     t_gen = time.time() - t0
-    eng = B.Engine(device=local_rank, kernel_timing=True)  # HIP events around k_walk / k_expand: the roofline needs the kernel time
+    eng = B.Engine(device=local_rank, kernel_timing=True,  # HIP events around k_walk / k_expand: the roofline needs the kernel time
+                   dedup_min_topics=1 if args.dedup else 0)
     kb, ko = w.keys_packed()
     # bmq_rebuild, three times each way (a fresh box's first call pays for page faults of the staging copy and the first builder launches;
     # the docs quoted a best run, the driver saw 3-5x more): min and median are reported
@@ -399,6 +401,8 @@ def main():
                    "tenants_this_rank": int(info.n_tenants), "trie_nodes_this_rank": int(info.n_nodes),
                    "index_bytes_this_rank": int(info.device_bytes), "publishes_per_batch_per_rank": n,
                    "batch_order": "random" if args.ungrouped else "grouped by tenant (one DistPack per tenant)",
+                   "in_batch_dedup": ("on: identical (tenant, topic) rows of a batch are walked once (k_dedup / k_fill), every row keeps its row; N_visit and "
+                                      "the algorithmic bytes count every row" if args.dedup else "off (the engine's default)"),
                    "parallelism": "tenant-shard x%d" % world if world > 1 else "single GPU",
                    "exchange_impl": None if dist is None else ("libbmq (bmq_exchange_*, RCCL loaded by the library)" if use_lib_ex else "torch.distributed (nccl backend = RCCL)"),
                    "exchange": ("none" if dist is None or args.exchange == "none" else

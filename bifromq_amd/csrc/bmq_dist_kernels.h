@@ -122,6 +122,12 @@ struct BatchArgs {
     // LDS geometry
     uint32_t qcap; // pow2
     uint32_t pcap; // >= 128
+    // in-batch de-duplication (bmq_dedup_kernels.h); rep == nullptr: off
+    uint32_t* rep;                  // [n_topics] the row that stands for this row's (tenant, topic): itself, or an identical earlier claimant
+    uint32_t* visit_cnt;            // [n_topics] nodes discovered for the row's topic (written for representatives)
+    unsigned long long* dd_table;   // open addressing, dd_mask + 1 entries: generation << 56 | hash tag << 32 | row
+    uint32_t dd_mask;
+    uint32_t dd_gen;                // 1..255
     uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising, 2 = fill dbg_wave
     uint4* dbg_wave;      // [n_blocks] {phase 1, phase 2, phase 3 shader clocks, rounds | items << 8} of every k_walk wave, or null
 };
@@ -470,7 +476,8 @@ __device__ __forceinline__ unsigned long long dbg_clock(bool on) {
     return __builtin_amdgcn_s_memtime();
 }
 } // namespace bmq
-#include "bmq_walk_kernel.h" // k_walk<LV, QC, PC>: one wave (= one 64-thread workgroup) per 64 topics
+#include "bmq_dedup_kernels.h" // k_dedup / k_fill: identical (tenant, topic) rows of a batch are walked once
+#include "bmq_walk_kernel.h"   // k_walk<TC, QC, PC, MIXED>: one wave (= one 64-thread workgroup) per 64 topics
 namespace bmq {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -485,6 +492,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         const uint32_t t = a.slow_list[i];
         const uint32_t beg = a.topic_off[t], end = a.topic_off[t + 1];
         const uint32_t ti = a.topic_tenant[t];
+        if (a.visit_cnt) a.visit_cnt[t] = 0;
         if (ti >= a.n_tenants) continue;
         const TenantSlot rg = resolve_tenant(a, ti);
         if (!tenant_known(rg)) continue;
@@ -577,6 +585,10 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
         a.pair_off[t] = (uint32_t)base;
         a.pair_cnt[t] = np;
         a.route_cnt[t] = nr;
+        if (a.rep) { // de-duplication on: k_fill sums the blocks and the statistics, duplicates of this row included
+            a.visit_cnt[t] = visits;
+            continue;
+        }
         if (nr) {
             atomicAdd(&a.wave_sums[t >> a.tpw_shift], (unsigned long long)nr);
             atomicAdd(&a.super_sums[(size_t)(t >> (a.tpw_shift + SUPER_SHIFT)) * SUPER_STRIDE], (unsigned long long)nr);
@@ -703,7 +715,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64, BMQ_EXP_MIN_WAVES) void k_expand(Ba
     const unsigned long long m_np = __ballot(np != 0);
     const uint32_t first_l = m_np ? (uint32_t)__ffsll((long long)m_np) - 1u : 0u;
     const uint32_t po0 = __shfl(po, first_l) - __shfl(pexcl, first_l);
-    const bool contiguous = __all(np == 0 || po == po0 + pexcl);
+    const bool contiguous = __all(np == 0 || po == po0 + pexcl) && !(a.debug_flags & 64u); // (BMQ_DEBUG=64: experiment, always gather)
 #if BMQ_EXP_PREFETCH
     MatchRange pf[EXP_EPL]; // the ranges of the coming pass (contiguous layout only)
 #pragma unroll

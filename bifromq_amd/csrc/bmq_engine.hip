@@ -103,6 +103,9 @@ struct bmq_engine {
     bool built = false;
     bool slow_on = false, sort_on = false; // the repair kernels are in the pipeline (see launch_dist)
     uint32_t slow_idle = 0, sort_idle = 0; // consecutive batches that ran them for nothing
+    DevBuf dd_table;                       // in-batch de-duplication (bmq_dedup_kernels.h): one table for all batch slots (batches run in stream order)
+    uint32_t dd_gen = 0;                   // generation of the last batch that used it (1..255; 0: fresh / just zeroed)
+    uint32_t dedup_min = 0xFFFFFFFFu;      // batches of at least this many topics are de-duplicated (bmq_config.dedup_min_topics; default: never)
     bool mixed_on = false;                 // k_walk runs in its MIXED instantiation (batches are not grouped by tenant)
     uint32_t mixed_idle = 0;
     int walk_geom = 0;                     // LDS geometry of k_walk: 0 default, 2 smallest lists (bmq_config caps <= 128)
@@ -112,7 +115,7 @@ struct bmq_engine {
     // host API (bmq_match_submit / bmq_match_wait) owns two slots of its own, so that the upload of batch i+1 and the download of
     // batch i-1 are in flight while the kernels of batch i run; every other entry point works on slot 0.
     struct BatchSlot {
-        DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave;
+        DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave, b_rep, b_visit;
         DevBuf b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch, b_sort_list, b_ctr,
             b_total;
         uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
@@ -327,6 +330,24 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     }
     a.qcap = e->cfg.wave_queue_cap;
     a.pcap = e->cfg.wave_pair_cap;
+    a.rep = nullptr, a.visit_cnt = nullptr, a.dd_table = nullptr, a.dd_mask = 0, a.dd_gen = 0;
+    if (a.n_topics >= e->dedup_min) { // identical (tenant, topic) rows are walked once
+        uint32_t cap = 1024;
+        while (cap < 2 * a.n_topics && cap < (1u << 31)) cap <<= 1;
+        if (e->dd_table.cap < sizeof(unsigned long long) * cap) e->dd_gen = 0; // (a new table: to be zeroed)
+        HIPCHK(e, e->dd_table.ensure(sizeof(unsigned long long) * cap));
+        cap = 1024; // the table in use = the largest power of two the buffer holds (it only grows)
+        while ((size_t)cap * 2 * sizeof(unsigned long long) <= e->dd_table.cap && cap < (1u << 31)) cap <<= 1;
+        if (e->dd_gen == 0 || e->dd_gen == 255) { // entries of other generations count as free; the 8-bit generation wrapped: start over
+            HIPCHK(e, hipMemsetAsync(e->dd_table.p, 0, sizeof(unsigned long long) * cap, e->stream));
+            e->dd_gen = 0;
+        }
+        e->dd_gen++;
+        HIPCHK(e, S.b_rep.ensure(sizeof(uint32_t) * a.n_topics));
+        HIPCHK(e, S.b_visit.ensure(sizeof(uint32_t) * a.n_topics));
+        a.rep = S.b_rep.as<uint32_t>(), a.visit_cnt = S.b_visit.as<uint32_t>();
+        a.dd_table = e->dd_table.as<unsigned long long>(), a.dd_mask = cap - 1, a.dd_gen = e->dd_gen;
+    }
     hipStream_t s = e->stream;
     S.timed = e->kernel_events;
     if (!S.clean) reset_slot(e, S, s); // first batch of the slot, buffers regrown, or a retain batch ran on it
@@ -337,6 +358,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     // the stream, measured).  k_walk keeps its own start event BEHIND ev[0]: the first packet after an idle stream is stamped before the
     // queue has woken up, and ev[0] -> ev[2] read 6 us more than the kernel's own duration (rocprofv3), ev[1] -> ev[2] agrees with it.
     if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[0], s));
+    if (a.rep) hipLaunchKernelGGL(k_dedup, dim3(a.n_blocks), dim3(64), 0, s, a); // (inside ms_total, in front of ms_walk)
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
         // k_walk<token table entries, stack items, range entries, MIXED>: the LDS geometry is a compile-time property (bmq_walk_kernel.h)
@@ -350,7 +372,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     } while (0)
         if (a.debug_flags & 16u) hipLaunchKernelGGL(k_occ_probe, grid, block, 0, s, a); // (experiments: its census replaces k_walk's)
         if (g == 2) BMQ_WALK_LAUNCH(192, 128, 128); // smallest lists: every overflow path runs all the time (tests)
-        else BMQ_WALK_LAUNCH(512, 192, 160);
+        else BMQ_WALK_LAUNCH(512, 176, 152);
 #undef BMQ_WALK_LAUNCH
     }
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[2], s));
@@ -363,6 +385,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
         if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[3], s));
     }
+    if (a.rep) hipLaunchKernelGGL(k_fill, dim3(a.n_blocks), dim3(64), 0, s, a); // (inside ms_expand)
     hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
     if (e->sort_on) {
         if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
@@ -584,6 +607,8 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     e->cfg = c;
     e->device = c.device;
     e->walk_geom = (c.wave_queue_cap <= 128 || c.wave_pair_cap <= 128) ? 2 : 0;
+    if (c.dedup_min_topics) e->dedup_min = c.dedup_min_topics;
+    if (const char* v = getenv("BMQ_DEDUP_MIN")) e->dedup_min = (uint32_t)strtoul(v, nullptr, 10); // profiling experiments (4294967295: never)
     if (const char* v = getenv("BMQ_WALK_GEOM")) e->walk_geom = atoi(v);
     if (const char* v = getenv("BMQ_WALK_MIXED")) e->mixed_on = atoi(v) != 0; // profiling experiments
     e->kernel_events = c.kernel_timing != 0;

@@ -41,7 +41,8 @@ template <int TC, int QC, int PC, bool MIXED> struct WalkLds { // byte offsets i
     static constexpr uint32_t STK = TOK + TC * 4;         // uint2 [QC]     work stack (node id, meta)     | phase 1: staged topic bytes from here on
     static constexpr uint32_t PRG = STK + QC * 8;         // uint2 [PC]     matched ranges (begin, count)
     static constexpr uint32_t PTP = PRG + PC * 8;         // u8 [PC]        ... topic-local index
-    static constexpr uint32_t REG = PTP + PC;             // uint2 [64]     MIXED only: (region base, buckets) of each topic's tenant
+    static constexpr uint32_t VIS = PTP + PC;             // u32 [64]       nodes discovered per topic (N_visit of SURVEY.md 8d, per row)
+    static constexpr uint32_t REG = VIS + 64 * 4;         // uint2 [64]     MIXED only: (region base, buckets) of each topic's tenant
     static constexpr uint32_t BYTES = (REG + (MIXED ? 64 * 8 : 0) + 15) & ~15u;
     static constexpr uint32_t STAGE = BYTES - STK;        // bytes available for staging
     // waves per SIMD the LDS slice allows (160 KB per CU, one wave per workgroup, 512-byte allocation granules assumed), at most 8
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     uint2* const stk = reinterpret_cast<uint2*>(lds + G::STK / 4);
     uint2* const p_rng = reinterpret_cast<uint2*>(lds + G::PRG / 4);
     uint8_t* const p_topic = reinterpret_cast<uint8_t*>(lds) + G::PTP;
+    uint32_t* const cnt_visit = lds + G::VIS / 4;
     uint2* const t_region = reinterpret_cast<uint2*>(lds + G::REG / 4); // MIXED only
     uint32_t* const cnt_pairs = lds + G::TOK / 4; // phase 3 (the token table is dead by then)
     uint32_t* const cnt_routes = cnt_pairs + 64;
@@ -120,7 +122,9 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
         tbytes = end - pos;
         ti = a.topic_tenant[t];
     }
-    const bool asked = ti < a.n_tenants; // (a topic of a tenant the index turns out not to know is tokenised for nothing: rare)
+    // walked here: rows of tenants the batch names -- with in-batch de-duplication (k_dedup) only the representative of every (tenant, topic)
+    // (a topic of a tenant the index turns out not to know is tokenised for nothing: rare)
+    const bool asked = ti < a.n_tenants && (a.rep == nullptr || a.rep[t] == t);
     wave_sync();
     const uint8_t* lbytes = reinterpret_cast<const uint8_t*>(stk);
     const uint32_t* lwords = reinterpret_cast<const uint32_t*>(stk);
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     // area, as chunks {header record, payload records}; the header links to the wave's previous chunk of the same kind
     // (base, length; length 0 ends the chain), so the bookkeeping is two wave-uniform registers per chain.
     // Everything below that is named s_* or is a list fill level is WAVE-UNIFORM and kept so explicitly (sgpr()).
-    uint32_t tail = 0, pcount = 0, rounds = 0, items = 0, my_visits = 0;
+    uint32_t tail = 0, pcount = 0, rounds = 0, items = 0;
     uint32_t fl_base = 0, fl_len = 0; // last flushed range chunk
     uint32_t qs_base = 0, qs_len = 0; // last parked stack chunk (LIFO)
     auto spill_alloc = [&](const BatchArgs& c, uint32_t ln, uint32_t n, uint32_t& base) -> bool { // wave-uniform; n payload records + header
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
             const uint32_t child = m1 ? line.b1.z : line.a1.z, bloom = m1 ? line.b1.w : line.a1.w;
             const uint32_t cmeta = (meta & ~KIND_P) + WALK_META_CHILD; // the same topic, one level on
             const bool last = ((meta >> 16) & 31u) == 0;               // no level of the topic behind this item's
-            my_visits += found ? 1u : 0u;
+            if (found) atomicAdd(&cnt_visit[tl], 1u); // (LDS, no return value)
             const uint32_t bloom_in = (found && !last) ? bloom : 0u;   // children only below an inner level
             // the literal child: the next token is known to the dictionary (TOK_UNKNOWN = 0: min() drops it) and the node's Bloom word has its bit
             const uint32_t lit = min((bloom_in >> bloom_bit(tnext)) & 1u, tnext);
@@ -346,6 +350,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     // A chunk = the longest prefix of the topics still to be walked whose tokens fit; its topics are tokenised (the first chunk from the
     // staged bytes, later ones from global memory: the staging area is stack and range buffer by then), then walked.
     unsigned long long left = ballot64(asked && !deep);
+    if (left == 0) cnt_visit[lane] = 0; // (nothing to walk: the counters are read below all the same)
     for (bool first = true; left != 0; first = false) {
         const bool cand = (left >> lane) & 1ull;
         uint32_t total;
@@ -354,7 +359,8 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
         left &= ~chunk;
         const bool mine = (chunk >> lane) & 1ull;
         tokenise(mine, first && staged);
-        wave_sync(); // (first chunk: the staged bytes are dead from here on: the area becomes stack + range buffer)
+        if (first) cnt_visit[lane] = 0; // (first chunk: the staged bytes are dead from here on: the area becomes stack + range buffer + counters)
+        wave_sync();
         if (!run) continue;
         if (MIXED) {
             if (first) { // (the staging area is free now)
@@ -465,15 +471,19 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
             else atomicOr(&d.ctr->status, ST_NEED_SLOW);
         }
     }
+    const uint32_t vis = cnt_visit[l3];
+    if (valid && d.visit_cnt) d.visit_cnt[t] = vis;
     const unsigned long long wsum = wave_sum_u64(nr);
-    const unsigned long long wvis = wave_sum_u64(my_visits);
+    const unsigned long long wvis = wave_sum_u64(vis);
     const unsigned long long wbytes = wave_sum_u64(tbytes);
     if (l3 == 0) {
-        d.wave_sums[blk] = wsum;
-        if (wsum) atomicAdd(&d.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], wsum);
-        // statistics: a plain store per wave.  (Atomics were measured twice: on the batch counters they set the kernel's duration,
-        // three more per wave on the super-block's line still cost +20 us per 1 M topics and +7 us per 10 k.)
-        d.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
+        if (d.rep == nullptr) { // (with in-batch de-duplication k_fill writes these, every duplicate row counted with its representative's figures)
+            d.wave_sums[blk] = wsum;
+            if (wsum) atomicAdd(&d.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], wsum);
+            // statistics: a plain store per wave.  (Atomics were measured twice: on the batch counters they set the kernel's duration,
+            // three more per wave on the super-block's line still cost +20 us per 1 M topics and +7 us per 10 k.)
+            d.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
+        }
         if (d.dbg_wave && (d.debug_flags & 8u)) { // residency census: when and where this wave ran (tools: BMQ_DEBUG=8)
             const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
             const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, all 32 bits

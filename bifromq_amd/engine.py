@@ -183,7 +183,8 @@ def java_string_hash(s) -> int:
 class Engine:
     """One engine per KV range replica (cf. DistWorkerCoProc's SubscriptionCache)."""
 
-    def __init__(self, device: int = 0, wave_queue_cap: int = 0, wave_pair_cap: int = 0, slow_scratch_mb: int = 0, kernel_timing: bool = False):
+    def __init__(self, device: int = 0, wave_queue_cap: int = 0, wave_pair_cap: int = 0, slow_scratch_mb: int = 0, kernel_timing: bool = False,
+                 dedup_min_topics: int = 0):
         L = _lib.lib()
         cfg = _lib.Config()
         cfg.struct_size = C.sizeof(_lib.Config)
@@ -192,6 +193,7 @@ class Engine:
         cfg.wave_pair_cap = wave_pair_cap
         cfg.slow_scratch_mb = slow_scratch_mb
         cfg.kernel_timing = 1 if kernel_timing else 0
+        cfg.dedup_min_topics = dedup_min_topics  # 0: default = never; n: batches of >= n topics are de-duplicated on the device first
         h = C.c_void_p()
         rc = L.bmq_engine_create(C.byref(cfg), C.byref(h))
         if rc:

@@ -66,7 +66,12 @@ typedef struct bmq_config {
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t kernel_timing;    /* 1: HIP events around k_walk / k_expand of every batch -> bmq_stats.ms_walk /  */
                                /* ms_expand (two extra events per batch, ~4 us each on the stream); 0: ms_total  */
-    uint32_t reserved[7];
+    uint32_t dedup_min_topics; /* a batch of at least this many topics is de-duplicated on the device first: identical      */
+                               /* (tenant, topic) rows are walked once, every row keeps its own row in the result (matchAll   */
+                               /* takes a Set<String>, TenantRouteMatcher.java:67-78).  0 = default = UINT32_MAX = never: on  */
+                               /* the survey's Zipf batches it takes 16 % off the walk kernel and costs more than that in the */
+                               /* two kernels around it                                                 */
+    uint32_t reserved[6];
 } bmq_config;
 
 /* Counters of the last completed match batch (for roofline accounting). */

@@ -236,6 +236,39 @@ def test_grouped_batch_equals_ungrouped(eng):
         assert np.array_equal(b_rp, res.row_ptr.astype(np.int64)) and np.array_equal(b, res.routes)
 
 
+def test_in_batch_dedup_changes_nothing_but_the_work():
+    """Identical (tenant, topic) rows of a batch are walked once (k_dedup / k_fill: matchAll takes a Set<String>,
+    TenantRouteMatcher.java:67-78); every row keeps its own row.  An engine that de-duplicates every batch and one that never does must
+    return the same CSR and the same statistics -- N_visit / ranges / bytes are counted per ROW (the roofline accounting of SURVEY.md 8d
+    treats them as properties of the data) -- on batches full of repeats: hot topics, topics of unknown tenants, empty topics, topics
+    deeper than FAST_LEVELS (k_walk_slow), in both batch orders and with the smallest LDS lists; and both equal the semantic oracle."""
+    rnd = random.Random(11)
+    tenants = ["tA", "tB", "租户", "t4", "t5", "t6"]
+    alphabet = ["a", "b", "c", "", "$sys", "dev", "x" * 17]
+    keys = sorted({U.rand_route_key(rnd, rnd.choice(tenants), U.rand_filter(rnd, 5, alphabet), i) for i in range(6000)} |
+                  {U.rand_route_key(rnd, "tA", "/".join(["a"] * 20 + ["#"]), 900001), U.rand_route_key(rnd, "tB", "/".join(["+"] * 18), 900002)})
+    kv = O.KV(keys)
+    pool = [U.rand_topic(rnd, 6, alphabet) for _ in range(700)] + ["", "/", "a", "/".join(["a"] * 21), "/".join(["a"] * 18)]
+    topics = [pool[min(int(rnd.paretovariate(1.1)) - 1, len(pool) - 1)] for _ in range(20000)]  # Zipf-like repeats
+    tnames = tenants + ["ghost"]
+    tt = [rnd.randrange(len(tnames)) for _ in topics]
+    exp = U.semantic_rows(kv, tnames, tt, topics)
+    for order in ("as is", "grouped"):
+        if order == "grouped":
+            o = sorted(range(len(topics)), key=lambda i: tt[i])
+            topics, tt, exp = [topics[i] for i in o], [tt[i] for i in o], [exp[i] for i in o]
+        stats = []
+        for dd, geom in ((1, {}), (0xFFFFFFFF, {}), (1, dict(wave_queue_cap=128, wave_pair_cap=128, slow_scratch_mb=1))):
+            e = B.Engine(device=0, dedup_min_topics=dd, **geom).rebuild(keys)
+            row, ids = e.match_batch(tnames, tt, topics)
+            assert U.csr_rows(row, ids) == exp
+            st = e.stats()
+            stats.append((st.n_visit, st.n_match, st.n_ranges, st.topic_bytes, st.n_slow_topics > 0))
+            e.close()
+        assert stats[0] == stats[1] == stats[2]
+        assert stats[0][0] == int(kv.count_visits(tnames, np.array(tt, dtype=np.uint32), O.pack(topics)).sum())
+
+
 # ---- the rare paths: LDS overflow -> per-lane DFS, deep topics, interleaved ranges -> fix-up sort ------------------
 def test_slow_path_equals_fast_path():
     rnd = random.Random(5)
