@@ -130,6 +130,7 @@ struct bmq_engine {
         bool clean = false; // counters / allocators / super sums are zero (k_reset ran behind the last batch of the slot)
         bool ran_slow = false, ran_sort = false; // k_walk_slow / k_sort_rows were part of this batch's launch
         bool ran_mixed = false;                  // k_walk ran in its MIXED instantiation
+        bool ran_rdeep = false;                  // retain: k_retain_walk_deep was part of this batch's launch
         bool timed = false; // this batch was launched with the per-kernel events (bmq_config.kernel_timing)
         bool total_timed = false; // ... with the two events around the whole batch (bmq_stats.ms_total)
         int pending_kind = 0; // 0 dist, 1 retain
@@ -165,7 +166,9 @@ struct bmq_engine {
     uint64_t repoch = 0;      // +1 per retain rebuild / apply / compact
     uint64_t rgeneration = 0; // +1 per retain rebuild / compact: topic ids of different generations are unrelated
     RetainLimit rlim;
-    DevBuf r_scratch;
+    DevBuf r_scratch, r_deep_list, r_deep_levels;
+    bool rdeep_on = false;   // k_retain_walk_deep is in the pipeline (batches hold filters of more than R_MAXL levels)
+    uint32_t rdeep_idle = 0;
     DevBuf range_buf; // staging of bmq_range_lookup
     // fan-out grouping (bmq_fanout.h): group table + per-route cache, created by the first call
     std::unique_ptr<Fanout<DevExec>> dfo;

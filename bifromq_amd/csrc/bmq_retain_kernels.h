@@ -52,6 +52,11 @@ struct RetainArgs {
     uint32_t n_filters;
     uint2* gscratch;       // per wave: 2 * gcap ranges
     uint32_t gcap;
+    // filters of more than R_MAXL levels (MQTT ingress rejects more than 16: Setting.MaxTopicLevels): the walk lists them (their count
+    // is Counters.slow_count), a second launch of the same walk with its per-level arrays in global memory answers them
+    uint32_t* deep_list;   // [n_filters]
+    uint32_t* deep_levels; // deep pass only: per wave 6 arrays of deep_maxl + 1 words
+    uint32_t deep_maxl;
 };
 
 struct Frontier {
@@ -89,12 +94,23 @@ __device__ __forceinline__ RNode load_rnode(const RetainIndexView& ix, uint32_t 
     return RNode{v.x, v.y, v.z, v.w};
 }
 
-__global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
-    __shared__ uint32_t lev_start[R_MAXL + 1], lev_end[R_MAXL + 1], ftok[R_MAXL + 1];
+// DEEP = false: every filter of the batch, the per-level arrays in LDS (filters deeper than R_MAXL are listed and left empty);
+// DEEP = true: the listed filters, the per-level arrays in global memory (launched only while batches hold such filters).
+template <bool DEEP>
+__device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const BatchArgs& a) {
+    __shared__ uint32_t s_lev_start[R_MAXL + 1], s_lev_end[R_MAXL + 1], s_ftok[R_MAXL + 1];
     __shared__ uint32_t fb0[R_FRONT], fc0[R_FRONT], fb1[R_FRONT], fc1[R_FRONT];
     __shared__ uint32_t sh[12];
     __shared__ uint32_t ob[R_OUT], oc[R_OUT];
-    __shared__ uint32_t lh1[R_MAXL + 1], lh2[R_MAXL + 1], llen[R_MAXL + 1]; // level hashes: the overlay is keyed by them
+    __shared__ uint32_t s_lh1[R_MAXL + 1], s_lh2[R_MAXL + 1], s_llen[R_MAXL + 1]; // level hashes: the overlay is keyed by them
+    const uint32_t maxl = DEEP ? r.deep_maxl : R_MAXL;
+    uint32_t* const gl = DEEP ? r.deep_levels + (size_t)blockIdx.x * 6 * ((size_t)r.deep_maxl + 1) : nullptr;
+    uint32_t* const lev_start = DEEP ? gl : s_lev_start;
+    uint32_t* const lev_end = DEEP ? gl + (maxl + 1) : s_lev_end;
+    uint32_t* const ftok = DEEP ? gl + 2 * (maxl + 1) : s_ftok;
+    uint32_t* const lh1 = DEEP ? gl + 3 * (maxl + 1) : s_lh1;
+    uint32_t* const lh2 = DEEP ? gl + 4 * (maxl + 1) : s_lh2;
+    uint32_t* const llen = DEEP ? gl + 5 * (maxl + 1) : s_llen;
     __shared__ uint32_t ovb[OV_OUT], ovs[OV_OUT];
     const RetainDynView dyn = r.ix.dyn;
     const uint32_t lane = threadIdx.x;
@@ -102,7 +118,9 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
     const uint32_t cap = R_FRONT + r.gcap;
     unsigned long long visits = 0, wranges = 0, wbytes = 0;
 
-    for (uint32_t f = blockIdx.x; f < r.n_filters; f += gridDim.x) {
+    const uint32_t n_work = DEEP ? min(a.ctr->slow_count, r.n_filters) : r.n_filters;
+    for (uint32_t fi = blockIdx.x; fi < n_work; fi += gridDim.x) {
+        const uint32_t f = DEEP ? r.deep_list[fi] : fi;
         // ---- tokenise the filter: '/' positions by ballot, then one lane per level for hash + dictionary ----------------
         const uint32_t beg = r.filter_off[f], end = r.filter_off[f + 1];
         uint32_t nsep = 0;
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             const unsigned long long m = __ballot(sep);
             if (sep) {
                 const uint32_t k = nsep + rank_below(m);
-                if (k < R_MAXL) {
+                if (k < maxl) {
                     lev_end[k] = i;
                     lev_start[k + 1] = i + 1;
                 }
@@ -122,24 +140,25 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             nsep += (uint32_t)__popcll(m);
         }
         const uint32_t nlev = nsep + 1;
-        if (nlev > R_MAXL) deep = true;
+        if (nlev > maxl) deep = true;
         if (lane == 0 && !deep) lev_end[nlev - 1] = end;
+        if (DEEP) __threadfence_block(); // (the arrays live in global memory: other lanes read what this lane wrote)
         __syncthreads();
         RTenantSlot ten{0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
         if (!deep) {
             const uint8_t* fbytes = r.filters;
             auto fbyte = [&](uint32_t k) -> uint32_t { return fbytes[k]; };
             auto fword = [&](uint32_t k) -> uint32_t { return global_word_at(fbytes, k); };
-            if (lane < nlev) {
-                uint32_t pos = lev_start[lane];
-                const uint32_t start = pos, e = lev_end[lane];
+            for (uint32_t lv = lane; lv < nlev; lv += 64) { // one lane per level (one round unless the filter is deep)
+                uint32_t pos = lev_start[lv];
+                const uint32_t start = pos, e = lev_end[lv];
                 LevelHash h;
                 uint32_t inl[4], len;
                 bool last;
                 scan_level(pos, e, false, fword, h, inl, len, last);
                 uint32_t tok;
                 if (len == 1 && inl[0] == '+') tok = RT_PLUS;
-                else if (len == 1 && inl[0] == '#' && lane == nlev - 1) tok = RT_HASH;
+                else if (len == 1 && inl[0] == '#' && lv == nlev - 1) tok = RT_HASH;
                 else {
                     DistIndexView dv{};
                     dv.dict = r.ix.dict;
@@ -147,10 +166,10 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                     dv.pool = r.ix.pool;
                     tok = dict_lookup(dv, h, len, inl, start, fbyte);
                 }
-                ftok[lane] = tok;
-                lh1[lane] = h.h1;
-                lh2[lane] = h.h2;
-                llen[lane] = len;
+                ftok[lv] = tok;
+                lh1[lv] = h.h1;
+                lh2[lv] = h.h2;
+                llen[lv] = len;
             }
             if (lane == 63) { // tenant -> root
                 const uint32_t ti = r.filter_tenant[f];
@@ -195,12 +214,16 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
                 sh[0] = root;
             }
         }
+        if (DEEP) __threadfence_block(); // (the level arrays in global memory: written by one lane each, read by all below)
         __syncthreads();
         const uint32_t root = deep ? NONE : sh[0];
         const uint32_t tnode = (deep || !dyn.ov_live) ? NONE : sh[9];
         ten.node_base = sh[1]; ten.edge_base = sh[2]; ten.edge_bucket_mask = sh[3]; ten.id_base = root != NONE ? sh[4] : 0u;
         ten.sys_node_lo = sh[5]; ten.sys_node_hi = sh[6]; ten.sys_id_lo = sh[7]; ten.sys_id_hi = sh[8];
-        if (deep && lane == 0) atomicOr(&a.ctr->status, ST_RETAIN_DEEP);
+        if (deep && lane == 0) {
+            if (DEEP) atomicOr(&a.ctr->status, ST_RETAIN_DEEP); // (deeper than a 64 KB filter can be: cannot happen)
+            else r.deep_list[atomicAdd(&a.ctr->slow_count, 1u)] = f; // left empty here; the deep pass answers it
+        }
 
         // ---- two passes: count, then write -------------------------------------------------------------------------------------
         unsigned long long base = 0;
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
             }
         }
         wranges += np_total;
-        wbytes += end - beg;
+        if (DEEP || !deep) wbytes += end - beg; // (a deep filter is counted by the pass that answers it)
         __syncthreads();
     }
     const unsigned long long wv = wave_sum_u64(visits);
@@ -522,6 +545,9 @@ __global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) {
         if (wbytes) atomicAdd(&a.ctr->topic_bytes, wbytes);
     }
 }
+
+__global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) { retain_walk_body<false>(r, a); }
+__global__ __launch_bounds__(64) void k_retain_walk_deep(RetainArgs r, BatchArgs a) { retain_walk_body<true>(r, a); }
 
 // ------------------------------------------------------------------------------------------------------------
 // RetainStoreCoProc.match(limit, now) without expanding anything (RS/RetainStoreCoProc.java:167-190): the reference walks the

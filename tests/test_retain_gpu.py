@@ -177,10 +177,53 @@ def test_edge_shapes(eng):
     assert [eng.retain_topic(i)[1] for i in eng.retain_match("t", "x" * 5000 + "/#")] == ["x" * 5000 + "/y"]
     assert eng.retain_match("t", "x" * 4999 + "/#") == []
     assert len(eng.retain_match("t", "#")) == 4
-    with pytest.raises(B.BmqError) as ei:  # documented limit of the kernel: 64 filter levels
-        eng.retain_match("t", "/".join(["+"] * 65))
-    assert ei.value.code == -6
-    assert len(eng.retain_match("t", "#")) == 4  # the engine stays usable after the error
+    assert eng.retain_match("t", "/".join(["+"] * 65)) == []  # (round 3: BMQ_E_RANGE for the whole batch -- the kernel's 64-level limit)
+    assert len(eng.retain_match("t", "#")) == 4
+
+
+def test_filters_deeper_than_64_levels_inside_a_normal_batch(eng):
+    """TopicLevelTrie.lookup has no depth limit (UTIL/index/TopicLevelTrie.java:190-249).  k_retain_walk keeps a filter's per-level arrays in
+    LDS (64 levels); deeper filters are listed and answered by a second launch of the same walk with those arrays in global memory
+    (k_retain_walk_deep, in the pipeline only while batches hold such filters).  65-, 100- and 300-level filters -- literal, '+', trailing
+    '#', matching and not -- inside a batch of ordinary ones, against the oracle; before and after an apply (overlay + dead ids); the deep
+    pass switches itself off again after 32 batches without such filters."""
+    rnd = random.Random(21)
+    deep_topics = ["/".join(["a"] * n) for n in (64, 65, 66, 100, 299, 300)] + ["/".join(["a"] * 99 + ["b"]), "/".join(["a"] * 70 + ["", "c"])]
+    shallow = sorted({U.rand_topic(rnd, 5, ["a", "b", "c", "", "$sys"]) for _ in range(400)})
+    topics = deep_topics + shallow
+    eng.retain_rebuild(["t"], [0] * len(topics), topics)
+    lt = O.LevelTrie(1)
+    ids = {}
+    for i in eng.retain_live_ids("t"):
+        ids[eng.retain_topic(i)[1]] = i
+    for tp, i in ids.items():
+        lt.add("t", tp, i)
+    filters = [U.rand_filter(rnd, 5, ["a", "b", "c", ""]) for _ in range(300)] + [
+        "/".join(["a"] * 65), "/".join(["+"] * 65), "/".join(["a"] * 64 + ["+"]), "/".join(["a"] * 64 + ["#"]), "/".join(["+"] * 64 + ["#"]),
+        "/".join(["a"] * 100), "/".join(["a"] * 99 + ["+"]), "/".join(["+"] * 99 + ["b"]), "/".join(["a"] * 300), "/".join(["+"] * 300),
+        "/".join(["a"] * 298 + ["#"]), "/".join(["a"] * 70 + ["", "+"]), "/".join(["b"] * 80), "/".join(["a"] * 301), "/".join(["a"] * 64)]
+    rnd.shuffle(filters)
+
+    def check():
+        row, got = eng.retain_match_batch(["t"], [0] * len(filters), filters)
+        exp = [sorted(lt.match("t", f)) for f in filters]
+        assert U.csr_rows(row, got) == exp
+        assert sum(len(e) for e, f in zip(exp, filters) if f.count("/") >= 64) >= 12  # the deep filters really match something
+
+    check()
+    # churn: remove two deep topics, add one deep and one shallow (overlay), then the same batch again
+    eng.retain_apply("t", [(1, deep_topics[1]), (1, deep_topics[3])])
+    lt.remove("t", deep_topics[1], ids[deep_topics[1]])
+    lt.remove("t", deep_topics[3], ids[deep_topics[3]])
+    new = ["/".join(["a"] * 65 + ["z"]), "a/zz"]
+    out = eng.retain_apply_batch(["t"], [0, 0], [(0, new[0]), (0, new[1])])
+    for tp, i in zip(new, out.tolist()):
+        lt.add("t", tp, i)
+    filters.append("/".join(["a"] * 65 + ["+"]))
+    check()
+    for _ in range(40):  # ordinary batches: the deep pass leaves the pipeline again, the next deep filter brings it back
+        assert eng.retain_match("t", "a/#") == sorted(lt.match("t", "a/#"))
+    check()
 
 
 def test_apply_is_per_tenant(eng):
