@@ -392,7 +392,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
     if (e->sort_on) {
         if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
-        hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_sort_rows, dim3(1024), dim3(256), 0, s, a);
     }
     if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[5], s));
     if (S.format == BMQ_FMT_RANGES) { // the compact range lists, while the slot's counters still say whether the batch is complete
@@ -531,7 +531,7 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
             e->sort_on = true, e->sort_idle = 0;
             // the slot's counters were reset behind the batch: k_sort_rows reads the row count from them
             HIPCHK(e, hipMemcpyAsync(S.last.ctr, S.h_ctr, sizeof(Counters), hipMemcpyHostToDevice, e->stream));
-            hipLaunchKernelGGL(k_sort_rows, dim3(128), dim3(256), 0, e->stream, S.last);
+            hipLaunchKernelGGL(k_sort_rows, dim3(1024), dim3(256), 0, e->stream, S.last);
             reset_slot(e, S, e->stream);
             HIPCHK(e, hipGetLastError());
             HIPCHK(e, hipStreamSynchronize(e->stream));
