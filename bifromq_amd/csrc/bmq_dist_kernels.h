@@ -228,6 +228,41 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
     return TOK_UNKNOWN;
 }
 
+// The same lookup, one 32-byte SLOT at a time: the builder fills a group's slot 0 before its slot 1, and at load factor <= 1/4 most
+// strings sit in slot 0 -- the second slot is requested only by the lanes that need it.  Half the bytes through the L1 / L2 path per lookup
+// for a dependent second request now and then: right for k_walk, whose tokeniser runs under the other waves' walk rounds while the kernel
+// as a whole sits at the memory system's rate of 64-byte lines (profiles/r04/k_walk_experiments.md).
+__device__ __forceinline__ void load_slot32(const void* p, uint4& a, uint4& b) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(p));
+}
+template <class ByteAt>
+__device__ __forceinline__ uint32_t dict_lookup_by_slot(const DistIndexView& ix, const LevelHash& h, uint32_t len, const uint32_t inl[4], uint32_t start,
+                                                        ByteAt&& byte_at) {
+    const uint32_t tag = level_hash_tag(h);
+    uint32_t g = level_hash_slot(h, len) & ix.dict_group_mask;
+    auto tail_eq = [&](uint32_t pool_off) { // bytes beyond the 16 inline ones (rare: levels are short)
+        bool eq = true;
+        for (uint32_t i = 16; i < len && eq; i++) eq = ix.pool[pool_off + i] == byte_at(start + i);
+        return eq;
+    };
+    for (uint32_t probes = 0; probes <= ix.dict_group_mask; probes++) { // bounded: a damaged table must not hang the GPU
+        const DictSlot* grp = ix.dict + DICT_GROUP * (size_t)g;
+#pragma unroll
+        for (uint32_t k = 0; k < DICT_GROUP; k++) {
+            uint4 hd, in;
+            load_slot32(grp + k, hd, in);
+            if (hd.x == tag && hd.z == len && in.x == inl[0] && in.y == inl[1] && in.z == inl[2] && in.w == inl[3] && (len <= 16 || tail_eq(hd.w))) return hd.y;
+            if (hd.x == 0) return TOK_UNKNOWN; // a free slot ends the probe sequence (slots of a group fill in order)
+        }
+        g = (g + 1) & ix.dict_group_mask;
+    }
+    return TOK_UNKNOWN;
+}
+
 // Scans one level starting at pos: bytes up to the next '/' (split) or to `end`, FOUR BYTES PER STEP.
 // word_at(p) returns the 4 bytes p..p+3 as a little-endian word (bytes at or beyond `end` may be garbage: masked here).
 template <class WordAt>

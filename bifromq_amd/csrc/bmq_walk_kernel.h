@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
         if (blockIdx.x >= a.n_blocks) return;
         // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
         // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
-        blk = a.n_blocks - 1 - blockIdx.x;
+        blk = (a.debug_flags & 256u) ? blockIdx.x : a.n_blocks - 1 - blockIdx.x; // (256: experiment, first blocks first)
     }
     // A wave owns TPW = 2^tpw_shift consecutive topics.  64 for large batches; a small batch is spread over more waves (16 or 4
     // topics each): the walk phase is a chain of dependent line fetches whose length is ~ max(depth, items / 64), so a wave with
@@ -166,7 +166,8 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
                 scan_level(p, end, true, word_at, h, inl, len, last);
                 more = !last;
             }
-            const uint32_t tok = now ? dict_lookup(a.ix, h, len, inl, start, byte_at) : TOK_UNKNOWN;
+            const uint32_t tok = now ? ((a.debug_flags & 128u) ? dict_lookup(a.ix, h, len, inl, start, byte_at) : dict_lookup_by_slot(a.ix, h, len, inl, start, byte_at))
+                                     : TOK_UNKNOWN;
             if (now) tokens[tok_base + l] = tok;
         }
     };

@@ -80,6 +80,7 @@ for gi, g in enumerate(GROUPS):
                 k = k[5:]
             if not k.startswith("bmq::"):
                 continue
+            k = k.replace(", ", " ")  # (template arguments: no commas inside a CSV field)
             acc[(k, r["Counter_Name"])].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
     for (k, c), v in sorted(acc.items()):
         gmax = max(g_ for g_, _ in v)

@@ -7,7 +7,7 @@ O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
 if [ -z "$SKIP_PYTEST" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -2
+  timeout 900 python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest_gpu.log 2>&1; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -2
 fi
 # the driver's command (N = 1): default workload C3 + the compact C2 / C4 / C5 / batching-front legs under "extra"
 timeout 300 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; tail -c 300 $O/bench_c3.json
