@@ -1,0 +1,98 @@
+// bmq_batch_args.h -- what the host and the kernels of one match batch share: the status bits, the per-batch counters and the argument
+// block of the dist-direction kernels (k_dedup, k_walk, k_walk_slow, k_fill, k_expand, k_sort_rows; the retain direction fills the same
+// block for k_expand / k_sort_rows).  Plain structs: included by bmq_dist_kernels.h (device) and by the wave emulator of tools/ (host).
+#pragma once
+#include <cstdint>
+
+#include "bmq_layout.h"
+
+namespace bmq {
+
+// status bits raised by kernels, resolved by the host in bmq_match_finish()
+enum : uint32_t {
+    ST_NEED_PAIRS = 1u,     // matched-range buffer too small
+    ST_NEED_SLOW = 2u,      // slow-topic list too small
+    ST_NEED_SCRATCH = 4u,   // slow-path scratch too small
+    ST_NOSPACE = 8u,        // caller's id buffer too small
+    ST_RANGE = 16u,         // >= 2^32 ids
+    ST_NEED_SORTLIST = 32u, // fix-up list too small
+    ST_NEED_SPILL = 64u,    // range spill buffer too small
+    ST_WANT_MIXED = 256u    // a wave held topics of many tenants (the batch is not grouped by tenant): the batch runs again through the MIXED instantiation
+};
+constexpr uint32_t ST_RERUN = ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH | ST_NEED_SPILL;
+
+struct Counters { // one per batch slot, zeroed behind every batch (k_reset)
+    unsigned long long pair_alloc;
+    unsigned long long scratch_alloc; // in uint32 units
+    unsigned long long spill_alloc;   // in records
+    unsigned long long n_visit;
+    unsigned long long total_ids;
+    unsigned long long n_ranges;
+    unsigned long long topic_bytes;
+    uint32_t slow_count;
+    uint32_t sort_count;
+    uint32_t status;
+    uint32_t pad;
+};
+constexpr uint32_t SUPER_SHIFT = 8;   // id counts are summed per 2^SUPER_SHIFT waves (super_sums) on top of the per-wave counts
+constexpr uint32_t SUPER_STRIDE = 16; // ... one sum per 128-byte line: 256 waves bump each, neighbours must not share a line
+
+// Contiguous space in the matched-range buffer is handed out by N_SUB independent allocators, each owning one slice
+// of the buffer and living in its own 128-byte line: a single counter bumped by every wave of a batch (15 625 waves
+// for 1M topics) serialises in the L2 atomic unit and was measured to set the kernel's duration.
+constexpr uint32_t N_SUB = 64;
+struct alignas(128) SubAlloc {
+    unsigned long long used;
+    unsigned long long pad[15];
+};
+struct BatchArgs {
+    DistIndexView ix;
+    // inputs (device)
+    const uint8_t* tenants;
+    const uint32_t* tenant_off;
+    uint32_t n_tenants;
+    const uint32_t* topic_tenant;
+    const uint8_t* topics;
+    const uint32_t* topic_off;
+    uint32_t n_topics;
+    // per-batch scratch (device)
+    uint32_t* pair_off;      // [n_topics]
+    uint32_t* pair_cnt;      // [n_topics]
+    uint32_t* route_cnt;     // [n_topics]
+    MatchRange* pairs;
+    unsigned long long pair_cap;
+    SubAlloc* subs;          // [2 * N_SUB] allocators of `pairs` (first N_SUB) and of `spill` (second N_SUB)
+    unsigned long long* super_sums; // [(n_blocks >> SUPER_SHIFT + 1) * SUPER_STRIDE] ids per 2^SUPER_SHIFT blocks (zeroed by k_reset)
+    uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, 0} written by k_walk; the last
+                             // k_expand wave of every super-block sums its 256 records into ctr (null: retain direction)
+    uint4* spill;            // LDS range buffer flushes: {begin, count, topic-local, 0}
+    unsigned long long spill_cap;
+    unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block
+    uint32_t n_blocks;
+    uint32_t tpw_shift;      // a wave owns 2^tpw_shift topics (6 = all 64 lanes; small batches use 4 or 2: more, shorter waves)
+    uint32_t* slow_list;
+    uint32_t slow_cap;
+    uint32_t* scratch;
+    unsigned long long scratch_cap; // uint32 units
+    uint32_t* sort_list;
+    uint32_t sort_cap;
+    Counters* ctr;
+    // outputs (device)
+    uint32_t* out_row_ptr;
+    uint32_t* out_ids;
+    unsigned long long out_capacity;
+    unsigned long long* out_total;
+    // LDS geometry
+    uint32_t qcap; // pow2
+    uint32_t pcap; // >= 128
+    // in-batch de-duplication (bmq_dedup_kernels.h); rep == nullptr: off
+    uint32_t* rep;                  // [n_topics] the row that stands for this row's (tenant, topic): itself, or an identical earlier claimant
+    uint32_t* visit_cnt;            // [n_topics] nodes discovered for the row's topic (written for representatives)
+    unsigned long long* dd_table;   // open addressing, dd_mask + 1 entries: generation << 56 | hash tag << 32 | row
+    uint32_t dd_mask;
+    uint32_t dd_gen;                // 1..255
+    uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising, 2 = fill dbg_wave
+    uint4* dbg_wave;      // [n_blocks] {phase 1, phase 2, phase 3 shader clocks, rounds | items << 8} of every k_walk wave, or null
+};
+
+} // namespace bmq

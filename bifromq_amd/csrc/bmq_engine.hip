@@ -389,7 +389,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[3], s));
     }
     if (a.rep) hipLaunchKernelGGL(k_fill, dim3(a.n_blocks), dim3(64), 0, s, a); // (inside ms_expand)
-    hipLaunchKernelGGL(k_expand, dim3((a.n_blocks + EXP_WAVES - 1) / EXP_WAVES), dim3(EXP_WAVES * 64), 0, s, a);
+    hipLaunchKernelGGL(k_expand, dim3(a.n_blocks), dim3(64), 0, s, a);
     if (e->sort_on) {
         if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
         hipLaunchKernelGGL(k_sort_rows, dim3(1024), dim3(256), 0, s, a);

@@ -1,0 +1,22 @@
+"""k_expand's LOGIC on the host: bifromq_amd/csrc/bmq_expand_kernel.h compiled by g++ against the wave64 emulator of tools/emu/wave_emu.h
+(64 lanes = 64 fibers, every cross-lane operation a checked rendezvous) and run over random batches -- pass boundaries, rank sort, short /
+streamed / indirect / empty ranges, gathered lists, rows of 2 / 16 / 64 per wave, buffers that are too small -- against a plain
+restatement of the kernel's contract (tools/emu/expand_emu.cpp).  What the GPU makes of the same source is what the -m gpu tests
+check against the oracle; this one needs no GPU and catches logic errors before a GPU minute is spent."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("defs,cases", [((), 60), (("-DBMQ_EXP_K=64", "-DBMQ_EXP_LONG=8", "-DBMQ_EXP_PREFETCH=0"), 40)])
+def test_k_expand_under_the_wave_emulator(tmp_path, defs, cases):
+    exe = str(tmp_path / "expand_emu")
+    cmd = ["g++", "-O1", "-std=c++17", *defs, "-I", os.path.join(ROOT, "bifromq_amd", "csrc"), "-I", os.path.join(ROOT, "tools", "emu"),
+           os.path.join(ROOT, "tools", "emu", "expand_emu.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([exe, str(cases), "12345"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok:"), r.stdout
