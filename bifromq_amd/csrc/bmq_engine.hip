@@ -450,10 +450,14 @@ static void print_wave_debug(bmq_engine* e, bmq_engine::BatchSlot& S) {
                 simd_peak_sum / std::max<size_t>(per_simd.size(), 1));
         return;
     }
-    if (a.debug_flags & 4u) { // k_expand: head (row pointers, wave base) | range load + order | prefix + order check | id generation
+    if (a.debug_flags & 4u) { // k_expand: head (row pointers, wave base) | plan + range load + order | prefix | id generation
+        if (!BMQ_EXP_CLOCKS) {
+            fprintf(stderr, "[bmq] k_expand phase clocks need a build with -DBMQ_EXP_CLOCKS=1 (tools/build_variant.sh)\n");
+            return;
+        }
         double p[4] = {0, 0, 0, 0};
         for (uint32_t i = 0; i < a.n_blocks; i++) p[0] += h[i].x, p[1] += h[i].y, p[2] += h[i].z, p[3] += h[i].w;
-        fprintf(stderr, "[bmq] k_expand waves=%u clocks/wave: head %.0f load+order %.0f prefix+check %.0f generate %.0f\n", a.n_blocks,
+        fprintf(stderr, "[bmq] k_expand waves=%u clocks/wave: head %.0f load+order %.0f prefix %.0f generate %.0f\n", a.n_blocks,
                 p[0] / a.n_blocks, p[1] / a.n_blocks, p[2] / a.n_blocks, p[3] / a.n_blocks);
         return;
     }

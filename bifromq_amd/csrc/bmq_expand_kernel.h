@@ -22,7 +22,12 @@
 // Round 4 rewrite.  The round-2 kernel ordered a row's ranges with one LANE per row (an 8-input network in registers, insertion sort
 // in LDS above that: the wave waited for its longest row), scanned with ds_bpermute shuffles and needed 125 VGPRs + 8.6 KB of LDS per
 // wave: 4 waves per SIMD, 1 605 VALU instructions per wave on the survey's workload, 54 % of the wave cycles waiting
-// (profiles/r04/c3_pmc_sq.csv).  This one: entry-parallel rank sort, DPP scans, end-marked bitmap, one wave per workgroup.
+// (profiles/r04/c3_pmc_sq.csv).  This one: entry-parallel rank sort, DPP scans, end-marked bitmap, one wave per workgroup (75-80 VGPRs,
+// 5.8 KB of LDS: 6 waves per SIMD), a body without a single load when the pass has no indirect ranges, the coming pass's ranges requested
+// a pass ahead.  Measured (1 x MI355X, HIP events): C3 0.096 -> 0.060 ms, C2 1.09 -> 0.97 ms, C4 0.71 -> 0.62 ms.  Variants that were
+// measured and lost: 192 ranges per pass at 7-8 waves per SIMD (C3 0.117 ms: more passes per wave cost more than the occupancy buys),
+// streaming from 32 / 48 ids on (C2 1.16-1.17 ms), 5 waves per SIMD with the row look-ups of the four entries interleaved (0.063 / 1.00 / 0.62).
+// The kernel's logic runs under the wave64 emulator of tools/emu/ on the host (tests/test_expand_emu.py).
 #pragma once
 
 namespace bmq {
