@@ -447,7 +447,10 @@ def main():
                      "algorithmic_bytes_per_launch": float(np.mean(alg_bytes)),
                      "kernel_own_frac": {k: own[k] / (max(v, 1e-9) * 1e-3) / 8e12 for k, v in (("k_walk", k_walk_ms), ("k_expand", k_exp_ms))}},
     }
-    attach_traffic(out, args.workload, world)
+    if args.topics == 1_000_000 and not args.ungrouped and not args.dedup and not args.churn:
+        attach_traffic(out, args.workload, world)
+    else:  # the counter passes ran the default batch: their bytes per launch say nothing about another batch size / order
+        out["roofline"]["traffic_source"] = "profiles/traffic_*.json was measured with the default batch (1 M grouped publishes, no churn): not reported for this run"
 
     if node is not None:
         out["node_batch"] = node
