@@ -209,3 +209,75 @@ def exchange_csr_v(dist, row_ptr, ids, total: int, world: int):
         outs = [flat[r * mx:r * mx + totals[r]] for r in range(world)]
     return rows_all.view(world, -1), outs, totals
 
+
+
+# ---- dynamic split decisions ----------------------------------------------------------------------------------------
+class FanoutSplitHinter:
+    """Which tenants are split by filter, decided continuously from the route mutations that pass by -- DW/hinter/FanoutSplitHinter.java
+    restated for a node whose shards are tenants instead of KV ranges:
+      * the reference looks at mutations only (recordQuery is empty, :81-83): every BatchMatch / BatchUnmatch re-estimates the record
+        count under the touched key prefix (doEstimate, :174-204) -- here the prefix is the tenant (all of a tenant's route keys share
+        it: SplitKey.java:34-57), the record count its live routes;
+      * a prefix whose scale reaches `split_at_scale` becomes a split candidate (:183-185), one that falls below HALF of it is dropped
+        again (:186-188): the same hysteresis decides here when a split tenant is merged back;
+      * the reference hands ONE split key at a time to base-kv (estimate(), :143-158); here a decision is executed by moving route
+        keys between the ranks' indexes: `plan()` lists, per rank, the keys to delete and the keys to add (bmq_routes_apply ops).
+    Ranks run the same hinter over the same mutation stream (the ops are broadcast to the owners anyway), so they agree without talking."""
+
+    def __init__(self, world: int, split_at_scale: int):
+        if split_at_scale < 2:
+            raise ValueError("split_at_scale must be at least 2")
+        self.world = int(world)
+        self.split_at_scale = int(split_at_scale)
+        self.routes = {}    # tenant -> live routes
+        self.split = set()  # tenants split by filter right now
+
+    def owner(self, tenant) -> int:
+        """rank that matches the tenant's publishes, or -1 = every rank"""
+        return -1 if tenant in self.split and self.world > 1 else tenant_rank(tenant, self.world)
+
+    def key_owner(self, tenant, route_key: bytes) -> int:
+        return key_rank(route_key, self.world) if tenant in self.split and self.world > 1 else tenant_rank(tenant, self.world)
+
+    def record_mutate(self, tenants: Sequence, deletes: Sequence[bool]):
+        """One batch of mutations (recordMutate, :86-129): deletes[i] tells an unsubscribe from a subscribe.  Only mutations that CHANGED
+        the index may be recorded (a repeated subscribe of an existing route adds no record).
+        -> (tenants to split, tenants to merge back) -- the decisions this batch triggers; `plan()` turns one into key moves."""
+        touched = {}
+        for t, d in zip(tenants, deletes):
+            touched[t] = touched.get(t, 0) + (-1 if d else 1)
+        to_split, to_merge = [], []
+        for t, delta in touched.items():
+            n = max(self.routes.get(t, 0) + delta, 0)
+            if n:
+                self.routes[t] = n
+            else:
+                self.routes.pop(t, None)
+            if self.world <= 1:
+                continue
+            if n >= self.split_at_scale and t not in self.split:
+                to_split.append(t)
+            elif t in self.split and 2 * n < self.split_at_scale:
+                to_merge.append(t)
+        return sorted(to_split, key=tenant_hash), sorted(to_merge, key=tenant_hash)
+
+    def plan(self, tenant, split: bool, keys_of_rank: Sequence[Sequence[bytes]]):
+        """Executes one decision: keys_of_rank[r] = the tenant's route keys rank r holds now.  -> per rank (keys to delete, keys to add);
+        the tenant's placement (`owner`, `key_owner`) switches with this call."""
+        if split:
+            self.split.add(tenant)
+        else:
+            self.split.discard(tenant)
+        dels = [[] for _ in range(self.world)]
+        adds = [[] for _ in range(self.world)]
+        for r, ks in enumerate(keys_of_rank):
+            for k in ks:
+                to = self.key_owner(tenant, k)
+                if to != r:
+                    dels[r].append(k)
+                    adds[to].append(k)
+        return [(sorted(d), sorted(a)) for d, a in zip(dels, adds)]
+
+    def load(self):
+        """what the reference reports as SplitHint load (:146-148): split prefixes, and their summed scale"""
+        return {"fanout_topicfilters": len(self.split), "fanout_scale": sum(self.routes.get(t, 0) for t in self.split)}

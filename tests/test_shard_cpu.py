@@ -163,3 +163,99 @@ def test_two_rank_hot_tenant_split_and_fanout_exchange():
     assert got[0][3] == got[1][3] and got[0][4] == got[1][4]  # all-gatherv: every rank holds every rank's ids, exact sizes
     assert [len(x) for x in got[0][4]] == got[0][3] and sum(got[0][3]) == sum(exp)
 
+
+
+def test_fanout_split_hinter_follows_the_mutations():
+    """DW/hinter/FanoutSplitHinter.java restated over tenants (bifromq_amd/shard.py): a tenant is split by filter when its live routes
+    reach split_at_scale, merged back below half of it, and after every executed decision the ranks' shards still partition the route
+    keys and the summed per-rank fan-outs equal the unsharded oracle."""
+    world, scale = 3, 40
+    rng = np.random.default_rng(77)
+    h = shard.FanoutSplitHinter(world, scale)
+    tenants = ["tenant%02d" % i for i in range(5)]
+    live = {t: set() for t in tenants}                    # the node-wide truth
+    held = [{t: set() for t in tenants} for _ in range(world)]  # what every rank indexes
+    serial = 0
+    decisions = []
+
+    def apply(ops):  # ops: (tenant, key, delete)
+        eff = []
+        for t, k, d in ops:
+            if d and k in live[t]:
+                live[t].discard(k)
+                held[h.key_owner(t, k)][t].discard(k)
+                eff.append((t, True))
+            elif not d and k not in live[t]:
+                live[t].add(k)
+                held[h.key_owner(t, k)][t].add(k)
+                eff.append((t, False))
+        to_split, to_merge = h.record_mutate([e[0] for e in eff], [e[1] for e in eff])
+        for t, s in [(t, True) for t in to_split] + [(t, False) for t in to_merge]:
+            moves = h.plan(t, s, [sorted(held[r][t]) for r in range(world)])
+            for r, (dels, adds) in enumerate(moves):
+                held[r][t] -= set(dels)
+                held[r][t] |= set(adds)
+            decisions.append((t, s))
+
+    def check():
+        for t in tenants:
+            parts = [held[r][t] for r in range(world)]
+            assert set().union(*parts) == live[t] and sum(len(p) for p in parts) == len(live[t])  # a partition of the tenant's keys
+            if t in h.split:
+                assert all(shard.key_rank(k, world) == r for r in range(world) for k in parts[r])
+                assert h.owner(t) == -1
+            else:
+                own = shard.tenant_rank(t, world)
+                assert all(not parts[r] for r in range(world) if r != own) and h.owner(t) == own
+            assert h.routes.get(t, 0) == len(live[t])
+        # fan-out: every rank matches the publishes it is a target of against its shard; the sums equal the unsharded oracle
+        whole = O.KV(sorted(k for t in tenants for k in live[t]))
+        shards = [O.KV(sorted(k for t in tenants for k in held[r][t])) for r in range(world)]
+        for t in tenants:
+            for topic in (b"a/b/c", b"a/x", b"q"):
+                exp = len(whole.match_all(t, [topic]).per_topic()[0])
+                targets = range(world) if h.owner(t) < 0 else [h.owner(t)]
+                assert sum(len(shards[r].match_all(t, [topic]).per_topic()[0]) for r in targets) == exp
+
+    def new_keys(t, n):
+        nonlocal serial
+        out = []
+        for _ in range(n):
+            serial += 1
+            f = ["a/b/c", "a/+/c", "a/#", "+/x", "#", "q"][serial % 6]
+            out.append(B.route_key(t, f, 1, "0\0inbox%d\0d%d" % (serial, serial % 7)))
+        return out
+
+    # grow tenant 0 past the scale in three batches, the others stay small
+    for n in (15, 15, 15):
+        apply([(tenants[0], k, False) for k in new_keys(tenants[0], n)] + [(t, k, False) for t in tenants[1:] for k in new_keys(t, 3)])
+        check()
+    assert decisions == [(tenants[0], True)] and h.split == {tenants[0]}
+    assert h.load() == {"fanout_topicfilters": 1, "fanout_scale": 45}
+    # a repeated subscribe changes nothing and is not recorded
+    k0 = sorted(live[tenants[0]])[0]
+    apply([(tenants[0], k0, False)])
+    assert h.routes[tenants[0]] == 45
+    # shrink it: still split at 20 routes (half the scale), merged back at 19
+    victims = sorted(live[tenants[0]])
+    apply([(tenants[0], k, True) for k in victims[:25]])
+    check()
+    assert h.split == {tenants[0]} and len(live[tenants[0]]) == 20
+    apply([(tenants[0], victims[25], True)])
+    check()
+    assert decisions[-1] == (tenants[0], False) and not h.split
+    # random churn across all tenants: decisions come and go, the invariants hold after every batch
+    for _ in range(30):
+        ops = []
+        for t in tenants:
+            if rng.random() < 0.6:
+                ops += [(t, k, False) for k in new_keys(t, int(rng.integers(1, 30)))]
+            if live[t] and rng.random() < 0.5:
+                ks = sorted(live[t])
+                ops += [(t, ks[int(i)], True) for i in rng.choice(len(ks), size=min(len(ks), int(rng.integers(1, 40))), replace=False)]
+        apply(ops)
+        check()
+    assert len(decisions) > 6 and any(not s for _, s in decisions[2:])
+    # one rank: nothing is ever split
+    h1 = shard.FanoutSplitHinter(1, 2)
+    assert h1.record_mutate(["t"] * 10, [False] * 10) == ([], []) and h1.owner("t") == 0
