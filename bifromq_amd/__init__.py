@@ -5,8 +5,9 @@ This package is the Python face used by tests and bench.py.
 """
 from . import _lib
 from .engine import Batcher, BmqError, Engine, RangeRouter, RouteCache, INT_MAX, decode_route_key, java_string_hash, pack, route_key, route_key_from_mqtt
+from .generations import GenerationalEngine
 from .matcher import MatchedRoutes, TenantRouteMatcher
 from .workload import Workload
 
-__all__ = ["Engine", "Batcher", "RouteCache", "RangeRouter", "BmqError", "TenantRouteMatcher", "MatchedRoutes", "Workload", "pack", "route_key",
+__all__ = ["Engine", "GenerationalEngine", "Batcher", "RouteCache", "RangeRouter", "BmqError", "TenantRouteMatcher", "MatchedRoutes", "Workload", "pack", "route_key",
            "route_key_from_mqtt", "decode_route_key", "java_string_hash", "INT_MAX"]

@@ -1,0 +1,107 @@
+"""bifromq_amd/generations.py: compaction beside the serving index (two engine handles, ops logged and replayed, swap).  Host-only engines
+here (device = -1: the index and its builder run on the host executor, nothing is matched): what is checked is the bookkeeping -- the key set
+of every generation, the log, the swap, the lifetime of a retired generation.  Matching through a pinned engine is the ordinary path of the
+-m gpu tests."""
+import threading
+
+import numpy as np
+import pytest
+
+import bifromq_amd as B
+from bifromq_amd.generations import GenerationalEngine
+
+
+def _key(i, t=None):
+    return B.route_key("tenant%d" % (i % 5 if t is None else t), ["a/%d/+", "b/%d/#", "%d/x", "+/%d"][i % 4] % i, 1, "0\0inbox%d\0d%d" % (i, i % 3))
+
+
+def _live(eng):
+    n = int(eng.info().next_route_id)
+    return sorted(k for k in eng.route_keys(np.arange(n, dtype=np.uint32)) if k)
+
+
+def test_compaction_beside_the_serving_generation_with_mutations_at_every_step():
+    g = GenerationalEngine(device=-1)
+    model = set(_key(i) for i in range(400))
+    g.rebuild(sorted(model))
+    serial = [1000]
+
+    def churn(n_add, n_del):
+        def f():
+            dels = sorted(model)[:n_del]
+            adds = [_key(serial[0] + j) for j in range(n_add)]
+            serial[0] += n_add
+            # a delete of a key, its re-insertion and a second delete in ONE stream: the replay must keep the order
+            ops = [(1, k) for k in dels] + [(0, k) for k in adds] + [(0, dels[0]), (1, dels[0])]
+            g.apply(ops)
+            model.difference_update(dels)
+            model.update(adds)
+        return f
+
+    # garbage first: deletes + re-adds leave dead ids behind
+    churn(50, 120)()
+    with g.pin() as (eng, gen):
+        info = eng.info()
+        assert gen == 0 and info.n_routes == len(model) and info.next_route_id > info.n_routes
+    g.hooks = {"after_snapshot": churn(7, 5), "after_export": churn(11, 13), "after_build": churn(3, 2), "after_replay_round": churn(2, 1)}
+    rounds = []
+    old = {}
+    with g.pin() as (eng_a, gen_a):  # a caller that is still inside generation 0 while the swap happens
+        ids_a = np.arange(10, dtype=np.uint32)
+        old["keys"] = eng_a.route_keys(ids_a)
+        t = threading.Thread(target=lambda: rounds.append(g.compact_online()))
+        t.start()
+        t.join(120)
+        assert not t.is_alive() and rounds
+        assert eng_a.route_keys(ids_a) == old["keys"]      # the retired generation still answers for its own ids
+        assert g.generation == 1
+    r = rounds[0]
+    assert r["generation"] == 1 and r["ops_replayed"] > 0 and r["replay_rounds"] >= 1
+    assert r["replay_rounds"] <= GenerationalEngine.MAX_REPLAY_ROUNDS and r["ops_replayed_under_lock"] <= r["ops_replayed"]
+    with g.pin() as (eng, gen):
+        info = eng.info()
+        assert gen == 1 and _live(eng) == sorted(model)
+        assert info.n_routes == len(model)
+        # the new generation carries at most the garbage of the replayed ops, not the old generation's
+        assert info.next_route_id - info.n_routes <= r["ops_replayed"]
+    assert eng_a.h is None                                   # generation 0 was closed when its last pin went
+    # and again, without mutations meanwhile: dense ids, nothing replayed
+    g.hooks = {}
+    r2 = g.compact_online()
+    with g.pin() as (eng, gen):
+        info = eng.info()
+        assert gen == 2 and r2["ops_replayed"] == 0 and info.next_route_id == info.n_routes == len(model) and _live(eng) == sorted(model)
+    g.close()
+
+
+def test_a_mutator_that_never_pauses_cannot_hold_the_swap_off():
+    g = GenerationalEngine(device=-1)
+    base = [_key(i) for i in range(300)]
+    g.rebuild(sorted(base))
+    added = []
+    g.hooks = {"after_replay_round": lambda: (g.apply([(0, _key(5000 + len(added)))]), added.append(1))}
+    g.hooks["after_build"] = g.hooks["after_replay_round"]
+    r = g.compact_online()
+    assert r["replay_rounds"] == GenerationalEngine.MAX_REPLAY_ROUNDS and r["ops_replayed_under_lock"] == 1   # the last op was replayed under the lock
+    with g.pin() as (eng, gen):
+        assert _live(eng) == sorted(base + [_key(5000 + j) for j in range(len(added))])
+    g.close()
+
+
+def test_a_failed_build_leaves_the_serving_generation_alone():
+    g = GenerationalEngine(device=-1)
+    g.rebuild(sorted(_key(i) for i in range(50)))
+
+    def boom():
+        raise RuntimeError("injected")
+
+    g.hooks = {"after_export": boom}
+    with pytest.raises(RuntimeError, match="injected"):
+        g.compact_online()
+    assert g.generation == 0
+    g.apply([(0, _key(777))])                                 # not logged any more, still served
+    with g.pin() as (eng, gen):
+        assert gen == 0 and eng.info().n_routes == 51
+    g.hooks = {}
+    assert g.compact_online()["generation"] == 1               # and a later compaction goes through
+    g.close()
