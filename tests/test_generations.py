@@ -105,3 +105,59 @@ def test_a_failed_build_leaves_the_serving_generation_alone():
     g.hooks = {}
     assert g.compact_online()["generation"] == 1               # and a later compaction goes through
     g.close()
+
+
+@pytest.mark.gpu
+def test_matching_through_the_generations_on_the_gpu():
+    """Two engine handles on one GPU: rows matched through generation 0 (garbage inside), through generation 1 after the swap -- with mutations
+    landing while it was built -- equal the semantic oracle key for key; a caller still inside generation 0 during the swap gets its rows."""
+    from oracle import oracle as O
+    from tests import util as U
+
+    w = B.Workload(0xB1F20041, 8, 300, 1)
+    keys = w.keys()
+    tn = w.tenants()
+    data, off, tt = w.topics(5, 1500)
+    topics = [bytes(data[off[i]:off[i + 1]]) for i in range(len(tt))]
+    g = GenerationalEngine(device=0)
+    g.rebuild(keys)
+    model = set(keys)
+    rng = np.random.default_rng(5)
+
+    def churn(n):
+        def f():
+            ks = sorted(model)
+            dels = [ks[int(i)] for i in rng.choice(len(ks), size=n, replace=False)]
+            adds = [B.route_key(tn[int(rng.integers(0, len(tn)))], "gen/%d/+" % int(rng.integers(0, 1 << 30)), 1, "0\0g%d\0d" % j) for j in range(n)]
+            g.apply([(1, k) for k in dels] + [(0, k) for k in adds])
+            model.difference_update(dels)
+            model.update(adds)
+        return f
+
+    def rows_as_keys(eng):
+        row, ids = eng.match_batch(tn, tt, topics)
+        ks = eng.route_keys(ids)
+        return [sorted(ks[row[i]:row[i + 1]]) for i in range(len(tt))]
+
+    def expected():
+        kv = O.KV(sorted(model))
+        ks = sorted(model)
+        return [sorted(ks[x] for x in r) for r in U.semantic_rows(kv, tn, tt, topics)]
+
+    churn(200)()
+    with g.pin() as (eng, gen):
+        got0 = rows_as_keys(eng)
+    assert got0 == expected()
+    g.hooks = {"after_export": churn(50), "after_build": churn(30)}
+    with g.pin() as (eng_a, gen_a):
+        t = threading.Thread(target=g.compact_online)
+        t.start()
+        t.join(300)
+        assert not t.is_alive() and g.generation == 1
+        assert gen_a == 0 and eng_a.h is not None and len(rows_as_keys(eng_a)) == len(tt)   # generation 0 still serves whoever is inside it
+    with g.pin() as (eng, gen):
+        info = eng.info()
+        assert gen == 1 and info.n_routes == len(model)
+        got1 = rows_as_keys(eng)
+    assert got1 == expected()
+    g.close()
