@@ -227,8 +227,9 @@ def parity_report(config, **fields):
     Printed (pytest -s / a failing test shows it) and appended to gpurun_out/parity_report.jsonl when that directory is writable."""
     import json
     import os
+    import sys
     line = json.dumps(dict(config=config, **fields))
-    print("[parity] " + line)
+    print("[parity] " + line, file=sys.stderr)  # (stderr: bench.py's stdout carries its ONE JSON line and nothing else)
     try:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(d, exist_ok=True)
