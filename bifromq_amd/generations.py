@@ -13,7 +13,9 @@ length of a bulk load.  The same rebuild can run BESIDE the serving index instea
 Nothing new is needed below the boundary: `bmq_engine_create`, `bmq_route_keys`, `bmq_rebuild`, `bmq_routes_apply` (include/bmq.h).  Route ids
 are renumbered by the swap exactly as `bmq_compact` renumbers them (they are dense ranks again; `generation` counts the swaps), so whatever
 a caller keeps per route id it re-derives per generation -- `pin()` tells it which generation a result came from.  Objects created ON an
-engine handle (the batching front, the route cache) belong to one generation and are re-created on the new one by their owner.
+engine handle (the batching front, the route cache) belong to one generation and are re-created on the new one by their owner.  The wrapper
+carries the ROUTE index (the dist direction); a handle that also holds retained topics is refused (the reference keeps the two in separate
+coprocs, and `bmq_retain_compact` rebuilds 1 M retained topics in a few milliseconds).
 The price: two copies of the index in HBM while B is built (the C3 index is 4 GB of 288), and B's builder kernels share the GPU with A's
 batches for the length of the bulk load.  The JVM adapter does the same with two `NativeMatcher` handles."""
 from __future__ import annotations
@@ -108,6 +110,9 @@ class GenerationalEngine:
         try:
             with self._lock:
                 a = self._cur
+                if a.eng.retain_find_all()[0]:
+                    # (dist worker and retain store are separate coprocs with an index each: DW/DistWorkerCoProc.java, RetainStoreCoProc.java)
+                    raise NotImplementedError("this handle also holds retained topics: only the route index is carried into the next generation")
                 a.pins += 1          # A must outlive the export whatever happens
                 self._log = []
                 n_ids = int(a.eng.info().next_route_id)

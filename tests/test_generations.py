@@ -107,6 +107,20 @@ def test_a_failed_build_leaves_the_serving_generation_alone():
     g.close()
 
 
+def test_a_handle_that_also_holds_retained_topics_is_refused():
+    g = GenerationalEngine(device=-1)
+    g.rebuild(sorted(_key(i) for i in range(10)))
+    with g.pin() as (eng, _):
+        eng.retain_rebuild(["tenant0"], [0, 0], [b"a/b", b"a/c"])
+    with pytest.raises(NotImplementedError):
+        g.compact_online()
+    assert g.generation == 0
+    g.apply([(0, _key(99))])          # nothing was left half-done: not logging, still serving
+    with g.pin() as (eng, _):
+        assert eng.info().n_routes == 11
+    g.close()
+
+
 @pytest.mark.gpu
 def test_matching_through_the_generations_on_the_gpu():
     """Two engine handles on one GPU: rows matched through generation 0 (garbage inside), through generation 1 after the swap -- with mutations
