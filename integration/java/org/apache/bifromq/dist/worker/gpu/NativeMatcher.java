@@ -33,6 +33,9 @@ final class NativeMatcher {
     /** +1 per rebuild: route ids are stable handles within a generation (a deleted route's id resolves to an empty key). */
     static native long generation(long engine);
 
+    /** bmq_index_info: {routes, tenants, nodes, tokens, trieSlots, dictSlots, deviceBytes, epoch, generation, nextRouteId, garbageBytes}. */
+    static native void indexInfo(long engine, long[] out11);
+
     /** One device gather: outOff[n + 1] byte offsets into out.  @return bytes, or -(needed) */
     static native long routeKeys(long engine, IntBuffer ids, int n, ByteBuffer out, LongBuffer outOff);
 

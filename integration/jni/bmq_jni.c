@@ -327,6 +327,20 @@ JNIEXPORT void JNICALL NM(retainInfo)(JNIEnv* env, jclass c, jlong h, jlongArray
                         (jlong)ri.added_ids, (jlong)ri.overlay_nodes, (jlong)ri.epoch, (jlong)ri.generation};
     (*env)->SetLongArrayRegion(env, out, 0, 9, v);
 }
+/* void indexInfo(long engine, long[] out11)   out = bmq_index_info {routes, tenants, nodes, tokens, trieSlots, dictSlots, deviceBytes, epoch, generation,
+ * nextRouteId, garbageBytes} -- nextRouteId bounds the ids GenerationalRangeIndex exports, garbageBytes tells it when a compaction pays */
+JNIEXPORT void JNICALL NM(indexInfo)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
+    (void)c;
+    bmq_index_info ii;
+    const int rc = bmq_index_info_get(ENGINE(h), &ii);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_index_info_get", rc);
+        return;
+    }
+    const jlong v[11] = {(jlong)ii.n_routes,     (jlong)ii.n_tenants,    (jlong)ii.n_nodes, (jlong)ii.n_tokens,    (jlong)ii.trie_slots,   (jlong)ii.dict_slots,
+                         (jlong)ii.device_bytes, (jlong)ii.epoch,        (jlong)ii.generation, (jlong)ii.next_route_id, (jlong)ii.garbage_bytes};
+    (*env)->SetLongArrayRegion(env, out, 0, 11, v);
+}
 /* long retainLiveIds(long engine, byte[] tenant (null: all tenants), IntBuffer outIds)    -> number of retained topics, or -(needed) */
 JNIEXPORT jlong JNICALL NM(retainLiveIds)(JNIEnv* env, jclass c, jlong h, jbyteArray tenant, jobject outIds) {
     (void)c;
