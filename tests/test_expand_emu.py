@@ -22,3 +22,13 @@ def test_k_expand_under_the_wave_emulator(tmp_path, defs, cases):
     r = subprocess.run([exe, str(cases), "12345"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok:"), r.stdout
+
+
+def test_the_emulator_against_the_definitions_of_its_operations(tmp_path):
+    """tools/emu/emu_selftest.cpp: ballot / readlane / readfirstlane with lanes gone, the DPP scan against a serial prefix sum, LDS hand-over
+    through wave_sync, and a divergent cross-lane operation aborting (in a forked child)."""
+    exe = str(tmp_path / "emu_selftest")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "tools", "emu"), os.path.join(ROOT, "tools", "emu", "emu_selftest.cpp"), "-o", exe],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "emu selftest ok" in r.stdout, r.stdout + r.stderr
