@@ -60,6 +60,7 @@ def main():
                     help="N = 1: skip the compact extra legs (configs[4] churn on this index, the batching front at 64 threads, C2 and C4 as "
                          "child runs) that the default run appends under `extra`")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-visible (PCIe-inclusive) measurement")
+    ap.add_argument("--no-churn", action="store_true", help="--workload c4: skip the add / remove leg (A/B runs of the walk kernel)")
     ap.add_argument("--batcher-threads", type=int, default=-1,
                     help="also measure the batching front (bmq_batcher_*, SURVEY 8f-1): N native threads issue single-topic calls")
     ap.add_argument("--batcher-topics", type=int, default=200_000)
@@ -1029,7 +1030,7 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
     walk_bytes = float(np.mean(alg)) - 4.0 * n_match / args.steps
     exp_bytes = 4.0 * n_match / args.steps
     achieved = (walk_bytes if dom_name == "k_retain_walk" else exp_bytes) / (k_ms * 1e-3) / 1e9
-    churn = retain_churn_leg(eng, w, data, off, n_topics, step, torch, np) if world == 1 else None
+    churn = retain_churn_leg(eng, w, data, off, n_topics, step, torch, np) if world == 1 and not args.no_churn else None
     out = {"metric": "retain-direction filter matches/sec (whole node)", "value": world * n * args.steps / elapsed,
            "unit": "filters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -33,7 +33,9 @@ struct Counters { // one per batch slot, zeroed behind every batch (k_reset)
     uint32_t sort_count;
     uint32_t status;
     uint32_t pad;
+    uint32_t rw_next[64]; // k_retain_walk: the next quad of filters of each partition of the batch (RW_PARTS)
 };
+constexpr uint32_t RW_PARTS = 64;
 constexpr uint32_t SUPER_SHIFT = 8;   // id counts are summed per 2^SUPER_SHIFT waves (super_sums) on top of the per-wave counts
 constexpr uint32_t SUPER_STRIDE = 16; // ... one sum per 128-byte line: 256 waves bump each, neighbours must not share a line
 
@@ -94,5 +96,17 @@ struct BatchArgs {
     uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising, 2 = fill dbg_wave
     uint4* dbg_wave;      // [n_blocks] {phase 1, phase 2, phase 3 shader clocks, rounds | items << 8} of every k_walk wave, or null
 };
+
+#if defined(__HIPCC__) || defined(BMQ_WAVE_EMU)
+// n contiguous entries of `pairs` from sub-allocator `key` (false: the slice is full, the batch is re-run with a larger buffer)
+__device__ __forceinline__ bool pair_alloc(SubAlloc* subs, unsigned long long pair_cap, uint32_t key, uint32_t n,
+                                           unsigned long long& base) {
+    const unsigned long long slice = pair_cap / N_SUB;
+    const uint32_t s = key & (N_SUB - 1);
+    const unsigned long long off = atomicAdd(&subs[s].used, (unsigned long long)n);
+    base = (unsigned long long)s * slice + off;
+    return off + n <= slice;
+}
+#endif
 
 } // namespace bmq

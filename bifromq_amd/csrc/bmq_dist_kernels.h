@@ -37,15 +37,6 @@
 
 namespace bmq {
 
-__device__ __forceinline__ bool pair_alloc(SubAlloc* subs, unsigned long long pair_cap, uint32_t key, uint32_t n,
-                                           unsigned long long& base) {
-    const unsigned long long slice = pair_cap / N_SUB;
-    const uint32_t s = key & (N_SUB - 1);
-    const unsigned long long off = atomicAdd(&subs[s].used, (unsigned long long)n);
-    base = (unsigned long long)s * slice + off;
-    return off + n <= slice;
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------------------------

@@ -166,7 +166,7 @@ struct bmq_engine {
     uint64_t repoch = 0;      // +1 per retain rebuild / apply / compact
     uint64_t rgeneration = 0; // +1 per retain rebuild / compact: topic ids of different generations are unrelated
     RetainLimit rlim;
-    DevBuf r_scratch, r_deep_list, r_deep_levels;
+    DevBuf r_scratch, r_deep_list, r_deep_levels, r_arena;
     bool rdeep_on = false;   // k_retain_walk_deep is in the pipeline (batches hold filters of more than R_MAXL levels)
     uint32_t rdeep_idle = 0;
     DevBuf range_buf; // staging of bmq_range_lookup
@@ -182,6 +182,9 @@ struct bmq_engine {
     DevBuf ex_buf;
     DevBuf part_buf; // bmq_partition_batch_dev: flags, lengths and their prefix sums
     uint32_t rgcap = 0;
+    uint32_t rwcap = 0;      // k_retain_walk: entries per frontier list in the waves' arena (grown on ST_RETAIN_LIST)
+    uint32_t rw_waves = 0;   // k_retain_walk: resident waves (its persistent grid)
+    bool rwalk_v1 = false;   // BMQ_RWALK_V1=1: the one-filter-per-wave walk for every batch (A/B measurements)
 };
 
 static int retain_finish(bmq_engine* e, uint64_t* out_total);
@@ -620,6 +623,7 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     if (const char* v = getenv("BMQ_WALK_MIXED")) e->mixed_on = atoi(v) != 0; // profiling experiments
     e->kernel_events = c.kernel_timing != 0;
     if (const char* v = getenv("BMQ_KERNEL_EVENTS")) e->kernel_events = atoi(v) != 0; // profiling experiments
+    if (const char* v = getenv("BMQ_RWALK_V1")) e->rwalk_v1 = atoi(v) != 0;             // profiling experiments
     if (c.device >= 0) {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || c.device >= n) return BMQ_E_NODEVICE;

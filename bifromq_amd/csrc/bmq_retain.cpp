@@ -120,14 +120,16 @@ void place_local(LocalBuild& b) { // phase 3: nodes + edge hash with global toke
         r.sub_end = p.sub_end;
         if (p.parent != NONE) {
             const uint32_t pb = pn[p.parent].bfs, tok = b.l2g[p.token - TOK_FIRST];
-            uint32_t bk = redge_bucket(pb, tok, bmask), s = NONE;
+            const uint32_t home = redge_bucket(pb, tok, bmask);
+            uint32_t bk = home, s = NONE;
             for (;;) {
                 for (uint32_t j = 0; j < 4 && s == NONE; j++)
                     if (t.edges[4 * bk + j].parent == NONE) s = 4 * bk + j;
                 if (s != NONE) break;
                 bk = (bk + 1) & bmask;
             }
-            t.edges[s] = REdge{pb, tok, i, 0};
+            t.edges[s] = REdge{pb, tok, i, p.sub_begin | (p.term ? RN_TERM : 0u)};
+            if (bk != home) t.edges[4 * home].child |= RE_OVERFLOW; // (the home bucket is full: its first entry exists)
         }
     }
     // the '$' children of the root form one contiguous run (children are sorted by label bytes)

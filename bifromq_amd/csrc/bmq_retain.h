@@ -36,8 +36,11 @@ struct alignas(16) RNode {
 };
 static_assert(sizeof(RNode) == 16, "RNode must be 16 bytes");
 
+constexpr uint32_t RE_OVERFLOW = 0x80000000u; // REdge.child flag, FIRST entry of a bucket only: an edge whose home bucket this is lies in a later bucket
 struct alignas(16) REdge { // hash entry: (parent node, token) -> child node (tenant-local ids); parent == NONE: empty
-    uint32_t parent, token, child, pad;
+    uint32_t parent, token;
+    uint32_t child; // | RE_OVERFLOW in a bucket's first entry: a look-up that misses in its home bucket goes on only then
+    uint32_t child_topic; // the child's sub_begin | RN_TERM if a retained topic ends at the child: a filter's last literal level needs no node read
 };
 
 struct alignas(64) RTenantSlot { // tenant directory entry (token == 0: empty)
@@ -144,12 +147,15 @@ BMQ_HD uint32_t tenant_hash(uint32_t token) {
     uint32_t x = token * 0x9E3779B1u;
     return x ^ (x >> 15);
 }
+// Home bucket of the edge (parent, token): hash(token) + parent.  LINEAR in the parent on purpose: a literal level behind a '+' looks the
+// same token up under every node of a node RANGE -- consecutive parents --, and their home buckets are then consecutive 64-byte lines
+// (one stream per 64 lanes instead of 64 random lines).  Tokens spread the edges of one parent; parents of one token never collide.
 BMQ_HD uint32_t redge_bucket(uint32_t parent, uint32_t token, uint32_t mask) {
-    uint32_t h = (parent ^ rotl32(token, 16)) * 0x9E3779B1u;
+    uint32_t h = token * 0x9E3779B1u;
     h ^= h >> 15;
     h *= 0x85EBCA77u;
     h ^= h >> 13;
-    return h & mask;
+    return (h + parent) & mask;
 }
 
 } // namespace bmq

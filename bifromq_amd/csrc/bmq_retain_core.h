@@ -134,7 +134,7 @@ BMQ_HD uint32_t redge_find(const RetainIndexView& ix, uint32_t edge_base, uint32
         bool free_slot = false;
         for (uint32_t j = 0; j < 4; j++) {
             const REdge& e = ix.edges[edge_base + 4 * (size_t)bk + j];
-            if (e.parent == parent && e.token == token) return e.child;
+            if (e.parent == parent && e.token == token) return e.child & ~RE_OVERFLOW;
             free_slot = free_slot || e.parent == NONE;
         }
         if (free_slot) return NONE;

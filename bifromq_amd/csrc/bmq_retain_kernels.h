@@ -14,6 +14,7 @@
 
 #include "bmq_dist_kernels.h"
 #include "bmq_retain.h"
+#include "bmq_retain_args.h"
 #include "bmq_retain_core.h"
 
 namespace bmq {
@@ -38,27 +39,6 @@ constexpr uint32_t OV_OUT = BMQ_OV_OUT;   // matched OVERLAY topic ids of one fi
 #endif
 constexpr uint32_t R_WAVES_PER_CU = BMQ_R_WAVES_PER_CU; // persistent waves per CU (LDS: 16 B per frontier entry + 8 B per range / overlay id + ~1.7 KB)
 static_assert(R_WAVES_PER_CU * (16u * BMQ_R_FRONT + 8u * BMQ_R_OUT + 8u * BMQ_OV_OUT + 1700u) <= 160u * 1024u, "the retain walk's LDS lists do not fit that many waves");
-constexpr uint32_t RT_PLUS = 0xFFFFFFFDu, RT_HASH = 0xFFFFFFFCu; // level kinds next to dictionary tokens
-constexpr uint32_t ST_RETAIN_DEEP = 128u, ST_RETAIN_FRONT = 256u;
-
-struct RetainArgs {
-    RetainIndexView ix;
-    const uint8_t* tenants;
-    const uint32_t* tenant_off;
-    uint32_t n_tenants;
-    const uint32_t* filter_tenant;
-    const uint8_t* filters;
-    const uint32_t* filter_off;
-    uint32_t n_filters;
-    uint2* gscratch;       // per wave: 2 * gcap ranges
-    uint32_t gcap;
-    // filters of more than R_MAXL levels (MQTT ingress rejects more than 16: Setting.MaxTopicLevels): the walk lists them (their count
-    // is Counters.slow_count), a second launch of the same walk with its per-level arrays in global memory answers them
-    uint32_t* deep_list;   // [n_filters]
-    uint32_t* deep_levels; // deep pass only: per wave 6 arrays of deep_maxl + 1 words
-    uint32_t deep_maxl;
-};
-
 struct Frontier {
     uint32_t* lb;
     uint32_t* lc;
@@ -80,10 +60,10 @@ __device__ __forceinline__ uint32_t redge_lookup(const RetainIndexView& ix, uint
         Line64 ln; // the whole bucket in one request (see load_line64)
         load_line64(ix.edges + edge_base + 4 * (size_t)bk, ln);
         const uint4 e0 = ln.a0, e1 = ln.a1, e2 = ln.b0, e3 = ln.b1;
-        if (e0.x == parent && e0.y == token) return e0.z;
-        if (e1.x == parent && e1.y == token) return e1.z;
-        if (e2.x == parent && e2.y == token) return e2.z;
-        if (e3.x == parent && e3.y == token) return e3.z;
+        if (e0.x == parent && e0.y == token) return e0.z & ~RE_OVERFLOW;
+        if (e1.x == parent && e1.y == token) return e1.z & ~RE_OVERFLOW;
+        if (e2.x == parent && e2.y == token) return e2.z & ~RE_OVERFLOW;
+        if (e3.x == parent && e3.y == token) return e3.z & ~RE_OVERFLOW;
         if (e0.x == NONE || e1.x == NONE || e2.x == NONE || e3.x == NONE) return NONE;
         bk = (bk + 1) & mask;
     }
@@ -529,10 +509,7 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
             a.pair_off[f] = (uint32_t)base;
             a.pair_cnt[f] = np_total;
             a.route_cnt[f] = nr_total;
-            if (nr_total) {
-                atomicAdd(&a.wave_sums[f >> a.tpw_shift], (unsigned long long)nr_total);
-                atomicAdd(&a.super_sums[(size_t)(f >> (a.tpw_shift + SUPER_SHIFT)) * SUPER_STRIDE], (unsigned long long)nr_total);
-            }
+            // (the per-block sums k_expand wants are added up by k_retain_sums)
         }
         wranges += np_total;
         if (DEEP || !deep) wbytes += end - beg; // (a deep filter is counted by the pass that answers it)
@@ -546,8 +523,32 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
     }
 }
 
-__global__ __launch_bounds__(64) void k_retain_walk(RetainArgs r, BatchArgs a) { retain_walk_body<false>(r, a); }
+// one filter per wave: the walk of the filters k_retain_walk lists (more than RW_LV levels: DEEP) and, until the overlay trie has its own
+// kernel, of every filter once topics were added since the bulk load (v1: the round-2..4 kernel)
+__global__ __launch_bounds__(64) void k_retain_walk_v1(RetainArgs r, BatchArgs a) { retain_walk_body<false>(r, a); }
 __global__ __launch_bounds__(64) void k_retain_walk_deep(RetainArgs r, BatchArgs a) { retain_walk_body<true>(r, a); }
+
+} // namespace bmq
+#include "bmq_rwalk_kernel.h"
+namespace bmq {
+
+template <int G, bool DYN> __global__ __launch_bounds__(64, BMQ_RW_MIN_WAVES) void k_retain_walk(RetainArgs r, BatchArgs a) {
+    __shared__ RwLds<G> L;
+    retain_walk_rounds<G, DYN>(r, a, L);
+}
+
+// k_retain_sums: ids per 64-row block (wave_sums) and per 2^SUPER_SHIFT blocks (super_sums) from the rows' id counts, behind the walk
+// kernels and in front of k_expand / k_retain_rowptr_dyn.  (Rounds 2-4: two atomics per filter inside the walk -- 100 k filters on the
+// seven super-block words are 14 k serialised atomics per word, ~0.2 ms of L2 atomic-unit time that a faster walk would wait for.)
+__global__ __launch_bounds__(64) void k_retain_sums(BatchArgs a) {
+    const uint32_t blk = blockIdx.x, t = (blk << a.tpw_shift) + threadIdx.x;
+    const unsigned long long v = (threadIdx.x < (1u << a.tpw_shift) && t < a.n_topics) ? a.route_cnt[t] : 0u;
+    const unsigned long long s = wave_sum_u64(v);
+    if (threadIdx.x == 0) {
+        a.wave_sums[blk] = s;
+        if (s) atomicAdd(&a.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], s);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // RetainStoreCoProc.match(limit, now) without expanding anything (RS/RetainStoreCoProc.java:167-190): the reference walks the

@@ -63,11 +63,21 @@ inline State& st() {
 }
 inline Dim3 tid() { return Dim3{(uint32_t)st().cur, 0, 0}; }
 inline Dim3 bid() { return Dim3{st().block, 0, 0}; }
+inline uint32_t& grid_size() { // what gridDim.x reads (persistent kernels stride by it); set by the harness
+    static uint32_t g = 1;
+    return g;
+}
+inline Dim3 gdim() { return Dim3{grid_size(), 1, 1}; }
 
+inline uint64_t& trace_lanes() { // WEMU_TRACE=<lane mask>: every cross-lane operation of these lanes goes to stderr (debugging a divergence)
+    static uint64_t m = getenv("WEMU_TRACE") ? strtoull(getenv("WEMU_TRACE"), nullptr, 0) : 0;
+    return m;
+}
 inline uint64_t collective(int kind, uint64_t param, uint64_t value) {
     State& s = st();
     const int me = s.cur;
     s.kind[me] = kind, s.param[me] = param, s.val[me] = value, s.parked[me] = true, s.seq[me]++;
+    if (trace_lanes() >> me & 1ull) fprintf(stderr, "wave_emu: lane %d #%u kind %d param %llu value %llu\n", me, s.seq[me], kind, (unsigned long long)param, (unsigned long long)value);
     swapcontext(&s.ctx[me], &s.sched);
     return s.res[me];
 }
@@ -187,6 +197,7 @@ inline void run_wave(uint32_t block, std::function<void()> body) {
 
 #define threadIdx (wemu::tid())
 #define blockIdx (wemu::bid())
+#define gridDim (wemu::gdim())
 
 // ---- the cross-lane vocabulary of the kernels ----
 namespace bmq {

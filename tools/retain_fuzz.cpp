@@ -103,7 +103,7 @@ static std::vector<uint32_t> image_match(const RetainIndexHost& h, std::string_v
                             bool hit = false, hole = false;
                             for (int j = 0; j < 4; j++) {
                                 if (e[j].parent == n && e[j].token == tok) {
-                                    nxt.push_back({e[j].child, 1});
+                                    nxt.push_back({e[j].child & ~RE_OVERFLOW, 1});
                                     hit = true;
                                 }
                                 hole |= e[j].parent == NONE;
