@@ -71,7 +71,7 @@ struct DevBuf {
 };
 
 struct RetainDevice { // the bulk-loaded part of the retained-topic index in HBM (the mutable part: RetainDyn, bmq_retain_dyn.h)
-    DevBuf nodes, edges, tenants, dict, pool;
+    DevBuf nodes, edges, posts, gps, tenants, dict, pool;
     RetainIndexView view{};
 };
 struct RetainLimit { // bmq_retain_match_limited in flight: select the first `limit` live ids from the ranges instead of expanding

@@ -132,6 +132,47 @@ void place_local(LocalBuild& b) { // phase 3: nodes + edge hash with global toke
             if (bk != home) t.edges[4 * home].child |= RE_OVERFLOW; // (the home bucket is full: its first entry exists)
         }
     }
+    // grandchild postings of the nodes with many children (RGp): (parent, token, child, child_topic) by (grandparent, token, parent)
+    {
+        struct PE {
+            uint32_t gp, tok, parent, child, topic;
+        };
+        std::vector<PE> pe;
+        for (uint32_t i = 1; i < nn; i++) {
+            const auto& p = pn[b.order[i]];
+            if (pn[p.parent].parent == NONE) continue; // a child of the root has no grandparent
+            const auto& g = pn[pn[p.parent].parent];
+            if (g.n_children < RPOST_MIN) continue;
+            pe.push_back({g.bfs, b.l2g[p.token - TOK_FIRST], pn[p.parent].bfs, i, p.sub_begin | (p.term ? RN_TERM : 0u)});
+        }
+        std::sort(pe.begin(), pe.end(), [](const PE& x, const PE& y) {
+            return x.gp != y.gp ? x.gp < y.gp : x.tok != y.tok ? x.tok < y.tok : x.parent < y.parent;
+        });
+        t.posts.resize(pe.size());
+        size_t runs = 0;
+        for (size_t i = 0; i < pe.size(); i++) {
+            t.posts[i] = REdge{pe[i].parent, pe[i].tok, pe[i].child, pe[i].topic};
+            if (i == 0 || pe[i].gp != pe[i - 1].gp || pe[i].tok != pe[i - 1].tok) runs++;
+        }
+        const uint32_t gslots = pow2_at_least(std::max<uint64_t>(4, (uint64_t)runs * 2));
+        const uint32_t gmask = gslots / 4 - 1;
+        t.gps.assign(gslots, RGp{NONE, 0, 0, 0});
+        for (size_t i = 0; i < pe.size();) {
+            size_t j = i;
+            while (j < pe.size() && pe[j].gp == pe[i].gp && pe[j].tok == pe[i].tok) j++;
+            const uint32_t home = rgp_bucket(pe[i].gp, pe[i].tok, gmask);
+            uint32_t bk = home, sl = NONE;
+            for (;;) {
+                for (uint32_t k = 0; k < 4 && sl == NONE; k++)
+                    if (t.gps[4 * bk + k].gp == NONE) sl = 4 * bk + k;
+                if (sl != NONE) break;
+                bk = (bk + 1) & gmask;
+            }
+            t.gps[sl] = RGp{pe[i].gp, pe[i].tok, (uint32_t)i, (uint32_t)(j - i)};
+            if (bk != home) t.gps[4 * home].count |= RE_OVERFLOW;
+            i = j;
+        }
+    }
     // the '$' children of the root form one contiguous run (children are sorted by label bytes)
     t.sys_node_lo = t.sys_node_hi = t.sys_id_lo = t.sys_id_hi = 0;
     uint32_t c = pn[0].first_child;
@@ -176,7 +217,9 @@ bool RetainIndexHost::rebuild(std::vector<Item>&& items) {
     edges.clear();
     dict_h = HostDict();
     strings.clear();
-    node_free = edge_free = 0;
+    node_free = edge_free = post_free = gp_free = 0;
+    posts.clear();
+    gps.clear();
     full_upload = dict_changed = true;
     dirty.clear();
     std::vector<RTenantState*> touched;
@@ -253,10 +296,22 @@ bool RetainIndexHost::refresh(std::vector<RTenantState*>& touched) {
             t.edge_cap = (uint32_t)t.edges.size();
             edge_free += t.edge_cap;
         }
+        if (t.posts.size() > t.post_cap) {
+            t.post_base = post_free;
+            t.post_cap = (uint32_t)t.posts.size();
+            post_free += t.post_cap;
+        }
+        if (t.gps.size() > t.gp_cap) {
+            t.gp_base = gp_free;
+            t.gp_cap = (uint32_t)t.gps.size();
+            gp_free += t.gp_cap;
+        }
     }
-    if (node_free > nodes.size() || edge_free > edges.size()) {
+    if (node_free > nodes.size() || edge_free > edges.size() || post_free > posts.size() || gp_free > gps.size()) {
         nodes.resize(std::max<size_t>((size_t)node_free + node_free / 4, 16));
         edges.resize(std::max<size_t>((size_t)edge_free + edge_free / 4, 16), REdge{NONE, 0, 0, 0});
+        posts.resize(std::max<size_t>((size_t)post_free + post_free / 4, 16), REdge{NONE, 0, 0, 0});
+        gps.resize(std::max<size_t>((size_t)gp_free + gp_free / 4, 16), RGp{NONE, 0, 0, 0});
         full_upload = true;
         dirty.clear();
     }
@@ -264,6 +319,8 @@ bool RetainIndexHost::refresh(std::vector<RTenantState*>& touched) {
         RTenantState& t = *b.st;
         std::copy(t.nodes.begin(), t.nodes.end(), nodes.begin() + t.node_base);
         std::copy(t.edges.begin(), t.edges.end(), edges.begin() + t.edge_base);
+        std::copy(t.posts.begin(), t.posts.end(), posts.begin() + t.post_base);
+        std::copy(t.gps.begin(), t.gps.end(), gps.begin() + t.gp_base);
         if (!full_upload) dirty.push_back(&t);
     }
     order.clear();
@@ -283,16 +340,19 @@ bool RetainIndexHost::refresh(std::vector<RTenantState*>& touched) {
         for (size_t i = 0; i < t->topics.size(); i++)
             expire_at[t->id_base + i] = (t->ts[i] == 0 && t->expiry[i] == 0xFFFFFFFFu) ? RETAIN_NEVER : retain_expire_at(t->ts[i], t->expiry[i]);
     const uint32_t tslots = pow2_at_least((uint64_t)order.size() * 2);
-    tenants.assign(tslots, RTenantSlot{0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}});
+    tenants.assign(tslots, RTenantSlot{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}});
     for (RTenantState* t : order) {
         uint32_t d = tenant_hash(t->token) & (tslots - 1);
         while (tenants[d].token) d = (d + 1) & (tslots - 1);
         tenants[d] = RTenantSlot{t->token, t->node_base, t->edge_base, (uint32_t)t->edges.size() / 4 - 1, t->id_base,
-                                 t->sys_node_lo, t->sys_node_hi, t->sys_id_lo, t->sys_id_hi, {0, 0, 0, 0, 0, 0, 0}};
+                                 t->sys_node_lo, t->sys_node_hi, t->sys_id_lo, t->sys_id_hi, t->post_base, t->gp_base, (uint32_t)t->gps.size() / 4 - 1,
+                                 {0, 0, 0, 0}};
     }
     if (dict_changed) flatten_dict(dict_h, dict, pool);
     if (nodes.empty()) nodes.resize(16);
     if (edges.empty()) edges.resize(16, REdge{NONE, 0, 0, 0});
+    if (posts.empty()) posts.resize(16, REdge{NONE, 0, 0, 0});
+    if (gps.empty()) gps.resize(16, RGp{NONE, 0, 0, 0});
     return true;
 }
 

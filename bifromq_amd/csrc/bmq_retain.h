@@ -43,6 +43,24 @@ struct alignas(16) REdge { // hash entry: (parent node, token) -> child node (te
     uint32_t child_topic; // the child's sub_begin | RN_TERM if a retained topic ends at the child: a filter's last literal level needs no node read
 };
 
+// Grandchild postings (round 5).  A literal level behind a '+' asks, for every child of ONE node g, for its child labelled t: hundreds of
+// look-ups that mostly miss (56 % of all node visits of the survey's retain workload).  For a node g with at least RPOST_MIN children the
+// index holds the answer ready: the edges (parent, t, child) of all grandchildren of g, ordered by (t, parent) -- `posts` --, and a hash
+// (g, t) -> their slice.  parent order is frontier order, so the slice IS the next frontier, and an entry carries what a filter's last
+// level needs (child_topic).
+constexpr uint32_t RPOST_MIN = 32;
+struct alignas(16) RGp { // hash entry: (grandparent node, token) -> posts[begin, begin + count) of the tenant; gp == NONE: empty
+    uint32_t gp, token, begin;
+    uint32_t count; // | RE_OVERFLOW in a bucket's first entry (see REdge.child)
+};
+BMQ_HD uint32_t rgp_bucket(uint32_t gp, uint32_t token, uint32_t mask) {
+    uint32_t h = (gp ^ rotl32(token, 16)) * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h & mask;
+}
+
 struct alignas(64) RTenantSlot { // tenant directory entry (token == 0: empty)
     uint32_t token;
     uint32_t node_base;                // first node of the tenant in the global node array (its root)
@@ -51,7 +69,9 @@ struct alignas(64) RTenantSlot { // tenant directory entry (token == 0: empty)
     uint32_t id_base;                  // global id of the tenant's first topic
     uint32_t sys_node_lo, sys_node_hi; // the root's '$'-prefixed children: local node ids [lo, hi)
     uint32_t sys_id_lo, sys_id_hi;     // ... and the local topic ranks below them: [lo, hi)
-    uint32_t pad[7];
+    uint32_t post_base;                // first entry of the tenant's grandchild postings
+    uint32_t gp_base, gp_bucket_mask;  // its (grandparent, token) hash: first entry, (entries / 4) - 1
+    uint32_t pad[4];
 };
 static_assert(sizeof(RTenantSlot) == 64, "RTenantSlot must be 64 bytes");
 
@@ -82,6 +102,8 @@ struct RetainDynView {
 struct RetainIndexView {
     const RNode* nodes;
     const REdge* edges;
+    const REdge* posts; // grandchild postings (see RGp)
+    const RGp* gps;
     const RTenantSlot* tenants;
     uint32_t tenant_mask;
     const DictSlot* dict;
@@ -104,7 +126,10 @@ struct RTenantState {
     uint32_t token = 0;
     std::vector<RNode> nodes;        // breadth-first, local ids
     std::vector<REdge> edges;        // the tenant's edge region (size = 4 * buckets, power of two)
+    std::vector<REdge> posts;        // grandchild postings, ordered by (grandparent, token, parent)
+    std::vector<RGp> gps;            // (grandparent, token) -> slice of posts (size = 4 * buckets, power of two)
     uint32_t node_base = 0, node_cap = 0, edge_base = 0, edge_cap = 0, id_base = 0;
+    uint32_t post_base = 0, post_cap = 0, gp_base = 0, gp_cap = 0;
     uint32_t sys_node_lo = 0, sys_node_hi = 0, sys_id_lo = 0, sys_id_hi = 0;
 };
 
@@ -112,6 +137,8 @@ struct RetainIndexHost {
     // ---- image of the device arrays ----
     std::vector<RNode> nodes;
     std::vector<REdge> edges;
+    std::vector<REdge> posts;
+    std::vector<RGp> gps;
     std::vector<RTenantSlot> tenants;
     std::vector<DictSlot> dict;
     std::vector<uint8_t> pool;
@@ -124,7 +151,7 @@ struct RetainIndexHost {
     std::vector<RTenantState*> order;                             // by id_base
     HostDict dict_h;
     std::deque<std::string> strings;
-    uint32_t node_free = 0, edge_free = 0;
+    uint32_t node_free = 0, edge_free = 0, post_free = 0, gp_free = 0;
     uint64_t n_topics = 0;
     std::string error;
 

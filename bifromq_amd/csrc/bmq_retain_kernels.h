@@ -124,7 +124,7 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
         if (lane == 0 && !deep) lev_end[nlev - 1] = end;
         if (DEEP) __threadfence_block(); // (the arrays live in global memory: other lanes read what this lane wrote)
         __syncthreads();
-        RTenantSlot ten{0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
+        RTenantSlot ten{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}};
         if (!deep) {
             const uint8_t* fbytes = r.filters;
             auto fbyte = [&](uint32_t k) -> uint32_t { return fbytes[k]; };

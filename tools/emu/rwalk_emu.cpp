@@ -92,6 +92,8 @@ template <int G> static int run(int rounds, uint64_t seed) {
         RetainIndexView v{};
         v.nodes = h.nodes.data();
         v.edges = h.edges.data();
+        v.posts = h.posts.data();
+        v.gps = h.gps.data();
         v.tenants = h.tenants.data();
         v.tenant_mask = (uint32_t)h.tenants.size() - 1;
         v.dict = h.dict.data();
@@ -235,6 +237,12 @@ template <int G> static int run(int rounds, uint64_t seed) {
             if (n && ctr.topic_bytes == 0 && fbytes.size() > 32 && deep.size() != n) FAIL("round %d: no filter bytes counted\n", round);
             break;
         }
+    }
+    static const char* const paths[8] = {"postings look-ups", "slices copied", "slices emitted", "merged subtrees", "bulk chunks", "arena reads", "overflow probes", "'+' over a list"};
+    for (int i = 0; i < 8; i++) {
+        if (bmq::g_rw_cover[i] == 0 && rounds >= 20) FAIL("G %d: no case reached the path '%s'\n", G, paths[i]);
+        printf("  %s: %llu\n", paths[i], bmq::g_rw_cover[i]);
+        bmq::g_rw_cover[i] = 0;
     }
     printf("ok: G %d: %llu filters (%llu deeper than the kernel walks), %llu ids, %llu re-runs after growth\n", G, (unsigned long long)n_filters_checked,
            (unsigned long long)n_deep, (unsigned long long)n_ids, (unsigned long long)n_reruns);

@@ -221,6 +221,8 @@ int main(int argc, char** argv) {
         RetainIndexView v{};
         v.nodes = h.nodes.data();
         v.edges = h.edges.data();
+        v.posts = h.posts.data();
+        v.gps = h.gps.data();
         v.tenants = h.tenants.data();
         v.tenant_mask = (uint32_t)h.tenants.size() - 1;
         v.dict = h.dict.data();
