@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--batcher-threads", type=int, default=-1,
                     help="also measure the batching front (bmq_batcher_*, SURVEY 8f-1): N native threads issue single-topic calls")
     ap.add_argument("--batcher-topics", type=int, default=200_000)
-    ap.add_argument("--cpu-sample-tenants", type=int, default=128)
+    ap.add_argument("--cpu-sample-tenants", type=int, default=1_000_000, help="the CPU baseline / parity leg takes the publishes of the first N tenants (default: all of them, the whole batch)")
     ap.add_argument("--cpu-sample-topics", type=int, default=1_000_000)
     args = ap.parse_args()
 
@@ -514,14 +514,19 @@ def main():
         torch.cuda.synchronize()
         out["cpu_baseline"] = cpu_baseline(args, w, batches[0][3], n, (d_row[0].cpu().numpy().view(np.uint32), d_ids[0].cpu().numpy().view(np.uint32)))
     if world == 1 and not args.no_extras and not args.churn and args.workload == "c3":
-        out["extra"] = extra_legs(args, eng, w, step, torch, np)
+        def fetch_csr(i):  # batch i once more on the index as it is now -> (host batch, engine CSR): the C5 leg's parity check
+            step(i)
+            torch.cuda.synchronize()
+            k = i % NBUF
+            return batches[i % len(batches)][3], (d_row[k].cpu().numpy().view(np.uint32), d_ids[k].cpu().numpy().view(np.uint32))
+        out["extra"] = extra_legs(args, eng, w, step, torch, np, fetch_csr if not args.no_cpu_baseline else None)
     eng.close()  # deterministic teardown of everything this script owns, in order, before the line goes out
     if dist is not None:
         dist.destroy_process_group()
     emit_json(out)
 
 
-def extra_legs(args, eng, w, step, torch, np):
+def extra_legs(args, eng, w, step, torch, np, fetch_csr=None):
     """Compact legs the default N = 1 run appends, so that the driver's own command exercises them: configs[4] (100 k route mutations
     before every batch) on THIS index, and configs[1] / configs[3] as child runs of this script (3 steps each)."""
     import subprocess
@@ -593,10 +598,70 @@ def extra_legs(args, eng, w, step, torch, np):
                        "roofline": {"bound": "hbm", "kernel": "k_walk", "achieved": (alg - 4 * st.n_match) / (st.ms_walk * 1e-3) / 1e9, "peak": 8000.0,
                                     "unit": "GB/s", "frac": (alg - 4 * st.n_match) / (st.ms_walk * 1e-3) / 8e12,
                                     "frac_batch": alg / (st.ms_walk * 1e-3) / 8e12}}
+        if fetch_csr is not None:
+            extra["c5"]["parity"] = c5_parity(w, cb, n_steps + 1, fetch_csr, np)
     except Exception as ex:  # noqa: BLE001
         extra["c5"] = {"error": repr(ex)}
     extra["wall_s"] = time.perf_counter() - t_all
     return extra
+
+
+def c5_parity(w, cb, n_applied, fetch_csr, np):
+    """configs[4]: the rows of batch 0 on the index AFTER the leg's mutation batches against the oracle over the key set as it is then --
+    the structural restatement row for row, every differing row against the semantic oracle (tests/util.py), the whole batch."""
+    try:
+        from oracle import oracle as O
+        from tests import util as U
+        t0 = time.perf_counter()
+        kb, ko = w.keys_packed()
+        ko64 = np.asarray(ko, dtype=np.int64)
+        raw = kb.tobytes()
+        key_id = None
+        dels, adds, new_ids = [], [], {}
+        next_id = w.n_keys
+        for b in range(n_applied):  # the ops in the order they were applied: a put gets the next unused id
+            data, off, opb = (x.numpy() for x in cb[b])
+            braw = data.tobytes()
+            for j, op in enumerate(opb.tolist()):
+                k = braw[off[j]:off[j + 1]]
+                if op == 0:
+                    adds.append(k)
+                    new_ids[k] = next_id
+                    next_id += 1
+                else:
+                    dels.append(k)
+        # a deleted key -> its old id: the old keys are sorted
+        class _Old:
+            def __len__(self):
+                return w.n_keys
+
+            def __getitem__(self, i):
+                return raw[ko64[i]:ko64[i + 1]]
+        import bisect
+        old = _Old()
+        del_ids = [bisect.bisect_left(old, k) for k in dels]
+        add_keys = sorted(set(adds))
+        kv, old_rank, add_rank, all_keys = U.kv_after_mutations(kb, ko, w.n_keys, del_ids, add_keys)
+        new_rank = {new_ids[k]: int(r) for k, r in zip(add_keys, add_rank.tolist())}
+        (data, off, tt), (row, ids) = fetch_csr(0)
+        n = len(tt)
+        res, sec = kv.match_singletons(w.tenants(), tt, (data, off), threads=effective_cpus())
+        got = ids[:int(row[n])].astype(np.int64)
+        is_old = got < w.n_keys
+        mapped = np.where(is_old, old_rank[np.where(is_old, got, 0)], 0)
+        if (~is_old).any():
+            mapped[~is_old] = [new_rank[int(x)] for x in got[~is_old]]
+        if (mapped < 0).any():
+            return {"FAILED": "the engine returned the id of a deleted route"}
+        got_rp = row[:n + 1].astype(np.int64)
+        mapped = U.csr_sorted(got_rp, mapped)
+        differ = U.assert_csr_equal_modulo_quirk_ii(all_keys, kv.key, w.tenants(), tt, res.row_ptr.astype(np.int64), res.routes.astype(np.int64), got_rp, mapped)
+        n_sem = U.assert_differing_rows_semantic("bench c5 (batch 0 after %d mutation batches)" % n_applied, kv, w.tenants(), tt, (data, off), differ, got_rp, mapped,
+                                                 livelocks=res.livelocks)
+        return {"rows_compared": int(n), "rows_differing_from_reference_restatement": int(len(differ)), "differing_rows_equal_semantic_oracle": int(n_sem),
+                "reference_livelocks": int(res.livelocks), "route_keys_after_the_mutations": int(len(kv)), "seconds": round(time.perf_counter() - t0, 1)}
+    except AssertionError as ex:
+        return {"FAILED": repr(ex)}
 
 
 def node_batch(args, rank, world, local_rank, dev, dist, total_tenants, per_tenant, mode, seed):

@@ -312,8 +312,16 @@ struct bmq_route_cache {
     // per-tenant caps that differ from the defaults (ISettingProvider.provide(MaxPersistentFanout / MaxGroupFanout, tenantId))
     std::mutex caps_mu;
     std::unordered_map<std::string, std::pair<int32_t, int32_t>> caps;
-    std::atomic<bmq_route_cache_event_cb> ev_cb{nullptr};
-    std::atomic<void*> ev_user{nullptr};
+    // the event sink: callback and user pointer travel as ONE immutable pair behind one atomic pointer (round 4 kept two atomics: a load
+    // between the two stores of a replacement could pair the new callback with the old user pointer); a pair is never freed before the
+    // cache is -- a load that read it just before a replacement may still call it
+    struct EvSink {
+        bmq_route_cache_event_cb cb;
+        void* user;
+    };
+    std::atomic<const EvSink*> ev{nullptr};
+    std::mutex ev_mu;
+    std::vector<std::unique_ptr<EvSink>> ev_all;
     // counters of tenants whose cache has been destroyed (the cache-wide statistics keep counting them)
     std::mutex retired_mu;
     bmq_route_cache_stats retired{};
@@ -484,9 +492,14 @@ int bmq_route_cache_set_caps(bmq_route_cache* c, const uint8_t* tenant, uint32_t
 
 int bmq_route_cache_set_event_sink(bmq_route_cache* c, bmq_route_cache_event_cb cb, void* user) {
     if (!c) return BMQ_E_INVAL;
-    c->ev_cb.store(nullptr, std::memory_order_release);
-    c->ev_user.store(user, std::memory_order_release);
-    c->ev_cb.store(cb, std::memory_order_release);
+    const bmq_route_cache::EvSink* next = nullptr;
+    if (cb) {
+        auto p = std::make_unique<bmq_route_cache::EvSink>(bmq_route_cache::EvSink{cb, user});
+        next = p.get();
+        std::lock_guard<std::mutex> g(c->ev_mu);
+        c->ev_all.push_back(std::move(p));
+    }
+    c->ev.store(next, std::memory_order_release);
     return BMQ_OK;
 }
 
@@ -514,8 +527,9 @@ int cap_rows_inplace(bmq_route_cache* c, const Caps* caps, const uint8_t* tenant
     std::vector<uint32_t> kept_all; // the capped rows, in lng order
     std::vector<uint32_t> s_rp, s_ids, o_rp, o_ids, o_cls;
     std::vector<int32_t> evs;
-    const bmq_route_cache_event_cb cb = c->ev_cb.load(std::memory_order_acquire);
-    void* const cb_user = c->ev_user.load(std::memory_order_acquire);
+    const bmq_route_cache::EvSink* const sink = c->ev.load(std::memory_order_acquire);
+    const bmq_route_cache_event_cb cb = sink ? sink->cb : nullptr;
+    void* const cb_user = sink ? sink->user : nullptr;
     for (size_t a = 0; a < lng.size();) {
         const uint32_t ti = row_tenant ? row_tenant[lng[a]] : 0;
         size_t z = a;

@@ -603,20 +603,20 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (cfg->struct_size < 8 || cfg->struct_size > sizeof(bmq_config)) return BMQ_E_INVAL;
         memcpy(&c, cfg, cfg->struct_size);
     }
-    // The LDS geometry of k_walk is a compile-time property of its instantiations (bmq_walk_kernel.h): the two caps select one --
-    // caps of 128 the smallest lists (tests force the overflow paths with them), anything else the default (192 / 160: 5.5 KB of LDS per
-    // one-wave workgroup, 7 waves per SIMD); BMQ_WALK_GEOM picks one by number (profiling experiments).
-    if (c.wave_queue_cap == 0) c.wave_queue_cap = 192;
-    if (c.wave_pair_cap == 0) c.wave_pair_cap = 160;
+    // The LDS geometry of k_walk is a compile-time property of its instantiations (bmq_walk_kernel.h): the two caps SELECT one -- 128 in
+    // either the smallest lists (192 tokens / 128 items / 128 ranges: tests force the overflow paths with them), 0 the default (512 / 176 /
+    // 152: 5.0 KB of LDS per one-wave workgroup, 8 waves per SIMD).  Other values used to run the default silently: refused.
+    // BMQ_WALK_GEOM picks an instantiation by number (profiling experiments).
     if (const char* v = getenv("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
     if (const char* v = getenv("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
-    if (c.wave_queue_cap < 128 || (c.wave_queue_cap & 63) || c.wave_queue_cap > 4096) return BMQ_E_INVAL;
-    // the range buffer must take one round's matches (two per work item) after a flush
-    if (c.wave_pair_cap < 128 || (c.wave_pair_cap & 3) || c.wave_pair_cap > 4096) return BMQ_E_INVAL;
+    if ((c.wave_queue_cap != 0 && c.wave_queue_cap != 128) || (c.wave_pair_cap != 0 && c.wave_pair_cap != 128)) return BMQ_E_INVAL;
+    const bool smallest = c.wave_queue_cap == 128 || c.wave_pair_cap == 128;
+    c.wave_queue_cap = smallest ? 128 : 176; // (what bmq_config reports back / BatchArgs carries: the geometry in use)
+    c.wave_pair_cap = smallest ? 128 : 152;
     auto e = std::make_unique<bmq_engine>();
     e->cfg = c;
     e->device = c.device;
-    e->walk_geom = (c.wave_queue_cap <= 128 || c.wave_pair_cap <= 128) ? 2 : 0;
+    e->walk_geom = smallest ? 2 : 0;
     if (c.dedup_min_topics) e->dedup_min = c.dedup_min_topics;
     if (const char* v = getenv("BMQ_DEDUP_MIN")) e->dedup_min = (uint32_t)strtoul(v, nullptr, 10); // profiling experiments (4294967295: never)
     if (const char* v = getenv("BMQ_WALK_GEOM")) e->walk_geom = atoi(v);

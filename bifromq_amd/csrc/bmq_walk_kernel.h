@@ -52,6 +52,7 @@ template <int TC, int QC, int PC, bool MIXED> struct WalkLds { // byte offsets i
     static constexpr uint32_t WAVES_LDS = (163840 / ALLOC) / 4 > 8 ? 8 : (163840 / ALLOC) / 4;
     static constexpr uint32_t WAVES = MIXED && WAVES_LDS > 5 ? 5 : WAVES_LDS;
     static_assert(3 * 64 * 4 <= STK && PC % 8 == 0 && QC % 8 == 0 && STK % 16 == 0 && WAVES >= 1 && TC >= 2 * FAST_LEVELS && TC <= 1023, "layout");
+    static_assert(FAST_LEVELS <= 32, "walk_meta keeps the levels behind an item in 5 bits");
     static_assert(STK + (QC + 64) * 8 <= BYTES, "a round reads 64 stack slots from `tail` on, whatever is there");
 };
 
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     auto boot = [&](bool mine, uint32_t r_hash_begin, uint32_t r_hash_count, uint32_t r_bloom) {
         const bool act = mine;
         const uint32_t ln = lane_here();
-        const uint32_t t0 = tokens[tok_base]; // (a lane that is not `mine` reads some entry of the table)
+        const uint32_t t0 = tokens[act ? tok_base : 0u]; // (a lane that is not `mine` reads entry 0: its own tok_base may lie beyond the table)
         const uint32_t bloom_in = act ? r_bloom : 0u;
         sink(0u, 0u,                                                        // a topic has at least one level: nothing ends at the root
              r_hash_begin, (act && !sys) ? r_hash_count : 0u,               // the filter "#"; never for '$' topics

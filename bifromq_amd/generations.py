@@ -51,6 +51,8 @@ class GenerationalEngine:
         self._compacting = threading.Lock()      # one compaction at a time
         self._cur = _Gen(Engine(**engine_args), 0)
         self._log: Optional[List[Tuple[int, bytes]]] = None
+        self._closed = False                     # close() was called: a compaction still running must not install its generation
+        self._log_broken = False                 # an apply() failed after it was logged: the running compaction is abandoned
         self.hooks = {}                          # test hooks: name -> callable, run at the named point of compact_online()
 
     # ---- serving ----
@@ -83,13 +85,19 @@ class GenerationalEngine:
         """(0 = put | 1 = delete, route key)*: to the serving generation, in order, and to the log of a running compaction"""
         ops = list(ops)
         with self._lock:
-            self._cur.eng.apply(ops)
             if self._log is not None:
-                self._log.extend(ops)
+                self._log.extend(ops)  # logged FIRST: a batch the serving generation applied in part must not be missing from the next one
+            try:
+                self._cur.eng.apply(ops)
+            except Exception:
+                if self._log is not None:
+                    self._log_broken = True  # what exactly reached the serving generation is unknown: the compaction gives up (ADVICE r4)
+                raise
         return self
 
     def close(self):
         with self._lock:
+            self._closed = True
             g = self._cur
             g.retired = True
             close = g.pins == 0
@@ -110,12 +118,16 @@ class GenerationalEngine:
         try:
             with self._lock:
                 a = self._cur
+                if self._closed:
+                    raise RuntimeError("closed")
+                # (everything that can fail comes BEFORE the pin and the log exist: ADVICE r4 -- a raising info() used to leak both)
                 if a.eng.retain_find_all()[0]:
                     # (dist worker and retain store are separate coprocs with an index each: DW/DistWorkerCoProc.java, RetainStoreCoProc.java)
                     raise NotImplementedError("this handle also holds retained topics: only the route index is carried into the next generation")
+                n_ids = int(a.eng.info().next_route_id)
                 a.pins += 1          # A must outlive the export whatever happens
                 self._log = []
-                n_ids = int(a.eng.info().next_route_id)
+                self._log_broken = False
             nxt = None
             try:
                 self._hook("after_snapshot")
@@ -133,6 +145,10 @@ class GenerationalEngine:
                 while True:
                     with self._lock:
                         chunk, self._log = self._log, []
+                        if self._log_broken:
+                            raise RuntimeError("an apply() failed while the compaction ran: the next generation is abandoned")
+                        if self._closed:
+                            raise RuntimeError("closed while the compaction ran: the next generation is dropped")
                         last = not chunk or rounds >= self.MAX_REPLAY_ROUNDS
                         if last:
                             if chunk:

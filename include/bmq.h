@@ -59,10 +59,11 @@ typedef struct bmq_engine bmq_engine;
 typedef struct bmq_config {
     uint32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = host-only engine (build/inspect, no match)      */
-    uint32_t wave_queue_cap;   /* per-wave LDS work stack, items (128..4096, x64).  The walk kernel's LDS geometry is */
-                               /* compiled in: a cap of 128 selects the smallest lists (128 / 128), any other value   */
-                               /* the default (192 / 160).  Overflow is parked in global memory, never an error       */
-    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer, entries (128..4096, x4): as above               */
+    uint32_t wave_queue_cap;   /* per-wave LDS work stack of the walk kernel.  Its LDS geometry is compiled in, so the two caps are a  */
+                               /* SELECTOR, not sizes: 0 = default (176 stack items / 152 range entries); 128 in either = the smallest */
+                               /* lists (128 / 128: tests force the overflow paths with them).  Any other value is refused           */
+                               /* (BMQ_E_INVAL): it would silently run the default.  Overflow is parked in global memory, never an error */
+    uint32_t wave_pair_cap;    /* per-wave LDS matched-range buffer: 0 or 128, as above                                          */
     uint32_t slow_scratch_mb;  /* global scratch for the per-lane DFS slow path (default 64)               */
     uint32_t kernel_timing;    /* 1: HIP events around k_walk / k_expand of every batch -> bmq_stats.ms_walk /  */
                                /* ms_expand (two extra events per batch, ~4 us each on the stream); 0: ms_total  */
@@ -427,7 +428,9 @@ int bmq_route_cache_set_caps(bmq_route_cache* c, const uint8_t* tenant, uint32_t
 /* IEventCollector.report(PersistentFanoutThrottled / GroupFanoutThrottled) (DW/cache/MatchedRoutes.java:95-101,124-130): called once
  * per route a load rejects -- type 0 = PersistentFanoutThrottled, 1 = GroupFanoutThrottled; route_id's key gives mqttTopicFilter
  * (bmq_route_key) -- on the thread that completes the load (the caller of get / get_batch, the batcher's dispatcher thread for
- * get_async), before the rows are handed out.  NULL switches reporting off.  Set it before the getters start. */
+ * get_async), before the rows are handed out.  NULL switches reporting off.  Callback and user pointer are replaced together (one atomic
+ * pointer to the pair).  May be called while getters run: a load that picked the previous sink up just before the call may still report to
+ * it once more afterwards, so a `user` object that was ever installed has to stay valid until bmq_route_cache_destroy has returned. */
 typedef void (*bmq_route_cache_event_cb)(void* user, const uint8_t* tenant, uint32_t tenant_len, const uint8_t* topic, uint32_t topic_len,
                                          int32_t type, uint32_t route_id, int32_t max_count);
 int bmq_route_cache_set_event_sink(bmq_route_cache* c, bmq_route_cache_event_cb cb, void* user);

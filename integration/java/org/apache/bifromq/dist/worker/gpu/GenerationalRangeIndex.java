@@ -96,11 +96,12 @@ final class GenerationalRangeIndex implements AutoCloseable {
         lock.lock();
         try {
             a = current;
-            a.pins.incrementAndGet(); // A outlives the export whatever happens
-            log = new ArrayList<>();
+            // (what can throw comes BEFORE the pin and the log exist: a failing indexInfo used to leak both -- ADVICE r4)
             long[] info = new long[11];
             NativeMatcher.indexInfo(a.engine, info);
             nIds = info[9];
+            a.pins.incrementAndGet(); // A outlives the export whatever happens
+            log = new ArrayList<>();
         } finally {
             lock.unlock();
         }

@@ -682,8 +682,8 @@ JNIEXPORT void JNICALL NM(routeCacheSetCaps)(JNIEnv* env, jclass c, jlong h, jby
  * (type 0) / GroupFanoutThrottled (type 1)), MatchedRoutes.java:95-101,124-130; it runs on the thread that completes the load (a Java
  * matcher thread, or the dispatcher thread of the batching front).  One sink PER CACHE: a dist worker hosts one GpuSubscriptionCache per
  * range and each installs a lambda that resolves route ids against ITS range's index -- the sink object travels as the `user` pointer of
- * bmq_route_cache_set_event_sink (a global ref held in a registry entry of the cache), it is deleted when the sink is replaced or cleared
- * and when the cache is destroyed.  (Round 3 kept one global sink per process: the events of the second and later caches went to the
+ * bmq_route_cache_set_event_sink (a global ref held in a registry entry of the cache); the entries of a cache -- the current one and
+ * those it replaced -- are deleted when the cache is destroyed.  (Round 3 kept one global sink per process: the events of the second and later caches went to the
  * first cache's lambda.) */
 typedef struct sink_entry {
     struct sink_entry* next;
@@ -708,28 +708,34 @@ static void throttle_event(void* user, const uint8_t* tenant, uint32_t tl, const
     if (jt) (*env)->DeleteLocalRef(env, jt);
     if (jp) (*env)->DeleteLocalRef(env, jp);
 }
-/* unlinks the cache's registry entry (the cache no longer calls it: its sink was replaced, cleared, or the cache is gone) and frees its ref */
+/* frees every registry entry of the cache and their refs.  Only routeCacheDestroy calls it: a loader thread that read the cache's sink just
+ * before a replacement may still call the OLD entry afterwards (bmq_route_cache_set_event_sink only swaps a pointer), so an entry that was
+ * replaced or cleared stays allocated, with its global ref, until the cache is gone (freeing it at replace time was a use after
+ * free). */
 static void sink_drop(JNIEnv* env, bmq_route_cache* cache) {
     sink_entry* dead = NULL;
     pthread_mutex_lock(&g_sinks_mu);
-    for (sink_entry** pp = &g_sinks; *pp; pp = &(*pp)->next)
+    for (sink_entry** pp = &g_sinks; *pp;) {
         if ((*pp)->cache == cache) {
-            dead = *pp;
-            *pp = dead->next;
-            break;
-        }
+            sink_entry* e = *pp;
+            *pp = e->next;
+            e->next = dead;
+            dead = e;
+        } else pp = &(*pp)->next;
+    }
     pthread_mutex_unlock(&g_sinks_mu);
-    if (dead) {
-        if (dead->ref) (*env)->DeleteGlobalRef(env, dead->ref);
-        free(dead);
+    while (dead) {
+        sink_entry* e = dead;
+        dead = e->next;
+        if (e->ref) (*env)->DeleteGlobalRef(env, e->ref);
+        free(e);
     }
 }
 JNIEXPORT void JNICALL NM(routeCacheSetEventSink)(JNIEnv* env, jclass c, jlong h, jobject sink) {
     (void)c;
     if (!g_vm) (*env)->GetJavaVM(env, &g_vm);
-    if (!sink) { /* reporting off: first the cache stops calling, then the reference goes */
+    if (!sink) { /* reporting off: the cache stops calling; the entry stays until routeCacheDestroy (a call may be in flight) */
         (void)bmq_route_cache_set_event_sink(CACHE(h), NULL, NULL);
-        sink_drop(env, CACHE(h));
         return;
     }
     if (!g_on_throttle) {
@@ -749,15 +755,14 @@ JNIEXPORT void JNICALL NM(routeCacheSetEventSink)(JNIEnv* env, jclass c, jlong h
         free(se);
         return;
     }
-    const int rc = bmq_route_cache_set_event_sink(CACHE(h), throttle_event, se); /* from here on the cache calls the NEW entry only */
+    const int rc = bmq_route_cache_set_event_sink(CACHE(h), throttle_event, se); /* new loads call the NEW entry; one in flight may still call the old */
     if (rc != BMQ_OK) {
         (*env)->DeleteGlobalRef(env, se->ref);
         free(se);
         throw_state(env, NULL, "bmq_route_cache_set_event_sink", rc);
         return;
     }
-    sink_drop(env, CACHE(h)); /* the entry this one replaces, if any */
-    pthread_mutex_lock(&g_sinks_mu);
+    pthread_mutex_lock(&g_sinks_mu); /* (the entry this one replaces, if any, stays registered: freed with the cache) */
     se->next = g_sinks;
     g_sinks = se;
     pthread_mutex_unlock(&g_sinks_mu);

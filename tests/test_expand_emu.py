@@ -32,3 +32,18 @@ def test_the_emulator_against_the_definitions_of_its_operations(tmp_path):
                    check=True, capture_output=True, text=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "emu selftest ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("defs,rounds", [((), 24), (("-DBMQ_RW_INL=4", "-DBMQ_RW_CHUNK=16"), 20)])
+def test_k_retain_walk_under_the_wave_emulator(tmp_path, defs, rounds):
+    """tools/emu/rwalk_emu.cpp: bifromq_amd/csrc/bmq_rwalk_kernel.h (the retain direction's walk: 8 / 4 / 2 filters per wave, lanes handed out to
+    units, range / list / postings frontiers, the '$' hole, bulk chunks, merged subtrees, refills, room reservation, lists that outgrow LDS and
+    the arena, filters too deep for it) over indexes built by the product's own host builder, against a brute force over the topic strings;
+    the harness fails if its cases miss one of the kernel's rarely taken paths."""
+    exe = str(tmp_path / "rwalk_emu")
+    cmd = ["g++", "-O1", "-std=c++17", *defs, "-I", os.path.join(ROOT, "bifromq_amd", "csrc"), "-I", os.path.join(ROOT, "tools", "emu"),
+           os.path.join(ROOT, "tools", "emu", "rwalk_emu.cpp"), os.path.join(ROOT, "bifromq_amd", "csrc", "bmq_retain.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([exe, str(rounds), "12345"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok: G") == 3, r.stdout[-2000:]

@@ -401,3 +401,14 @@ def test_expand_ranges_orders_rows_whose_ranges_interleave():
     rptr = np.array([0, 4, 6, 6, 7], dtype=np.uint32)
     rows = B.Engine.expand_ranges(rptr, ranges, side, 4)
     assert [r.tolist() for r in rows] == [[7, 9, 10, 11, 12, 30, 31], [40, 41, 50], [], [5]]
+
+
+def test_walk_geometry_caps_are_a_selector():
+    """bmq_config.wave_queue_cap / wave_pair_cap select one of the walk kernel's two compiled LDS geometries: 0 (default) or 128 (smallest
+    lists); a value that would silently run the default is refused."""
+    B.Engine(device=-1, wave_queue_cap=128, wave_pair_cap=128).close()
+    B.Engine(device=-1, wave_queue_cap=128).close()
+    for bad in (dict(wave_queue_cap=192), dict(wave_pair_cap=160), dict(wave_queue_cap=4096, wave_pair_cap=4096), dict(wave_queue_cap=64)):
+        with pytest.raises(B.BmqError) as ei:
+            B.Engine(device=-1, **bad)
+        assert ei.value.code == -1  # BMQ_E_INVAL

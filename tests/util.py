@@ -122,11 +122,11 @@ def assert_rows_equal_modulo_quirk_ii(keys, tenants, topic_tenant, reference_row
     """reference_rows come from the structural restatement in the reference's production call pattern (one
     matchAll per topic); they may only differ from the engine by routes LOST to quirk (ii)."""
     quirk = None
-    n_diff = 0
+    differ = []
     for i, (ref, got) in enumerate(zip(reference_rows, engine_rows)):
         if ref == got:
             continue
-        n_diff += 1
+        differ.append(i)
         if quirk is None:
             quirk = quirk_ii_filters(keys)
         assert set(ref) <= set(got), i
@@ -135,7 +135,7 @@ def assert_rows_equal_modulo_quirk_ii(keys, tenants, topic_tenant, reference_row
             if flag != 1:
                 mqtt = mqtt.split("/", 2)[2]
             assert (tenant, mqtt) in quirk, (i, mqtt)
-    return n_diff
+    return differ  # the rows the reference loses routes in (callers check every one of them against the semantic oracle)
 
 
 def retain_order(tenant_names, topic_tenant, topics):
@@ -260,6 +260,48 @@ def assert_differing_rows_semantic(config, kv, tenants, topic_tenant, packed_top
     return len(differ)
 
 
+def kv_after_mutations(kb, ko, hi_old, del_ids, add_keys):
+    """The key set of a KV after deletes and adds, and the rank every id maps to, WITHOUT a Python object per key (10 M of them at full
+    size): the first hi_old keys of the packed, sorted (kb, ko) minus the ids del_ids plus the sorted, distinct byte strings add_keys (none
+    of them an old key).  -> (oracle KV, old_rank[hi_old] (-1: deleted), add_rank[len(add_keys)], all_keys() -> the sorted key list)."""
+    import bisect
+    raw_k = kb.tobytes() if hasattr(kb, "tobytes") else bytes(kb)
+    ko64 = np.asarray(ko, dtype=np.int64)
+    dels = np.unique(np.asarray(list(del_ids), dtype=np.int64))
+    alive = np.ones(hi_old, dtype=bool)
+    alive[dels] = False
+
+    class _Old:  # the old keys as a sorted sequence for bisect
+        def __len__(self):
+            return hi_old
+
+        def __getitem__(self, i):
+            return raw_k[ko64[i]:ko64[i + 1]]
+    pos = np.asarray([bisect.bisect_left(_Old(), k) for k in add_keys], dtype=np.int64)  # old keys (deleted ones included) below the added key
+    dead_below = np.concatenate([[0], np.cumsum(~alive)]).astype(np.int64)            # deleted old ids below i
+    old_rank = np.arange(hi_old, dtype=np.int64) - dead_below[:-1] + np.searchsorted(pos, np.arange(hi_old), side="right")
+    old_rank[~alive] = -1
+    add_rank = pos - dead_below[pos] + np.arange(len(add_keys), dtype=np.int64)
+    # the packed key set: the old bytes without the deleted keys' (runs between two deleted keys are copied whole) + the added keys; KV sorts
+    cuts = np.concatenate([[-1], dels, [hi_old]])
+    parts = [raw_k[ko64[int(cuts[x]) + 1]:ko64[int(cuts[x + 1])]] for x in range(len(cuts) - 1) if int(cuts[x]) + 1 < int(cuts[x + 1])]
+    surv_len = (ko64[1:hi_old + 1] - ko64[:hi_old])[alive]
+    all_len = np.concatenate([surv_len, np.asarray([len(k) for k in add_keys], dtype=np.int64)])
+    m_off = np.concatenate([[0], np.cumsum(all_len)]).astype(np.uint32)
+    m_raw = b"".join(parts) + b"".join(add_keys)
+    assert len(m_raw) == int(m_off[-1])
+    m_data = np.zeros(len(m_raw) + 32, dtype=np.uint8)
+    m_data[:len(m_raw)] = np.frombuffer(m_raw, dtype=np.uint8)
+    kv = O.KV(packed=(m_data, m_off))  # (sorts: rank = position in byte order = what old_rank / add_rank compute)
+    n_kv = len(m_off) - 1
+    assert len(kv) == n_kv == int(alive.sum()) + len(add_keys)
+
+    def all_keys():
+        so = np.concatenate([[0], np.cumsum(all_len)])
+        return sorted(m_raw[so[i]:so[i + 1]] for i in range(n_kv))
+    return kv, old_rank, add_rank, all_keys
+
+
 def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_tenants=16, n_sample=2000, seed=0xB1F20005):
     """configs[4]: an index of n_tenants x per_tenant generated routes, then ONE batch of n_ops mutations (50 % unsubscribes of
     existing routes, 50 % subscribes of new filters, spread over all tenants) through bmq_routes_apply, then a batch of
@@ -318,12 +360,8 @@ def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_ten
     some_added = rnd.sample(sorted(added), min(200, len(added)))
     assert eng.route_keys([added_id[k] for k in some_added]) == some_added
     owner_of_new = {added_id[k]: t for k, t in added.items()}
-    # the key set of the first S tenants after the batch
     S = min(sample_tenants, n_tenants)
     hi_old = int(first[S])
-    keys_s = [key_at(i) for i in range(hi_old) if i not in deleted] + [k for k, t in added.items() if t < S]
-    kv = O.KV(keys_s)  # sorts
-    keys_sorted = sorted(keys_s)
     data, off, tt = w.topics(seed + 1000, n_topics)
     row, ids = match_fn(tn, tt, (data, off))
     assert row[0] == 0 and row[-1] == len(ids) and (np.diff(row.astype(np.int64)) >= 0).all()
@@ -341,17 +379,18 @@ def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_ten
             assert owner_of_new[x] == o
     cand = np.nonzero(tt < S)[0]
     if n_sample is None:
-        # EVERY publish addressed to the first S tenants, whole-CSR comparison (the shape of test_full_size_config3_properties): the
-        # post-churn index -- indirect id lists, re-hashed regions, dead ids -- is where a wrong row would hide from a sample
-        rank = {k: i for i, k in enumerate(keys_sorted)}
-        old_rank = np.full(hi_old, -1, dtype=np.int64)
-        for i in range(hi_old):
-            if i not in deleted:
-                old_rank[i] = rank[key_at(i)]
+        # EVERY publish addressed to the first S tenants (S = all of them at full size), whole-CSR comparison: the post-churn index --
+        # indirect id lists, re-hashed regions, dead ids -- is where a wrong row would hide from a sample.  The key set after the batch and
+        # the rank every id must map to are computed without a Python object per key (10 M of them at full size): the old keys are sorted,
+        # a deleted one leaves, an added one enters at its bisection point.
+        add_keys = sorted(k for k, t in added.items() if t < S)
+        kv, old_rank, add_rank, all_keys = kv_after_mutations(kb, ko, hi_old, [i for i in del_ids if i < hi_old], add_keys)
         new_rank = np.full(n_ops - n_ops // 2, -1, dtype=np.int64)
-        for k, t in added.items():
-            if t < S:
-                new_rank[added_id[k] - w.n_keys] = rank[k]
+        for k, rk in zip(add_keys, add_rank.tolist()):
+            new_rank[added_id[k] - w.n_keys] = rk
+        for rk in rnd.sample(range(len(kv)), min(50, len(kv))):  # the computed ranks are the KV's
+            src = np.nonzero(old_rank == rk)[0]
+            assert kv.key(rk) == (key_at(int(src[0])) if len(src) else add_keys[int(np.nonzero(add_rank == rk)[0][0])])
         traw = data.tobytes()
         t_off = np.concatenate([[0], np.cumsum((off[cand + 1] - off[cand]).astype(np.int64))]).astype(np.uint32)
         t_data = np.zeros(int(t_off[-1]) + 32, dtype=np.uint8)
@@ -361,17 +400,21 @@ def churn_case(eng, match_fn, n_tenants, per_tenant, n_ops, n_topics, sample_ten
         got_rp, got = csr_select(row, ids, cand)
         got = got.astype(np.int64)
         is_old = got < w.n_keys
+        assert (got[is_old] < hi_old).all()
         mapped = np.where(is_old, old_rank[np.where(is_old, got, 0)], new_rank[np.where(is_old, 0, got - w.n_keys)])
         assert (mapped >= 0).all()  # no deleted id, no id of another tenant's new route
         mapped = csr_sorted(got_rp, mapped)
-        differ = assert_csr_equal_modulo_quirk_ii(lambda: keys_sorted, lambda r: keys_sorted[r], tn[:S], stt, res.row_ptr.astype(np.int64),
-                                                  res.routes.astype(np.int64), got_rp, mapped)
-        for j in differ[:20].tolist() + rnd.sample(range(len(cand)), min(20, len(cand))):  # the semantic oracle on quirk rows + a sub-sample
-            i = int(cand[j])
-            assert mapped[got_rp[j]:got_rp[j + 1]].tolist() == kv.match_bruteforce(tn[int(tt[i])], [traw[off[i]:off[i + 1]]]).per_topic()[0]
-        new_ranks = {rank[k] for k, t in added.items() if t < S}
-        assert np.isin(mapped, np.fromiter(new_ranks, dtype=np.int64)).any()  # routes subscribed by the batch are matched
+
+        differ = assert_csr_equal_modulo_quirk_ii(all_keys, kv.key, tn[:S], stt, res.row_ptr.astype(np.int64), res.routes.astype(np.int64), got_rp, mapped)
+        # the semantic oracle on EVERY row that differs from the restatement + a sub-sample of the others, counted in the parity report
+        assert_differing_rows_semantic("c5: %d tenants x %d routes after one batch of %d mutations, %d publishes (every publish of the first %d tenants)"
+                                       % (n_tenants, per_tenant, n_ops, n_topics, S), kv, tn[:S], stt, (t_data, t_off), differ, got_rp, mapped,
+                                       livelocks=res.livelocks, extra_rows=rnd.sample(range(len(cand)), min(200, len(cand))))
+        assert np.isin(mapped, add_rank).any()  # routes subscribed by the batch are matched
         return n_new
+    keys_s = [key_at(i) for i in range(hi_old) if i not in deleted] + [k for k, t in added.items() if t < S]
+    kv = O.KV(keys_s)  # sorts
+    keys_sorted = sorted(keys_s)
     sample = sorted(rnd.sample(cand.tolist(), min(n_sample, len(cand))))
     traw = data.tobytes()
     topics = [traw[off[i]:off[i + 1]] for i in sample]
