@@ -167,6 +167,10 @@ struct bmq_engine {
     uint64_t rgeneration = 0; // +1 per retain rebuild / compact: topic ids of different generations are unrelated
     RetainLimit rlim;
     DevBuf r_scratch, r_deep_list, r_deep_levels, r_arena;
+    DevBuf r_ov_off, r_ov_cnt, r_ov_route, r_ov_pairs; // k_retain_overlay's range list
+    uint64_t ov_pair_cap = 0;
+    hipStream_t s_side = nullptr;                      // ... runs beside k_retain_walk
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool rdeep_on = false;   // k_retain_walk_deep is in the pipeline (batches hold filters of more than R_MAXL levels)
     uint32_t rdeep_idle = 0;
     DevBuf range_buf; // staging of bmq_range_lookup
@@ -677,6 +681,9 @@ void bmq_engine_destroy(bmq_engine* e) {
         bmq_comm_destroy(e);
         if (e->ev_ex) (void)hipEventDestroy(e->ev_ex);
         if (e->s_ex) (void)hipStreamDestroy(e->s_ex);
+        if (e->s_side) (void)hipStreamDestroy(e->s_side);
+        if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+        if (e->ev_join) (void)hipEventDestroy(e->ev_join);
         e->dfo.reset();
         e->drt.reset();
         e->dix.reset(); // frees the HBM arrays while the stream still exists

@@ -11,6 +11,8 @@ namespace bmq {
 
 constexpr uint32_t RT_PLUS = 0xFFFFFFFDu, RT_HASH = 0xFFFFFFFCu; // level kinds next to dictionary tokens
 constexpr uint32_t ST_RETAIN_DEEP = 128u, ST_RETAIN_FRONT = 256u;
+constexpr uint32_t RW_LV = 16;            // levels of a filter k_retain_walk handles (MQTT ingress rejects more: Setting.MaxTopicLevels); deeper: k_retain_walk_deep
+constexpr uint32_t ST_RETAIN_LIST = 512u; // k_retain_walk: a frontier list outgrew the wave's arena (the batch is re-run with a larger one)
 
 struct RetainArgs {
     RetainIndexView ix;
@@ -31,6 +33,16 @@ struct RetainArgs {
     // k_retain_walk (bmq_rwalk_kernel.h): per persistent wave and slot two frontier lists of rw_cap entries (what does not fit the LDS part)
     uint32_t* rw_arena;
     uint32_t rw_cap;
+};
+
+// Topics added since the bulk load (the overlay trie) are matched by a kernel of their own, next to k_retain_walk, into a range list of
+// their own (ids above every bulk-loaded id: a row is its bulk-loaded ids, then these): what the kernels behind the walks read beside
+// BatchArgs' list.  All null: no such list.
+struct RetainOvList {
+    const uint32_t* pair_off;
+    const uint32_t* pair_cnt;
+    const uint32_t* route_cnt;
+    const MatchRange* pairs;
 };
 
 } // namespace bmq

@@ -76,7 +76,9 @@ __device__ __forceinline__ RNode load_rnode(const RetainIndexView& ix, uint32_t 
 
 // DEEP = false: every filter of the batch, the per-level arrays in LDS (filters deeper than R_MAXL are listed and left empty);
 // DEEP = true: the listed filters, the per-level arrays in global memory (launched only while batches hold such filters).
-template <bool DEEP>
+// OVONLY: the overlay trie alone (the bulk-loaded index is walked by k_retain_walk at the same time, on another stream): the filters that
+// kernel answers, i.e. those of at most RW_LV levels; `a` carries the overlay's own range list
+template <bool DEEP, bool OVONLY = false>
 __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const BatchArgs& a) {
     __shared__ uint32_t s_lev_start[R_MAXL + 1], s_lev_end[R_MAXL + 1], s_ftok[R_MAXL + 1];
     __shared__ uint32_t fb0[R_FRONT], fc0[R_FRONT], fb1[R_FRONT], fc1[R_FRONT];
@@ -120,7 +122,7 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
             nsep += (uint32_t)__popcll(m);
         }
         const uint32_t nlev = nsep + 1;
-        if (nlev > maxl) deep = true;
+        if (nlev > maxl || (OVONLY && nlev > RW_LV)) deep = true;
         if (lane == 0 && !deep) lev_end[nlev - 1] = end;
         if (DEEP) __threadfence_block(); // (the arrays live in global memory: other lanes read what this lane wrote)
         __syncthreads();
@@ -196,13 +198,13 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
         }
         if (DEEP) __threadfence_block(); // (the level arrays in global memory: written by one lane each, read by all below)
         __syncthreads();
-        const uint32_t root = deep ? NONE : sh[0];
+        const uint32_t root = (deep || OVONLY) ? NONE : sh[0];
         const uint32_t tnode = (deep || !dyn.ov_live) ? NONE : sh[9];
         ten.node_base = sh[1]; ten.edge_base = sh[2]; ten.edge_bucket_mask = sh[3]; ten.id_base = root != NONE ? sh[4] : 0u;
         ten.sys_node_lo = sh[5]; ten.sys_node_hi = sh[6]; ten.sys_id_lo = sh[7]; ten.sys_id_hi = sh[8];
         if (deep && lane == 0) {
             if (DEEP) atomicOr(&a.ctr->status, ST_RETAIN_DEEP); // (deeper than a 64 KB filter can be: cannot happen)
-            else r.deep_list[atomicAdd(&a.ctr->slow_count, 1u)] = f; // left empty here; the deep pass answers it
+            else if (!OVONLY) r.deep_list[atomicAdd(&a.ctr->slow_count, 1u)] = f; // left empty here; the deep pass answers it
         }
 
         // ---- two passes: count, then write -------------------------------------------------------------------------------------
@@ -495,7 +497,7 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
                 if (lane == 0 && wp) fits_l = pair_alloc(a.subs, a.pair_cap, f, wp, base) ? 1u : 0u;
                 base = __shfl(base, 0);
                 if (!__shfl(fits_l, 0)) {
-                    if (lane == 0) atomicOr(&a.ctr->status, ST_NEED_PAIRS);
+                    if (lane == 0) atomicOr(&a.ctr->status, OVONLY ? (uint32_t)ST_NEED_SPILL : (uint32_t)ST_NEED_PAIRS); // (the overlay's list: the host grows that one)
                     break;
                 }
                 if (wp == 0) break;
@@ -512,7 +514,7 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
             // (the per-block sums k_expand wants are added up by k_retain_sums)
         }
         wranges += np_total;
-        if (DEEP || !deep) wbytes += end - beg; // (a deep filter is counted by the pass that answers it)
+        if (!OVONLY && (DEEP || !deep)) wbytes += end - beg; // (a deep filter is counted by the pass that answers it)
         __syncthreads();
     }
     const unsigned long long wv = wave_sum_u64(visits);
@@ -527,6 +529,7 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
 // kernel, of every filter once topics were added since the bulk load (v1: the round-2..4 kernel)
 __global__ __launch_bounds__(64) void k_retain_walk_v1(RetainArgs r, BatchArgs a) { retain_walk_body<false>(r, a); }
 __global__ __launch_bounds__(64) void k_retain_walk_deep(RetainArgs r, BatchArgs a) { retain_walk_body<true>(r, a); }
+__global__ __launch_bounds__(64) void k_retain_overlay(RetainArgs r, BatchArgs a) { retain_walk_body<false, true>(r, a); }
 
 } // namespace bmq
 #include "bmq_rwalk_kernel.h"
@@ -540,9 +543,10 @@ template <int G, bool DYN> __global__ __launch_bounds__(64, BMQ_RW_MIN_WAVES) vo
 // k_retain_sums: ids per 64-row block (wave_sums) and per 2^SUPER_SHIFT blocks (super_sums) from the rows' id counts, behind the walk
 // kernels and in front of k_expand / k_retain_rowptr_dyn.  (Rounds 2-4: two atomics per filter inside the walk -- 100 k filters on the
 // seven super-block words are 14 k serialised atomics per word, ~0.2 ms of L2 atomic-unit time that a faster walk would wait for.)
-__global__ __launch_bounds__(64) void k_retain_sums(BatchArgs a) {
+__global__ __launch_bounds__(64) void k_retain_sums(BatchArgs a, RetainOvList ov) {
     const uint32_t blk = blockIdx.x, t = (blk << a.tpw_shift) + threadIdx.x;
-    const unsigned long long v = (threadIdx.x < (1u << a.tpw_shift) && t < a.n_topics) ? a.route_cnt[t] : 0u;
+    const bool in = threadIdx.x < (1u << a.tpw_shift) && t < a.n_topics;
+    const unsigned long long v = in ? (unsigned long long)a.route_cnt[t] + (ov.route_cnt ? ov.route_cnt[t] : 0u) : 0ull;
     const unsigned long long s = wave_sum_u64(v);
     if (threadIdx.x == 0) {
         a.wave_sums[blk] = s;
@@ -562,7 +566,7 @@ constexpr uint32_t LIM_FAST = 64; // per-filter limits up to this go through k_l
 __global__ __launch_bounds__(64) void k_limit_select(BatchArgs a, const uint32_t* limit, const unsigned long long* expire_at,
                                                      unsigned long long now, uint32_t n, uint32_t* tmp_ids, uint32_t* kept, uint32_t* counts) {
     const uint32_t lane = threadIdx.x;
-    const bool blocked = (a.ctr->status & (ST_NEED_PAIRS | ST_RETAIN_FRONT | ST_RETAIN_DEEP)) != 0; // the walk is re-run anyway
+    const bool blocked = (a.ctr->status & (ST_NEED_PAIRS | ST_RETAIN_FRONT | ST_RETAIN_LIST | ST_RETAIN_DEEP)) != 0; // the walk is re-run anyway
     for (uint32_t f = blockIdx.x; f < n; f += gridDim.x) {
         const uint32_t po = a.pair_off[f], np = blocked ? 0u : a.pair_cnt[f];
         const uint32_t lim = min(limit[f], LIM_FAST);
@@ -663,12 +667,12 @@ __global__ __launch_bounds__(256) void k_limit_copy_live(const uint32_t* row_ptr
 // bitmap word per 64 ids, writes whole lines.  (A first version let one wave work through its 64 rows one after the other: 5.1 ms for
 // the C4 batch against 0.7 ms of k_expand -- rows of 5 000 ids want a wave each.)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_retain_rowptr_dyn(BatchArgs a) {
+__global__ __launch_bounds__(64) void k_retain_rowptr_dyn(BatchArgs a, RetainOvList ov) {
     const uint32_t lane = threadIdx.x, blk = blockIdx.x;
     if (blk >= a.n_blocks) return;
     const uint32_t t = (blk << a.tpw_shift) + lane;
     const bool valid = t < a.n_topics;
-    const uint32_t nr = valid ? a.route_cnt[t] : 0u;
+    const uint32_t nr = valid ? a.route_cnt[t] + (ov.route_cnt ? ov.route_cnt[t] : 0u) : 0u;
     uint32_t wtotal;
     const uint32_t excl = wave_excl_scan(nr, lane, wtotal);
     unsigned long long wbase;
@@ -693,75 +697,98 @@ __global__ __launch_bounds__(64) void k_retain_rowptr_dyn(BatchArgs a) {
 }
 constexpr uint32_t RXD_WAVES = 4;  // rows per workgroup of k_retain_expand_dyn (independent waves)
 constexpr uint32_t RXD_SHORT = 16; // ranges up to this length are written by ONE lane each (64 ranges per step), longer ones streamed by the wave
-// One wave per row, 64 ranges per step: every lane takes a range and learns its LIVE length from the rank directory of the DEAD bitmap
-// (two words + two popcounts), a wave scan turns the lengths into output offsets; short ranges -- a filter like a/+/c matches thousands
-// of single topics -- are written by their lanes, long ones (a '#' subtree) are streamed by the whole wave, 64 ids per step, through the
-// bitmap only if the range contains a dead id at all.  (First version: one range after the other, 64 ids per step whatever the range
-// length: 1.69 ms on the churned C4 index against 0.70 ms for the plain expansion.)
-__global__ __launch_bounds__(RXD_WAVES * 64) void k_retain_expand_dyn(BatchArgs a, const unsigned long long* dead_bits, const uint32_t* dead_rank,
-                                                                      uint32_t base_n) {
+// One wave per row, 64 ranges per step: every lane takes a range and learns its LIVE length -- a single id from its bit, a longer range
+// from the rank directory of the DEAD bitmap (two words + two popcounts) --, a wave scan turns the lengths into output offsets; short
+// ranges -- a filter like a/+/c matches thousands of single topics -- are written by their lanes (the one or two bitmap words they span
+// are read once), long ones (a '#' subtree) are streamed by the whole wave one 64-id WORD of the bitmap at a time: the word's address is
+// wave-uniform (scalar loads, four words per request), its live bits are the lanes that store -- a dozen instructions per 64 ids.
+// (Round 3: 64 ids per step through per-lane bitmap tests whatever the alignment, 1.4 ms for the churned C4 batch against 0.6 ms for the
+// plain expansion; first version, one range after the other: 1.69 ms.)
+__global__ __launch_bounds__(RXD_WAVES * 64) void k_retain_expand_dyn(BatchArgs a, RetainOvList ov, const unsigned long long* dead_bits,
+                                                                      const uint32_t* dead_rank, uint32_t base_n) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = blockIdx.x * RXD_WAVES + (threadIdx.x >> 6);
     if (t >= a.n_topics) return;
     // (the status word is complete: k_retain_rowptr_dyn ran in front)
-    if (a.ctr->status & (ST_NEED_PAIRS | ST_RETAIN_FRONT | ST_RETAIN_DEEP | ST_RANGE | ST_NOSPACE)) return;
-    const uint32_t np = a.pair_cnt[t], nr = a.route_cnt[t];
-    if (np == 0 || nr == 0) return;
-    const uint32_t po = a.pair_off[t];
+    if (a.ctr->status & (ST_NEED_PAIRS | ST_NEED_SPILL | ST_RETAIN_FRONT | ST_RETAIN_DEEP | ST_RETAIN_LIST | ST_RANGE | ST_NOSPACE)) return;
+    const uint32_t np1 = a.pair_cnt[t], np2 = ov.pair_cnt ? ov.pair_cnt[t] : 0u;
+    const uint32_t nr = a.route_cnt[t] + (ov.route_cnt ? ov.route_cnt[t] : 0u);
+    if (np1 + np2 == 0 || nr == 0) return;
     uint32_t* out = a.out_ids + a.out_row_ptr[t];
     uint32_t done = 0, carry_last = 0;
-    bool bad = false;
-    // dead ids among [b, b + c): only bulk-loaded ids (< base_n) can be dead (overlay topics were checked by the walk)
-    auto dead_in = [&](uint32_t b, uint32_t c) -> uint32_t {
-        const uint32_t lo = b < base_n ? b : base_n, hi = b + c < base_n ? b + c : base_n;
-        return hi > lo ? dead_before(dead_bits, dead_rank, hi) - dead_before(dead_bits, dead_rank, lo) : 0u;
-    };
+    bool bad = false, first_range = true;
+    // the row's two range lists one after the other: the bulk-loaded ids, then the overlay's (above every bulk-loaded id)
+    for (uint32_t part = 0; part < 2; part++) {
+    const uint32_t np = part ? np2 : np1;
+    if (np == 0) continue;
+    const MatchRange* const prs = part ? ov.pairs + ov.pair_off[t] : a.pairs + a.pair_off[t];
     for (uint32_t k0 = 0; k0 < np; k0 += 64) {
         const uint32_t k = k0 + lane;
         const bool have = k < np;
-        const MatchRange rg = have ? a.pairs[po + k] : MatchRange{0u, 0u};
+        const MatchRange rg = have ? prs[k] : MatchRange{0u, 0u};
         // ranges out of order (overlay ids flushed unordered): the row is sorted afterwards
         const uint32_t last = rg.begin + rg.count - 1;
         uint32_t prev_last = __shfl_up(last, 1);
         if (lane == 0) prev_last = carry_last;
-        if (have && rg.count && (k != 0) && rg.begin <= prev_last) bad = true;
+        if (have && rg.count && !(first_range && k == 0) && rg.begin <= prev_last) bad = true;
         carry_last = __shfl(last, (int)(min(np - k0, 64u) - 1u));
-        const uint32_t dead = have && rg.count ? dead_in(rg.begin, rg.count) : 0u;
+        // dead ids of the range: only bulk-loaded ids (< base_n) can be dead (overlay topics were checked by the walk); the words a SHORT
+        // range spans are kept for the write below
+        const bool is_long = have && rg.count > RXD_SHORT, is_short = have && rg.count != 0 && !is_long;
+        const uint32_t lo = rg.begin < base_n ? rg.begin : base_n, hi = rg.begin + rg.count < base_n ? rg.begin + rg.count : base_n;
+        uint32_t dead = 0;
+        unsigned long long w0 = 0, w1 = 0;
+        if (is_short && hi > lo) {
+            w0 = dead_bits[lo >> 6];
+            if (((hi - 1) >> 6) != (lo >> 6)) w1 = dead_bits[(lo >> 6) + 1];
+            // bit i of `span`: id lo + i is dead (i < 16)
+            const unsigned long long span = (w0 >> (lo & 63u)) | ((lo & 63u) ? (w1 << (64u - (lo & 63u))) : 0ull);
+            w0 = span & ((1ull << (hi - lo)) - 1ull);
+            dead = (uint32_t)__popcll(w0);
+        } else if (is_long && hi > lo) dead = dead_before(dead_bits, dead_rank, hi) - dead_before(dead_bits, dead_rank, lo);
         const uint32_t live_n = rg.count - dead;
         uint32_t tot;
         const uint32_t excl = wave_excl_scan(have ? live_n : 0u, lane, tot);
-        const bool is_long = have && rg.count > RXD_SHORT;
-        if (have && !is_long && live_n) {
+        if (is_short && live_n) {
             uint32_t p = done + excl;
-            for (uint32_t o = 0; o < rg.count; o++) {
-                const uint32_t id = rg.begin + o;
-                if (dead == 0 || !(id < base_n && id_dead(dead_bits, id))) out[p++] = id;
-            }
+            for (uint32_t o = 0; o < rg.count; o++)
+                if (!((w0 >> o) & 1ull)) out[p++] = rg.begin + o; // (ids from base_n on have no bit: w0 covers [lo, hi) only, o beyond it is live)
         }
         for (unsigned long long m_long = __ballot(is_long); m_long; m_long &= m_long - 1ull) {
             const int l = __ffsll((long long)m_long) - 1;
-            const uint32_t b = __shfl(rg.begin, l), c = __shfl(rg.count, l), d = __shfl(dead, l);
-            uint32_t at = done + __shfl(excl, l);
+            const uint32_t b = sgpr(__shfl(rg.begin, l)), c = sgpr(__shfl(rg.count, l)), d = sgpr(__shfl(dead, l));
+            uint32_t at = sgpr(done + __shfl(excl, l));
             if (d == 0) { // clean: nothing to look up
                 for (uint32_t o = lane; o < c; o += 64) out[at + o] = b + o;
                 continue;
             }
-            for (uint32_t o = 0; o < c; o += 256) { // four 64-id steps per trip: their bitmap words are requested together
-                bool live[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t q = o + 64 * j + lane, id = b + q;
-                    live[j] = q < c && !(id < base_n && id_dead(dead_bits, id));
+            // word by word: [b, e) meets the bitmap words wb .. we; ids from base_n on are live
+            const uint32_t e = b + c, eb = e < base_n ? e : base_n;
+            uint32_t id0 = b;
+            if (b < eb) {
+                const uint32_t wb = b >> 6, we = (eb - 1) >> 6;
+                // the live lanes of one bitmap word store: `keep` = the word's ids inside the range that are not dead
+                auto put_word = [&](uint32_t w, unsigned long long keep) {
+                    if ((keep >> lane) & 1ull) out[at + rank_below(keep)] = (w << 6) + lane;
+                    at += (uint32_t)__popcll(keep);
+                };
+                unsigned long long edge = ~0ull << (b & 63u); // the first word: from b on (and, if it is the last one too, up to eb)
+                if (wb == we && (eb & 63u)) edge &= ~0ull >> (64u - (eb & 63u));
+                put_word(wb, ~dead_bits[wb] & edge);
+                uint32_t w = wb + 1;
+                for (; w + 4 <= we; w += 4) { // whole words, four per request (a word's address is wave-uniform: scalar loads)
+                    const unsigned long long d0 = dead_bits[w], d1 = dead_bits[w + 1], d2 = dead_bits[w + 2], d3 = dead_bits[w + 3];
+                    put_word(w, ~d0), put_word(w + 1, ~d1), put_word(w + 2, ~d2), put_word(w + 3, ~d3);
                 }
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const unsigned long long m = __ballot(live[j]);
-                    if (live[j]) out[at + rank_below(m)] = b + o + 64 * j + lane;
-                    at += (uint32_t)__popcll(m);
-                }
+                for (; w < we; w++) put_word(w, ~dead_bits[w]);
+                if (we > wb) put_word(we, ~dead_bits[we] & ((eb & 63u) ? ~0ull >> (64u - (eb & 63u)) : ~0ull)); // the last word: up to eb
+                id0 = eb;
             }
+            for (uint32_t o = id0 + lane; o < e; o += 64) out[at + (o - id0)] = o; // (the part of the range above the bulk-loaded ids)
         }
         done += tot;
+    }
+    first_range = false;
     }
     if (__any(bad) && nr > 1 && lane == 0) {
         const uint32_t sp = atomicAdd(&a.ctr->sort_count, 1u);

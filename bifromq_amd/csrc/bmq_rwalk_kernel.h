@@ -32,7 +32,6 @@
 
 namespace bmq {
 
-constexpr uint32_t RW_LV = 16; // levels of a filter walked here
 #ifndef BMQ_RW_INL
 #define BMQ_RW_INL 16
 #endif
@@ -54,7 +53,6 @@ constexpr uint32_t RT_GP = 0xFFFFFFFAu;     // a literal level over ALL children
 constexpr uint32_t RT_PCOPY = 0xFFFFFFF9u;  // ... the postings slice it found becomes the next list
 constexpr uint32_t RT_PEMIT = 0xFFFFFFF8u;  // ... or, behind the filter's last level, the matched topics
 constexpr uint32_t RT_LIT_MAX = 0xFFFFFFF0u; // level kinds from here on are not dictionary tokens
-constexpr uint32_t ST_RETAIN_LIST = 512u;   // a frontier list outgrew the wave's arena (the batch is re-run with a larger one)
 // slot flags
 constexpr uint32_t RF_RANGE = 1u;   // the frontier is a node range (else: a list)
 constexpr uint32_t RF_PAR = 2u;     // which of the slot's two lists is the CURRENT one
