@@ -96,6 +96,12 @@ struct BuildCounters {
     unsigned long long rp_garbage; // words of abandoned id lists
     uint32_t n_tokens;             // dictionary tokens handed out (next = TOK_FIRST + n_tokens)
     uint32_t dpool_used;           // bytes used in the dictionary string pool
+    // bmq_routes_apply's stages run back to back with ONE read-back at the end: the first stage that finds something the host has to
+    // deal with (an error, an unknown tenant, a region / the dictionary / the id-list pool to grow) closes the gate -- gate = its number:
+    // 1 prepare, 2 locate, 3 group --, the stages behind it return at once and the host takes over from that stage (they are idempotent).
+    // Not part of the per-batch block below: it has to survive the zeroing between the stages.
+    uint32_t gate;
+    uint32_t pad_gate;
     // per batch (zeroed by the host before prepare)
     uint32_t err;
     uint32_t n_unknown;            // ops whose tenant is not in the directory (listed in unknown_list)

@@ -188,8 +188,40 @@ public:
             !x.copy_in_async(s_op, op, n) || !x.copy_in_async(s_put_rank, put_rank.data(), sizeof(uint32_t) * (size_t)n))
             return xfail();
         pt.lap("apply: upload ops");
+        auto count_groups = [&]() { // what the group step of this round did (the counters are zeroed in front of every round)
+            uint64_t a = 0, r = 0, du = 0;
+            for (uint32_t c = 0; c < N_CTR_LANES; c++) a += hbc.n_added[c], r += hbc.n_removed[c], du += hbc.n_dups[c];
+            n_routes += a;
+            n_routes -= r;
+            if (res) {
+                res->added += (uint32_t)a;
+                res->removed += (uint32_t)r;
+                res->dups += (uint32_t)du;
+            }
+        };
+        // ---- the stages back to back, ONE read-back (round 5; rounds 1-4: a read-back behind each of the three stages).  A stage that
+        // leaves work for the host closes the gate (BuildCounters.gate): the stages behind it do nothing and the loops below -- the
+        // stage-by-stage form, idempotent -- take over from that stage.  The common batch needs nothing from the host.
+        uint32_t from = 1; // the stage the stage-by-stage form starts at; 4: nothing left to do
+        bool groups_pending = false;
+        if (Exec::gated) {
+            DistIndexMut ix = mut();
+            if (!x.zero(&bc->gate, sizeof(uint32_t)) || !zero_batch_counters() || !x.prepare(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !x.gate(bc, 1) ||
+                !zero_batch_counters() || !x.locate(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !x.gate(bc, 2) || !x.zero(ob.group_done, n) ||
+                !x.sort_targets(ob) || !zero_batch_counters() || !x.group(ix, ob) || !x.gate(bc, 3) || !read_counters())
+                return xfail();
+            pt.lap("apply: prepare, locate, sort, groups (one read-back)");
+            from = hbc.gate ? hbc.gate : 4;
+            if (from >= 3) { // the group step ran (to the end, or up to the groups that found the id-list pool full)
+                if (hbc.err) return broke("apply: group step failed");
+                count_groups();
+                groups_pending = hbc.n_deferred != 0;
+                if (groups_pending && !grow_route_pos(hbc.rp_used + 2 * hbc.rp_need + 1024)) return false;
+            }
+            if (hbc.gate && !x.zero(&bc->gate, sizeof(uint32_t))) return xfail();
+        }
         // ---- prepare: validate + tenants + growth bounds (re-run once if tenants had to be created) ----
-        for (int round = 0;; round++) {
+        for (int round = 0; from <= 1; round++) {
             if (!zero_batch_counters()) return false;
             DistIndexMut ix = mut();
             if (!x.prepare(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !read_counters()) return xfail();
@@ -211,11 +243,13 @@ public:
             if (!flush_directory()) return false;
             ob.grow_list = s_grow; // the directory may have grown, and its scratch with it
         }
-        pt.lap("apply: prepare (+ tenants)");
-        if (!grow_flagged_regions(ob)) return false;
-        pt.lap("apply: region growth");
+        if (from <= 1) {
+            pt.lap("apply: prepare (+ tenants)");
+            if (!grow_flagged_regions(ob)) return false;
+            pt.lap("apply: region growth");
+        }
         // ---- locate (idempotent: re-run after growing what it ran out of) ----
-        for (int attempt = 0;; attempt++) {
+        for (int attempt = 0; from <= 2; attempt++) {
             if (attempt == 8) return broke("apply: growth did not converge");
             if (!zero_batch_counters()) return false;
             DistIndexMut ix = mut();
@@ -225,27 +259,19 @@ public:
             if ((hbc.err & ERR_DICT_FULL) && !grow_dict(std::max<uint64_t>((uint64_t)dict_slots * 4, 4096), (uint64_t)dpool_cap * 2 + kb)) return false;
             if (!grow_flagged_regions(ob)) return false;
         }
-        pt.lap("apply: locate");
         // ---- sort by filter node, apply the groups ----
-        if (!x.zero(ob.group_done, n) || !x.sort_targets(ob)) return xfail();
-        pt.lap("apply: sort by filter node");
-        for (int attempt = 0;; attempt++) {
+        if (from <= 2) {
+            pt.lap("apply: locate");
+            if (!x.zero(ob.group_done, n) || !x.sort_targets(ob)) return xfail();
+            pt.lap("apply: sort by filter node");
+        }
+        for (int attempt = 0; from <= 2 || groups_pending; attempt++) {
             if (attempt == 8) return broke("apply: id-list pool growth did not converge");
             if (!zero_batch_counters()) return false;
             DistIndexMut ix = mut();
             if (!x.group(ix, ob) || !read_counters()) return xfail();
             if (hbc.err) return broke("apply: group step failed");
-            {
-                uint64_t a = 0, r = 0, du = 0;
-                for (uint32_t c = 0; c < N_CTR_LANES; c++) a += hbc.n_added[c], r += hbc.n_removed[c], du += hbc.n_dups[c];
-                n_routes += a;
-                n_routes -= r;
-                if (res) {
-                    res->added += (uint32_t)a;
-                    res->removed += (uint32_t)r;
-                    res->dups += (uint32_t)du;
-                }
-            }
+            count_groups();
             if (hbc.n_deferred == 0) break;
             if (!grow_route_pos(hbc.rp_used + 2 * hbc.rp_need + 1024)) return false;
         }

@@ -37,8 +37,14 @@ __global__ __launch_bounds__(BK) void k_b_prepare(DistIndexMut ix, OpBatch ob) {
     if (i < ob.n) prepare_one(ix, ob, i);
 }
 __global__ __launch_bounds__(BK) void k_b_prepare_check(DistIndexMut ix, OpBatch ob, uint32_t n_dir) {
+    if (ix.bc->gate) return; // (an earlier stage of the batch handed over to the host: BuildCounters.gate)
     const uint32_t d = blockIdx.x * BK + threadIdx.x;
     if (d < n_dir) prepare_check_one(ix, ob, d);
+}
+// closes the gate behind a stage that left work for the host
+__global__ void k_b_gate(BuildCounters* bc, uint32_t stage) {
+    if (threadIdx.x || blockIdx.x || bc->gate) return;
+    if (bc->err || bc->n_unknown || bc->n_grow || bc->n_deferred) bc->gate = stage;
 }
 __global__ __launch_bounds__(BK) void k_b_bulk_prepare(DistIndexMut ix, OpBatch ob) {
     const uint32_t i = blockIdx.x * BK + threadIdx.x;
@@ -53,10 +59,12 @@ __global__ __launch_bounds__(BK) void k_b_bulk_counts(OpBatch ob, uint32_t n_ten
     if (t < n_ten) bulk_counts_one(ob, t, n_ten, nn_incl);
 }
 __global__ __launch_bounds__(BK) void k_b_locate(DistIndexMut ix, OpBatch ob) {
+    if (ix.bc->gate) return;
     const uint32_t i = blockIdx.x * BK + threadIdx.x;
     if (i < ob.n) locate_one(ix, ob, i);
 }
 __global__ __launch_bounds__(BK) void k_b_group(DistIndexMut ix, OpBatch ob) {
+    if (ix.bc->gate) return;
     const uint32_t p = blockIdx.x * BK + threadIdx.x;
     if (p < ob.n) group_one(ix, ob, p);
 }
@@ -203,6 +211,11 @@ struct DevExec {
     }
     bool prepare(const DistIndexMut& ix, const OpBatch& ob) {
         hipLaunchKernelGGL(k_b_prepare, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob);
+        return launched();
+    }
+    static constexpr bool gated = true; // the stages of an apply batch can run back to back behind BuildCounters.gate
+    bool gate(BuildCounters* bc, uint32_t stage) {
+        hipLaunchKernelGGL(k_b_gate, dim3(1), dim3(1), 0, stream, bc, stage);
         return launched();
     }
     bool prepare_check(const DistIndexMut& ix, const OpBatch& ob, uint32_t n_dir) {

@@ -69,6 +69,8 @@ struct HostExec {
         par(ob.n, [&](size_t i) { prepare_one(ix, ob, (uint32_t)i); });
         return true;
     }
+    static constexpr bool gated = false; // (host threads: every stage is followed by its read of the counters, there is nothing to save)
+    bool gate(BuildCounters*, uint32_t) { return true; }
     bool prepare_check(const DistIndexMut& ix, const OpBatch& ob, uint32_t n_dir) {
         par(n_dir, [&](size_t d) { prepare_check_one(ix, ob, (uint32_t)d); });
         return true;
