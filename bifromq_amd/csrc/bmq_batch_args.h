@@ -93,9 +93,16 @@ struct BatchArgs {
     unsigned long long* dd_table;   // open addressing, dd_mask + 1 entries: generation << 56 | hash tag << 32 | row
     uint32_t dd_mask;
     uint32_t dd_gen;                // 1..255
-    uint32_t debug_flags; // BMQ_DEBUG env (profiling experiments only): 1 = stop after tokenising, 2 = fill dbg_wave
+    uint32_t debug_flags; // BMQ_DEBUG env, read by builds with -DBMQ_EXPERIMENTS=1 only (tools/build_variant.sh): 1 = stop after tokenising, 2 = fill dbg_wave
     uint4* dbg_wave;      // [n_blocks] {phase 1, phase 2, phase 3 shader clocks, rounds | items << 8} of every k_walk wave, or null
 };
+
+// The profiling experiments of the kernels (BatchArgs.debug_flags: per-wave clocks, the residency census, alternative block orders, ...) are
+// compiled in by -DBMQ_EXPERIMENTS=1 only: the library that ships is the kernel that is measured, without their branches.
+#ifndef BMQ_EXPERIMENTS
+#define BMQ_EXPERIMENTS 0
+#endif
+#define BMQ_DBG(a, bits) (BMQ_EXPERIMENTS != 0 && ((a).debug_flags & (bits)) != 0)
 
 #if defined(__HIPCC__) || defined(BMQ_WAVE_EMU)
 // n contiguous entries of `pairs` from sub-allocator `key` (false: the slice is full, the batch is re-run with a larger buffer)

@@ -331,7 +331,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     a.ctr = S.b_ctr.as<Counters>();
     {
         const char* dbg = getenv("BMQ_DEBUG");
-        a.debug_flags = dbg ? (uint32_t)atoi(dbg) : 0u;
+        a.debug_flags = (BMQ_EXPERIMENTS && dbg) ? (uint32_t)atoi(dbg) : 0u; // (the kernels' experiments exist in -DBMQ_EXPERIMENTS=1 builds only)
         a.dbg_wave = nullptr;
         if (a.debug_flags & 30u) {
             HIPCHK(e, S.b_dbg_wave.ensure(sizeof(uint4) * 2 * std::max(a.n_blocks, 1u)));
@@ -380,7 +380,9 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         if (e->mixed_on) hipLaunchKernelGGL((k_walk<TC, QC, PC, true>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((k_walk<TC, QC, PC, false>), grid, block, 0, s, a);            \
     } while (0)
+#if BMQ_EXPERIMENTS
         if (a.debug_flags & 16u) hipLaunchKernelGGL(k_occ_probe, grid, block, 0, s, a); // (experiments: its census replaces k_walk's)
+#endif
         if (g == 2) BMQ_WALK_LAUNCH(192, 128, 128); // smallest lists: every overflow path runs all the time (tests)
         else BMQ_WALK_LAUNCH(512, 176, 152);
 #undef BMQ_WALK_LAUNCH

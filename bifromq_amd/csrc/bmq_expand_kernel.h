@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) {
     const bool valid = lane < (1u << a.tpw_shift) && t < a.n_topics;
     // per-wave phase clocks (BMQ_DEBUG=4) only in builds with -DBMQ_EXP_CLOCKS=1: five time stamps held across the pass loop cost the
     // scalar registers that keep the loop free of spills
-    const bool dbg_x = BMQ_EXP_CLOCKS && a.dbg_wave && (a.debug_flags & 4u);
+    const bool dbg_x = BMQ_EXP_CLOCKS && BMQ_DBG(a, 4u) && a.dbg_wave;
     const unsigned long long xc0 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long xc_load = 0, xc_scan = 0, xc_gen = 0;
     // everything the head needs is requested before anything is waited for: no load below depends on another one, none sits in a branch
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) {
     const unsigned long long m_np = ballot64(np != 0);
     const uint32_t first_l = m_np ? first_bit(m_np) : 0u;
     const uint32_t po0 = read_lane(po, first_l) - read_lane(pexcl, first_l);
-    const bool contiguous = ballot64(np != 0 && po != po0 + pexcl) == 0ull && !(a.debug_flags & 64u); // (BMQ_DEBUG=64: experiment, always gather)
+    const bool contiguous = ballot64(np != 0 && po != po0 + pexcl) == 0ull && !BMQ_DBG(a, 64u); // (BMQ_DEBUG=64: experiment, always gather)
     l_po[lane] = po;
     l_px[lane] = pexcl;
     if (lane == 63) l_px[64] = ptotal;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
 
     const uint32_t lane = threadIdx.x;
     uint32_t blk;
-    if (a.debug_flags & 32u) { // (experiment) every XCD -- workgroup b runs on XCD b % 8 -- takes ONE contiguous eighth of the batch: a tenant's region is cached by one L2, not by eight
+    if (BMQ_DBG(a, 32u)) { // (experiment) every XCD -- workgroup b runs on XCD b % 8 -- takes ONE contiguous eighth of the batch: a tenant's region is cached by one L2, not by eight
         const uint32_t per = (a.n_blocks + 7u) >> 3;
         blk = (blockIdx.x & 7u) * per + (per - 1u - (blockIdx.x >> 3));
         if ((blockIdx.x >> 3) >= per || blk >= a.n_blocks) return;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
         if (blockIdx.x >= a.n_blocks) return;
         // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
         // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
-        blk = (a.debug_flags & 256u) ? blockIdx.x : a.n_blocks - 1 - blockIdx.x; // (256: experiment, first blocks first)
+        blk = BMQ_DBG(a, 256u) ? blockIdx.x : a.n_blocks - 1 - blockIdx.x; // (256: experiment, first blocks first)
     }
     // A wave owns TPW = 2^tpw_shift consecutive topics.  64 for large batches; a small batch is spread over more waves (16 or 4
     // topics each): the walk phase is a chain of dependent line fetches whose length is ~ max(depth, items / 64), so a wave with
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     const uint32_t tpw = 1u << a.tpw_shift;
     const uint32_t t = (blk << a.tpw_shift) + lane;
     const bool valid = lane < tpw && t < a.n_topics;
-    const bool dbg_w = a.dbg_wave && (a.debug_flags & 2u);
+    const bool dbg_w = BMQ_DBG(a, 2u) && a.dbg_wave;
     const unsigned long long clk0 = dbg_w ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long clk0c = (a.dbg_wave && (a.debug_flags & 8u)) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long clk0c = (BMQ_DBG(a, 8u) && a.dbg_wave) ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- phase 1: tokenise ---------------------------------------------------------------------------------------------
     const uint32_t t_first = blk << a.tpw_shift, t_end = min(t_first + tpw, a.n_topics);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
                 scan_level(p, end, true, word_at, h, inl, len, last);
                 more = !last;
             }
-            const uint32_t tok = now ? ((a.debug_flags & 128u) ? dict_lookup(a.ix, h, len, inl, start, byte_at) : dict_lookup_by_slot(a.ix, h, len, inl, start, byte_at))
+            const uint32_t tok = now ? (BMQ_DBG(a, 128u) ? dict_lookup(a.ix, h, len, inl, start, byte_at) : dict_lookup_by_slot(a.ix, h, len, inl, start, byte_at))
                                      : TOK_UNKNOWN;
             if (now) tokens[tok_base + l] = tok;
         }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     };
     {
     const BatchArgs& b = a;
-    const bool run = !(b.debug_flags & 1u);
+    const bool run = !BMQ_DBG(b, 1u);
     uint2 t_region_early = make_uint2(0u, 1u);
     // MIXED: every topic resolves its own tenant (three dependent requests per lane); the region goes to LDS, the root's payload stays in
     // three registers (a topic of a tenant the index does not know: an empty root, nothing is pushed)
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
             // three more per wave on the super-block's line still cost +20 us per 1 M topics and +7 us per 10 k.)
             d.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
         }
-        if (d.dbg_wave && (d.debug_flags & 8u)) { // residency census: when and where this wave ran (tools: BMQ_DEBUG=8)
+        if (BMQ_DBG(d, 8u) && d.dbg_wave) { // residency census: when and where this wave ran (tools: BMQ_DEBUG=8)
             const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
             const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, all 32 bits
             const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
@@ -500,6 +500,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     }
 }
 
+#if BMQ_EXPERIMENTS
 // Residency probe (BMQ_DEBUG=16, profiling experiments only): a kernel with k_walk's launch shape and resource footprint (one-wave
 // workgroups, 5024 B of LDS, 64 VGPRs, 78 SGPRs, the same argument block) that only waits ~100 k shader ticks and reports where it ran.
 __global__ __launch_bounds__(64, 8) void k_occ_probe(BatchArgs a) {
@@ -517,5 +518,7 @@ __global__ __launch_bounds__(64, 8) void k_occ_probe(BatchArgs a) {
         a.dbg_wave[blockIdx.x] = make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)(t1 - t0) | (acc == 0x1234567u), (hw & 0xFFFFu) | (xcc << 16));
     }
 }
+
+#endif // BMQ_EXPERIMENTS
 
 } // namespace bmq

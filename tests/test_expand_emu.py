@@ -11,9 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("defs,cases", [((), 60), (("-DBMQ_EXP_K=64", "-DBMQ_EXP_LONG=8"), 40),
-                                        # the variant prepared for the next round (tools/next_round/README.md): its header goes in front of the product's
-                                        (("-I", os.path.join(ROOT, "tools", "next_round"), "-DBMQ_EXP_GEN_UNROLL=4"), 40)])
+@pytest.mark.parametrize("defs,cases", [((), 60), (("-DBMQ_EXP_K=64", "-DBMQ_EXP_LONG=8"), 40)])
 def test_k_expand_under_the_wave_emulator(tmp_path, defs, cases):
     exe = str(tmp_path / "expand_emu")
     cmd = ["g++", "-O1", "-std=c++17", *defs, "-I", os.path.join(ROOT, "bifromq_amd", "csrc"), "-I", os.path.join(ROOT, "tools", "emu"),

@@ -8,7 +8,8 @@ from collections import defaultdict
 R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = os.path.join("gpurun_out", R), os.path.join("profiles", R)
 os.makedirs(dst, exist_ok=True)
-for name in ("pytest_gpu.log", "bench_c3.json", "bench_c2.json", "bench_c4.json", "bench_c3.err", "c3_pmc_sq.csv", "parity_report.jsonl"):
+for name in ("pytest_gpu.log", "bench_c3.json", "bench_c2.json", "bench_c4.json", "bench_c3.err", "c3_pmc_sq.csv", "c4_pmc_sq.csv", "parity_report.jsonl",
+             "write_calibration.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))
@@ -16,6 +17,27 @@ for w in ("c3", "c2", "c4"):
     hits = glob.glob(os.path.join(src, "kt_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, w + "_kernel_stats.csv"))
+    # rocprofv3's --stats averages EVERY dispatch of a kernel -- warm-up probes, growth re-runs, launches of other sizes --:
+    # the same trace restricted to the dispatches of the kernel's largest grid, the first of them dropped = the launches the bench line times
+    hits = glob.glob(os.path.join(src, "kt_" + w, "**", "*kernel_trace.csv"), recursive=True)
+    if hits:
+        acc = defaultdict(list)
+        with open(hits[0]) as f:
+            for r in csv.DictReader(f):
+                k = r["Kernel_Name"].split("(")[0]
+                k = k[5:] if k.startswith("void ") else k
+                g = int(r.get("Grid_Size", 0) or 0) or int(r.get("Grid_Size_X", 0) or 0)
+                acc[k.replace(", ", " ")].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        with open(os.path.join(dst, w + "_kernel_trace_timed.csv"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace of the bench command: per kernel the dispatches of its largest grid (= the timed launches), the first dropped\n")
+            f.write("kernel,grid,dispatches,avg_us,min_us,max_us\n")
+            for k in sorted(acc):
+                if not k.startswith("bmq::"):
+                    continue
+                gmax = max(g for g, _ in acc[k])
+                v = [x for g, x in acc[k] if g == gmax]
+                v = v[1:] if len(v) > 1 else v
+                f.write("%s,%d,%d,%.2f,%.2f,%.2f\n" % (k, gmax, len(v), sum(v) / len(v), min(v), max(v)))
 sys.path.insert(0, os.getcwd())
 from bench import kernel_sources_sha  # the same hash bench.py checks before it quotes a traffic file
 
@@ -65,7 +87,17 @@ for w in ("c3", "c2", "c4"):
     fk, wk = per.get(("bmq::" + kernel, "FETCH_SIZE")), per.get(("bmq::" + kernel, "WRITE_SIZE"))
     if fk is None or wk is None:
         continue
-    traffic = fk * 1024 * 0.992 + wk * 1024
+    # WRITE_SIZE is calibrated against stores of known size (tools/ubench_stores.hip): k_expand stores ids 16 bytes at a time on the workloads
+    # it dominates (long ranges), the walk kernels store scattered 8-byte range records
+    wf, wf_kind = 1.0, "uncalibrated"
+    cal = os.path.join(dst, "write_calibration.json")
+    if os.path.exists(cal):
+        cj = json.load(open(cal))
+        kind = "k_store16" if "expand" in kernel else "k_store8s"
+        if kind in cj and cj[kind].get("write_factor"):
+            wf, wf_kind = cj[kind]["write_factor"], kind
+    traffic = fk * 1024 * 0.992 + wk * 1024 * wf
+    traffic_out[w + "_write_factor"] = {"factor": wf, "calibrated_on": wf_kind}
     traffic_out[w] = traffic
     traffic_out[w + "_kernel"] = kernel
     print("%s: %s traffic per launch: %.1f MB" % (w, kernel, traffic / 1e6))
@@ -78,7 +110,8 @@ for w in ("c3", "c2", "c4"):
 if traffic_out:
     traffic_out["kernel_sources_sha"] = kernel_sources_sha()
     traffic_out["_note"] = ("HBM bytes per launch of the workload's dominant kernel = FETCH_SIZE*1024*0.992 (calibrated on random 64-byte line "
-                            "fetches, tools/ubench_lines.hip) + WRITE_SIZE*1024 (uncalibrated); profiles/%s/<workload>_pmc_hbm.csv" % R)
+                            "fetches, tools/ubench_lines.hip) + WRITE_SIZE*1024*write_factor (calibrated on stores of known size, tools/ubench_stores.hip: "
+                            "profiles/%s/write_calibration.json); profiles/%s/<workload>_pmc_hbm.csv" % (R, R))
     with open(os.path.join("profiles", "traffic_%s.json" % R), "w") as f:
         json.dump(traffic_out, f)
 ex = os.path.join(src, "extras")

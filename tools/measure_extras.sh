@@ -9,9 +9,12 @@ done
 python bench.py --ungrouped --no-cpu-baseline --no-host-path > $O/ungrouped.json 2> $O/ungrouped.err
 python bench.py --exchange-selftest --no-cpu-baseline --no-host-path > $O/exchange_selftest.json 2> $O/exchange_selftest.err
 python bench.py --exchange-selftest --exchange-impl lib --no-cpu-baseline --no-host-path > $O/exchange_selftest_lib.json 2> $O/exchange_selftest_lib.err
-# per-wave phase clocks of k_walk (BMQ_DEBUG=2) and k_expand (BMQ_DEBUG=4), C3
+# per-wave phase clocks of k_walk (BMQ_DEBUG=2) and k_expand (BMQ_DEBUG=4), C3: the kernels' experiments exist in -DBMQ_EXPERIMENTS=1 builds
+# only (tools/build_variant.sh exp -DBMQ_EXPERIMENTS=1 -DBMQ_EXP_CLOCKS=1 -> build/variants/libbmq_exp.so, built before the GPU call)
+export BMQ_LIB=$PWD/build/variants/libbmq_exp.so
 (BMQ_DEBUG=2 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-path 2>&1 >/dev/null | grep 'k_walk waves' | tail -1
  BMQ_DEBUG=4 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-path 2>&1 >/dev/null | grep 'k_expand waves' | tail -1) > $O/wave_clocks.txt
+unset BMQ_LIB
 BMQ_TIMING=1 python bench.py --churn 100000 --steps 10 --warmup 2 --no-cpu-baseline --no-host-path > $O/churn100k.json 2> $O/churn100k.err
 grep 'bmq index' $O/churn100k.err | tail -30 > $O/churn100k_phases.txt
 BMQ_TIMING=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path 2>&1 | grep 'rebuild:' > $O/rebuild_phases.txt

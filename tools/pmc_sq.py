@@ -49,7 +49,7 @@ def have(c):
 
 skipped, rows = [], []
 bench = ["python", "bench.py", "--workload", W, "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--batcher-threads", "0",
-         "--no-host-path"] + EXTRA
+         "--no-host-path"] + EXTRA  # (e.g. --no-churn for c4: its add / remove leg launches the same kernels on another index)
 for gi, g in enumerate(GROUPS):
     if ONLY is not None and gi not in ONLY:
         continue

@@ -17,14 +17,18 @@ P="--no-cpu-baseline --no-extras --batcher-threads 0"
 for w in c3 c2 c4; do
   # (--no-host-path: only the timed loop launches the match kernels, so that the trace's AVERAGE is the average of the same launches the
   # bench line times -- the host-visible legs run the kernels next to PCIe copies and other result formats)
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o $w -- python bench.py --workload $w --steps 20 --warmup 5 $P --no-host-path > $O/kt_$w.log 2>&1
+  # (--no-churn: C4's add / remove leg launches the same kernels on another index)
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o $w -- python bench.py --workload $w --steps 20 --warmup 5 $P --no-host-path --no-churn > $O/kt_$w.log 2>&1
 done
 # HBM traffic: separate counter passes, nothing else enabled (MI355X_MICROARCH.md, HBM / rocprofv3 section)
 for w in c3 c2 c4; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 400 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -o $w -- python bench.py --workload $w --steps 4 --warmup 1 $P > $O/pmc_${w}_$c.log 2>&1
+    timeout 400 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -o $w -- python bench.py --workload $w --steps 4 --warmup 1 $P --no-host-path --no-churn > $O/pmc_${w}_$c.log 2>&1
   done
 done
-# SQ / TCC / TCP counters of the C3 kernels (one pass per counter group; tools/pmc_sq.py writes $O/c3_pmc_sq.csv)
+# what WRITE_SIZE reports for stores of known size (tools/ubench_stores.hip) -> $O/write_calibration.json, applied by tools/collect_profiles.py
+timeout 300 python tools/calibrate_writes.py $R > $O/calibrate_writes.log 2>&1; tail -3 $O/calibrate_writes.log
+# SQ / TCC / TCP counters of the C3 and C4 kernels (one pass per counter group; tools/pmc_sq.py writes $O/<workload>_pmc_sq.csv)
 timeout 900 python tools/pmc_sq.py $R c3 > $O/pmc_sq.log 2>&1; tail -2 $O/pmc_sq.log
+timeout 600 python tools/pmc_sq.py $R c4 --groups=0,1,2,4 --no-churn > $O/pmc_sq_c4.log 2>&1; tail -2 $O/pmc_sq_c4.log
 find $O -name "*.csv" | head -60
