@@ -519,14 +519,30 @@ def main():
             torch.cuda.synchronize()
             k = i % NBUF
             return batches[i % len(batches)][3], (d_row[k].cpu().numpy().view(np.uint32), d_ids[k].cpu().numpy().view(np.uint32))
-        out["extra"] = extra_legs(args, eng, w, step, torch, np, fetch_csr if not args.no_cpu_baseline else None)
+        import ctypes as C_
+
+        def submit_dev(i):  # the same batch as a TICKET (bmq_match_submit_dev): the engine is not taken, an apply may be queued behind it
+            bt = batches[i % len(batches)]
+            k = i % NBUF
+            t = C_.c_int()
+            rc = B._lib.lib().bmq_match_submit_dev(eng.h, d_tenants.data_ptr(), d_tenant_off.data_ptr(), n_tenants, bt[2].data_ptr(), bt[0].data_ptr(),
+                                                   bt[1].data_ptr(), n, d_row[k].data_ptr(), d_ids[k].data_ptr(), d_ids[k].numel(), d_total.data_ptr(), C_.byref(t))
+            if rc:
+                raise RuntimeError("bmq_match_submit_dev failed: %d" % rc)
+            return t.value
+
+        def wait_dev(t):
+            rc = B._lib.lib().bmq_match_wait_dev(eng.h, t, None)
+            if rc:
+                raise RuntimeError("bmq_match_wait_dev failed: %d" % rc)
+        out["extra"] = extra_legs(args, eng, w, step, torch, np, fetch_csr if not args.no_cpu_baseline else None, (submit_dev, wait_dev))
     eng.close()  # deterministic teardown of everything this script owns, in order, before the line goes out
     if dist is not None:
         dist.destroy_process_group()
     emit_json(out)
 
 
-def extra_legs(args, eng, w, step, torch, np, fetch_csr=None):
+def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
     """Compact legs the default N = 1 run appends, so that the driver's own command exercises them: configs[4] (100 k route mutations
     before every batch) on THIS index, and configs[1] / configs[3] as child runs of this script (3 steps each)."""
     import subprocess
@@ -550,7 +566,7 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None):
             extra[wl] = {"error": repr(ex)}
     # configs[4] on the C3 index of this run: 5 steps, each = bmq_routes_apply(100 k ops from pinned memory) + the 1 M-publish batch
     try:
-        n_ops, n_steps = 100_000, 5
+        n_ops, n_steps = 100_000, 6
         rng = np.random.default_rng(4321)
         kb_h, ko_h = w.keys_packed()
         mv = memoryview(kb_h)
@@ -580,19 +596,47 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None):
                 raise RuntimeError("bmq_routes_apply failed: %d" % rc)
             return (time.perf_counter() - t0c) * 1e3
 
+        # Two shapes of the same work.  "blocking": bmq_routes_apply, then the batch (rounds 1-4).  "pipelined" (the first n_pipe batches of the
+        # mutation stream): the batch is handed over as a ticket, the NEXT mutation batch with bmq_routes_apply_async right behind it -- its
+        # upload runs beside the match kernels, its builder kernels behind them, nobody waits in between -- and the ticket is waited for.
+        n_pipe = n_steps // 2 if tickets is not None else 0
         apply(0)
         step(0)
         torch.cuda.synchronize()
+        pipe = None
+        if n_pipe:
+            submit_dev, wait_dev = tickets
+            for i in range(3):  # (every ticket slot once: their scratch buffers are allocated on first use)
+                wait_dev(submit_dev(i))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_pipe):
+                t = submit_dev(i)
+                data, off, opb = cb[i + 1]
+                rc = lib.bmq_routes_apply_async(eng.h, data.data_ptr(), off.data_ptr(), opb.data_ptr(), len(opb))
+                if rc:
+                    raise RuntimeError("bmq_routes_apply_async failed: %d" % rc)
+                wait_dev(t)
+            rc = lib.bmq_routes_apply_wait(eng.h)
+            if rc:
+                raise RuntimeError("bmq_routes_apply_wait failed: %d" % rc)
+            torch.cuda.synchronize()
+            el_p = time.perf_counter() - t0
+            pipe = {"value": args.topics * n_pipe / el_p, "unit": "topics/s", "steps": n_pipe, "ms_per_step": el_p / n_pipe * 1e3,
+                    "shape": "ticket(batch i) | bmq_routes_apply_async(mutations i + 1) | wait(ticket): the upload beside the match kernels, the builder kernels "
+                             "behind them, one host wait per step"}
         ams, t0 = [], time.perf_counter()
-        for i in range(n_steps):
+        for i in range(n_pipe, n_steps):
             ams.append(apply(i + 1))
             step(i)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        n_steps_blocking = n_steps - n_pipe
         st = eng.stats()
         alg = st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit + 4 * st.n_match
         extra["c5"] = {"workload": "C5 = C3 + %d route mutations (50 %% unsubscribe / 50 %% subscribe) before every 1 M-publish batch" % n_ops,
-                       "value": args.topics * n_steps / el, "unit": "topics/s", "steps": n_steps, "ms_per_step": el / n_steps * 1e3,
+                       "value": args.topics * n_steps_blocking / el, "unit": "topics/s", "steps": n_steps_blocking, "ms_per_step": el / n_steps_blocking * 1e3,
+                       "pipelined": pipe,
                        "apply_ms_mean": float(np.mean(ams)), "apply_ms_max": float(np.max(ams)),
                        "kernel_ms": {"k_walk": st.ms_walk, "k_expand": st.ms_expand, "all_kernels": st.ms_total},
                        "roofline": {"bound": "hbm", "kernel": "k_walk", "achieved": (alg - 4 * st.n_match) / (st.ms_walk * 1e-3) / 1e9, "peak": 8000.0,

@@ -162,32 +162,69 @@ public:
     }
 
     // ---- post-commit mutations, applied in order.  op[i]: 0 = put, 1 = delete ----
+    // apply = apply_begin + apply_end.  On the device apply_begin only ENQUEUES: the ops are uploaded on the executor's upload stream (beside
+    // whatever the engine stream still runs), the stages follow on the engine stream behind the gate, the counters travel back into
+    // page-locked memory; apply_end waits for them, lets the stage-by-stage loops finish what the gate stopped and does the bookkeeping.
+    // The caller's buffers must stay valid in between; at most one batch is open.
+    struct OpenApply {
+        bool open = false;
+        const uint8_t* keys = nullptr;
+        const uint32_t* key_off = nullptr;
+        const uint8_t* op = nullptr;
+        uint32_t n = 0, n_put = 0;
+        uint64_t kb = 0;
+        OpBatch ob{};
+        std::vector<uint32_t> put_rank;
+    } open_apply;
     bool apply(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n, ApplyResult* res = nullptr) {
+        return apply_begin(keys, key_off, op, n) && apply_end(res);
+    }
+    bool apply_begin(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
         error.clear();
+        OpenApply& oa = open_apply;
+        if (oa.open) return fail("an apply batch is open: apply_end first");
         if (n == 0) return true;
         if (broken) return fail("the index is inconsistent after a failed batch: bmq_rebuild is required");
         if (!built && !reset_empty()) return false;
         const uint64_t kb = key_off[n];
-        std::vector<uint32_t> put_rank(n);
+        oa.put_rank.resize(n);
         uint32_t n_put = 0;
         for (uint32_t i = 0; i < n; i++) {
-            put_rank[i] = n_put;
+            oa.put_rank[i] = n_put;
             n_put += op[i] == 0;
         }
         if ((uint64_t)next_id + n_put >= 0xFFFFFFF0ull) return fail("route id space exhausted: bmq_rebuild re-numbers the routes");
-        PhaseTimer pt(x);
         if (!ensure_keys(kb) || !ensure_ids(next_id + n_put) || !ensure_scratch(n, true)) return false;
-        pt.lap("apply: put ranks, buffers");
         OpBatch ob = batch(n);
         ob.key_base = kpool_used;
         ob.id_base = next_id;
         ob.put_rank = s_put_rank;
         ob.op = s_op;
         ob.bulk = 0;
-        if (!x.copy_in_async(kpool + kpool_used, keys, kb) || !x.copy_in_async(s_key_off, key_off, sizeof(uint32_t) * ((size_t)n + 1)) ||
-            !x.copy_in_async(s_op, op, n) || !x.copy_in_async(s_put_rank, put_rank.data(), sizeof(uint32_t) * (size_t)n))
+        if (!x.upload_async(kpool + kpool_used, keys, kb) || !x.upload_async(s_key_off, key_off, sizeof(uint32_t) * ((size_t)n + 1)) ||
+            !x.upload_async(s_op, op, n) || !x.upload_async(s_put_rank, oa.put_rank.data(), sizeof(uint32_t) * (size_t)n) || !x.uploads_done())
             return xfail();
-        pt.lap("apply: upload ops");
+        oa.keys = keys, oa.key_off = key_off, oa.op = op, oa.n = n, oa.n_put = n_put, oa.kb = kb, oa.ob = ob;
+        if (Exec::gated) { // the stages back to back behind the gate, the counters on their way back: nothing waits here
+            DistIndexMut ix = mut();
+            if (!x.zero(&bc->gate, sizeof(uint32_t)) || !zero_batch_counters() || !x.prepare(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !x.gate(bc, 1) ||
+                !zero_batch_counters() || !x.locate(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !x.gate(bc, 2) || !x.zero(ob.group_done, n) ||
+                !x.sort_targets(ob) || !zero_batch_counters() || !x.group(ix, ob) || !x.gate(bc, 3) || !x.read_back_async(&hbc, bc, sizeof(BuildCounters)))
+                return xfail();
+        }
+        oa.open = true;
+        return true;
+    }
+    bool apply_end(ApplyResult* res = nullptr) {
+        OpenApply& oa = open_apply;
+        if (!oa.open) return true;
+        oa.open = false;
+        const uint8_t* const keys = oa.keys;
+        const uint32_t* const key_off = oa.key_off;
+        const uint32_t n = oa.n, n_put = oa.n_put;
+        const uint64_t kb = oa.kb;
+        OpBatch ob = oa.ob;
+        PhaseTimer pt(x);
         auto count_groups = [&]() { // what the group step of this round did (the counters are zeroed in front of every round)
             uint64_t a = 0, r = 0, du = 0;
             for (uint32_t c = 0; c < N_CTR_LANES; c++) a += hbc.n_added[c], r += hbc.n_removed[c], du += hbc.n_dups[c];
@@ -205,11 +242,7 @@ public:
         uint32_t from = 1; // the stage the stage-by-stage form starts at; 4: nothing left to do
         bool groups_pending = false;
         if (Exec::gated) {
-            DistIndexMut ix = mut();
-            if (!x.zero(&bc->gate, sizeof(uint32_t)) || !zero_batch_counters() || !x.prepare(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !x.gate(bc, 1) ||
-                !zero_batch_counters() || !x.locate(ix, ob) || !x.prepare_check(ix, ob, dir_slots) || !x.gate(bc, 2) || !x.zero(ob.group_done, n) ||
-                !x.sort_targets(ob) || !zero_batch_counters() || !x.group(ix, ob) || !x.gate(bc, 3) || !read_counters())
-                return xfail();
+            if (!x.read_back_wait(&hbc, sizeof(BuildCounters))) return xfail();
             pt.lap("apply: prepare, locate, sort, groups (one read-back)");
             from = hbc.gate ? hbc.gate : 4;
             if (from >= 3) { // the group step ran (to the end, or up to the groups that found the id-list pool full)

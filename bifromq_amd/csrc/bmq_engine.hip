@@ -188,12 +188,14 @@ struct bmq_engine {
     uint32_t rgcap = 0;
     uint32_t rwcap = 0;      // k_retain_walk: entries per frontier list in the waves' arena (grown on ST_RETAIN_LIST)
     uint32_t rw_waves = 0;   // k_retain_walk: resident waves (its persistent grid)
+    bool apply_open = false; // bmq_routes_apply_async: the batch's outcome has not been fetched yet (complete_apply)
     bool rwalk_v1 = false;   // BMQ_RWALK_V1=1: the one-filter-per-wave walk for every batch (A/B measurements)
 };
 
 static int retain_finish(bmq_engine* e, uint64_t* out_total);
 extern "C" void bmq_comm_destroy(bmq_engine* e);
 
+static int complete_apply(bmq_engine* e); // (defined behind the index helpers below)
 namespace {
 
 #define HIPCHK(e, expr)                                                                                  \
@@ -308,6 +310,7 @@ int enqueue_ranges(bmq_engine* e, bmq_engine::BatchSlot& S, const BatchArgs& a) 
 }
 
 int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
+    if (int rc = complete_apply(e)) return rc; // (an apply batch still open: the launch needs the index as it leaves it)
     a.ix = e->dix->view();
     a.tpw_shift = tpw_shift_for(a.n_topics);
     a.n_blocks = (a.n_topics + (1u << a.tpw_shift) - 1) >> a.tpw_shift;
@@ -593,6 +596,29 @@ static int index_error(bmq_engine* e, const std::string& msg, bool invalid_input
     return set_err(e, invalid_input ? BMQ_E_INVAL : BMQ_E_STATE, msg);
 }
 
+// A batch handed over with bmq_routes_apply_async: waits for its counters, lets the index finish what the gate stopped, does the
+// bookkeeping.  Called (under e->mu) by bmq_routes_apply_wait and in front of everything that reads or changes the route index -- a match
+// launch needs the index as the batch left it (regions may have moved), a mutation the ids it handed out.  The batch's error, if any, is
+// the caller's: a match launched behind a failed apply fails with it.
+static int complete_apply(bmq_engine* e) {
+    if (!e->apply_open) return BMQ_OK;
+    e->apply_open = false;
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    bool bad_input = false;
+    const bool ok = with_index(e, [&](auto& ix) {
+        const bool r = ix.apply_end();
+        if (!r) {
+            e->err = ix.error;
+            bad_input = !ix.broken && ix.error.find("malformed") != std::string::npos;
+        }
+        return r;
+    });
+    if (!ok) return index_error(e, e->err, bad_input);
+    e->epoch++;
+    e->built = true;
+    return BMQ_OK;
+}
+
 // ====================================================================================================================
 // C ABI
 // ====================================================================================================================
@@ -638,6 +664,7 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking) != hipSuccess)
             return BMQ_E_HIP;
+        e->dx.upload_stream = e->s_in; // an apply batch's ops are uploaded beside the batch the engine stream still runs
         for (auto& sl : e->slots) {
             for (auto& ev : sl.ev)
                 if (hipEventCreate(&ev) != hipSuccess) return BMQ_E_HIP;
@@ -704,6 +731,7 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
     if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || (n_keys && (!keys || !key_off))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
+    if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first)
     if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     static const uint32_t zero_off[1] = {0};
@@ -725,6 +753,7 @@ int bmq_compact(bmq_engine* e) {
     if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
+    if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first)
     for (auto& sl : e->slots)
         if (sl.pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: finish / wait for it first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
@@ -738,21 +767,22 @@ int bmq_compact(bmq_engine* e) {
     return BMQ_OK;
 }
 
-int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+static int routes_apply_common(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n, bool async) {
     std::unique_lock<std::recursive_mutex> api_lock;
     if (e) api_lock = std::unique_lock<std::recursive_mutex>(e->api);
     if (!e || (n && (!keys || !key_off || !op))) return BMQ_E_INVAL;
-    if (n == 0) return BMQ_OK;
     // The builder kernels run on the engine stream, in order with the match batches: a mutation costs the matcher threads the
     // duration of its kernels (well under a millisecond for 100 k ops), not a host-side rebuild.
     std::lock_guard<std::mutex> g(e->mu);
+    if (int rc = complete_apply(e)) return rc; // the batch before this one
+    if (n == 0) return BMQ_OK;
     // a batch handed over with bmq_match_submit is simply in front of the builder kernels on the engine stream; only the
     // caller-driven *_dev protocol (results read by the caller between launch and finish) excludes a mutation in between
     if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     bool bad_input = false;
     const bool ok = with_index(e, [&](auto& ix) {
-        const bool r = ix.apply(keys, key_off, op, n);
+        const bool r = ix.apply_begin(keys, key_off, op, n);
         if (!r) {
             e->err = ix.error;
             bad_input = !ix.broken && ix.error.find("malformed") != std::string::npos;
@@ -760,15 +790,27 @@ int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off
         return r;
     });
     if (!ok) return index_error(e, e->err, bad_input);
-    e->epoch++;
-    e->built = true;
-    return BMQ_OK;
+    e->apply_open = true;
+    return async ? BMQ_OK : complete_apply(e);
+}
+int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+    return routes_apply_common(e, keys, key_off, op, n, false);
+}
+int bmq_routes_apply_async(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+    return routes_apply_common(e, keys, key_off, op, n, true);
+}
+int bmq_routes_apply_wait(bmq_engine* e) {
+    if (!e) return BMQ_E_INVAL;
+    std::lock_guard<std::recursive_mutex> api_lock(e->api);
+    std::lock_guard<std::mutex> g(e->mu);
+    return complete_apply(e);
 }
 
 int bmq_index_info_get(const bmq_engine* ce, bmq_index_info* out) {
     bmq_engine* e = const_cast<bmq_engine*>(ce);
     if (!e || !out) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
+    if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first)
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     DistIndexStats st;
     uint64_t generation = 0;
@@ -798,6 +840,7 @@ int bmq_route_key(const bmq_engine* ce, uint32_t route_id, uint8_t* out, uint32_
     bmq_engine* e = const_cast<bmq_engine*>(ce);
     if (!e || !out_len) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
+    if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first)
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     std::string k;
     bool hard = false;
@@ -820,6 +863,7 @@ int bmq_route_keys(const bmq_engine* ce, const uint32_t* route_ids, uint32_t n, 
     bmq_engine* e = const_cast<bmq_engine*>(ce);
     if (!e || !out_off || (n && !route_ids)) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
+    if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first)
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     std::vector<uint8_t> bytes;
     std::vector<uint64_t> off;
@@ -841,6 +885,7 @@ int bmq_index_find(const bmq_engine* ce, const uint8_t* tenant, uint32_t tenant_
     if (!e || !out_n) return BMQ_E_INVAL;
     *out_n = 0;
     std::lock_guard<std::mutex> g(e->mu);
+    if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first)
     if (!e->built) return BMQ_E_STATE;
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     std::vector<uint32_t> ids;

@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "bmq_build_core.h"
@@ -192,9 +193,43 @@ struct DevExec {
     void release(void* p) {
         if (p) (void)hipFree(p);
     }
-    ~DevExec() { release(tmp); }
+    ~DevExec() {
+        release(tmp);
+        if (pinned) (void)hipHostFree(pinned);
+        if (ev_up) (void)hipEventDestroy(ev_up);
+        if (ev_back) (void)hipEventDestroy(ev_back);
+    }
     bool sync() { return BMQ_X(hipStreamSynchronize(stream)); }
     bool copy_in_async(void* d, const void* s, size_t n) { return n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream)); }
+    // an apply batch's ops: uploaded on `upload_stream` (the engine's copy stream, if it has one) -- beside whatever `stream` still runs --,
+    // `stream` waits for them (uploads_done); its counters come back into page-locked memory behind an event (read_back_async / _wait)
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t ev_up = nullptr, ev_back = nullptr;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    bool upload_async(void* d, const void* s, size_t n) {
+        return n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, upload_stream ? upload_stream : stream));
+    }
+    bool uploads_done() {
+        if (!upload_stream) return true;
+        if (!ev_up && !BMQ_X(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming))) return false;
+        return BMQ_X(hipEventRecord(ev_up, upload_stream)) && BMQ_X(hipStreamWaitEvent(stream, ev_up, 0));
+    }
+    bool read_back_async(void* /*host*/, const void* dev, size_t n) {
+        if (pinned_cap < n) {
+            if (pinned) (void)hipHostFree(pinned);
+            pinned = nullptr, pinned_cap = 0;
+            if (!BMQ_X(hipHostMalloc(&pinned, n, hipHostMallocDefault))) return false;
+            pinned_cap = n;
+        }
+        if (!ev_back && !BMQ_X(hipEventCreateWithFlags(&ev_back, hipEventDisableTiming))) return false;
+        return BMQ_X(hipMemcpyAsync(pinned, dev, n, hipMemcpyDeviceToHost, stream)) && BMQ_X(hipEventRecord(ev_back, stream));
+    }
+    bool read_back_wait(void* host, size_t n) {
+        if (!BMQ_X(hipEventSynchronize(ev_back))) return false;
+        memcpy(host, pinned, n);
+        return true;
+    }
     bool copy_in(void* d, const void* s, size_t n) { return copy_in_async(d, s, n) && sync(); }
     bool copy_out(void* d, const void* s, size_t n) { return (n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream))) && sync(); }
     bool copy(void* d, const void* s, size_t n) { return n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream)); }

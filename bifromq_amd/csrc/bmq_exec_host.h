@@ -29,6 +29,10 @@ struct HostExec {
         return true;
     }
     bool copy_in_async(void* d, const void* s, size_t n) { return copy_in(d, s, n); }
+    bool upload_async(void* d, const void* s, size_t n) { return copy_in(d, s, n); }
+    bool uploads_done() { return true; }
+    bool read_back_async(void*, const void*, size_t) { return true; } // (not gated: the stage-by-stage form reads after every stage)
+    bool read_back_wait(void*, size_t) { return true; }
     bool copy_out(void* d, const void* s, size_t n) { return copy_in(d, s, n); }
     bool copy(void* d, const void* s, size_t n) { return copy_in(d, s, n); }
     bool zero(void* p, size_t n) {

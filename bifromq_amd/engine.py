@@ -234,6 +234,23 @@ class Engine:
         self._check(_lib.lib().bmq_routes_apply(self.h, _ptr(data), _ptr(off), _ptr(op), len(ops)))
         return self
 
+    def apply_async(self, ops: Sequence[Tuple[int, bytes]]):
+        """bmq_routes_apply_async: the batch is uploaded and queued behind whatever the engine stream holds, the call returns at once; its
+        outcome is apply_wait()'s (or the next index call's).  The op buffers are kept in page-locked memory owned by this object until then."""
+        data, off = pack([k for _, k in ops])
+        op = np.array([o for o, _ in ops], dtype=np.uint8)
+        bufs = (pinned(len(data), np.uint8), pinned(len(off), np.uint32), pinned(max(len(op), 1), np.uint8))
+        bufs[0][:], bufs[1][:], bufs[2][:len(op)] = data, off, op
+        self._open_apply = bufs  # (must outlive the upload)
+        self._check(_lib.lib().bmq_routes_apply_async(self.h, _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]), len(ops)))
+        return self
+
+    def apply_wait(self):
+        """bmq_routes_apply_wait: the outcome of the batch handed over with apply_async (raises what apply would have raised)"""
+        self._check(_lib.lib().bmq_routes_apply_wait(self.h))
+        self._open_apply = None
+        return self
+
     def compact(self):
         """bmq_compact: re-build from the live routes (ids become ranks again, new generation)."""
         self._check(_lib.lib().bmq_compact(self.h))

@@ -124,6 +124,15 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
  * key is a no-op; the j-th put of the batch that adds a route gets id next_route_id + j.  A malformed key or op code fails
  * the whole batch with BMQ_E_INVAL before anything is changed. */
 int bmq_routes_apply(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
+/* The same without the wait (DistWorkerCoProc applies a batch of mutations and goes on serving, DW/DistWorkerCoProc.java:188-209): the ops
+ * are uploaded on the engine's copy stream -- beside a batch handed over with bmq_match_submit* that still runs --, the builder kernels are
+ * queued behind that batch, the call returns after the enqueue.  The buffers (page-locked memory from bmq_host_alloc, or the upload is
+ * not asynchronous) must stay untouched until the batch's outcome has been fetched: bmq_routes_apply_wait returns what bmq_routes_apply
+ * would have returned (nothing is changed by a batch that holds a malformed key).  Every later call that reads or changes the route index
+ * fetches the outcome first -- a match launched behind a failed batch returns that batch's error.  At most one batch is open: a second
+ * bmq_routes_apply[_async] completes the first. */
+int bmq_routes_apply_async(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n);
+int bmq_routes_apply_wait(bmq_engine* e);
 
 /* Maintenance: re-build the index from its own live routes (the keys are gathered from the HBM key store).  Frees what churn leaves
  * behind until then -- abandoned tenant regions and id lists, trie nodes and dictionary tokens of filters nobody subscribes to any

@@ -712,6 +712,63 @@ def test_submit_wait_two_batches_in_flight(eng):
     assert len(ids2) > len(expect[0][1])  # the '#' route of tenant 0 now matches its non-'$' topics
 
 
+def test_apply_async_lands_behind_a_submitted_batch(eng):
+    """bmq_routes_apply_async: the batch is uploaded beside, and applied behind, a match batch handed over with bmq_match_submit; its
+    outcome is bmq_routes_apply_wait's or the next index call's.  Same rows, same ids as the blocking bmq_routes_apply on a second engine --
+    also when the batch needs the host (a tenant the index does not know: the gate closes, the stage-by-stage loops finish the batch) --; a
+    batch with a malformed key changes nothing and its error reaches whoever asks next."""
+    from bifromq_amd.engine import pinned
+    w = B.Workload(23, 5, 2500, 1)
+    keys = w.keys()
+    tn = w.tenants() + ["a-tenant-the-index-does-not-know-yet"]
+    ref = B.Engine(device=0)
+    try:
+        eng.rebuild(keys)
+        ref.rebuild(keys)
+        tdata, toff = O.pack(tn)
+        p_t, p_to = pinned(len(tdata), np.uint8), pinned(len(toff), np.uint32)
+        p_t[:], p_to[:] = tdata, toff
+        data, off, tt = w.topics(77, 30000)
+        tt = tt.copy()
+        tt[::50] = len(tn) - 1  # publishes of the tenant that only appears with the second batch
+        pd, po, pt = pinned(len(data), np.uint8), pinned(len(off), np.uint32), pinned(len(tt), np.uint32)
+        pd[:], po[:], pt[:] = data, off, tt
+        rows, ids = pinned(40000, np.uint32), pinned(8_000_000, np.uint32)
+        rnd = random.Random(5)
+        batches = []
+        dels = rnd.sample(range(len(keys)), 600)
+        batches.append([(1, keys[i]) for i in dels[:300]] + [(0, _normal(tn[q % 5], "l0_%d/#" % (q % 8), 0, "as%d" % q, "d%d" % (q % 7))) for q in range(300)])
+        batches.append([(1, keys[i]) for i in dels[300:]] + [(0, _normal(tn[-1], "#" if q % 2 else "+/+/#", 0, "nt%d" % q, "d1")) for q in range(40)])
+        for ops in batches:
+            rnd.shuffle(ops)
+            before = ref.match_batch(tn, tt, packed_topics=(data, off))
+            t = eng.match_submit(p_t, p_to, len(tn), pt, pd, po, len(tt))
+            eng.apply_async(ops)  # queued behind the submitted batch; the call does not wait
+            got = eng.match_wait(t, rows, ids)
+            assert got == len(before[1]) and (rows[:len(tt) + 1] == before[0]).all() and (ids[:got] == before[1]).all()  # the batch saw the index as it was
+            ref.apply(ops)
+            after = ref.match_batch(tn, tt, packed_topics=(data, off))
+            row2, ids2 = eng.match_batch(tn, tt, packed_topics=(data, off))  # (fetches the apply's outcome first)
+            assert (row2 == after[0]).all() and (ids2 == after[1]).all() and not (len(after[1]) == len(before[1]) and (after[1] == before[1]).all())
+            eng.apply_wait()
+            assert eng.info().n_routes == ref.info().n_routes and eng.info().next_route_id == ref.info().next_route_id
+        # a malformed key: nothing is changed; the error is apply_wait's ...
+        bad = [(0, _normal(tn[0], "x/#", 0, "ok", "d")), (0, b"\x00\x07not-a-route-key")]
+        n0 = eng.info().n_routes
+        eng.apply_async(bad)
+        with pytest.raises(B.BmqError) as ei:
+            eng.apply_wait()
+        assert ei.value.code == -1 and eng.info().n_routes == n0
+        # ... or, when nobody waits, the next call's that needs the index; the call after it works again
+        eng.apply_async(bad)
+        with pytest.raises(B.BmqError):
+            eng.match_batch(tn, tt, packed_topics=(data, off))
+        row3, ids3 = eng.match_batch(tn, tt, packed_topics=(data, off))
+        assert (ids3 == ids2).all() and eng.info().n_routes == n0
+    finally:
+        ref.close()
+
+
 def test_dev_protocol_belongs_to_one_thread(eng):
     """bmq_match_batch_dev .. bmq_match_finish is one caller's window: another thread's *_dev launch is refused meanwhile
     (BMQ_E_STATE) instead of overwriting the batch in flight.  Device buffers come straight from the HIP runtime the library
