@@ -51,6 +51,12 @@ def main():
     ap.add_argument("--csr-exchange-steps", type=int, default=5,
                     help="N>1: extra steps, outside the timed region, with the OTHER exchange form (the all-gatherv of the complete CSR that "
                          "north_star names when --exchange is fanout, and vice versa): reported as exchange.csr_ms / exchange.fanout_ms")
+    ap.add_argument("--split-policy", default="fanout-hinter", choices=["fanout-hinter", "publish-share"],
+                    help="node-wide leg: which tenants are split by filter over all ranks.  fanout-hinter: bifromq_amd.shard.FanoutSplitHinter "
+                         "(DW/hinter/FanoutSplitHinter.java restated: a prefix whose route count reaches --split-threshold) fed with the bulk load; "
+                         "publish-share: tenants whose share of the batch exceeds half a rank's fair share (no analogue in the reference: its "
+                         "hinters look at mutations only)")
+    ap.add_argument("--split-threshold", type=int, default=100_000, help="FanoutSplitHinterFactory.java:33: splitThreshold default")
     ap.add_argument("--node-batch-steps", type=int, default=10,
                     help="N>1: steps of the extra node-wide measurement (one shared Zipf batch, device-side partition, hot tenants "
                          "split by filter, fan-out all-reduce); 0 = skip")
@@ -754,7 +760,17 @@ def _node_batch_setup(args, rank, world, local_rank, dev, total_tenants, per_ten
     tn = full.tenants()
     data, off, tt = full.topics(seed + 77, n, grouped=not args.ungrouped)  # same batch on every rank
     share = np.bincount(tt, minlength=len(tn)) / float(n)
-    hot = shard.pick_hot_tenants(share, world, 0.5)
+    hot_by_share = shard.pick_hot_tenants(share, world, 0.5)
+    if args.split_policy == "fanout-hinter":
+        # the split the reference's own rule would make: FanoutSplitHinter over the mutation stream -- here the bulk load, one batch of
+        # per-tenant route counts -- with the reference's threshold; every rank computes the same decision from the same counts
+        hinter = shard.FanoutSplitHinter(world, args.split_threshold)
+        counts = np.diff(np.asarray(full.tenant_first(), dtype=np.int64))
+        to_split, _ = hinter.record_counts({tn[t]: int(counts[t]) for t in range(total_tenants)})
+        index_of = {name: t for t, name in enumerate(tn)}
+        hot = sorted(index_of[name] for name in to_split)
+    else:
+        hot = hot_by_share
     owner_np = shard.topic_targets(tn, hot, world)
     # this rank's index: its tenants (bulk load of the sorted keys) + its hash share of the split tenants' keys (apply)
     mine = [t for t in range(total_tenants) if owner_np[t] == rank]
@@ -777,6 +793,8 @@ def _node_batch_setup(args, rank, world, local_rank, dev, total_tenants, per_ten
     d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
     d_tt = torch.from_numpy(tt.astype(np.int32)).to(dev)
     torch.cuda.synchronize()
+    args._split_info = {"policy": args.split_policy, "threshold": args.split_threshold if args.split_policy == "fanout-hinter" else None,
+                        "tenants_the_publish_share_rule_would_split": [tn[h] for h in hot_by_share]}
     return eng, tn, tt, hot, n_split_keys, d_tenants, d_tenant_off, d_owner, d_data, d_off, d_tt
 
 
@@ -849,7 +867,7 @@ def _node_batch_run(args, rank, world, dev, dist, n, eng, tn, tt, hot, n_split_k
             "ms_per_step": elapsed / args.node_batch_steps * 1e3, "publishes_per_batch_node": n, "fanout_total": int(fan.sum().item()),
             "split_tenants": [tn[h] for h in hot], "split_route_keys_this_rank": n_split_keys,
             "publishes_per_rank": [int(x) for x in per_rank], "imbalance_max_over_mean": float(per_rank.max() / per_rank.mean()),
-            "imbalance_without_split": float(plain.max() / plain.mean()),
+            "imbalance_without_split": float(plain.max() / plain.mean()), "split": getattr(args, "_split_info", None),
             "note": "one shared batch: device-side partition (bmq_partition_batch_dev) by hash(tenantId) mod N (hot tenants split by filter, publishes to all ranks) "
                     "-> match -> all-reduce of per-topic fan-out; includes the partition and the exchange"}
 

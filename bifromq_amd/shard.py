@@ -246,6 +246,10 @@ class FanoutSplitHinter:
         touched = {}
         for t, d in zip(tenants, deletes):
             touched[t] = touched.get(t, 0) + (-1 if d else 1)
+        return self.record_counts(touched)
+
+    def record_counts(self, touched):
+        """The same for a batch that is already summed up: {tenant: routes added - routes removed} (a bulk load is one such batch)."""
         to_split, to_merge = [], []
         for t, delta in touched.items():
             n = max(self.routes.get(t, 0) + delta, 0)
