@@ -66,6 +66,8 @@ def main():
                     help="N = 1: skip the compact extra legs (configs[4] churn on this index, the batching front at 64 threads, C2 and C4 as "
                          "child runs) that the default run appends under `extra`")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-visible (PCIe-inclusive) measurement")
+    ap.add_argument("--compact-chunk", type=int, default=8192, help="compaction leg: route ids handed to the next generation's builder per bmq_compact_poll")
+    ap.add_argument("--compact-duty", type=float, default=0.5, help="compaction leg: share of its time the compacting thread spends inside bmq_compact_poll")
     ap.add_argument("--no-churn", action="store_true", help="--workload c4: skip the add / remove leg (A/B runs of the walk kernel)")
     ap.add_argument("--batcher-threads", type=int, default=-1,
                     help="also measure the batching front (bmq_batcher_*, SURVEY 8f-1): N native threads issue single-topic calls")
@@ -652,8 +654,101 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
             extra["c5"]["parity"] = c5_parity(w, cb, n_steps + 1, fetch_csr, np)
     except Exception as ex:  # noqa: BLE001
         extra["c5"] = {"error": repr(ex)}
+    try:  # last: the route ids are re-numbered by it
+        extra["compaction"] = compaction_leg(args, eng, step, torch, np, fetch_csr)
+    except Exception as ex:  # noqa: BLE001
+        extra["compaction"] = {"error": repr(ex)}
     extra["wall_s"] = time.perf_counter() - t_all
     return extra
+
+
+def compaction_leg(args, eng, step, torch, np, fetch_csr=None):
+    """bmq_compact_begin / _poll / _swap on the index the C5 leg left behind (700 k mutations: abandoned id lists, dead ids, dead trie nodes):
+    one thread matches 1 M-publish batches back to back and clocks every one, a second thread builds the next generation in chunks of
+    --compact-chunk route ids (its kernels share the engine stream with the batches) -> batch latency idle / while compacting, the
+    generation change itself, and the rows of batch 0 before / after it (ids re-numbered: the map old id -> new id must be ONE increasing
+    function over every row)."""
+    import threading
+
+    from tests import util as U
+
+    def clocked(k, base=0):
+        out = []
+        for i in range(k):
+            t0 = time.perf_counter()
+            step(base + i)
+            out.append((time.perf_counter() - t0) * 1e3)
+        return out
+
+    def pct(v):
+        v = np.sort(np.asarray(v))
+        return {"n": int(len(v)), "p50": float(v[len(v) // 2]), "p99": float(v[min(len(v) - 1, int(len(v) * 0.99))]),
+                "p999": float(v[min(len(v) - 1, int(len(v) * 0.999))]), "max": float(v[-1])}
+
+    clocked(8)
+    torch.cuda.synchronize()
+    idle = clocked(400)
+    before = fetch_csr(0) if fetch_csr is not None else None
+    info0 = eng.info()
+    t_begin = time.perf_counter()
+    eng.compact_begin()
+    begin_ms = (time.perf_counter() - t_begin) * 1e3
+    poll_ms, failure = [], []
+
+    def compactor():
+        try:
+            done, t_start = 0, time.perf_counter()
+            while done < 1000:
+                if time.perf_counter() - t_start > 90:
+                    raise RuntimeError("the compaction leg is limited to 90 s: at %d permille" % done)
+                t0 = time.perf_counter()
+                done = eng.compact_poll(args.compact_chunk)
+                dt = time.perf_counter() - t0
+                poll_ms.append(dt * 1e3)
+                time.sleep(dt * (1.0 - args.compact_duty) / max(args.compact_duty, 1e-3))
+        except Exception as ex:  # noqa: BLE001
+            failure.append(repr(ex))
+
+    th = threading.Thread(target=compactor)
+    t0 = time.perf_counter()
+    th.start()
+    during, i = [], 0
+    while th.is_alive():
+        during.extend(clocked(4, i))
+        i += 4
+    th.join()
+    build_s = time.perf_counter() - t0
+    if failure:
+        eng.compact_abort()
+        return {"error": failure[0]}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    carried, replayed = eng.compact_swap()
+    swap_ms = (time.perf_counter() - t0) * 1e3
+    info1 = eng.info()
+    after_idle = clocked(200)
+    out = {"what": "bmq_compact_begin / _poll(%d ids) / _swap while 1 M-publish batches are matched back to back by another thread" % args.compact_chunk,
+           "batch_ms_idle": pct(idle), "batch_ms_while_compacting": pct(during), "batch_ms_after_swap": pct(after_idle),
+           "p99_ratio": pct(during)["p99"] / pct(idle)["p99"], "poll_ms": pct(poll_ms), "polls": len(poll_ms), "duty": args.compact_duty,
+           "begin_ms": begin_ms, "build_s": build_s, "swap_ms": swap_ms, "keys_carried": int(carried), "ops_replayed": int(replayed),
+           "before": {"n_routes": int(info0.n_routes), "next_route_id": int(info0.next_route_id), "garbage_bytes": int(info0.garbage_bytes),
+                      "device_bytes": int(info0.device_bytes), "generation": int(info0.generation)},
+           "after": {"n_routes": int(info1.n_routes), "next_route_id": int(info1.next_route_id), "garbage_bytes": int(info1.garbage_bytes),
+                     "device_bytes": int(info1.device_bytes), "generation": int(info1.generation)}}
+    if before is not None:
+        (_, _, tt), (row0, ids0) = before
+        _, (row1, ids1) = fetch_csr(0)
+        n = len(tt)
+        same_rows = bool((row0[:n + 1] == row1[:n + 1]).all())
+        ok = same_rows
+        if same_rows:
+            rp = row0[:n + 1].astype(np.int64)
+            a = U.csr_sorted(rp, ids0[:int(rp[n])].astype(np.int64))
+            b = U.csr_sorted(rp, ids1[:int(rp[n])].astype(np.int64))
+            pairs = np.unique(np.stack([a, b], axis=1), axis=0)  # sorted by old id, then new id
+            ok = bool(len(pairs) == len(np.unique(a)) and (np.diff(pairs[:, 1]) > 0).all())
+        out["rows_of_batch_0_equal_across_the_swap"] = {"row_sizes_equal": same_rows, "old_id_to_new_id_is_one_increasing_map": ok, "rows": int(n)}
+    return out
 
 
 def c5_parity(w, cb, n_applied, fetch_csr, np):

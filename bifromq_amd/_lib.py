@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/bmq.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_compact", "bmq_routes_apply", "bmq_routes_apply_async", "bmq_routes_apply_wait",
+    "bmq_engine_create", "bmq_engine_destroy", "bmq_last_error", "bmq_version", "bmq_rebuild", "bmq_compact", "bmq_compact_begin", "bmq_compact_poll", "bmq_compact_swap", "bmq_compact_abort", "bmq_routes_apply", "bmq_routes_apply_async", "bmq_routes_apply_wait",
     "bmq_index_info_get", "bmq_route_key", "bmq_route_keys", "bmq_index_find", "bmq_match_batch", "bmq_match_batch_dev",
     "bmq_match_finish", "bmq_set_kernel_timing", "bmq_match_submit", "bmq_match_wait", "bmq_match_submit_fmt", "bmq_match_submit_dev", "bmq_match_wait_dev", "bmq_match_wait_counts", "bmq_match_wait_ranges", "bmq_match_wait_grouped", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_range_lookup", "bmq_comm_unique_id", "bmq_comm_init", "bmq_comm_destroy", "bmq_exchange_fanout",
@@ -116,6 +116,10 @@ def lib() -> C.CDLL:
             "bmq_last_error": (C.c_char_p, [vp]),
             "bmq_version": (C.c_char_p, []),
             "bmq_rebuild": (C.c_int, [vp, vp, vp, u32]),
+            "bmq_compact_begin": (C.c_int, [vp]),
+            "bmq_compact_poll": (C.c_int, [vp, u32, P(u32)]),
+            "bmq_compact_swap": (C.c_int, [vp, P(u64), P(u64)]),
+            "bmq_compact_abort": (C.c_int, [vp]),
             "bmq_routes_apply": (C.c_int, [vp, vp, vp, vp, u32]),
             "bmq_routes_apply_async": (C.c_int, [vp, vp, vp, vp, u32]),
             "bmq_routes_apply_wait": (C.c_int, [vp]),

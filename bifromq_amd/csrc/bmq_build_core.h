@@ -151,6 +151,7 @@ struct OpBatch {
     uint32_t id_base;        // a put's id = id_base + (number of puts before it in the batch) -- see put_rank
     const uint32_t* put_rank;// [n] exclusive count of puts before op i; null (bulk load) = i
     uint32_t bulk;           // 1 = bulk load into an empty index: keys strictly ascending, all puts, no membership tests
+    uint32_t sized;          // 1 = the tenants' regions already hold whatever the batch adds (DistIndex::reserve_like): no growth bound is taken
     // scratch, [n] each unless noted
     uint32_t* dir_slot;      // prepare: directory slot of the op's tenant, NONE = unknown
     uint32_t* nn;            // bulk prepare: nodes the key adds (exact); then reused as tenant index after the scan
@@ -457,7 +458,7 @@ BMQ_HD void prepare_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t i) {
     if (d == NONE) {
         const uint32_t p = atom_add(&ix.bc->n_unknown, 1u);
         ob.unknown_list[p] = i;
-    } else {
+    } else if (!ob.sized) { // (a batch of a generation change: nl, the bound, would ask for room the exactly sized region does not need)
         atom_add(&ix.tenants[d].pending, nl);
     }
 }
@@ -542,7 +543,12 @@ BMQ_HD void bulk_counts_one(const OpBatch& ob, uint32_t t, uint32_t n_ten, const
 // ------------------------------------------------------------------------------------------------------------
 // locate: the filter node of an op (created on the way for puts)
 // ------------------------------------------------------------------------------------------------------------
-BMQ_HD void locate_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t i) {
+// phase 0: the puts of the batch (filter nodes and dictionary tokens come into being), phase 1: its deletes (they find what exists --
+// including what a put of the SAME batch in front of them created: one pass over both would let a delete's lane run ahead of the put's and
+// drop the delete as "no such filter"; found by replaying merged mutation batches into the next generation, round 5), phase 2: every op
+// (bulk loads and batches without deletes).
+BMQ_HD void locate_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t i, uint32_t phase) {
+    if (phase != 2 && (!ob.op || ob.op[i] == 0) != (phase == 0)) return;
     ob.target[i] = TARGET_NONE;
     uint32_t d = ob.dir_slot[i];
     if (ob.bulk) d = ob.bt_dir[d];

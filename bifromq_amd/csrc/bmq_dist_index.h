@@ -179,7 +179,8 @@ public:
     bool apply(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n, ApplyResult* res = nullptr) {
         return apply_begin(keys, key_off, op, n) && apply_end(res);
     }
-    bool apply_begin(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n) {
+    // sized: a batch of the carry-over behind reserve_like(old) (import_apply) -- all puts of keys `old` holds, `keys` is device memory
+    bool apply_begin(const uint8_t* keys, const uint32_t* key_off, const uint8_t* op, uint32_t n, bool sized = false) {
         error.clear();
         OpenApply& oa = open_apply;
         if (oa.open) return fail("an apply batch is open: apply_end first");
@@ -201,6 +202,7 @@ public:
         ob.put_rank = s_put_rank;
         ob.op = s_op;
         ob.bulk = 0;
+        ob.sized = sized ? 1 : 0;
         if (!x.upload_async(kpool + kpool_used, keys, kb) || !x.upload_async(s_key_off, key_off, sizeof(uint32_t) * ((size_t)n + 1)) ||
             !x.upload_async(s_op, op, n) || !x.upload_async(s_put_rank, oa.put_rank.data(), sizeof(uint32_t) * (size_t)n) || !x.uploads_done())
             return xfail();
@@ -219,7 +221,6 @@ public:
         OpenApply& oa = open_apply;
         if (!oa.open) return true;
         oa.open = false;
-        const uint8_t* const keys = oa.keys;
         const uint32_t* const key_off = oa.key_off;
         const uint32_t n = oa.n, n_put = oa.n_put;
         const uint64_t kb = oa.kb;
@@ -264,8 +265,21 @@ public:
             std::vector<uint32_t> unk(hbc.n_unknown);
             if (!x.copy_out(unk.data(), ob.unknown_list, sizeof(uint32_t) * unk.size())) return xfail();
             std::unordered_map<std::string, uint64_t> need; // new tenant -> nodes its puts may add
+            // (from this index's key pool, where apply_begin put the batch: the caller's pointer may be device memory -- the builder of the
+            // next generation hands the keys over where they live.  A few keys one by one, many with one copy of the batch.)
+            std::vector<uint8_t> kbuf;
+            const bool whole = unk.size() > 8;
+            if (whole) {
+                kbuf.resize(kb);
+                if (!x.copy_out(kbuf.data(), kpool + ob.key_base, kb)) return xfail();
+            }
             for (uint32_t i : unk) {
-                const std::string_view k((const char*)keys + key_off[i], key_off[i + 1] - key_off[i]);
+                const size_t klen = key_off[i + 1] - key_off[i];
+                if (!whole) {
+                    kbuf.resize(klen);
+                    if (!x.copy_out(kbuf.data(), kpool + ob.key_base + key_off[i], klen)) return xfail();
+                }
+                const std::string_view k((const char*)kbuf.data() + (whole ? key_off[i] : 0u), klen);
                 const size_t tlen = ((size_t)(uint8_t)k[1] << 8) | (uint8_t)k[2]; // validated by prepare
                 uint64_t levels = 1;
                 for (size_t q = 3 + tlen; q < k.size(); q++) levels += k[q] == 0;
@@ -372,6 +386,93 @@ public:
             return xfail();
         return true;
     }
+    // ---- generation change: THIS index (the generation being built, behind reserve_like(old)) takes the live keys among old's ids [lo, hi).
+    // Two steps, so that the caller needs to keep `old` still only for the first.  import_snapshot ENQUEUES a copy of old's key references
+    // kref[lo, hi) on this index's executor (the caller ordered it behind whatever old was told so far) and notes where old's key bytes
+    // lie -- the key pool is append-only, and while a generation change runs old keeps the blocks it outgrows (defer_release), so the
+    // pointer stays good whatever old is told meanwhile.  import_apply does the rest on this index's executor alone: the references come
+    // back (8 bytes per id: length + liveness), the live keys are gathered -- HBM to HBM, the bytes never visit the host -- and go through
+    // the apply path as puts (no order required, so no sort) into regions that are already sized.
+    struct Import {
+        uint32_t n = 0;
+        const uint8_t* old_kpool = nullptr;
+    } imp;
+    bool import_snapshot(DistIndex& old, uint32_t lo, uint32_t hi) {
+        error.clear();
+        imp = Import{};
+        if (!old.built) return true;
+        if (hi > old.next_id) hi = old.next_id;
+        if (hi <= lo) return true;
+        const uint32_t n = hi - lo;
+        if (!ensure_buf(g_refs, g_refs_cap, n)) return false;
+        if (!x.copy(g_refs, old.kref + lo, sizeof(unsigned long long) * (size_t)n)) return xfail();
+        imp.n = n;
+        imp.old_kpool = old.kpool;
+        return true;
+    }
+    bool import_apply(uint32_t& n_live) {
+        n_live = 0;
+        const uint32_t n = imp.n;
+        if (n == 0) return true;
+        imp.n = 0;
+        std::vector<unsigned long long> refs(n);
+        if (!x.copy_out(refs.data(), g_refs, sizeof(unsigned long long) * (size_t)n)) return xfail();
+        std::vector<uint64_t> offs((size_t)n + 1, 0);
+        std::vector<uint32_t> live_off(1, 0u);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t len = refs[i] >> KREF_LEN_SHIFT; // 0: no such route (never existed / deleted)
+            offs[i + 1] = offs[i] + len;
+            if (len) live_off.push_back((uint32_t)offs[i + 1]);
+        }
+        const uint64_t total = offs[n];
+        if (total == 0) return true;
+        if (total >= 0xFFFFFFF0ull) return fail("generation change: more than 4 GB of route keys in one chunk");
+        if (!ensure_buf(g_offs, g_offs_cap, (size_t)n + 1) || !ensure_buf(g_bytes, g_bytes_cap, total + 16)) return false;
+        DistIndexMut m = mut();
+        m.kpool = const_cast<uint8_t*>(imp.old_kpool); // (gather_bytes reads the key pool and nothing else)
+        if (!x.copy_in_async(g_offs, offs.data(), sizeof(uint64_t) * ((size_t)n + 1)) || !x.gather_bytes(m, g_refs, g_offs, n, g_bytes) || !x.sync()) return xfail();
+        n_live = (uint32_t)live_off.size() - 1;
+        const std::vector<uint8_t> puts(n_live, 0);
+        return apply_begin(g_bytes, live_off.data(), puts.data(), n_live, true) && apply_end(nullptr);
+    }
+    // blocks this index outgrew while another generation was being built from it
+    bool defer_release = false;
+    std::vector<void*> graveyard;
+    void release_deferred() {
+        for (void* q : graveyard) x.release(q);
+        graveyard.clear();
+    }
+    uint32_t id_bound() const { return next_id; } // ids handed out so far (live or not)
+    // Room for everything a generation change is about to hand over, taken once: every tenant of `old` that has routes gets its region at
+    // the size its trie had there (dead nodes included: an upper bound), the trie pool, the dictionary, the id-list pool, the key store
+    // and the id tables likewise.  The batches that carry the keys over then meet no unknown tenant and grow nothing.
+    bool reserve_like(DistIndex& old) {
+        error.clear();
+        if (!built && !reset_empty()) return false;
+        if (!old.built) return true;
+        if (!old.read_counters()) return fail(old.x.err);
+        std::vector<TenantSlot> d(old.dir_slots);
+        if (old.dir_slots && !old.x.copy_out(d.data(), old.dir, sizeof(TenantSlot) * (size_t)old.dir_slots)) return fail(old.x.err);
+        uint64_t slots = 0, n_ten = 0;
+        for (auto& t : d)
+            if ((t.hash_lo | t.hash_hi) && t.n_routes) slots += 2ull * buckets_for((uint64_t)t.n_nodes + 1), n_ten++;
+        if (trie_used + slots > trie_cap) {
+            if (trie_used + slots >= 0xFFFFFFF0ull) return fail("trie too large (2^32 slots)");
+            const uint64_t cap = std::min<uint64_t>(trie_used + slots + (tiny ? 0 : slots / 8 + (1u << 16)), 0xFFFFFFF0ull);
+            if (!regrow(trie, trie_used, cap)) return false;
+            if (!x.fill_slots(trie + trie_used, cap - trie_used)) return xfail();
+            trie_cap = cap;
+        }
+        if (!ensure_directory(tenant_slot.size() + n_ten)) return false;
+        for (auto& t : d)
+            if ((t.hash_lo | t.hash_hi) && t.n_routes &&
+                !create_tenant(std::string((const char*)old.names_h.data() + t.name_off, t.name_len), (uint64_t)t.n_nodes + 1, 0))
+                return false;
+        if (!flush_directory()) return false;
+        if (old.dict_slots > dict_slots && !grow_dict(old.dict_slots, old.dpool_cap)) return false;
+        if (!grow_route_pos(old.hbc.rp_used + 1024)) return false; // (lists are handed out in blocks: the old pool's size, not the live words)
+        return ensure_keys(old.kpool_used) && ensure_ids(std::min<uint64_t>((uint64_t)next_id + old.next_id + 64, 0xFFFFFFF0ull));
+    }
     // exact lookup (inspection only -- never used for matching): ids stored under (tenant, MQTT filter)
     bool find(std::string_view tenant, std::string_view filter, std::vector<uint32_t>& ids) {
         ids.clear();
@@ -428,6 +529,7 @@ public:
             if (p) x.release((void*)p);
             p = nullptr;
         };
+        release_deferred();
         rel(trie); rel(dir); rel(names); rel(dict); rel(dpool); rel(route_pos); rel(kref); rel(khash); rel(kpool); rel(bc);
         rel(s_key_off); rel(s_op); rel(s_put_rank); rel(s_dir_slot); rel(s_nn); rel(s_flag); rel(s_target); rel(s_order);
         rel(s_sorted_target); rel(s_group_done); rel(s_unknown); rel(s_grow); rel(s_bt_first); rel(s_bt_nodes); rel(s_bt_keys); rel(s_bt_dir);
@@ -476,7 +578,8 @@ private:
         T* q = (T*)x.alloc(new_n * sizeof(T) + 16);
         if (!q) return fail("out of memory");
         if (p && old_n && !x.copy(q, p, old_n * sizeof(T))) return xfail();
-        if (p) {
+        if (p && defer_release) graveyard.push_back((void*)p); // (somebody may still read it: see import_snapshot)
+        else if (p) {
             if (!x.sync()) return xfail();
             x.release(p);
         }

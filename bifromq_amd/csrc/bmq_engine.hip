@@ -96,6 +96,8 @@ struct bmq_engine {
     // dist direction: the index lives in HBM and is built / mutated there by the builder kernels (bmq_exec_dev.h); a host-only
     // engine (device < 0) runs the same builder on host threads (bmq_exec_host.h) for inspection -- it can never match
     DevExec dx;
+    DevExec dxi[2]; // the route index's executors: one under the serving generation (engine stream), the other free -- or, while a generation
+                    // is being built beside it (bmq_compact_begin), under that one, on the build stream; the swap exchanges the roles
     std::unique_ptr<DistIndex<DevExec>> dix;
     HostExec hx;
     std::unique_ptr<DistIndex<HostExec>> hix;
@@ -188,6 +190,21 @@ struct bmq_engine {
     uint32_t rgcap = 0;
     uint32_t rwcap = 0;      // k_retain_walk: entries per frontier list in the waves' arena (grown on ST_RETAIN_LIST)
     uint32_t rw_waves = 0;   // k_retain_walk: resident waves (its persistent grid)
+    // bmq_compact_begin / _poll / _swap: the next generation of the route index, built beside the serving one from its live keys
+    struct Compaction {
+        bool active = false; // (guarded by mu, like the log; the rest by cmp_mu)
+        DevExec* bx = nullptr; // the executor under the generation being built
+        std::unique_ptr<DistIndex<DevExec>> next_d; // the generation being built: on the device,
+        std::unique_ptr<DistIndex<HostExec>> next_h; // or (host-only engine) in host memory, like the serving one
+        uint32_t cursor = 0, n_ids = 0; // ids of the serving generation handed over so far / to hand over
+        uint64_t carried = 0;           // live keys handed over
+        std::vector<uint8_t> log_keys;  // what was mutated meanwhile: replayed into `next` before the swap
+        std::vector<uint32_t> log_off{0};
+        std::vector<uint8_t> log_op;
+    } cmp;
+    std::mutex cmp_mu;                // one compaction call at a time (taken BEFORE mu)
+    hipStream_t s_build = nullptr;    // the stream the next generation is built on: lowest priority, beside the match batches
+    hipEvent_t ev_serving = nullptr;  // "what the serving generation was told so far": the build stream waits for it before a snapshot
     bool apply_open = false; // bmq_routes_apply_async: the batch's outcome has not been fetched yet (complete_apply)
     bool rwalk_v1 = false;   // BMQ_RWALK_V1=1: the one-filter-per-wave walk for every batch (A/B measurements)
 };
@@ -590,8 +607,12 @@ int check_dist_ready(bmq_engine* e) {
 
 // run `f` on whichever index the engine has (HBM-resident, or host memory for a host-only engine)
 template <class F> static auto with_index(bmq_engine* e, F&& f) { return e->dix ? f(*e->dix) : f(*e->hix); }
+// (serving generation, generation being built) of whichever executor the engine has
+template <class F> static auto with_generations(bmq_engine* e, F&& f) { return e->dix ? f(*e->dix, *e->cmp.next_d) : f(*e->hix, *e->cmp.next_h); }
 static int index_error(bmq_engine* e, const std::string& msg, bool invalid_input) {
-    if (e->dix && !e->dx.err.empty() && msg == e->dx.err) return set_err(e, BMQ_E_HIP, msg);
+    if (e->dix)
+        for (DevExec* x : {&e->dx, &e->dxi[0], &e->dxi[1]})
+            if (!x->err.empty() && msg == x->err) return set_err(e, BMQ_E_HIP, msg);
     if (msg.find("out of") == 0) return set_err(e, BMQ_E_NOMEM, msg);
     return set_err(e, invalid_input ? BMQ_E_INVAL : BMQ_E_STATE, msg);
 }
@@ -664,7 +685,7 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         if (hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking) != hipSuccess)
             return BMQ_E_HIP;
-        e->dx.upload_stream = e->s_in; // an apply batch's ops are uploaded beside the batch the engine stream still runs
+        e->dx.upload_stream = e->dxi[0].upload_stream = e->s_in; // an apply batch's ops are uploaded beside the batch the engine stream still runs
         for (auto& sl : e->slots) {
             for (auto& ev : sl.ev)
                 if (hipEventCreate(&ev) != hipSuccess) return BMQ_E_HIP;
@@ -677,9 +698,9 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
             if (hipHostMalloc((void**)&sl.h_fsums, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return BMQ_E_NOMEM;
             memset(sl.h_fsums, 0, 4 * sizeof(unsigned long long));
         }
-        e->dx.device = c.device;
-        e->dx.stream = e->stream;
-        e->dix = std::make_unique<DistIndex<DevExec>>(e->dx);
+        e->dx.device = e->dxi[0].device = e->dxi[1].device = c.device;
+        e->dx.stream = e->dxi[0].stream = e->stream;
+        e->dix = std::make_unique<DistIndex<DevExec>>(e->dxi[0]);
         e->drt = std::make_unique<RetainDyn<DevExec>>(e->dx);
     } else {
         e->hix = std::make_unique<DistIndex<HostExec>>(e->hx);
@@ -711,6 +732,10 @@ void bmq_engine_destroy(bmq_engine* e) {
         if (e->ev_ex) (void)hipEventDestroy(e->ev_ex);
         if (e->s_ex) (void)hipStreamDestroy(e->s_ex);
         if (e->s_side) (void)hipStreamDestroy(e->s_side);
+        if (e->s_build) (void)hipStreamSynchronize(e->s_build);
+        e->cmp = bmq_engine::Compaction{}; // (a generation left half-built)
+        if (e->s_build) (void)hipStreamDestroy(e->s_build);
+        if (e->ev_serving) (void)hipEventDestroy(e->ev_serving);
         if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
         if (e->ev_join) (void)hipEventDestroy(e->ev_join);
         e->dfo.reset();
@@ -732,6 +757,7 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
     if (!e || (n_keys && (!keys || !key_off))) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first)
+    if (e->cmp.active) return set_err(e, BMQ_E_STATE, "a compaction is running: bmq_compact_swap or bmq_compact_abort first");
     if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     static const uint32_t zero_off[1] = {0};
@@ -754,6 +780,7 @@ int bmq_compact(bmq_engine* e) {
     if (!e) return BMQ_E_INVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first)
+    if (e->cmp.active) return set_err(e, BMQ_E_STATE, "a compaction is running: bmq_compact_swap or bmq_compact_abort first");
     for (auto& sl : e->slots)
         if (sl.pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: finish / wait for it first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
@@ -790,6 +817,13 @@ static int routes_apply_common(bmq_engine* e, const uint8_t* keys, const uint32_
         return r;
     });
     if (!ok) return index_error(e, e->err, bad_input);
+    if (e->cmp.active) { // a generation is being built beside this one: it gets the batch too, before the swap
+        bmq_engine::Compaction& c = e->cmp;
+        const uint32_t base = c.log_off.back();
+        c.log_keys.insert(c.log_keys.end(), keys, keys + key_off[n]);
+        for (uint32_t i = 1; i <= n; i++) c.log_off.push_back(base + key_off[i]);
+        c.log_op.insert(c.log_op.end(), op, op + n);
+    }
     e->apply_open = true;
     return async ? BMQ_OK : complete_apply(e);
 }
@@ -804,6 +838,164 @@ int bmq_routes_apply_wait(bmq_engine* e) {
     std::lock_guard<std::recursive_mutex> api_lock(e->api);
     std::lock_guard<std::mutex> g(e->mu);
     return complete_apply(e);
+}
+
+// ---- compaction without a stall: the next generation is built beside the serving one -------------------------------------------------
+// (TopicLevelTrie contracts as it goes, UTIL/index/TopicLevelTrie.java:257-384; here deleted routes leave garbage -- abandoned id lists,
+// dead trie nodes, dictionary tokens nobody uses, key bytes -- until a generation change.)  The key bytes never leave HBM: a chunk of the
+// serving generation's live keys is gathered into its staging buffer and handed to the next generation's builder as it is (puts through
+// the apply path: no order required, so no sort); what is mutated meanwhile is logged and replayed before the swap.
+static int replay_log(bmq_engine* e, size_t from) {
+    bmq_engine::Compaction& c = e->cmp;
+    const size_t n = c.log_op.size();
+    std::vector<uint32_t> off;
+    for (size_t lo = from; lo < n;) {
+        const size_t hi = std::min(n, lo + 65536);
+        off.resize(hi - lo + 1);
+        for (size_t i = lo; i <= hi; i++) off[i - lo] = c.log_off[i] - c.log_off[lo];
+        std::string msg;
+        if (!with_generations(e, [&](auto&, auto& next) {
+                const bool r = next.apply(c.log_keys.data() + c.log_off[lo], off.data(), c.log_op.data() + lo, (uint32_t)(hi - lo));
+                if (!r) msg = next.error;
+                return r;
+            }))
+            return index_error(e, msg, false);
+        lo = hi;
+    }
+    return BMQ_OK;
+}
+int bmq_compact_begin(bmq_engine* e) {
+    if (!e) return BMQ_E_INVAL;
+    std::lock_guard<std::recursive_mutex> api_lock(e->api);
+    std::lock_guard<std::mutex> gc(e->cmp_mu);
+    std::lock_guard<std::mutex> g(e->mu);
+    if (int rc = complete_apply(e)) return rc;
+    if (e->cmp.active) return set_err(e, BMQ_E_STATE, "a compaction is running: bmq_compact_swap or bmq_compact_abort first");
+    if (!e->built) return set_err(e, BMQ_E_STATE, "no index");
+    e->cmp = bmq_engine::Compaction{};
+    if (e->dix) {
+        HIPCHK(e, hipSetDevice(e->device));
+        if (!e->s_build) {
+            int least = 0, greatest = 0;
+            HIPCHK(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(e, hipStreamCreateWithPriority(&e->s_build, hipStreamNonBlocking, least)); // a match batch's waves go first
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_serving, hipEventDisableTiming));
+        }
+        DevExec* bx = &e->dix->x == &e->dxi[0] ? &e->dxi[1] : &e->dxi[0];
+        bx->stream = e->s_build;
+        bx->upload_stream = nullptr;
+        e->cmp.bx = bx;
+        e->cmp.next_d = std::make_unique<DistIndex<DevExec>>(*bx);
+        // the sizes below are read through the serving generation's executor: behind what the engine stream holds
+    } else {
+        e->cmp.next_h = std::make_unique<DistIndex<HostExec>>(e->hx);
+    }
+    std::string msg;
+    if (!with_generations(e, [&](auto& cur, auto& next) {
+            e->cmp.n_ids = cur.id_bound();
+            const bool r = next.reserve_like(cur); // regions, pools and tables at their final size: the carry-over grows nothing
+            if (!r) msg = next.error;
+            cur.defer_release = r; // what the serving generation outgrows meanwhile stays readable for the builder
+            return r;
+        })) {
+        e->cmp = bmq_engine::Compaction{};
+        return index_error(e, msg, false);
+    }
+    e->cmp.active = true;
+    return BMQ_OK;
+}
+int bmq_compact_poll(bmq_engine* e, uint32_t max_ids, uint32_t* out_done_permille) {
+    if (!e) return BMQ_E_INVAL;
+    std::lock_guard<std::mutex> gc(e->cmp_mu);
+    bmq_engine::Compaction& c = e->cmp;
+    std::unique_lock<std::mutex> g(e->mu);
+    if (!c.active) return set_err(e, BMQ_E_STATE, "no compaction is running");
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    if (c.cursor < c.n_ids) {
+        const uint32_t hi = (uint32_t)std::min<uint64_t>(c.n_ids, (uint64_t)c.cursor + std::max(max_ids, 1u));
+        std::string msg;
+        // (1) under the engine lock, nothing waited for: the build stream is put behind what the serving generation was told so far and
+        // copies its key references of the chunk.  A mutation that lands later is in the log (routes_apply_common), whichever side of the
+        // copy its effect on a reference falls.
+        if (e->dix) {
+            HIPCHK(e, hipEventRecord(e->ev_serving, e->stream));
+            HIPCHK(e, hipStreamWaitEvent(e->s_build, e->ev_serving, 0));
+        }
+        bool ok = with_generations(e, [&](auto& cur, auto& next) {
+            const bool r = next.import_snapshot(cur, c.cursor, hi);
+            if (!r) msg = next.error;
+            return r;
+        });
+        // (2) the rest touches the generation being built only, on its own stream: matching and mutations go on meanwhile
+        if (ok && e->dix) g.unlock();
+        uint32_t n_live = 0;
+        if (ok) {
+            auto finish = [&](auto& next) {
+                const bool r = next.import_apply(n_live);
+                if (!r) msg = next.error;
+                return r;
+            };
+            ok = c.next_d ? finish(*c.next_d) : finish(*c.next_h);
+        }
+        if (!g.owns_lock()) g.lock();
+        if (!ok) return index_error(e, msg, false);
+        c.carried += n_live;
+        c.cursor = hi;
+    }
+    if (out_done_permille) *out_done_permille = c.n_ids ? (uint32_t)((uint64_t)c.cursor * 1000 / c.n_ids) : 1000u;
+    return BMQ_OK;
+}
+int bmq_compact_swap(bmq_engine* e, uint64_t* out_carried, uint64_t* out_replayed) {
+    if (!e) return BMQ_E_INVAL;
+    std::lock_guard<std::recursive_mutex> api_lock(e->api);
+    std::lock_guard<std::mutex> gc(e->cmp_mu);
+    std::lock_guard<std::mutex> g(e->mu);
+    bmq_engine::Compaction& c = e->cmp;
+    if (!c.active) return set_err(e, BMQ_E_STATE, "no compaction is running");
+    if (c.cursor < c.n_ids) return set_err(e, BMQ_E_STATE, "the next generation is not complete: bmq_compact_poll until it reports 1000");
+    if (int rc = complete_apply(e)) return rc;
+    for (auto& sl : e->slots)
+        if (sl.pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: finish / wait for it first");
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    if (int rc = replay_log(e, 0)) return rc; // what the serving generation was told since bmq_compact_begin, in order
+    if (e->dix) {
+        HIPCHK(e, hipStreamSynchronize(e->s_build));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        c.bx->stream = e->stream; // the executor under the new serving generation works on the engine stream from here on
+        c.bx->upload_stream = e->s_in;
+    }
+    if (out_carried) *out_carried = c.carried;
+    if (out_replayed) *out_replayed = c.log_op.size();
+    with_generations(e, [&](auto& cur, auto& next) {
+        next.generation = cur.generation + 1; // route ids of the two generations are unrelated
+        return true;
+    });
+    e->dfo.reset(); // (the fan-out grouping state belongs to the index it was built over)
+    if (e->dix) e->dix.swap(c.next_d);
+    else e->hix.swap(c.next_h);
+    e->cmp = bmq_engine::Compaction{}; // frees the old generation (and the blocks it outgrew meanwhile)
+    e->epoch++;
+    return BMQ_OK;
+}
+int bmq_compact_abort(bmq_engine* e) {
+    if (!e) return BMQ_E_INVAL;
+    std::lock_guard<std::recursive_mutex> api_lock(e->api);
+    std::lock_guard<std::mutex> gc(e->cmp_mu);
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    if (e->cmp.active) {
+        if (e->dix) {
+            HIPCHK(e, hipStreamSynchronize(e->s_build));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+        }
+        with_index(e, [&](auto& cur) {
+            cur.defer_release = false;
+            cur.release_deferred();
+            return true;
+        });
+    }
+    e->cmp = bmq_engine::Compaction{};
+    return BMQ_OK;
 }
 
 int bmq_index_info_get(const bmq_engine* ce, bmq_index_info* out) {

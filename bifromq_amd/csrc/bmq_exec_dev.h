@@ -59,10 +59,10 @@ __global__ __launch_bounds__(BK) void k_b_bulk_counts(OpBatch ob, uint32_t n_ten
     const uint32_t t = blockIdx.x * BK + threadIdx.x;
     if (t < n_ten) bulk_counts_one(ob, t, n_ten, nn_incl);
 }
-__global__ __launch_bounds__(BK) void k_b_locate(DistIndexMut ix, OpBatch ob) {
+__global__ __launch_bounds__(BK) void k_b_locate(DistIndexMut ix, OpBatch ob, uint32_t phase) {
     if (ix.bc->gate) return;
     const uint32_t i = blockIdx.x * BK + threadIdx.x;
-    if (i < ob.n) locate_one(ix, ob, i);
+    if (i < ob.n) locate_one(ix, ob, i, phase);
 }
 __global__ __launch_bounds__(BK) void k_b_group(DistIndexMut ix, OpBatch ob) {
     if (ix.bc->gate) return;
@@ -208,7 +208,7 @@ struct DevExec {
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     bool upload_async(void* d, const void* s, size_t n) {
-        return n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, upload_stream ? upload_stream : stream));
+        return n == 0 || BMQ_X(hipMemcpyAsync(d, s, n, hipMemcpyDefault, upload_stream ? upload_stream : stream)); // (s: host or device memory)
     }
     bool uploads_done() {
         if (!upload_stream) return true;
@@ -285,7 +285,12 @@ struct DevExec {
         return launched();
     }
     bool locate(const DistIndexMut& ix, const OpBatch& ob) {
-        hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob);
+        if (!ob.op) {
+            hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, 2u);
+            return launched();
+        }
+        hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, 0u); // the puts: filter nodes come into being
+        hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, 1u); // the deletes: they find them
         return launched();
     }
     bool sort_targets(const OpBatch& ob) { // stable: ops on one target stay in op order.  Values = op indices.

@@ -97,7 +97,12 @@ struct HostExec {
         return true;
     }
     bool locate(const DistIndexMut& ix, const OpBatch& ob) {
-        par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i); });
+        if (!ob.op) {
+            par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i, 2u); });
+            return true;
+        }
+        par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i, 0u); });
+        par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i, 1u); });
         return true;
     }
     bool sort_targets(const OpBatch& ob) {

@@ -256,6 +256,27 @@ class Engine:
         self._check(_lib.lib().bmq_compact(self.h))
         return self
 
+    def compact_begin(self):
+        """bmq_compact_begin: the next generation of the route index starts being built beside the serving one"""
+        self._check(_lib.lib().bmq_compact_begin(self.h))
+        return self
+
+    def compact_poll(self, max_ids: int = 8192) -> int:
+        """bmq_compact_poll: hands the next max_ids route ids' live keys to the builder -> progress in permille (1000: ready to swap)"""
+        done = C.c_uint32()
+        self._check(_lib.lib().bmq_compact_poll(self.h, max_ids, C.byref(done)))
+        return int(done.value)
+
+    def compact_swap(self) -> Tuple[int, int]:
+        """bmq_compact_swap: replays what was mutated meanwhile, swaps the generations -> (keys carried over, ops replayed)"""
+        carried, replayed = C.c_uint64(), C.c_uint64()
+        self._check(_lib.lib().bmq_compact_swap(self.h, C.byref(carried), C.byref(replayed)))
+        return int(carried.value), int(replayed.value)
+
+    def compact_abort(self):
+        self._check(_lib.lib().bmq_compact_abort(self.h))
+        return self
+
     def info(self) -> _lib.IndexInfo:
         out = _lib.IndexInfo()
         self._check(_lib.lib().bmq_index_info_get(self.h, C.byref(out)))

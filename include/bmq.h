@@ -138,6 +138,21 @@ int bmq_routes_apply_wait(bmq_engine* e);
  * behind until then -- abandoned tenant regions and id lists, trie nodes and dictionary tokens of filters nobody subscribes to any
  * more (bmq_index_info.garbage_bytes) -- and re-numbers the route ids to ranks: a new generation, like bmq_rebuild. */
 int bmq_compact(bmq_engine* e);
+/* The same without the stall (TopicLevelTrie contracts as it goes, UTIL/index/TopicLevelTrie.java:257-384; GenerationalRangeIndex.java /
+ * bifromq_amd/generations.py did this with two handles on the caller's side, shipping every key through the host).  The next generation of
+ * the route index is built BESIDE the serving one, inside the engine, from the serving generation's live keys -- gathered and handed over on
+ * the device: the key bytes never leave HBM, nothing is sorted on the host --, in chunks the caller paces:
+ *   bmq_compact_begin   starts one (BMQ_E_STATE while one is running; bmq_rebuild / bmq_compact are refused until it is swapped or aborted)
+ *   bmq_compact_poll    hands the next max_ids route ids' live keys to the builder (kernels on the engine stream, between the match batches:
+ *                       a chunk of 8192 ids costs a batch queued behind it ~0.2 ms); *out_done_permille = 1000: ready to swap.  Matching
+ *                       and bmq_routes_apply[_async] go on in between: what is mutated meanwhile is logged.
+ *   bmq_compact_swap    replays the log, swaps the generations (no batch may be in flight: BMQ_E_STATE) and frees the old one.  Route ids are
+ *                       re-numbered: bmq_index_info.generation + 1, ids of the old generation mean nothing any more (as after bmq_compact).
+ *   bmq_compact_abort   drops the half-built generation. */
+int bmq_compact_begin(bmq_engine* e);
+int bmq_compact_poll(bmq_engine* e, uint32_t max_ids, uint32_t* out_done_permille);
+int bmq_compact_swap(bmq_engine* e, uint64_t* out_carried /* may be NULL */, uint64_t* out_replayed /* may be NULL */);
+int bmq_compact_abort(bmq_engine* e);
 
 int bmq_index_info_get(const bmq_engine* e, bmq_index_info* out);
 /* id -> key (so the Java adapter can materialise Matching objects, SCHEMA/KVSchemaUtil.java:73-89).  BMQ_E_INVAL: no such

@@ -439,6 +439,27 @@ def test_apply_creates_and_removes_tenants(eng):
         assert U.rows_as_ranks(eng, row, ids, keys) == U.semantic_rows(kv, tn, tt, tp)
 
 
+def test_ops_of_one_batch_apply_in_order_also_when_the_filter_is_new(eng):
+    """One batch = one ordered stream (ISubscriptionCache.refresh applies mutations in arrival order): subscribe to a filter nobody had,
+    unsubscribe again -- thousands of such pairs, so that the deletes' lanes would run beside the puts' -- leaves nothing; delete / put /
+    delete of an existing route leaves it deleted; put / delete / put leaves it there.  (Round 5: the locate stage took puts and deletes
+    in one pass, and a delete whose filter node was being created by a put of the same batch was dropped as "no such filter".)"""
+    base = [_normal("t1", "a/%d/+" % i, 0, "r%d" % i, "d") for i in range(200)]
+    eng.rebuild(base)
+    n = 20000
+    fresh = [_normal("t%d" % (i % 3), "fresh/%d/x%d/#" % (i, i % 7), 0, "f%d" % i, "d") for i in range(n)]   # t0, t2: tenants born in the batch too
+    stay = [_normal("t1", "stay/%d" % i, 0, "s%d" % i, "d") for i in range(500)]
+    ops = [(0, k) for k in fresh] + [(1, base[3]), (0, base[3]), (1, base[3])] + [(0, k) for k in stay] + [(1, k) for k in fresh] + \
+          [(0, stay[5]), (1, stay[5]), (0, stay[5])]
+    eng.apply(ops)
+    live = sorted(set(base) - {base[3]} | set(stay))
+    info = eng.info()
+    assert info.n_routes == len(live)
+    assert sorted(k for k in eng.route_keys(np.arange(int(info.next_route_id), dtype=np.uint32)) if k) == live
+    row, ids = eng.match_batch(["t0", "t1", "t2"], [0, 1, 2, 1], ["fresh/0/x0/y", "stay/5", "fresh/2/x2", "a/3/q"])
+    assert [len(r) for r in U.csr_rows(row, ids)] == [0, 1, 0, 0]
+
+
 def test_edge_shapes(eng):
     """maximum-size and degenerate inputs: a 65535-byte topic of 32768 empty levels, a 60000-byte single level, batches of
     one topic, only-slash topics, levels longer than the 16-byte inline prefix that differ only in their tail."""

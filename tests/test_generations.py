@@ -175,3 +175,134 @@ def test_matching_through_the_generations_on_the_gpu():
         got1 = rows_as_keys(eng)
     assert got1 == expected()
     g.close()
+
+
+def test_compaction_entry_points_refuse_what_they_cannot_do():
+    """_poll / _swap without a compaction running are state errors, _abort is idempotent, _begin needs an index."""
+    eng = B.Engine(device=-1)
+    try:
+        with pytest.raises(B.BmqError) as ei:
+            eng.compact_begin()
+        assert ei.value.code == -7
+        eng.rebuild(sorted(_key(i) for i in range(20)))
+        for f in (eng.compact_poll, eng.compact_swap):
+            with pytest.raises(B.BmqError) as ei:
+                f()
+            assert ei.value.code == -7
+        eng.compact_abort().compact_abort()
+    finally:
+        eng.close()
+
+
+def _compaction_inside_the_engine(device, n_tenants, per_tenant, n_topics, chunk):
+    """bmq_compact_begin / _poll / _swap through ctypes: the next generation is built inside ONE handle (on the device: from keys that never
+    leave it), mutation batches (blocking and async) -- and on a GPU match batches -- land between the polls, and after the swap the key set
+    and the matched rows equal the model / the semantic oracle key for key, the garbage is gone and the ids are dense again (+ what was
+    replayed).  bmq_rebuild / bmq_compact are refused meanwhile.  device = -1: the same code over the host executor, nothing is matched."""
+    from oracle import oracle as O
+    from tests import util as U
+
+    w = B.Workload(0xB1F20051, n_tenants, per_tenant, 1)
+    keys = w.keys()
+    tn = w.tenants()
+    data, off, tt = w.topics(5, n_topics)
+    topics = [bytes(data[off[i]:off[i + 1]]) for i in range(len(tt))]
+    eng = B.Engine(device=device)
+    try:
+        eng.rebuild(keys)
+        model = set(keys)
+        rng = np.random.default_rng(7)
+        serial, progress = [0], [-1]
+
+        def churn(n, async_=False):
+            ks = sorted(model)
+            dels = [ks[int(i)] for i in rng.choice(len(ks), size=n, replace=False)]
+            adds = [B.route_key(tn[int(rng.integers(0, len(tn)))], "gen/%d/+" % (serial[0] + j), 1, "0\0g%d\0d" % j) for j in range(n)]
+            adds.append(B.route_key("tenant-born-%d" % serial[0], "x/#", 1, "0\0nb\0d"))   # a tenant the next generation has no region for
+            serial[0] += n
+            ops = [(1, k) for k in dels] + [(0, k) for k in adds] + [(0, dels[0]), (1, dels[0])]   # order inside one stream matters
+            (eng.apply_async if async_ and device >= 0 else eng.apply)(ops)   # (page-locked buffers need a GPU)
+            for o, k in ops:
+                history.setdefault(k, []).append(("put" if o == 0 else "del", serial[0], "async" if async_ else "blocking", "at %d permille" % progress[0]))
+            model.difference_update(dels)
+            model.update(adds)
+
+        def live_keys():
+            return sorted(k for k in eng.route_keys(np.arange(int(eng.info().next_route_id), dtype=np.uint32)) if k)
+
+        history = {}   # key -> what the test did with it, for the message of a failing comparison
+
+        def check_rows():
+            live = live_keys()
+            if live != sorted(model):
+                extra, missing = sorted(set(live) - model), sorted(model - set(live))
+                dup = len(live) - len(set(live))
+                raise AssertionError("key set differs: %d extra %d missing %d stored twice; extra: %r; missing: %r" % (
+                    len(extra), len(missing), dup, [(k, history.get(k)) for k in extra[:6]], [(k, history.get(k)) for k in missing[:6]]))
+            if device < 0:
+                return
+            row, ids = eng.match_batch(tn, tt, topics)
+            ks = eng.route_keys(ids)
+            got = [sorted(ks[row[i]:row[i + 1]]) for i in range(len(tt))]
+            srt = sorted(model)
+            kv = O.KV(srt)
+            assert got == [sorted(srt[x] for x in r) for r in U.semantic_rows(kv, tn, tt, topics)]
+
+        churn(len(keys) // 7)             # garbage first: a seventh of the routes deleted, as many new ones
+        info0 = eng.info()
+        assert info0.next_route_id > info0.n_routes == len(model)
+        eng.compact_begin()
+        with pytest.raises(B.BmqError) as ei:
+            eng.compact_begin()
+        assert ei.value.code == -7
+        for f in (eng.compact, lambda: eng.rebuild(keys)):
+            with pytest.raises(B.BmqError) as ei:
+                f()
+            assert ei.value.code == -7
+        with pytest.raises(B.BmqError) as ei:
+            eng.compact_swap()            # not complete yet
+        assert ei.value.code == -7
+        polls, done = 0, 0
+        while done < 1000:
+            done = progress[0] = eng.compact_poll(chunk)
+            polls += 1
+            if polls % 3 == 1:
+                churn(len(keys) // 200, async_=(polls % 2 == 0))   # some hit keys already carried over, some keys not yet, some are new
+            if polls == 4:
+                check_rows()              # the serving generation serves, mutations included
+            assert polls < 200
+        assert polls >= 8
+        carried, replayed = eng.compact_swap()
+        info1 = eng.info()
+        check_rows()
+        assert info1.generation == info0.generation + 1 and info1.n_routes == len(model)
+        assert replayed > 0 and carried >= info0.n_routes - replayed
+        assert info1.next_route_id - info1.n_routes <= replayed        # at most the replayed ops' garbage, not the old generation's
+        check_rows()
+        # the generation after the swap is an ordinary index: mutations, another compaction without mutations meanwhile -> dense ids
+        churn(len(keys) // 100)
+        eng.compact_begin()
+        while eng.compact_poll(1 << 20) < 1000:
+            pass
+        carried2, replayed2 = eng.compact_swap()
+        info2 = eng.info()
+        assert replayed2 == 0 and carried2 == len(model) == info2.n_routes == info2.next_route_id and info2.garbage_bytes == 0
+        assert info2.device_bytes <= info1.device_bytes or device < 0
+        check_rows()
+        # abort drops the half-built generation; the serving one is untouched
+        eng.compact_begin()
+        eng.compact_poll(1000)
+        eng.compact_abort()
+        assert eng.info().generation == info2.generation
+        check_rows()
+    finally:
+        eng.close()
+
+
+def test_compaction_inside_the_engine_over_the_host_executor():
+    _compaction_inside_the_engine(-1, 6, 400, 10, 250)
+
+
+@pytest.mark.gpu
+def test_compaction_inside_the_engine_between_batches_and_mutations():
+    _compaction_inside_the_engine(0, 12, 2500, 3000, 3000)

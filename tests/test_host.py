@@ -412,3 +412,27 @@ def test_walk_geometry_caps_are_a_selector():
         with pytest.raises(B.BmqError) as ei:
             B.Engine(device=-1, **bad)
         assert ei.value.code == -1  # BMQ_E_INVAL
+
+
+def test_ops_of_one_batch_apply_in_order_also_when_the_filter_is_new():
+    """tests/test_dist_gpu.py's test of the same name over the host executor (its par() runs the ops of a large batch on several threads)."""
+    import bifromq_amd as B
+    from oracle import oracle as O
+
+    def normal(tenant, tf, recv):
+        return B.route_key_from_mqtt(tenant, tf, O.receiver_url(0, recv, "d"))
+    eng = B.Engine(device=-1)
+    try:
+        base = [normal("t1", "a/%d/+" % i, "r%d" % i) for i in range(200)]
+        eng.rebuild(base)
+        fresh = [normal("t%d" % (i % 3), "fresh/%d/x%d/#" % (i, i % 7), "f%d" % i) for i in range(20000)]
+        stay = [normal("t1", "stay/%d" % i, "s%d" % i) for i in range(500)]
+        ops = [(0, k) for k in fresh] + [(1, base[3]), (0, base[3]), (1, base[3])] + [(0, k) for k in stay] + [(1, k) for k in fresh] + \
+              [(0, stay[5]), (1, stay[5]), (0, stay[5])]
+        eng.apply(ops)
+        live = sorted(set(base) - {base[3]} | set(stay))
+        info = eng.info()
+        assert info.n_routes == len(live)
+        assert sorted(k for k in eng.route_keys(np.arange(int(info.next_route_id), dtype=np.uint32)) if k) == live
+    finally:
+        eng.close()
