@@ -1,5 +1,9 @@
 """Compaction that does not stop the world -- on the CALLER's side of the C-ABI, with two engine handles.
 
+(Round 5: the engine does this itself, inside one handle and without shipping the keys through the host -- bmq_compact_begin / _poll / _swap,
+Engine.compact_begin / compact_poll / compact_swap.  This module stays as the variant that needs nothing below the boundary, and for a caller
+that wants the old generation to keep answering for its own ids until the last reader has left.)
+
 What it answers: TopicLevelTrie contracts tombed nodes as it goes (bifromq-util/.../index/TopicLevelTrie.java:257-384); here dead ids,
 abandoned regions and id lists only grow until `bmq_compact`, which rebuilds the index inside the engine and holds every entry point for the
 length of a bulk load.  The same rebuild can run BESIDE the serving index instead:

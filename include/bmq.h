@@ -140,15 +140,20 @@ int bmq_routes_apply_wait(bmq_engine* e);
 int bmq_compact(bmq_engine* e);
 /* The same without the stall (TopicLevelTrie contracts as it goes, UTIL/index/TopicLevelTrie.java:257-384; GenerationalRangeIndex.java /
  * bifromq_amd/generations.py did this with two handles on the caller's side, shipping every key through the host).  The next generation of
- * the route index is built BESIDE the serving one, inside the engine, from the serving generation's live keys -- gathered and handed over on
- * the device: the key bytes never leave HBM, nothing is sorted on the host --, in chunks the caller paces:
- *   bmq_compact_begin   starts one (BMQ_E_STATE while one is running; bmq_rebuild / bmq_compact are refused until it is swapped or aborted)
- *   bmq_compact_poll    hands the next max_ids route ids' live keys to the builder (kernels on the engine stream, between the match batches:
- *                       a chunk of 8192 ids costs a batch queued behind it ~0.2 ms); *out_done_permille = 1000: ready to swap.  Matching
- *                       and bmq_routes_apply[_async] go on in between: what is mutated meanwhile is logged.
+ * the route index is built BESIDE the serving one, inside the engine: on its own executor and a lowest-priority stream, from the serving
+ * generation's live keys -- gathered HBM to HBM: the key bytes never leave the device, nothing is sorted on the host --, in chunks the caller
+ * paces from a maintenance thread while its matcher threads go on:
+ *   bmq_compact_begin   starts one: sizes the next generation's regions, pools and tables from the serving one's (BMQ_E_STATE while one is
+ *                       running; bmq_rebuild / bmq_compact are refused until it is swapped or aborted).
+ *   bmq_compact_poll    carries the live keys among the next max_ids route ids over.  The engine lock is held only while the build stream is
+ *                       put behind what the serving generation was told so far and a copy of the chunk's key references is ENQUEUED; the
+ *                       gather, the builder kernels and the waits touch the new generation alone.  *out_done_permille = 1000: ready to swap.
+ *                       Matching and bmq_routes_apply[_async] go on meanwhile; what is mutated is logged.  Measured (bench.py, compaction
+ *                       leg: 10 M routes, 1 M-publish batches back to back on another thread): batch p99 0.35 -> 0.60 ms while it runs.
  *   bmq_compact_swap    replays the log, swaps the generations (no batch may be in flight: BMQ_E_STATE) and frees the old one.  Route ids are
  *                       re-numbered: bmq_index_info.generation + 1, ids of the old generation mean nothing any more (as after bmq_compact).
- *   bmq_compact_abort   drops the half-built generation. */
+ *   bmq_compact_abort   drops the half-built generation.
+ * One compaction call at a time (they serialise among themselves); a host-only engine runs the same procedure over the host executor. */
 int bmq_compact_begin(bmq_engine* e);
 int bmq_compact_poll(bmq_engine* e, uint32_t max_ids, uint32_t* out_done_permille);
 int bmq_compact_swap(bmq_engine* e, uint64_t* out_carried /* may be NULL */, uint64_t* out_replayed /* may be NULL */);

@@ -36,6 +36,17 @@ final class NativeMatcher {
     /** bmq_index_info: {routes, tenants, nodes, tokens, trieSlots, dictSlots, deviceBytes, epoch, generation, nextRouteId, garbageBytes}. */
     static native void indexInfo(long engine, long[] out11);
 
+    /** bmq_compact_begin / _poll / _swap / _abort: the next generation of the route index is built beside the serving one INSIDE the handle (its own
+     *  stream, keys that never leave HBM); compactPoll(maxIds) from a maintenance thread until it returns 1000, then compactSwap (no batch in flight;
+     *  route ids are re-numbered: everything keyed by route id is re-created).  GenerationalRangeIndex is the same with two handles. */
+    static native void compactBegin(long engine);
+
+    static native int compactPoll(long engine, int maxIds);
+
+    static native void compactSwap(long engine, long[] out2);
+
+    static native void compactAbort(long engine);
+
     /** One device gather: outOff[n + 1] byte offsets into out.  @return bytes, or -(needed) */
     static native long routeKeys(long engine, IntBuffer ids, int n, ByteBuffer out, LongBuffer outOff);
 

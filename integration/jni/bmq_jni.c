@@ -327,6 +327,39 @@ JNIEXPORT void JNICALL NM(retainInfo)(JNIEnv* env, jclass c, jlong h, jlongArray
                         (jlong)ri.added_ids, (jlong)ri.overlay_nodes, (jlong)ri.epoch, (jlong)ri.generation};
     (*env)->SetLongArrayRegion(env, out, 0, 9, v);
 }
+/* Compaction without a stall, inside ONE handle (include/bmq.h: bmq_compact_begin / _poll / _swap / _abort): the next generation is built beside the
+ * serving one, on its own stream, from keys that never leave HBM; the adapter paces it with compactPoll from a maintenance thread while its
+ * matcher threads go on, and re-creates what belongs to a generation (id -> Matching cache, route cache) after compactSwap.
+ * void compactBegin(long engine) / int compactPoll(long engine, int maxIds) -> progress in permille / void compactSwap(long engine, long[] out2
+ * {keys carried over, ops replayed}) / void compactAbort(long engine) */
+JNIEXPORT void JNICALL NM(compactBegin)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    const int rc = bmq_compact_begin(ENGINE(h));
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_compact_begin", rc);
+}
+JNIEXPORT jint JNICALL NM(compactPoll)(JNIEnv* env, jclass c, jlong h, jint maxIds) {
+    (void)c;
+    uint32_t done = 0;
+    const int rc = bmq_compact_poll(ENGINE(h), (uint32_t)maxIds, &done);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_compact_poll", rc);
+    return (jint)done;
+}
+JNIEXPORT void JNICALL NM(compactSwap)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
+    (void)c;
+    uint64_t carried = 0, replayed = 0;
+    const int rc = bmq_compact_swap(ENGINE(h), &carried, &replayed);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_compact_swap", rc);
+        return;
+    }
+    const jlong v[2] = {(jlong)carried, (jlong)replayed};
+    if (out) (*env)->SetLongArrayRegion(env, out, 0, 2, v);
+}
+JNIEXPORT void JNICALL NM(compactAbort)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    const int rc = bmq_compact_abort(ENGINE(h));
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_compact_abort", rc);
+}
 /* void indexInfo(long engine, long[] out11)   out = bmq_index_info {routes, tenants, nodes, tokens, trieSlots, dictSlots, deviceBytes, epoch, generation,
  * nextRouteId, garbageBytes} -- nextRouteId bounds the ids GenerationalRangeIndex exports, garbageBytes tells it when a compaction pays */
 JNIEXPORT void JNICALL NM(indexInfo)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
