@@ -66,7 +66,7 @@ def main():
                     help="N = 1: skip the compact extra legs (configs[4] churn on this index, the batching front at 64 threads, C2 and C4 as "
                          "child runs) that the default run appends under `extra`")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-visible (PCIe-inclusive) measurement")
-    ap.add_argument("--compact-chunk", type=int, default=65536, help="compaction leg: route ids handed to the next generation's builder per bmq_compact_poll")
+    ap.add_argument("--compact-chunk", type=int, default=8192, help="compaction leg: route ids handed to the next generation's builder per bmq_compact_poll")
     ap.add_argument("--compact-duty", type=float, default=0.5, help="compaction leg: share of its time the compacting thread spends inside bmq_compact_poll")
     ap.add_argument("--no-churn", action="store_true", help="--workload c4: skip the add / remove leg (A/B runs of the walk kernel)")
     ap.add_argument("--batcher-threads", type=int, default=-1,
