@@ -28,6 +28,12 @@ final class NativeMatcher {
     /** Post-commit AddRoutesTask / RemoveRoutesTask: ops[i] 0 = put, 1 = delete; applied in order. */
     static native void routesApply(long engine, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n);
 
+    /** bmq_routes_apply_async / _wait: uploaded beside the batch in flight, applied behind it; the buffers stay untouched until routesApplyWait
+     *  (or the next call that needs the route index) has returned -- that call throws what routesApply would have thrown. */
+    static native void routesApplyAsync(long engine, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n);
+
+    static native void routesApplyWait(long engine);
+
     static native long epoch(long engine);
 
     /** +1 per rebuild: route ids are stable handles within a generation (a deleted route's id resolves to an empty key). */

@@ -72,6 +72,20 @@ JNIEXPORT void JNICALL NM(routesApply)(JNIEnv* env, jclass c, jlong h, jobject k
     const int rc = bmq_routes_apply(ENGINE(h), (const uint8_t*)ADDR(keys), (const uint32_t*)ADDR(keyOff), (const uint8_t*)ADDR(ops), (uint32_t)n);
     if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_routes_apply", rc);
 }
+/* void routesApplyAsync(long engine, ByteBuffer keys, IntBuffer keyOff, ByteBuffer ops, int n) / void routesApplyWait(long engine)
+ * bmq_routes_apply_async / _wait: the ops are uploaded beside the batch in flight and applied behind it; the call returns after the enqueue.
+ * The three DIRECT buffers (page-locked ones from hostAlloc make the upload a DMA) must stay alive and unchanged until routesApplyWait --
+ * or any other call that reads or changes the route index -- has returned; that call throws what routesApply would have thrown. */
+JNIEXPORT void JNICALL NM(routesApplyAsync)(JNIEnv* env, jclass c, jlong h, jobject keys, jobject keyOff, jobject ops, jint n) {
+    (void)c;
+    const int rc = bmq_routes_apply_async(ENGINE(h), (const uint8_t*)ADDR(keys), (const uint32_t*)ADDR(keyOff), (const uint8_t*)ADDR(ops), (uint32_t)n);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_routes_apply_async", rc);
+}
+JNIEXPORT void JNICALL NM(routesApplyWait)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    const int rc = bmq_routes_apply_wait(ENGINE(h));
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_routes_apply_wait", rc);
+}
 /* long epoch(long engine) */
 JNIEXPORT jlong JNICALL NM(epoch)(JNIEnv* env, jclass c, jlong h) {
     (void)c;
