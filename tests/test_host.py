@@ -154,7 +154,9 @@ def test_host_index_fuzz_under_sanitizers():
     the same host control (bmq_dist_index.h) -- on host threads under ASan + UBSan and under TSan: random rebuild / apply
     sequences with minimal initial capacities (every growth path runs all the time); after every step ids must follow the ABI's
     rule (ranks after a rebuild, next unused id for an adding put, stable otherwise) and a CPU walk over the image (directory,
-    regions, dictionary, exactly the probes k_walk does) must give the brute-force result of the matching rule."""
+    regions, dictionary, exactly the probes k_walk does) must give the brute-force result of the matching rule.  Round 5: every fourth
+    round also builds the NEXT GENERATION beside the index (reserve_like, import_snapshot / import_apply in chunks of random size, the
+    index mutated between a chunk's snapshot and its apply, the log replayed as one merged batch): its key set must be the model's."""
     import subprocess
     csrc = os.path.join(ROOT, "bifromq_amd", "csrc")
     subprocess.run(["make", "-C", csrc, "fuzz"], check=True, capture_output=True, timeout=600)

@@ -184,7 +184,7 @@ int main(int argc, char** argv) {
     hx.threads = threads;
     DistIndex<HostExec> h(hx);
     h.tiny = getenv("BMQ_FUZZ_BIG") == nullptr;
-    uint64_t checks = 0, n_apply = 0, n_rebuild = 0, fo_pairs = 0;
+    uint64_t checks = 0, n_apply = 0, n_rebuild = 0, fo_pairs = 0, n_generations = 0;
     Fanout<HostExec> fo(hx, h); // fan-out grouping (bmq_fanout.h) over the same index, kept across rebuilds and applies
     fo.initial_table = 4;       // 36 deliverer keys: the group table grows twice
     for (int round = 0; round < rounds; round++) {
@@ -284,6 +284,108 @@ int main(int argc, char** argv) {
                 }
                 i++;
             }
+        }
+        // ---- a generation change beside this index (bmq_compact_begin / _poll / _swap: DistIndex::reserve_like, import_snapshot, import_apply,
+        // the log, its replay): chunks of random size, `h` mutated between a chunk's snapshot and its apply and between the chunks; afterwards
+        // the new generation holds exactly the model's keys, with dense ids + at most the replayed ops' garbage.  `h` stays the index of the
+        // following rounds (the engine would swap the two).
+        if (h.built && rnd(4) == 0) {
+            DistIndex<HostExec> g(hx);
+            g.tiny = h.tiny;
+            if (!g.reserve_like(h)) {
+                fprintf(stderr, "round %d: reserve_like failed: %s\n", round, g.error.c_str());
+                return 1;
+            }
+            h.defer_release = true;
+            std::vector<std::string> log_keys;
+            std::vector<uint8_t> log_ops;
+            auto mutate = [&]() -> bool { // a small batch into h, the model and the log
+                std::vector<std::string> mk;
+                std::vector<uint8_t> mo;
+                const size_t n = 1 + rnd(40);
+                for (size_t i = 0; i < n; i++) {
+                    if (!model.empty() && rnd(2)) {
+                        auto it = model.begin();
+                        std::advance(it, rnd(std::min<size_t>(model.size(), 500)));
+                        mk.push_back(it->first);
+                        mo.push_back(1);
+                    } else {
+                        mk.push_back(rnd(5) == 0 && !mk.empty() ? mk[rnd(mk.size())] : rand_key());
+                        mo.push_back(0);
+                    }
+                }
+                uint32_t put_no = 0;
+                for (size_t i = 0; i < mk.size(); i++) {
+                    if (mo[i]) model.erase(mk[i]);
+                    else {
+                        if (!model.count(mk[i])) model[mk[i]] = next_id + put_no;
+                        put_no++;
+                    }
+                }
+                next_id += put_no;
+                std::vector<uint8_t> mb;
+                std::vector<uint32_t> mf{0};
+                for (auto& k : mk) {
+                    mb.insert(mb.end(), k.begin(), k.end());
+                    mf.push_back((uint32_t)mb.size());
+                }
+                mb.resize(mb.size() + 16, 0);
+                log_keys.insert(log_keys.end(), mk.begin(), mk.end());
+                log_ops.insert(log_ops.end(), mo.begin(), mo.end());
+                n_apply++;
+                return h.apply(mb.data(), mf.data(), mo.data(), (uint32_t)mk.size());
+            };
+            const uint32_t n_ids = h.id_bound();
+            uint64_t carried = 0;
+            for (uint32_t cursor = 0; cursor < n_ids;) {
+                const uint32_t hi = (uint32_t)std::min<uint64_t>(n_ids, (uint64_t)cursor + 1 + rnd(rnd(3) == 0 ? 2000 : 150));
+                uint32_t n_live = 0;
+                if (!g.import_snapshot(h, cursor, hi) || (rnd(3) == 0 && !mutate()) || !g.import_apply(n_live)) {
+                    fprintf(stderr, "round %d: generation change failed at id %u: %s | %s\n", round, cursor, g.error.c_str(), h.error.c_str());
+                    return 1;
+                }
+                carried += n_live;
+                cursor = hi;
+                if (rnd(4) == 0 && !mutate()) {
+                    fprintf(stderr, "round %d: apply during a generation change failed: %s\n", round, h.error.c_str());
+                    return 1;
+                }
+            }
+            if (!log_keys.empty()) { // the replay: ONE merged batch, in order
+                std::vector<uint8_t> mb;
+                std::vector<uint32_t> mf{0};
+                for (auto& k : log_keys) {
+                    mb.insert(mb.end(), k.begin(), k.end());
+                    mf.push_back((uint32_t)mb.size());
+                }
+                mb.resize(mb.size() + 16, 0);
+                if (!g.apply(mb.data(), mf.data(), log_ops.data(), (uint32_t)log_keys.size())) {
+                    fprintf(stderr, "round %d: replay failed: %s\n", round, g.error.c_str());
+                    return 1;
+                }
+            }
+            h.defer_release = false;
+            h.release_deferred();
+            DistIndexStats gs;
+            g.stats(gs);
+            if (gs.n_routes != model.size() || gs.next_id - gs.n_routes > log_keys.size()) {
+                fprintf(stderr, "round %d: new generation: %llu routes (model %zu), %u ids, %zu ops replayed, %llu carried\n", round,
+                        (unsigned long long)gs.n_routes, model.size(), gs.next_id, log_keys.size(), (unsigned long long)carried);
+                return 1;
+            }
+            std::vector<uint32_t> ids(gs.next_id);
+            for (uint32_t i = 0; i < gs.next_id; i++) ids[i] = i;
+            std::vector<uint8_t> kb;
+            std::vector<uint64_t> ko;
+            if (!g.route_keys(ids.data(), gs.next_id, kb, ko)) return 3;
+            std::set<std::string> got;
+            for (uint32_t i = 0; i < gs.next_id; i++)
+                if (ko[i + 1] > ko[i]) got.insert(std::string((const char*)kb.data() + ko[i], ko[i + 1] - ko[i]));
+            if (got.size() != model.size() || !std::equal(got.begin(), got.end(), model.begin(), [](const std::string& a, const auto& b) { return a == b.first; })) {
+                fprintf(stderr, "round %d: the new generation's key set differs from the model (%zu keys against %zu)\n", round, got.size(), model.size());
+                return 1;
+            }
+            n_generations++;
         }
         // decoded form of the model, for the brute force
         struct Dec {
@@ -401,9 +503,9 @@ int main(int argc, char** argv) {
     }
     DistIndexStats st;
     h.stats(st);
-    printf("host_fuzz ok: seed %llu, %d rounds (%llu rebuilds, %llu applies), %llu topic checks, final %zu routes, %llu nodes, %llu tokens, "
+    printf("host_fuzz ok: seed %llu, %d rounds (%llu rebuilds, %llu applies, %llu generation changes), %llu topic checks, final %zu routes, %llu nodes, %llu tokens, "
            "%llu trie slots (%llu garbage), %llu id-list words (%llu garbage), %llu fan-out pairs grouped\n",
-           (unsigned long long)seed, rounds, (unsigned long long)n_rebuild, (unsigned long long)n_apply, (unsigned long long)checks, model.size(),
+           (unsigned long long)seed, rounds, (unsigned long long)n_rebuild, (unsigned long long)n_apply, (unsigned long long)n_generations, (unsigned long long)checks, model.size(),
            (unsigned long long)st.n_nodes, (unsigned long long)st.n_tokens, (unsigned long long)st.trie_slots, (unsigned long long)st.trie_garbage_slots,
            (unsigned long long)st.id_list_words, (unsigned long long)st.id_list_garbage, (unsigned long long)fo_pairs);
     return 0;
