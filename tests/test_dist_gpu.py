@@ -755,6 +755,12 @@ def test_apply_async_lands_behind_a_submitted_batch(eng):
         pd, po, pt = pinned(len(data), np.uint8), pinned(len(off), np.uint32), pinned(len(tt), np.uint32)
         pd[:], po[:], pt[:] = data, off, tt
         rows, ids = pinned(40000, np.uint32), pinned(8_000_000, np.uint32)
+        # (every ticket slot once, so that its buffers have their size and the engine knows the batch is not grouped by tenant: a batch that does
+        # not fit, or that wants the other k_walk instantiation, is run AGAIN by bmq_match_wait -- against the index as it is then, mutations
+        # queued behind the first run included)
+        warm = [eng.match_submit(p_t, p_to, len(tn), pt, pd, po, len(tt)) for _ in range(3)]
+        for t in warm:
+            eng.match_wait(t, rows, ids)
         rnd = random.Random(5)
         batches = []
         dels = rnd.sample(range(len(keys)), 600)
