@@ -153,7 +153,10 @@ int bmq_compact(bmq_engine* e);
  *   bmq_compact_swap    replays the log, swaps the generations (no batch may be in flight: BMQ_E_STATE) and frees the old one.  Route ids are
  *                       re-numbered: bmq_index_info.generation + 1, ids of the old generation mean nothing any more (as after bmq_compact).
  *   bmq_compact_abort   drops the half-built generation.
- * One compaction call at a time (they serialise among themselves); a host-only engine runs the same procedure over the host executor. */
+ * One compaction call at a time (they serialise among themselves; call them from a maintenance thread, not from the matcher threads); a
+ * host-only engine runs the same procedure over the host executor.  The log of mutations lives in host memory and grows until
+ * bmq_compact_swap / _abort: a caller that begins a compaction finishes it.  Only the route index is covered (retained topics:
+ * bmq_retain_compact). */
 int bmq_compact_begin(bmq_engine* e);
 int bmq_compact_poll(bmq_engine* e, uint32_t max_ids, uint32_t* out_done_permille);
 int bmq_compact_swap(bmq_engine* e, uint64_t* out_carried /* may be NULL */, uint64_t* out_replayed /* may be NULL */);
