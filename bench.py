@@ -574,7 +574,7 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
             extra[wl] = {"error": repr(ex)}
     # configs[4] on the C3 index of this run: 5 steps, each = bmq_routes_apply(100 k ops from pinned memory) + the 1 M-publish batch
     try:
-        n_ops, n_steps = 100_000, 6
+        n_ops, n_steps = 100_000, 10  # (5 pipelined + 5 blocking: 3 + 3 gave numbers that moved 15 % from run to run)
         rng = np.random.default_rng(4321)
         kb_h, ko_h = w.keys_packed()
         mv = memoryview(kb_h)
