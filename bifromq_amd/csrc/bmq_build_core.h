@@ -249,10 +249,49 @@ BMQ_HD uint64_t tenant_hash_bytes(const uint8_t* b, unsigned long long beg, unsi
     for (unsigned long long i = beg; i < end; i++) h = tenant_hash_step(h, b[i]);
     return tenant_hash_final(h);
 }
+// 16 bytes at byte offset p (any alignment) as four little-endian words, the bytes from n on (n <= 16) read as zero.  Five aligned words,
+// requested together: ONE memory latency instead of sixteen (a byte loop waits for every byte; the builder's lanes run at 1-2 waves per SIMD,
+// nothing hides a latency there).  Key-pool only: the pool is readable 32 bytes past its last key (DistIndex::ensure_keys).
+BMQ_HD void bytes_chunk16(const uint8_t* base, unsigned long long p, uint32_t n, uint32_t w[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(base + (p & ~3ull));
+    const uint32_t sh = (uint32_t)(p & 3ull);
+    const uint32_t a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4];
+    w[0] = __builtin_amdgcn_alignbyte(a1, a0, sh);
+    w[1] = __builtin_amdgcn_alignbyte(a2, a1, sh);
+    w[2] = __builtin_amdgcn_alignbyte(a3, a2, sh);
+    w[3] = __builtin_amdgcn_alignbyte(a4, a3, sh);
+#else
+    __builtin_memcpy(w, base + p, 16);
+#endif
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t have = n > 4 * i ? n - 4 * i : 0u; // valid bytes of word i
+        if (have < 4) w[i] &= have ? (1u << (8 * have)) - 1u : 0u;
+    }
+}
+// hash of a key's tail (bucket, flag, receiver, receiver length): the builder's membership tests compare it before they compare bytes
 BMQ_HD uint32_t tail_hash(const uint8_t* kp, unsigned long long beg, unsigned long long end) {
-    uint32_t h = 0x811C9DC5u;
-    for (unsigned long long i = beg; i < end; i++) h = (h ^ kp[i]) * 0x01000193u;
+    uint32_t h = 0x811C9DC5u ^ (uint32_t)(end - beg);
+    for (unsigned long long p = beg; p < end; p += 16) {
+        uint32_t w[4];
+        bytes_chunk16(kp, p, (uint32_t)(end - p < 16 ? end - p : 16), w);
+        h = (h ^ w[0]) * 0x01000193u;
+        h = (rotl32(h, 13) ^ w[1]) * 0x01000193u;
+        h = (rotl32(h, 13) ^ w[2]) * 0x01000193u;
+        h = (rotl32(h, 13) ^ w[3]) * 0x01000193u;
+    }
     return mix32(h) | 1u;
+}
+// kp[ao, ao + n) == kp[bo, bo + n), 16 bytes per step (key pool only, see bytes_chunk16)
+BMQ_HD bool pool_bytes_equal(const uint8_t* kp, unsigned long long ao, unsigned long long bo, unsigned long long n) {
+    for (unsigned long long i = 0; i < n; i += 16) {
+        uint32_t x[4], y[4];
+        const uint32_t m = (uint32_t)(n - i < 16 ? n - i : 16);
+        bytes_chunk16(kp, ao + i, m, x);
+        bytes_chunk16(kp, bo + i, m, y);
+        if (((x[0] ^ y[0]) | (x[1] ^ y[1]) | (x[2] ^ y[2]) | (x[3] ^ y[3])) != 0) return false;
+    }
+    return true;
 }
 BMQ_HD bool bytes_equal(const uint8_t* a, unsigned long long ao, const uint8_t* b, unsigned long long bo, unsigned long long n) {
     for (unsigned long long i = 0; i < n; i++)
@@ -629,7 +668,7 @@ BMQ_HD uint32_t idset_find_key(const DistIndexMut& ix, const IdSet& s, const Key
         const unsigned long long off = r & KREF_OFF_MASK, len = r >> KREF_LEN_SHIFT;
         if (len < tl) continue;
         // same filter node => same tenant + levels; the keys are equal iff their tails are
-        if (bytes_equal(ix.kpool, off + len - tl, ix.kpool, k.tail, tl)) return m;
+        if (pool_bytes_equal(ix.kpool, off + len - tl, k.tail, tl)) return m;
     }
     return NONE;
 }
@@ -650,9 +689,17 @@ BMQ_HD void group_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t p) {
     if (tg == TARGET_NONE) return;
     if (p > 0 && ob.sorted_target[p - 1] == tg) return; // not a head
     if (ob.group_done[p]) return;
-    uint32_t e; // end of the group: upper bound of tg in the sorted array
+    uint32_t e; // end of the group: upper bound of tg in the sorted array.  Groups are short (an op or two per filter): the next positions one by
+                // one first -- a binary search over the whole batch is 17 dependent reads for a group of one
     {
         uint32_t lo = p + 1, hi = ob.n;
+        for (uint32_t probe = 0; probe < 4 && lo < hi; probe++) {
+            if (ob.sorted_target[lo] != tg) {
+                hi = lo;
+                break;
+            }
+            lo++;
+        }
         while (lo < hi) {
             const uint32_t mid = lo + (hi - lo) / 2;
             if (ob.sorted_target[mid] == tg) lo = mid + 1;
