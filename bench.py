@@ -543,11 +543,101 @@ def main():
             rc = B._lib.lib().bmq_match_wait_dev(eng.h, t, None)
             if rc:
                 raise RuntimeError("bmq_match_wait_dev failed: %d" % rc)
+        try:  # (first: the index is still the one the headline ran on)
+            ordered = ordered_batch_leg(eng, w, batches[0][3], n, local_rank, torch, np)
+        except Exception as ex:  # noqa: BLE001
+            ordered = {"error": repr(ex)}
         out["extra"] = extra_legs(args, eng, w, step, torch, np, fetch_csr if not args.no_cpu_baseline else None, (submit_dev, wait_dev))
+        out["extra"]["ordered_batch"] = ordered
     eng.close()  # deterministic teardown of everything this script owns, in order, before the line goes out
     if dist is not None:
         dist.destroy_process_group()
     emit_json(out)
+
+
+def ordered_batch_leg(eng, w, host_batch, n, device, torch, np, steps=5, warm=2):
+    """The batch as BatchDistRequest carries it: "sorted by tenantId and topic", every topic once (DistWorkerCoProc.proto:75-83,
+    BatchDistServerCall.java:138-152).  The headline's batch 0 -- 1 M Zipf publishes, repeats included -- (a) as generated, (b) ordered by
+    (tenant, topic) with its repeats, through the same engine; (c) the same rows through an engine with bmq_config.dedup_sorted: equal rows are
+    neighbours, the run heads go into a dense batch, the walk runs on that (bmq_dedup_adj_kernels.h); (d) the distinct rows only, the
+    caller having done what the reference's batcher does.  Rates are PUBLISHES per second: (c) and (d) answer all n publishes."""
+    import bifromq_amd as B
+    dev = torch.device("cuda:%d" % device)
+    hdata, hoff, htt = host_batch
+    t_host = time.perf_counter()
+    mv = memoryview(np.ascontiguousarray(hdata))
+    rows = [bytes(mv[int(hoff[i]):int(hoff[i + 1])]) for i in range(n)]
+    tt_l = htt.tolist()
+    order = sorted(range(n), key=lambda i: (tt_l[i], rows[i]))
+    srows, stt = [rows[i] for i in order], np.asarray([tt_l[i] for i in order], dtype=np.uint32)
+    head = np.ones(n, dtype=bool)
+    head[1:] = [stt[i] != stt[i - 1] or srows[i] != srows[i - 1] for i in range(1, n)]
+    hidx = np.flatnonzero(head)
+    host_s = time.perf_counter() - t_host
+
+    def upload(rs, tts):
+        data = np.frombuffer(b"".join(rs) + b"\0" * 64, dtype=np.uint8)
+        off = np.zeros(len(rs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(r) for r in rs])
+        return (torch.from_numpy(data.copy()).to(dev), torch.from_numpy(off.astype(np.int32)).to(dev), torch.from_numpy(tts.astype(np.int32)).to(dev), len(rs))
+    tdata, toff = w.tenants_packed()
+    d_tenants, d_tenant_off = torch.from_numpy(tdata.copy()).to(dev), torch.from_numpy(toff.astype(np.int32)).to(dev)
+    cap = 24 * n
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def run(engine, bt):
+        nonlocal cap
+        d_data, d_off, d_tt, m = bt
+        d_row, d_ids = torch.zeros(m + 1, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+        ms, st, total = [], None, 0
+        for i in range(warm + steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while True:
+                engine.match_batch_device(d_tenants.data_ptr(), d_tenant_off.data_ptr(), w.n_tenants, d_tt.data_ptr(), d_data.data_ptr(), d_off.data_ptr(), m,
+                                          d_row.data_ptr(), d_ids.data_ptr(), d_ids.numel(), d_total.data_ptr())
+                try:
+                    total = engine.finish()
+                    break
+                except B.BmqError as ex:  # the id buffer was too small: the total is known now (a warm-up step's business)
+                    if ex.code != -3:
+                        raise
+                    cap = int(d_total.item()) + int(d_total.item()) // 8 + 4096
+                    d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+            if i >= warm:
+                ms.append((time.perf_counter() - t0) * 1e3)
+                st = engine.stats()
+        r = {"rows": m, "ms_per_step": float(np.mean(ms)), "publishes_per_s": n / (float(np.mean(ms)) * 1e-3),
+             "kernel_ms": {"k_walk": st.ms_walk, "k_expand (+ k_fill_adj)": st.ms_expand, "dedup kernels": max(0.0, st.ms_total - st.ms_walk - st.ms_expand),
+                           "all_kernels": st.ms_total},
+             "n_walked": int(st.n_walked), "n_visit": int(st.n_visit), "n_match": int(st.n_match)}
+        return r, d_row, d_ids[:total]
+
+    b_gen = (torch.from_numpy(np.ascontiguousarray(hdata)).to(dev), torch.from_numpy(hoff.astype(np.int32)).to(dev), torch.from_numpy(htt.astype(np.int32)).to(dev), n)
+    b_ord = upload(srows, stt)
+    b_dis = upload([srows[i] for i in hidx], stt[hidx])
+    out = {"workload": "the headline's batch 0 (%d Zipf publishes, %d distinct (tenant, topic) pairs) ordered by (tenant, topic) as BatchDistRequest is" % (n, len(hidx)),
+           "host_sort_s": host_s}
+    out["as_generated"], _, _ = run(eng, b_gen)
+    out["ordered_with_repeats"], row_b, ids_b = run(eng, b_ord)
+    eng2 = B.Engine(device=device, kernel_timing=True, dedup_min_topics=1, dedup_sorted=True)
+    kb, ko = w.keys_packed()
+    eng2.rebuild_raw(kb.ctypes.data, ko.ctypes.data, w.n_keys)
+    out["ordered_dedup_sorted"], row_c, ids_c = run(eng2, b_ord)
+    eng2.close()
+    out["ordered_dedup_sorted"]["rows_equal_undeduplicated_engine"] = bool(torch.equal(row_b, row_c) and torch.equal(ids_b, ids_c))
+    out["ordered_distinct"], row_d, ids_d = run(eng, b_dis)
+    # the distinct batch's rows are the heads' rows of the ordered batch: same lengths, same ids
+    hi = torch.from_numpy(hidx).to(dev)
+    len_b = (row_b[1:] - row_b[:-1])[hi]
+    same_len = bool(torch.equal(len_b, row_d[1:] - row_d[:-1]))
+    same_ids = False
+    if same_len:
+        starts = row_b[:-1][hi].long()
+        pos = torch.repeat_interleave(starts - row_d[:-1].long(), len_b.long()) + torch.arange(ids_d.numel(), device=dev)
+        same_ids = bool(torch.equal(ids_b[pos], ids_d))
+    out["ordered_distinct"]["rows_equal_heads_of_ordered_batch"] = same_len and same_ids
+    return out
 
 
 def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
@@ -1130,15 +1220,34 @@ def attach_traffic(out, workload, world):
             continue
         if world > 1:  # the counter passes ran the single-GPU configuration (a rank of N holds 1/N of the index)
             out["roofline"]["traffic_source"] = "profiles/%s was measured at n_gpus = 1: not reported for a shard" % tf
-        elif tj.get("kernel_sources_sha") != kernel_sources_sha():
-            out["roofline"]["traffic_source"] = "profiles/%s is stale (kernel sources changed since): not reported" % tf
+        elif tj.get("kernel_sources_sha") != kernel_sources_sha() and not kernel_code_unchanged(tj, tj.get(workload + "_kernel")):
+            out["roofline"]["traffic_source"] = "profiles/%s is stale (the sources changed since, and so did the code of the measured kernel): not reported" % tf
         elif tj.get(workload + "_kernel") not in (None, out["roofline"].get("kernel")):
             out["roofline"]["traffic_source"] = "profiles/%s holds the traffic of %s, this run's dominant kernel is %s: not reported" % (
                 tf, tj.get(workload + "_kernel"), out["roofline"].get("kernel"))
         else:
             out["roofline"]["traffic"] = tj.get(workload)
             out["roofline"]["traffic_source"] = "profiles/" + tf
+            if tj.get("kernel_sources_sha") != kernel_sources_sha():
+                out["roofline"]["traffic_source"] += (" (sources under bifromq_amd/csrc/ changed since it was measured; the machine code of %s in the library "
+                                                      "is byte for byte the measured one: tools/kernel_isa.py)" % tj.get(workload + "_kernel"))
         break
+
+
+def kernel_code_unchanged(tj, kernel):
+    """the measured kernel's machine code (code bytes + kernel descriptor, tools/kernel_isa.py) in the library this run loads is the one the traffic
+    file recorded: a change elsewhere in the sources does not retire a measurement of a kernel it did not touch"""
+    want = (tj.get("kernel_isa_sha") or {}).get(kernel)
+    if not want:
+        return False
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_isa
+        return kernel_isa.kernel_hashes().get(kernel) == want
+    except Exception:  # noqa: BLE001
+        return False
+    finally:
+        sys.path.pop(0)
 
 
 def kernel_sources_sha():

@@ -45,13 +45,13 @@ def build(force: bool = False) -> None:
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("wave_queue_cap", C.c_uint32),
                 ("wave_pair_cap", C.c_uint32), ("slow_scratch_mb", C.c_uint32), ("kernel_timing", C.c_uint32),
-                ("dedup_min_topics", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("dedup_min_topics", C.c_uint32), ("dedup_sorted", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class Stats(C.Structure):
     _fields_ = [("n_topics", C.c_uint64), ("n_visit", C.c_uint64), ("n_match", C.c_uint64), ("n_ranges", C.c_uint64),
                 ("n_slow_topics", C.c_uint64), ("n_sorted_rows", C.c_uint64), ("topic_bytes", C.c_uint64),
-                ("ms_total", C.c_float), ("ms_walk", C.c_float), ("ms_expand", C.c_float), ("ms_reserved", C.c_float)]
+                ("ms_total", C.c_float), ("ms_walk", C.c_float), ("ms_expand", C.c_float), ("n_walked", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):

@@ -17,6 +17,9 @@ enum : uint32_t {
     ST_RANGE = 16u,         // >= 2^32 ids
     ST_NEED_SORTLIST = 32u, // fix-up list too small
     ST_NEED_SPILL = 64u,    // range spill buffer too small
+    ST_NEED_ADJ = 1024u,    // (128 and 512 are the retain direction's, bmq_retain_args.h) the dense batch's topic-byte buffer too small (bmq_dedup_adj_kernels.h;
+                            // Counters.adj_bytes says what it takes).  Not part of ST_RERUN: the kernels behind it need not know -- the dense batch
+                            // is empty then, every row comes out empty, and the host runs the batch again with the larger buffer
     ST_WANT_MIXED = 256u    // a wave held topics of many tenants (the batch is not grouped by tenant): the batch runs again through the MIXED instantiation
 };
 constexpr uint32_t ST_RERUN = ST_NEED_PAIRS | ST_NEED_SLOW | ST_NEED_SCRATCH | ST_NEED_SPILL;
@@ -32,6 +35,8 @@ struct Counters { // one per batch slot, zeroed behind every batch (k_reset)
     uint32_t slow_count;
     uint32_t sort_count;
     uint32_t status;
+    uint32_t n_walked; // rows of the dense batch the walk ran on (bmq_dedup_adj_kernels.h); 0: the walk ran on the batch itself
+    uint32_t adj_bytes; // ST_NEED_ADJ: topic bytes of the dense batch
     uint32_t pad;
     uint32_t rw_next[64]; // k_retain_walk: the next quad of filters of each partition of the batch (RW_PARTS)
 };
@@ -103,6 +108,32 @@ struct BatchArgs {
 #define BMQ_EXPERIMENTS 0
 #endif
 #define BMQ_DBG(a, bits) (BMQ_EXPERIMENTS != 0 && ((a).debug_flags & (bits)) != 0)
+
+// De-duplication of a batch that arrives ORDERED by (tenant, topic) (bmq_config.dedup_sorted; bmq_dedup_adj_kernels.h): equal rows are
+// neighbours, the first row of a run (its HEAD) stands for the run, and the heads are copied into a dense batch of their own that the walk
+// kernels run on unchanged -- (c_topics, c_off, c_tenant) in the layout of (topics, topic_off, topic_tenant), the rows behind the last head
+// marked "no such tenant" (never walked).  Per-block sums use the super-block scheme of the id counts above.
+constexpr uint32_t ADJ_PENDING = 0xFFFFFFFFu; // rep[] between the two kernels: the row's head lies in an earlier block
+struct AdjArgs {
+    const uint8_t* topics;
+    const uint32_t* topic_off;
+    const uint32_t* topic_tenant;
+    uint32_t n_topics;
+    uint32_t n_blocks;
+    uint32_t tpw_shift;
+    uint32_t* rep;                  // [n_topics] out: the head of the row's run (a row index of the batch)
+    uint32_t* dense;                // [n_topics] out, heads only: the head's row in the dense batch
+    unsigned long long* blk_cnt;    // [n_blocks] heads << 32 | bytes of the heads' topics, per block of 2^tpw_shift rows
+    uint32_t* blk_last;             // [n_blocks] 1 + the block's last head row (0: the block has none)
+    unsigned long long* super_cnt;  // [n_super * SUPER_STRIDE] entry 0 of a line: the sum of blk_cnt over 2^SUPER_SHIFT blocks; entry 1: the
+                                    // largest blk_last among them (zeroed in front of every batch)
+    uint8_t* c_topics;              // the dense batch (16-byte aligned, readable 16 bytes past the last byte like every packed input)
+    unsigned long long c_cap;       // ... bytes it may hold; a batch whose heads need more raises ST_NEED_ADJ, walks nothing and runs again
+    uint32_t* c_off;                // [n_topics + 1]
+    uint32_t* c_tenant;             // [n_topics]
+    uint32_t* c_rep;                // [n_topics] the identity: every dense row is walked
+    Counters* ctr;                  // n_walked = number of heads
+};
 
 #if defined(__HIPCC__) || defined(BMQ_WAVE_EMU)
 // n contiguous entries of `pairs` from sub-allocator `key` (false: the slice is full, the batch is re-run with a larger buffer)

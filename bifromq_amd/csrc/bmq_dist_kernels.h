@@ -540,6 +540,7 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
 
 } // namespace bmq
 #include "bmq_expand_kernel.h" // k_expand -- CSR row pointers + ids
+#include "bmq_dedup_adj_kernels.h" // k_dd_adj_heads / k_dd_adj_scatter / k_fill_adj: an ORDERED batch is reduced to its distinct rows by comparing neighbours
 namespace bmq {
 
 // ------------------------------------------------------------------------------------------------------------

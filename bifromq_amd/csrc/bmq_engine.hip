@@ -108,6 +108,7 @@ struct bmq_engine {
     DevBuf dd_table;                       // in-batch de-duplication (bmq_dedup_kernels.h): one table for all batch slots (batches run in stream order)
     uint32_t dd_gen = 0;                   // generation of the last batch that used it (1..255; 0: fresh / just zeroed)
     uint32_t dedup_min = 0xFFFFFFFFu;      // batches of at least this many topics are de-duplicated (bmq_config.dedup_min_topics; default: never)
+    bool dedup_sorted = false;             // ... by comparing neighbours: the caller's batches are ordered by (tenant, topic) (bmq_config.dedup_sorted)
     bool mixed_on = false;                 // k_walk runs in its MIXED instantiation (batches are not grouped by tenant)
     uint32_t mixed_idle = 0;
     int walk_geom = 0;                     // LDS geometry of k_walk: 0 default, 2 smallest lists (bmq_config caps <= 128)
@@ -118,6 +119,9 @@ struct bmq_engine {
     // batch i-1 are in flight while the kernels of batch i run; every other entry point works on slot 0.
     struct BatchSlot {
         DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave, b_rep, b_visit;
+        // de-duplication of an ordered batch (bmq_dedup_adj_kernels.h): per-block sums, the dense batch of run heads and its per-row results
+        DevBuf b_dense, b_adj_cnt, b_adj_last, b_adj_super, b_c_topics, b_c_off, b_c_tenant, b_c_rep, b_c_pair_off, b_c_pair_cnt, b_c_route_cnt;
+        uint64_t adj_cap = 0; // bytes of b_c_topics in use as the dense batch's topic bytes (grown on ST_NEED_ADJ)
         DevBuf b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch, b_sort_list, b_ctr,
             b_total;
         uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
@@ -361,7 +365,40 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     a.qcap = e->cfg.wave_queue_cap;
     a.pcap = e->cfg.wave_pair_cap;
     a.rep = nullptr, a.visit_cnt = nullptr, a.dd_table = nullptr, a.dd_mask = 0, a.dd_gen = 0;
-    if (a.n_topics >= e->dedup_min) { // identical (tenant, topic) rows are walked once
+    const bool adj = a.n_topics >= e->dedup_min && e->dedup_sorted; // an ordered batch: equal rows are neighbours (bmq_dedup_adj_kernels.h)
+    BatchArgs a2{};  // adj: the dense batch of run heads the walk kernels run on
+    AdjArgs g{};
+    AdjFill gf{};
+    if (adj) {
+        const size_t n = a.n_topics, nb = a.n_blocks, n_super = ((nb - 1) >> SUPER_SHIFT) + 1;
+        if (S.adj_cap == 0) S.adj_cap = 48 * n + 4096; // (a first guess: the scatter kernel asks for more -- ST_NEED_ADJ -- and the batch runs again)
+        HIPCHK(e, S.b_rep.ensure(4 * n));
+        HIPCHK(e, S.b_visit.ensure(4 * n));
+        HIPCHK(e, S.b_dense.ensure(4 * n));
+        HIPCHK(e, S.b_adj_cnt.ensure(8 * nb));
+        HIPCHK(e, S.b_adj_last.ensure(4 * nb));
+        HIPCHK(e, S.b_adj_super.ensure(8 * SUPER_STRIDE * n_super));
+        HIPCHK(e, S.b_c_topics.ensure(S.adj_cap + 64));
+        HIPCHK(e, S.b_c_off.ensure(4 * (n + 1)));
+        HIPCHK(e, S.b_c_tenant.ensure(4 * n));
+        HIPCHK(e, S.b_c_rep.ensure(4 * n));
+        HIPCHK(e, S.b_c_pair_off.ensure(4 * n));
+        HIPCHK(e, S.b_c_pair_cnt.ensure(4 * n));
+        HIPCHK(e, S.b_c_route_cnt.ensure(4 * n));
+        g.topics = a.topics, g.topic_off = a.topic_off, g.topic_tenant = a.topic_tenant;
+        g.n_topics = a.n_topics, g.n_blocks = a.n_blocks, g.tpw_shift = a.tpw_shift;
+        g.rep = S.b_rep.as<uint32_t>(), g.dense = S.b_dense.as<uint32_t>();
+        g.blk_cnt = S.b_adj_cnt.as<unsigned long long>(), g.blk_last = S.b_adj_last.as<uint32_t>(), g.super_cnt = S.b_adj_super.as<unsigned long long>();
+        g.c_topics = S.b_c_topics.as<uint8_t>(), g.c_cap = S.adj_cap;
+        g.c_off = S.b_c_off.as<uint32_t>(), g.c_tenant = S.b_c_tenant.as<uint32_t>(), g.c_rep = S.b_c_rep.as<uint32_t>();
+        g.ctr = a.ctr;
+        a.rep = g.rep; // (k_expand and the repair kernels see a de-duplicated batch: k_fill_adj writes the per-block sums)
+        a.visit_cnt = S.b_visit.as<uint32_t>();
+        a2 = a;
+        a2.topics = g.c_topics, a2.topic_off = g.c_off, a2.topic_tenant = g.c_tenant, a2.rep = g.c_rep;
+        a2.pair_off = S.b_c_pair_off.as<uint32_t>(), a2.pair_cnt = S.b_c_pair_cnt.as<uint32_t>(), a2.route_cnt = S.b_c_route_cnt.as<uint32_t>();
+        gf.rep = g.rep, gf.dense = g.dense, gf.c_pair_off = a2.pair_off, gf.c_pair_cnt = a2.pair_cnt, gf.c_route_cnt = a2.route_cnt, gf.c_visit = a2.visit_cnt;
+    } else if (a.n_topics >= e->dedup_min) { // identical (tenant, topic) rows are walked once
         uint32_t cap = 1024;
         while (cap < 2 * a.n_topics && cap < (1u << 31)) cap <<= 1;
         if (e->dd_table.cap < sizeof(unsigned long long) * cap) e->dd_gen = 0; // (a new table: to be zeroed)
@@ -378,6 +415,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         a.rep = S.b_rep.as<uint32_t>(), a.visit_cnt = S.b_visit.as<uint32_t>();
         a.dd_table = e->dd_table.as<unsigned long long>(), a.dd_mask = cap - 1, a.dd_gen = e->dd_gen;
     }
+    const BatchArgs& w = adj ? a2 : a; // what the walk kernels run on
     hipStream_t s = e->stream;
     S.timed = e->kernel_events;
     if (!S.clean) reset_slot(e, S, s); // first batch of the slot, buffers regrown, or a retain batch ran on it
@@ -388,7 +426,11 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     // the stream, measured).  k_walk keeps its own start event BEHIND ev[0]: the first packet after an idle stream is stamped before the
     // queue has woken up, and ev[0] -> ev[2] read 6 us more than the kernel's own duration (rocprofv3), ev[1] -> ev[2] agrees with it.
     if (S.total_timed) HIPCHK(e, hipEventRecord(S.ev[0], s));
-    if (a.rep) hipLaunchKernelGGL(k_dedup, dim3(a.n_blocks), dim3(64), 0, s, a); // (inside ms_total, in front of ms_walk)
+    if (adj) { // (inside ms_total, in front of ms_walk)
+        HIPCHK(e, hipMemsetAsync(S.b_adj_super.p, 0, 8 * SUPER_STRIDE * ((((size_t)a.n_blocks - 1) >> SUPER_SHIFT) + 1), s));
+        hipLaunchKernelGGL(k_dd_adj_heads, dim3(a.n_blocks), dim3(64), 0, s, g);
+        hipLaunchKernelGGL(k_dd_adj_scatter, dim3(a.n_blocks), dim3(64), 0, s, g);
+    } else if (a.rep) hipLaunchKernelGGL(k_dedup, dim3(a.n_blocks), dim3(64), 0, s, a);
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[1], s));
     {
         // k_walk<token table entries, stack items, range entries, MIXED>: the LDS geometry is a compile-time property (bmq_walk_kernel.h)
@@ -397,8 +439,8 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         const int g = e->walk_geom;
 #define BMQ_WALK_LAUNCH(TC, QC, PC)                                                        \
     do {                                                                                   \
-        if (e->mixed_on) hipLaunchKernelGGL((k_walk<TC, QC, PC, true>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((k_walk<TC, QC, PC, false>), grid, block, 0, s, a);            \
+        if (e->mixed_on) hipLaunchKernelGGL((k_walk<TC, QC, PC, true>), grid, block, 0, s, w); \
+        else hipLaunchKernelGGL((k_walk<TC, QC, PC, false>), grid, block, 0, s, w);            \
     } while (0)
 #if BMQ_EXPERIMENTS
         if (a.debug_flags & 16u) hipLaunchKernelGGL(k_occ_probe, grid, block, 0, s, a); // (experiments: its census replaces k_walk's)
@@ -414,10 +456,11 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     S.ran_slow = e->slow_on;
     S.ran_sort = e->sort_on;
     if (e->slow_on) {
-        hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_walk_slow, dim3(256), dim3(64), 0, s, w);
         if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[3], s));
     }
-    if (a.rep) hipLaunchKernelGGL(k_fill, dim3(a.n_blocks), dim3(64), 0, s, a); // (inside ms_expand)
+    if (adj) hipLaunchKernelGGL(k_fill_adj, dim3(a.n_blocks), dim3(64), 0, s, a, gf); // (inside ms_expand)
+    else if (a.rep) hipLaunchKernelGGL(k_fill, dim3(a.n_blocks), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_expand, dim3(a.n_blocks), dim3(64), 0, s, a);
     if (e->sort_on) {
         if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
@@ -514,7 +557,7 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
         HIPCHK(e, hipEventSynchronize(S.ev_done)); // this batch only: a later batch may already be running behind it
         if (S.last.debug_flags & 30u) print_wave_debug(e, S);
         const Counters c = *S.h_ctr;
-        const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST);
+        const uint32_t grow = c.status & (ST_RERUN | ST_NEED_SORTLIST | ST_NEED_ADJ);
         if (grow) {
             if (grow & ST_NEED_PAIRS) {
                 S.pair_cap = S.pair_cap * 2; // slices fill unevenly: double until every sub-allocator fits
@@ -533,6 +576,10 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
             if (grow & ST_NEED_SCRATCH) {
                 S.scratch_cap = std::max<uint64_t>(S.scratch_cap * 2, c.scratch_alloc + c.scratch_alloc / 8);
                 HIPCHK(e, S.b_scratch.ensure(sizeof(uint32_t) * S.scratch_cap));
+            }
+            if (grow & ST_NEED_ADJ) { // the dense batch of an ordered, de-duplicated batch: its topic bytes are known now
+                S.adj_cap = (uint64_t)c.adj_bytes + c.adj_bytes / 8 + 4096;
+                HIPCHK(e, S.b_c_topics.ensure(S.adj_cap + 64));
             }
             if (grow & ST_NEED_SORTLIST) {
                 S.sort_cap = std::max<uint32_t>(S.sort_cap * 2, c.sort_count);
@@ -583,6 +630,7 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
         st.n_slow_topics = c.slow_count;
         st.n_sorted_rows = c.sort_count;
         st.topic_bytes = c.topic_bytes;
+        st.n_walked = c.n_walked ? c.n_walked : (S.last.rep ? 0u : S.last.n_topics);
         if (S.total_timed) (void)hipEventElapsedTime(&st.ms_total, S.ev[0], S.ev[5]);
         if (S.timed) {
             (void)hipEventElapsedTime(&st.ms_walk, S.ev[1], S.ev[2]);
@@ -672,6 +720,7 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     e->walk_geom = smallest ? 2 : 0;
     if (c.dedup_min_topics) e->dedup_min = c.dedup_min_topics;
     if (const char* v = getenv("BMQ_DEDUP_MIN")) e->dedup_min = (uint32_t)strtoul(v, nullptr, 10); // profiling experiments (4294967295: never)
+    e->dedup_sorted = c.dedup_sorted != 0;
     if (const char* v = getenv("BMQ_WALK_GEOM")) e->walk_geom = atoi(v);
     if (const char* v = getenv("BMQ_WALK_MIXED")) e->mixed_on = atoi(v) != 0; // profiling experiments
     e->kernel_events = c.kernel_timing != 0;

@@ -40,7 +40,7 @@ class Workload:
         self.n_keys = G.bmqgen_n_keys(self.h)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _lib is not None and getattr(_lib, "gen", None) is not None:  # (module globals are gone at interpreter exit)
             _lib.gen().bmqgen_destroy(self.h)
             self.h = None
 

@@ -72,7 +72,11 @@ typedef struct bmq_config {
                                /* takes a Set<String>, TenantRouteMatcher.java:67-78).  0 = default = UINT32_MAX = never: on  */
                                /* the survey's Zipf batches it takes 16 % off the walk kernel and costs more than that in the */
                                /* two kernels around it                                                 */
-    uint32_t reserved[6];
+    uint32_t dedup_sorted;     /* 1: the caller's batches are ORDERED by (tenant index, topic bytes) -- BatchDistRequest is "sorted by   */
+                               /* tenantId and topic" (DistWorkerCoProc.proto:75-83) --, so the de-duplication above compares a row with */
+                               /* the row before it instead of hashing, and the walk runs on a dense copy of the distinct rows.  Only    */
+                               /* speed depends on the order: a row that equals no neighbour is matched on its own.  0 = hash           */
+    uint32_t reserved[5];
 } bmq_config;
 
 /* Counters of the last completed match batch (for roofline accounting). */
@@ -88,7 +92,8 @@ typedef struct bmq_stats {
                              /* than 4096 topics unless bmq_config.kernel_timing: the two events cost ~8 us)  */
     float ms_walk;           /* ... of the tokenise+walk kernel alone (0 unless bmq_config.kernel_timing)   */
     float ms_expand;         /* ... of the expand kernel alone (0 unless bmq_config.kernel_timing)          */
-    float ms_reserved;
+    uint32_t n_walked;       /* rows the walk kernel walked: n_topics, fewer with bmq_config.dedup_sorted (the distinct  */
+                             /* rows), 0 = not counted (the hashing de-duplication)                                       */
 } bmq_stats;
 
 typedef struct bmq_index_info {

@@ -270,6 +270,65 @@ def test_in_batch_dedup_changes_nothing_but_the_work():
         assert stats[0][0] == int(kv.count_visits(tnames, np.array(tt, dtype=np.uint32), O.pack(topics)).sum())
 
 
+def _run_heads(tt, topics):
+    """rows that differ from the row before them (tenant index or bytes): what the neighbour compare keeps"""
+    return sum(1 for i in range(len(topics)) if i == 0 or tt[i] != tt[i - 1] or topics[i] != topics[i - 1])
+
+
+def test_dedup_of_an_ordered_batch_by_neighbour_compare():
+    """bmq_config.dedup_sorted (bmq_dedup_adj_kernels.h): BatchDistRequest is "sorted by tenantId and topic" (DistWorkerCoProc.proto:75-83), so
+    equal rows are neighbours -- the run heads are copied into a dense batch, the walk kernels run on that, every row takes its head's result.
+    The CSR and the statistics must equal those of an engine that never de-duplicates, and the semantic oracle, on batches full of repeats
+    (hot topics, unknown tenants, empty topics, topics deeper than FAST_LEVELS, long topics): ordered -- then n_walked is the number of DISTINCT
+    (tenant, topic) pairs --, grouped by tenant only and not ordered at all (only speed depends on the order: n_walked = the rows that differ
+    from their predecessor); with 4 / 16 / 64 rows per wave; with the smallest LDS lists; through the device-resident entry point's growth
+    path when the dense batch's bytes outgrow the first guess (ST_NEED_ADJ)."""
+    rnd = random.Random(23)
+    tenants = ["tA", "tB", "租户", "t4", "t5", "t6"]
+    alphabet = ["a", "b", "c", "", "$sys", "dev", "x" * 17]
+    keys = sorted({U.rand_route_key(rnd, rnd.choice(tenants), U.rand_filter(rnd, 5, alphabet), i) for i in range(6000)} |
+                  {U.rand_route_key(rnd, "tA", "/".join(["a"] * 20 + ["#"]), 900001), U.rand_route_key(rnd, "tB", "/".join(["+"] * 18), 900002),
+                   U.rand_route_key(rnd, "tA", "long/#", 900003)})
+    kv = O.KV(keys)
+    pool = [U.rand_topic(rnd, 6, alphabet) for _ in range(700)] + ["", "/", "a", "/".join(["a"] * 21), "/".join(["a"] * 18)]
+    pool += ["long/" + "y" * rnd.randrange(100, 900) for _ in range(40)]  # blocks whose bytes do not fit the LDS image; > 48 bytes per row on average
+    tnames = tenants + ["ghost"]
+    plain = B.Engine(device=0).rebuild(keys)
+    for n in (37, 900, 20000, 140000):
+        topics = [pool[min(int(rnd.paretovariate(1.1)) - 1, len(pool) - 1)] for _ in range(n)]  # Zipf-like repeats
+        if n == 900:
+            topics = [rnd.choice(pool[-40:]) for _ in range(n)]  # long topics only: the first guess of the dense buffer is too small
+        tt = [rnd.randrange(len(tnames)) for _ in topics]
+        for order in ("ordered", "grouped", "as is"):
+            if order == "ordered":
+                o = sorted(range(n), key=lambda i: (tt[i], topics[i].encode()))
+            elif order == "grouped":
+                o = sorted(range(n), key=lambda i: tt[i])
+            else:
+                o = list(range(n))
+            ts, tts = [topics[i] for i in o], [tt[i] for i in o]
+            row0, ids0 = plain.match_batch(tnames, tts, ts)
+            st0 = plain.stats()
+            assert st0.n_walked == n
+            if n <= 20000:
+                assert U.csr_rows(row0, ids0) == U.semantic_rows(kv, tnames, tts, ts)
+            for geom in ({}, dict(wave_queue_cap=128, wave_pair_cap=128, slow_scratch_mb=1)):
+                if geom and n != 20000:
+                    continue
+                e = B.Engine(device=0, dedup_min_topics=1, dedup_sorted=True, **geom).rebuild(keys)
+                for rep in range(2):  # (the second batch runs on buffers the first one sized)
+                    row, ids = e.match_batch(tnames, tts, ts)
+                    assert np.array_equal(row, row0) and np.array_equal(ids, ids0), (n, order, rep)
+                    st = e.stats()
+                    assert (st.n_visit, st.n_match, st.n_ranges, st.topic_bytes, st.n_slow_topics > 0) == \
+                           (st0.n_visit, st0.n_match, st0.n_ranges, st0.topic_bytes, st0.n_slow_topics > 0), (n, order, rep)
+                    assert st.n_walked == _run_heads(tts, ts), (n, order)
+                    if order == "ordered":
+                        assert st.n_walked == len(set(zip(tts, ts)))
+                e.close()
+    plain.close()
+
+
 # ---- the rare paths: LDS overflow -> per-lane DFS, deep topics, interleaved ranges -> fix-up sort ------------------
 def test_slow_path_equals_fast_path():
     rnd = random.Random(5)

@@ -45,3 +45,18 @@ def test_k_retain_walk_under_the_wave_emulator(tmp_path, defs, rounds):
     r = subprocess.run([exe, str(rounds), "12345"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok: G") == 3, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("defs,cases", [((), 60), (("-DBMQ_ADJ_IMG=256",), 45)])
+def test_dedup_of_an_ordered_batch_under_the_wave_emulator(tmp_path, defs, cases):
+    """tools/emu/dedup_adj_emu.cpp: bifromq_amd/csrc/bmq_dedup_adj_kernels.h (k_dd_adj_heads / k_dd_adj_scatter / k_fill_adj: equal rows of a batch
+    ordered by (tenant, topic) are neighbours; the run heads are copied into a dense batch for the walk kernels) -- runs across block and
+    super-block borders, the dense batch's order, offsets and bytes (through the LDS image and, with the small image, through the byte-copy
+    path), the rows behind the last head, a buffer that is too small, 4 / 16 / 64 rows per wave, batches that are not ordered at all."""
+    exe = str(tmp_path / "dedup_adj_emu")
+    cmd = ["g++", "-O1", "-std=c++17", *defs, "-I", os.path.join(ROOT, "bifromq_amd", "csrc"), "-I", os.path.join(ROOT, "tools", "emu"),
+           os.path.join(ROOT, "tools", "emu", "dedup_adj_emu.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([exe, str(cases), "12345"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("dedup_adj emu ok:"), r.stdout

@@ -80,9 +80,25 @@ def test_traffic_comes_from_the_pmc_passes_and_covers_the_mandatory_bytes():
     assert re.fullmatch(r"[0-9a-f]{16}", tj["kernel_sources_sha"])
     import sys
     sys.path.insert(0, ROOT)
-    from bench import kernel_sources_sha
+    from bench import kernel_code_unchanged, kernel_sources_sha
     if tj["kernel_sources_sha"] != kernel_sources_sha():
-        warnings.warn("profiles/traffic_r05.json was measured with older kernel sources: bench.py will not report it")
+        # ... or while the machine code of the measured kernels in the in-tree library is byte for byte what it was (tools/kernel_isa.py: the
+        # sources of OTHER kernels changed since the passes -- bmq_dedup_adj_kernels.h was added): the library built from this tree must say so
+        for kernel in ("k_walk", "k_expand"):
+            assert re.fullmatch(r"[0-9a-f]{16}", tj["kernel_isa_sha"][kernel])
+            if not kernel_code_unchanged(tj, kernel):
+                warnings.warn("profiles/traffic_r05.json: the code of %s changed since it was measured: bench.py will not report its traffic" % kernel)
+
+
+def test_kernel_isa_hash_reads_the_library():
+    """tools/kernel_isa.py finds the three kernels the bench lines quote in the in-tree library's gfx950 code object (pure Python: bundle -> ELF ->
+    symbol -> bytes) and its hash ignores nothing but the descriptor's offset to the code."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_isa
+    h = kernel_isa.kernel_hashes()
+    assert set(h) == {"k_walk", "k_expand", "k_retain_walk"} and all(v and len(v) == 16 for v in h.values()), h
+    assert kernel_isa.kernel_hashes(kernels={"nope": "_ZN3bmq4nopeEv"}) == {"nope": None}
 
 
 def test_parity_report_covers_whole_batches():

@@ -115,6 +115,9 @@ for w in ("c3", "c2", "c4"):
         open(bj, "w").write(json.dumps(d) + "\n")
 if traffic_out:
     traffic_out["kernel_sources_sha"] = kernel_sources_sha()
+    sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+    import kernel_isa  # the measured kernels' machine code in the library the passes ran (bench.py: kernel_code_unchanged)
+    traffic_out["kernel_isa_sha"] = kernel_isa.kernel_hashes()
     traffic_out["_note"] = ("HBM bytes per launch of the workload's dominant kernel = FETCH_SIZE*1024*0.992 (calibrated on random 64-byte line "
                             "fetches, tools/ubench_lines.hip) + WRITE_SIZE*1024*write_factor (calibrated on stores of known size, tools/ubench_stores.hip: "
                             "profiles/%s/write_calibration.json); profiles/%s/<workload>_pmc_hbm.csv" % (R, R))

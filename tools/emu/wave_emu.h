@@ -235,5 +235,10 @@ WEMU_ATOMIC(atomicOr, |, unsigned long long)
 WEMU_ATOMIC(atomicAdd, +, uint32_t)
 WEMU_ATOMIC(atomicAdd, +, unsigned long long)
 #undef WEMU_ATOMIC
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+    const unsigned long long o = *p;
+    *p = o > v ? o : v;
+    return o;
+}
 using std::max;
 using std::min;
