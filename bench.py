@@ -62,6 +62,8 @@ def main():
                          "split by filter, fan-out all-reduce); 0 = skip")
     ap.add_argument("--dedup", action="store_true", help="de-duplicate every batch on the device first (bmq_config.dedup_min_topics = 1; default: never)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ordered-only", action="store_true",
+                    help="after the step loop only the ordered-batch leg (extra.ordered_batch): what tools/ordered_collect.py profiles under rocprofv3")
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1: skip the compact extra legs (configs[4] churn on this index, the batching front at 64 threads, C2 and C4 as "
                          "child runs) that the default run appends under `extra`")
@@ -75,6 +77,9 @@ def main():
     ap.add_argument("--cpu-sample-tenants", type=int, default=1_000_000, help="the CPU baseline / parity leg takes the publishes of the first N tenants (default: all of them, the whole batch)")
     ap.add_argument("--cpu-sample-topics", type=int, default=1_000_000)
     args = ap.parse_args()
+    if args.ordered_only:
+        args.no_host_path = args.no_cpu_baseline = True
+        args.batcher_threads = 0
 
     import numpy
     import torch
@@ -547,7 +552,7 @@ def main():
             ordered = ordered_batch_leg(eng, w, batches[0][3], n, local_rank, torch, np)
         except Exception as ex:  # noqa: BLE001
             ordered = {"error": repr(ex)}
-        out["extra"] = extra_legs(args, eng, w, step, torch, np, fetch_csr if not args.no_cpu_baseline else None, (submit_dev, wait_dev))
+        out["extra"] = {} if args.ordered_only else extra_legs(args, eng, w, step, torch, np, fetch_csr if not args.no_cpu_baseline else None, (submit_dev, wait_dev))
         out["extra"]["ordered_batch"] = ordered
     eng.close()  # deterministic teardown of everything this script owns, in order, before the line goes out
     if dist is not None:
@@ -555,7 +560,7 @@ def main():
     emit_json(out)
 
 
-def ordered_batch_leg(eng, w, host_batch, n, device, torch, np, steps=5, warm=2):
+def ordered_batch_leg(eng, w, host_batch, n, device, torch, np, steps=5, warm=2):  # noqa: C901
     """The batch as BatchDistRequest carries it: "sorted by tenantId and topic", every topic once (DistWorkerCoProc.proto:75-83,
     BatchDistServerCall.java:138-152).  The headline's batch 0 -- 1 M Zipf publishes, repeats included -- (a) as generated, (b) ordered by
     (tenant, topic) with its repeats, through the same engine; (c) the same rows through an engine with bmq_config.dedup_sorted: equal rows are
@@ -585,12 +590,12 @@ def ordered_batch_leg(eng, w, host_batch, n, device, torch, np, steps=5, warm=2)
     cap = 24 * n
     d_total = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    def run(engine, bt):
+    def run(engine, bt, k, bufs=None):  # k steps of one shape -> (ms per step, stats of the last one, row pointers, ids)
         nonlocal cap
         d_data, d_off, d_tt, m = bt
-        d_row, d_ids = torch.zeros(m + 1, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+        d_row, d_ids = bufs if bufs else (torch.zeros(m + 1, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev))
         ms, st, total = [], None, 0
-        for i in range(warm + steps):
+        for _ in range(k):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             while True:
@@ -604,29 +609,36 @@ def ordered_batch_leg(eng, w, host_batch, n, device, torch, np, steps=5, warm=2)
                         raise
                     cap = int(d_total.item()) + int(d_total.item()) // 8 + 4096
                     d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
-            if i >= warm:
-                ms.append((time.perf_counter() - t0) * 1e3)
-                st = engine.stats()
-        r = {"rows": m, "ms_per_step": float(np.mean(ms)), "publishes_per_s": n / (float(np.mean(ms)) * 1e-3),
-             "kernel_ms": {"k_walk": st.ms_walk, "k_expand (+ k_fill_adj)": st.ms_expand, "dedup kernels": max(0.0, st.ms_total - st.ms_walk - st.ms_expand),
-                           "all_kernels": st.ms_total},
-             "n_walked": int(st.n_walked), "n_visit": int(st.n_visit), "n_match": int(st.n_match)}
-        return r, d_row, d_ids[:total]
+            ms.append((time.perf_counter() - t0) * 1e3)
+            st = engine.stats()
+        return ms, st, d_row, d_ids, total
 
     b_gen = (torch.from_numpy(np.ascontiguousarray(hdata)).to(dev), torch.from_numpy(hoff.astype(np.int32)).to(dev), torch.from_numpy(htt.astype(np.int32)).to(dev), n)
     b_ord = upload(srows, stt)
     b_dis = upload([srows[i] for i in hidx], stt[hidx])
-    out = {"workload": "the headline's batch 0 (%d Zipf publishes, %d distinct (tenant, topic) pairs) ordered by (tenant, topic) as BatchDistRequest is" % (n, len(hidx)),
-           "host_sort_s": host_s}
-    out["as_generated"], _, _ = run(eng, b_gen)
-    out["ordered_with_repeats"], row_b, ids_b = run(eng, b_ord)
     eng2 = B.Engine(device=device, kernel_timing=True, dedup_min_topics=1, dedup_sorted=True)
     kb, ko = w.keys_packed()
     eng2.rebuild_raw(kb.ctypes.data, ko.ctypes.data, w.n_keys)
-    out["ordered_dedup_sorted"], row_c, ids_c = run(eng2, b_ord)
+    shapes = (("as_generated", eng, b_gen), ("ordered_with_repeats", eng, b_ord), ("ordered_dedup_sorted", eng2, b_ord), ("ordered_distinct", eng, b_dis))
+    # every shape warmed up first (buffers grow, re-runs happen), then `steps` launches of each, shape after shape: in a kernel trace of
+    # `bench.py --ordered-only` the LAST 4 x steps dispatches of k_walk are these, in this order (tools/ordered_collect.py)
+    bufs = {}
+    for name, engine, bt in shapes:
+        _, _, d_row, d_ids, _ = run(engine, bt, warm)
+        bufs[name] = (d_row, d_ids)
+    out = {"workload": "the headline's batch 0 (%d Zipf publishes, %d distinct (tenant, topic) pairs) ordered by (tenant, topic) as BatchDistRequest is" % (n, len(hidx)),
+           "host_sort_s": host_s, "steps": steps}
+    res = {}
+    for name, engine, bt in shapes:
+        ms, st, d_row, d_ids, total = run(engine, bt, steps, bufs[name])
+        res[name] = (d_row, d_ids[:total])
+        out[name] = {"rows": bt[3], "ms_per_step": float(np.mean(ms)), "publishes_per_s": n / (float(np.mean(ms)) * 1e-3),
+                     "kernel_ms": {"k_walk": st.ms_walk, "k_expand (+ k_fill_adj)": st.ms_expand, "dedup kernels": max(0.0, st.ms_total - st.ms_walk - st.ms_expand),
+                                   "all_kernels": st.ms_total},
+                     "n_walked": int(st.n_walked), "n_visit": int(st.n_visit), "n_match": int(st.n_match)}
     eng2.close()
+    (row_b, ids_b), (row_c, ids_c), (row_d, ids_d) = res["ordered_with_repeats"], res["ordered_dedup_sorted"], res["ordered_distinct"]
     out["ordered_dedup_sorted"]["rows_equal_undeduplicated_engine"] = bool(torch.equal(row_b, row_c) and torch.equal(ids_b, ids_c))
-    out["ordered_distinct"], row_d, ids_d = run(eng, b_dis)
     # the distinct batch's rows are the heads' rows of the ordered batch: same lengths, same ids
     hi = torch.from_numpy(hidx).to(dev)
     len_b = (row_b[1:] - row_b[:-1])[hi]

@@ -20,6 +20,11 @@ final class NativeMatcher {
     // ---- engine ----
     static native long create(int device);
 
+    /** bmq_config.dedup_sorted: for a caller that hands over the publishes of a BatchDistRequest in the request's own order -- "sorted by tenantId
+     *  and topic" (DistWorkerCoProc.proto:75-83) -- repeats included: batches of at least dedupMinTopics rows are reduced to their distinct rows on the
+     *  device by comparing neighbours (every row keeps its own row in the result).  matchAll(Set) callers need none of it: a set has no repeats. */
+    static native long createOrdered(int device, int dedupMinTopics);
+
     static native void destroy(long engine);
 
     /** IKVRangeCoProc.reset(): all route keys of the range (a KV scan: ascending; route id = rank).  Built on the GPU. */

@@ -54,6 +54,24 @@ JNIEXPORT jlong JNICALL NM(create)(JNIEnv* env, jclass c, jint device) {
     }
     return (jlong)(intptr_t)e;
 }
+/* long createOrdered(int device, int dedupMinTopics)   -- bmq_config.dedup_sorted: the caller's batches are ordered by (tenant, topic), as the
+ * packs of a BatchDistRequest are (DistWorkerCoProc.proto:75-83); batches of at least dedupMinTopics rows are reduced to their distinct rows by
+ * comparing neighbours, every row keeps its own row in the result */
+JNIEXPORT jlong JNICALL NM(createOrdered)(JNIEnv* env, jclass c, jint device, jint dedupMinTopics) {
+    (void)c;
+    bmq_config cfg = {0};
+    cfg.struct_size = sizeof cfg;
+    cfg.device = device;
+    cfg.dedup_min_topics = dedupMinTopics > 0 ? (uint32_t)dedupMinTopics : 1u;
+    cfg.dedup_sorted = 1;
+    bmq_engine* e = NULL;
+    const int rc = bmq_engine_create(&cfg, &e);
+    if (rc != BMQ_OK) {
+        throw_state(env, NULL, "bmq_engine_create (a gfx950 device is required)", rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)e;
+}
 /* void destroy(long engine) */
 JNIEXPORT void JNICALL NM(destroy)(JNIEnv* env, jclass c, jlong h) {
     (void)env, (void)c;
