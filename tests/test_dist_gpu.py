@@ -294,10 +294,10 @@ def test_dedup_of_an_ordered_batch_by_neighbour_compare():
     pool += ["long/" + "y" * rnd.randrange(100, 900) for _ in range(40)]  # blocks whose bytes do not fit the LDS image; > 48 bytes per row on average
     tnames = tenants + ["ghost"]
     plain = B.Engine(device=0).rebuild(keys)
-    for n in (37, 900, 20000, 140000):
+    for n, kind in ((37, "zipf"), (900, "long"), (20000, "zipf"), (20000, "long"), (140000, "zipf")):
         topics = [pool[min(int(rnd.paretovariate(1.1)) - 1, len(pool) - 1)] for _ in range(n)]  # Zipf-like repeats
-        if n == 900:
-            topics = [rnd.choice(pool[-40:]) for _ in range(n)]  # long topics only: the first guess of the dense buffer is too small
+        if kind == "long":  # long topics only: the first guess of the dense buffer is too small (ST_NEED_ADJ); with 16 rows per wave (n = 20000) a
+            topics = [rnd.choice(pool[-40:]) for _ in range(n)]  # block's bytes outgrow the LDS image too: the byte-copy path of k_dd_adj_scatter
         tt = [rnd.randrange(len(tnames)) for _ in topics]
         for order in ("ordered", "grouped", "as is"):
             if order == "ordered":
@@ -310,10 +310,10 @@ def test_dedup_of_an_ordered_batch_by_neighbour_compare():
             row0, ids0 = plain.match_batch(tnames, tts, ts)
             st0 = plain.stats()
             assert st0.n_walked == n
-            if n <= 20000:
+            if n <= 20000 and order == "ordered":  # (the engine that never de-duplicates is itself checked against the oracle)
                 assert U.csr_rows(row0, ids0) == U.semantic_rows(kv, tnames, tts, ts)
             for geom in ({}, dict(wave_queue_cap=128, wave_pair_cap=128, slow_scratch_mb=1)):
-                if geom and n != 20000:
+                if geom and (n != 20000 or kind != "zipf"):
                     continue
                 e = B.Engine(device=0, dedup_min_topics=1, dedup_sorted=True, **geom).rebuild(keys)
                 for rep in range(2):  # (the second batch runs on buffers the first one sized)
