@@ -113,7 +113,6 @@ struct BatchArgs {
 // neighbours, the first row of a run (its HEAD) stands for the run, and the heads are copied into a dense batch of their own that the walk
 // kernels run on unchanged -- (c_topics, c_off, c_tenant) in the layout of (topics, topic_off, topic_tenant), the rows behind the last head
 // marked "no such tenant" (never walked).  Per-block sums use the super-block scheme of the id counts above.
-constexpr uint32_t ADJ_PENDING = 0xFFFFFFFFu; // rep[] between the two kernels: the row's head lies in an earlier block
 struct AdjArgs {
     const uint8_t* topics;
     const uint32_t* topic_off;
@@ -121,12 +120,10 @@ struct AdjArgs {
     uint32_t n_topics;
     uint32_t n_blocks;
     uint32_t tpw_shift;
-    uint32_t* rep;                  // [n_topics] out: the head of the row's run (a row index of the batch)
-    uint32_t* dense;                // [n_topics] out, heads only: the head's row in the dense batch
+    uint32_t* drow;                 // [n_topics] out: the dense row that answers for the row (its own, or its run head's)
+    unsigned long long* blk_mask;   // [n_blocks] bit l: row l of the block is a head (differs from the row before it)
     unsigned long long* blk_cnt;    // [n_blocks] heads << 32 | bytes of the heads' topics, per block of 2^tpw_shift rows
-    uint32_t* blk_last;             // [n_blocks] 1 + the block's last head row (0: the block has none)
-    unsigned long long* super_cnt;  // [n_super * SUPER_STRIDE] entry 0 of a line: the sum of blk_cnt over 2^SUPER_SHIFT blocks; entry 1: the
-                                    // largest blk_last among them (zeroed in front of every batch)
+    unsigned long long* super_cnt;  // [n_super * SUPER_STRIDE] entry 0 of a line: the sum of blk_cnt over 2^SUPER_SHIFT blocks (zeroed in front of every batch)
     uint8_t* c_topics;              // the dense batch (16-byte aligned, readable 16 bytes past the last byte like every packed input)
     unsigned long long c_cap;       // ... bytes it may hold; a batch whose heads need more raises ST_NEED_ADJ, walks nothing and runs again
     uint32_t* c_off;                // [n_topics + 1]

@@ -7,15 +7,18 @@
 // NEIGHBOURS: no hash table, no compare-and-swap (k_dedup spends 0.095 ms of a 1 M-publish batch on 10 k rows of one hot topic meeting
 // in one table slot), and -- what the hash variant cannot do -- the representatives come out in batch order, so
 // they are COPIED into a dense batch and the walk kernels run on that: 64 representatives per wave instead of 64 rows of which some are.
-//   k_dd_adj_heads   : one wave per block of rows; a row is a HEAD unless it equals the row before it (tenant index, length, bytes);
-//                      rep[row] = the nearest head at or before it inside the block, ADJ_PENDING where the run began in an earlier
-//                      block; per block: heads | bytes of the heads' topics, the last head; the same per super-block (one atomic each).
+//   k_dd_adj_heads   : one wave per block of rows; the block's bytes are staged in LDS (coalesced 16-byte loads); a row is a HEAD unless it
+//                      equals the row before it (tenant index, length, bytes); per block: the 64-bit mask of its heads, heads | bytes of
+//                      the heads' topics; the latter summed per super-block (one atomic).
 //   k_dd_adj_scatter : one wave per block; heads and bytes in front of the block from <= 4 + n_super / 64 loads per lane (the scheme of
-//                      k_expand's row pointers), the pending rows take the nearest head in front of the block; every head gets its dense
+//                      k_expand's row pointers); every row learns the DENSE ROW that answers for it (its own if it is a head, else the
+//                      last head at or before it: in front of the block that is dense row heads_before - 1); every head gets its dense
 //                      row (tenant, offset, bytes: the block's heads are ONE contiguous piece of the dense batch, assembled in LDS and
 //                      stored 16 bytes at a time); every other row marks one row behind the last head as "no such tenant".
-//   k_fill_adj       : (k_fill's part) behind the walk: a row takes the ranges and counts of its head's dense row; per-block id counts
+//   k_fill_adj       : (k_fill's part) behind the walk: a row takes the ranges and counts of its dense row; per-block id counts
 //                      and statistics, every row counted with its representative's figures.
+// First version (profiles/r05b/ordered_kernels_v1.txt): rows compared through dependent reads of global memory, row indices of the heads
+// resolved by a second look-up: 26 + 28 + 14 us per 1 M rows.
 // Nothing here depends on the batch BEING ordered: a row that equals no neighbour is its own head, whatever else the batch holds.
 #pragma once
 
@@ -24,21 +27,24 @@ namespace bmq {
 #ifndef BMQ_ADJ_IMG
 #define BMQ_ADJ_IMG 4096
 #endif
-constexpr uint32_t ADJ_IMG = BMQ_ADJ_IMG; // bytes of LDS a k_dd_adj_scatter wave assembles its heads' topics in (a block of longer topics: byte copies)
+constexpr uint32_t ADJ_IMG = BMQ_ADJ_IMG; // bytes of LDS a wave stages a block's topics in (k_dd_adj_heads) / assembles its heads' topics in (k_dd_adj_scatter);
+                                          // a block of longer topics: reads from global memory / byte copies
+static_assert(ADJ_IMG % 16 == 0 && ADJ_IMG >= 64, "16-byte chunks");
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((unsigned long long)v, d));
-    return v;
+#ifndef BMQ_WAVE_EMU
+// 4 bytes at byte offset rel of an LDS image (any alignment; the image is readable 4 bytes past what is asked for)
+__device__ __forceinline__ uint32_t lds_word_at(const uint32_t* words, uint32_t rel) {
+    return __builtin_amdgcn_alignbyte(words[(rel >> 2) + 1], words[rel >> 2], rel & 3u);
 }
-// rows a and b hold the same bytes (of the same length `len`)
-__device__ __forceinline__ bool adj_same_bytes(const uint8_t* base, uint32_t pa, uint32_t pb, uint32_t len) {
-    for (uint32_t k = 0; k < len; k += 16) { // four words per step: eight loads in flight
+#endif
+// rows at pa and pb hold the same `len` bytes; word_at(i) = 4 bytes at byte offset i of the batch
+template <class W> __device__ __forceinline__ bool adj_same_bytes(W word_at, uint32_t pa, uint32_t pb, uint32_t len) {
+    for (uint32_t k = 0; k < len; k += 16) { // four words per step
         uint32_t x = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 16; j += 4) {
             if (k + j >= len) break;
-            uint32_t w = global_word_at(base, pa + k + j) ^ global_word_at(base, pb + k + j);
+            uint32_t w = word_at(pa + k + j) ^ word_at(pb + k + j);
             if (len - (k + j) < 4) w &= (1u << (8u * (len - (k + j)))) - 1u;
             x |= w;
         }
@@ -48,36 +54,48 @@ __device__ __forceinline__ bool adj_same_bytes(const uint8_t* base, uint32_t pa,
 }
 
 __global__ __launch_bounds__(64) void k_dd_adj_heads(AdjArgs a) {
+    __shared__ uint4 img16[ADJ_IMG / 16 + 1]; // (+ 16 bytes: a word read at the image's last byte reaches past it)
     const uint32_t lane = threadIdx.x;
     const uint32_t blk = blockIdx.x;
     if (blk >= a.n_blocks) return;
-    const uint32_t t_first = blk << a.tpw_shift;
+    const uint32_t tpw = 1u << a.tpw_shift;
+    const uint32_t t_first = blk << a.tpw_shift, t_end = min(t_first + tpw, a.n_topics);
     const uint32_t t = t_first + lane;
-    const bool valid = lane < (1u << a.tpw_shift) && t < a.n_topics;
-    uint32_t len = 0;
-    bool head = false;
+    const bool valid = lane < tpw && t < a.n_topics;
+    // the block's bytes and those of the row in front of it, staged with coalesced 16-byte loads: every row is compared with its
+    // predecessor out of LDS (one trip to memory for the offsets, one for the bytes)
+    const uint32_t s_beg = uniform_word(a.topic_off + (t_first ? t_first - 1u : 0u)), s_end = uniform_word(a.topic_off + t_end);
+    const uint32_t a0 = s_beg & ~15u;
+    const bool staged = (s_end - a0) <= ADJ_IMG;
+    if (staged) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.topics + a0);
+        const uint32_t n16 = (s_end - a0 + 15u) >> 4;
+        for (uint32_t o = lane; o < n16; o += 64) img16[o] = src[o];
+    }
+    uint32_t pos = 0, len = 0, ppos = 0;
+    bool cand = false; // same tenant and length as the row before: the bytes decide
     if (valid) {
-        const uint32_t pos = a.topic_off[t], end = a.topic_off[t + 1];
-        len = end - pos;
-        head = true;
+        pos = a.topic_off[t];
+        len = a.topic_off[t + 1] - pos;
         if (t > 0) {
-            const uint32_t ppos = a.topic_off[t - 1];
-            if (pos - ppos == len && a.topic_tenant[t - 1] == a.topic_tenant[t]) head = !adj_same_bytes(a.topics, pos, ppos, len);
+            ppos = a.topic_off[t - 1];
+            cand = pos - ppos == len && a.topic_tenant[t - 1] == a.topic_tenant[t];
         }
     }
+    wave_sync();
+    bool head = valid;
+    if (cand) {
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(img16);
+        const uint8_t* gbytes = a.topics;
+        if (staged) head = !adj_same_bytes([&](uint32_t i) { return lds_word_at(words, i - a0); }, pos, ppos, len);
+        else head = !adj_same_bytes([&](uint32_t i) { return global_word_at(gbytes, i); }, pos, ppos, len);
+    }
     const unsigned long long heads = ballot64(head);
-    const unsigned long long upto = heads & ((2ull << lane) - 1ull); // (lane 63: 2 << 63 wraps to 0, minus one = every lane)
-    if (valid) a.rep[t] = upto ? t_first + 63u - (uint32_t)__builtin_clzll(upto) : ADJ_PENDING;
     const unsigned long long packed = wave_total_u64(head ? (1ull << 32) | len : 0ull); // (a batch's topic bytes are < 2^32: its offsets are 32 bits)
     if (lane == 0) {
-        const unsigned long long last1 = heads ? (unsigned long long)t_first + 64u - (uint32_t)__builtin_clzll(heads) : 0ull;
+        a.blk_mask[blk] = heads;
         a.blk_cnt[blk] = packed;
-        a.blk_last[blk] = (uint32_t)last1;
-        if (heads) {
-            unsigned long long* line = a.super_cnt + (size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE;
-            atomicAdd(line, packed);
-            atomicMax(line + 1, last1);
-        }
+        if (heads) atomicAdd(a.super_cnt + (size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE, packed);
     }
 }
 
@@ -93,45 +111,48 @@ __global__ __launch_bounds__(64) void k_dd_adj_scatter(AdjArgs a) {
     // what lies in front of this block: whole super-blocks + the blocks of its own super-block before it -- and the batch's totals
     const uint32_t sb = blk >> SUPER_SHIFT, w0 = sb << SUPER_SHIFT, n_super = ((a.n_blocks - 1u) >> SUPER_SHIFT) + 1u;
     unsigned long long before = 0, all = 0;
-    uint32_t near1 = 0; // 1 + the last head in front of the block
     for (uint32_t i = lane; i < n_super; i += 64) {
-        const unsigned long long c = a.super_cnt[(size_t)i * SUPER_STRIDE], l = a.super_cnt[(size_t)i * SUPER_STRIDE + 1];
+        const unsigned long long c = a.super_cnt[(size_t)i * SUPER_STRIDE];
         all += c;
-        if (i < sb) before += c, near1 = max(near1, (uint32_t)l);
+        if (i < sb) before += c;
     }
     static_assert(SUPER_SHIFT == 8, "four loads per lane cover a super-block");
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t i = w0 + lane + 64u * j, ii = min(i, blk);
-        const unsigned long long c = a.blk_cnt[ii];
-        const uint32_t l = a.blk_last[ii];
-        if (i < blk) before += c, near1 = max(near1, l);
+        const uint32_t i = w0 + lane + 64u * j;
+        const unsigned long long c = a.blk_cnt[min(i, blk)];
+        if (i < blk) before += c;
     }
-    uint32_t rep = 0, pos = 0, len = 0, ti = 0;
+    const unsigned long long heads = ((unsigned long long)uniform_word(reinterpret_cast<const uint32_t*>(a.blk_mask + blk) + 1) << 32) |
+                                     uniform_word(reinterpret_cast<const uint32_t*>(a.blk_mask + blk));
+    uint32_t pos = 0, len = 0, ti = 0;
     if (valid) {
-        rep = a.rep[t];
         pos = a.topic_off[t];
         len = a.topic_off[t + 1] - pos;
         ti = a.topic_tenant[t];
     }
+    const bool head = lane_bit(heads) != 0;
+    // a head's first words, requested before anything is waited for (a topic of the survey's workloads is 37 bytes: one trip)
+    constexpr uint32_t PRE = 12; // words held in registers
+    uint32_t pre[PRE];
+#pragma unroll
+    for (uint32_t k = 0; k < PRE; k++) pre[k] = (head && 4u * k < len) ? global_word_at(a.topics, pos + 4u * k) : 0u;
     before = wave_total_u64(before);
     all = wave_total_u64(all);
-    near1 = wave_max_u32(near1);
     const uint32_t heads_before = (uint32_t)(before >> 32), bytes_before = (uint32_t)before;
     const uint32_t n_heads = (uint32_t)(all >> 32), bytes_all = (uint32_t)all;
-    const bool head = valid && rep == t;
-    if (valid && rep == ADJ_PENDING) a.rep[t] = near1 - 1u; // (row 0 is a head: a pending row has one in front of its block)
     // The dense batch's bytes do not fit the buffer: every wave sees the same totals and takes this turn together -- the dense rows are all
     // marked "no such tenant" with empty topics (the walk kernels touch nothing), the host grows the buffer and runs the batch again.
     const bool over = (unsigned long long)bytes_all + 64u > a.c_cap;
-    const unsigned long long heads = ballot64(head);
     const uint32_t rk = rank_below(heads);
     const uint32_t hlen = head ? len : 0u;
     const uint32_t incl = wave_incl_scan(hlen);
     const uint32_t excl = incl - hlen, wbytes = read_lane(incl, 63);
+    // the dense row that answers for this row: its own if it is a head, else the last head at or before it -- in front of the block
+    // that is dense row heads_before - 1 (row 0 is a head: there is one)
+    if (valid) a.drow[t] = heads_before + rk + (head ? 1u : 0u) - 1u;
     if (head) {
         const uint32_t d = heads_before + rk;
-        a.dense[t] = d;
         a.c_tenant[d] = over ? 0xFFFFFFFFu : ti;
         a.c_off[d] = over ? 0u : bytes_before + excl;
         a.c_rep[d] = d;
@@ -155,13 +176,23 @@ __global__ __launch_bounds__(64) void k_dd_adj_scatter(AdjArgs a) {
     uint8_t* const dst0 = a.c_topics + (bytes_before - lead); // 16-byte aligned; image byte i <-> dst0[i]
     if (total <= ADJ_IMG) {
         if (head) {
-            for (uint32_t k = 0; k < hlen; k += 4) {
+            uint8_t* o = img + lead + excl;
+#pragma unroll
+            for (uint32_t k = 0; k < PRE; k++) {
+                if (4u * k < hlen) {
+                    const uint32_t w = pre[k];
+                    o[4u * k] = (uint8_t)w;
+                    if (4u * k + 1 < hlen) o[4u * k + 1] = (uint8_t)(w >> 8);
+                    if (4u * k + 2 < hlen) o[4u * k + 2] = (uint8_t)(w >> 16);
+                    if (4u * k + 3 < hlen) o[4u * k + 3] = (uint8_t)(w >> 24);
+                }
+            }
+            for (uint32_t k = 4u * PRE; k < hlen; k += 4) { // (longer topics)
                 const uint32_t w = global_word_at(a.topics, pos + k);
-                uint8_t* o = img + lead + excl + k;
-                o[0] = (uint8_t)w;
-                if (k + 1 < hlen) o[1] = (uint8_t)(w >> 8);
-                if (k + 2 < hlen) o[2] = (uint8_t)(w >> 16);
-                if (k + 3 < hlen) o[3] = (uint8_t)(w >> 24);
+                o[k] = (uint8_t)w;
+                if (k + 1 < hlen) o[k + 1] = (uint8_t)(w >> 8);
+                if (k + 2 < hlen) o[k + 2] = (uint8_t)(w >> 16);
+                if (k + 3 < hlen) o[k + 3] = (uint8_t)(w >> 24);
             }
         }
         wave_sync();
@@ -178,8 +209,7 @@ __global__ __launch_bounds__(64) void k_dd_adj_scatter(AdjArgs a) {
 }
 
 struct AdjFill {
-    const uint32_t* rep;
-    const uint32_t* dense;
+    const uint32_t* drow;
     const uint32_t* c_pair_off;
     const uint32_t* c_pair_cnt;
     const uint32_t* c_route_cnt;
@@ -194,11 +224,11 @@ __global__ __launch_bounds__(64) void k_fill_adj(BatchArgs a, AdjFill f) {
     const bool valid = lane < (1u << a.tpw_shift) && t < a.n_topics;
     uint32_t nr = 0, np = 0, vis = 0, bytes = 0;
     if (valid) {
-        const uint32_t r = f.dense[f.rep[t]];
+        const uint32_t r = f.drow[t];
+        bytes = a.topic_off[t + 1] - a.topic_off[t];
         np = f.c_pair_cnt[r];
         nr = f.c_route_cnt[r];
         vis = f.c_visit[r];
-        bytes = a.topic_off[t + 1] - a.topic_off[t];
         a.pair_off[t] = f.c_pair_off[r];
         a.pair_cnt[t] = np;
         a.route_cnt[t] = nr;

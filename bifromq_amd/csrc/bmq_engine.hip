@@ -120,7 +120,7 @@ struct bmq_engine {
     struct BatchSlot {
         DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave, b_rep, b_visit;
         // de-duplication of an ordered batch (bmq_dedup_adj_kernels.h): per-block sums, the dense batch of run heads and its per-row results
-        DevBuf b_dense, b_adj_cnt, b_adj_last, b_adj_super, b_c_topics, b_c_off, b_c_tenant, b_c_rep, b_c_pair_off, b_c_pair_cnt, b_c_route_cnt;
+        DevBuf b_drow, b_adj_cnt, b_adj_mask, b_adj_super, b_c_topics, b_c_off, b_c_tenant, b_c_rep, b_c_pair_off, b_c_pair_cnt, b_c_route_cnt;
         uint64_t adj_cap = 0; // bytes of b_c_topics in use as the dense batch's topic bytes (grown on ST_NEED_ADJ)
         DevBuf b_pair_off, b_pair_cnt, b_route_cnt, b_pairs, b_spill, b_wave_sums, b_slow_list, b_scratch, b_sort_list, b_ctr,
             b_total;
@@ -372,11 +372,10 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     if (adj) {
         const size_t n = a.n_topics, nb = a.n_blocks, n_super = ((nb - 1) >> SUPER_SHIFT) + 1;
         if (S.adj_cap == 0) S.adj_cap = 48 * n + 4096; // (a first guess: the scatter kernel asks for more -- ST_NEED_ADJ -- and the batch runs again)
-        HIPCHK(e, S.b_rep.ensure(4 * n));
         HIPCHK(e, S.b_visit.ensure(4 * n));
-        HIPCHK(e, S.b_dense.ensure(4 * n));
+        HIPCHK(e, S.b_drow.ensure(4 * n));
         HIPCHK(e, S.b_adj_cnt.ensure(8 * nb));
-        HIPCHK(e, S.b_adj_last.ensure(4 * nb));
+        HIPCHK(e, S.b_adj_mask.ensure(8 * nb));
         HIPCHK(e, S.b_adj_super.ensure(8 * SUPER_STRIDE * n_super));
         HIPCHK(e, S.b_c_topics.ensure(S.adj_cap + 64));
         HIPCHK(e, S.b_c_off.ensure(4 * (n + 1)));
@@ -387,17 +386,17 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         HIPCHK(e, S.b_c_route_cnt.ensure(4 * n));
         g.topics = a.topics, g.topic_off = a.topic_off, g.topic_tenant = a.topic_tenant;
         g.n_topics = a.n_topics, g.n_blocks = a.n_blocks, g.tpw_shift = a.tpw_shift;
-        g.rep = S.b_rep.as<uint32_t>(), g.dense = S.b_dense.as<uint32_t>();
-        g.blk_cnt = S.b_adj_cnt.as<unsigned long long>(), g.blk_last = S.b_adj_last.as<uint32_t>(), g.super_cnt = S.b_adj_super.as<unsigned long long>();
+        g.drow = S.b_drow.as<uint32_t>();
+        g.blk_cnt = S.b_adj_cnt.as<unsigned long long>(), g.blk_mask = S.b_adj_mask.as<unsigned long long>(), g.super_cnt = S.b_adj_super.as<unsigned long long>();
         g.c_topics = S.b_c_topics.as<uint8_t>(), g.c_cap = S.adj_cap;
         g.c_off = S.b_c_off.as<uint32_t>(), g.c_tenant = S.b_c_tenant.as<uint32_t>(), g.c_rep = S.b_c_rep.as<uint32_t>();
         g.ctr = a.ctr;
-        a.rep = g.rep; // (k_expand and the repair kernels see a de-duplicated batch: k_fill_adj writes the per-block sums)
+        a.rep = g.drow; // (only its being there matters to the kernels behind the walk: a de-duplicated batch, k_fill_adj writes the per-block sums)
         a.visit_cnt = S.b_visit.as<uint32_t>();
         a2 = a;
         a2.topics = g.c_topics, a2.topic_off = g.c_off, a2.topic_tenant = g.c_tenant, a2.rep = g.c_rep;
         a2.pair_off = S.b_c_pair_off.as<uint32_t>(), a2.pair_cnt = S.b_c_pair_cnt.as<uint32_t>(), a2.route_cnt = S.b_c_route_cnt.as<uint32_t>();
-        gf.rep = g.rep, gf.dense = g.dense, gf.c_pair_off = a2.pair_off, gf.c_pair_cnt = a2.pair_cnt, gf.c_route_cnt = a2.route_cnt, gf.c_visit = a2.visit_cnt;
+        gf.drow = g.drow, gf.c_pair_off = a2.pair_off, gf.c_pair_cnt = a2.pair_cnt, gf.c_route_cnt = a2.route_cnt, gf.c_visit = a2.visit_cnt;
     } else if (a.n_topics >= e->dedup_min) { // identical (tenant, topic) rows are walked once
         uint32_t cap = 1024;
         while (cap < 2 * a.n_topics && cap < (1u << 31)) cap <<= 1;

@@ -19,6 +19,11 @@ inline uint32_t global_word_at(const uint8_t* base, uint32_t p) { // 4 bytes at 
     memcpy(&w, base + p, 4);
     return w;
 }
+inline uint32_t lds_word_at(const uint32_t* words, uint32_t rel) { // (the device: two aligned LDS words + v_alignbyte)
+    uint32_t w;
+    memcpy(&w, reinterpret_cast<const uint8_t*>(words) + rel, 4);
+    return w;
+}
 } // namespace bmq
 #include "bmq_expand_kernel.h" // the cross-lane vocabulary (wave_total_u64, wave_incl_scan, read_lane)
 #include "bmq_dedup_adj_kernels.h"
@@ -67,15 +72,15 @@ static int one_case(std::mt19937_64& rng, uint32_t n, uint32_t tpw_shift, bool o
     for (uint32_t h : x_heads) x_bytes += off[h + 1] - off[h];
 
     const uint32_t nb = (n + (1u << tpw_shift) - 1) >> tpw_shift, n_super = ((nb - 1) >> SUPER_SHIFT) + 1;
-    std::vector<uint32_t> rep(n, 0xABABABABu), dense(n, 0xABABABABu), blk_last(nb, 0xABABABABu), c_off(n + 1, 0xABABABABu), c_tenant(n, 0xABABABABu), c_rep(n, 0xABABABABu);
-    std::vector<unsigned long long> blk_cnt(nb, ~0ull), super_cnt((size_t)n_super * SUPER_STRIDE, 0ull);
+    std::vector<uint32_t> drow(n, 0xABABABABu), c_off(n + 1, 0xABABABABu), c_tenant(n, 0xABABABABu), c_rep(n, 0xABABABABu);
+    std::vector<unsigned long long> blk_cnt(nb, ~0ull), blk_mask(nb, 0x5555ull), super_cnt((size_t)n_super * SUPER_STRIDE, 0ull);
     const uint64_t cap = short_buffer ? (uint64_t)x_bytes + 63 - rnd(std::min<uint32_t>(x_bytes + 1, 64)) : (uint64_t)x_bytes + 64 + rnd(100);
     std::vector<uint8_t> c_topics((size_t)x_bytes + 256, 0xCD);
     Counters ctr{};
     AdjArgs g{};
     g.topics = topics.data(), g.topic_off = off.data(), g.topic_tenant = tenant.data();
     g.n_topics = n, g.n_blocks = nb, g.tpw_shift = tpw_shift;
-    g.rep = rep.data(), g.dense = dense.data(), g.blk_cnt = blk_cnt.data(), g.blk_last = blk_last.data(), g.super_cnt = super_cnt.data();
+    g.drow = drow.data(), g.blk_cnt = blk_cnt.data(), g.blk_mask = blk_mask.data(), g.super_cnt = super_cnt.data();
     g.c_topics = c_topics.data(), g.c_cap = cap, g.c_off = c_off.data(), g.c_tenant = c_tenant.data(), g.c_rep = c_rep.data(), g.ctr = &ctr;
     for (uint32_t b = 0; b < nb; b++) wemu::run_wave(nb - 1 - b, [&] { k_dd_adj_heads(g); });
     // (the blocks in a scrambled order: nothing may depend on which wave runs first; every block once when 7 and nb are coprime -- else the rest
@@ -83,8 +88,10 @@ static int one_case(std::mt19937_64& rng, uint32_t n, uint32_t tpw_shift, bool o
     for (uint32_t b = 0; b < nb; b++) wemu::run_wave((b * 7 + 3) % nb, [&] { k_dd_adj_scatter(g); });
     if (nb % 7 == 0)
         for (uint32_t b = 0; b < nb; b++) wemu::run_wave(b, [&] { k_dd_adj_scatter(g); });
+    std::vector<uint32_t> dense(n, 0); // head row -> its dense row
+    for (uint32_t d = 0; d < x_heads.size(); d++) dense[x_heads[d]] = d;
     for (uint32_t i = 0; i < n; i++)
-        if (rep[i] != x_rep[i]) FAIL("rep[%u] = %u, expected %u (n %u tpw %u ordered %d)\n", i, rep[i], x_rep[i], n, 1u << tpw_shift, (int)ordered);
+        if (drow[i] != dense[x_rep[i]]) FAIL("drow[%u] = %u, expected %u (n %u tpw %u ordered %d)\n", i, drow[i], dense[x_rep[i]], n, 1u << tpw_shift, (int)ordered);
     if (ctr.n_walked != x_heads.size()) FAIL("n_walked %u, expected %zu\n", ctr.n_walked, x_heads.size());
     const bool over = (uint64_t)x_bytes + 64 > cap;
     if (over != ((ctr.status & ST_NEED_ADJ) != 0)) FAIL("ST_NEED_ADJ %u, expected %d\n", ctr.status, (int)over);
@@ -92,7 +99,7 @@ static int one_case(std::mt19937_64& rng, uint32_t n, uint32_t tpw_shift, bool o
     uint32_t run = 0;
     for (uint32_t d = 0; d < x_heads.size(); d++) {
         const uint32_t h = x_heads[d], len = off[h + 1] - off[h];
-        if (dense[h] != d || c_rep[d] != d) FAIL("dense[%u] = %u / c_rep %u, expected %u\n", h, dense[h], c_rep[d], d);
+        if (c_rep[d] != d) FAIL("c_rep[%u] = %u\n", d, c_rep[d]);
         if (over) {
             if (c_tenant[d] != 0xFFFFFFFFu || c_off[d] != 0) FAIL("over: dense row %u not neutral\n", d);
             continue;
@@ -115,7 +122,7 @@ static int one_case(std::mt19937_64& rng, uint32_t n, uint32_t tpw_shift, bool o
     a.topic_off = off.data(), a.n_topics = n, a.n_blocks = nb, a.tpw_shift = tpw_shift;
     a.pair_off = po.data(), a.pair_cnt = pc.data(), a.route_cnt = rc.data();
     a.wave_sums = wave_sums.data(), a.super_sums = super_sums.data(), a.blk_stats = blk_stats.data();
-    AdjFill f{rep.data(), dense.data(), cpo.data(), cpc.data(), crc.data(), cvis.data()};
+    AdjFill f{drow.data(), cpo.data(), cpc.data(), crc.data(), cvis.data()};
     for (uint32_t b = 0; b < nb; b++) wemu::run_wave(b, [&] { k_fill_adj(a, f); });
     std::vector<unsigned long long> x_super(n_super, 0);
     for (uint32_t b = 0; b < nb; b++) {
