@@ -75,7 +75,9 @@ typedef struct bmq_config {
     uint32_t dedup_sorted;     /* 1: the caller's batches are ORDERED by (tenant index, topic bytes) -- BatchDistRequest is "sorted by   */
                                /* tenantId and topic" (DistWorkerCoProc.proto:75-83) --, so the de-duplication above compares a row with */
                                /* the row before it instead of hashing, and the walk runs on a dense copy of the distinct rows.  Only    */
-                               /* speed depends on the order: a row that equals no neighbour is matched on its own.  0 = hash           */
+                               /* speed depends on the order: a row that equals no neighbour is matched on its own.  0 = hash.          */
+                               /* Measured on the survey's 1 M-publish batch (profiles/r05b/): 56 us of de-duplication (hash: 125 us)  */
+                               /* for 31 us less walking -- a loss there; a caller that sends every topic ONCE gains 17 %              */
     uint32_t reserved[5];
 } bmq_config;
 
