@@ -119,3 +119,40 @@ def test_compaction_leg_meets_its_bar():
     assert c["p99_ratio"] <= 2.0  # p99 of 1 M-topic batches during a compaction <= 2 x idle
     eq = c["rows_of_batch_0_equal_across_the_swap"]
     assert eq["row_sizes_equal"] and eq["old_id_to_new_id_is_one_increasing_map"] and eq["rows"] == 1_000_000
+
+
+def test_the_last_passes_of_the_round_are_self_consistent():
+    """profiles/r05b: the GPU suite and the driver's command on the FINAL code, and the ordered-batch leg -- the bench line's
+    leg agrees with the rocprofv3 trace of `bench.py --ordered-only` within 10 %, its parity flags are set, the four shapes say what DESIGN section 5
+    says they do, and the kernels whose traffic the line quotes are the ones profiles/r05 measured."""
+    R2 = os.path.join(ROOT, "profiles", "r05b")
+    log = open(os.path.join(R2, "pytest_gpu.log")).read()
+    assert "72 passed" in log and "failed" not in log
+    d = json.loads(open(os.path.join(R2, "bench_c3.json")).read().strip().splitlines()[-1])
+    assert "topic matches/sec" in d["metric"] and d["n_gpus"] == 1 and d["value"] > 3.0e9
+    assert d["roofline"]["traffic"] and "byte for byte" in d["roofline"]["traffic_source"]  # the sources changed, the measured kernel did not
+    assert d["cpu_baseline"]["parity"]["rows_compared"] == 1_000_000
+    o = d["extra"]["ordered_batch"]
+    assert o["ordered_dedup_sorted"]["rows_equal_undeduplicated_engine"] is True and o["ordered_distinct"]["rows_equal_heads_of_ordered_batch"] is True
+    assert o["ordered_dedup_sorted"]["n_walked"] == o["ordered_distinct"]["rows"] < o["as_generated"]["rows"] == 1_000_000
+    # same publishes, same answers: the per-row statistics of the three 1 M-row shapes agree
+    assert len({(o[k]["n_visit"], o[k]["n_match"]) for k in ("as_generated", "ordered_with_repeats", "ordered_dedup_sorted")}) == 1
+    trace = {}
+    for line in open(os.path.join(R2, "ordered_kernels.txt")):
+        if line.startswith("#"):
+            section = "us" if "kernel-trace" in line else "l2"
+            continue
+        name, rest = line[:30].strip(), line[30:]
+        toks = rest.replace("|", " ").split()
+        trace.setdefault(section, {})[name] = {toks[i]: float(toks[i + 1]) for i in range(0, len(toks) - 1) if toks[i][0].isalpha() and toks[i + 1][0].isdigit()}
+    us, l2 = trace["us"], trace["l2"]
+    for shape, key in (("as generated", "as_generated"), ("ordered, repeats kept", "ordered_with_repeats"), ("ordered, dedup_sorted", "ordered_dedup_sorted"),
+                       ("ordered, distinct rows only", "ordered_distinct")):
+        assert abs(us[shape]["k_walk"] - o[key]["kernel_ms"]["k_walk"] * 1e3) / us[shape]["k_walk"] < 0.10, shape
+    assert us["ordered, repeats kept"]["k_walk"] < 0.92 * us["as generated"]["k_walk"]          # the order helps the walk ...
+    assert us["ordered, repeats kept"]["k_expand"] > 1.25 * us["as generated"]["k_expand"]      # ... and costs the expansion
+    assert l2["ordered, repeats kept"]["TCC_REQ_sum"] < 0.7 * l2["as generated"]["TCC_REQ_sum"]
+    dd = us["ordered, dedup_sorted"]
+    assert dd["k_dd_adj_heads"] + dd["k_dd_adj_scatter"] + dd["k_fill_adj"] < 60  # (the hashing variant: 125 us)
+    assert o["ordered_distinct"]["publishes_per_s"] > 1.1 * o["as_generated"]["publishes_per_s"]  # every topic once: what pays
+    assert o["ordered_dedup_sorted"]["publishes_per_s"] < o["ordered_with_repeats"]["publishes_per_s"]  # the device-side variant loses: off by default
