@@ -227,6 +227,17 @@ __global__ __launch_bounds__(64) void k_reset(Counters* ctr, SubAlloc* subs, uns
     if (i < n_super) super_sums[(size_t)i * SUPER_STRIDE] = 0ull;
 }
 
+// k_publish: the batch's counters -> the slot's page-locked host copy, behind the batch's last kernel.  Where it stands a 336-byte
+// hipMemcpyAsync stood: that copy runs on an SDMA engine, i.e. on another hardware queue that has to be signalled and signals back -- for the
+// small launches of the batching front (tens of topics, ~60 us in all) a kernel that stays in the compute queue is the shorter way
+// (engine: publish_mode; the stores are visible to the host when the event behind the kernel has completed, like the results such
+// launches write in place into page-locked memory).
+static_assert(sizeof(Counters) % 16 == 0 && sizeof(Counters) / 16 <= 64, "one wave copies the counters, 16 bytes per lane");
+__global__ __launch_bounds__(64) void k_publish(const Counters* ctr, Counters* host) {
+    const uint32_t i = threadIdx.x;
+    if (i < sizeof(Counters) / 16) reinterpret_cast<uint4*>(host)[i] = reinterpret_cast<const uint4*>(ctr)[i];
+}
+
 // The directory entry of a batch tenant (EMPTY_TENANT: no such tenant).  Resolved by the walk kernels themselves, per topic: the
 // lanes of a wave mostly share one tenant (batches arrive grouped by tenant) and every wave of the launch keeps the few lines
 // involved hot in L2 -- as a kernel of its own in front of the walk the same lookups were cold, dependent round trips.

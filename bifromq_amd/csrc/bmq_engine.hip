@@ -108,6 +108,7 @@ struct bmq_engine {
     DevBuf dd_table;                       // in-batch de-duplication (bmq_dedup_kernels.h): one table for all batch slots (batches run in stream order)
     uint32_t dd_gen = 0;                   // generation of the last batch that used it (1..255; 0: fresh / just zeroed)
     uint32_t dedup_min = 0xFFFFFFFFu;      // batches of at least this many topics are de-duplicated (bmq_config.dedup_min_topics; default: never)
+    int publish_mode = 1;                  // a batch's counters reach the host through k_publish: 0 never (hipMemcpyAsync), 1 launches of fewer than 4096 topics, 2 always (BMQ_PUBLISH_KERNEL)
     bool dedup_sorted = false;             // ... by comparing neighbours: the caller's batches are ordered by (tenant, topic) (bmq_config.dedup_sorted)
     bool mixed_on = false;                 // k_walk runs in its MIXED instantiation (batches are not grouped by tenant)
     uint32_t mixed_idle = 0;
@@ -127,6 +128,7 @@ struct bmq_engine {
         uint64_t pair_cap = 0, scratch_cap = 0, spill_cap = 0;
         uint32_t slow_cap = 0, sort_cap = 0;
         Counters* h_ctr = nullptr; // pinned
+        Counters* d_h_ctr = nullptr; // ... as the device addresses it (k_publish)
         // staging for the host-buffer API
         DevBuf s_tenants, s_tenant_off, s_topic_tenant, s_topics, s_topic_off, s_row_ptr, s_ids, s_lim, s_lim_ids, s_lim_tmp;
         hipEvent_t ev[8]{};
@@ -470,7 +472,9 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         const int frc = enqueue_ranges(e, S, a);
         if (frc) return frc;
     }
-    HIPCHK(e, hipMemcpyAsync(S.h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    // the counters' way to the host: a kernel for small launches (k_publish: stays in the compute queue), the copy engine otherwise
+    if (S.d_h_ctr && (e->publish_mode == 2 || (e->publish_mode == 1 && a.n_topics < 4096))) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, a.ctr, S.d_h_ctr);
+    else HIPCHK(e, hipMemcpyAsync(S.h_ctr, a.ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipEventRecord(S.ev_done, s));
     reset_slot(e, S, s); // behind the batch: the counters / allocators are clean again when the next batch arrives
     HIPCHK(e, hipGetLastError());
@@ -720,6 +724,7 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     if (c.dedup_min_topics) e->dedup_min = c.dedup_min_topics;
     if (const char* v = getenv("BMQ_DEDUP_MIN")) e->dedup_min = (uint32_t)strtoul(v, nullptr, 10); // profiling experiments (4294967295: never)
     e->dedup_sorted = c.dedup_sorted != 0;
+    if (const char* v = getenv("BMQ_PUBLISH_KERNEL")) e->publish_mode = atoi(v); // profiling experiments
     if (const char* v = getenv("BMQ_WALK_GEOM")) e->walk_geom = atoi(v);
     if (const char* v = getenv("BMQ_WALK_MIXED")) e->mixed_on = atoi(v) != 0; // profiling experiments
     e->kernel_events = c.kernel_timing != 0;
@@ -742,6 +747,7 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
                 return BMQ_E_HIP;
             if (hipHostMalloc((void**)&sl.h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) return BMQ_E_NOMEM;
             memset(sl.h_ctr, 0, sizeof(Counters));
+            if (hipHostGetDevicePointer((void**)&sl.d_h_ctr, sl.h_ctr, 0) != hipSuccess) sl.d_h_ctr = nullptr; // (then: the copy engine, always)
             if (hipEventCreateWithFlags(&sl.ev_fmt, hipEventDisableTiming) != hipSuccess) return BMQ_E_HIP;
             if (hipHostMalloc((void**)&sl.h_fsums, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return BMQ_E_NOMEM;
             memset(sl.h_fsums, 0, 4 * sizeof(unsigned long long));
