@@ -122,7 +122,7 @@ def test_compaction_leg_meets_its_bar():
 
 
 def test_the_last_passes_of_the_round_are_self_consistent():
-    """profiles/r05b: the GPU suite and the driver's command on the FINAL code, and the ordered-batch leg -- the bench line's
+    """profiles/r05b: the GPU suite and the driver's command after the ordered-batch work, and the ordered-batch leg -- the bench line's
     leg agrees with the rocprofv3 trace of `bench.py --ordered-only` within 10 %, its parity flags are set, the four shapes say what DESIGN section 5
     says they do, and the kernels whose traffic the line quotes are the ones profiles/r05 measured."""
     R2 = os.path.join(ROOT, "profiles", "r05b")
