@@ -94,6 +94,7 @@ struct BatchArgs {
     uint32_t pcap; // >= 128
     // in-batch de-duplication (bmq_dedup_kernels.h); rep == nullptr: off
     uint32_t* rep;                  // [n_topics] the row that stands for this row's (tenant, topic): itself, or an identical earlier claimant
+                                    // (bmq_config.dedup_sorted: the walk kernels get the dense batch's identity, the kernels behind them any non-null pointer)
     uint32_t* visit_cnt;            // [n_topics] nodes discovered for the row's topic (written for representatives)
     unsigned long long* dd_table;   // open addressing, dd_mask + 1 entries: generation << 56 | hash tag << 32 | row
     uint32_t dd_mask;
