@@ -438,3 +438,27 @@ def test_ops_of_one_batch_apply_in_order_also_when_the_filter_is_new():
         assert sorted(k for k in eng.route_keys(np.arange(int(info.next_route_id), dtype=np.uint32)) if k) == live
     finally:
         eng.close()
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
+    """bifromq_amd/_lib.py restates bmq_config / bmq_stats / bmq_index_info of include/bmq.h as ctypes structures: same size, every field at the
+    same offset (a C program prints what the compiler makes of the header)."""
+    import ctypes as C
+    import subprocess
+
+    from bifromq_amd import _lib
+    structs = {"bmq_config": _lib.Config, "bmq_stats": _lib.Stats, "bmq_index_info": _lib.IndexInfo}
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "bmq.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True, text=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
