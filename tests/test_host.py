@@ -441,13 +441,15 @@ def test_ops_of_one_batch_apply_in_order_also_when_the_filter_is_new():
 
 
 def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
-    """bifromq_amd/_lib.py restates bmq_config / bmq_stats / bmq_index_info of include/bmq.h as ctypes structures: same size, every field at the
-    same offset (a C program prints what the compiler makes of the header)."""
+    """bifromq_amd/_lib.py restates the structures of include/bmq.h as ctypes structures: same size, every field at the same offset (a C program
+    prints what the compiler makes of the header)."""
     import ctypes as C
     import subprocess
 
     from bifromq_amd import _lib
-    structs = {"bmq_config": _lib.Config, "bmq_stats": _lib.Stats, "bmq_index_info": _lib.IndexInfo}
+    structs = {"bmq_config": _lib.Config, "bmq_stats": _lib.Stats, "bmq_index_info": _lib.IndexInfo, "bmq_batcher_config": _lib.BatcherConfig,
+               "bmq_batcher_stats": _lib.BatcherStats, "bmq_route_cache_config": _lib.RouteCacheConfig, "bmq_route_cache_stats": _lib.RouteCacheStats,
+               "bmq_route_cache_tenant_stats": _lib.RouteCacheTenantStats, "bmq_retain_info": _lib.RetainInfo, "bmq_ranges_info": _lib.RangesInfo}
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "bmq.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
