@@ -28,7 +28,9 @@
 //   k_sort_rows       : bitonic fix-up of rows whose range list was too long to order in k_expand; launched only while batches
 //                       have such rows.
 #pragma once
+#ifndef BMQ_WAVE_EMU // (tools/emu/walk_emu.cpp compiles this file with g++ against the wave64 emulator: the device-only pieces step aside)
 #include <hip/hip_runtime.h>
+#endif
 
 #include <type_traits>
 
@@ -43,6 +45,7 @@ namespace bmq {
 // Waves of one workgroup are independent here (each owns a slice of LDS).  LDS operations of ONE wave execute in issue
 // order, so lanes of a wave see each other's LDS writes without a hardware barrier; this only stops the compiler from
 // moving LDS accesses across the hand-off point.
+#ifndef BMQ_WAVE_EMU
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -52,6 +55,7 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+#endif
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t& total) {
     uint32_t inc = v;
 #pragma unroll
@@ -85,6 +89,7 @@ struct Line64 {
     uint4 a0, a1, b0, b1;
 };
 static_assert(DICT_GROUP == 2, "a dictionary group is one Line64");
+#ifndef BMQ_WAVE_EMU
 __device__ __forceinline__ void load_line64(const void* p, Line64& r) {
     asm volatile("global_load_dwordx4 %0, %4, off\n\t"
                  "global_load_dwordx4 %1, %4, off offset:16\n\t"
@@ -104,6 +109,10 @@ __device__ __forceinline__ void load_line64_s(const void* sbase, uint32_t voff, 
                  : "=&v"(r.a0), "=&v"(r.a1), "=&v"(r.b0), "=&v"(r.b1)
                  : "v"(voff), "s"(sbase));
 }
+#else // (emulator: the same bytes through memcpy)
+inline void load_line64(const void* p, Line64& r) { memcpy(&r, p, 64); }
+inline void load_line64_s(const void* sbase, uint32_t voff, Line64& r) { memcpy(&r, reinterpret_cast<const uint8_t*>(sbase) + voff, 64); }
+#endif
 // ------------------------------------------------------------------------------------------------------------
 // dictionary lookup (exact: tag + length + bytes).  ONE latency: the whole home group (one 64-byte line) is requested together.
 // byte_at(i) returns byte i of the string buffer the level lives in (LDS-staged or global).
@@ -137,6 +146,7 @@ __device__ __forceinline__ uint32_t dict_lookup(const DistIndexView& ix, const L
 // strings sit in slot 0 -- the second slot is requested only by the lanes that need it.  Half the bytes through the L1 / L2 path per lookup
 // for a dependent second request now and then: right for k_walk, whose tokeniser runs under the other waves' walk rounds while the kernel
 // as a whole sits at the memory system's rate of 64-byte lines (profiles/r04/k_walk_experiments.md).
+#ifndef BMQ_WAVE_EMU
 __device__ __forceinline__ void load_slot32(const void* p, uint4& a, uint4& b) {
     asm volatile("global_load_dwordx4 %0, %2, off\n\t"
                  "global_load_dwordx4 %1, %2, off offset:16\n\t"
@@ -144,6 +154,12 @@ __device__ __forceinline__ void load_slot32(const void* p, uint4& a, uint4& b) {
                  : "=&v"(a), "=&v"(b)
                  : "v"(p));
 }
+#else
+inline void load_slot32(const void* p, uint4& a, uint4& b) {
+    memcpy(&a, p, 16);
+    memcpy(&b, reinterpret_cast<const uint8_t*>(p) + 16, 16);
+}
+#endif
 template <class ByteAt>
 __device__ __forceinline__ uint32_t dict_lookup_by_slot(const DistIndexView& ix, const LevelHash& h, uint32_t len, const uint32_t inl[4], uint32_t start,
                                                         ByteAt&& byte_at) {
@@ -304,7 +320,11 @@ __device__ __forceinline__ TenantSlot tenant_verdict(const BatchArgs& a, const T
 }
 // The same lookup for a wave-uniform tenant, on the scalar unit: the loads go through the constant address space (s_load, scalar
 // cache), which is legal because neither the batch's tenant table nor the index is written while a batch runs.
+#ifndef BMQ_WAVE_EMU
 typedef const uint32_t __attribute__((address_space(4))) * ScalarWords;
+#else
+typedef const uint32_t* ScalarWords;
+#endif
 __device__ __forceinline__ ScalarWords scalar_words(const void* p) { return (ScalarWords)(uintptr_t)p; }
 __device__ __forceinline__ uint32_t scalar_word_at(const void* base, uint32_t p) { // 4 bytes at byte offset p, any alignment
     ScalarWords q = scalar_words(base) + (p >> 2);
@@ -421,13 +441,19 @@ __device__ __forceinline__ void step_item(const DistIndexView& ix, const TenantS
 }
 
 // profiling experiments only (BMQ_DEBUG=2): a time stamp behind everything this wave has requested so far
+#ifndef BMQ_WAVE_EMU
 __device__ __forceinline__ unsigned long long dbg_clock(bool on) {
     if (!on) return 0ull;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     return __builtin_amdgcn_s_memtime();
 }
+#else
+inline unsigned long long dbg_clock(bool) { return 0ull; }
+#endif
 } // namespace bmq
+#ifndef BMQ_WAVE_EMU
 #include "bmq_dedup_kernels.h" // k_dedup / k_fill: identical (tenant, topic) rows of a batch are walked once
+#endif
 #include "bmq_walk_kernel.h"   // k_walk<TC, QC, PC, MIXED>: one wave (= one 64-thread workgroup) per 64 topics
 namespace bmq {
 
@@ -559,6 +585,7 @@ namespace bmq {
 // of the row in global memory; round 3 ran the whole network in global memory: 66 round trips for a 1000-id row, 157 us per C2 batch
 // for a few hundred rows), in global memory beyond
 // ------------------------------------------------------------------------------------------------------------
+#ifndef BMQ_WAVE_EMU // (a 256-thread workgroup with __syncthreads: not a single-wave kernel)
 constexpr uint32_t SORT_LDS = 4096;
 __global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
     __shared__ uint32_t s_v[SORT_LDS];
@@ -597,5 +624,7 @@ __global__ __launch_bounds__(256) void k_sort_rows(BatchArgs a) {
         }
     }
 }
+
+#endif
 
 } // namespace bmq

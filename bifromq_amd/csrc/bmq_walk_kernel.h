@@ -61,6 +61,7 @@ template <int TC, int QC, int PC, bool MIXED> struct WalkLds { // byte offsets i
 // -- and a kernel that uses ANY scratch got 5 wave slots per SIMD instead of 8 in this process, measured with the census: BMQ_DEBUG=8).
 // (Reading the kernel's arguments through an opaque copy of the kernarg pointer, to keep the compiler from loading all 328 bytes at the
 // entry, was tried too: it made the register allocation worse -- 60 VGPRs spilled -- and was dropped.)
+#ifndef BMQ_WAVE_EMU
 __device__ __forceinline__ uint32_t lane_here() {
     uint32_t v = threadIdx.x;
     asm volatile("" : "+v"(v));
@@ -68,6 +69,7 @@ __device__ __forceinline__ uint32_t lane_here() {
 }
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#endif
 
 template <int TC, int QC, int PC, bool MIXED>
 __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_walk(BatchArgs a) {

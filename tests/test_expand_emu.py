@@ -60,3 +60,19 @@ def test_dedup_of_an_ordered_batch_under_the_wave_emulator(tmp_path, defs, cases
     r = subprocess.run([exe, str(cases), "12345"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("dedup_adj emu ok:"), r.stdout
+
+
+@pytest.mark.parametrize("seed", [12345, 777])
+def test_the_match_kernels_of_the_dist_direction_under_the_wave_emulator(tmp_path, seed):
+    """tools/emu/walk_emu.cpp: k_walk<TC, QC, PC, MIXED> (the dominant kernel; both LDS geometries, the grouped and the MIXED instantiation), k_walk_slow
+    and k_expand behind them, compiled by g++ from the product's sources (bmq_dist_kernels.h with its device-only pieces stepped aside: the library's
+    machine code is unchanged, tools/kernel_isa.py) and run on indexes the product's own builder makes on the host -- fresh and after mutations -- against a
+    brute force over the model's route keys: '$' topics, empty levels, unknown tenants, waves that hold several tenants, batches in any order, topics and
+    filters deeper than FAST_LEVELS, spill chains of the stack and the range buffer; the harness fails if its cases miss one of those paths."""
+    exe = str(tmp_path / "walk_emu")
+    cmd = ["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "bifromq_amd", "csrc"), "-I", os.path.join(ROOT, "tools", "emu"),
+           os.path.join(ROOT, "tools", "emu", "walk_emu.cpp"), os.path.join(ROOT, "bifromq_amd", "csrc", "bmq_codec.cpp"), "-o", exe, "-pthread"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([exe, "16", str(seed)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.startswith("walk emu ok:"), r.stdout

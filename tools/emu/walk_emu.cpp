@@ -1,0 +1,298 @@
+// walk_emu.cpp -- host-side logic test of the dist direction's match kernels -- k_walk<TC, QC, PC, MIXED> (bmq_walk_kernel.h), k_walk_slow
+// (bmq_dist_kernels.h) and k_expand behind them -- under the wave64 emulator of wave_emu.h, on indexes the product's own builder makes
+// (bmq_dist_index.h through HostExec: the code the builder kernels run).  Test tooling: the kernels' LOGIC -- tokeniser and ragged token
+// table, chunked waves, the work stack and the range buffer with their spill chains (smallest LDS lists), tenants of a wave walked one after
+// the other, the MIXED instantiation for batches that are not grouped by tenant, '$' topics, empty levels, unknown tenants, topics deeper than
+// FAST_LEVELS (k_walk_slow), indexes after mutations (id lists, indirect ranges) -- against a brute force over the model's route keys
+// (the rule of SURVEY.md 8a-0).  What the GPU makes of the same source is what tests/ (-m gpu) check against the oracle.
+//   g++ -O1 -g -std=c++17 -I bifromq_amd/csrc -I tools/emu tools/emu/walk_emu.cpp bifromq_amd/csrc/bmq_codec.cpp -o build/walk_emu -pthread && build/walk_emu [rounds] [seed]
+#define BMQ_WAVE_EMU 1
+#include "wave_emu.h"
+
+#include <map>
+#include <random>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "bmq_codec.h"
+#include "bmq_dist_index.h"
+#include "bmq_exec_host.h"
+
+// the device builtins the kernels' sources spell out
+#define __align__(n)
+inline uint32_t wemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (s & 3u))); }
+#define __builtin_amdgcn_alignbyte(hi, lo, s) wemu_alignbyte((hi), (lo), (s))
+#define __builtin_amdgcn_readlane(v, l) ((int)bmq::read_lane((uint32_t)(v), (uint32_t)(l)))
+#define __builtin_amdgcn_s_getreg(x) 0u
+#define __ffs(x) __builtin_ffs(x)
+#define __popc(x) __builtin_popcount(x)
+namespace bmq {
+inline uint32_t lds_word_at(const uint32_t* words, uint32_t rel) { // (bmq_dedup_adj_kernels.h comes along with bmq_dist_kernels.h)
+    uint32_t w;
+    memcpy(&w, reinterpret_cast<const uint8_t*>(words) + rel, 4);
+    return w;
+}
+} // namespace bmq
+#include "bmq_dist_kernels.h"
+
+using namespace bmq;
+
+static std::vector<std::string> split(std::string_view s, char sep) {
+    std::vector<std::string> out;
+    size_t b = 0;
+    for (size_t i = 0; i <= s.size(); i++)
+        if (i == s.size() || s[i] == sep) {
+            out.emplace_back(s.substr(b, i - b));
+            b = i + 1;
+        }
+    return out;
+}
+// the rule itself, on level lists
+static bool filter_matches(const std::vector<std::string>& f, const std::vector<std::string>& t) {
+    for (size_t i = 0; i < f.size(); i++) {
+        const bool wild0 = i == 0 && !t.empty() && !t[0].empty() && t[0][0] == '$';
+        if (f[i] == "#" && i + 1 == f.size()) return !wild0;
+        if (i >= t.size()) return false;
+        if (f[i] == "+") {
+            if (wild0) return false;
+            continue;
+        }
+        if (f[i] != t[i]) return false;
+    }
+    return f.size() == t.size();
+}
+
+#define FAIL(...)                     \
+    do {                              \
+        fprintf(stderr, __VA_ARGS__); \
+        return 1;                     \
+    } while (0)
+
+template <class T> static T* buf(std::vector<uint8_t>& store, size_t n) {
+    store.assign(n * sizeof(T) + 64, 0);
+    return reinterpret_cast<T*>(store.data());
+}
+
+struct Coverage {
+    uint64_t rows = 0, ids = 0, batches = 0, mixed = 0, slow_rows = 0, spills = 0, chunked = 0, sorted_rows = 0, after_apply = 0, two_tenant_waves = 0;
+};
+
+// one batch through walk (+ slow) + expand; rows -> sorted id lists
+template <int TC, int QC, int PC>
+static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tnames, const std::vector<uint32_t>& tt, const std::vector<std::string>& topics, uint32_t tpw_shift,
+                     std::vector<std::vector<uint32_t>>& rows, Coverage& cov) {
+    const uint32_t n = (uint32_t)topics.size();
+    std::vector<uint8_t> tb, pb;
+    std::vector<uint32_t> toff{0}, poff{0};
+    for (auto& s : tnames) tb.insert(tb.end(), s.begin(), s.end()), toff.push_back((uint32_t)tb.size());
+    for (auto& s : topics) pb.insert(pb.end(), s.begin(), s.end()), poff.push_back((uint32_t)pb.size());
+    tb.resize(tb.size() + 32, 0), pb.resize(pb.size() + 32, 0);
+    // the topic bytes 16-byte aligned, as the ABI asks
+    std::vector<uint8_t> pstore(pb.size() + 32);
+    uint8_t* pal = pstore.data() + ((16 - ((uintptr_t)pstore.data() & 15)) & 15);
+    memcpy(pal, pb.data(), pb.size());
+    const uint32_t nb = (n + (1u << tpw_shift) - 1) >> tpw_shift, n_super = ((nb - 1) >> SUPER_SHIFT) + 1;
+    std::vector<uint8_t> s_po, s_pc, s_rc, s_pairs, s_subs, s_super, s_stats, s_spill, s_ws, s_slow, s_scr, s_sort, s_ctr, s_row, s_ids, s_tot;
+    BatchArgs a{};
+    a.ix = ix;
+    a.tenants = tb.data(), a.tenant_off = toff.data(), a.n_tenants = (uint32_t)tnames.size();
+    a.topic_tenant = tt.data(), a.topics = pal, a.topic_off = poff.data(), a.n_topics = n;
+    a.pair_cap = 1u << 16, a.spill_cap = 1u << 16, a.slow_cap = n + 8, a.scratch_cap = 1u << 20, a.sort_cap = n + 8;
+    a.n_blocks = nb, a.tpw_shift = tpw_shift;
+    a.qcap = QC, a.pcap = PC;
+    const uint64_t out_cap = 1u << 20;
+    bool mixed = false;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        a.pair_off = buf<uint32_t>(s_po, n), a.pair_cnt = buf<uint32_t>(s_pc, n), a.route_cnt = buf<uint32_t>(s_rc, n);
+        a.pairs = buf<MatchRange>(s_pairs, a.pair_cap), a.subs = buf<SubAlloc>(s_subs, 2 * N_SUB + 1);
+        a.subs = reinterpret_cast<SubAlloc*>(((uintptr_t)a.subs + 127) & ~(uintptr_t)127);
+        a.super_sums = buf<unsigned long long>(s_super, (size_t)n_super * SUPER_STRIDE), a.blk_stats = buf<uint4>(s_stats, nb);
+        a.spill = buf<uint4>(s_spill, a.spill_cap), a.wave_sums = buf<unsigned long long>(s_ws, nb);
+        a.slow_list = buf<uint32_t>(s_slow, a.slow_cap), a.scratch = buf<uint32_t>(s_scr, a.scratch_cap), a.sort_list = buf<uint32_t>(s_sort, a.sort_cap);
+        a.ctr = buf<Counters>(s_ctr, 1);
+        a.out_row_ptr = buf<uint32_t>(s_row, n + 1), a.out_ids = buf<uint32_t>(s_ids, out_cap), a.out_capacity = out_cap;
+        a.out_total = buf<unsigned long long>(s_tot, 1);
+        wemu::grid_size() = nb;
+        for (uint32_t b = 0; b < nb; b++) {
+            if (mixed) wemu::run_wave(b, [&] { k_walk<TC, QC, PC, true>(a); });
+            else wemu::run_wave(b, [&] { k_walk<TC, QC, PC, false>(a); });
+        }
+        if ((a.ctr->status & ST_WANT_MIXED) && !mixed) { // the batch is not grouped by tenant: once more through the instantiation for that (bmq_engine.hip)
+            mixed = true;
+            cov.mixed++;
+            continue;
+        }
+        if (a.ctr->status & ST_RERUN) FAIL("walk asked for larger buffers: status %u (the harness' are meant to be large enough)\n", a.ctr->status);
+        if (a.ctr->slow_count) {
+            cov.slow_rows += a.ctr->slow_count;
+            wemu::grid_size() = 2;
+            for (uint32_t b = 0; b < 2; b++) wemu::run_wave(b, [&] { k_walk_slow(a); });
+            if (a.ctr->status & ST_RERUN) FAIL("slow walk asked for larger buffers: status %u\n", a.ctr->status);
+        }
+        break;
+    }
+    {
+        unsigned long long spilled = 0; // records handed out by the spill area's sub-allocators: a full range buffer was flushed, a full stack parked
+        for (uint32_t i = 0; i < N_SUB; i++) spilled += a.subs[N_SUB + i].used;
+        if (spilled) cov.spills++;
+    }
+    wemu::grid_size() = nb;
+    for (uint32_t b = 0; b < nb; b++) wemu::run_wave(b, [&] { k_expand(a); });
+    if (a.ctr->status & (ST_NOSPACE | ST_RANGE | ST_RERUN)) FAIL("expand: status %u\n", a.ctr->status);
+    if (*a.out_total != a.out_row_ptr[n]) FAIL("total %llu, row_ptr[n] %u\n", *a.out_total, a.out_row_ptr[n]);
+    rows.assign(n, {});
+    std::set<uint32_t> to_sort(a.sort_list, a.sort_list + std::min(a.ctr->sort_count, a.sort_cap));
+    cov.sorted_rows += to_sort.size();
+    for (uint32_t t = 0; t < n; t++) {
+        rows[t].assign(a.out_ids + a.out_row_ptr[t], a.out_ids + a.out_row_ptr[t + 1]);
+        if (to_sort.count(t)) std::sort(rows[t].begin(), rows[t].end()); // (k_sort_rows' business)
+        else if (!std::is_sorted(rows[t].begin(), rows[t].end())) FAIL("row %u is not ascending and not listed for k_sort_rows\n", t);
+        cov.ids += rows[t].size();
+    }
+    cov.rows += n, cov.batches++;
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 12;
+    const uint64_t seed = argc > 2 ? strtoull(argv[2], nullptr, 0) : 1;
+    std::mt19937_64 rng(seed);
+    auto rnd = [&](size_t n) { return (size_t)(rng() % n); };
+    const std::vector<std::string> tenants = {"t", "tenantB", "x", "a-much-longer-tenant-identifier", ""};
+    const std::vector<std::string> alpha = {"a", "b", "c", "", "$sys", "+", "a-level-longer-than-sixteen-bytes", "\xE4\xBD\xA0\xE5\xA5\xBD", "0", "exactly-16-bytes", "#"};
+    auto rand_filter = [&](size_t max_depth) {
+        std::string f;
+        const size_t depth = 1 + rnd(max_depth);
+        for (size_t i = 0; i < depth; i++) {
+            if (i) f += '/';
+            if (i + 1 == depth && rnd(5) == 0) f += "#";
+            else {
+                std::string l = alpha[rnd(alpha.size())];
+                if (l == "#") l = "#x";
+                f += l;
+            }
+        }
+        return f;
+    };
+    auto rand_topic = [&](size_t max_depth) {
+        std::string t;
+        const size_t depth = 1 + rnd(max_depth);
+        for (size_t i = 0; i < depth; i++) {
+            if (i) t += '/';
+            std::string l = alpha[rnd(alpha.size())];
+            if (l == "+" || l == "#") l = "zz";
+            t += l;
+        }
+        return t;
+    };
+    auto rand_key = [&](size_t max_depth) {
+        const std::string& tn = tenants[rnd(tenants.size())];
+        const uint8_t flag = rnd(10) == 0 ? 2 : 1;
+        return encode_route_key(tn, rand_filter(max_depth), flag,
+                                flag == 1 ? std::to_string(rnd(3)) + std::string("\0", 1) + "inbox" + std::to_string(rnd(40)) + std::string("\0d", 2) + std::to_string(rnd(12))
+                                          : "g" + std::to_string(rnd(3)));
+    };
+    Coverage cov;
+    for (int round = 0; round < rounds; round++) {
+        HostExec hx;
+        hx.threads = 2;
+        DistIndex<HostExec> h(hx);
+        h.tiny = true;
+        std::map<std::string, uint32_t> model;
+        const size_t max_depth = round % 4 == 3 ? 22 : 5; // (every fourth round: filters and topics deeper than FAST_LEVELS)
+        {
+            std::set<std::string> ks;
+            const size_t nk = 1 + rnd(round % 3 == 0 ? 4000 : 600);
+            for (size_t i = 0; i < nk; i++) ks.insert(rand_key(max_depth));
+            for (size_t i = 0; i < 40; i++) ks.insert(encode_route_key("t", "a/b", 1, "0" + std::string("\0", 1) + "fan" + std::to_string(i) + std::string("\0d", 2))); // one filter, many receivers
+            std::vector<uint8_t> bytes;
+            std::vector<uint32_t> off{0};
+            uint32_t r = 0;
+            for (auto& k : ks) {
+                model[k] = r++;
+                bytes.insert(bytes.end(), k.begin(), k.end());
+                off.push_back((uint32_t)bytes.size());
+            }
+            bytes.resize(bytes.size() + 16, 0);
+            if (!h.rebuild(bytes.data(), off.data(), (uint32_t)ks.size())) FAIL("rebuild: %s\n", h.error.c_str());
+        }
+        uint32_t next_id = (uint32_t)model.size();
+        for (int phase = 0; phase < 2; phase++) {
+            if (phase == 1) { // the same index after a batch of mutations: ids out of key order, id lists, dead ids
+                std::vector<std::string> keys;
+                std::vector<uint8_t> ops;
+                const size_t nm = 1 + rnd(400);
+                for (size_t i = 0; i < nm; i++) {
+                    if (!model.empty() && rnd(2)) {
+                        auto it = model.begin();
+                        std::advance(it, rnd(std::min<size_t>(model.size(), 300)));
+                        keys.push_back(it->first), ops.push_back(1);
+                    } else keys.push_back(rand_key(max_depth)), ops.push_back(0);
+                }
+                uint32_t put_no = 0;
+                for (size_t i = 0; i < keys.size(); i++) {
+                    if (ops[i]) model.erase(keys[i]);
+                    else {
+                        if (!model.count(keys[i])) model[keys[i]] = next_id + put_no;
+                        put_no++;
+                    }
+                }
+                next_id += put_no;
+                std::vector<uint8_t> bytes;
+                std::vector<uint32_t> off{0};
+                for (auto& k : keys) bytes.insert(bytes.end(), k.begin(), k.end()), off.push_back((uint32_t)bytes.size());
+                bytes.resize(bytes.size() + 16, 0);
+                if (!h.apply(bytes.data(), off.data(), ops.data(), (uint32_t)keys.size())) FAIL("apply: %s\n", h.error.c_str());
+                cov.after_apply++;
+            }
+            // the model per tenant: (filter levels, id)
+            std::map<std::string, std::vector<std::pair<std::vector<std::string>, uint32_t>>> by_tenant;
+            for (auto& e : model) {
+                RouteKeyParts kp;
+                if (!decode_route_key(e.first, kp)) FAIL("model key does not decode\n");
+                by_tenant[std::string(kp.tenant)].emplace_back(split(kp.esc_filter, '\0'), e.second);
+            }
+            for (int bt = 0; bt < 3; bt++) {
+                std::vector<std::string> tnames = tenants;
+                tnames.push_back("ghost"); // a tenant the index does not know
+                const uint32_t shifts[3] = {6, 4, 2};
+                const uint32_t tpw_shift = shifts[(round + bt) % 3];
+                const uint32_t n = 1 + (uint32_t)rnd(tpw_shift == 6 ? 330 : 60);
+                std::vector<std::pair<uint32_t, std::string>> rowsrc;
+                for (uint32_t i = 0; i < n; i++) rowsrc.emplace_back((uint32_t)rnd(tnames.size()), rnd(12) == 0 ? std::string() : rand_topic(max_depth));
+                const bool grouped = bt != 2; // the third batch of a phase arrives in any order: waves hold many tenants each (MIXED)
+                if (grouped) std::stable_sort(rowsrc.begin(), rowsrc.end(), [](auto& x, auto& y) { return x.first < y.first; });
+                std::vector<uint32_t> tt;
+                std::vector<std::string> topics;
+                for (auto& r : rowsrc) tt.push_back(r.first), topics.push_back(r.second);
+                std::vector<std::vector<uint32_t>> got;
+                const bool small_lists = (round + bt) % 2 == 1; // the smallest LDS lists: stack and range buffer spill all the time
+                const DistIndexView ix = h.view();
+                const int rc = small_lists ? run_batch<192, 128, 128>(ix, tnames, tt, topics, tpw_shift, got, cov) : run_batch<512, 176, 152>(ix, tnames, tt, topics, tpw_shift, got, cov);
+                if (rc) FAIL("round %d phase %d batch %d (n %u, tpw %u, %s, %s lists) failed (seed %llu)\n", round, phase, bt, n, 1u << tpw_shift, grouped ? "grouped" : "any order",
+                             small_lists ? "smallest" : "default", (unsigned long long)seed);
+                for (uint32_t i = 0; i < n; i++) {
+                    std::vector<uint32_t> want;
+                    auto it = by_tenant.find(tnames[tt[i]]);
+                    if (it != by_tenant.end()) {
+                        const auto tl = split(topics[i], '/');
+                        for (auto& fe : it->second)
+                            if (filter_matches(fe.first, tl)) want.push_back(fe.second);
+                    }
+                    std::sort(want.begin(), want.end());
+                    if (got[i] != want)
+                        FAIL("round %d phase %d batch %d row %u: tenant '%s' topic '%s': kernels give %zu ids, the rule %zu (n %u, tpw %u, %s, %s lists; seed %llu)\n", round, phase, bt, i,
+                             tnames[tt[i]].c_str(), topics[i].c_str(), got[i].size(), want.size(), n, 1u << tpw_shift, grouped ? "grouped" : "any order", small_lists ? "smallest" : "default",
+                             (unsigned long long)seed);
+                }
+            }
+        }
+    }
+    printf("walk emu ok: %d rounds, %llu batches (%llu through the MIXED instantiation, %llu on an index after mutations), %llu rows, %llu ids, %llu rows through k_walk_slow, "
+           "%llu batches with spill chains, %llu rows left to k_sort_rows\n",
+           rounds, (unsigned long long)cov.batches, (unsigned long long)cov.mixed, (unsigned long long)cov.after_apply * 3, (unsigned long long)cov.rows, (unsigned long long)cov.ids,
+           (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills, (unsigned long long)cov.sorted_rows);
+    if (rounds >= 8 && (!cov.mixed || !cov.slow_rows || !cov.spills)) FAIL("the cases missed a path: mixed %llu slow %llu spills %llu\n", (unsigned long long)cov.mixed, (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills);
+    return 0;
+}
