@@ -5,6 +5,8 @@
 // restatement on random batches, ordered and not.  What the GPU makes of the same source is what tests/ (-m gpu) check against the oracle.
 //   g++ -O1 -g -std=c++17 -I bifromq_amd/csrc -I tools/emu tools/emu/dedup_adj_emu.cpp -o build/dedup_adj_emu && build/dedup_adj_emu [cases] [seed]
 //   -DBMQ_ADJ_IMG=256: a small LDS image, so that the byte-copy path runs all the time
+//   add -fsanitize=address,undefined (ASAN_OPTIONS=detect_stack_use_after_return=0: the lanes are ucontext fibers): LDS arrays are function statics here, so a read or
+//   write past one is reported -- both harnesses run clean that way (round 5)
 #define BMQ_WAVE_EMU 1
 #include "wave_emu.h"
 

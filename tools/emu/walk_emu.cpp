@@ -6,6 +6,8 @@
 // FAST_LEVELS (k_walk_slow), indexes after mutations (id lists, indirect ranges) -- against a brute force over the model's route keys
 // (the rule of SURVEY.md 8a-0).  What the GPU makes of the same source is what tests/ (-m gpu) check against the oracle.
 //   g++ -O1 -g -std=c++17 -I bifromq_amd/csrc -I tools/emu tools/emu/walk_emu.cpp bifromq_amd/csrc/bmq_codec.cpp -o build/walk_emu -pthread && build/walk_emu [rounds] [seed]
+//   add -fsanitize=address,undefined (ASAN_OPTIONS=detect_stack_use_after_return=0: the lanes are ucontext fibers): LDS arrays are function statics here, so a read or
+//   write past one is reported -- both harnesses run clean that way (round 5)
 #define BMQ_WAVE_EMU 1
 #include "wave_emu.h"
 
