@@ -68,7 +68,9 @@ def test_the_match_kernels_of_the_dist_direction_under_the_wave_emulator(tmp_pat
     and k_expand behind them, compiled by g++ from the product's sources (bmq_dist_kernels.h with its device-only pieces stepped aside: the library's
     machine code is unchanged, tools/kernel_isa.py) and run on indexes the product's own builder makes on the host -- fresh and after mutations -- against a
     brute force over the model's route keys: '$' topics, empty levels, unknown tenants, waves that hold several tenants, batches in any order, topics and
-    filters deeper than FAST_LEVELS, spill chains of the stack and the range buffer; the harness fails if its cases miss one of those paths."""
+    filters deeper than FAST_LEVELS, spill chains of the stack and the range buffer, and ordered batches full of repeats through the whole
+    bmq_config.dedup_sorted pipeline (neighbour compare -> dense batch -> walk kernels -> k_fill_adj -> k_expand); the harness fails if its cases miss
+    one of those paths."""
     exe = str(tmp_path / "walk_emu")
     cmd = ["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "bifromq_amd", "csrc"), "-I", os.path.join(ROOT, "tools", "emu"),
            os.path.join(ROOT, "tools", "emu", "walk_emu.cpp"), os.path.join(ROOT, "bifromq_amd", "csrc", "bmq_codec.cpp"), "-o", exe, "-pthread"]

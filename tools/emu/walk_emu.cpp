@@ -3,8 +3,9 @@
 // (bmq_dist_index.h through HostExec: the code the builder kernels run).  Test tooling: the kernels' LOGIC -- tokeniser and ragged token
 // table, chunked waves, the work stack and the range buffer with their spill chains (smallest LDS lists), tenants of a wave walked one after
 // the other, the MIXED instantiation for batches that are not grouped by tenant, '$' topics, empty levels, unknown tenants, topics deeper than
-// FAST_LEVELS (k_walk_slow), indexes after mutations (id lists, indirect ranges) -- against a brute force over the model's route keys
-// (the rule of SURVEY.md 8a-0).  What the GPU makes of the same source is what tests/ (-m gpu) check against the oracle.
+// FAST_LEVELS (k_walk_slow), indexes after mutations (id lists, indirect ranges), and the whole pipeline of an engine with bmq_config.dedup_sorted
+// (k_dd_adj_heads -> k_dd_adj_scatter -> the walk kernels on the dense batch -> k_fill_adj -> k_expand, wired as launch_dist wires them) on
+// ordered batches full of repeats -- against a brute force over the model's route keys (the rule of SURVEY.md 8a-0).  What the GPU makes of the same source is what tests/ (-m gpu) check against the oracle.
 //   g++ -O1 -g -std=c++17 -I bifromq_amd/csrc -I tools/emu tools/emu/walk_emu.cpp bifromq_amd/csrc/bmq_codec.cpp -o build/walk_emu -pthread && build/walk_emu [rounds] [seed]
 //   add -fsanitize=address,undefined (ASAN_OPTIONS=detect_stack_use_after_return=0: the lanes are ucontext fibers): LDS arrays are function statics here, so a read or
 //   write past one is reported -- both harnesses run clean that way (round 5)
@@ -78,12 +79,13 @@ template <class T> static T* buf(std::vector<uint8_t>& store, size_t n) {
 
 struct Coverage {
     uint64_t rows = 0, ids = 0, batches = 0, mixed = 0, slow_rows = 0, spills = 0, chunked = 0, sorted_rows = 0, after_apply = 0, two_tenant_waves = 0;
+    uint64_t adj_batches = 0, adj_rows = 0, adj_walked = 0, adj_slow = 0;
 };
 
 // one batch through walk (+ slow) + expand; rows -> sorted id lists
 template <int TC, int QC, int PC>
 static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tnames, const std::vector<uint32_t>& tt, const std::vector<std::string>& topics, uint32_t tpw_shift,
-                     std::vector<std::vector<uint32_t>>& rows, Coverage& cov) {
+                     std::vector<std::vector<uint32_t>>& rows, Coverage& cov, bool adj = false) {
     const uint32_t n = (uint32_t)topics.size();
     std::vector<uint8_t> tb, pb;
     std::vector<uint32_t> toff{0}, poff{0};
@@ -96,6 +98,7 @@ static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tn
     memcpy(pal, pb.data(), pb.size());
     const uint32_t nb = (n + (1u << tpw_shift) - 1) >> tpw_shift, n_super = ((nb - 1) >> SUPER_SHIFT) + 1;
     std::vector<uint8_t> s_po, s_pc, s_rc, s_pairs, s_subs, s_super, s_stats, s_spill, s_ws, s_slow, s_scr, s_sort, s_ctr, s_row, s_ids, s_tot;
+    std::vector<uint8_t> s_drow, s_mask, s_cnt, s_asup, s_ctop, s_coff, s_cten, s_crep, s_cpo, s_cpc, s_crc, s_vis; // bmq_config.dedup_sorted: the dense batch and its results
     BatchArgs a{};
     a.ix = ix;
     a.tenants = tb.data(), a.tenant_off = toff.data(), a.n_tenants = (uint32_t)tnames.size();
@@ -116,9 +119,29 @@ static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tn
         a.out_row_ptr = buf<uint32_t>(s_row, n + 1), a.out_ids = buf<uint32_t>(s_ids, out_cap), a.out_capacity = out_cap;
         a.out_total = buf<unsigned long long>(s_tot, 1);
         wemu::grid_size() = nb;
+        BatchArgs w = a; // what the walk kernels run on
+        AdjFill gf{};
+        if (adj) { // the wiring of launch_dist (bmq_engine.hip) for an engine with bmq_config.dedup_sorted
+            AdjArgs g{};
+            g.topics = a.topics, g.topic_off = a.topic_off, g.topic_tenant = a.topic_tenant, g.n_topics = n, g.n_blocks = nb, g.tpw_shift = tpw_shift;
+            g.drow = buf<uint32_t>(s_drow, n), g.blk_mask = buf<unsigned long long>(s_mask, nb), g.blk_cnt = buf<unsigned long long>(s_cnt, nb);
+            g.super_cnt = buf<unsigned long long>(s_asup, (size_t)n_super * SUPER_STRIDE);
+            g.c_cap = pb.size() + 64;
+            s_ctop.assign(g.c_cap + 128, 0xCD);
+            g.c_topics = s_ctop.data() + ((16 - ((uintptr_t)s_ctop.data() & 15)) & 15);
+            g.c_off = buf<uint32_t>(s_coff, n + 1), g.c_tenant = buf<uint32_t>(s_cten, n), g.c_rep = buf<uint32_t>(s_crep, n), g.ctr = a.ctr;
+            for (uint32_t b = 0; b < nb; b++) wemu::run_wave(b, [&] { k_dd_adj_heads(g); });
+            for (uint32_t b = 0; b < nb; b++) wemu::run_wave(nb - 1 - b, [&] { k_dd_adj_scatter(g); });
+            if (a.ctr->status & ST_NEED_ADJ) FAIL("the dense batch did not fit a buffer as large as the batch\n");
+            a.rep = g.drow, a.visit_cnt = buf<uint32_t>(s_vis, n);
+            w = a;
+            w.topics = g.c_topics, w.topic_off = g.c_off, w.topic_tenant = g.c_tenant, w.rep = g.c_rep;
+            w.pair_off = buf<uint32_t>(s_cpo, n), w.pair_cnt = buf<uint32_t>(s_cpc, n), w.route_cnt = buf<uint32_t>(s_crc, n);
+            gf = AdjFill{g.drow, w.pair_off, w.pair_cnt, w.route_cnt, w.visit_cnt};
+        }
         for (uint32_t b = 0; b < nb; b++) {
-            if (mixed) wemu::run_wave(b, [&] { k_walk<TC, QC, PC, true>(a); });
-            else wemu::run_wave(b, [&] { k_walk<TC, QC, PC, false>(a); });
+            if (mixed) wemu::run_wave(b, [&] { k_walk<TC, QC, PC, true>(w); });
+            else wemu::run_wave(b, [&] { k_walk<TC, QC, PC, false>(w); });
         }
         if ((a.ctr->status & ST_WANT_MIXED) && !mixed) { // the batch is not grouped by tenant: once more through the instantiation for that (bmq_engine.hip)
             mixed = true;
@@ -128,9 +151,15 @@ static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tn
         if (a.ctr->status & ST_RERUN) FAIL("walk asked for larger buffers: status %u (the harness' are meant to be large enough)\n", a.ctr->status);
         if (a.ctr->slow_count) {
             cov.slow_rows += a.ctr->slow_count;
+            if (adj) cov.adj_slow += a.ctr->slow_count;
             wemu::grid_size() = 2;
-            for (uint32_t b = 0; b < 2; b++) wemu::run_wave(b, [&] { k_walk_slow(a); });
+            for (uint32_t b = 0; b < 2; b++) wemu::run_wave(b, [&] { k_walk_slow(w); });
             if (a.ctr->status & ST_RERUN) FAIL("slow walk asked for larger buffers: status %u\n", a.ctr->status);
+        }
+        if (adj) {
+            wemu::grid_size() = nb;
+            for (uint32_t b = 0; b < nb; b++) wemu::run_wave(b, [&] { k_fill_adj(a, gf); });
+            cov.adj_batches++, cov.adj_rows += n, cov.adj_walked += a.ctr->n_walked;
         }
         break;
     }
@@ -255,24 +284,31 @@ int main(int argc, char** argv) {
                 if (!decode_route_key(e.first, kp)) FAIL("model key does not decode\n");
                 by_tenant[std::string(kp.tenant)].emplace_back(split(kp.esc_filter, '\0'), e.second);
             }
-            for (int bt = 0; bt < 3; bt++) {
+            for (int bt = 0; bt < 4; bt++) {
                 std::vector<std::string> tnames = tenants;
                 tnames.push_back("ghost"); // a tenant the index does not know
                 const uint32_t shifts[3] = {6, 4, 2};
                 const uint32_t tpw_shift = shifts[(round + bt) % 3];
-                const uint32_t n = 1 + (uint32_t)rnd(tpw_shift == 6 ? 330 : 60);
+                const uint32_t n0 = 1 + (uint32_t)rnd(tpw_shift == 6 ? 330 : 60);
                 std::vector<std::pair<uint32_t, std::string>> rowsrc;
-                for (uint32_t i = 0; i < n; i++) rowsrc.emplace_back((uint32_t)rnd(tnames.size()), rnd(12) == 0 ? std::string() : rand_topic(max_depth));
+                for (uint32_t i = 0; i < n0; i++) rowsrc.emplace_back((uint32_t)rnd(tnames.size()), rnd(12) == 0 ? std::string() : rand_topic(max_depth));
                 const bool grouped = bt != 2; // the third batch of a phase arrives in any order: waves hold many tenants each (MIXED)
-                if (grouped) std::stable_sort(rowsrc.begin(), rowsrc.end(), [](auto& x, auto& y) { return x.first < y.first; });
+                const bool ordered = bt == 3;  // the fourth: ordered by (tenant, topic), every row up to four times -- through the neighbour-compare kernels (dedup_sorted)
+                if (ordered) {
+                    const size_t m = rowsrc.size();
+                    for (size_t i = 0; i < m; i++)
+                        for (size_t c = rnd(4); c > 0; c--) rowsrc.push_back(rowsrc[i]);
+                    std::sort(rowsrc.begin(), rowsrc.end());
+                } else if (grouped) std::stable_sort(rowsrc.begin(), rowsrc.end(), [](auto& x, auto& y) { return x.first < y.first; });
                 std::vector<uint32_t> tt;
                 std::vector<std::string> topics;
                 for (auto& r : rowsrc) tt.push_back(r.first), topics.push_back(r.second);
                 std::vector<std::vector<uint32_t>> got;
                 const bool small_lists = (round + bt) % 2 == 1; // the smallest LDS lists: stack and range buffer spill all the time
                 const DistIndexView ix = h.view();
-                const int rc = small_lists ? run_batch<192, 128, 128>(ix, tnames, tt, topics, tpw_shift, got, cov) : run_batch<512, 176, 152>(ix, tnames, tt, topics, tpw_shift, got, cov);
-                if (rc) FAIL("round %d phase %d batch %d (n %u, tpw %u, %s, %s lists) failed (seed %llu)\n", round, phase, bt, n, 1u << tpw_shift, grouped ? "grouped" : "any order",
+                const uint32_t n = (uint32_t)topics.size(); // (the ordered batch grew)
+                const int rc = small_lists ? run_batch<192, 128, 128>(ix, tnames, tt, topics, tpw_shift, got, cov, ordered) : run_batch<512, 176, 152>(ix, tnames, tt, topics, tpw_shift, got, cov, ordered);
+                if (rc) FAIL("round %d phase %d batch %d (n %u, tpw %u, %s, %s lists) failed (seed %llu)\n", round, phase, bt, n, 1u << tpw_shift, ordered ? "ordered + dedup_sorted" : grouped ? "grouped" : "any order",
                              small_lists ? "smallest" : "default", (unsigned long long)seed);
                 for (uint32_t i = 0; i < n; i++) {
                     std::vector<uint32_t> want;
@@ -285,16 +321,17 @@ int main(int argc, char** argv) {
                     std::sort(want.begin(), want.end());
                     if (got[i] != want)
                         FAIL("round %d phase %d batch %d row %u: tenant '%s' topic '%s': kernels give %zu ids, the rule %zu (n %u, tpw %u, %s, %s lists; seed %llu)\n", round, phase, bt, i,
-                             tnames[tt[i]].c_str(), topics[i].c_str(), got[i].size(), want.size(), n, 1u << tpw_shift, grouped ? "grouped" : "any order", small_lists ? "smallest" : "default",
+                             tnames[tt[i]].c_str(), topics[i].c_str(), got[i].size(), want.size(), n, 1u << tpw_shift, ordered ? "ordered + dedup_sorted" : grouped ? "grouped" : "any order", small_lists ? "smallest" : "default",
                              (unsigned long long)seed);
                 }
             }
         }
     }
     printf("walk emu ok: %d rounds, %llu batches (%llu through the MIXED instantiation, %llu on an index after mutations), %llu rows, %llu ids, %llu rows through k_walk_slow, "
-           "%llu batches with spill chains, %llu rows left to k_sort_rows\n",
-           rounds, (unsigned long long)cov.batches, (unsigned long long)cov.mixed, (unsigned long long)cov.after_apply * 3, (unsigned long long)cov.rows, (unsigned long long)cov.ids,
-           (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills, (unsigned long long)cov.sorted_rows);
-    if (rounds >= 8 && (!cov.mixed || !cov.slow_rows || !cov.spills)) FAIL("the cases missed a path: mixed %llu slow %llu spills %llu\n", (unsigned long long)cov.mixed, (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills);
+           "%llu batches with spill chains, %llu rows left to k_sort_rows; %llu ordered batches through the neighbour-compare kernels (%llu rows, %llu walked, %llu of those by k_walk_slow)\n",
+           rounds, (unsigned long long)cov.batches, (unsigned long long)cov.mixed, (unsigned long long)cov.after_apply * 4, (unsigned long long)cov.rows, (unsigned long long)cov.ids,
+           (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills, (unsigned long long)cov.sorted_rows, (unsigned long long)cov.adj_batches, (unsigned long long)cov.adj_rows,
+           (unsigned long long)cov.adj_walked, (unsigned long long)cov.adj_slow);
+    if (rounds >= 8 && (!cov.mixed || !cov.slow_rows || !cov.spills || !cov.adj_slow || cov.adj_walked >= cov.adj_rows)) FAIL("the cases missed a path: mixed %llu slow %llu spills %llu\n", (unsigned long long)cov.mixed, (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills);
     return 0;
 }
