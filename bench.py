@@ -676,7 +676,11 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
             extra[wl] = {"error": repr(ex)}
     # configs[4] on the C3 index of this run: 5 steps, each = bmq_routes_apply(100 k ops from pinned memory) + the 1 M-publish batch
     try:
-        n_ops, n_steps = 100_000, 10  # (5 pipelined + 5 blocking: 3 + 3 gave numbers that moved 15 % from run to run)
+        # 20 pipelined + 5 blocking steps.  (Round 5's line had 5 + 5 and ONE mean for the pipelined shape: the driver's run read 18.99 ms per
+        # step where the builder's read 0.8 and the line could not tell a one-off stall from a steady state.  Now every pipelined step is
+        # clocked -- the three calls separately -- and the line carries the list.)
+        n_ops, n_pipe_steps, n_block_steps = 100_000, 20, 5
+        n_steps = n_pipe_steps + n_block_steps
         rng = np.random.default_rng(4321)
         kb_h, ko_h = w.keys_packed()
         mv = memoryview(kb_h)
@@ -709,32 +713,58 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
         # Two shapes of the same work.  "blocking": bmq_routes_apply, then the batch (rounds 1-4).  "pipelined" (the first n_pipe batches of the
         # mutation stream): the batch is handed over as a ticket, the NEXT mutation batch with bmq_routes_apply_async right behind it -- its
         # upload runs beside the match kernels, its builder kernels behind them, nobody waits in between -- and the ticket is waited for.
-        n_pipe = n_steps // 2 if tickets is not None else 0
+        n_pipe = n_pipe_steps if tickets is not None else 0
         apply(0)
         step(0)
         torch.cuda.synchronize()
         pipe = None
         if n_pipe:
             submit_dev, wait_dev = tickets
-            for i in range(3):  # (every ticket slot once: their scratch buffers are allocated on first use)
-                wait_dev(submit_dev(i))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(n_pipe):
+
+            def pipe_step(i, clk=None):
+                t_a = time.perf_counter()
                 t = submit_dev(i)
+                t_b = time.perf_counter()
                 data, off, opb = cb[i + 1]
                 rc = lib.bmq_routes_apply_async(eng.h, data.data_ptr(), off.data_ptr(), opb.data_ptr(), len(opb))
                 if rc:
                     raise RuntimeError("bmq_routes_apply_async failed: %d" % rc)
+                t_c = time.perf_counter()
                 wait_dev(t)
+                t_d = time.perf_counter()
+                if clk is not None:
+                    clk.append(((t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (t_d - t_c) * 1e3))
+
+            for i in range(3):  # (every ticket slot once: their scratch buffers are allocated on first use)
+                wait_dev(submit_dev(i))
+            # ... and two untimed steps of the pipelined shape itself: the first bmq_routes_apply_async of an engine sets up its upload
+            # stream's staging and the page-locked counter block (include/bmq.h says what that first call costs)
+            warm_clk = []
+            for i in range(2):
+                pipe_step(i, warm_clk)
+            rc = lib.bmq_routes_apply_wait(eng.h)
+            if rc:
+                raise RuntimeError("bmq_routes_apply_wait failed: %d" % rc)
+            torch.cuda.synchronize()
+            clk = []
+            t0 = time.perf_counter()
+            for i in range(2, n_pipe):
+                pipe_step(i, clk)
             rc = lib.bmq_routes_apply_wait(eng.h)
             if rc:
                 raise RuntimeError("bmq_routes_apply_wait failed: %d" % rc)
             torch.cuda.synchronize()
             el_p = time.perf_counter() - t0
-            pipe = {"value": args.topics * n_pipe / el_p, "unit": "topics/s", "steps": n_pipe, "ms_per_step": el_p / n_pipe * 1e3,
+            n_timed = n_pipe - 2
+            tot = [sum(c) for c in clk]
+            pipe = {"value": args.topics * n_timed / el_p, "unit": "topics/s", "steps": n_timed, "ms_per_step": el_p / n_timed * 1e3,
+                    "ms_per_step_p50": float(np.median(tot)), "ms_per_step_max": float(np.max(tot)),
+                    "step_ms": [round(x, 3) for x in tot],
+                    "call_ms_mean": {"submit": float(np.mean([c[0] for c in clk])), "apply_async": float(np.mean([c[1] for c in clk])),
+                                     "wait": float(np.mean([c[2] for c in clk]))},
+                    "warm_step_ms": [[round(x, 3) for x in c] for c in warm_clk],
                     "shape": "ticket(batch i) | bmq_routes_apply_async(mutations i + 1) | wait(ticket): the upload beside the match kernels, the builder kernels "
-                             "behind them, one host wait per step"}
+                             "behind them, one host wait per step; 2 untimed steps of the same shape first"}
         ams, t0 = [], time.perf_counter()
         for i in range(n_pipe, n_steps):
             ams.append(apply(i + 1))

@@ -207,6 +207,12 @@ struct bmq_engine {
         std::vector<uint8_t> log_keys;  // what was mutated meanwhile: replayed into `next` before the swap
         std::vector<uint32_t> log_off{0};
         std::vector<uint8_t> log_op;
+        // the batch whose outcome is not known yet (between apply_begin and complete_apply): it enters the log only once apply_end has
+        // accepted it -- a batch refused for a malformed key, or one that fails on the device, must not be replayed
+        std::vector<uint8_t> pend_keys, pend_op;
+        std::vector<uint32_t> pend_off;
+        bool log_overflow = false;      // the log outgrew LOG_CAP_BYTES: this compaction cannot be swapped any more (abort + begin again)
+        static constexpr uint64_t LOG_CAP_BYTES = 1ull << 30;
     } cmp;
     std::mutex cmp_mu;                // one compaction call at a time (taken BEFORE mu)
     hipStream_t s_build = nullptr;    // the stream the next generation is built on: lowest priority, beside the match batches
@@ -660,10 +666,12 @@ int check_dist_ready(bmq_engine* e) {
 template <class F> static auto with_index(bmq_engine* e, F&& f) { return e->dix ? f(*e->dix) : f(*e->hix); }
 // (serving generation, generation being built) of whichever executor the engine has
 template <class F> static auto with_generations(bmq_engine* e, F&& f) { return e->dix ? f(*e->dix, *e->cmp.next_d) : f(*e->hix, *e->cmp.next_h); }
-static int index_error(bmq_engine* e, const std::string& msg, bool invalid_input) {
+// (`also`: the executor of a generation being built, when the caller is the thread that drives it -- bmq_compact_poll works on it with
+// e->mu released, so nobody else may read its error string: ADVICE r5)
+static int index_error(bmq_engine* e, const std::string& msg, bool invalid_input, DevExec* also = nullptr) {
     if (e->dix)
-        for (DevExec* x : {&e->dx, &e->dxi[0], &e->dxi[1]})
-            if (!x->err.empty() && msg == x->err) return set_err(e, BMQ_E_HIP, msg);
+        for (DevExec* x : {&e->dx, &e->dix->x, also})
+            if (x && !x->err.empty() && msg == x->err) return set_err(e, BMQ_E_HIP, msg);
     if (msg.find("out of") == 0) return set_err(e, BMQ_E_NOMEM, msg);
     return set_err(e, invalid_input ? BMQ_E_INVAL : BMQ_E_STATE, msg);
 }
@@ -685,7 +693,23 @@ static int complete_apply(bmq_engine* e) {
         }
         return r;
     });
-    if (!ok) return index_error(e, e->err, bad_input);
+    bmq_engine::Compaction& c = e->cmp;
+    if (!ok) {
+        c.pend_keys.clear(), c.pend_off.clear(), c.pend_op.clear(); // never applied: never replayed
+        return index_error(e, e->err, bad_input);
+    }
+    if (c.active && !c.pend_op.empty()) { // accepted: the generation being built gets it too, before the swap
+        if (c.log_keys.size() + c.pend_keys.size() > bmq_engine::Compaction::LOG_CAP_BYTES) {
+            c.log_overflow = true; // (the mutation itself is applied all the same: what gives way is the compaction)
+            c.log_keys.clear(), c.log_keys.shrink_to_fit(), c.log_off.assign(1, 0u), c.log_op.clear();
+        } else if (!c.log_overflow) {
+            const uint32_t base = c.log_off.back();
+            c.log_keys.insert(c.log_keys.end(), c.pend_keys.begin(), c.pend_keys.end());
+            for (size_t i = 1; i < c.pend_off.size(); i++) c.log_off.push_back(base + c.pend_off[i]);
+            c.log_op.insert(c.log_op.end(), c.pend_op.begin(), c.pend_op.end());
+        }
+    }
+    c.pend_keys.clear(), c.pend_off.clear(), c.pend_op.clear();
     e->epoch++;
     e->built = true;
     return BMQ_OK;
@@ -871,12 +895,11 @@ static int routes_apply_common(bmq_engine* e, const uint8_t* keys, const uint32_
         return r;
     });
     if (!ok) return index_error(e, e->err, bad_input);
-    if (e->cmp.active) { // a generation is being built beside this one: it gets the batch too, before the swap
+    if (e->cmp.active && !e->cmp.log_overflow) { // a generation is being built beside this one: remembered until the batch's outcome is known (complete_apply)
         bmq_engine::Compaction& c = e->cmp;
-        const uint32_t base = c.log_off.back();
-        c.log_keys.insert(c.log_keys.end(), keys, keys + key_off[n]);
-        for (uint32_t i = 1; i <= n; i++) c.log_off.push_back(base + key_off[i]);
-        c.log_op.insert(c.log_op.end(), op, op + n);
+        c.pend_keys.assign(keys, keys + key_off[n]);
+        c.pend_off.assign(key_off, key_off + n + 1);
+        c.pend_op.assign(op, op + n);
     }
     e->apply_open = true;
     return async ? BMQ_OK : complete_apply(e);
@@ -913,7 +936,7 @@ static int replay_log(bmq_engine* e, size_t from) {
                 if (!r) msg = next.error;
                 return r;
             }))
-            return index_error(e, msg, false);
+            return index_error(e, msg, false, c.bx);
         lo = hi;
     }
     return BMQ_OK;
@@ -964,6 +987,7 @@ int bmq_compact_poll(bmq_engine* e, uint32_t max_ids, uint32_t* out_done_permill
     bmq_engine::Compaction& c = e->cmp;
     std::unique_lock<std::mutex> g(e->mu);
     if (!c.active) return set_err(e, BMQ_E_STATE, "no compaction is running");
+    if (c.log_overflow) return set_err(e, BMQ_E_NOSPACE, "the mutation log of this compaction outgrew its cap (1 GiB of route keys): bmq_compact_abort, then begin again");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
     if (c.cursor < c.n_ids) {
         const uint32_t hi = (uint32_t)std::min<uint64_t>(c.n_ids, (uint64_t)c.cursor + std::max(max_ids, 1u));
@@ -992,7 +1016,7 @@ int bmq_compact_poll(bmq_engine* e, uint32_t max_ids, uint32_t* out_done_permill
             ok = c.next_d ? finish(*c.next_d) : finish(*c.next_h);
         }
         if (!g.owns_lock()) g.lock();
-        if (!ok) return index_error(e, msg, false);
+        if (!ok) return index_error(e, msg, false, c.bx);
         c.carried += n_live;
         c.cursor = hi;
     }
@@ -1008,6 +1032,7 @@ int bmq_compact_swap(bmq_engine* e, uint64_t* out_carried, uint64_t* out_replaye
     if (!c.active) return set_err(e, BMQ_E_STATE, "no compaction is running");
     if (c.cursor < c.n_ids) return set_err(e, BMQ_E_STATE, "the next generation is not complete: bmq_compact_poll until it reports 1000");
     if (int rc = complete_apply(e)) return rc;
+    if (c.log_overflow) return set_err(e, BMQ_E_NOSPACE, "the mutation log of this compaction outgrew its cap (1 GiB of route keys): bmq_compact_abort, then begin again");
     for (auto& sl : e->slots)
         if (sl.pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: finish / wait for it first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
@@ -1517,6 +1542,7 @@ int cap_rows(bmq_engine* e, const uint32_t* rp, const uint32_t* ids, uint32_t n_
     std::vector<uint64_t> ko;
     {
         std::lock_guard<std::mutex> g(e->mu);
+        if (int rc_open = complete_apply(e)) return rc_open; // (a batch handed over with bmq_routes_apply_async first: its bookkeeping is read below)
         if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
         const bool ok = with_index(e, [&](auto& ix) {
             const bool r = ix.route_keys(g_ids.data(), (uint32_t)g_ids.size(), kb, ko);

@@ -207,6 +207,10 @@ class Engine:
         if getattr(self, "h", None):
             _lib.lib().bmq_engine_destroy(self.h)
             self.h = None
+            for arena in getattr(self, "_apply_arenas", ()) if self.device >= 0 else ():  # (apply_async's page-locked buffers: nothing reads them any more)
+                for a in arena or ():
+                    _lib.lib().bmq_host_free(C.c_void_p(a.ctypes.data))
+            self._apply_arenas = [None, None]
 
     def __del__(self):
         try:
@@ -240,16 +244,29 @@ class Engine:
         outcome is apply_wait()'s (or the next index call's).  The op buffers are kept in page-locked memory owned by this object until then."""
         data, off = pack([k for _, k in ops])
         op = np.array([o for o, _ in ops], dtype=np.uint8)
-        bufs = (pinned(len(data), np.uint8), pinned(len(off), np.uint32), pinned(max(len(op), 1), np.uint8))
-        bufs[0][:], bufs[1][:], bufs[2][:len(op)] = data, off, op
-        self._open_apply = bufs  # (must outlive the upload)
-        self._check(_lib.lib().bmq_routes_apply_async(self.h, _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]), len(ops)))
+        # Two page-locked arenas taken in turns, grow-only (ADVICE r5: a fresh set per call was never freed).  The engine reads batch k's
+        # buffers until batch k is completed -- by bmq_routes_apply_wait or inside the NEXT bmq_routes_apply_async --, so call k + 1 must not
+        # touch arena k: it takes the other one, whose batch k - 1 was completed during call k.
+        if not hasattr(self, "_apply_arenas"):
+            self._apply_arenas, self._apply_turn = [None, None], 0
+        self._apply_turn ^= 1
+        need = (len(data), len(off) * 4, max(len(op), 1))
+        arena = self._apply_arenas[self._apply_turn]
+        if arena is None or any(a.nbytes < n for a, n in zip(arena, need)):
+            if arena is not None:
+                for a in arena:
+                    _lib.lib().bmq_host_free(C.c_void_p(a.ctypes.data))
+            # (a host-only engine has no page-locked allocator -- and nothing to upload: ordinary memory, kept alive the same way)
+            arena = tuple((pinned if self.device >= 0 else np.empty)(max(2 * n, 4096), np.uint8) for n in need)
+            self._apply_arenas[self._apply_turn] = arena
+        b_data, b_off, b_op = arena[0][:len(data)], arena[1][:len(off) * 4].view(np.uint32), arena[2][:max(len(op), 1)]
+        b_data[:], b_off[:], b_op[:len(op)] = data, off, op
+        self._check(_lib.lib().bmq_routes_apply_async(self.h, _ptr(b_data), _ptr(b_off), _ptr(b_op), len(ops)))
         return self
 
     def apply_wait(self):
         """bmq_routes_apply_wait: the outcome of the batch handed over with apply_async (raises what apply would have raised)"""
         self._check(_lib.lib().bmq_routes_apply_wait(self.h))
-        self._open_apply = None
         return self
 
     def compact(self):

@@ -194,6 +194,44 @@ def test_compaction_entry_points_refuse_what_they_cannot_do():
         eng.close()
 
 
+def test_a_refused_batch_during_a_compaction_is_not_replayed():
+    """a mutation batch entered the compaction's log as soon as apply_begin had returned -- a batch later refused for a malformed
+    key (or failing asynchronously) stayed in it and bmq_compact_swap's replay failed for ever.  The log now takes a batch only once its
+    outcome is known: refused batches, blocking and async, leave no trace, the valid ones around them are replayed."""
+    eng = B.Engine(device=-1)
+    try:
+        model = set(_key(i) for i in range(300))
+        eng.rebuild(sorted(model))
+        eng.apply([(1, k) for k in sorted(model)[:40]])  # garbage for the compaction to drop
+        model.difference_update(sorted(model)[:40])
+        eng.compact_begin()
+        good1 = [_key(1000 + j) for j in range(25)]
+        eng.apply([(0, k) for k in good1])
+        with pytest.raises(B.BmqError) as ei:  # refused as a whole, before anything is changed
+            eng.apply([(0, _key(5000)), (0, b"\x07garbage")])
+        assert ei.value.code == -1
+        eng.apply_async([(0, _key(6000)), (1, b"\x00\x00")])  # the same through the asynchronous form: the error is the wait's
+        with pytest.raises(B.BmqError) as ei:
+            eng.apply_wait()
+        assert ei.value.code == -1
+        good2 = [_key(2000 + j) for j in range(10)]
+        eng.apply_async([(0, k) for k in good2] + [(1, good1[0])])
+        done = 0
+        while done < 1000:
+            done = eng.compact_poll(64)
+        carried, replayed = eng.compact_swap()  # (r5: BMQ_E_STATE 'malformed route key' on every call from here on)
+        model.update(good1)
+        model.update(good2)
+        model.discard(good1[0])
+        assert carried == 260 and replayed == len(good1) + len(good2) + 1
+        assert _live(eng) == sorted(model)
+        info = eng.info()
+        # (the replayed put + delete of good1[0] used up one id of the new generation)
+        assert info.n_routes == len(model) and info.next_route_id == carried + len(good1) + len(good2)
+    finally:
+        eng.close()
+
+
 def _compaction_inside_the_engine(device, n_tenants, per_tenant, n_topics, chunk):
     """bmq_compact_begin / _poll / _swap through ctypes: the next generation is built inside ONE handle (on the device: from keys that never
     leave it), mutation batches (blocking and async) -- and on a GPU match batches -- land between the polls, and after the swap the key set
