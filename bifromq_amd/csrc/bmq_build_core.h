@@ -395,53 +395,102 @@ BMQ_HD uint32_t dict_intern(const DistIndexMut& ix, const LevelHash& h, uint32_t
 // ------------------------------------------------------------------------------------------------------------
 // Returns the child's node id (NONE: absent and !insert, or failure) and its absolute slot index in *slot_abs.
 // `created` tells the caller to record the child in the parent's Bloom word.
-BMQ_HD uint32_t trie_child(const DistIndexMut& ix, TenantSlot* ten, uint32_t base, uint32_t buckets, uint32_t parent, uint32_t token,
-                           bool insert, unsigned long long& slot_abs, bool& created) {
+// parent_slot: absolute slot index of the parent's own slot (PARENT_IS_ROOT for the tenant root, which has none).
+// Layout v3: the '+' child of a node X is looked for in the OTHER slot of X's line first, then along the probe sequence of its hashed home
+// (where a region growth leaves a '+' child that did not sit beside its parent before, and where it is created when that other slot is
+// taken); it is CREATED beside X whenever that slot is free.  Readers therefore never conclude anything from a free neighbour slot.
+//   Two lanes creating X/+ at once agree: slots only go from free to taken, so either both see the neighbour slot taken by another edge
+//   (both go to the hashed home, where the first-free protocol of literal edges applies) or the loser of the CAS on it finds the winner's key.
+constexpr unsigned long long PARENT_IS_ROOT = ~0ull;
+BMQ_HD uint32_t trie_child(const DistIndexMut& ix, TenantSlot* ten, uint32_t base, uint32_t buckets, uint32_t parent, unsigned long long parent_slot,
+                           uint32_t token, bool insert, unsigned long long& slot_abs, bool& created) {
     created = false;
     const uint64_t key = (uint64_t)parent | ((uint64_t)token << 32);
-    uint32_t bk = edge_bucket(parent, token, buckets), j = 0, probes = 0, spins = 0;
-    const uint32_t max_probes = insert && buckets > 256u ? 256u : buckets;
-    for (;;) {
-        if (probes >= max_probes || spins > (1u << 22)) {
-            if (probes >= max_probes) {
-                if (!insert) return NONE; // a lookup that wrapped around a full region: absent
-                atom_or(&ten->pending, PENDING_FORCE); // the host moves the tenant into a larger region and re-runs locate
-                atom_or(&ix.bc->err, (uint32_t)ERR_REGION_FULL);
-            } else atom_or(&ix.bc->err, (uint32_t)ERR_STUCK);
-            return NONE;
-        }
-        TrieSlot* s = ix.trie + (size_t)base + 2 * (size_t)bk + j;
-        uint64_t* kp64 = reinterpret_cast<uint64_t*>(s);
-        uint64_t k = atom_load(kp64);
-        if (k == EDGE_EMPTY) {
-            if (!insert) {
-                // first-free placement: an edge is never stored behind a free slot of its probe sequence
+    uint32_t spins = 0;
+    auto await_id = [&](TrieSlot* s, unsigned long long abs) -> uint32_t { // the slot holds `key`: its node id, once the claiming lane has published it
+        for (;;) {
+            const uint32_t id = atom_load(&s->node);
+            if (id != NONE) {
+                slot_abs = abs;
+                return id;
+            }
+            if (++spins > (1u << 22)) {
+                atom_or(&ix.bc->err, (uint32_t)ERR_STUCK);
                 return NONE;
             }
-            k = atom_cas(kp64, EDGE_EMPTY, key);
-            if (k == EDGE_EMPTY) { // claimed (payload of a free slot is all zero, node = NONE): publish the node id
+        }
+    };
+    const bool root_plus = token == TOK_PLUS && parent_slot == PARENT_IS_ROOT;
+    const bool try_beside = token == TOK_PLUS && parent_slot != PARENT_IS_ROOT;
+    if (root_plus) { // the root's '+' child: hashed like a literal edge, the directory entry remembers the slot
+        const uint32_t rp = atom_load(&ten->root_plus);
+        if (rp != NONE) return await_id(ix.trie + (size_t)base + rp, (unsigned long long)base + rp);
+    }
+    if (try_beside) {
+        TrieSlot* s = ix.trie + (size_t)(parent_slot ^ 1ull);
+        if (atom_load(reinterpret_cast<uint64_t*>(s)) == key) return await_id(s, parent_slot ^ 1ull);
+    }
+    // pass 0 (try_beside && insert only): a pure lookup along the hashed home's probe sequence -- the child may have been left there by a
+    // region growth --, and if it is absent: beside the parent if that slot can be claimed.  pass 1: find or insert at the hashed home.
+    for (uint32_t pass = (try_beside && insert) ? 0u : 1u; pass < 2; pass++) {
+        const bool ins = insert && pass == 1;
+        uint32_t bk = edge_bucket(parent, token, buckets), j = 0, probes = 0;
+        const uint32_t max_probes = ins && buckets > 256u ? 256u : buckets;
+        for (;;) {
+            if (probes >= max_probes || spins > (1u << 22)) {
+                if (probes >= max_probes) {
+                    if (!ins) break; // a lookup that wrapped around a full region: absent
+                    atom_or(&ten->pending, PENDING_FORCE); // the host moves the tenant into a larger region and re-runs locate
+                    atom_or(&ix.bc->err, (uint32_t)ERR_REGION_FULL);
+                } else atom_or(&ix.bc->err, (uint32_t)ERR_STUCK);
+                return NONE;
+            }
+            TrieSlot* s = ix.trie + (size_t)base + 2 * (size_t)bk + j;
+            uint64_t* kp64 = reinterpret_cast<uint64_t*>(s);
+            uint64_t k = atom_load(kp64);
+            if (k == EDGE_EMPTY) {
+                if (!ins) break; // first-free placement: an edge is never stored behind a free slot of its probe sequence
+                k = atom_cas(kp64, EDGE_EMPTY, key);
+                if (k == EDGE_EMPTY) { // claimed (payload of a free slot is all zero, node = NONE): publish the node id
+                    const uint32_t id = atom_add(&ten->n_nodes, 1u) + 1u;
+                    atom_publish(&s->node, id);
+                    slot_abs = (unsigned long long)base + 2ull * bk + j;
+                    if (root_plus) atom_publish(&ten->root_plus, 2u * bk + j);
+                    created = true;
+                    return id;
+                }
+            }
+            if (k == key) {
+                const uint32_t id = atom_load(&s->node);
+                if (id == NONE) { // claimed by another lane a moment ago
+                    spins++;
+                    continue;
+                }
+                slot_abs = (unsigned long long)base + 2ull * bk + j;
+                if (root_plus && atom_load(&ten->root_plus) == NONE) atom_publish(&ten->root_plus, 2u * bk + j); // (found before its creator said where)
+                return id;
+            }
+            if (++j == 2) {
+                j = 0;
+                bk = (bk + 1 == buckets) ? 0 : bk + 1;
+                probes++;
+            }
+        }
+        if (!insert) return NONE;
+        if (pass == 0) { // absent at the hashed home: beside the parent, if that slot is (still) free
+            TrieSlot* s = ix.trie + (size_t)(parent_slot ^ 1ull);
+            const uint64_t k = atom_cas(reinterpret_cast<uint64_t*>(s), EDGE_EMPTY, key);
+            if (k == EDGE_EMPTY) {
                 const uint32_t id = atom_add(&ten->n_nodes, 1u) + 1u;
                 atom_publish(&s->node, id);
-                slot_abs = (unsigned long long)base + 2ull * bk + j;
+                slot_abs = parent_slot ^ 1ull;
                 created = true;
                 return id;
             }
-        }
-        if (k == key) {
-            const uint32_t id = atom_load(&s->node);
-            if (id == NONE) { // claimed by another lane a moment ago
-                spins++;
-                continue;
-            }
-            slot_abs = (unsigned long long)base + 2ull * bk + j;
-            return id;
-        }
-        if (++j == 2) {
-            j = 0;
-            bk = (bk + 1 == buckets) ? 0 : bk + 1;
-            probes++;
+            if (k == key) return await_id(s, parent_slot ^ 1ull); // another lane put it there meanwhile
         }
     }
+    return NONE; // (not reached: pass 1 of an insert returns from inside the loop)
 }
 
 // Levels of an escaped filter.  Calls f(level_start, len, hash, inl, is_last) for each level; f returns false to stop.
@@ -617,7 +666,7 @@ BMQ_HD void locate_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t i, ui
         }
         bool created;
         unsigned long long sa = 0;
-        const uint32_t child = trie_child(ix, ten, base, buckets, node, tok, is_put, sa, created);
+        const uint32_t child = trie_child(ix, ten, base, buckets, node, at_root ? PARENT_IS_ROOT : slot_abs, tok, is_put, sa, created);
         if (child == NONE) {
             ok = false;
             return false;
@@ -841,20 +890,54 @@ BMQ_HD void group_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t p) {
 // ------------------------------------------------------------------------------------------------------------
 // region growth: re-insert one slot of the old region into the new one (node ids do not change)
 // ------------------------------------------------------------------------------------------------------------
-BMQ_HD void rehash_one(const DistIndexMut& ix, uint32_t old_base, uint32_t new_base, uint32_t new_buckets, uint32_t s) {
+// Two passes over the old region (layout v3).  Pass 0: every literal edge, the root's '+' child and every '+' child that did NOT sit beside
+// its parent, each to the first free slot from its hashed home on.  Pass 1: the '+' children that sat beside their parent (the other slot of
+// their old line holds it): the parent -- placed by pass 0 -- is looked up in the new region and the child goes into the other slot of ITS
+// line if that is free, else to its hashed home.  `d`: the tenant's directory slot (the root's '+' child reports its new place there).
+BMQ_HD bool rehash_place(const DistIndexMut& ix, TrieSlot* d, const TrieSlot& src, uint64_t key) {
+    if (atom_cas(reinterpret_cast<uint64_t*>(d), EDGE_EMPTY, key) != EDGE_EMPTY) return false;
+    d->own_begin = src.own_begin;
+    d->own_count = src.own_count;
+    d->hash_begin = src.hash_begin;
+    d->hash_count = src.hash_count;
+    d->lit_bloom = src.lit_bloom;
+    atom_publish(&d->node, src.node); // (pass 1 looks parents up while other lanes of pass 1 still place: a slot is readable once its id is)
+    (void)ix;
+    return true;
+}
+BMQ_HD void rehash_one(const DistIndexMut& ix, uint32_t old_base, uint32_t new_base, uint32_t new_buckets, uint32_t s, uint32_t pass, uint32_t d) {
     const TrieSlot src = ix.trie[(size_t)old_base + s];
     if (src.parent == NONE) return;
     const uint64_t key = (uint64_t)src.parent | ((uint64_t)src.token << 32);
+    bool beside = false; // this is a '+' child and the other slot of its line holds its parent
+    TrieSlot par{};
+    if (src.token == TOK_PLUS && src.parent != 0) {
+        par = ix.trie[(size_t)old_base + (s ^ 1u)];
+        beside = par.parent != NONE && par.node == src.parent;
+    }
+    if ((pass == 1) != beside) return;
+    if (beside) { // where did pass 0 put the parent?
+        const uint64_t pkey = (uint64_t)par.parent | ((uint64_t)par.token << 32);
+        uint32_t bk = edge_bucket(par.parent, par.token, new_buckets), j = 0;
+        for (uint32_t probes = 0; probes < new_buckets;) {
+            TrieSlot* q = ix.trie + (size_t)new_base + 2 * (size_t)bk + j;
+            const uint64_t k = atom_load(reinterpret_cast<uint64_t*>(q));
+            if (k == pkey) {
+                if (rehash_place(ix, ix.trie + (size_t)new_base + ((2 * (size_t)bk + j) ^ 1u), src, key)) return;
+                break; // the slot beside the parent is taken: hashed home
+            }
+            if (k == EDGE_EMPTY) break; // (cannot happen: pass 0 placed every parent)
+            if (++j == 2) {
+                j = 0;
+                bk = (bk + 1 == new_buckets) ? 0 : bk + 1;
+                probes++;
+            }
+        }
+    }
     uint32_t bk = edge_bucket(src.parent, src.token, new_buckets), j = 0;
     for (uint32_t probes = 0; probes < new_buckets;) {
-        TrieSlot* d = ix.trie + (size_t)new_base + 2 * (size_t)bk + j;
-        if (atom_cas(reinterpret_cast<uint64_t*>(d), EDGE_EMPTY, key) == EDGE_EMPTY) {
-            d->own_begin = src.own_begin;
-            d->own_count = src.own_count;
-            d->hash_begin = src.hash_begin;
-            d->hash_count = src.hash_count;
-            d->node = src.node;
-            d->lit_bloom = src.lit_bloom;
+        if (rehash_place(ix, ix.trie + (size_t)new_base + 2 * (size_t)bk + j, src, key)) {
+            if (src.token == TOK_PLUS && src.parent == 0) ix.tenants[d].root_plus = 2u * bk + j;
             return;
         }
         if (++j == 2) {
@@ -894,7 +977,7 @@ BMQ_HD bool find_filter(const DistIndexMut& ix, const uint8_t* q, uint32_t tenan
         const uint32_t tok = level_is_plus(q, start, len) ? TOK_PLUS : dict_intern(ix, h, len, inl, q, start, false);
         if (tok == TOK_UNKNOWN) return false;
         bool created;
-        node = trie_child(ix, ten, ten->base, ten->buckets, node, tok, false, slot_abs, created);
+        node = trie_child(ix, ten, ten->base, ten->buckets, node, at_root ? PARENT_IS_ROOT : slot_abs, tok, false, slot_abs, created);
         if (node == NONE) return false;
         at_root = false;
         if (last) break;

@@ -787,7 +787,8 @@ private:
         t.hash_hi = (uint32_t)(h >> 32);
         t.name_off = (uint32_t)names_h.size();
         t.name_len = (uint32_t)name.size();
-        memcpy(t.name16, name.data(), std::min<size_t>(name.size(), 16));
+        memcpy(t.name12, name.data(), std::min<size_t>(name.size(), 12));
+        t.root_plus = NONE;
         t.base = (uint32_t)base;
         t.buckets = buckets;
         t.n_routes = n_routes;
@@ -838,7 +839,7 @@ private:
             const uint32_t nb = std::max<uint32_t>(buckets_for(need + need / 2), t.buckets < 0x3FFFFFFFu ? t.buckets * 2 : t.buckets);
             uint64_t base;
             if (!alloc_region(2ull * nb, base)) return false;
-            if (!x.rehash(mut(), t.base, 2 * t.buckets, (uint32_t)base, nb)) return xfail();
+            if (!x.rehash(mut(), t.base, 2 * t.buckets, (uint32_t)base, nb, d)) return xfail();
             const uint32_t upd[2] = {(uint32_t)base, nb};
             if (!x.copy_in(&dir[d].base, upd, sizeof(upd))) return xfail(); // base and buckets are adjacent
             dir_h[d].base = (uint32_t)base;

@@ -230,7 +230,7 @@ __device__ __forceinline__ uint32_t global_word_at(const uint8_t* base, uint32_t
 // ------------------------------------------------------------------------------------------------------------
 // batch slot reset, tenant directory lookup
 // ------------------------------------------------------------------------------------------------------------
-constexpr TenantSlot EMPTY_TENANT{0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}};
+constexpr TenantSlot EMPTY_TENANT{0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, {0, 0, 0}, NONE};
 __device__ __forceinline__ bool tenant_known(const TenantSlot& t) { return (t.hash_lo | t.hash_hi) != 0; }
 
 // k_reset: zeroes the batch counters / sub-allocators / super sums of a batch slot.  Enqueued BEHIND a batch (after its counters
@@ -284,7 +284,7 @@ __device__ __forceinline__ void tenant_stage(const BatchArgs& a, uint32_t ti, Te
         for (uint32_t k = 0; k < 4; k++) { // (constant indices: the words stay in registers)
             const uint32_t w = __builtin_amdgcn_alignbyte(q.raw[k + 1], q.raw[k], sh);
             const uint32_t nb = q.len > 4 * k ? min(4u, q.len - 4 * k) : 0u;
-            q.w[k] = nb >= 4 ? w : (w & ((1u << (8 * nb)) - 1u)); // zero padded like TenantSlot.name16
+            q.w[k] = nb >= 4 ? w : (w & ((1u << (8 * nb)) - 1u)); // zero padded like TenantSlot.name12
             for (uint32_t j = 0; j < 4; j++)
                 if (4 * k + j < q.len) h = tenant_hash_step(h, (q.w[k] >> (8 * j)) & 0xFFu);
         }
@@ -305,9 +305,9 @@ __device__ __forceinline__ TenantSlot tenant_verdict(const BatchArgs& a, const T
     for (uint32_t probes = 0; probes <= a.ix.tenant_mask; probes++) {
         if (!tenant_known(t)) break;
         if (t.hash_lo == q.lo && t.hash_hi == q.hi && t.name_len == q.len) {
-            // both sides are zero padded to 16 bytes: the first four words compare whole
-            bool eq = t.name16[0] == q.w[0] && t.name16[1] == q.w[1] && t.name16[2] == q.w[2] && t.name16[3] == q.w[3];
-            for (uint32_t k = 16; k < q.len && eq; k += 4) {
+            // both sides are zero padded: the first three words compare whole
+            bool eq = t.name12[0] == q.w[0] && t.name12[1] == q.w[1] && t.name12[2] == q.w[2];
+            for (uint32_t k = 12; k < q.len && eq; k += 4) {
                 const uint32_t nb = min(4u, q.len - k), m = nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
                 eq = ((global_word_at(a.ix.tenant_names, t.name_off + k) ^ global_word_at(a.tenants, q.beg + k)) & m) == 0;
             }
@@ -356,11 +356,11 @@ __device__ __forceinline__ TenantSlot resolve_tenant_uniform(const BatchArgs& a,
         t.hash_lo = sp[0], t.hash_hi = sp[1], t.name_off = sp[2], t.name_len = sp[3];
         t.base = sp[4], t.buckets = sp[5], t.n_nodes = sp[6], t.n_routes = sp[7];
         t.root_hash_begin = sp[8], t.root_hash_count = sp[9], t.root_lit_bloom = sp[10], t.pending = sp[11];
-        t.name16[0] = sp[12], t.name16[1] = sp[13], t.name16[2] = sp[14], t.name16[3] = sp[15];
+        t.name12[0] = sp[12], t.name12[1] = sp[13], t.name12[2] = sp[14], t.root_plus = sp[15];
         if (!tenant_known(t)) break;
         if (t.hash_lo == lo && t.hash_hi == hi && t.name_len == len) {
-            bool eq = t.name16[0] == w[0] && t.name16[1] == w[1] && t.name16[2] == w[2] && t.name16[3] == w[3];
-            for (uint32_t k = 16; k < len && eq; k += 4) {
+            bool eq = t.name12[0] == w[0] && t.name12[1] == w[1] && t.name12[2] == w[2];
+            for (uint32_t k = 12; k < len && eq; k += 4) {
                 const uint32_t nb = min(4u, len - k), m = nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
                 eq = ((scalar_word_at(a.ix.tenant_names, t.name_off + k) ^ scalar_word_at(a.tenants, beg + k)) & m) == 0;
             }
@@ -385,14 +385,18 @@ __device__ __forceinline__ TenantSlot resolve_tenant(const BatchArgs& a, uint32_
 //   kind L (0): probe the child of `node` labelled with the topic's token at `level`
 //   kind P (1): probe the '+' child of `node` (it consumes the topic's level `level` whatever its token)
 constexpr uint32_t KIND_P = 0x80000000u;
+// (k_walk_slow only) kind P with KIND_DIRECT: the item's first word is not the parent's node id but the SLOT (relative to the region) of the
+// '+' child itself -- found beside its parent (layout v3) or through TenantSlot.root_plus --: the slot is read, nothing is searched
+constexpr uint32_t KIND_DIRECT = 0x40000000u;
 __device__ __forceinline__ uint32_t make_meta(uint32_t tl, uint32_t level, uint32_t kind) { return tl | (level << 6) | kind; }
-__device__ __forceinline__ uint32_t meta_level(uint32_t m) { return (m >> 6) & 0xFFFFFFu; }
+__device__ __forceinline__ uint32_t meta_level(uint32_t m) { return (m >> 6) & 0xFFFFFFu; } // (bits 6-29)
 
 struct StepOut {
     bool found;      // a node was discovered
     bool emit_own, emit_hash, push_l, push_h;
-    uint32_t idx;    // its slot
+    uint32_t idx;    // its node id
     uint32_t dl;     // levels consumed on arrival
+    uint32_t plus_slot; // push_h: the slot (relative to the region) of the node's '+' child if it lies beside the node, else NONE (hashed home)
     TrieSlot s;
 };
 
@@ -422,12 +426,38 @@ __device__ __forceinline__ void resolve_item(const DistIndexView& ix, Line64 ln,
     o.emit_own = o.found && (o.dl == nlev) && o.s.own_count != 0;
     o.emit_hash = o.found && o.s.hash_count != 0; // "<path>/#" matches whatever follows, also nothing
     o.push_l = o.push_h = false;
+    o.plus_slot = NONE;
     if (o.found && o.dl < nlev) {
         const uint32_t t = tok_at(o.dl);
         o.push_l = t != TOK_UNKNOWN && ((o.s.lit_bloom >> bloom_bit(t)) & 1u);
         o.push_h = (o.s.lit_bloom & BLOOM_PLUS) != 0;
+        const uint4& other = m1 ? ln.a0 : ln.b0; // layout v3: the '+' child lies in the other slot of this line if that was free when it came into being
+        if (o.push_h && other.x == o.s.node && other.y == TOK_PLUS) o.plus_slot = 2 * bk + (m1 ? 0u : 1u);
     }
     (void)sys;
+}
+// ... of an item that names the '+' child's slot itself (KIND_DIRECT)
+template <class TokAt>
+__device__ __forceinline__ void step_direct(const DistIndexView& ix, const TenantSlot& rg, uint32_t slot_rel, uint32_t level, uint32_t nlev, TokAt&& tok_at, StepOut& o) {
+    Line64 ln;
+    load_line64(ix.trie + (size_t)rg.base + (slot_rel & ~1u), ln);
+    const bool odd = (slot_rel & 1u) != 0;
+    const uint4& hd = odd ? ln.b0 : ln.a0;
+    o.found = hd.x != NONE && hd.y == TOK_PLUS;
+    o.s = odd ? unpack_slot(ln.b0, ln.b1) : unpack_slot(ln.a0, ln.a1);
+    o.idx = o.s.node;
+    o.dl = level + 1;
+    o.emit_own = o.found && (o.dl == nlev) && o.s.own_count != 0;
+    o.emit_hash = o.found && o.s.hash_count != 0;
+    o.push_l = o.push_h = false;
+    o.plus_slot = NONE;
+    if (o.found && o.dl < nlev) {
+        const uint32_t t = tok_at(o.dl);
+        o.push_l = t != TOK_UNKNOWN && ((o.s.lit_bloom >> bloom_bit(t)) & 1u);
+        o.push_h = (o.s.lit_bloom & BLOOM_PLUS) != 0;
+        const uint4& other = odd ? ln.a0 : ln.b0; // (the node's parent if the node lies beside it; the root's '+' child may have its own '+' child here)
+        if (o.push_h && other.x == o.s.node && other.y == TOK_PLUS) o.plus_slot = slot_rel ^ 1u;
+    }
 }
 
 template <class TokAt>
@@ -515,9 +545,9 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                     stack[2 * sp + 1] = make_meta(0, 0, 0);
                     sp++;
                 }
-                if ((rg.root_lit_bloom & BLOOM_PLUS) && !sys) {
-                    stack[2 * sp] = 0;
-                    stack[2 * sp + 1] = make_meta(0, 0, KIND_P);
+                if ((rg.root_lit_bloom & BLOOM_PLUS) && !sys) { // the root's '+' child: the directory entry knows its slot
+                    stack[2 * sp] = rg.root_plus != NONE ? rg.root_plus : 0u;
+                    stack[2 * sp + 1] = make_meta(0, 0, rg.root_plus != NONE ? (KIND_P | KIND_DIRECT) : KIND_P);
                     sp++;
                 }
             }
@@ -525,7 +555,8 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                 sp--;
                 const uint32_t node = stack[2 * sp], meta = stack[2 * sp + 1];
                 StepOut o;
-                step_item(a.ix, rg, node, meta_level(meta), (meta & KIND_P) != 0, nlev, sys, [&](uint32_t l) { return toks[l]; }, o);
+                if (meta & KIND_DIRECT) step_direct(a.ix, rg, node, meta_level(meta), nlev, [&](uint32_t l) { return toks[l]; }, o);
+                else step_item(a.ix, rg, node, meta_level(meta), (meta & KIND_P) != 0, nlev, sys, [&](uint32_t l) { return toks[l]; }, o);
                 if (!o.found) continue;
                 if (pass == 0) visits++;
                 if (o.emit_own) {
@@ -546,8 +577,8 @@ __global__ __launch_bounds__(64) void k_walk_slow(BatchArgs a) {
                     sp++;
                 }
                 if (o.push_h) {
-                    stack[2 * sp] = o.idx;
-                    stack[2 * sp + 1] = make_meta(0, o.dl, KIND_P);
+                    stack[2 * sp] = o.plus_slot != NONE ? o.plus_slot : o.idx;
+                    stack[2 * sp + 1] = make_meta(0, o.dl, o.plus_slot != NONE ? (KIND_P | KIND_DIRECT) : KIND_P);
                     sp++;
                 }
             }

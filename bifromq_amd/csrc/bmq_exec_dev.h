@@ -69,9 +69,9 @@ __global__ __launch_bounds__(BK) void k_b_group(DistIndexMut ix, OpBatch ob) {
     const uint32_t p = blockIdx.x * BK + threadIdx.x;
     if (p < ob.n) group_one(ix, ob, p);
 }
-__global__ __launch_bounds__(BK) void k_b_rehash(DistIndexMut ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets) {
+__global__ __launch_bounds__(BK) void k_b_rehash(DistIndexMut ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets, uint32_t pass, uint32_t d) {
     const uint32_t s = blockIdx.x * BK + threadIdx.x;
-    if (s < old_slots) rehash_one(ix, old_base, new_base, new_buckets, s);
+    if (s < old_slots) rehash_one(ix, old_base, new_base, new_buckets, s, pass, d);
 }
 __global__ __launch_bounds__(BK) void k_b_dict_rehash(const DictSlot* old, uint32_t old_slots, DistIndexMut ix) {
     const uint32_t i = blockIdx.x * BK + threadIdx.x;
@@ -308,8 +308,9 @@ struct DevExec {
         hipLaunchKernelGGL(k_b_group, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob);
         return launched();
     }
-    bool rehash(const DistIndexMut& ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets) {
-        hipLaunchKernelGGL(k_b_rehash, grid(old_slots, BK), dim3(BK), 0, stream, ix, old_base, old_slots, new_base, new_buckets);
+    bool rehash(const DistIndexMut& ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets, uint32_t d) {
+        hipLaunchKernelGGL(k_b_rehash, grid(old_slots, BK), dim3(BK), 0, stream, ix, old_base, old_slots, new_base, new_buckets, 0u, d);
+        hipLaunchKernelGGL(k_b_rehash, grid(old_slots, BK), dim3(BK), 0, stream, ix, old_base, old_slots, new_base, new_buckets, 1u, d); // ('+' children beside their parents)
         return launched();
     }
     bool dict_rehash(const DictSlot* old, uint32_t old_slots, const DistIndexMut& ix) {

@@ -115,8 +115,8 @@ struct HostExec {
         par(ob.n, [&](size_t p) { group_one(ix, ob, (uint32_t)p); });
         return true;
     }
-    bool rehash(const DistIndexMut& ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets) {
-        par(old_slots, [&](size_t s) { rehash_one(ix, old_base, new_base, new_buckets, (uint32_t)s); });
+    bool rehash(const DistIndexMut& ix, uint32_t old_base, uint32_t old_slots, uint32_t new_base, uint32_t new_buckets, uint32_t d) {
+        for (uint32_t pass = 0; pass < 2; pass++) par(old_slots, [&](size_t s) { rehash_one(ix, old_base, new_base, new_buckets, (uint32_t)s, pass, d); });
         return true;
     }
     bool dict_rehash(const DictSlot* old, uint32_t old_slots, const DistIndexMut& ix) {

@@ -11,7 +11,11 @@
 //     key (load factor <= 1/2), so a child lookup reads ONE line in ~92 % of the cases and gets the child's complete
 //     header with it.  Node ids are not slot positions: a region is grown by re-inserting its slots into a larger
 //     region in parallel (k_rehash_region), no id changes;
-//   * '+' children are ordinary edges with token TOK_PLUS; bit 31 of the parent's Bloom word says whether one exists;
+//   * '+' children are edges with token TOK_PLUS; bit 31 of the parent's Bloom word says whether one exists.  Layout v3 (round 6): the
+//     '+' child of node X is placed in the OTHER slot of the line X's own slot lies in whenever that slot is free at the time (else at
+//     the hashed home of (X, TOK_PLUS), like a literal edge): 44 % of the nodes a publish topic discovers on the survey's workload are
+//     '+' children, and a walk that has fetched X's line then has X/+ with it -- no second line, no second round.  The '+' child of a
+//     tenant ROOT sits at its hashed home and the directory entry remembers where (TenantSlot.root_plus);
 //   * '#' children are never nodes: the routes of "<path>/#" hang off the parent (hash_*);
 //   * the tenant root is not a slot: its payload lives in the directory entry the walk reads anyway.
 // Route ids: after bmq_rebuild the id of a route is the rank of its KV key (keys arrive sorted from the KV iterator);
@@ -68,7 +72,8 @@ struct alignas(64) TenantSlot {
     uint32_t root_hash_begin, root_hash_count; // routes of the filter "#"
     uint32_t root_lit_bloom;                   // Bloom word of the root (bit 31: a first-level '+' exists)
     uint32_t pending;          // builder scratch: upper bound of the nodes the batch being prepared may add
-    uint32_t name16[4];        // the first 16 bytes of the tenant id (zero padded): ids up to 16 bytes are compared without the pool
+    uint32_t name12[3];        // the first 12 bytes of the tenant id (zero padded): ids up to 12 bytes are compared without the pool
+    uint32_t root_plus;        // slot of the root's '+' child, relative to `base` (NONE: there is none): the walk reads it straight away
 };
 static_assert(sizeof(TenantSlot) == 64, "TenantSlot must be 64 bytes");
 

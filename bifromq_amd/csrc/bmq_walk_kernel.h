@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
             const uint32_t tl = meta & 63u;
             const uint32_t tcur = tokens[(meta >> 6) & 1023u];        // the topic's token at the item's level
             const uint32_t tnext = tokens[((meta >> 6) & 1023u) + 1]; // ... at the next one (whatever follows the topic's last: unused then)
+            const uint32_t tnext2 = tokens[((meta >> 6) & 1023u) + 2]; // ... and at the one after it (the literal child of a '+' child found in the same line)
             const uint32_t tok = (meta & KIND_P) ? TOK_PLUS : tcur;
             uint2 reg = make_uint2(0u, s_rbuckets);
             if (MODE == 2) reg = t_region[tl];
@@ -314,26 +315,72 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
             const uint32_t hash_begin = m1 ? line.b1.x : line.a1.x, hash_count = m1 ? line.b1.y : line.a1.y;
             const uint32_t child = m1 ? line.b1.z : line.a1.z, bloom = m1 ? line.b1.w : line.a1.w;
             const uint32_t cmeta = (meta & ~KIND_P) + WALK_META_CHILD; // the same topic, one level on
-            const bool last = ((meta >> 16) & 31u) == 0;               // no level of the topic behind this item's
-            if (found) atomicAdd(&cnt_visit[tl], 1u); // (LDS, no return value)
+            const uint32_t rem = (meta >> 16) & 31u;                   // levels of the topic behind this item's
+            const bool last = rem == 0;
             const uint32_t bloom_in = (found && !last) ? bloom : 0u;   // children only below an inner level
+            // Layout v3: the OTHER slot of the line holds the found node's '+' child whenever it was free when that child came into being
+            // (bmq_build_core.h, trie_child).  Then the child P is resolved right here -- it consumes the topic's next level whatever its
+            // token --: no item, no line, no round of its own.  Otherwise (the slot holds some other edge) the '+' child sits at its hashed home.
+            const uint32_t o_parent = m1 ? line.a0.x : line.b0.x, o_token = m1 ? line.a0.y : line.b0.y;
+            const bool plus_here = (int32_t)bloom_in < 0 && o_parent == child && o_token == TOK_PLUS;
+            // (P's payload leaves the line's registers HERE, in front of the first sink: with the whole line alive across it the compiler
+            // spilled 30 vector registers of the 64 that 8 waves per SIMD allow)
+            const uint32_t p_own_begin = m1 ? line.a0.z : line.b0.z, p_own_count = m1 ? line.a0.w : line.b0.w;
+            const uint32_t p_hash_begin = m1 ? line.a1.x : line.b1.x, p_hash_count = m1 ? line.a1.y : line.b1.y;
+            const uint32_t p_node = m1 ? line.a1.z : line.b1.z, p_bloom = m1 ? line.a1.w : line.b1.w;
+            if (found) atomicAdd(&cnt_visit[tl], plus_here ? 2u : 1u); // (LDS, no return value)
             // the literal child: the next token is known to the dictionary (TOK_UNKNOWN = 0: min() drops it) and the node's Bloom word has its bit
-            const uint32_t lit = min((bloom_in >> bloom_bit(tnext)) & 1u, tnext);
-            sink(own_begin, (found && last) ? own_count : 0u, hash_begin, found ? hash_count : 0u /* "<path>/#" matches whatever follows, also nothing */,
-                 lit, bloom_in, child, cmeta, tl, ln);
+            // ONE sink body run once or twice (not two copies of it: the second copy cost 11 spilled vector registers): first the found node,
+            // then -- if some lane of the wave has one -- the '+' child P beside it.  (P's own '+' child cannot lie beside P -- that slot
+            // holds P's parent --: it is at its hashed home, an ordinary '+' probe.)
+            uint32_t e_own_begin = own_begin, e_own_count = (found && last) ? own_count : 0u, e_hash_begin = hash_begin;
+            uint32_t e_hash_count = found ? hash_count : 0u; // "<path>/#" matches whatever follows, also nothing
+            uint32_t e_lit = min((bloom_in >> bloom_bit(tnext)) & 1u, tnext), e_bloom = plus_here ? 0u : bloom_in, e_child = child, e_meta = cmeta;
+            const bool second = ballot64(plus_here) != 0;
+#pragma clang loop unroll(disable)
+            for (uint32_t part = 0;; part++) {
+                sink(e_own_begin, e_own_count, e_hash_begin, e_hash_count, e_lit, e_bloom, e_child, e_meta, tl, ln);
+                if (part == 1 || !second) break;
+                const bool p_last = rem == 1; // P's level is the topic's last
+                const uint32_t p_bloom_in = (plus_here && !p_last) ? p_bloom : 0u;
+                e_own_begin = p_own_begin, e_own_count = (plus_here && p_last) ? p_own_count : 0u, e_hash_begin = p_hash_begin;
+                e_hash_count = plus_here ? p_hash_count : 0u;
+                e_lit = min((p_bloom_in >> bloom_bit(tnext2)) & 1u, tnext2), e_bloom = p_bloom_in, e_child = p_node, e_meta = cmeta + WALK_META_CHILD;
+            }
         }
     };
-    // Round 0 visits the tenant roots: their slot payload comes with the directory entry, no line is fetched.
-    auto boot = [&](bool mine, uint32_t r_hash_begin, uint32_t r_hash_count, uint32_t r_bloom) {
-        const bool act = mine;
+    // Round 0 visits the tenant roots: their slot payload comes with the directory entry, no line is fetched.  Layout v3: the entry also says
+    // where the root's '+' child P0 lies; the grouped instantiations read P0's whole line on the scalar unit (the wave shares the tenant) and
+    // resolve P0 -- and P0's own '+' child PP0 if it lies beside P0 -- right here.  rp: what was read: has (0: nothing, 1: P0, 2: P0 and PP0),
+    // then per node (own_begin, own_count, hash_begin, hash_count) + (node id, Bloom word).  MIXED passes has = 0: P0 is then probed for at
+    // its hashed home like any other node and the drain finds PP0 beside it.
+    struct RootPlus {
+        uint32_t has;
+        uint4 p0;
+        uint2 p0n;
+        uint4 pp0;
+        uint2 pp0n;
+    };
+    auto boot = [&](bool mine, uint32_t r_hash_begin, uint32_t r_hash_count, uint32_t r_bloom, const RootPlus& rp) {
         const uint32_t ln = lane_here();
-        const uint32_t t0 = tokens[act ? tok_base : 0u]; // (a lane that is not `mine` reads entry 0: its own tok_base may lie beyond the table)
-        const uint32_t bloom_in = act ? r_bloom : 0u;
-        sink(0u, 0u,                                                        // a topic has at least one level: nothing ends at the root
-             r_hash_begin, (act && !sys) ? r_hash_count : 0u,               // the filter "#"; never for '$' topics
-             min((bloom_in >> bloom_bit(t0)) & 1u, t0),
-             sys ? (bloom_in & ~BLOOM_PLUS) : bloom_in,                      // a first-level '+' never matches a '$' topic
-             0u /* the tenant root's node id */, walk_meta(ln, tok_base, nlev - 1), ln, ln);
+        bool actp = mine; // the lane's topic reaches the node of this part
+        // part 0: the root; 1: P0 = "+" (consumes the first level); 2: PP0 = "+/+".  ONE sink body (see the drain); the per-part values are
+        // wave-uniform selects on the scalar unit.
+#pragma clang loop unroll(disable)
+        for (uint32_t part = 0; part <= rp.has; part++) {
+            const uint4 pl = part == 0 ? make_uint4(0u, 0u, r_hash_begin, r_hash_count) : (part == 1 ? rp.p0 : rp.pp0);
+            const uint32_t nd = part == 0 ? 0u : (part == 1 ? rp.p0n.x : rp.pp0n.x), bl = part == 0 ? r_bloom : (part == 1 ? rp.p0n.y : rp.pp0n.y);
+            const uint32_t tk = tokens[actp ? tok_base + part : 0u]; // (a lane that is not active reads entry 0: its own tok_base may lie beyond the table)
+            const bool root_sys = part == 0 && sys;                  // a first-level wildcard never matches a '$' topic
+            const uint32_t bloom_in = (actp && nlev > part) ? bl : 0u; // children only while the topic has a level left
+            if (part != 0 && actp) cnt_visit[ln] += 1u; // (the lane's own topic; the drain's atomics come later)
+            sink(pl.x, (actp && nlev == part) ? pl.y : 0u /* (part 0: pl.y = 0: a topic has at least one level) */,
+                 pl.z, (actp && !root_sys) ? pl.w : 0u, min((bloom_in >> bloom_bit(tk)) & 1u, tk),
+                 (root_sys || part < rp.has) ? (bloom_in & ~BLOOM_PLUS) : bloom_in, // ('+' child resolved by the next part, or probed for at its hashed home)
+                 nd, walk_meta(ln, tok_base + part, nlev - 1 - part), ln, ln);
+            actp = actp && !root_sys && (int32_t)bloom_in < 0;
+            if (ballot64(actp) == 0) break;
+        }
     };
     {
     const BatchArgs& b = a;
@@ -371,7 +418,7 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
                 t_region[lane] = t_region_early;
                 wave_sync();
             }
-            boot(mine, m_hash_begin, m_hash_count, m_bloom);
+            boot(mine, m_hash_begin, m_hash_count, m_bloom, RootPlus{0u, make_uint4(0u, 0u, 0u, 0u), make_uint2(0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint2(0u, 0u)});
             drain(std::integral_constant<int, 2>{}, b.ix.trie, 1u);
         } else {
             // the chunk's tenants, one after the other (batches arrive grouped by tenant: one, sometimes two)
@@ -388,7 +435,16 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
                 const TenantSlot rg = resolve_tenant_uniform(b, cur); // on the scalar unit
                 if (!tenant_known(rg)) continue;                      // no such tenant: no routes
                 const uint32_t s_rbase = sgpr(rg.base), s_rbuckets = sgpr(rg.buckets);
-                boot(mine && ti == cur, sgpr(rg.root_hash_begin), sgpr(rg.root_hash_count), sgpr(rg.root_lit_bloom));
+                RootPlus rp{0u, make_uint4(0u, 0u, 0u, 0u), make_uint2(0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint2(0u, 0u)};
+                const uint32_t s_rplus = sgpr(rg.root_plus);
+                if ((int32_t)sgpr(rg.root_lit_bloom) < 0 && s_rplus != NONE) { // the line of the root's '+' child: 64 bytes through the scalar cache
+                    ScalarWords sp = scalar_words(b.ix.trie + (size_t)s_rbase + (s_rplus & ~1u));
+                    const uint32_t o0 = (s_rplus & 1u) * 8u, o1 = 8u - o0; // word offsets of P0's slot and of the other one
+                    rp.has = 1u, rp.p0 = make_uint4(sp[o0 + 2], sp[o0 + 3], sp[o0 + 4], sp[o0 + 5]), rp.p0n = make_uint2(sp[o0 + 6], sp[o0 + 7]);
+                    if (sp[o1] == rp.p0n.x && sp[o1 + 1] == TOK_PLUS)
+                        rp.has = 2u, rp.pp0 = make_uint4(sp[o1 + 2], sp[o1 + 3], sp[o1 + 4], sp[o1 + 5]), rp.pp0n = make_uint2(sp[o1 + 6], sp[o1 + 7]);
+                }
+                boot(mine && ti == cur, sgpr(rg.root_hash_begin), sgpr(rg.root_hash_count), sgpr(rg.root_lit_bloom), rp);
                 if (s_rbuckets < (1u << 25)) drain(std::integral_constant<int, 0>{}, b.ix.trie + s_rbase, s_rbuckets);
                 else drain(std::integral_constant<int, 1>{}, b.ix.trie + s_rbase, s_rbuckets);
             }

@@ -80,7 +80,7 @@ static uint32_t dict_find_host(const DistIndex<HostExec>& h, std::string_view le
 }
 
 // the walk of k_walk, on the host image
-static std::vector<uint32_t> image_match(const DistIndex<HostExec>& h, std::string_view tenant, std::string_view topic, uint64_t* visits) {
+static std::vector<uint32_t> image_match(const DistIndex<HostExec>& h, std::string_view tenant, std::string_view topic, uint64_t* visits, uint64_t* beside = nullptr /* [2]: '+' children found beside their parent, '+' children found below a non-root node */) {
     std::vector<uint32_t> ids;
     const DistIndexMut ix = h.mut();
     const uint32_t d = tenant_find(ix.tenants, ix.tenant_mask, ix.tenant_names, (const uint8_t*)tenant.data(), 0, tenant.size());
@@ -94,34 +94,66 @@ static std::vector<uint32_t> image_match(const DistIndex<HostExec>& h, std::stri
         const uint32_t c = cf & ~RANGE_INDIRECT;
         for (uint32_t i = 0; i < c; i++) ids.push_back((cf & RANGE_INDIRECT) ? h.route_pos[b + i] : b + i);
     };
+    // Layout v3 (bmq_layout.h): the '+' child of a node lies in the OTHER slot of the node's line if that slot was free when the child came
+    // into being, else at its hashed home; the root's '+' child P0 lies at its hashed home and the directory entry names the slot.  This walker reads the image by that rule and nothing else.
+    constexpr uint64_t AT_ROOT = ~0ull;
     struct Item {
         uint32_t node, tok, level;
+        uint64_t pslot; // where `node`'s own slot is (relative to the region), or AT_ROOT
     };
     std::vector<Item> st;
-    auto visit = [&](uint32_t node, uint32_t dl, uint32_t own_b, uint32_t own_c, uint32_t hash_b, uint32_t hash_c, uint32_t bloom) {
+    auto visit = [&](uint32_t node, uint64_t slot, uint32_t dl, uint32_t own_b, uint32_t own_c, uint32_t hash_b, uint32_t hash_c, uint32_t bloom) {
         const bool root_sys = dl == 0 && sys;
         if (dl == toks.size() && own_c) emit(own_b, own_c);
         if (hash_c && !root_sys) emit(hash_b, hash_c);
         if (dl < toks.size()) {
             const uint32_t t = toks[dl];
-            if (t != TOK_UNKNOWN && ((bloom >> bloom_bit(t)) & 1u)) st.push_back({node, t, dl});
-            if ((bloom & BLOOM_PLUS) && !root_sys) st.push_back({node, TOK_PLUS, dl});
+            if (t != TOK_UNKNOWN && ((bloom >> bloom_bit(t)) & 1u)) st.push_back({node, t, dl, slot});
+            if ((bloom & BLOOM_PLUS) && !root_sys) st.push_back({node, TOK_PLUS, dl, slot});
         }
     };
-    visit(0, 0, 0, 0, rg.root_hash_begin, rg.root_hash_count, rg.root_lit_bloom); // round 0: payload from the directory
+    visit(0, AT_ROOT, 0, 0, 0, rg.root_hash_begin, rg.root_hash_count, rg.root_lit_bloom); // round 0: payload from the directory
     while (!st.empty()) {
         const Item it = st.back();
         st.pop_back();
+        auto arrive = [&](const TrieSlot* hit, uint64_t slot) {
+            if (visits) (*visits)++;
+            visit(hit->node, slot, it.level + 1, hit->own_begin, hit->own_count, hit->hash_begin, hit->hash_count, hit->lit_bloom);
+        };
+        if (it.tok == TOK_PLUS) {
+            if (it.pslot == AT_ROOT) {
+                if (rg.root_plus != NONE) {
+                    const TrieSlot& p0 = h.trie[rg.base + rg.root_plus];
+                    if (p0.parent != 0 || p0.token != TOK_PLUS) {
+                        fprintf(stderr, "root_plus of a tenant does not name the root's '+' child\n");
+                        abort();
+                    }
+                    arrive(&p0, rg.root_plus);
+                    continue;
+                }
+            } else {
+                const uint64_t ns = it.pslot ^ 1ull;
+                const TrieSlot& o = h.trie[rg.base + ns];
+                if (o.parent == it.node && o.token == TOK_PLUS) {
+                    if (beside) beside[0]++, beside[1]++;
+                    arrive(&o, ns);
+                    continue;
+                }
+                // (a free or otherwise taken neighbour says nothing: a region growth leaves a '+' child that was not beside its parent at its hashed home)
+            }
+        }
         uint32_t bk = edge_bucket(it.node, it.tok, rg.buckets);
         for (uint32_t probes = 0; probes < rg.buckets; probes++) { // bucket probes, first-free order
             const TrieSlot& a = h.trie[rg.base + 2 * bk];
             const TrieSlot& b = h.trie[rg.base + 2 * bk + 1];
-            const TrieSlot* hit = nullptr;
-            if (a.parent == it.node && a.token == it.tok) hit = &a;
-            else if (b.parent == it.node && b.token == it.tok) hit = &b;
-            if (hit) {
-                if (visits) (*visits)++;
-                visit(hit->node, it.level + 1, hit->own_begin, hit->own_count, hit->hash_begin, hit->hash_count, hit->lit_bloom);
+            if (a.parent == it.node && a.token == it.tok) {
+                if (beside && it.tok == TOK_PLUS && it.pslot != AT_ROOT) beside[1]++;
+                arrive(&a, 2ull * bk);
+                break;
+            }
+            if (b.parent == it.node && b.token == it.tok) {
+                if (beside && it.tok == TOK_PLUS && it.pslot != AT_ROOT) beside[1]++;
+                arrive(&b, 2ull * bk + 1);
                 break;
             }
             if (a.parent == NONE || b.parent == NONE) break;
@@ -184,7 +216,7 @@ int main(int argc, char** argv) {
     hx.threads = threads;
     DistIndex<HostExec> h(hx);
     h.tiny = getenv("BMQ_FUZZ_BIG") == nullptr;
-    uint64_t checks = 0, n_apply = 0, n_rebuild = 0, fo_pairs = 0, n_generations = 0;
+    uint64_t checks = 0, n_apply = 0, n_rebuild = 0, fo_pairs = 0, n_generations = 0, plus_stat[2] = {0, 0};
     Fanout<HostExec> fo(hx, h); // fan-out grouping (bmq_fanout.h) over the same index, kept across rebuilds and applies
     fo.initial_table = 4;       // 36 deliverer keys: the group table grows twice
     for (int round = 0; round < rounds; round++) {
@@ -488,7 +520,7 @@ int main(int argc, char** argv) {
             for (auto& d : dec)
                 if (d.tenant == tn && filter_matches(d.levels, tl)) want.push_back(d.id);
             std::sort(want.begin(), want.end());
-            const auto got = image_match(h, tn, topic, nullptr);
+            const auto got = image_match(h, tn, topic, nullptr, plus_stat);
             checks++;
             if (got != want) {
                 fprintf(stderr, "round %d (%s): tenant '%s' topic '%s': image gives %zu ids, the rule %zu\n", round, full ? "rebuild" : "apply", tn.c_str(),
@@ -503,6 +535,7 @@ int main(int argc, char** argv) {
     }
     DistIndexStats st;
     h.stats(st);
+    printf("layout v3: %llu of the %llu nodes the checks discovered through a '+' edge below a non-root node lay beside their parent\n", (unsigned long long)plus_stat[0], (unsigned long long)plus_stat[1]);
     printf("host_fuzz ok: seed %llu, %d rounds (%llu rebuilds, %llu applies, %llu generation changes), %llu topic checks, final %zu routes, %llu nodes, %llu tokens, "
            "%llu trie slots (%llu garbage), %llu id-list words (%llu garbage), %llu fan-out pairs grouped\n",
            (unsigned long long)seed, rounds, (unsigned long long)n_rebuild, (unsigned long long)n_apply, (unsigned long long)n_generations, (unsigned long long)checks, model.size(),
