@@ -383,6 +383,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed_plain = float(tmax.item())
     eng.set_kernel_timing(True)
+    # Per rank, next to the whole-job value: with the index sharded N ways every rank's k_walk runs over 1 / N of the
+    # 10 M route keys -- it hits its L2 more often, and a curve that reads super-linear explains itself only with these beside it.
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([float(np.mean(walk_ms)), float(np.mean(expand_ms)), float(np.mean(total_ms)), float(info.device_bytes), float(info.n_routes),
+                             float(info.n_nodes), float(n_visit) / max(1, args.steps), float(n_match) / max(1, args.steps), float(np.mean(lat))],
+                            dtype=torch.float64, device=dev)
+        allr = torch.zeros(world, mine.numel(), dtype=torch.float64, device=dev)  # (a sum over rows of which every rank fills its own: any backend does it)
+        allr[rank] = mine
+        dist.all_reduce(allr)
+        per_rank = [{"rank": r, "kernel_ms": {"k_walk": float(v[0]), "k_expand": float(v[1]), "all_kernels": float(v[2])}, "index_bytes_this_rank": int(v[3]),
+                     "route_keys_this_rank": int(v[4]), "trie_nodes_this_rank": int(v[5]), "n_visit_per_batch": float(v[6]), "n_match_per_batch": float(v[7]),
+                     "ms_per_step_this_rank": float(v[8])} for r, v in enumerate(x.tolist() for x in allr)]
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -468,6 +481,8 @@ def main():
 
     if node is not None:
         out["node_batch"] = node
+    if per_rank is not None:
+        out["per_rank"] = per_rank  # (every rank's own kernel times and shard size: what a super-linear weak-scaling curve has to be read with)
     if world == 1 and not args.no_host_path:
         out["fanout_group"] = fanout_group_leg(eng, d_row[0], d_ids[0], n, dev, torch, np)
     if world == 1 and not args.no_host_path:
@@ -662,13 +677,17 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
 
     extra = {}
     t_all = time.perf_counter()
+    try:  # configs[0]: the reference's own CPU-runnable case, engine and restatement side by side
+        extra["c1"] = c1_leg(args, torch, np, torch.device("cuda", torch.cuda.current_device()))
+    except Exception as ex:  # noqa: BLE001
+        extra["c1"] = {"error": repr(ex)}
     for wl in ("c2", "c4"):  # child runs: their own index, their own roofline
         try:
             t0 = time.perf_counter()
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                                 "--no-host-path", "--no-extras"], capture_output=True, text=True, timeout=240)
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            keep = ("metric", "value", "unit", "ms_per_step", "kernel_ms", "roofline", "routes_per_topic", "topics_per_filter", "churn")
+            keep = ("metric", "value", "unit", "ms_per_step", "kernel_ms", "roofline", "routes_per_topic", "topics_per_filter", "churn", "limited")
             extra[wl] = {k: d[k] for k in keep if k in d}
             extra[wl]["workload"] = d["config"]["workload"]
             extra[wl]["wall_s"] = time.perf_counter() - t0
@@ -792,6 +811,88 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
         extra["compaction"] = {"error": repr(ex)}
     extra["wall_s"] = time.perf_counter() - t_all
     return extra
+
+
+def c1_leg(args, torch, np, dev):
+    """configs[0]: 1 tenant, 10 k literal filters (no wildcards), 100 k publishes -- "the reference Java TopicTrie on host CPU" case, the
+    small-index / small-batch regime where launch latency, not k_walk, is the story.  The structural restatement of matchAll on the box's
+    host cores (one matchAll(singleton) per publish, and ONE matchAll(Set) for the whole batch: a single tenant's call is sequential) beside
+    the engine on the same inputs: device-resident batch (kernels + finish) and one blocking host-to-host call; all 100 k rows compared."""
+    import bifromq_amd as B
+    from bifromq_amd.workload import MODE_LITERAL
+    from oracle import oracle as O
+    from tests import util as U
+
+    w = B.Workload(0xB1F20001, 1, 10_000, MODE_LITERAL)
+    n = 100_000
+    data, off, tt = w.topics(0xB1F20001 + 7, n, 0, 1, 900, True)
+    tn = w.tenants()
+    eng = B.Engine(device=dev.index if dev.index is not None else 0, kernel_timing=True)
+    try:
+        kb, ko = w.keys_packed()
+        eng.rebuild(packed=(kb, ko))
+        tdata, toff = w.tenants_packed()
+        d_t, d_to = torch.from_numpy(tdata.copy()).to(dev), torch.from_numpy(toff.astype(np.int32)).to(dev)
+        d_data, d_off, d_tt = torch.from_numpy(data).to(dev), torch.from_numpy(off.astype(np.int32)).to(dev), torch.from_numpy(tt.astype(np.int32)).to(dev)
+        d_row = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        d_ids = torch.zeros(16 * n, dtype=torch.int32, device=dev)
+        d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def step():
+            eng.match_batch_device(d_t.data_ptr(), d_to.data_ptr(), 1, d_tt.data_ptr(), d_data.data_ptr(), d_off.data_ptr(), n, d_row.data_ptr(),
+                                   d_ids.data_ptr(), d_ids.numel(), d_total.data_ptr())
+            return eng.finish()
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            total = step()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        st = eng.stats()
+        host_ms = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            row, ids = eng.match_batch(tn, tt, packed_topics=(data, off))
+            host_ms.append((time.perf_counter() - t0) * 1e3)
+        cores = effective_cpus()
+        kv = O.KV(packed=(kb, ko))
+        raw = data.tobytes()
+        topics = [raw[off[i]:off[i + 1]] for i in range(n)]
+        packed = O.pack(topics)
+        res, sec = kv.match_singletons(tn, tt, packed, threads=cores)
+        t0 = time.perf_counter()
+        whole = kv.match_all(tn[0], sorted(set(topics)))
+        sec_whole = time.perf_counter() - t0
+        parity = {"rows_compared": n}
+        try:
+            differ = U.assert_csr_equal_modulo_quirk_ii(lambda: w.keys(), kv.key, tn, tt, res.row_ptr.astype(np.int64), res.routes,
+                                                        row.astype(np.int64), ids)
+            parity["rows_differing_from_reference_restatement"] = int(len(differ))
+            parity["differing_rows_equal_semantic_oracle"] = int(U.assert_differing_rows_semantic("bench c1", kv, tn, tt, packed, differ, row.astype(np.int64), ids,
+                                                                                                 livelocks=res.livelocks))
+        except AssertionError as ex:
+            parity = {"FAILED": repr(ex)}
+        med = float(np.median(ms))
+        alg = st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit + 4 * st.n_match
+        return {"workload": "C1: 1 tenant, 10 k literal filters, 100 k publishes (configs[0])",
+                "gpu": {"value": n / (med * 1e-3), "unit": "topics/s", "ms_per_batch_p50": med, "ms_per_batch_max": float(np.max(ms)), "steps": len(ms),
+                        "kernel_ms": {"k_walk": st.ms_walk, "k_expand": st.ms_expand, "all_kernels": st.ms_total},
+                        "host_to_host_call_ms_p50": float(np.median(host_ms)), "routes_per_topic": total / n,
+                        "roofline": {"bound": "hbm", "kernel": "k_walk", "achieved": (alg - 4 * st.n_match) / (st.ms_walk * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                     "frac": (alg - 4 * st.n_match) / (st.ms_walk * 1e-3) / 8e12,
+                                     "note": "a 100 k-topic launch is 1563 waves on 1024 SIMDs: the chip is not full, latency of the launch and of "
+                                             "one wave's dependent chain set the time, not bandwidth"}},
+                "cpu_baseline": {"value": n / sec, "unit": "topics/s", "cores": cores, "kind": "port",
+                                 "sample": "all %d publishes, one matchAll(singleton(topic)) per publish on %d threads; %.2f s" % (n, cores, sec),
+                                 "whole_batch": {"value": n / sec_whole, "unit": "topics/s", "threads": 1, "seconds": sec_whole,
+                                                 "note": "ONE matchAll(Set<topic>) with the batch's %d distinct topics: a tenant's call is sequential" % len(set(topics)),
+                                                 "reference_livelocks_stepped_over": int(whole.livelocks)}},
+                "parity": parity}
+    finally:
+        eng.close()
 
 
 def compaction_leg(args, eng, step, torch, np, fetch_csr=None):
@@ -1336,8 +1437,14 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
     n_topics, n = 1_000_000, min(args.topics, 100_000) if args.topics != 1_000_000 else 100_000
     data, off, tt = w.retain(seed, n_topics, filters=False)
     eng = B.Engine(device=local_rank, kernel_timing=True)
+    # every retained topic carries (timestamp, expiry) as IRetainTopicIndex.add hands them over (RS/RetainStoreCoProc.java:240-255): the
+    # complete-set legs ignore them, the match(limit, now) leg below picks live topics with `now` in the middle of the expiry instants
+    rng_t = np.random.default_rng(0xB1F2)
+    base_ms = 1_700_000_000_000
+    ts_hlc = ((base_ms + rng_t.integers(0, 100_000, n_topics)).astype(np.uint64) << np.uint64(16))
+    expiry_s = rng_t.choice(np.array([30, 60, 3600, 0x7FFFFFFF], dtype=np.uint32), n_topics)
     t0 = time.time()
-    eng.retain_rebuild(w.tenants(), tt, packed_topics=(data, off))
+    eng.retain_rebuild(w.tenants(), tt, packed_topics=(data, off), timestamps=ts_hlc, expiry=expiry_s)
     t_build = time.time() - t0
     tdata, toff = w.tenants_packed()
     d_tenants = torch.from_numpy(tdata.copy()).to(dev)
@@ -1403,7 +1510,12 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
     walk_bytes = float(np.mean(alg)) - 4.0 * n_match / args.steps
     exp_bytes = 4.0 * n_match / args.steps
     achieved = (walk_bytes if dom_name == "k_retain_walk" else exp_bytes) / (k_ms * 1e-3) / 1e9
+    limited = None
+    if world == 1:  # (before the churn leg: the index as loaded)
+        limited = {"clean": retain_limited_leg(eng, w, batches[0][3], base_ms + 95_000, np)}
     churn = retain_churn_leg(eng, w, data, off, n_topics, step, torch, np) if world == 1 and not args.no_churn else None
+    if limited is not None and churn is not None:
+        limited["churned"] = retain_limited_leg(eng, w, batches[0][3], base_ms + 95_000, np)
     out = {"metric": "retain-direction filter matches/sec (whole node)", "value": world * n * args.steps / elapsed,
            "unit": "filters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -1423,7 +1535,7 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
                         "frac_pipeline": float(np.mean(alg)) / ((kw + ke) * 1e-3) / 8e12,
                         "algorithmic_bytes_per_launch": float(np.mean(alg)),
                         "kernel_own_frac": {"k_retain_walk": walk_bytes / (max(kw, 1e-9) * 1e-3) / 8e12, "k_expand": exp_bytes / (max(ke, 1e-9) * 1e-3) / 8e12}},
-           "churn": churn}
+           "churn": churn, "limited": limited}
     attach_traffic(out, "c4", world)
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
@@ -1442,6 +1554,56 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
     if world > 1:
         dist.destroy_process_group()
     emit_json(out)
+
+
+def retain_limited_leg(eng, w, batch0, now_ms, np, limit=10, reps=5):
+    """RetainStoreCoProc.match(tenant, filter, limit, now) as production calls it (RS/RetainStoreCoProc.java:167-190, limit =
+    RetainMessageMatchLimit = 10, Setting.java:77): bmq_retain_match_limited for the 100 k filters of batch 0, host buffers in, the <= 10 live
+    ids per filter out -- nothing is expanded: k_retain_walk (+ k_retain_overlay on a churned index) and k_limit_select over the matched id
+    ranges.  filters/s is the wall time of the C-ABI call (upload + kernels + download); the roofline is the walk's own bytes over its time."""
+    import ctypes as C
+
+    import bifromq_amd as B
+    from bifromq_amd.engine import pinned
+
+    fdata, foff, ft = batch0
+    n = len(foff) - 1
+    lib = B._lib.lib()
+    tdata, toff = w.tenants_packed()
+    bufs = {}
+    for name, src, dt in (("t", tdata, np.uint8), ("to", toff, np.uint32), ("ft", ft, np.uint32), ("f", fdata, np.uint8), ("fo", foff, np.uint32),
+                          ("lim", np.full(n, limit, dtype=np.uint32), np.uint32)):
+        bufs[name] = pinned(len(src) + 16, dt)
+        bufs[name][:len(src)] = src
+    row, ids, cnt = pinned(n + 1, np.uint32), pinned(n * limit + 16, np.uint32), pinned(n, np.uint32)
+    need = C.c_uint64()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+    def call():
+        rc = lib.bmq_retain_match_limited(eng.h, ptr(bufs["t"]), ptr(bufs["to"]), 1, ptr(bufs["ft"]), ptr(bufs["f"]), ptr(bufs["fo"]), n, ptr(bufs["lim"]),
+                                          now_ms, ptr(row), ptr(ids), n * limit + 16, C.byref(need), ptr(cnt))
+        if rc:
+            raise RuntimeError("bmq_retain_match_limited failed: %d %s" % (rc, lib.bmq_last_error(eng.h)))
+
+    call()
+    ms, kw, kl = [], [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        call()
+        ms.append((time.perf_counter() - t0) * 1e3)
+        st = eng.stats()
+        kw.append(st.ms_walk)
+        kl.append(st.ms_expand)
+    st = eng.stats()
+    walk_bytes = st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit
+    med = float(np.median(ms))
+    return {"what": "bmq_retain_match_limited: %d filters, limit %d, now in the middle of the expiry instants; host buffers in, ids out" % (n, limit),
+            "value": n / (med * 1e-3), "unit": "filters/s", "call_ms_median": med, "call_ms": [round(x, 3) for x in ms],
+            "kernel_ms": {"k_retain_walk (+ k_retain_overlay beside it)": float(np.mean(kw)), "k_limit_select + rowptr + compact": float(np.mean(kl))},
+            "ids_returned": int(need.value), "matches_counted": int(cnt[:n].astype(np.int64).sum()),
+            "roofline": {"bound": "hbm", "kernel": "k_retain_walk", "achieved": walk_bytes / (float(np.mean(kw)) * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": walk_bytes / (float(np.mean(kw)) * 1e-3) / 8e12, "own_algorithmic_bytes_per_launch": walk_bytes,
+                         "own_bytes_rule": "len(filter) + 8 + 32 * N_visit per filter (nothing is expanded)"}}
 
 
 def retain_churn_leg(eng, w, data, off, n_topics, step, torch, np, n_ops=100_000, reps=6):

@@ -401,96 +401,114 @@ BMQ_HD uint32_t dict_intern(const DistIndexMut& ix, const LevelHash& h, uint32_t
 // taken); it is CREATED beside X whenever that slot is free.  Readers therefore never conclude anything from a free neighbour slot.
 //   Two lanes creating X/+ at once agree: slots only go from free to taken, so either both see the neighbour slot taken by another edge
 //   (both go to the hashed home, where the first-free protocol of literal edges applies) or the loser of the CAS on it finds the winner's key.
+// ONE loop, one step per iteration (a probe, a claim, a look at a slot somebody else is filling): a lane that has to wait for another
+// lane's publication goes round the SAME loop the publishing lane is in.  (A first version waited in an inner loop of its own: where the
+// compiler put that loop in front of the claiming lane's "claim, publish" block of the same wave, the waiting lane span for ever -- a wave's
+// lanes run a divergent branch one side after the other -- and the GPU build ended with ERR_STUCK; the host executor never showed it.)
 constexpr unsigned long long PARENT_IS_ROOT = ~0ull;
 BMQ_HD uint32_t trie_child(const DistIndexMut& ix, TenantSlot* ten, uint32_t base, uint32_t buckets, uint32_t parent, unsigned long long parent_slot,
                            uint32_t token, bool insert, unsigned long long& slot_abs, bool& created) {
     created = false;
     const uint64_t key = (uint64_t)parent | ((uint64_t)token << 32);
-    uint32_t spins = 0;
-    auto await_id = [&](TrieSlot* s, unsigned long long abs) -> uint32_t { // the slot holds `key`: its node id, once the claiming lane has published it
-        for (;;) {
-            const uint32_t id = atom_load(&s->node);
-            if (id != NONE) {
-                slot_abs = abs;
-                return id;
-            }
-            if (++spins > (1u << 22)) {
-                atom_or(&ix.bc->err, (uint32_t)ERR_STUCK);
-                return NONE;
-            }
-        }
-    };
     const bool root_plus = token == TOK_PLUS && parent_slot == PARENT_IS_ROOT;
     const bool try_beside = token == TOK_PLUS && parent_slot != PARENT_IS_ROOT;
-    if (root_plus) { // the root's '+' child: hashed like a literal edge, the directory entry remembers the slot
-        const uint32_t rp = atom_load(&ten->root_plus);
-        if (rp != NONE) return await_id(ix.trie + (size_t)base + rp, (unsigned long long)base + rp);
-    }
-    if (try_beside) {
-        TrieSlot* s = ix.trie + (size_t)(parent_slot ^ 1ull);
-        if (atom_load(reinterpret_cast<uint64_t*>(s)) == key) return await_id(s, parent_slot ^ 1ull);
-    }
-    // pass 0 (try_beside && insert only): a pure lookup along the hashed home's probe sequence -- the child may have been left there by a
-    // region growth --, and if it is absent: beside the parent if that slot can be claimed.  pass 1: find or insert at the hashed home.
-    for (uint32_t pass = (try_beside && insert) ? 0u : 1u; pass < 2; pass++) {
-        const bool ins = insert && pass == 1;
-        uint32_t bk = edge_bucket(parent, token, buckets), j = 0, probes = 0;
-        const uint32_t max_probes = ins && buckets > 256u ? 256u : buckets;
-        for (;;) {
-            if (probes >= max_probes || spins > (1u << 22)) {
-                if (probes >= max_probes) {
-                    if (!ins) break; // a lookup that wrapped around a full region: absent
-                    atom_or(&ten->pending, PENDING_FORCE); // the host moves the tenant into a larger region and re-runs locate
-                    atom_or(&ix.bc->err, (uint32_t)ERR_REGION_FULL);
-                } else atom_or(&ix.bc->err, (uint32_t)ERR_STUCK);
-                return NONE;
+    const unsigned long long beside_abs = parent_slot ^ 1ull; // the other slot of the parent's line (try_beside only)
+    // phase 0: the quick looks (the directory entry's reference to the root's '+' child / the slot beside the parent); 1: a pure lookup along
+    // the hashed home's probe sequence (an insert that may go beside the parent: the child may have been left at its hashed home by a
+    // region growth); 2: absent there -- claim the slot beside the parent; 3: find or insert along the hashed home's probe sequence
+    uint32_t phase = 0, spins = 0, bk = 0, j = 0, probes = 0;
+    TrieSlot* wait = nullptr; // a slot that holds `key`: its node id, once the claiming lane has published it
+    unsigned long long wait_abs = 0;
+    for (;;) {
+        if (spins > (1u << 22)) {
+            atom_or(&ix.bc->err, (uint32_t)ERR_STUCK);
+            return NONE;
+        }
+        if (wait) {
+            const uint32_t id = atom_load(&wait->node);
+            if (id == NONE) { // claimed by another lane a moment ago
+                spins++;
+                continue;
             }
-            TrieSlot* s = ix.trie + (size_t)base + 2 * (size_t)bk + j;
-            uint64_t* kp64 = reinterpret_cast<uint64_t*>(s);
-            uint64_t k = atom_load(kp64);
-            if (k == EDGE_EMPTY) {
-                if (!ins) break; // first-free placement: an edge is never stored behind a free slot of its probe sequence
-                k = atom_cas(kp64, EDGE_EMPTY, key);
-                if (k == EDGE_EMPTY) { // claimed (payload of a free slot is all zero, node = NONE): publish the node id
-                    const uint32_t id = atom_add(&ten->n_nodes, 1u) + 1u;
-                    atom_publish(&s->node, id);
-                    slot_abs = (unsigned long long)base + 2ull * bk + j;
-                    if (root_plus) atom_publish(&ten->root_plus, 2u * bk + j);
-                    created = true;
-                    return id;
-                }
-            }
-            if (k == key) {
-                const uint32_t id = atom_load(&s->node);
-                if (id == NONE) { // claimed by another lane a moment ago
-                    spins++;
+            slot_abs = wait_abs;
+            if (root_plus && atom_load(&ten->root_plus) == NONE) atom_publish(&ten->root_plus, (uint32_t)(wait_abs - base)); // (found before its creator said where)
+            return id;
+        }
+        if (phase == 0) {
+            if (root_plus) {
+                const uint32_t rp = atom_load(&ten->root_plus);
+                if (rp != NONE) {
+                    wait = ix.trie + (size_t)base + rp, wait_abs = (unsigned long long)base + rp;
                     continue;
                 }
-                slot_abs = (unsigned long long)base + 2ull * bk + j;
-                if (root_plus && atom_load(&ten->root_plus) == NONE) atom_publish(&ten->root_plus, 2u * bk + j); // (found before its creator said where)
-                return id;
             }
-            if (++j == 2) {
-                j = 0;
-                bk = (bk + 1 == buckets) ? 0 : bk + 1;
-                probes++;
+            if (try_beside && atom_load(reinterpret_cast<uint64_t*>(ix.trie + (size_t)beside_abs)) == key) {
+                wait = ix.trie + (size_t)beside_abs, wait_abs = beside_abs;
+                continue;
             }
+            phase = (try_beside && insert) ? 1u : 3u;
+            bk = edge_bucket(parent, token, buckets), j = 0, probes = 0;
+            continue;
         }
-        if (!insert) return NONE;
-        if (pass == 0) { // absent at the hashed home: beside the parent, if that slot is (still) free
-            TrieSlot* s = ix.trie + (size_t)(parent_slot ^ 1ull);
+        if (phase == 2) {
+            TrieSlot* s = ix.trie + (size_t)beside_abs;
             const uint64_t k = atom_cas(reinterpret_cast<uint64_t*>(s), EDGE_EMPTY, key);
-            if (k == EDGE_EMPTY) {
+            if (k == EDGE_EMPTY) { // claimed (payload of a free slot is all zero, node = NONE): publish the node id
                 const uint32_t id = atom_add(&ten->n_nodes, 1u) + 1u;
                 atom_publish(&s->node, id);
-                slot_abs = parent_slot ^ 1ull;
+                slot_abs = beside_abs;
                 created = true;
                 return id;
             }
-            if (k == key) return await_id(s, parent_slot ^ 1ull); // another lane put it there meanwhile
+            if (k == key) { // another lane put it there meanwhile
+                wait = s, wait_abs = beside_abs;
+                continue;
+            }
+            phase = 3; // taken by another edge: the hashed home
+            bk = edge_bucket(parent, token, buckets), j = 0, probes = 0;
+            continue;
+        }
+        // phases 1 and 3: one slot of the probe sequence
+        const bool ins = insert && phase == 3;
+        if (probes >= (ins && buckets > 256u ? 256u : buckets)) {
+            if (phase == 1) {
+                phase = 2;
+                continue;
+            }
+            if (!ins) return NONE; // a lookup that wrapped around a full region: absent
+            atom_or(&ten->pending, PENDING_FORCE); // the host moves the tenant into a larger region and re-runs locate
+            atom_or(&ix.bc->err, (uint32_t)ERR_REGION_FULL);
+            return NONE;
+        }
+        TrieSlot* s = ix.trie + (size_t)base + 2 * (size_t)bk + j;
+        uint64_t* kp64 = reinterpret_cast<uint64_t*>(s);
+        uint64_t k = atom_load(kp64);
+        if (k == EDGE_EMPTY) { // first-free placement: an edge is never stored behind a free slot of its probe sequence
+            if (phase == 1) {
+                phase = 2;
+                continue;
+            }
+            if (!ins) return NONE;
+            k = atom_cas(kp64, EDGE_EMPTY, key);
+            if (k == EDGE_EMPTY) {
+                const uint32_t id = atom_add(&ten->n_nodes, 1u) + 1u;
+                atom_publish(&s->node, id);
+                slot_abs = (unsigned long long)base + 2ull * bk + j;
+                if (root_plus) atom_publish(&ten->root_plus, 2u * bk + j);
+                created = true;
+                return id;
+            }
+        }
+        if (k == key) {
+            wait = s, wait_abs = (unsigned long long)base + 2ull * bk + j;
+            continue;
+        }
+        if (++j == 2) {
+            j = 0;
+            bk = (bk + 1 == buckets) ? 0 : bk + 1;
+            probes++;
         }
     }
-    return NONE; // (not reached: pass 1 of an insert returns from inside the loop)
 }
 
 // Levels of an escaped filter.  Calls f(level_start, len, hash, inl, is_last) for each level; f returns false to stop.

@@ -50,7 +50,7 @@ template <class Exec> class DistIndex {
         Exec& x;
         bool on;
         std::chrono::steady_clock::time_point t0;
-        explicit PhaseTimer(Exec& ex) : x(ex), on(getenv("BMQ_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+        explicit PhaseTimer(Exec& ex) : x(ex), on(bmq_env("BMQ_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
         void lap(const char* what) {
             if (!on) return;
             (void)x.sync();

@@ -218,7 +218,6 @@ struct bmq_engine {
     hipStream_t s_build = nullptr;    // the stream the next generation is built on: lowest priority, beside the match batches
     hipEvent_t ev_serving = nullptr;  // "what the serving generation was told so far": the build stream waits for it before a snapshot
     bool apply_open = false; // bmq_routes_apply_async: the batch's outcome has not been fetched yet (complete_apply)
-    bool rwalk_v1 = false;   // BMQ_RWALK_V1=1: the one-filter-per-wave walk for every batch (A/B measurements)
 };
 
 static int retain_finish(bmq_engine* e, uint64_t* out_total);
@@ -250,7 +249,7 @@ int upload(bmq_engine* e, DevBuf& b, const void* src, size_t bytes) {
 // ---- dist batch ------------------------------------------------------------------------------------------------
 // topics per k_walk / k_expand wave = 2^shift: small batches are spread over more, shorter waves (see k_walk)
 uint32_t tpw_shift_for(uint32_t n_topics) {
-    if (const char* v = getenv("BMQ_TPW_SHIFT")) return (uint32_t)std::min(6, std::max(0, atoi(v))); // profiling experiments
+    if (const char* v = bmq_env("BMQ_TPW_SHIFT")) return (uint32_t)std::min(6, std::max(0, atoi(v))); // profiling experiments
     return n_topics >= 131072 ? 6u : (n_topics >= 16384 ? 4u : 2u); // measured: profiles/r02/extras/tpw_sweep.txt (10 k topics: 0.117 / 0.092 / 0.084 ms)
 }
 
@@ -362,7 +361,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     a.sort_cap = S.sort_cap;
     a.ctr = S.b_ctr.as<Counters>();
     {
-        const char* dbg = getenv("BMQ_DEBUG");
+        const char* dbg = bmq_env("BMQ_DEBUG");
         a.debug_flags = (BMQ_EXPERIMENTS && dbg) ? (uint32_t)atoi(dbg) : 0u; // (the kernels' experiments exist in -DBMQ_EXPERIMENTS=1 builds only)
         a.dbg_wave = nullptr;
         if (a.debug_flags & 30u) {
@@ -509,7 +508,7 @@ static void print_wave_debug(bmq_engine* e, bmq_engine::BatchSlot& S) {
             const uint32_t simd_key = (h[i].w >> 4) & 0xFFFFFu & ~0xCu; // simd + cu + sh + se + xcc (pipe bits dropped)
             per_simd[simd_key].push_back({st, 1}), per_simd[simd_key].push_back({en, -1});
         }
-        if (const char* fn = getenv("BMQ_CENSUS_FILE")) { // raw records for offline analysis (tools/census.py)
+        if (const char* fn = bmq_env("BMQ_CENSUS_FILE")) { // raw records for offline analysis (tools/census.py)
             if (FILE* f = fopen(fn, "wb")) {
                 fwrite(h.data(), sizeof(uint4), a.n_blocks, f);
                 fclose(f);
@@ -735,8 +734,8 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     // either the smallest lists (192 tokens / 128 items / 128 ranges: tests force the overflow paths with them), 0 the default (512 / 176 /
     // 152: 5.0 KB of LDS per one-wave workgroup, 8 waves per SIMD).  Other values used to run the default silently: refused.
     // BMQ_WALK_GEOM picks an instantiation by number (profiling experiments).
-    if (const char* v = getenv("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
-    if (const char* v = getenv("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
+    if (const char* v = bmq_env("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
+    if (const char* v = bmq_env("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
     if ((c.wave_queue_cap != 0 && c.wave_queue_cap != 128) || (c.wave_pair_cap != 0 && c.wave_pair_cap != 128)) return BMQ_E_INVAL;
     const bool smallest = c.wave_queue_cap == 128 || c.wave_pair_cap == 128;
     c.wave_queue_cap = smallest ? 128 : 176; // (what bmq_config reports back / BatchArgs carries: the geometry in use)
@@ -746,14 +745,13 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     e->device = c.device;
     e->walk_geom = smallest ? 2 : 0;
     if (c.dedup_min_topics) e->dedup_min = c.dedup_min_topics;
-    if (const char* v = getenv("BMQ_DEDUP_MIN")) e->dedup_min = (uint32_t)strtoul(v, nullptr, 10); // profiling experiments (4294967295: never)
+    if (const char* v = bmq_env("BMQ_DEDUP_MIN")) e->dedup_min = (uint32_t)strtoul(v, nullptr, 10); // profiling experiments (4294967295: never)
     e->dedup_sorted = c.dedup_sorted != 0;
-    if (const char* v = getenv("BMQ_PUBLISH_KERNEL")) e->publish_mode = atoi(v); // profiling experiments
-    if (const char* v = getenv("BMQ_WALK_GEOM")) e->walk_geom = atoi(v);
-    if (const char* v = getenv("BMQ_WALK_MIXED")) e->mixed_on = atoi(v) != 0; // profiling experiments
+    if (const char* v = bmq_env("BMQ_PUBLISH_KERNEL")) e->publish_mode = atoi(v); // profiling experiments
+    if (const char* v = bmq_env("BMQ_WALK_GEOM")) e->walk_geom = atoi(v);
+    if (const char* v = bmq_env("BMQ_WALK_MIXED")) e->mixed_on = atoi(v) != 0; // profiling experiments
     e->kernel_events = c.kernel_timing != 0;
-    if (const char* v = getenv("BMQ_KERNEL_EVENTS")) e->kernel_events = atoi(v) != 0; // profiling experiments
-    if (const char* v = getenv("BMQ_RWALK_V1")) e->rwalk_v1 = atoi(v) != 0;             // profiling experiments
+    if (const char* v = bmq_env("BMQ_KERNEL_EVENTS")) e->kernel_events = atoi(v) != 0; // profiling experiments
     if (c.device >= 0) {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || c.device >= n) return BMQ_E_NODEVICE;

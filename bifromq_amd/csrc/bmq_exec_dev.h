@@ -365,7 +365,7 @@ struct DevExec {
     }
     bool fo_fast(const DistIndexMut& ix, const FanoutState& st, const FanoutFast& f) {
         const dim3 grid((f.n_tiles + FO_WAVES - 1) / FO_WAVES), block(FO_WAVES * 64);
-        static const bool timing = getenv("BMQ_TIMING") != nullptr; // profiling experiments only: per-kernel HIP-event times on stderr
+        static const bool timing = bmq_env("BMQ_TIMING") != nullptr; // profiling experiments only: per-kernel HIP-event times on stderr
         hipEvent_t ev[5] = {};
         if (timing)
             for (auto& e : ev) (void)hipEventCreate(&e);

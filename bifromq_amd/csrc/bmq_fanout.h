@@ -136,7 +136,7 @@ private:
 
     static uint32_t fast_tile() { // BMQ_FO_TILE: experiments only
         static const uint32_t t = [] {
-            const char* v = getenv("BMQ_FO_TILE");
+            const char* v = bmq_env("BMQ_FO_TILE");
             const long n = v ? atol(v) : 0;
             return n >= 64 && n <= 2048 ? (uint32_t)(n / 64 * 64) : FO_TILE;
         }();

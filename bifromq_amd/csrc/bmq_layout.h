@@ -23,6 +23,15 @@
 // next bmq_rebuild; per id the key store holds (offset, length) of the key bytes and a hash of the key's tail.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
+
+// Environment switches (profiling experiments: kernel geometry, debug clocks, phase timers ...) exist in -DBMQ_EXPERIMENTS=1 builds only
+// (tools/build_variant.sh): in the library that ships bmq_config is the ONLY switch -- a broker's environment cannot change which kernel
+// runs ("the shipped kernel is the measured kernel").
+#ifndef BMQ_EXPERIMENTS
+#define BMQ_EXPERIMENTS 0
+#endif
+inline const char* bmq_env(const char* name) { return BMQ_EXPERIMENTS ? getenv(name) : nullptr; }
 
 #if defined(__HIP__)
 #include <hip/hip_runtime.h>

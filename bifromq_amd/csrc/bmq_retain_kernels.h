@@ -525,9 +525,8 @@ __device__ __forceinline__ void retain_walk_body(const RetainArgs& r, const Batc
     }
 }
 
-// one filter per wave: the walk of the filters k_retain_walk lists (more than RW_LV levels: DEEP) and, until the overlay trie has its own
-// kernel, of every filter once topics were added since the bulk load (v1: the round-2..4 kernel)
-__global__ __launch_bounds__(64) void k_retain_walk_v1(RetainArgs r, BatchArgs a) { retain_walk_body<false>(r, a); }
+// one filter per wave: the walk of the filters k_retain_walk lists (more than RW_LV levels: DEEP) and of the overlay trie (OVONLY).  (The
+// round-2..4 instantiation that walked both tries for every filter -- k_retain_walk_v1 -- is gone: round 6.)
 __global__ __launch_bounds__(64) void k_retain_walk_deep(RetainArgs r, BatchArgs a) { retain_walk_body<true>(r, a); }
 __global__ __launch_bounds__(64) void k_retain_overlay(RetainArgs r, BatchArgs a) { retain_walk_body<false, true>(r, a); }
 
@@ -563,45 +562,53 @@ __global__ __launch_bounds__(64) void k_retain_sums(BatchArgs a, RetainOvList ov
 // met.  With the default limit of 10 (Setting.java:77) a filter matching 5000 topics touches ~10 ids instead of 5000.
 // ------------------------------------------------------------------------------------------------------------
 constexpr uint32_t LIM_FAST = 64; // per-filter limits up to this go through k_limit_select; larger ones through the full CSR
-__global__ __launch_bounds__(64) void k_limit_select(BatchArgs a, const uint32_t* limit, const unsigned long long* expire_at,
+// Round 6: TWO range lists per filter -- the walk of the bulk-loaded index leaves one (BatchArgs), the overlay's walk, once topics were
+// added since the load, another (RetainOvList) -- taken one after the other: overlay ids lie above every bulk-loaded id, so "ascending
+// topic id" is the first list, then the second.  (Rounds 2-5 read ONE list, and match(limit, now) on an index with an overlay therefore
+// ran the retired one-filter-per-wave walk that filled one list from both tries: k_retain_walk_v1, gone.)
+__global__ __launch_bounds__(64) void k_limit_select(BatchArgs a, RetainOvList ov, const uint32_t* limit, const unsigned long long* expire_at,
                                                      unsigned long long now, uint32_t n, uint32_t* tmp_ids, uint32_t* kept, uint32_t* counts) {
     const uint32_t lane = threadIdx.x;
-    const bool blocked = (a.ctr->status & (ST_NEED_PAIRS | ST_RETAIN_FRONT | ST_RETAIN_LIST | ST_RETAIN_DEEP)) != 0; // the walk is re-run anyway
+    const bool blocked = (a.ctr->status & (ST_NEED_PAIRS | ST_NEED_SPILL | ST_RETAIN_FRONT | ST_RETAIN_LIST | ST_RETAIN_DEEP)) != 0; // the walk is re-run anyway
     for (uint32_t f = blockIdx.x; f < n; f += gridDim.x) {
-        const uint32_t po = a.pair_off[f], np = blocked ? 0u : a.pair_cnt[f];
         const uint32_t lim = min(limit[f], LIM_FAST);
-        uint32_t taken = 0, cursor = 0;
-        while (taken < lim) {
-            uint32_t bb = 0xFFFFFFFFu, bc = 0;
-            for (uint32_t k = lane; k < np; k += 64) {
-                const MatchRange r = a.pairs[po + k];
-                if (r.begin >= cursor && r.begin < bb && r.count) {
-                    bb = r.begin;
-                    bc = r.count;
+        uint32_t taken = 0;
+        for (uint32_t list = 0; list < (ov.pairs ? 2u : 1u) && taken < lim; list++) {
+            const MatchRange* const pairs = list ? ov.pairs : a.pairs;
+            const uint32_t po = list ? ov.pair_off[f] : a.pair_off[f], np = blocked ? 0u : (list ? ov.pair_cnt[f] : a.pair_cnt[f]);
+            uint32_t cursor = 0;
+            while (taken < lim) {
+                uint32_t bb = 0xFFFFFFFFu, bc = 0;
+                for (uint32_t k = lane; k < np; k += 64) {
+                    const MatchRange r = pairs[po + k];
+                    if (r.begin >= cursor && r.begin < bb && r.count) {
+                        bb = r.begin;
+                        bc = r.count;
+                    }
                 }
-            }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const uint32_t ob = __shfl_xor(bb, d), oc = __shfl_xor(bc, d);
-                if (ob < bb) {
-                    bb = ob;
-                    bc = oc;
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint32_t ob = __shfl_xor(bb, d), oc = __shfl_xor(bc, d);
+                    if (ob < bb) {
+                        bb = ob;
+                        bc = oc;
+                    }
                 }
+                if (bb == 0xFFFFFFFFu) break;
+                for (uint32_t o = 0; o < bc && taken < lim; o += 64) {
+                    const uint32_t id = bb + o + lane;
+                    const bool live = o + lane < bc && expire_at[id] > now;
+                    const unsigned long long m = __ballot(live);
+                    const uint32_t slot = taken + rank_below(m);
+                    if (live && slot < lim) tmp_ids[(size_t)f * LIM_FAST + slot] = id;
+                    taken = min(lim, taken + (uint32_t)__popcll(m));
+                }
+                cursor = bb + bc; // ranges of one filter are disjoint intervals
             }
-            if (bb == 0xFFFFFFFFu) break;
-            for (uint32_t o = 0; o < bc && taken < lim; o += 64) {
-                const uint32_t id = bb + o + lane;
-                const bool live = o + lane < bc && expire_at[id] > now;
-                const unsigned long long m = __ballot(live);
-                const uint32_t slot = taken + rank_below(m);
-                if (live && slot < lim) tmp_ids[(size_t)f * LIM_FAST + slot] = id;
-                taken = min(lim, taken + (uint32_t)__popcll(m));
-            }
-            cursor = bb + bc; // ranges of one filter are disjoint intervals
         }
         if (lane == 0) {
             kept[f] = taken;
-            counts[f] = blocked ? 0u : a.route_cnt[f];
+            counts[f] = blocked ? 0u : a.route_cnt[f] + (ov.route_cnt ? ov.route_cnt[f] : 0u);
         }
     }
 }

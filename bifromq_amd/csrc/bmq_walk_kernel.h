@@ -49,7 +49,10 @@ template <int TC, int QC, int PC, bool MIXED> struct WalkLds { // byte offsets i
     static constexpr uint32_t ALLOC = (BYTES + 511) & ~511u;
     // (the MIXED instantiation carries 64-bit addresses and per-topic regions through the loop: at more than 5 waves -- <= 96 VGPRs --
     // the compiler spills 50-80 registers to scratch)
-    static constexpr uint32_t WAVES_LDS = (163840 / ALLOC) / 4 > 8 ? 8 : (163840 / ALLOC) / 4;
+#ifndef BMQ_WALK_MAX_WAVES
+#define BMQ_WALK_MAX_WAVES 8 // (variant builds: tools/build_variant.sh w7 -DBMQ_WALK_MAX_WAVES=7 gives the compiler 72 vector registers)
+#endif
+    static constexpr uint32_t WAVES_LDS = (163840 / ALLOC) / 4 > BMQ_WALK_MAX_WAVES ? BMQ_WALK_MAX_WAVES : (163840 / ALLOC) / 4;
     static constexpr uint32_t WAVES = MIXED && WAVES_LDS > 5 ? 5 : WAVES_LDS;
     static_assert(3 * 64 * 4 <= STK && PC % 8 == 0 && QC % 8 == 0 && STK % 16 == 0 && WAVES >= 1 && TC >= 2 * FAST_LEVELS && TC <= 1023, "layout");
     static_assert(FAST_LEVELS <= 32, "walk_meta keeps the levels behind an item in 5 bits");

@@ -144,6 +144,7 @@ extern "C" int bmq_match_wait_dev(bmq_engine*, int ticket, uint64_t* out_total) 
 }
 
 #define BMQ_BATCHER_INITIAL_IDS 4
+static const char* bmq_env(const char* name) { return getenv(name); } // (the library's: bmq_layout.h -- environment switches are experiment builds' only)
 #include "../bifromq_amd/csrc/bmq_batcher.inc"
 
 static std::atomic<int> g_fail{0};
