@@ -653,8 +653,15 @@ BMQ_HD void bulk_counts_one(const OpBatch& ob, uint32_t t, uint32_t n_ten, const
 // including what a put of the SAME batch in front of them created: one pass over both would let a delete's lane run ahead of the put's and
 // drop the delete as "no such filter"; found by replaying merged mutation batches into the next generation, round 5), phase 2: every op
 // (bulk loads and batches without deletes).
+// Round 6 -- the same guarantee for half the price: phase 3 = EVERY op in one pass, a delete that does not find its filter is not dropped
+// but marked TARGET_RETRY; phase 4 = the marked deletes once more, behind the kernel boundary that makes every put of the batch visible.
+// A delete that found its filter in phase 3 found what phase 1 would have found (nodes are never removed); in the common batch -- unsubscribes
+// of filters that exist -- phase 4 finds nothing to do (round 5: two full passes of ~60 us each over a 100 k-op batch).
+constexpr unsigned long long TARGET_RETRY = ~0ull - 1;
 BMQ_HD void locate_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t i, uint32_t phase) {
-    if (phase != 2 && (!ob.op || ob.op[i] == 0) != (phase == 0)) return;
+    if (phase == 4) {
+        if (ob.target[i] != TARGET_RETRY) return;
+    } else if (phase < 2 && (!ob.op || ob.op[i] == 0) != (phase == 0)) return;
     ob.target[i] = TARGET_NONE;
     uint32_t d = ob.dir_slot[i];
     if (ob.bulk) d = ob.bt_dir[d];
@@ -699,7 +706,10 @@ BMQ_HD void locate_one(const DistIndexMut& ix, const OpBatch& ob, uint32_t i, ui
         at_root = false;
         return true;
     });
-    if (!ok) return;
+    if (!ok) {
+        if (phase == 3 && !is_put) ob.target[i] = TARGET_RETRY; // (a put of this batch may be creating the filter right now)
+        return;
+    }
     if (at_root && !is_hash) return; // cannot happen: a filter has at least one level
     // the filter "#" hangs off the tenant root (directory entry); every other filter off its node's slot
     ob.target[i] = at_root ? make_target(2, d) : make_target(is_hash ? 1 : 0, slot_abs);
@@ -725,17 +735,27 @@ struct IdSet {
 BMQ_HD uint32_t idset_at(const DistIndexMut& ix, const IdSet& s, uint32_t m) { return s.indirect() ? ix.route_pos[s.begin + m] : s.begin + m; }
 
 // position of the member whose key tail equals key `k`'s, or NONE
+// (Eight members per step: their ids and tail hashes are requested together -- one memory latency per eight members instead of two per
+// member.  A group lane is alone on its chain of dependent reads, the builder's kernels run at 1-2 waves per SIMD, and a filter with a few
+// hundred routes made its lane the one the whole k_b_group launch waited for.)
 BMQ_HD uint32_t idset_find_key(const DistIndexMut& ix, const IdSet& s, const KeyView& k, uint32_t th) {
     const uint32_t n = s.count();
     const unsigned long long tl = k.end - k.tail;
-    for (uint32_t m = 0; m < n; m++) {
-        const uint32_t id = idset_at(ix, s, m);
-        if (ix.khash[id] != th) continue;
-        const unsigned long long r = ix.kref[id];
-        const unsigned long long off = r & KREF_OFF_MASK, len = r >> KREF_LEN_SHIFT;
-        if (len < tl) continue;
-        // same filter node => same tenant + levels; the keys are equal iff their tails are
-        if (pool_bytes_equal(ix.kpool, off + len - tl, k.tail, tl)) return m;
+    for (uint32_t m0 = 0; m0 < n; m0 += 8) {
+        uint32_t id[8], h[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) id[j] = m0 + j < n ? idset_at(ix, s, m0 + j) : NONE;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) h[j] = id[j] != NONE ? ix.khash[id[j]] : ~th;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            if (h[j] != th) continue;
+            const unsigned long long r = ix.kref[id[j]];
+            const unsigned long long off = r & KREF_OFF_MASK, len = r >> KREF_LEN_SHIFT;
+            if (len < tl) continue;
+            // same filter node => same tenant + levels; the keys are equal iff their tails are
+            if (pool_bytes_equal(ix.kpool, off + len - tl, k.tail, tl)) return m0 + j;
+        }
     }
     return NONE;
 }

@@ -289,8 +289,8 @@ struct DevExec {
             hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, 2u);
             return launched();
         }
-        hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, 0u); // the puts: filter nodes come into being
-        hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, 1u); // the deletes: they find them
+        hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, 3u); // every op; a delete that finds no filter is marked
+        hipLaunchKernelGGL(k_b_locate, grid(ob.n, BK), dim3(BK), 0, stream, ix, ob, 4u); // the marked deletes, behind every put of the batch
         return launched();
     }
     bool sort_targets(const OpBatch& ob) { // stable: ops on one target stay in op order.  Values = op indices.

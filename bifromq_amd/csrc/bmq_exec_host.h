@@ -101,8 +101,8 @@ struct HostExec {
             par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i, 2u); });
             return true;
         }
-        par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i, 0u); });
-        par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i, 1u); });
+        par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i, 3u); }); // every op; a delete that finds no filter is marked
+        par(ob.n, [&](size_t i) { locate_one(ix, ob, (uint32_t)i, 4u); }); // the marked deletes, behind every put of the batch
         return true;
     }
     bool sort_targets(const OpBatch& ob) {
