@@ -497,13 +497,28 @@ def main():
         hdata, hoff, htt = batches[0][3]
         m = min(args.batcher_topics, n)
         sub = (hdata, hoff[:m + 1].copy())
+        # the same calls twice: generations launched one by one (rounds 2-5), then through the persistent matcher (round 6: resident waves
+        # poll a request ring, bmq_poll_kernel.h) -- the default; `calls_per_s` is the default's
+        eng.poller_control(eng.POLLER_DISABLE)
+        bt = eng.batcher()
+        cnt0, hsh0, sec0 = bt.drive_singletons(w.tenants(), htt[:m], sub, args.batcher_threads)
+        bs0 = bt.stats()
+        bt.close()
+        eng.poller_control(eng.POLLER_ENABLE)
+        p0 = eng.poller_stats()
         bt = eng.batcher()
         cnt, hsh, sec = bt.drive_singletons(w.tenants(), htt[:m], sub, args.batcher_threads)
         bs = bt.stats()
+        p1 = eng.poller_stats()
         out["batching_front"] = {"threads": args.batcher_threads, "host_cpus_granted": effective_cpus(), "single_topic_calls": m, "calls_per_s": m / sec,
                                  "launches": int(bs.n_batches), "mean_topics_per_launch": bs.n_topics / max(1, bs.n_batches),
                                  "max_topics_per_launch": int(bs.max_batch_topics), "ids_returned": int(cnt.sum()),
-                                 "note": "bmq_batcher_match_all, blocking callers: a launch holds at most one topic per thread"}
+                                 "persistent_matcher": {"generations_served": int(p1.n_served - p0.n_served), "handed_back_or_unserved": int(p1.n_fallback - p0.n_fallback),
+                                                        "k_poll_launches": int(p1.n_starts - p0.n_starts), "timeouts": int(p1.n_timeouts)},
+                                 "with_a_launch_per_generation": {"calls_per_s": m / sec0, "launches": int(bs0.n_batches),
+                                                                  "mean_topics_per_launch": bs0.n_topics / max(1, bs0.n_batches),
+                                                                  "same_rows": bool((cnt0 == cnt).all() and (hsh0 == hsh).all())},
+                                 "note": "bmq_batcher_match_all, blocking callers: a generation holds at most one topic per thread"}
         bt.close()
         bt = eng.batcher()  # asynchronous side: 4 submitting threads, nobody blocks on the GPU
         cnt2, hsh2, sec2 = bt.drive_singletons(w.tenants(), htt[:m], sub, 4, asynchronous=True)

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired", "bmq_retain_apply_batch", "bmq_retain_compact", "bmq_retain_info_get",
     "bmq_retain_live_ids", "bmq_retain_topics",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
-    "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get",
+    "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get", "bmq_poller_stats_get", "bmq_poller_control",
     "bmq_route_cache_create", "bmq_route_cache_destroy", "bmq_route_cache_get", "bmq_route_cache_get_async", "bmq_route_cache_get_batch", "bmq_batcher_match_batch", "bmq_route_cache_is_cached", "bmq_route_cache_apply",
     "bmq_route_cache_rebuild", "bmq_route_cache_reset", "bmq_route_cache_expire", "bmq_route_cache_stats_get", "bmq_route_cache_tenant_stats_get",
     "bmq_route_cache_set_caps", "bmq_route_cache_set_event_sink", "bmq_routes_cap", "bmq_fanout_group", "bmq_fanout_group_dev", "bmq_router_find_by_key", "bmq_router_find_by_boundary", "bmq_retain_range_lookup", "bmq_router_create", "bmq_router_destroy", "bmq_router_lookup_key", "bmq_router_lookup_boundary", "bmq_router_retain_lookup",
@@ -68,6 +68,11 @@ class BatcherConfig(C.Structure):
 class BatcherStats(C.Structure):
     _fields_ = [("n_requests", C.c_uint64), ("n_topics", C.c_uint64), ("n_batches", C.c_uint64),
                 ("max_batch_topics", C.c_uint64), ("n_deduped", C.c_uint64)]
+
+
+class PollerStats(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("running", C.c_uint32), ("n_starts", C.c_uint64), ("n_served", C.c_uint64), ("n_fallback", C.c_uint64),
+                ("n_unserved", C.c_uint64), ("n_timeouts", C.c_uint64)]
 
 
 class RouteCacheConfig(C.Structure):
@@ -180,6 +185,8 @@ def lib() -> C.CDLL:
             "bmq_batcher_match_all": (C.c_int, [vp, C.c_char_p, u32, vp, vp, u32, vp, vp, u64, P(u64), P(u64)]),
             "bmq_batcher_submit": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32, vp, vp]),
             "bmq_batcher_stats_get": (C.c_int, [vp, P(BatcherStats)]),
+            "bmq_poller_stats_get": (C.c_int, [vp, P(PollerStats)]),
+            "bmq_poller_control": (C.c_int, [vp, C.c_int]),
             "bmq_route_cache_create": (C.c_int, [vp, vp, P(RouteCacheConfig), P(vp)]),
             "bmq_route_cache_destroy": (None, [vp]),
             "bmq_route_cache_get": (C.c_int, [vp, C.c_char_p, u32, C.c_char_p, u32, u64, vp, u32, P(u32), P(u64)]),

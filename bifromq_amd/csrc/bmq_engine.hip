@@ -24,6 +24,7 @@
 #include "bmq_codec.h"
 #include "bmq_dist_index.h"
 #include "bmq_dist_kernels.h"
+#include "bmq_poll_kernel.h"
 #include "bmq_exec_dev.h"
 #include "bmq_exec_host.h"
 #include "bmq_fanout.h"
@@ -218,9 +219,26 @@ struct bmq_engine {
     hipStream_t s_build = nullptr;    // the stream the next generation is built on: lowest priority, beside the match batches
     hipEvent_t ev_serving = nullptr;  // "what the serving generation was told so far": the build stream waits for it before a snapshot
     bool apply_open = false; // bmq_routes_apply_async: the batch's outcome has not been fetched yet (complete_apply)
+    // the persistent matcher of the batching front (bmq_poll_kernel.h, bmq_poller.inc)
+    struct Poller {
+        bool enabled = true;   // bmq_batcher_config.persistent_matcher
+        bool running = false;  // k_poll was launched and has not been waited for (guarded by mu, like everything here but the ring words)
+        bool broken = false;   // a generation timed out: never started again on this engine
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_index = nullptr; // "the index is complete": recorded on the engine stream, waited for by the poller's
+        PollDesc* desc = nullptr; // page-locked, POLL_SLOTS
+        PollDone* done = nullptr;
+        PollCtl* ctl = nullptr;
+        DevBuf scratch;           // every per-wave array of PollArgs, one allocation
+        PollArgs args{};
+        bool busy[POLL_SLOTS] = {};
+        uint32_t rr = 0;          // slot hand-out: round robin over the waves
+        uint64_t n_served = 0, n_fallback = 0, n_timeouts = 0, n_starts = 0, n_unserved = 0;
+    } pol;
 };
 
 static int retain_finish(bmq_engine* e, uint64_t* out_total);
+static void poller_stop_locked(bmq_engine* e);
 extern "C" void bmq_comm_destroy(bmq_engine* e);
 
 static int complete_apply(bmq_engine* e); // (defined behind the index helpers below)
@@ -790,6 +808,13 @@ void bmq_engine_destroy(bmq_engine* e) {
     if (!e) return;
     if (e->device >= 0) {
         (void)hipSetDevice(e->device);
+        poller_stop_locked(e);
+        if (e->pol.stream) (void)hipStreamDestroy(e->pol.stream);
+        if (e->pol.ev_index) (void)hipEventDestroy(e->pol.ev_index);
+        if (e->pol.desc) (void)hipHostFree(e->pol.desc);
+        if (e->pol.done) (void)hipHostFree(e->pol.done);
+        if (e->pol.ctl) (void)hipHostFree(e->pol.ctl);
+        e->pol.scratch.release();
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         if (e->s_in) (void)hipStreamSynchronize(e->s_in);
         if (e->s_out) (void)hipStreamSynchronize(e->s_out);
@@ -836,6 +861,7 @@ int bmq_rebuild(bmq_engine* e, const uint8_t* keys, const uint32_t* key_off, uin
     if (e->cmp.active) return set_err(e, BMQ_E_STATE, "a compaction is running: bmq_compact_swap or bmq_compact_abort first");
     if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    poller_stop_locked(e); // (the persistent matcher reads the index: it leaves before the index changes)
     static const uint32_t zero_off[1] = {0};
     static const uint8_t no_bytes[16] = {0};
     e->built = false;
@@ -860,6 +886,7 @@ int bmq_compact(bmq_engine* e) {
     for (auto& sl : e->slots)
         if (sl.pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: finish / wait for it first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    poller_stop_locked(e);
     const bool ok = with_index(e, [&](auto& ix) {
         const bool r = ix.compact();
         if (!r) e->err = ix.error;
@@ -883,6 +910,7 @@ static int routes_apply_common(bmq_engine* e, const uint8_t* keys, const uint32_
     // caller-driven *_dev protocol (results read by the caller between launch and finish) excludes a mutation in between
     if (e->cur->pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: call bmq_match_finish first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    poller_stop_locked(e); // (the persistent matcher reads the index: it leaves before the builder kernels are enqueued)
     bool bad_input = false;
     const bool ok = with_index(e, [&](auto& ix) {
         const bool r = ix.apply_begin(keys, key_off, op, n);
@@ -1034,6 +1062,7 @@ int bmq_compact_swap(bmq_engine* e, uint64_t* out_carried, uint64_t* out_replaye
     for (auto& sl : e->slots)
         if (sl.pending) return set_err(e, BMQ_E_STATE, "a batch is in flight: finish / wait for it first");
     if (e->device >= 0) HIPCHK(e, hipSetDevice(e->device));
+    poller_stop_locked(e); // (the generations change places below)
     if (int rc = replay_log(e, 0)) return rc; // what the serving generation was told since bmq_compact_begin, in order
     if (e->dix) {
         HIPCHK(e, hipStreamSynchronize(e->s_build));
@@ -1756,6 +1785,7 @@ int32_t bmq_java_string_hash(const uint8_t* utf8, uint32_t len) { return java_st
 } // extern "C"
 
 #include "bmq_retain_engine.inc"
+#include "bmq_poller.inc"
 #include "bmq_batcher.inc"
 #include "bmq_range_engine.inc"
 #include "bmq_exchange.inc"

@@ -98,7 +98,9 @@ __device__ __forceinline__ unsigned long long wave_total_u64(unsigned long long 
     return ((unsigned long long)read_lane((uint32_t)(v >> 32), 63) << 32) | read_lane((uint32_t)v, 63);
 }
 
-__global__ __launch_bounds__(64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) {
+// The body of k_expand as a function of (argument block, block index): the kernel below is this and nothing else; the persistent matcher of
+// the batching front (k_poll, bmq_poll_kernel.h) runs the same code behind its walk.
+__device__ __forceinline__ void expand_wave(const BatchArgs& a, const uint32_t block_x) {
     __shared__ uint32_t s_begin[EXP_K], s_cnt[EXP_K];
     __shared__ uint32_t s_delta[EXP_K + 4]; // order step: first id of every range | then, per SHORT range in order: first id (or route_pos index) - its
                                         // start in the short space; from the top down, per other range in order: its offset in the pass's output
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) {
     __shared__ uint8_t nz[64];                            // the rows that have ranges, in order
     uint32_t* const s_key = s_delta;
     const uint32_t lane = threadIdx.x;
-    const uint32_t blk = blockIdx.x; // every wave owns one block of 2^tpw_shift rows
+    const uint32_t blk = block_x; // every wave owns one block of 2^tpw_shift rows
     if (blk >= a.n_blocks) return;
     const uint32_t t = (blk << a.tpw_shift) + lane;
     const bool valid = lane < (1u << a.tpw_shift) && t < a.n_topics;
@@ -496,5 +498,7 @@ __global__ __launch_bounds__(64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) {
         else atomicOr(&a.ctr->status, ST_NEED_SORTLIST);
     }
 }
+
+__global__ __launch_bounds__(64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) { expand_wave(a, blockIdx.x); }
 
 } // namespace bmq

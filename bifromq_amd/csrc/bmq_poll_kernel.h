@@ -1,0 +1,196 @@
+// bmq_poll_kernel.h -- k_poll: the PERSISTENT matcher of the batching front (bmq_batcher.inc).
+//
+// Production asks for one topic per call (TenantRouteCache.java:180-193: one matchAll(singleton(topic)) per cache miss from the
+// matchExecutor pool, DW/DistWorkerCoProcFactory.java:74-88); the batching front collects what is missing right now into a generation of a
+// few dozen topics.  Up to round 5 every generation was a LAUNCH (k_walk + k_expand + the counters' way back + an event to wait for):
+// 58-67 us for 1-256 topics, of which the kernels are a few -- the rest is launch and completion latency.  k_poll takes the launch out:
+// a handful of one-wave workgroups stay resident and poll a ring of request descriptors in page-locked host memory; the leader of a
+// generation fills the slot's input blob (in place, as before), writes the descriptor and rings the doorbell (a sequence number); the wave
+// that owns the slot runs walk_wave<MIXED> and expand_wave -- the very code of k_walk and k_expand -- on it, writes the CSR in place into the
+// slot's page-locked output blob and publishes the sequence number in the slot's completion word, which the leader spins on.
+//
+// What keeps this safe:
+//   * the index is IMMUTABLE while the poller runs.  Every entry point that changes index memory (bmq_rebuild, bmq_routes_apply[_async],
+//     bmq_compact*, destroy) stops the poller first (exit flag + stream synchronisation, bmq_poller.inc) and it is started again by the next
+//     generation that wants it: kernel boundaries stay the only fences between index writers and readers, as everywhere in this engine;
+//   * its lifetime is bounded three ways: an exit flag the host raises, an idle limit (no doorbell for POLL_IDLE_TICKS) and a hard limit
+//     (POLL_LIFE_TICKS) -- a poller nobody talks to leaves the GPU by itself, a wedged one cannot hold it (the host falls back to launches);
+//   * a generation the wave cannot finish by itself (a topic deeper than FAST_LEVELS, a buffer of the wave too small, rows that need the
+//     sort fix-up) is handed back with POLL_FALLBACK: the leader launches it the old way.  Rare by construction (generations are small).
+#pragma once
+
+namespace bmq {
+
+constexpr uint32_t POLL_SLOTS = 16;       // ring slots = generations that can be in the ring at once
+constexpr uint32_t POLL_WAVES = 8;        // resident one-wave workgroups; wave w serves the slots s with s % POLL_WAVES == w
+constexpr uint32_t POLL_MAX_TOPICS = 64;  // one wave's worth (larger generations are launches: the chip is the better place for them)
+constexpr unsigned long long POLL_TICK_HZ = 100000000ull;          // s_memtime counts the 100 MHz reference clock
+constexpr unsigned long long POLL_IDLE_TICKS = POLL_TICK_HZ / 50;  // 20 ms without a doorbell: leave (the next generation starts a new one)
+constexpr unsigned long long POLL_LIFE_TICKS = POLL_TICK_HZ * 2;   // 2 s: leave whatever happens
+enum : uint32_t { POLL_OK = 0, POLL_FALLBACK = 1 };
+
+struct alignas(64) PollDesc { // host -> device, one per slot, page-locked host memory
+    const uint8_t* tenants;
+    const uint32_t* tenant_off;
+    const uint32_t* topic_tenant;
+    const uint8_t* topics;
+    const uint32_t* topic_off;
+    uint32_t* out_row_ptr;
+    uint32_t* out_ids;
+    unsigned long long out_capacity;
+    unsigned long long* out_total;
+    uint32_t n_tenants, n_topics;
+    uint32_t seq;  // the doorbell, written LAST: served + 1
+    uint32_t pad[3];
+};
+struct alignas(64) PollDone { // device -> host, one per slot, page-locked host memory
+    unsigned long long total, n_visit, n_ranges, topic_bytes;
+    uint32_t status;      // POLL_OK / POLL_FALLBACK
+    uint32_t batch_status; // Counters.status of the generation (ST_NOSPACE, ST_RANGE: the leader's business)
+    uint32_t seq;         // written LAST: the generation with this sequence number is complete
+    uint32_t pad[5];
+};
+struct alignas(64) PollCtl { // page-locked host memory
+    uint32_t exit;        // host -> device: leave after the generation in hand
+    uint32_t ignore;      // host -> device (test hook): doorbells are not answered -- the leader's time-out path
+    uint32_t exited;      // device -> host: waves that have left (a poller with exited != 0 is not handed anything any more)
+    uint32_t served;      // device -> host: generations served by this launch (statistics)
+};
+
+struct PollArgs {
+    DistIndexView ix;
+    const PollDesc* desc;
+    PollDone* done;
+    PollCtl* ctl;
+    // per-wave scratch in device memory, [POLL_WAVES] pieces each
+    uint32_t* pair_off;   // [64] per wave
+    uint32_t* pair_cnt;
+    uint32_t* route_cnt;
+    MatchRange* pairs;    // pair_cap per wave
+    unsigned long long pair_cap;
+    SubAlloc* subs;       // 2 * N_SUB per wave
+    unsigned long long* super_sums; // SUPER_STRIDE per wave
+    uint4* blk_stats;     // 1 per wave
+    uint4* spill;         // spill_cap per wave
+    unsigned long long spill_cap;
+    unsigned long long* wave_sums; // 1 per wave
+    uint32_t* slow_list;  // 64 per wave
+    uint32_t* sort_list;  // 64 per wave
+    Counters* ctr;        // 1 per wave
+};
+
+#ifndef BMQ_WAVE_EMU
+// host memory, system scope, around every cache: the doorbells and the control words
+__device__ __forceinline__ uint32_t poll_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void poll_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+using PollGeom = WalkLds<512, 176, 152, true>; // the MIXED instantiation: a generation holds requests of any tenants, in arrival order
+
+__global__ __launch_bounds__(64) void k_poll(PollArgs p) {
+    __shared__ __align__(16) uint32_t lds[PollGeom::BYTES / 4];
+    const uint32_t w = blockIdx.x, lane = threadIdx.x;
+    constexpr uint32_t OWN = POLL_SLOTS / POLL_WAVES;
+    static_assert(POLL_SLOTS % POLL_WAVES == 0, "every wave owns the same number of slots");
+    uint32_t served[OWN];
+#pragma unroll
+    for (uint32_t k = 0; k < OWN; k++) served[k] = sgpr(poll_load(&p.done[w + k * POLL_WAVES].seq)); // where the last launch left off
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t_work = t0;
+    uint32_t n_served = 0;
+    Counters* const ctr = p.ctr + w;
+    SubAlloc* const subs = p.subs + (size_t)w * 2 * N_SUB;
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (uint32_t k = 0; k < OWN; k++) {
+            const uint32_t s = w + k * POLL_WAVES;
+            const PollDesc* const d = p.desc + s;
+            const uint32_t seq = sgpr(poll_load(&d->seq));
+            if (seq != served[k] + 1u || sgpr(poll_load(&p.ctl->ignore)) != 0u) continue;
+            any = true;
+            // ---- the generation's argument block: what launch_dist fills for a launch, from the descriptor and this wave's scratch ----
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the descriptor behind the doorbell; the scratch this wave wrote a generation ago)
+            BatchArgs a{};
+            a.ix = p.ix;
+            {
+                const unsigned long long* q = reinterpret_cast<const unsigned long long*>(d);
+                unsigned long long v[9];
+#pragma unroll
+                for (uint32_t i = 0; i < 9; i++) {
+                    const unsigned long long x = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    v[i] = ((unsigned long long)sgpr((uint32_t)(x >> 32)) << 32) | sgpr((uint32_t)x);
+                }
+                a.tenants = reinterpret_cast<const uint8_t*>(v[0]);
+                a.tenant_off = reinterpret_cast<const uint32_t*>(v[1]);
+                a.topic_tenant = reinterpret_cast<const uint32_t*>(v[2]);
+                a.topics = reinterpret_cast<const uint8_t*>(v[3]);
+                a.topic_off = reinterpret_cast<const uint32_t*>(v[4]);
+                a.out_row_ptr = reinterpret_cast<uint32_t*>(v[5]);
+                a.out_ids = reinterpret_cast<uint32_t*>(v[6]);
+                a.out_capacity = v[7];
+                a.out_total = reinterpret_cast<unsigned long long*>(v[8]);
+            }
+            a.n_tenants = sgpr(poll_load(&d->n_tenants));
+            a.n_topics = min(sgpr(poll_load(&d->n_topics)), POLL_MAX_TOPICS);
+            a.pair_off = p.pair_off + w * 64u, a.pair_cnt = p.pair_cnt + w * 64u, a.route_cnt = p.route_cnt + w * 64u;
+            a.pairs = p.pairs + (size_t)w * p.pair_cap, a.pair_cap = p.pair_cap;
+            a.subs = subs;
+            a.super_sums = p.super_sums + (size_t)w * SUPER_STRIDE;
+            a.blk_stats = p.blk_stats + w;
+            a.spill = p.spill + (size_t)w * p.spill_cap, a.spill_cap = p.spill_cap;
+            a.wave_sums = p.wave_sums + w;
+            a.n_blocks = 1, a.tpw_shift = 6;
+            a.slow_list = p.slow_list + w * 64u, a.slow_cap = 64;
+            a.scratch = nullptr, a.scratch_cap = 0;
+            a.sort_list = p.sort_list + w * 64u, a.sort_cap = 64;
+            a.ctr = ctr;
+            a.qcap = 176, a.pcap = 152;
+            // k_reset's work for this wave's one-block batch
+            if (lane < sizeof(Counters) / 8) reinterpret_cast<unsigned long long*>(ctr)[lane] = 0ull;
+            if (lane == 0) subs[0].used = 0ull, subs[N_SUB].used = 0ull, a.super_sums[0] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            walk_wave<512, 176, 152, true>(a, 0u, lds);
+            // what the walk left in this wave's scratch is read back below (status, the ranges): around this CU's L1
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            uint32_t st = sgpr(__hip_atomic_load(&ctr->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const uint32_t n_slow = sgpr(__hip_atomic_load(&ctr->slow_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            uint32_t verdict = ((st & (ST_RERUN | ST_WANT_MIXED)) != 0 || n_slow != 0) ? (uint32_t)POLL_FALLBACK : (uint32_t)POLL_OK;
+            if (verdict == POLL_OK) {
+                expand_wave(a, 0u);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                st = sgpr(__hip_atomic_load(&ctr->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (sgpr(__hip_atomic_load(&ctr->sort_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) verdict = POLL_FALLBACK; // rows for k_sort_rows
+            }
+            PollDone* const dn = p.done + s;
+            if (lane == 0) {
+                dn->total = __hip_atomic_load(&ctr->total_ids, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dn->n_visit = __hip_atomic_load(&ctr->n_visit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dn->n_ranges = __hip_atomic_load(&ctr->n_ranges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dn->topic_bytes = __hip_atomic_load(&ctr->topic_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dn->status = verdict;
+                dn->batch_status = st;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // every lane's stores into the output blob and lane 0's above ...
+            if (lane == 0) poll_store(&dn->seq, seq);                 // ... are in host memory before the completion word
+            served[k] = seq;
+            n_served++;
+        }
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (any) t_work = now;
+        if (sgpr(poll_load(&p.ctl->exit)) != 0u || now - t0 > POLL_LIFE_TICKS || now - t_work > POLL_IDLE_TICKS) break;
+        if (!any) __builtin_amdgcn_s_sleep(8);
+    }
+    // Leaving: say so FIRST, then look at the doorbells once more -- a leader that rang after this wave's last look either sees `exited`
+    // (and waits for the kernel to end before it decides) or is served here.
+    if (lane == 0) {
+        __hip_atomic_fetch_add(&p.ctl->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(&p.ctl->served, n_served, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+}
+#endif // BMQ_WAVE_EMU
+
+} // namespace bmq

@@ -74,10 +74,11 @@ __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_r
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 #endif
 
+// The body of k_walk as a function of (argument block, block index, the wave's LDS): the kernel below is this and nothing else; the
+// persistent matcher of the batching front (k_poll, bmq_poll_kernel.h) runs the very same code on batches it finds in its request ring.
 template <int TC, int QC, int PC, bool MIXED>
-__global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_walk(BatchArgs a) {
+__device__ __forceinline__ void walk_wave(const BatchArgs& a, const uint32_t block_x, uint32_t* const lds) {
     using G = WalkLds<TC, QC, PC, MIXED>;
-    __shared__ __align__(16) uint32_t lds[G::BYTES / 4];
     uint32_t* const tokens = lds + G::TOK / 4;
     uint2* const stk = reinterpret_cast<uint2*>(lds + G::STK / 4);
     uint2* const p_rng = reinterpret_cast<uint2*>(lds + G::PRG / 4);
@@ -92,13 +93,13 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
     uint32_t blk;
     if (BMQ_DBG(a, 32u)) { // (experiment) every XCD -- workgroup b runs on XCD b % 8 -- takes ONE contiguous eighth of the batch: a tenant's region is cached by one L2, not by eight
         const uint32_t per = (a.n_blocks + 7u) >> 3;
-        blk = (blockIdx.x & 7u) * per + (per - 1u - (blockIdx.x >> 3));
-        if ((blockIdx.x >> 3) >= per || blk >= a.n_blocks) return;
+        blk = (block_x & 7u) * per + (per - 1u - (block_x >> 3));
+        if ((block_x >> 3) >= per || blk >= a.n_blocks) return;
     } else {
-        if (blockIdx.x >= a.n_blocks) return;
+        if (block_x >= a.n_blocks) return;
         // last blocks first: batches arrive grouped by tenant with the hot tenants (L2-resident regions, fast waves) in
         // front; starting with the cold ones leaves the fast waves for the tail of the launch (measured: -4 % on C3)
-        blk = BMQ_DBG(a, 256u) ? blockIdx.x : a.n_blocks - 1 - blockIdx.x; // (256: experiment, first blocks first)
+        blk = BMQ_DBG(a, 256u) ? block_x : a.n_blocks - 1 - block_x; // (256: experiment, first blocks first)
     }
     // A wave owns TPW = 2^tpw_shift consecutive topics.  64 for large batches; a small batch is spread over more waves (16 or 4
     // topics each): the walk phase is a chain of dependent line fetches whose length is ~ max(depth, items / 64), so a wave with
@@ -559,6 +560,12 @@ __global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_wal
             d.dbg_wave[d.n_blocks + blk] = make_uint4((uint32_t)(clkA - clk0), 0u, (uint32_t)(clk1 - clkA), 0u); // phase 1 in detail
         }
     }
+}
+
+template <int TC, int QC, int PC, bool MIXED>
+__global__ __launch_bounds__(64, (WalkLds<TC, QC, PC, MIXED>::WAVES)) void k_walk(BatchArgs a) {
+    __shared__ __align__(16) uint32_t lds[WalkLds<TC, QC, PC, MIXED>::BYTES / 4];
+    walk_wave<TC, QC, PC, MIXED>(a, blockIdx.x, lds);
 }
 
 #if BMQ_EXPERIMENTS

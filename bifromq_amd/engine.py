@@ -269,6 +269,18 @@ class Engine:
         self._check(_lib.lib().bmq_routes_apply_wait(self.h))
         return self
 
+    POLLER_DISABLE, POLLER_ENABLE, POLLER_STOP, POLLER_TEST_IGNORE_DOORBELLS = 0, 1, 2, 3
+
+    def poller_stats(self) -> _lib.PollerStats:
+        """bmq_poller_stats_get: the persistent matcher behind the batching front (k_poll)"""
+        out = _lib.PollerStats()
+        self._check(_lib.lib().bmq_poller_stats_get(self.h, C.byref(out)))
+        return out
+
+    def poller_control(self, what: int):
+        self._check(_lib.lib().bmq_poller_control(self.h, what))
+        return self
+
     def compact(self):
         """bmq_compact: re-build from the live routes (ids become ranks again, new generation)."""
         self._check(_lib.lib().bmq_compact(self.h))

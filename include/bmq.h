@@ -371,6 +371,33 @@ int bmq_batcher_submit(bmq_batcher* b, const uint8_t* tenant, uint32_t tenant_le
                        bmq_batcher_cb cb, void* user);
 int bmq_batcher_stats_get(bmq_batcher* b, bmq_batcher_stats* out);
 
+/* ---- the persistent matcher behind the batching front (round 6; bmq_poll_kernel.h) ------------------------------------------------------
+ * A generation of the batching front of at most 64 topics is not LAUNCHED any more: a few resident one-wave workgroups (k_poll) poll a ring
+ * of request descriptors in page-locked host memory, run the walk + expansion of k_walk / k_expand on the generation whose doorbell rang and
+ * write the CSR in place; the leader spins on the slot's completion word.  The reference's call shape -- one matchAll(singleton(topic)) per
+ * cache miss from the matchExecutor pool (DW/cache/TenantRouteCache.java:180-193, DW/DistWorkerCoProcFactory.java:74-88) -- pays a
+ * PCIe round trip per generation instead of a kernel launch and an event.  It needs no call of its own: bmq_batcher_match_all /
+ * bmq_route_cache_get use it whenever it is enabled (the default on a device engine).
+ *   - the index never changes under it: bmq_rebuild, bmq_routes_apply[_async], bmq_compact, bmq_compact_swap and bmq_engine_destroy stop it
+ *     first (it finishes the generation in hand, a few microseconds); the next generation starts it again.  The FIRST generation after a
+ *     start pays the launch (~15 us); a generation whose doorbell it never saw is launched the old way by its leader;
+ *   - it leaves the GPU by itself after 20 ms without a doorbell and after 2 s whatever happens;
+ *   - a generation not answered within 250 ms marks it wedged: it is told to leave, never started again on this engine
+ *     (bmq_poller_stats.n_timeouts), and the generation -- like every later one -- is launched the old way: callers see results, not errors. */
+typedef struct bmq_poller_stats {
+    uint32_t enabled;     /* generations of <= 64 topics go to it */
+    uint32_t running;     /* a k_poll launch is resident right now */
+    uint64_t n_starts;    /* k_poll launches so far */
+    uint64_t n_served;    /* generations answered by it */
+    uint64_t n_fallback;  /* generations handed back or never seen: launched the old way */
+    uint64_t n_unserved;  /* ... of which: rang while it was leaving */
+    uint64_t n_timeouts;  /* generations that waited 250 ms in vain (the poller is off for good after the first) */
+} bmq_poller_stats;
+enum { BMQ_POLLER_DISABLE = 0, BMQ_POLLER_ENABLE = 1, BMQ_POLLER_STOP = 2 /* leave now; the next generation starts it again */,
+       BMQ_POLLER_TEST_IGNORE_DOORBELLS = 3 /* test hook: doorbells are seen and not answered -- the leaders' time-out path */ };
+int bmq_poller_stats_get(bmq_engine* e, bmq_poller_stats* out);
+int bmq_poller_control(bmq_engine* e, int what);
+
 /* ---- route cache ---------------------------------------------------------------------------------- */
 /* ISubscriptionCache (DW/cache/ISubscriptionCache.java:30-40) on the engine's side of the boundary: SubscriptionCache ->
  * TenantRouteCache (DW/cache/TenantRouteCache.java:116-296: topic -> matched routes, loaded by matchAll(singleton(topic)), bounded by

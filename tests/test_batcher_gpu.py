@@ -332,3 +332,74 @@ def test_route_cache_get_batch_one_launch_for_all_misses(setup):
     c.close()
     b.close()
     eng.close()
+
+
+def test_persistent_matcher_serves_the_small_generations(setup):
+    """Round 6: generations of at most 64 topics are not launched -- resident waves (k_poll, bmq_poll_kernel.h) find them in a request ring
+    and answer in place.  Every caller still gets exactly the oracle's rows; the poller's counters say it was the one that answered; a
+    mutation stops it (the index never changes under it) and the next generation starts it again; deep topics are handed back to a launch."""
+    eng, tn, tt, packed, topics, exp = setup
+    eng.poller_control(eng.POLLER_ENABLE)
+    b = eng.batcher()
+    s0 = eng.poller_stats()
+    assert s0.enabled
+    for i in (0, 1, 2, 57, 4000):
+        rows, epoch = b.match_all(tn[tt[i]], [topics[i]])
+        assert rows == [exp[i]] and epoch == eng.info().epoch
+    s1 = eng.poller_stats()
+    assert s1.n_served - s0.n_served >= 5 and s1.n_starts >= 1 and s1.n_timeouts == 0
+    cnt, hsh, sec = b.drive_singletons(tn, tt, packed, n_threads=32)
+    assert cnt.tolist() == [len(r) for r in exp]
+    assert hsh.tolist() == [_row_hash(r) for r in exp]
+    s2 = eng.poller_stats()
+    assert s2.n_served - s1.n_served > 100 and s2.n_timeouts == 0  # the generations of 32 blocked callers fit a wave
+    # a topic of more than 16 levels: the wave hands the generation back, its leader launches it (k_walk_slow is a launch's business)
+    deep = "/".join(["x"] * 40)
+    rows, _ = b.match_all(tn[0], [deep])
+    assert rows == U.semantic_rows(O.KV(eng.route_keys(np.arange(int(eng.info().next_route_id), dtype=np.uint32))), tn, [0], [deep])
+    assert eng.poller_stats().n_fallback > s2.n_fallback
+    # a mutation stops the poller; afterwards the new route is seen (by a new launch of it)
+    starts = eng.poller_stats().n_starts
+    key = B.route_key(tn[1], "poller/+/probe", 1, "0\0px\0d1")
+    eng.apply([(0, key)])
+    assert not eng.poller_stats().running
+    rows, epoch = b.match_all(tn[1], ["poller/x/probe"])
+    rid = rows[0]
+    assert len(rid) == 1 and eng.route_key(rid[0]) == key and epoch == eng.info().epoch
+    assert eng.poller_stats().n_starts > starts
+    eng.apply([(1, key)])
+    assert b.match_all(tn[1], ["poller/x/probe"])[0] == [[]]
+    # switched off: the same answers through launches
+    eng.poller_control(eng.POLLER_DISABLE)
+    served = eng.poller_stats().n_served
+    rows, _ = b.match_all(tn[tt[7]], [topics[7]])
+    assert rows == [exp[7]] and eng.poller_stats().n_served == served
+    eng.poller_control(eng.POLLER_ENABLE)
+    b.close()
+
+
+def test_a_wedged_poller_costs_a_time_out_not_an_answer():
+    """The test hook makes the resident waves see the doorbells and not answer: the first generation waits out its time-out (250 ms), the
+    poller is told to leave and is off for good on this engine, and the generation -- like every later one -- is launched: the caller
+    sees its rows, bmq_poller_stats.n_timeouts says what happened."""
+    w = B.Workload(22, 2, 300, 1)
+    keys = w.keys()
+    eng = B.Engine(device=0).rebuild(keys)
+    try:
+        tn = w.tenants()
+        data, off, tt = w.topics(5, 40)
+        topics = [t.decode() for t in unpack(data, off)]
+        exp = U.semantic_rows(O.KV(keys), tn, tt, topics)
+        b = eng.batcher()
+        assert b.match_all(tn[tt[0]], [topics[0]])[0] == [exp[0]]
+        assert eng.poller_stats().n_served >= 1
+        eng.poller_control(eng.POLLER_TEST_IGNORE_DOORBELLS)
+        assert b.match_all(tn[tt[1]], [topics[1]])[0] == [exp[1]]  # (after the time-out, through a launch)
+        st = eng.poller_stats()
+        assert st.n_timeouts == 1 and not st.enabled and not st.running
+        for i in range(2, 10):
+            assert b.match_all(tn[tt[i]], [topics[i]])[0] == [exp[i]]
+        assert eng.poller_stats().n_timeouts == 1
+        b.close()
+    finally:
+        eng.close()

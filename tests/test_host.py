@@ -448,7 +448,7 @@ def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
 
     from bifromq_amd import _lib
     structs = {"bmq_config": _lib.Config, "bmq_stats": _lib.Stats, "bmq_index_info": _lib.IndexInfo, "bmq_batcher_config": _lib.BatcherConfig,
-               "bmq_batcher_stats": _lib.BatcherStats, "bmq_route_cache_config": _lib.RouteCacheConfig, "bmq_route_cache_stats": _lib.RouteCacheStats,
+               "bmq_batcher_stats": _lib.BatcherStats, "bmq_poller_stats": _lib.PollerStats, "bmq_route_cache_config": _lib.RouteCacheConfig, "bmq_route_cache_stats": _lib.RouteCacheStats,
                "bmq_route_cache_tenant_stats": _lib.RouteCacheTenantStats, "bmq_retain_info": _lib.RetainInfo, "bmq_ranges_info": _lib.RangesInfo}
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "bmq.h"', 'int main(void) {']
     for cname, cls in structs.items():
