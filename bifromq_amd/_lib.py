@@ -72,7 +72,7 @@ class BatcherStats(C.Structure):
 
 class PollerStats(C.Structure):
     _fields_ = [("enabled", C.c_uint32), ("running", C.c_uint32), ("n_starts", C.c_uint64), ("n_served", C.c_uint64), ("n_fallback", C.c_uint64),
-                ("n_unserved", C.c_uint64), ("n_timeouts", C.c_uint64)]
+                ("n_unserved", C.c_uint64), ("n_timeouts", C.c_uint64), ("n_bad_input", C.c_uint64)]
 
 
 class RouteCacheConfig(C.Structure):

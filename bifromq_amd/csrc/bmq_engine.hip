@@ -229,11 +229,13 @@ struct bmq_engine {
         PollDesc* desc = nullptr; // page-locked, POLL_SLOTS
         PollDone* done = nullptr;
         PollCtl* ctl = nullptr;
+        uint8_t *blob_in = nullptr, *blob_out = nullptr; // page-locked: one input and one output blob per slot (pinned before any launch)
         DevBuf scratch;           // every per-wave array of PollArgs, one allocation
         PollArgs args{};
         bool busy[POLL_SLOTS] = {};
         uint32_t rr = 0;          // slot hand-out: round robin over the waves
         uint64_t n_served = 0, n_fallback = 0, n_timeouts = 0, n_starts = 0, n_unserved = 0;
+        std::atomic<uint64_t> n_bad_input{0}; // generations a wave refused to touch (offsets / tenant indices out of range: never seen outside bring-up)
     } pol;
 };
 
@@ -814,6 +816,8 @@ void bmq_engine_destroy(bmq_engine* e) {
         if (e->pol.desc) (void)hipHostFree(e->pol.desc);
         if (e->pol.done) (void)hipHostFree(e->pol.done);
         if (e->pol.ctl) (void)hipHostFree(e->pol.ctl);
+        if (e->pol.blob_in) (void)hipHostFree(e->pol.blob_in);
+        if (e->pol.blob_out) (void)hipHostFree(e->pol.blob_out);
         e->pol.scratch.release();
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         if (e->s_in) (void)hipStreamSynchronize(e->s_in);

@@ -392,6 +392,7 @@ typedef struct bmq_poller_stats {
     uint64_t n_fallback;  /* generations handed back or never seen: launched the old way */
     uint64_t n_unserved;  /* ... of which: rang while it was leaving */
     uint64_t n_timeouts;  /* generations that waited 250 ms in vain (the poller is off for good after the first) */
+    uint64_t n_bad_input; /* generations a wave refused to touch: offsets or tenant indices out of range (handed back, launched the old way) */
 } bmq_poller_stats;
 enum { BMQ_POLLER_DISABLE = 0, BMQ_POLLER_ENABLE = 1, BMQ_POLLER_STOP = 2 /* leave now; the next generation starts it again */,
        BMQ_POLLER_TEST_IGNORE_DOORBELLS = 3 /* test hook: doorbells are seen and not answered -- the leaders' time-out path */ };
