@@ -60,6 +60,12 @@ template <class T> BMQ_HD T atom_cas(T* p, T expect, T desired) { // returns the
 }
 template <class T> BMQ_HD T atom_add(T* p, T v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> BMQ_HD T atom_or(T* p, T v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A look through the caches (an ordinary load) at something that never changes once it is PUBLISHED -- a dictionary slot with its token, a trie
+// slot with its node id.  A hit is final whatever the age of the line; a miss says nothing (the line may be older than the entry) and sends the
+// caller to the coherent loads above.  (Round 6: every lane of a 100 k-op batch used to read the dictionary slots of the few level strings
+// all keys share -- "churn", the eight first-level tokens -- around the caches: hundreds of thousands of requests for a handful of lines,
+// one L2 channel each, and k_b_locate took 114 us however its passes were arranged.)
+template <class T> BMQ_HD T peek_load(const T* p) { return *reinterpret_cast<const volatile T*>(p); }
 #else
 template <class T> BMQ_HD T atom_load(const T* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 template <class T> BMQ_HD void shared_store(T* p, T v) { *p = v; } // ordered by the release store of the flag that follows
@@ -71,6 +77,7 @@ template <class T> BMQ_HD T atom_cas(T* p, T expect, T desired) { // returns the
 }
 template <class T> BMQ_HD T atom_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 template <class T> BMQ_HD T atom_or(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_ACQ_REL); }
+template <class T> BMQ_HD T peek_load(const T* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); } // (the host has one kind of load)
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
@@ -334,6 +341,21 @@ BMQ_HD uint32_t dict_intern(const DistIndexMut& ix, const LevelHash& h, uint32_t
                             unsigned long long start, bool insert) {
     const uint32_t tag = level_hash_tag(h);
     uint32_t g = level_hash_slot(h, len) & ix.dict_group_mask;
+    // through the caches first: the home group's slots, if they hold this string with its token published (peek_load)
+    for (uint32_t jj = 0; jj < DICT_GROUP; jj++) {
+        const DictSlot* s = ix.dict + DICT_GROUP * (size_t)g + jj;
+        if (peek_load(&s->tag) != tag) continue;
+        const uint32_t tok = peek_load(&s->token);
+        if (tok == 0 || peek_load(&s->len) != len || peek_load(&s->inl[0]) != inl[0] || peek_load(&s->inl[1]) != inl[1] || peek_load(&s->inl[2]) != inl[2] ||
+            peek_load(&s->inl[3]) != inl[3])
+            continue;
+        bool eq = true;
+        if (len > 16) {
+            const uint32_t po = peek_load(&s->pool_off);
+            for (uint32_t i = 16; i < len && eq; i++) eq = peek_load(ix.dpool + po + i) == kp[start + i];
+        }
+        if (eq) return tok;
+    }
     uint32_t j = 0, probes = 0, spins = 0;
     // an insert gives up early (the host grows the table and re-runs locate) instead of crawling through a nearly full table
     const uint32_t max_probes = insert && ix.dict_group_mask > 128u ? 128u : ix.dict_group_mask;
@@ -419,6 +441,32 @@ BMQ_HD uint32_t trie_child(const DistIndexMut& ix, TenantSlot* ten, uint32_t bas
     uint32_t phase = 0, spins = 0, bk = 0, j = 0, probes = 0;
     TrieSlot* wait = nullptr; // a slot that holds `key`: its node id, once the claiming lane has published it
     unsigned long long wait_abs = 0;
+    // through the caches first (peek_load): the slot beside the parent, then the two slots of the hashed home -- a slot that holds the edge
+    // with its node id published is the answer, whatever the age of the line
+    {
+        auto peek = [&](unsigned long long abs) -> uint32_t {
+            const TrieSlot* s = ix.trie + (size_t)abs;
+            if (peek_load(reinterpret_cast<const uint64_t*>(s)) != key) return NONE;
+            return peek_load(&s->node);
+        };
+        if (try_beside) {
+            const uint32_t id = peek(beside_abs);
+            if (id != NONE) {
+                slot_abs = beside_abs;
+                return id;
+            }
+        }
+        if (!root_plus) {
+            const unsigned long long home = (unsigned long long)base + 2ull * edge_bucket(parent, token, buckets);
+            for (uint32_t jj = 0; jj < 2; jj++) {
+                const uint32_t id = peek(home + jj);
+                if (id != NONE) {
+                    slot_abs = home + jj;
+                    return id;
+                }
+            }
+        }
+    }
     for (;;) {
         if (spins > (1u << 22)) {
             atom_or(&ix.bc->err, (uint32_t)ERR_STUCK);
@@ -735,20 +783,21 @@ struct IdSet {
 BMQ_HD uint32_t idset_at(const DistIndexMut& ix, const IdSet& s, uint32_t m) { return s.indirect() ? ix.route_pos[s.begin + m] : s.begin + m; }
 
 // position of the member whose key tail equals key `k`'s, or NONE
-// (Eight members per step: their ids and tail hashes are requested together -- one memory latency per eight members instead of two per
+// (Sixteen members per step: their ids and tail hashes are requested together -- one memory latency per sixteen members instead of two per
 // member.  A group lane is alone on its chain of dependent reads, the builder's kernels run at 1-2 waves per SIMD, and a filter with a few
 // hundred routes made its lane the one the whole k_b_group launch waited for.)
 BMQ_HD uint32_t idset_find_key(const DistIndexMut& ix, const IdSet& s, const KeyView& k, uint32_t th) {
     const uint32_t n = s.count();
     const unsigned long long tl = k.end - k.tail;
-    for (uint32_t m0 = 0; m0 < n; m0 += 8) {
-        uint32_t id[8], h[8];
+    constexpr uint32_t STEP = 16;
+    for (uint32_t m0 = 0; m0 < n; m0 += STEP) {
+        uint32_t id[STEP], h[STEP];
 #pragma unroll
-        for (uint32_t j = 0; j < 8; j++) id[j] = m0 + j < n ? idset_at(ix, s, m0 + j) : NONE;
+        for (uint32_t j = 0; j < STEP; j++) id[j] = m0 + j < n ? idset_at(ix, s, m0 + j) : NONE;
 #pragma unroll
-        for (uint32_t j = 0; j < 8; j++) h[j] = id[j] != NONE ? ix.khash[id[j]] : ~th;
+        for (uint32_t j = 0; j < STEP; j++) h[j] = id[j] != NONE ? ix.khash[id[j]] : ~th;
 #pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
+        for (uint32_t j = 0; j < STEP; j++) {
             if (h[j] != th) continue;
             const unsigned long long r = ix.kref[id[j]];
             const unsigned long long off = r & KREF_OFF_MASK, len = r >> KREF_LEN_SHIFT;

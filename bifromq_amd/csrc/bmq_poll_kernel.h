@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64) void k_poll(PollArgs p) {
             const PollDesc* const d = p.desc + s;
             const uint32_t seq = sgpr(poll_load(&d->seq));
             const uint32_t hook = seq == served[k] + 1u ? sgpr(poll_load(&p.ctl->ignore)) : 0u;
+            if (hook == 1u) any = true; // (the test hook plays a wedged wave: it does not answer and does not leave by itself either)
             if (seq != served[k] + 1u || hook == 1u) continue;
             any = true;
             // ---- the generation's argument block: what launch_dist fills for a launch, from the descriptor and this wave's scratch ----
