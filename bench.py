@@ -702,7 +702,7 @@ def extra_legs(args, eng, w, step, torch, np, fetch_csr=None, tickets=None):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                                 "--no-host-path", "--no-extras"], capture_output=True, text=True, timeout=240)
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            keep = ("metric", "value", "unit", "ms_per_step", "kernel_ms", "roofline", "routes_per_topic", "topics_per_filter", "churn", "limited")
+            keep = ("metric", "value", "unit", "ms_per_step", "kernel_ms", "roofline", "routes_per_topic", "topics_per_filter", "churn", "limited", "compaction")
             extra[wl] = {k: d[k] for k in keep if k in d}
             extra[wl]["workload"] = d["config"]["workload"]
             extra[wl]["wall_s"] = time.perf_counter() - t0
@@ -1531,6 +1531,12 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
     churn = retain_churn_leg(eng, w, data, off, n_topics, step, torch, np) if world == 1 and not args.no_churn else None
     if limited is not None and churn is not None:
         limited["churned"] = retain_limited_leg(eng, w, batches[0][3], base_ms + 95_000, np)
+    compaction = None
+    if churn is not None:  # the churned index (50 k dead ids, 50 k overlay topics) folded into a fresh bulk load, beside the matcher and with the stall
+        try:
+            compaction = retain_compaction_leg(eng, step, torch, np)
+        except Exception as ex:  # noqa: BLE001
+            compaction = {"error": repr(ex)}
     out = {"metric": "retain-direction filter matches/sec (whole node)", "value": world * n * args.steps / elapsed,
            "unit": "filters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -1550,7 +1556,7 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
                         "frac_pipeline": float(np.mean(alg)) / ((kw + ke) * 1e-3) / 8e12,
                         "algorithmic_bytes_per_launch": float(np.mean(alg)),
                         "kernel_own_frac": {"k_retain_walk": walk_bytes / (max(kw, 1e-9) * 1e-3) / 8e12, "k_expand": exp_bytes / (max(ke, 1e-9) * 1e-3) / 8e12}},
-           "churn": churn, "limited": limited}
+           "churn": churn, "limited": limited, "compaction": compaction}
     attach_traffic(out, "c4", world)
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
@@ -1569,6 +1575,68 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
     if world > 1:
         dist.destroy_process_group()
     emit_json(out)
+
+
+def retain_compaction_leg(eng, step, torch, np):
+    """bmq_retain_compact_begin / _build / _swap on the churned C4 index while the main thread matches 100 k-filter batches back to back
+    (TopicLevelTrie contracts online, UTIL/index/TopicLevelTrie.java:257-384), then bmq_retain_compact -- the same generation change under the
+    engine lock -- for the length of the stall it replaces."""
+    import threading
+
+    def pct(v):
+        v = np.sort(np.asarray(v))
+        return {"n": int(len(v)), "p50": float(v[len(v) // 2]), "p99": float(v[min(len(v) - 1, int(len(v) * 0.99))]), "max": float(v[-1])}
+
+    def clocked(k):
+        out = []
+        for i in range(k):
+            t0 = time.perf_counter()
+            step(i)
+            out.append((time.perf_counter() - t0) * 1e3)
+        return out
+
+    clocked(3)
+    idle = clocked(30)
+    info0 = eng.retain_info()
+    t0 = time.perf_counter()
+    eng.retain_compact_begin()
+    begin_ms = (time.perf_counter() - t0) * 1e3
+    fail, build_s = [], [0.0]
+
+    def builder():
+        try:
+            t1 = time.perf_counter()
+            eng.retain_compact_build()
+            build_s[0] = time.perf_counter() - t1
+        except Exception as ex:  # noqa: BLE001
+            fail.append(repr(ex))
+
+    th = threading.Thread(target=builder)
+    th.start()
+    during = []
+    while th.is_alive():
+        during.extend(clocked(2))
+    th.join()
+    if fail:
+        eng.retain_compact_abort()
+        return {"error": fail[0]}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    carried, replayed = eng.retain_compact_swap()
+    swap_ms = (time.perf_counter() - t0) * 1e3
+    info1 = eng.retain_info()
+    after = clocked(10)
+    st = eng.stats()
+    t0 = time.perf_counter()
+    eng.retain_compact()  # the stall the three calls replace (on the index they left: same size)
+    blocking_s = time.perf_counter() - t0
+    return {"what": "bmq_retain_compact_begin / _build / _swap while 100 k-filter batches are matched back to back by the calling thread",
+            "begin_ms": begin_ms, "build_s": build_s[0], "swap_ms": swap_ms, "topics_carried": int(carried), "ops_replayed": int(replayed),
+            "batch_ms_idle": pct(idle), "batch_ms_while_building": pct(during), "batch_ms_after_swap": pct(after),
+            "kernel_ms_after_swap": {"k_retain_walk": st.ms_walk, "k_expand": st.ms_expand},
+            "before": {"retained": int(info0.n_topics), "loaded_removed": int(info0.loaded_removed), "added_ids": int(info0.added_ids)},
+            "after": {"retained": int(info1.n_topics), "loaded_removed": int(info1.loaded_removed), "added_ids": int(info1.added_ids), "generation": int(info1.generation)},
+            "bmq_retain_compact_blocking_s": blocking_s}
 
 
 def retain_limited_leg(eng, w, batch0, now_ms, np, limit=10, reps=5):

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "bmq_match_finish", "bmq_set_kernel_timing", "bmq_match_submit", "bmq_match_wait", "bmq_match_submit_fmt", "bmq_match_submit_dev", "bmq_match_wait_dev", "bmq_match_wait_counts", "bmq_match_wait_ranges", "bmq_match_wait_grouped", "bmq_host_alloc", "bmq_host_free", "bmq_sync", "bmq_stats_get", "bmq_stream", "bmq_match_all", "bmq_route_key_encode",
     "bmq_route_key_decode", "bmq_java_string_hash", "bmq_range_lookup", "bmq_comm_unique_id", "bmq_comm_init", "bmq_comm_destroy", "bmq_exchange_fanout",
     "bmq_exchange_csr", "bmq_exchange_wait", "bmq_partition_batch_dev", "bmq_retain_message_key", "bmq_retain_filter_route", "bmq_retain_rebuild", "bmq_retain_rebuild_ex", "bmq_retain_apply", "bmq_retain_apply_ex", "bmq_retain_topic",
-    "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired", "bmq_retain_apply_batch", "bmq_retain_compact", "bmq_retain_info_get",
+    "bmq_retain_topic_info", "bmq_retain_find_all", "bmq_retain_expired", "bmq_retain_apply_batch", "bmq_retain_compact", "bmq_retain_compact_begin", "bmq_retain_compact_build", "bmq_retain_compact_swap", "bmq_retain_compact_abort", "bmq_retain_info_get",
     "bmq_retain_live_ids", "bmq_retain_topics",
     "bmq_retain_match_batch", "bmq_retain_match_batch_dev", "bmq_retain_match_limited", "bmq_batcher_create", "bmq_batcher_destroy",
     "bmq_batcher_match_all", "bmq_batcher_submit", "bmq_batcher_stats_get", "bmq_poller_stats_get", "bmq_poller_control",
@@ -121,6 +121,10 @@ def lib() -> C.CDLL:
             "bmq_last_error": (C.c_char_p, [vp]),
             "bmq_version": (C.c_char_p, []),
             "bmq_rebuild": (C.c_int, [vp, vp, vp, u32]),
+            "bmq_retain_compact_begin": (C.c_int, [vp]),
+            "bmq_retain_compact_build": (C.c_int, [vp]),
+            "bmq_retain_compact_swap": (C.c_int, [vp, P(u64), P(u64)]),
+            "bmq_retain_compact_abort": (C.c_int, [vp]),
             "bmq_compact_begin": (C.c_int, [vp]),
             "bmq_compact_poll": (C.c_int, [vp, u32, P(u32)]),
             "bmq_compact_swap": (C.c_int, [vp, P(u64), P(u64)]),

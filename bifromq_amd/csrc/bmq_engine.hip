@@ -172,6 +172,23 @@ struct bmq_engine {
     std::unique_ptr<RetainDyn<HostExec>> hrt; // ... of a host-only engine (inspection, sanitizer fuzzers)
     RetainIndexView rhview{};                 // host-only engine: the bulk-loaded arrays where RetainIndexHost keeps them
     bool rbuilt = false;
+    // bmq_retain_compact_begin / _build / _swap: the next generation of the retained-topic index, built beside the serving one (round 6)
+    struct RetainCompaction {
+        bool active = false;  // (guarded by mu, like the log; `next` and `items` belong to the one thread that drives the compaction)
+        bool built = false;
+        std::vector<RetainIndexHost::Item> items; // the live topics at begin, with their stamps
+        RetainIndexHost next;                     // ... loaded into an index of their own, outside the engine lock
+        struct Op {
+            std::string tenant, topic;
+            uint8_t op;
+            bool has_ts;
+            unsigned long long ts;
+            uint32_t expiry;
+        };
+        std::vector<Op> log;                      // IRetainTopicIndex.add / remove since begin, in order: replayed before the swap
+        uint64_t log_bytes = 0;
+        bool log_overflow = false;
+    } rcmp;
     uint64_t repoch = 0;      // +1 per retain rebuild / apply / compact
     uint64_t rgeneration = 0; // +1 per retain rebuild / compact: topic ids of different generations are unrelated
     RetainLimit rlim;
@@ -1000,7 +1017,7 @@ int bmq_compact_begin(bmq_engine* e) {
     std::string msg;
     if (!with_generations(e, [&](auto& cur, auto& next) {
             e->cmp.n_ids = cur.id_bound();
-            const bool r = next.reserve_like(cur); // regions, pools and tables at their final size: the carry-over grows nothing
+            const bool r = next.reserve_like(cur) && next.reserve_import(65536, 65536ull * 192); // regions, pools and tables at their final size, the chunk buffers too: the carry-over allocates nothing (chunks of up to 65536 ids)
             if (!r) msg = next.error;
             cur.defer_release = r; // what the serving generation outgrows meanwhile stays readable for the builder
             return r;

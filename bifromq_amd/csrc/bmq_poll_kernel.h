@@ -77,6 +77,7 @@ struct PollArgs {
     uint32_t* slow_list;  // 64 per wave
     uint32_t* sort_list;  // 64 per wave
     Counters* ctr;        // 1 per wave
+    unsigned long long* t_work; // device memory: when ANY wave last had a doorbell (the idle limit is the poller's, not a wave's)
 };
 
 #ifndef BMQ_WAVE_EMU
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64) void k_poll(PollArgs p) {
 #pragma unroll
     for (uint32_t k = 0; k < OWN; k++) served[k] = sgpr(poll_load(&p.done[w + k * POLL_WAVES].seq)); // where the last launch left off
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long t_work = t0;
+    if (lane == 0) atomicMax(p.t_work, t0);
     Counters* const ctr = p.ctr + w;
     SubAlloc* const subs = p.subs + (size_t)w * 2 * N_SUB;
     for (;;) {
@@ -263,9 +264,13 @@ __global__ __launch_bounds__(64) void k_poll(PollArgs p) {
             if (lane == 0) poll_store(&dn->seq, seq);                 // ... are in host memory before the completion word
             served[k] = seq;
         }
+        // The idle limit is the POLLER's: a wave whose slots are quiet stays while others are busy -- a poller that has lost some of its
+        // waves would leave their slots unanswered, and the leaders that rang them waiting for the rest to end.
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        if (any) t_work = now;
-        if (sgpr(poll_load(&p.ctl->exit)) != 0u || now - t0 > POLL_LIFE_TICKS || now - t_work > POLL_IDLE_TICKS) break;
+        if (any && lane == 0) atomicMax(p.t_work, now);
+        const unsigned long long tw = __hip_atomic_load(p.t_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t idle = now > tw && now - tw > POLL_IDLE_TICKS ? 1u : 0u;
+        if (sgpr(poll_load(&p.ctl->exit)) != 0u || now - t0 > POLL_LIFE_TICKS || sgpr(idle) != 0u) break;
         if (!any) __builtin_amdgcn_s_sleep(8);
     }
     // Leaving: say so FIRST, then look at the doorbells once more -- a leader that rang after this wave's last look either sees `exited`

@@ -203,7 +203,11 @@ __device__ __forceinline__ void retain_walk_rounds(const RetainArgs& r, const Ba
     const uint32_t list_cap = RW_INL + r.rw_cap;
     // the batch is handed out in QUADS of RQ consecutive filters, dynamically: quad q belongs to partition q % RW_PARTS, a wave takes the
     // next quad of its partition with one atomic (requested a refill ahead of its use: the wave never waits for it)
-    const uint32_t n_quads = (r.n_filters + RQ - 1) / RQ, n_parts = gridDim.x < RW_PARTS ? gridDim.x : RW_PARTS, part = blockIdx.x % n_parts;
+    // Round 6: a wave whose partition has run dry goes on with a NEIGHBOUR's (the partitions part ^ 1, ^ 2, ^ 4 ... in turn: at most six
+    // more counters per wave, a few hundred requests per counter at the end of a launch) instead of leaving -- the partitions hold equal
+    // numbers of quads, not equal amounts of work, and the waves of a dry partition used to sit out the end of the launch.
+    const uint32_t n_quads = (r.n_filters + RQ - 1) / RQ, n_parts = gridDim.x < RW_PARTS ? gridDim.x : RW_PARTS, part0 = blockIdx.x % n_parts;
+    uint32_t part = part0, steal = 0; // (wave-uniform)
     uint32_t visits = 0;                        // per lane
     unsigned long long wranges = 0, wbytes = 0; // home lanes
     bool ovf = false;
@@ -312,7 +316,14 @@ __device__ __forceinline__ void retain_walk_rounds(const RetainArgs& r, const Ba
             const unsigned long long c_g0 = RW_CLK();
             const uint32_t quad = sgpr(fetched) * n_parts + part;
             if (quad >= n_quads) {
-                exhausted = true;
+                // this partition is dry: the next neighbour that exists (power-of-two distances), or done
+                do steal = steal ? steal << 1 : 1u;
+                while (steal < RW_PARTS && (part0 ^ steal) >= n_parts);
+                if (steal >= RW_PARTS) exhausted = true;
+                else {
+                    part = part0 ^ steal;
+                    request_quad();
+                }
                 continue;
             }
             request_quad(); // the one after this

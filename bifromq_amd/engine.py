@@ -561,6 +561,26 @@ class Engine:
                                                      _ptr(poff), len(poff) - 1, _ptr(ts), _ptr(ex)))
         return self
 
+    def retain_compact_begin(self):
+        """bmq_retain_compact_begin: snapshot of the live retained topics -- the next generation starts from it"""
+        self._check(_lib.lib().bmq_retain_compact_begin(self.h))
+        return self
+
+    def retain_compact_build(self):
+        """bmq_retain_compact_build: loads the snapshot into an index of its own; no engine lock held (matching / add / remove go on)"""
+        self._check(_lib.lib().bmq_retain_compact_build(self.h))
+        return self
+
+    def retain_compact_swap(self) -> Tuple[int, int]:
+        """bmq_retain_compact_swap: upload, replay of what was added / removed meanwhile, swap -> (topics carried over, ops replayed)"""
+        carried, replayed = C.c_uint64(), C.c_uint64()
+        self._check(_lib.lib().bmq_retain_compact_swap(self.h, C.byref(carried), C.byref(replayed)))
+        return int(carried.value), int(replayed.value)
+
+    def retain_compact_abort(self):
+        self._check(_lib.lib().bmq_retain_compact_abort(self.h))
+        return self
+
     def retain_apply(self, tenant, ops: Sequence):
         """ops: (0 = add | 1 = remove, topic[, timestamp_hlc, expiry_seconds]) -- IRetainTopicIndex.add / remove"""
         t = _b(tenant)

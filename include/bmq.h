@@ -673,6 +673,21 @@ int bmq_retain_apply_batch(bmq_engine* e, const uint8_t* tenants, const uint32_t
 /* Maintenance: fold what bmq_retain_apply* changed into a fresh bulk load (removed topics and their ids go, added topics become ranks
  * again: every subtree one id range, the fast path of '+' and '#').  A new generation of ids. */
 int bmq_retain_compact(bmq_engine* e);
+/* The same generation change without the stall (round 6): TopicLevelTrie contracts tombed branches as it goes
+ * (UTIL/index/TopicLevelTrie.java:257-384); bmq_retain_compact holds the engine for the whole load (2 s for 1 M topics).
+ *   bmq_retain_compact_begin   snapshot of the live topics with their stamps (the engine lock for tens of milliseconds);
+ *   bmq_retain_compact_build   loads them into an index of their own: the long part, NO engine lock held -- matching and bmq_retain_apply* go
+ *                              on meanwhile, what they add / remove is logged;
+ *   bmq_retain_compact_swap    uploads the new generation, replays the log in order and makes it the serving one (no batch may be in flight:
+ *                              BMQ_E_STATE).  Topic ids are re-numbered: bmq_retain_info.generation + 1, as after bmq_retain_compact.
+ *                              *out_carried = topics of the new bulk load, *out_replayed = logged ops replayed.  BMQ_E_NOSPACE: the log outgrew
+ *                              1 GiB (abort and begin again; no mutation is ever refused).
+ *   bmq_retain_compact_abort   drops the half-built generation.
+ * One compaction call at a time; bmq_retain_rebuild* / bmq_retain_compact are refused (BMQ_E_STATE) between begin and swap / abort. */
+int bmq_retain_compact_begin(bmq_engine* e);
+int bmq_retain_compact_build(bmq_engine* e);
+int bmq_retain_compact_swap(bmq_engine* e, uint64_t* out_carried /* may be NULL */, uint64_t* out_replayed /* may be NULL */);
+int bmq_retain_compact_abort(bmq_engine* e);
 typedef struct bmq_retain_info {
     uint64_t n_topics;        /* retained topics now */
     uint64_t n_tenants;       /* tenants of the last bulk load */

@@ -464,3 +464,68 @@ def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_retain_compaction_beside_the_serving_generation_over_the_host_executor():
+    """bmq_retain_compact_begin / _build / _swap / _abort on a host-only engine (the retain index and its mutations run on the host executor;
+    nothing is matched): the live set, the replay of what was added / removed between begin and swap -- in order --, ids = ranks after a
+    second round, the refusals.  The rows a GPU engine serves through the same calls: tests/test_retain_churn_gpu.py."""
+    import random
+    rnd = random.Random(5)
+    eng = B.Engine(device=-1)
+    try:
+        tenants = ["tA", "tB"]
+        base = sorted({(rnd.randrange(2), "l%d/m%d/n%d" % (rnd.randrange(5), rnd.randrange(20), rnd.randrange(50))) for _ in range(1500)})
+        eng.retain_rebuild(tenants, [t for t, _ in base], [p for _, p in base])
+        live = {(tenants[t], p) for t, p in base}
+
+        def live_now():
+            out = {}
+            for t in tenants:
+                ids = eng.retain_live_ids(t)
+                for i, k in zip(ids, eng.retain_topics(ids)):
+                    out[k] = i
+            return out
+
+        def churn(n_rm, n_add, tag):
+            rm = rnd.sample(sorted(live), n_rm)
+            add = [(tenants[j % 2], "z%s/%d" % (tag, j)) for j in range(n_add)]
+            for t in tenants:
+                ops = [(1, p) for tt_, p in rm if tt_ == t] + [(0, p) for tt_, p in add if tt_ == t]
+                eng.retain_apply(t, ops)
+            live.difference_update(rm)
+            live.update(add)
+            return rm, add
+
+        with pytest.raises(B.BmqError) as ei:
+            eng.retain_compact_swap()
+        assert ei.value.code == -7
+        churn(200, 100, "a")
+        g0 = eng.retain_info().generation
+        eng.retain_compact_begin()
+        with pytest.raises(B.BmqError):
+            eng.retain_compact_begin()
+        with pytest.raises(B.BmqError):
+            eng.retain_compact_swap()  # not built yet
+        rm, add = churn(50, 70, "b")
+        eng.retain_compact_build()
+        eng.retain_apply(rm[0][0], [(0, rm[0][1])])
+        live.add(rm[0])
+        eng.retain_apply(add[0][0], [(1, add[0][1])])
+        live.discard(add[0])
+        carried, replayed = eng.retain_compact_swap()
+        assert carried == len(base) - 200 + 100 and replayed == 50 + 70 + 2
+        assert set(live_now()) == live and eng.retain_info().generation == g0 + 1
+        eng.retain_compact_begin().retain_compact_build()
+        eng.retain_compact_swap()
+        got = live_now()
+        order = sorted(live, key=lambda k: (k[0].encode(), [lv.encode() for lv in k[1].split("/")]))
+        assert [got[k] for k in order] == list(range(len(order)))
+        info = eng.retain_info()
+        assert info.loaded_removed == 0 and info.added_ids == 0 and info.n_topics == len(live)
+        eng.retain_compact_begin()
+        churn(3, 3, "c")
+        eng.retain_compact_abort().retain_compact_abort()
+        assert set(live_now()) == live
+    finally:
+        eng.close()

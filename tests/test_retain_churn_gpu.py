@@ -219,3 +219,84 @@ def test_full_size_config4_churn(eng):
     lrow, lids, counts = eng.retain_match_limited(tn, np.zeros(len(sample), dtype=np.uint32), filters[:len(sample)], [10] * len(sample), now_ms=0)
     assert counts.tolist() == [len(e) for e in exp[:len(sample)]]
     assert U.csr_rows(lrow, lids) == [e[:10] for e in exp[:len(sample)]]
+
+
+def test_retain_compaction_beside_the_serving_generation(eng):
+    """Round 6: bmq_retain_compact_begin / _build / _swap -- the generation change of the retained-topic index without the stall (TopicLevelTrie
+    contracts as it goes, UTIL/index/TopicLevelTrie.java:257-384).  Adds / removes and match batches land between the three calls (the ones
+    after `begin` are logged and replayed in order: a topic removed and retained again, one added and removed); after the swap every row equals
+    the oracle's over the live set, ids are the ranks of an independent sort again, nothing dead, no overlay."""
+    rnd = random.Random(11)
+    tenants = ["tA", "tB"]
+    base = sorted({(rnd.randrange(2), U.rand_topic(rnd, 5)) for _ in range(3000)})
+    eng.retain_rebuild(tenants, [t for t, _ in base], [p for _, p in base])
+    live = {(tenants[t], p) for t, p in base}
+
+    def churn(n_rm, n_add, tag):
+        rm = rnd.sample(sorted(live), n_rm)
+        add = [(tenants[rnd.randrange(2)], "cmp/%s/%d/%s" % (tag, j, U.rand_topic(rnd, 2))) for j in range(n_add)]
+        for t in tenants:
+            ops = [(1, p) for tt_, p in rm if tt_ == t] + [(0, p) for tt_, p in add if tt_ == t]
+            if ops:
+                eng.retain_apply(t, ops)
+        live.difference_update(rm)
+        live.update(add)
+        return rm, add
+
+    def check():
+        order = sorted(live, key=lambda k: (k[0].encode(), [lv.encode() for lv in k[1].split("/")]))
+        lt = O.LevelTrie(1)
+        got_live = {}
+        for tname in tenants:
+            lids = eng.retain_live_ids(tname)
+            for i, (tn_, tp_) in zip(lids, eng.retain_topics(lids)):
+                got_live[(tn_, tp_)] = i
+        assert set(got_live) == live
+        for k, i in got_live.items():
+            lt.add(k[0], k[1], i)
+        filters = [U.rand_filter(rnd, 6) for _ in range(300)] + ["#", "+", "+/#", "cmp/#", "cmp/+/+/#", "$sys/#"]
+        ft = [rnd.randrange(2) for _ in filters]
+        row, mids = eng.retain_match_batch(tenants, ft, filters)
+        got = U.csr_rows(row, mids)
+        for i, f in enumerate(filters):
+            assert got[i] == sorted(lt.match(tenants[ft[i]], f)), (f, tenants[ft[i]])
+        return got_live, order
+
+    churn(400, 300, "a")  # garbage first: dead ids + an overlay
+    info0 = eng.retain_info()
+    assert info0.loaded_removed > 0 and info0.added_ids > 0
+    check()
+    eng.retain_compact_begin()
+    with pytest.raises(B.BmqError) as ei:
+        eng.retain_compact()  # (refused while a compaction is running)
+    assert ei.value.code == -7
+    rm, add = churn(150, 200, "b")  # logged
+    check()  # the serving generation goes on answering
+    eng.retain_compact_build()
+    rm2, add2 = churn(60, 80, "c")  # logged too: the build is over, the swap is not
+    # a topic removed after `begin` and retained again, one added after `begin` and removed again: the replay keeps the order
+    back = rm[0]
+    eng.retain_apply(back[0], [(0, back[1])])
+    live.add(back)
+    gone = add[0]
+    eng.retain_apply(gone[0], [(1, gone[1])])
+    live.discard(gone)
+    carried, replayed = eng.retain_compact_swap()
+    assert carried == len(base) - 400 + 300 and replayed == 150 + 200 + 60 + 80 + 2
+    got_live, order = check()
+    info1 = eng.retain_info()
+    assert info1.generation == info0.generation + 1
+    # (the replayed ops live in the new generation's overlay / dead set; one more round folds them in: ids become ranks again)
+    eng.retain_compact_begin().retain_compact_build()
+    eng.retain_compact_swap()
+    got_live, order = check()
+    info2 = eng.retain_info()
+    assert info2.loaded_removed == 0 and info2.added_ids == 0 and info2.n_topics == len(live) == info2.id_bound
+    assert [got_live[k] for k in order] == list(range(len(order)))
+    # abort: nothing changes
+    eng.retain_compact_begin()
+    churn(5, 5, "d")
+    eng.retain_compact_abort()
+    with pytest.raises(B.BmqError):
+        eng.retain_compact_swap()
+    check()

@@ -24,6 +24,14 @@ elif sc == "set50":
     print("set50", sum(len(r) for r in rows), flush=True)
 elif sc == "unknown":
     print(b.match_all("no-such-tenant", ["a/b"]), flush=True)
+elif sc == "wedge":
+    import time
+    print(b.match_all(tn[tt[0]], [topics[0]])[0] is not None, eng.poller_stats().n_served, flush=True)
+    eng.poller_control(eng.POLLER_TEST_IGNORE_DOORBELLS)
+    t0 = time.time()
+    r = b.match_all(tn[tt[1]], [topics[1]])
+    st = eng.poller_stats()
+    print("wedge call took %.3f s" % (time.time() - t0), "timeouts", st.n_timeouts, "unserved", st.n_unserved, "fallback", st.n_fallback, "enabled", st.enabled, "running", st.running, flush=True)
 elif sc.startswith("threads"):
     n = int(sc[7:])
     cnt, hsh, sec = b.drive_singletons(tn, tt, (data, off), n_threads=n)
