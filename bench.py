@@ -665,7 +665,12 @@ def ordered_batch_leg(eng, w, host_batch, n, device, torch, np, steps=5, warm=2)
         out[name] = {"rows": bt[3], "ms_per_step": float(np.mean(ms)), "publishes_per_s": n / (float(np.mean(ms)) * 1e-3),
                      "kernel_ms": {"k_walk": st.ms_walk, "k_expand (+ k_fill_adj)": st.ms_expand, "dedup kernels": max(0.0, st.ms_total - st.ms_walk - st.ms_expand),
                                    "all_kernels": st.ms_total},
-                     "n_walked": int(st.n_walked), "n_visit": int(st.n_visit), "n_match": int(st.n_match)}
+                     "n_walked": int(st.n_walked), "n_visit": int(st.n_visit), "n_match": int(st.n_match),
+                     # every shape with its own roofline: the walk's own algorithmic bytes (len + 8 + 32 N_visit per walked row) over its time
+                     "roofline": {"bound": "hbm", "kernel": "k_walk", "peak": 8000.0, "unit": "GB/s",
+                                  "achieved": (st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit) / (max(st.ms_walk, 1e-9) * 1e-3) / 1e9,
+                                  "frac": (st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit) / (max(st.ms_walk, 1e-9) * 1e-3) / 8e12,
+                                  "frac_batch": (st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit + 4 * st.n_match) / (max(st.ms_walk, 1e-9) * 1e-3) / 8e12}}
     eng2.close()
     (row_b, ids_b), (row_c, ids_c), (row_d, ids_d) = res["ordered_with_repeats"], res["ordered_dedup_sorted"], res["ordered_distinct"]
     out["ordered_dedup_sorted"]["rows_equal_undeduplicated_engine"] = bool(torch.equal(row_b, row_c) and torch.equal(ids_b, ids_c))

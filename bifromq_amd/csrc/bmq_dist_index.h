@@ -32,6 +32,11 @@
 
 #include "bmq_build_core.h"
 
+// A tenant's region holds nodes * (1 + BMQ_REGION_SLACK_NUM / 4) two-slot buckets: 1 -> load factor 0.4 (rounds 2-5), 3 -> 0.29.
+#ifndef BMQ_REGION_SLACK_NUM
+#define BMQ_REGION_SLACK_NUM 1
+#endif
+
 namespace bmq {
 
 struct DistIndexStats {
@@ -782,7 +787,7 @@ private:
         trie_used += slots;
         return true;
     }
-    uint32_t buckets_for(uint64_t nodes) const { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nodes + (tiny ? 0 : nodes / 4 + 2), tiny ? 1 : 8), 0x7FFFFFF0ull); }
+    uint32_t buckets_for(uint64_t nodes) const { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nodes + (tiny ? 0 : nodes * BMQ_REGION_SLACK_NUM / 4 + 2), tiny ? 1 : 8), 0x7FFFFFF0ull); }
     // new tenant with room for `nodes` nodes; written to the host mirror (flush_directory uploads)
     bool create_tenant(const std::string& name, uint64_t nodes, uint32_t n_routes) {
         if (tenant_slot.count(name)) return true;

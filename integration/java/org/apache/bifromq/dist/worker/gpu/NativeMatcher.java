@@ -123,6 +123,22 @@ final class NativeMatcher {
     /** Maintenance: a fresh bulk load of the live topics (a new generation of ids). */
     static native void retainCompact(long engine);
 
+    /** The same without the stall (bmq_retain_compact_begin / _build / _swap / _abort): begin = snapshot, build = the load with NO engine lock held
+     *  (matching and add / remove go on, what they change is logged), swap = upload + replay; topic ids are re-numbered. */
+    static native void retainCompactBegin(long engine);
+
+    static native void retainCompactBuild(long engine);
+
+    static native void retainCompactSwap(long engine, long[] out2);
+
+    static native void retainCompactAbort(long engine);
+
+    /** The persistent matcher behind batcherMatchAll / routeCacheGet (bmq_poller_*): out8 = {enabled, running, starts, served, fallback, unserved,
+     *  timeouts, badInput}; pollerControl: 0 off, 1 on, 2 leave now. */
+    static native void pollerStats(long engine, long[] out8);
+
+    static native void pollerControl(long engine, int what);
+
     /** out9 = {topics, tenants, idBound, loaded, loadedRemoved, addedIds, overlayNodes, epoch, generation} */
     static native void retainInfo(long engine, long[] out9);
 

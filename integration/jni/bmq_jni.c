@@ -392,6 +392,55 @@ JNIEXPORT void JNICALL NM(compactAbort)(JNIEnv* env, jclass c, jlong h) {
     const int rc = bmq_compact_abort(ENGINE(h));
     if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_compact_abort", rc);
 }
+/* The retained-topic index's generation change without the stall (round 6; include/bmq.h: bmq_retain_compact_begin / _build / _swap / _abort):
+ * retainCompactBegin from the maintenance thread (snapshot, tens of ms), retainCompactBuild (the load: seconds, no engine lock held),
+ * retainCompactSwap(out2 {topics carried over, ops replayed}) -- topic ids are re-numbered: the adapter's id -> topic cache is dropped. */
+JNIEXPORT void JNICALL NM(retainCompactBegin)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    const int rc = bmq_retain_compact_begin(ENGINE(h));
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_compact_begin", rc);
+}
+JNIEXPORT void JNICALL NM(retainCompactBuild)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    const int rc = bmq_retain_compact_build(ENGINE(h));
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_compact_build", rc);
+}
+JNIEXPORT void JNICALL NM(retainCompactSwap)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
+    (void)c;
+    uint64_t carried = 0, replayed = 0;
+    const int rc = bmq_retain_compact_swap(ENGINE(h), &carried, &replayed);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_retain_compact_swap", rc);
+        return;
+    }
+    const jlong v[2] = {(jlong)carried, (jlong)replayed};
+    if (out) (*env)->SetLongArrayRegion(env, out, 0, 2, v);
+}
+JNIEXPORT void JNICALL NM(retainCompactAbort)(JNIEnv* env, jclass c, jlong h) {
+    (void)c;
+    const int rc = bmq_retain_compact_abort(ENGINE(h));
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_retain_compact_abort", rc);
+}
+/* The persistent matcher behind the batching front (round 6; bmq_poller_*): nothing to call for it to work -- batcherMatchAll / routeCacheGet
+ * use it --; pollerStats(out8 {enabled, running, starts, served, fallback, unserved, timeouts, badInput}) feeds the broker's meters,
+ * pollerControl(what) switches it (0 off, 1 on, 2 leave now). */
+JNIEXPORT void JNICALL NM(pollerStats)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
+    (void)c;
+    bmq_poller_stats ps;
+    const int rc = bmq_poller_stats_get(ENGINE(h), &ps);
+    if (rc != BMQ_OK) {
+        throw_state(env, ENGINE(h), "bmq_poller_stats_get", rc);
+        return;
+    }
+    const jlong v[8] = {(jlong)ps.enabled, (jlong)ps.running, (jlong)ps.n_starts, (jlong)ps.n_served, (jlong)ps.n_fallback, (jlong)ps.n_unserved,
+                        (jlong)ps.n_timeouts, (jlong)ps.n_bad_input};
+    if (out) (*env)->SetLongArrayRegion(env, out, 0, 8, v);
+}
+JNIEXPORT void JNICALL NM(pollerControl)(JNIEnv* env, jclass c, jlong h, jint what) {
+    (void)c;
+    const int rc = bmq_poller_control(ENGINE(h), (int)what);
+    if (rc != BMQ_OK) throw_state(env, ENGINE(h), "bmq_poller_control", rc);
+}
 /* void indexInfo(long engine, long[] out11)   out = bmq_index_info {routes, tenants, nodes, tokens, trieSlots, dictSlots, deviceBytes, epoch, generation,
  * nextRouteId, garbageBytes} -- nextRouteId bounds the ids GenerationalRangeIndex exports, garbageBytes tells it when a compaction pays */
 JNIEXPORT void JNICALL NM(indexInfo)(JNIEnv* env, jclass c, jlong h, jlongArray out) {
