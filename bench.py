@@ -314,6 +314,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Python's cyclic garbage collector is kept out of every timed region of this script.  The workload generator leaves millions of small
+    # objects behind (10 M route keys, 1 M topics as lists of bytes); a generation-2 collection that walks them takes 100-250 ms, and one of
+    # them inside a 5-step leg is how the driver's round-5 line came to read 18.99 ms per pipelined C5 step (the builder's: 0.79) and how
+    # profiles/r06's first full line read p99 1.60 ms / 2.59 G topics/s for a loop whose kernels take 0.28 ms: what exists now is frozen
+    # (never scanned again), what the legs allocate later is collected by reference counting (no cycles are built).
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for i in range(args.warmup):
         churn(i)
         step(i)
@@ -1494,6 +1503,10 @@ def bench_retain(args, rank, world, local_rank, dev, dist):
                 cap = int(d_total.item()) * 2
                 d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
 
+    import gc  # (as in main(): no cyclic collection inside a timed region)
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
