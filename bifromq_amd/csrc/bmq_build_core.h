@@ -23,6 +23,7 @@
 // waits for may be masked off) -- "not ready yet" always means `continue` of the outermost probe loop; every loop is
 // bounded and raises ERR_STUCK instead of hanging the GPU.
 #pragma once
+#include <sched.h>
 #include <stdint.h>
 
 #include "bmq_layout.h"
@@ -66,6 +67,7 @@ template <class T> BMQ_HD T atom_or(T* p, T v) { return __hip_atomic_fetch_or(p,
 // all keys share -- "churn", the eight first-level tokens -- around the caches: hundreds of thousands of requests for a handful of lines,
 // one L2 channel each, and k_b_locate took 114 us however its passes were arranged.)
 template <class T> BMQ_HD T peek_load(const T* p) { return *reinterpret_cast<const volatile T*>(p); }
+BMQ_HD void spin_pause(uint32_t) {}
 #else
 template <class T> BMQ_HD T atom_load(const T* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 template <class T> BMQ_HD void shared_store(T* p, T v) { *p = v; } // ordered by the release store of the flag that follows
@@ -78,6 +80,12 @@ template <class T> BMQ_HD T atom_cas(T* p, T expect, T desired) { // returns the
 template <class T> BMQ_HD T atom_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 template <class T> BMQ_HD T atom_or(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_ACQ_REL); }
 template <class T> BMQ_HD T peek_load(const T* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); } // (the host has one kind of load)
+// A host thread that waits for another thread's publication gives the processor away after a few looks: the publisher may have lost it
+// between its claim and its publication (fuzzer threads on a busy box: the spin bound -- iterations, not time -- ran out: ERR_STUCK
+// without anything being stuck, one run in ten with the CPU test tier running beside it).  On the GPU the publishing lane is running by construction.
+BMQ_HD void spin_pause(uint32_t spins) {
+    if (spins > 64) sched_yield();
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
@@ -393,7 +401,7 @@ BMQ_HD uint32_t dict_intern(const DistIndexMut& ix, const LevelHash& h, uint32_t
         if (t == tag) {
             const uint32_t tok = atom_load(&s->token);
             if (tok == 0) { // its inserter has not published yet: look again (never spin inside a branch)
-                spins++;
+                spin_pause(spins++);
                 continue;
             }
             bool eq = shared_load(&s->len) == len && shared_load(&s->inl[0]) == inl[0] && shared_load(&s->inl[1]) == inl[1] &&
@@ -475,7 +483,7 @@ BMQ_HD uint32_t trie_child(const DistIndexMut& ix, TenantSlot* ten, uint32_t bas
         if (wait) {
             const uint32_t id = atom_load(&wait->node);
             if (id == NONE) { // claimed by another lane a moment ago
-                spins++;
+                spin_pause(spins++);
                 continue;
             }
             slot_abs = wait_abs;
