@@ -671,10 +671,18 @@ def ordered_batch_leg(eng, w, host_batch, n, device, torch, np, steps=5, warm=2)
     for name, engine, bt in shapes:
         ms, st, d_row, d_ids, total = run(engine, bt, steps, bufs[name])
         res[name] = (d_row, d_ids[:total])
+        # ids per wave of k_expand (64 consecutive rows): an ordered batch puts a hot prefix's rows -- the same big filters' subscribers -- side by side
+        rp = d_row.long()
+        edge = torch.arange(0, bt[3] + 64, 64, device=dev).clamp(max=bt[3])
+        per_wave = (rp[edge[1:]] - rp[edge[:-1]]).float()
+        row_len = (rp[1:] - rp[:-1]).float()
+        wave_ids = {"mean": float(per_wave.mean()), "p50": float(per_wave.median()), "p99": float(per_wave.quantile(0.99)), "max": float(per_wave.max()),
+                    "waves_over_16k_ids": int((per_wave > 16384).sum()), "share_of_ids_in_them": float(per_wave[per_wave > 16384].sum() / max(1.0, float(per_wave.sum()))),
+                    "row_max": float(row_len.max())}
         out[name] = {"rows": bt[3], "ms_per_step": float(np.mean(ms)), "publishes_per_s": n / (float(np.mean(ms)) * 1e-3),
                      "kernel_ms": {"k_walk": st.ms_walk, "k_expand (+ k_fill_adj)": st.ms_expand, "dedup kernels": max(0.0, st.ms_total - st.ms_walk - st.ms_expand),
                                    "all_kernels": st.ms_total},
-                     "n_walked": int(st.n_walked), "n_visit": int(st.n_visit), "n_match": int(st.n_match),
+                     "n_walked": int(st.n_walked), "n_visit": int(st.n_visit), "n_match": int(st.n_match), "ids_per_expand_wave": wave_ids,
                      # every shape with its own roofline: the walk's own algorithmic bytes (len + 8 + 32 N_visit per walked row) over its time
                      "roofline": {"bound": "hbm", "kernel": "k_walk", "peak": 8000.0, "unit": "GB/s",
                                   "achieved": (st.topic_bytes + 8 * st.n_topics + 32 * st.n_visit) / (max(st.ms_walk, 1e-9) * 1e-3) / 1e9,

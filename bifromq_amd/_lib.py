@@ -51,7 +51,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_topics", C.c_uint64), ("n_visit", C.c_uint64), ("n_match", C.c_uint64), ("n_ranges", C.c_uint64),
                 ("n_slow_topics", C.c_uint64), ("n_sorted_rows", C.c_uint64), ("topic_bytes", C.c_uint64),
-                ("ms_total", C.c_float), ("ms_walk", C.c_float), ("ms_expand", C.c_float), ("n_walked", C.c_uint32)]
+                ("ms_total", C.c_float), ("ms_walk", C.c_float), ("ms_expand", C.c_float), ("n_walked", C.c_uint32),
+                ("n_split_blocks", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):

@@ -37,10 +37,33 @@ struct Counters { // one per batch slot, zeroed behind every batch (k_reset)
     uint32_t status;
     uint32_t n_walked; // rows of the dense batch the walk ran on (bmq_dedup_adj_kernels.h); 0: the walk ran on the batch itself
     uint32_t adj_bytes; // ST_NEED_ADJ: topic bytes of the dense batch
-    uint32_t pad;
+    uint32_t heavy_count; // blocks k_walk put on BatchArgs.heavy_list (may exceed heavy_cap: the blocks beyond it are not split)
     uint32_t rw_next[64]; // k_retain_walk: the next quad of filters of each partition of the batch (RW_PARTS)
 };
 constexpr uint32_t RW_PARTS = 64;
+// k_expand's tail (round 6): a batch ORDERED by (tenant, topic) -- the shape BatchDistRequest has -- puts the rows under a hot prefix, which
+// match the same big filters, side by side: 1 % of its 64-row blocks hold 4-7 x the ranges and ids of the average block, their waves live
+// 6 x as long (150 k clocks, the duration of the whole launch), and the ones at the end of the dispatch order ARE the launch's tail
+// (+ 48 % on C3's batch ordered).  Whoever writes a block's sums (k_walk, k_fill, k_fill_adj) lists the block if it holds split_ranges
+// ranges or split_ids ids or more; k_expand's grid starts with three helper waves per listed block (rows 16-31, 32-47, 48-63: the heavy work
+// begins first), the block's own wave expands rows 0-15.  The thresholds are the host's: a multiple of the mean block of the batches before
+// (bmq_engine.hip, launch_dist), so that the list -- heavy_cap = n_blocks / EXPAND_HEAVY_DIV entries -- holds the heavy blocks of the batch and
+// not a random part of them (a list that overflows leaves heavy blocks whole wherever they lie, also at the end: measured, no gain then).
+#ifndef BMQ_EXPAND_SPLIT_RANGES
+#define BMQ_EXPAND_SPLIT_RANGES 1024 // thresholds of an engine's first large batch
+#endif
+#ifndef BMQ_EXPAND_SPLIT_IDS
+#define BMQ_EXPAND_SPLIT_IDS 3072
+#endif
+#ifndef BMQ_EXPAND_SPLIT_MULT_X16
+#define BMQ_EXPAND_SPLIT_MULT_X16 32 // afterwards: 32 / 16 = 2 x the mean block (measured 1.5 / 1.75 / 2 / 2.5: profiles/r06/extras/ab_expand_split.txt)
+#endif
+#ifndef BMQ_EXPAND_HEAVY_DIV
+#define BMQ_EXPAND_HEAVY_DIV 4
+#endif
+constexpr uint32_t EXPAND_SPLIT_RANGES = BMQ_EXPAND_SPLIT_RANGES, EXPAND_SPLIT_IDS = BMQ_EXPAND_SPLIT_IDS, EXPAND_SPLIT_MULT_X16 = BMQ_EXPAND_SPLIT_MULT_X16;
+constexpr uint32_t EXPAND_HEAVY_DIV = BMQ_EXPAND_HEAVY_DIV;
+constexpr uint32_t EXPAND_PARTS = 4; // a listed block is expanded by this many waves, 64 / EXPAND_PARTS rows each
 constexpr uint32_t SUPER_SHIFT = 8;   // id counts are summed per 2^SUPER_SHIFT waves (super_sums) on top of the per-wave counts
 constexpr uint32_t SUPER_STRIDE = 16; // ... one sum per 128-byte line: 256 waves bump each, neighbours must not share a line
 
@@ -70,8 +93,12 @@ struct BatchArgs {
     unsigned long long pair_cap;
     SubAlloc* subs;          // [2 * N_SUB] allocators of `pairs` (first N_SUB) and of `spill` (second N_SUB)
     unsigned long long* super_sums; // [(n_blocks >> SUPER_SHIFT + 1) * SUPER_STRIDE] ids per 2^SUPER_SHIFT blocks (zeroed by k_reset)
-    uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, 0} written by k_walk; the last
-                             // k_expand wave of every super-block sums its 256 records into ctr (null: retain direction)
+    uint4* blk_stats;        // [n_blocks] per 64-topic block: {nodes visited, ranges, topic bytes, split} written by k_walk; the last
+                             // k_expand wave of every super-block sums its 256 records into ctr (null: retain direction).  split != 0: the
+                             // block is on heavy_list -- its own k_expand wave expands rows 0-15 only, three helper waves the rest
+    uint32_t* heavy_list;    // [heavy_cap] blocks whose 64 rows hold split_ranges ranges / split_ids ids or more (null: no splitting)
+    uint32_t heavy_cap;
+    uint32_t split_ranges, split_ids;
     uint4* spill;            // LDS range buffer flushes: {begin, count, topic-local, 0}
     unsigned long long spill_cap;
     unsigned long long* wave_sums; // [n_blocks] ids per 64-topic block
@@ -134,6 +161,14 @@ struct AdjArgs {
 };
 
 #if defined(__HIPCC__) || defined(BMQ_WAVE_EMU)
+// (one lane of the wave that knows a block's totals) lists the block for k_expand's helpers if it is heavy; the return value goes into blk_stats[blk].w
+__device__ __forceinline__ uint32_t heavy_mark(const BatchArgs& d, uint32_t blk, unsigned long long ranges, unsigned long long ids) {
+    if (d.heavy_list == nullptr || (ranges < d.split_ranges && ids < d.split_ids)) return 0u;
+    const uint32_t hs = atomicAdd(&d.ctr->heavy_count, 1u);
+    if (hs >= d.heavy_cap) return 0u;
+    d.heavy_list[hs] = blk;
+    return 1u;
+}
 // n contiguous entries of `pairs` from sub-allocator `key` (false: the slice is full, the batch is re-run with a larger buffer)
 __device__ __forceinline__ bool pair_alloc(SubAlloc* subs, unsigned long long pair_cap, uint32_t key, uint32_t n,
                                            unsigned long long& base) {

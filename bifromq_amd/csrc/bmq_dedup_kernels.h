@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void k_fill(BatchArgs a) {
     if (lane == 0) {
         a.wave_sums[blk] = wsum;
         if (wsum) atomicAdd(&a.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], wsum);
-        a.blk_stats[blk] = make_uint4((uint32_t)wvis, (uint32_t)wnp, (uint32_t)wbytes, 0u);
+        a.blk_stats[blk] = make_uint4((uint32_t)wvis, (uint32_t)wnp, (uint32_t)wbytes, heavy_mark(a, blk, wnp, wsum));
     }
 }
 

@@ -114,13 +114,15 @@ struct bmq_engine {
     bool mixed_on = false;                 // k_walk runs in its MIXED instantiation (batches are not grouped by tenant)
     uint32_t mixed_idle = 0;
     int walk_geom = 0;                     // LDS geometry of k_walk: 0 default, 2 smallest lists (bmq_config caps <= 128)
+    double split_mult = EXPAND_SPLIT_MULT_X16 / 16.0; // heavy = this many mean blocks (finish_dist raises it while the list overflows)
+    double blk_mean_ranges = 0, blk_mean_ids = 0; // per 64-row block of the large dist batches so far (k_expand's heavy blocks: launch_dist)
     bool kernel_events = false; // bmq_config.kernel_timing: HIP events around k_walk / k_expand of every dist batch (~4 us each)
 
     // Everything ONE batch in flight needs: per-batch scratch, staging of the host-buffer API, counters, events.  The asynchronous
     // host API (bmq_match_submit / bmq_match_wait) owns two slots of its own, so that the upload of batch i+1 and the download of
     // batch i-1 are in flight while the kernels of batch i run; every other entry point works on slot 0.
     struct BatchSlot {
-        DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave, b_rep, b_visit;
+        DevBuf b_subs, b_super, b_blk_stats, b_dbg_wave, b_rep, b_visit, b_heavy;
         // de-duplication of an ordered batch (bmq_dedup_adj_kernels.h): per-block sums, the dense batch of run heads and its per-row results
         DevBuf b_drow, b_adj_cnt, b_adj_mask, b_adj_super, b_c_topics, b_c_off, b_c_tenant, b_c_rep, b_c_pair_off, b_c_pair_cnt, b_c_route_cnt;
         uint64_t adj_cap = 0; // bytes of b_c_topics in use as the dense batch's topic bytes (grown on ST_NEED_ADJ)
@@ -409,6 +411,17 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     a.qcap = e->cfg.wave_queue_cap;
     a.pcap = e->cfg.wave_pair_cap;
     a.rep = nullptr, a.visit_cnt = nullptr, a.dd_table = nullptr, a.dd_mask = 0, a.dd_gen = 0;
+    // k_expand's heavy blocks (bmq_batch_args.h): listed by whoever writes the per-block sums, expanded by four waves each.  Large batches only:
+    // a small one has no tail to speak of, and its waves own fewer than 64 rows.
+    a.heavy_list = nullptr, a.heavy_cap = 0, a.split_ranges = a.split_ids = 0xFFFFFFFFu;
+    if (a.tpw_shift == 6 && a.n_blocks >= 1024) {
+        a.heavy_cap = a.n_blocks / EXPAND_HEAVY_DIV;
+        // heavy = EXPAND_SPLIT_MULT_X16 / 16 x the mean block of the large batches so far (finish_dist keeps the means)
+        a.split_ranges = e->blk_mean_ranges > 0 ? (uint32_t)std::min(4e9, std::max(64.0, e->blk_mean_ranges * e->split_mult)) : EXPAND_SPLIT_RANGES;
+        a.split_ids = e->blk_mean_ids > 0 ? (uint32_t)std::min(4e9, std::max(256.0, e->blk_mean_ids * e->split_mult)) : EXPAND_SPLIT_IDS;
+        HIPCHK(e, S.b_heavy.ensure(sizeof(uint32_t) * a.heavy_cap));
+        a.heavy_list = S.b_heavy.as<uint32_t>();
+    }
     const bool adj = a.n_topics >= e->dedup_min && e->dedup_sorted; // an ordered batch: equal rows are neighbours (bmq_dedup_adj_kernels.h)
     BatchArgs a2{};  // adj: the dense batch of run heads the walk kernels run on
     AdjArgs g{};
@@ -504,7 +517,7 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
     }
     if (adj) hipLaunchKernelGGL(k_fill_adj, dim3(a.n_blocks), dim3(64), 0, s, a, gf); // (inside ms_expand)
     else if (a.rep) hipLaunchKernelGGL(k_fill, dim3(a.n_blocks), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_expand, dim3(a.n_blocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_expand, dim3(a.n_blocks + (EXPAND_PARTS - 1u) * a.heavy_cap), dim3(64), 0, s, a); // (helper waves of the heavy blocks first)
     if (e->sort_on) {
         if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[4], s));
         hipLaunchKernelGGL(k_sort_rows, dim3(1024), dim3(256), 0, s, a);
@@ -576,6 +589,17 @@ static void print_wave_debug(bmq_engine* e, bmq_engine::BatchSlot& S) {
         for (uint32_t i = 0; i < a.n_blocks; i++) p[0] += h[i].x, p[1] += h[i].y, p[2] += h[i].z, p[3] += h[i].w;
         fprintf(stderr, "[bmq] k_expand waves=%u clocks/wave: head %.0f load+order %.0f prefix %.0f generate %.0f\n", a.n_blocks,
                 p[0] / a.n_blocks, p[1] / a.n_blocks, p[2] / a.n_blocks, p[3] / a.n_blocks);
+        { // the waves' lifetimes, and where in the dispatch order the long ones sit (the last tenth of the blocks is the launch's tail)
+            std::vector<unsigned long long> tot(a.n_blocks);
+            unsigned long long mx_tail = 0;
+            for (uint32_t i = 0; i < a.n_blocks; i++) {
+                tot[i] = (unsigned long long)h[i].x + h[i].y + h[i].z + h[i].w;
+                if (i >= a.n_blocks - a.n_blocks / 10) mx_tail = std::max(mx_tail, tot[i]);
+            }
+            std::sort(tot.begin(), tot.end());
+            fprintf(stderr, "[bmq] k_expand wave lifetimes (clocks): p50 %llu p90 %llu p99 %llu max %llu; longest among the last tenth of the blocks %llu\n",
+                    tot[a.n_blocks / 2], tot[(size_t)(a.n_blocks * 0.9)], tot[(size_t)(a.n_blocks * 0.99)], tot.back(), mx_tail);
+        }
         return;
     }
     double s1 = 0, s2 = 0, s3 = 0, sr = 0, si = 0;
@@ -676,6 +700,19 @@ int finish_dist(bmq_engine* e, bmq_engine::BatchSlot& S, uint64_t* out_total) {
         st.n_sorted_rows = c.sort_count;
         st.topic_bytes = c.topic_bytes;
         st.n_walked = c.n_walked ? c.n_walked : (S.last.rep ? 0u : S.last.n_topics);
+        st.n_split_blocks = S.last.heavy_list ? std::min(c.heavy_count, S.last.heavy_cap) : 0u;
+        if (S.last.heavy_list) { // what a block of the coming batches is measured against (launch_dist): a moving mean over the large batches
+            const double nb = S.last.n_blocks, mr = c.n_ranges / nb, mi = c.total_ids / nb;
+            e->blk_mean_ranges = e->blk_mean_ranges > 0 ? 0.75 * e->blk_mean_ranges + 0.25 * mr : mr;
+            e->blk_mean_ids = e->blk_mean_ids > 0 ? 0.75 * e->blk_mean_ids + 0.25 * mi : mi;
+            // a list that overflowed held a random part of the heavy blocks (no gain): the bar goes up until the list holds them, and comes back slowly
+            constexpr double base = EXPAND_SPLIT_MULT_X16 / 16.0;
+            if (c.heavy_count > S.last.heavy_cap) e->split_mult *= 1.25;
+            else if (c.heavy_count < S.last.heavy_cap / 4) e->split_mult = std::max(base, e->split_mult / 1.05);
+            if (BMQ_EXPERIMENTS && bmq_env("BMQ_DEBUG_HEAVY"))
+                fprintf(stderr, "[bmq] k_expand: %u of %u blocks listed as heavy (room for %u; thresholds %u ranges / %u ids; mean block %.0f / %.0f)\n", c.heavy_count,
+                        S.last.n_blocks, S.last.heavy_cap, S.last.split_ranges, S.last.split_ids, mr, mi);
+        }
         if (S.total_timed) (void)hipEventElapsedTime(&st.ms_total, S.ev[0], S.ev[5]);
         if (S.timed) {
             (void)hipEventElapsedTime(&st.ms_walk, S.ev[1], S.ev[2]);

@@ -100,7 +100,8 @@ __device__ __forceinline__ unsigned long long wave_total_u64(unsigned long long 
 
 // The body of k_expand as a function of (argument block, block index): the kernel below is this and nothing else; the persistent matcher of
 // the batching front (k_poll, bmq_poll_kernel.h) runs the same code behind its walk.
-__device__ __forceinline__ void expand_wave(const BatchArgs& a, const uint32_t block_x) {
+// (blk, r0, r1): the wave expands rows r0 .. r1 - 1 of block blk -- all 64 but for the blocks k_walk listed as heavy (bmq_batch_args.h).
+__device__ __forceinline__ void expand_wave(const BatchArgs& a, const uint32_t block_x, const uint32_t r0 = 0u, const uint32_t r1 = 64u) {
     __shared__ uint32_t s_begin[EXP_K], s_cnt[EXP_K];
     __shared__ uint32_t s_delta[EXP_K + 4]; // order step: first id of every range | then, per SHORT range in order: first id (or route_pos index) - its
                                         // start in the short space; from the top down, per other range in order: its offset in the pass's output
@@ -142,7 +143,9 @@ __device__ __forceinline__ void expand_wave(const BatchArgs& a, const uint32_t b
             if (w0 + lane + 64u * j < blk) acc += w[j];
     }
     if (!valid) nr = 0u, po = 0u, np = 0u;
-    if (a.blk_stats && ((blk & ((1u << SUPER_SHIFT) - 1u)) == (1u << SUPER_SHIFT) - 1u || blk == a.n_blocks - 1)) {
+    const bool mine = lane >= r0 && lane < r1; // this wave's part of the block: offsets come from all 64 rows, ranges and ids from these only
+    if (!mine) np = 0u;
+    if (r0 == 0u && a.blk_stats && ((blk & ((1u << SUPER_SHIFT) - 1u)) == (1u << SUPER_SHIFT) - 1u || blk == a.n_blocks - 1)) {
         // the batch statistics: the last wave of every super-block sums the records the walk left for its (up to) 256 blocks
         unsigned long long v = 0, r = 0, b = 0;
         for (uint32_t i = ((blk >> SUPER_SHIFT) << SUPER_SHIFT) + lane; i <= blk; i += 64) {
@@ -162,19 +165,20 @@ __device__ __forceinline__ void expand_wave(const BatchArgs& a, const uint32_t b
     const unsigned long long row = wbase + (nr_incl - nr);
     const unsigned long long wend = wbase + wtotal;
     const bool range_err = wend >= 0xFFFFFFFFull, no_space = wend > a.out_capacity;
-    if (blk == a.n_blocks - 1 && lane == 0) { // the last wave knows the grand total
+    if (blk == a.n_blocks - 1 && lane == 0 && r0 == 0u) { // the last wave knows the grand total
         a.ctr->total_ids = wend;
         *a.out_total = wend;
     }
     if ((range_err || no_space) && lane == 0) atomicOr(&a.ctr->status, range_err ? (uint32_t)ST_RANGE : (uint32_t)ST_NOSPACE);
     const bool writable = !(status & ST_RERUN) && !range_err && !no_space; // rows in front of the overflow are still written
-    if (valid && !range_err) {
+    if (valid && mine && !range_err) {
         a.out_row_ptr[t] = (uint32_t)row;
         if (t == a.n_topics - 1) a.out_row_ptr[a.n_topics] = (uint32_t)(row + nr);
     }
     if (!writable || wtotal == 0) return;
     const uint32_t np_incl = wave_incl_scan(np);
     const uint32_t ptotal = read_lane(np_incl, 63);
+    if (ptotal == 0) return; // (a part of a split block without ranges)
     const uint32_t pexcl = np_incl - np;
     // the walk lays the ranges of a wave's 64 rows out as ONE contiguous piece of `pairs`, row after row (rows finished by k_walk_slow or
     // filled in by k_fill live elsewhere: then every entry is fetched from its own row's list)
@@ -255,7 +259,7 @@ __device__ __forceinline__ void expand_wave(const BatchArgs& a, const uint32_t b
     for (uint32_t i = 0; i < EXP_EPL; i++) eb[i] = copy_here(pf[i].begin), ec[i] = copy_here(pf[i].count);
     const unsigned long long xc1 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t pass = 0;
-    unsigned long long out_done = 0; // output elements produced by earlier LDS passes
+    unsigned long long out_done = read_lane(nr_incl - nr, r0); // output elements in front of the pass: the block's rows in front of this wave's part, then what earlier LDS passes produced
     uint32_t carry_last = 0;         // last id of the previous pass's last range
     for (uint32_t k0 = 0; k0 < ptotal; pass++) {
         const unsigned long long xp0 = dbg_x ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -499,6 +503,23 @@ __device__ __forceinline__ void expand_wave(const BatchArgs& a, const uint32_t b
     }
 }
 
-__global__ __launch_bounds__(64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) { expand_wave(a, blockIdx.x); }
+// Grid: [EXPAND_PARTS - 1 helper waves per entry of heavy_list's capacity] [one wave per block].  The helpers come first in the dispatch
+// order: the launch begins with the heavy blocks' rows 16-63, a helper without an entry leaves after one scalar load.
+__global__ __launch_bounds__(64, BMQ_EXP_MIN_WAVES) void k_expand(BatchArgs a) {
+    uint32_t bx = blockIdx.x;
+    if (a.heavy_list == nullptr) return expand_wave(a, bx);
+    constexpr uint32_t HP = EXPAND_PARTS - 1u, RP = 64u / EXPAND_PARTS;
+    const uint32_t n_help = HP * a.heavy_cap;
+    if (bx < n_help) {
+        const uint32_t listed = min(uniform_word(&a.ctr->heavy_count), a.heavy_cap);
+        const uint32_t h = bx / HP, part = 1u + bx % HP;
+        if (h >= listed) return;
+        return expand_wave(a, uniform_word(&a.heavy_list[h]), part * RP, (part + 1u) * RP);
+    }
+    bx -= n_help;
+    if (bx >= a.n_blocks) return;
+    const bool split = uniform_word(reinterpret_cast<const uint32_t*>(a.blk_stats + bx) + 3) != 0u;
+    expand_wave(a, bx, 0u, split ? RP : 64u);
+}
 
 } // namespace bmq

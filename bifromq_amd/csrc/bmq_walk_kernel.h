@@ -546,7 +546,7 @@ __device__ __forceinline__ void walk_wave(const BatchArgs& a, const uint32_t blo
             if (wsum) atomicAdd(&d.super_sums[(size_t)(blk >> SUPER_SHIFT) * SUPER_STRIDE], wsum);
             // statistics: a plain store per wave.  (Atomics were measured twice: on the batch counters they set the kernel's duration,
             // three more per wave on the super-block's line still cost +20 us per 1 M topics and +7 us per 10 k.)
-            d.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, 0u);
+            d.blk_stats[blk] = make_uint4((uint32_t)wvis, total_pairs, (uint32_t)wbytes, heavy_mark(d, blk, total_pairs, wsum)); // (.w: k_expand splits the block)
         }
         if (BMQ_DBG(d, 8u) && d.dbg_wave) { // residency census: when and where this wave ran (tools: BMQ_DEBUG=8)
             const unsigned long long clk3 = __builtin_amdgcn_s_memtime();

@@ -96,6 +96,9 @@ typedef struct bmq_stats {
     float ms_expand;         /* ... of the expand kernel alone (0 unless bmq_config.kernel_timing)          */
     uint32_t n_walked;       /* rows the walk kernel walked: n_topics, fewer with bmq_config.dedup_sorted (the distinct  */
                              /* rows), 0 = not counted (the hashing de-duplication)                                       */
+    uint32_t n_split_blocks; /* 64-row blocks of the batch the expand kernel gave to four waves each (blocks of more than  */
+                             /* ~2 x the ranges / ids of the mean block: batches of 65536 rows and more)                   */
+    uint32_t reserved0;
 } bmq_stats;
 
 typedef struct bmq_index_info {

@@ -237,6 +237,48 @@ def test_grouped_batch_equals_ungrouped(eng):
         assert np.array_equal(b_rp, res.row_ptr.astype(np.int64)) and np.array_equal(b, res.routes)
 
 
+def test_expand_gives_heavy_blocks_to_four_waves_each(eng):
+    """k_expand (round 6): a batch ORDERED by (tenant, topic) -- what BatchDistRequest carries -- puts the rows under a hot prefix side by side;
+    the 64-row blocks that hold more than ~2 x the ranges / ids of the mean block are listed by k_walk and expanded by four waves each (rows
+    0-15 by the block's own wave, three helper waves in front of the grid for the rest).  The ordered batch must give the rows of the batch
+    as generated -- which the oracle tests check --, with repeats and without, blocks must in fact have been split, and an engine's first
+    large batch (absolute thresholds) must agree with its later ones (thresholds from the batches before)."""
+    w = B.Workload(0xB1F20009, 200, 5000, 1)
+    e2 = B.Engine(device=0)  # a fresh engine: its first large batch has no history to take thresholds from
+    try:
+        for engine in (eng, e2):
+            engine.rebuild(packed=w.keys_packed())
+        kv = O.KV(packed=w.keys_packed())
+        tn = w.tenants()
+        n = 300_000
+        data, off, tt = w.topics(0xB1F20009 + 5, n)
+        row, ids = eng.match_batch(tn, tt, packed_topics=(data, off))
+        assert eng.stats().n_visit == int(kv.count_visits(tn, tt, (data, off)).sum())
+        topics = unpack(data, off)
+        order = np.asarray(sorted(range(n), key=lambda i: (int(tt[i]), topics[i])), dtype=np.int64)
+        head = np.ones(n, dtype=bool)
+        head[1:] = [tt[order[i]] != tt[order[i - 1]] or topics[order[i]] != topics[order[i - 1]] for i in range(1, n)]
+        for name, sel in (("ordered, repeats kept", order), ("ordered, every topic once", order[head])):
+            sd, so = U.sub_packed(data, off, sel)
+            want_rp, want = U.csr_select(row, ids, sel)
+            splits = []
+            for engine in (e2, eng, eng):
+                grow, gids = engine.match_batch(tn, tt[sel], packed_topics=(sd, so))
+                assert np.array_equal(want_rp, grow.astype(np.int64)) and np.array_equal(want, gids), name
+                splits.append(engine.stats().n_split_blocks)
+            assert min(splits) > 0, (name, splits)  # the hot prefixes' blocks were split, with either kind of threshold
+            per_block = np.add.reduceat(np.diff(want_rp), np.arange(0, len(sel), 64))
+            assert per_block.max() > 3 * per_block.mean(), name  # (what makes this batch a test of the path)
+        # ... and a slice of the ordered batch against the semantic oracle directly
+        pick = order[:: max(1, n // 3000)]
+        sd, so = U.sub_packed(data, off, pick)
+        res, _ = kv.match_semantic_batch(tn, tt[pick], (sd, so), threads=U.host_threads())
+        b_rp, b = U.csr_select(row, ids, pick)
+        assert np.array_equal(b_rp, res.row_ptr.astype(np.int64)) and np.array_equal(b, res.routes)
+    finally:
+        e2.close()
+
+
 def test_in_batch_dedup_changes_nothing_but_the_work():
     """Identical (tenant, topic) rows of a batch are walked once (k_dedup / k_fill: matchAll takes a Set<String>,
     TenantRouteMatcher.java:67-78); every row keeps its own row.  An engine that de-duplicates every batch and one that never does must

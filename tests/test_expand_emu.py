@@ -69,8 +69,8 @@ def test_the_match_kernels_of_the_dist_direction_under_the_wave_emulator(tmp_pat
     machine code is unchanged, tools/kernel_isa.py) and run on indexes the product's own builder makes on the host -- fresh and after mutations -- against a
     brute force over the model's route keys: '$' topics, empty levels, unknown tenants, waves that hold several tenants, batches in any order, topics and
     filters deeper than FAST_LEVELS, spill chains of the stack and the range buffer, and ordered batches full of repeats through the whole
-    bmq_config.dedup_sorted pipeline (neighbour compare -> dense batch -> walk kernels -> k_fill_adj -> k_expand); the harness fails if its cases miss
-    one of those paths."""
+    bmq_config.dedup_sorted pipeline (neighbour compare -> dense batch -> walk kernels -> k_fill_adj -> k_expand), and k_expand's heavy blocks -- listed by
+    k_walk / k_fill_adj, expanded by four waves each, the list overflowing; the harness fails if its cases miss one of those paths."""
     exe = str(tmp_path / "walk_emu")
     cmd = ["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "bifromq_amd", "csrc"), "-I", os.path.join(ROOT, "tools", "emu"),
            os.path.join(ROOT, "tools", "emu", "walk_emu.cpp"), os.path.join(ROOT, "bifromq_amd", "csrc", "bmq_codec.cpp"), "-o", exe, "-pthread"]

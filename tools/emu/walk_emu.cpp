@@ -80,6 +80,7 @@ template <class T> static T* buf(std::vector<uint8_t>& store, size_t n) {
 struct Coverage {
     uint64_t rows = 0, ids = 0, batches = 0, mixed = 0, slow_rows = 0, spills = 0, chunked = 0, sorted_rows = 0, after_apply = 0, two_tenant_waves = 0;
     uint64_t adj_batches = 0, adj_rows = 0, adj_walked = 0, adj_slow = 0;
+    uint64_t split_blocks = 0, split_overflow = 0, split_adj = 0; // k_expand: heavy blocks expanded by four waves, blocks the list had no room for
 };
 
 // one batch through walk (+ slow) + expand; rows -> sorted id lists
@@ -97,6 +98,7 @@ static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tn
     uint8_t* pal = pstore.data() + ((16 - ((uintptr_t)pstore.data() & 15)) & 15);
     memcpy(pal, pb.data(), pb.size());
     const uint32_t nb = (n + (1u << tpw_shift) - 1) >> tpw_shift, n_super = ((nb - 1) >> SUPER_SHIFT) + 1;
+    std::vector<uint8_t> s_heavy;
     std::vector<uint8_t> s_po, s_pc, s_rc, s_pairs, s_subs, s_super, s_stats, s_spill, s_ws, s_slow, s_scr, s_sort, s_ctr, s_row, s_ids, s_tot;
     std::vector<uint8_t> s_drow, s_mask, s_cnt, s_asup, s_ctop, s_coff, s_cten, s_crep, s_cpo, s_cpc, s_crc, s_vis; // bmq_config.dedup_sorted: the dense batch and its results
     BatchArgs a{};
@@ -116,6 +118,8 @@ static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tn
         a.spill = buf<uint4>(s_spill, a.spill_cap), a.wave_sums = buf<unsigned long long>(s_ws, nb);
         a.slow_list = buf<uint32_t>(s_slow, a.slow_cap), a.scratch = buf<uint32_t>(s_scr, a.scratch_cap), a.sort_list = buf<uint32_t>(s_sort, a.sort_cap);
         a.ctr = buf<Counters>(s_ctr, 1);
+        a.heavy_list = nullptr, a.heavy_cap = 0;
+        if (tpw_shift == 6 && (n & 1u)) a.heavy_cap = 1 + (n >> 1) % 3, a.heavy_list = buf<uint32_t>(s_heavy, a.heavy_cap), a.split_ranges = 24, a.split_ids = 40; // (a list of 1-3 entries: it overflows)
         a.out_row_ptr = buf<uint32_t>(s_row, n + 1), a.out_ids = buf<uint32_t>(s_ids, out_cap), a.out_capacity = out_cap;
         a.out_total = buf<unsigned long long>(s_tot, 1);
         wemu::grid_size() = nb;
@@ -168,8 +172,16 @@ static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tn
         for (uint32_t i = 0; i < N_SUB; i++) spilled += a.subs[N_SUB + i].used;
         if (spilled) cov.spills++;
     }
-    wemu::grid_size() = nb;
-    for (uint32_t b = 0; b < nb; b++) wemu::run_wave(b, [&] { k_expand(a); });
+    { // k_expand's grid as launch_dist lays it out: the helper waves of the heavy blocks in front
+        const uint32_t grid = nb + (EXPAND_PARTS - 1) * a.heavy_cap;
+        wemu::grid_size() = grid;
+        for (uint32_t b = 0; b < grid; b++) wemu::run_wave(b, [&] { k_expand(a); });
+        const uint32_t listed = std::min(a.ctr->heavy_count, a.heavy_cap);
+        cov.split_blocks += listed, cov.split_overflow += a.ctr->heavy_count - listed;
+        if (adj) cov.split_adj += listed;
+        for (uint32_t i = 0; i < listed; i++)
+            if (a.heavy_list[i] >= nb || a.blk_stats[a.heavy_list[i]].w != 1u) FAIL("heavy list entry %u: block %u is not flagged\n", i, a.heavy_list[i]);
+    }
     if (a.ctr->status & (ST_NOSPACE | ST_RANGE | ST_RERUN)) FAIL("expand: status %u\n", a.ctr->status);
     if (*a.out_total != a.out_row_ptr[n]) FAIL("total %llu, row_ptr[n] %u\n", *a.out_total, a.out_row_ptr[n]);
     rows.assign(n, {});
@@ -332,6 +344,10 @@ int main(int argc, char** argv) {
            rounds, (unsigned long long)cov.batches, (unsigned long long)cov.mixed, (unsigned long long)cov.after_apply * 4, (unsigned long long)cov.rows, (unsigned long long)cov.ids,
            (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills, (unsigned long long)cov.sorted_rows, (unsigned long long)cov.adj_batches, (unsigned long long)cov.adj_rows,
            (unsigned long long)cov.adj_walked, (unsigned long long)cov.adj_slow);
+    printf("k_expand splitting: %llu heavy blocks expanded by four waves (%llu of them behind k_fill_adj), %llu more the list had no room for\n", (unsigned long long)cov.split_blocks,
+           (unsigned long long)cov.split_adj, (unsigned long long)cov.split_overflow);
+    if (rounds >= 8 && (!cov.split_blocks || !cov.split_overflow || !cov.split_adj)) FAIL("the cases missed k_expand's split blocks: %llu listed, %llu overflowed, %llu in ordered batches\n",
+                                                                                         (unsigned long long)cov.split_blocks, (unsigned long long)cov.split_overflow, (unsigned long long)cov.split_adj);
     if (rounds >= 8 && (!cov.mixed || !cov.slow_rows || !cov.spills || !cov.adj_slow || cov.adj_walked >= cov.adj_rows)) FAIL("the cases missed a path: mixed %llu slow %llu spills %llu\n", (unsigned long long)cov.mixed, (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills);
     return 0;
 }
