@@ -493,7 +493,8 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
         const dim3 grid((a.debug_flags & 32u) ? ((a.n_blocks + 7u) / 8u) * 8u : a.n_blocks), block(64);
         S.ran_mixed = e->mixed_on;
         const int g = e->walk_geom;
-#define BMQ_WALK_LAUNCH(TC, QC, PC)                                                        \
+#define BMQ_WALK_LAUNCH(...) BMQ_WALK_LAUNCH3(__VA_ARGS__)
+#define BMQ_WALK_LAUNCH3(TC, QC, PC)                                                       \
     do {                                                                                   \
         if (e->mixed_on) hipLaunchKernelGGL((k_walk<TC, QC, PC, true>), grid, block, 0, s, w); \
         else hipLaunchKernelGGL((k_walk<TC, QC, PC, false>), grid, block, 0, s, w);            \
@@ -501,9 +502,10 @@ int launch_dist(bmq_engine* e, bmq_engine::BatchSlot& S, BatchArgs& a) {
 #if BMQ_EXPERIMENTS
         if (a.debug_flags & 16u) hipLaunchKernelGGL(k_occ_probe, grid, block, 0, s, a); // (experiments: its census replaces k_walk's)
 #endif
-        if (g == 2) BMQ_WALK_LAUNCH(192, 128, 128); // smallest lists: every overflow path runs all the time (tests)
-        else BMQ_WALK_LAUNCH(512, 176, 152);
+        if (g == 2) BMQ_WALK_LAUNCH(BMQ_WALK_GEOM_SMALLEST); // smallest lists: every overflow path runs all the time (tests)
+        else BMQ_WALK_LAUNCH(BMQ_WALK_GEOM_DEFAULT);
 #undef BMQ_WALK_LAUNCH
+#undef BMQ_WALK_LAUNCH3
     }
     if (e->kernel_events) HIPCHK(e, hipEventRecord(S.ev[2], s));
     // The two repair kernels run only while batches need them (finish_dist turns them on -- and completes the batch that found
@@ -812,8 +814,8 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     if (const char* v = bmq_env("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
     if ((c.wave_queue_cap != 0 && c.wave_queue_cap != 128) || (c.wave_pair_cap != 0 && c.wave_pair_cap != 128)) return BMQ_E_INVAL;
     const bool smallest = c.wave_queue_cap == 128 || c.wave_pair_cap == 128;
-    c.wave_queue_cap = smallest ? 128 : 176; // (what bmq_config reports back / BatchArgs carries: the geometry in use)
-    c.wave_pair_cap = smallest ? 128 : 152;
+    c.wave_queue_cap = smallest ? WALK_QC_SMALLEST : WALK_QC_DEFAULT; // (what bmq_config reports back / BatchArgs carries: the geometry in use)
+    c.wave_pair_cap = smallest ? WALK_PC_SMALLEST : WALK_PC_DEFAULT;
     auto e = std::make_unique<bmq_engine>();
     e->cfg = c;
     e->device = c.device;

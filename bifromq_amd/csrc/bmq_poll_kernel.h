@@ -85,7 +85,7 @@ struct PollArgs {
 __device__ __forceinline__ uint32_t poll_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void poll_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-using PollGeom = WalkLds<512, 176, 152, true>; // the MIXED instantiation: a generation holds requests of any tenants, in arrival order
+using PollGeom = WalkLds<BMQ_WALK_GEOM_DEFAULT, true>; // the MIXED instantiation: a generation holds requests of any tenants, in arrival order
 
 __global__ __launch_bounds__(64) void k_poll(PollArgs p) {
     __shared__ __align__(16) uint32_t lds[PollGeom::BYTES / 4];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_poll(PollArgs p) {
             a.scratch = nullptr, a.scratch_cap = 0;
             a.sort_list = p.sort_list + w * 64u, a.sort_cap = 64;
             a.ctr = ctr;
-            a.qcap = 176, a.pcap = 152;
+            a.qcap = WALK_QC_DEFAULT, a.pcap = WALK_PC_DEFAULT;
             // What the wave is about to trust, looked at first: every piece inside the copy, offsets ascending, tenant indices inside the
             // batch's tenant table.  A generation that fails is handed back untouched (POLL_BAD_INPUT): nothing a host thread wrote can make a
             // resident wave run off into unmapped memory.
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) void k_poll(PollArgs p) {
                 continue;
             }
 #endif
-            walk_wave<512, 176, 152, true>(a, 0u, lds);
+            walk_wave<BMQ_WALK_GEOM_DEFAULT, true>(a, 0u, lds);
 #if BMQ_EXPERIMENTS
             if (hook == 4u) { // (bring-up) the walk only
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");

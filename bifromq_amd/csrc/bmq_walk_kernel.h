@@ -35,7 +35,12 @@ constexpr uint32_t WALK_MAX_TENANTS = 4; // distinct tenants a wave of the group
 __device__ __forceinline__ uint32_t walk_meta(uint32_t tl, uint32_t tokpos, uint32_t rem) { return tl | (tokpos << 6) | (rem << 16); }
 constexpr uint32_t WALK_META_CHILD = 64u - 65536u; // (wraps: + 1 token position, - 1 level behind)
 
-// TC: token table, entries (<= 1023); QC: work stack, items; PC: matched-range buffer, entries
+// The instantiations the engine launches: the default geometry and the smallest lists (tests: every overflow path runs all the time)
+#define BMQ_WALK_GEOM_DEFAULT 512, 176, 152
+#define BMQ_WALK_GEOM_SMALLEST 192, 128, 128
+constexpr uint32_t WALK_QC_DEFAULT = 176, WALK_PC_DEFAULT = 152, WALK_QC_SMALLEST = 128, WALK_PC_SMALLEST = 128;
+
+// TC: token table, entries (<= 1023); QC: work stack, items; PC: matched-range buffer, entries (both >= 128: one sink pushes / emits up to 128)
 template <int TC, int QC, int PC, bool MIXED> struct WalkLds { // byte offsets into the wave's LDS
     static constexpr uint32_t TOK = 0;                    // u32 [TC]       tokens of the wave's topics, topic after topic | phase 3: cnt_pairs, cnt_routes, cursor
     static constexpr uint32_t STK = TOK + TC * 4;         // uint2 [QC]     work stack (node id, meta)     | phase 1: staged topic bytes from here on
@@ -56,8 +61,20 @@ template <int TC, int QC, int PC, bool MIXED> struct WalkLds { // byte offsets i
     static constexpr uint32_t WAVES = MIXED && WAVES_LDS > 5 ? 5 : WAVES_LDS;
     static_assert(3 * 64 * 4 <= STK && PC % 8 == 0 && QC % 8 == 0 && STK % 16 == 0 && WAVES >= 1 && TC >= 2 * FAST_LEVELS && TC <= 1023, "layout");
     static_assert(FAST_LEVELS <= 32, "walk_meta keeps the levels behind an item in 5 bits");
+    static_assert(QC >= 128 && PC >= 128, "one sink pushes up to 128 items and emits up to 128 ranges into an empty list");
     static_assert(STK + (QC + 64) * 8 <= BYTES, "a round reads 64 stack slots from `tail` on, whatever is there");
 };
+
+// (emulator builds only: which of the cold paths of the work stack and the range buffer a harness has driven through)
+#ifdef BMQ_WAVE_EMU
+struct WalkCoverage {
+    unsigned long long flushes = 0, parks = 0, restores = 0;
+};
+inline WalkCoverage walk_cov;
+#define BMQ_WALK_COV(field) do { if (threadIdx.x == 0) walk_cov.field++; } while (0)
+#else
+#define BMQ_WALK_COV(field) do { } while (0)
+#endif
 
 // The lane id behind an opaque copy: address arithmetic derived from it cannot be hoisted out of the walk loop (the compiler otherwise
 // precomputes a dozen lane-dependent LDS addresses at the kernel's entry, keeps them alive across all phases and spills them to scratch
@@ -214,6 +231,7 @@ __device__ __forceinline__ void walk_wave(const BatchArgs& a, const uint32_t blo
             const uint32_t n_own = (uint32_t)__popcll(m_own), n_emit = n_own + (uint32_t)__popcll(m_hash);
             if (__builtin_expect(pcount + n_emit > (uint32_t)PC, 0)) { // (cold) this round's matches do not fit: the buffer is flushed to the spill area first
                 const BatchArgs& c = a;
+                BMQ_WALK_COV(flushes);
                 uint32_t cb;
                 if (spill_alloc(c, ln, pcount, cb)) {
                     if (ln == 0) c.spill[cb] = make_uint4(fl_base, fl_len, 0u, 0u);
@@ -241,6 +259,7 @@ __device__ __forceinline__ void walk_wave(const BatchArgs& a, const uint32_t blo
             const uint32_t n_l = (uint32_t)__popcll(m_l), n_push = n_l + (uint32_t)__popcll(m_h);
             if (__builtin_expect(tail + n_push > (uint32_t)QC, 0)) { // (cold)
                 const BatchArgs& c = a;
+                BMQ_WALK_COV(parks);
                 uint32_t cb;
                 if (spill_alloc(c, ln, tail, cb)) {
                     if (ln == 0) c.spill[cb] = make_uint4(qs_base, qs_len, 0u, 0u);
@@ -266,6 +285,7 @@ __device__ __forceinline__ void walk_wave(const BatchArgs& a, const uint32_t blo
             const uint32_t ln = lane_here();
             if (__builtin_expect(tail == 0, 0)) { // (cold) the stack ran dry: take the most recently parked chunk back
                 const BatchArgs& c = a;
+                BMQ_WALK_COV(restores);
                 const uint32_t hx = sgpr(c.spill[qs_base].x), hy = sgpr(c.spill[qs_base].y);
                 for (uint32_t i = ln; i < qs_len; i += 64) {
                     const uint4 r = c.spill[qs_base + 1 + i];

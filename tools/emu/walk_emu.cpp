@@ -105,7 +105,7 @@ static int run_batch(const DistIndexView& ix, const std::vector<std::string>& tn
     a.ix = ix;
     a.tenants = tb.data(), a.tenant_off = toff.data(), a.n_tenants = (uint32_t)tnames.size();
     a.topic_tenant = tt.data(), a.topics = pal, a.topic_off = poff.data(), a.n_topics = n;
-    a.pair_cap = 1u << 16, a.spill_cap = 1u << 16, a.slow_cap = n + 8, a.scratch_cap = 1u << 20, a.sort_cap = n + 8;
+    a.pair_cap = 1u << 19, a.spill_cap = 1u << 21, a.slow_cap = n + 8, a.scratch_cap = 1u << 20, a.sort_cap = n + 8;
     a.n_blocks = nb, a.tpw_shift = tpw_shift;
     a.qcap = QC, a.pcap = PC;
     const uint64_t out_cap = 1u << 20;
@@ -248,6 +248,16 @@ int main(int argc, char** argv) {
             std::set<std::string> ks;
             const size_t nk = 1 + rnd(round % 3 == 0 ? 4000 : 600);
             for (size_t i = 0; i < nk; i++) ks.insert(rand_key(max_depth));
+            if (round % 4 == 1) // a family that branches at every level (tenant "x"): every mix of literal and '+' over five levels, and '#' behind every prefix of those --
+                                // a wave of such topics holds hundreds of pending items (both stacks of the work list are parked) and emits more than 64 ranges in one sink
+                for (uint32_t m = 0; m < 32; m++)
+                    for (uint32_t d = 1; d <= 5; d++) {
+                        std::string f;
+                        for (uint32_t l = 0; l < d; l++) f += (l ? "/" : "") + (((m >> l) & 1u) ? std::string("+") : "w" + std::to_string(l));
+                        if (d < 5 && (m >> d) != 0) continue;
+                        ks.insert(encode_route_key("x", f, 1, std::string("0\0wide\0d", 8) + std::to_string(m))); // (below depth 5: a node with routes of its own AND '#' routes)
+                        if (d < 5) ks.insert(encode_route_key("x", f + "/#", 1, std::string("0\0wide#\0d", 9) + std::to_string(m)));
+                    }
             for (size_t i = 0; i < 40; i++) ks.insert(encode_route_key("t", "a/b", 1, "0" + std::string("\0", 1) + "fan" + std::to_string(i) + std::string("\0d", 2))); // one filter, many receivers
             std::vector<uint8_t> bytes;
             std::vector<uint32_t> off{0};
@@ -303,7 +313,14 @@ int main(int argc, char** argv) {
                 const uint32_t tpw_shift = shifts[(round + bt) % 3];
                 const uint32_t n0 = 1 + (uint32_t)rnd(tpw_shift == 6 ? 330 : 60);
                 std::vector<std::pair<uint32_t, std::string>> rowsrc;
-                for (uint32_t i = 0; i < n0; i++) rowsrc.emplace_back((uint32_t)rnd(tnames.size()), rnd(12) == 0 ? std::string() : rand_topic(max_depth));
+                for (uint32_t i = 0; i < n0; i++) {
+                    if (round % 4 == 1 && rnd(3) != 0) { // the branching family's topics: the full path, a prefix of it, one level off
+                        std::string t;
+                        const uint32_t d = rnd(3) == 0 ? 1 + (uint32_t)rnd(5) : 5, off = rnd(5) == 0 ? (uint32_t)rnd(5) : 99;
+                        for (uint32_t l = 0; l < d; l++) t += (l ? "/" : "") + (l == off ? std::string("zz") : "w" + std::to_string(l));
+                        rowsrc.emplace_back(2u /* "x" */, t);
+                    } else rowsrc.emplace_back((uint32_t)rnd(tnames.size()), rnd(12) == 0 ? std::string() : rand_topic(max_depth));
+                }
                 const bool grouped = bt != 2; // the third batch of a phase arrives in any order: waves hold many tenants each (MIXED)
                 const bool ordered = bt == 3;  // the fourth: ordered by (tenant, topic), every row up to four times -- through the neighbour-compare kernels (dedup_sorted)
                 if (ordered) {
@@ -319,7 +336,7 @@ int main(int argc, char** argv) {
                 const bool small_lists = (round + bt) % 2 == 1; // the smallest LDS lists: stack and range buffer spill all the time
                 const DistIndexView ix = h.view();
                 const uint32_t n = (uint32_t)topics.size(); // (the ordered batch grew)
-                const int rc = small_lists ? run_batch<192, 128, 128>(ix, tnames, tt, topics, tpw_shift, got, cov, ordered) : run_batch<512, 176, 152>(ix, tnames, tt, topics, tpw_shift, got, cov, ordered);
+                const int rc = small_lists ? run_batch<BMQ_WALK_GEOM_SMALLEST>(ix, tnames, tt, topics, tpw_shift, got, cov, ordered) : run_batch<BMQ_WALK_GEOM_DEFAULT>(ix, tnames, tt, topics, tpw_shift, got, cov, ordered);
                 if (rc) FAIL("round %d phase %d batch %d (n %u, tpw %u, %s, %s lists) failed (seed %llu)\n", round, phase, bt, n, 1u << tpw_shift, ordered ? "ordered + dedup_sorted" : grouped ? "grouped" : "any order",
                              small_lists ? "smallest" : "default", (unsigned long long)seed);
                 for (uint32_t i = 0; i < n; i++) {
@@ -348,6 +365,8 @@ int main(int argc, char** argv) {
            (unsigned long long)cov.split_adj, (unsigned long long)cov.split_overflow);
     if (rounds >= 8 && (!cov.split_blocks || !cov.split_overflow || !cov.split_adj)) FAIL("the cases missed k_expand's split blocks: %llu listed, %llu overflowed, %llu in ordered batches\n",
                                                                                          (unsigned long long)cov.split_blocks, (unsigned long long)cov.split_overflow, (unsigned long long)cov.split_adj);
+    printf("k_walk's work stack and range buffer: the range buffer flushed %llu times, the stack parked %llu times, %llu chunks taken back\n", walk_cov.flushes, walk_cov.parks, walk_cov.restores);
+    if (rounds >= 8 && (walk_cov.flushes < 100 || walk_cov.parks < 100 || walk_cov.restores < 100)) FAIL("the cases hardly touched the cold paths of k_walk's lists\n");
     if (rounds >= 8 && (!cov.mixed || !cov.slow_rows || !cov.spills || !cov.adj_slow || cov.adj_walked >= cov.adj_rows)) FAIL("the cases missed a path: mixed %llu slow %llu spills %llu\n", (unsigned long long)cov.mixed, (unsigned long long)cov.slow_rows, (unsigned long long)cov.spills);
     return 0;
 }
