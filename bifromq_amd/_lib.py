@@ -45,7 +45,7 @@ def build(force: bool = False) -> None:
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("wave_queue_cap", C.c_uint32),
                 ("wave_pair_cap", C.c_uint32), ("slow_scratch_mb", C.c_uint32), ("kernel_timing", C.c_uint32),
-                ("dedup_min_topics", C.c_uint32), ("dedup_sorted", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("dedup_min_topics", C.c_uint32), ("dedup_sorted", C.c_uint32), ("region_slack", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class Stats(C.Structure):

@@ -32,9 +32,13 @@
 
 #include "bmq_build_core.h"
 
-// A tenant's region holds nodes * (1 + BMQ_REGION_SLACK_NUM / 4) two-slot buckets: 1 -> load factor 0.4 (rounds 2-5), 3 -> 0.29.
+// A tenant's region holds nodes * (1 + slack / 4) two-slot buckets (DistIndex::slack_num, bmq_config.region_slack): 1 -> load factor 0.4
+// (rounds 2-5), 3 -> 0.29, 6 -> 0.2 (the default since round 6).  What the slack buys is fewer SECOND probes: at 0.4 a publish of the survey's
+// workload pays 1.24 line fetches beyond the home buckets of its 10.2 probes (a home bucket full of other edges; a Bloom false positive walks on
+// to the first bucket with a free slot), at 0.29 0.55, at 0.2 0.28, at 0.125 0.12 -- and k_walk, which is bound by the rate of its line requests,
+// takes 0.212 / 0.198 / 0.195 / 0.194 ms (profiles/r06/extras/ab_region_slack.txt).  The price is memory: 64 bytes x (1 + slack / 4) per node.
 #ifndef BMQ_REGION_SLACK_NUM
-#define BMQ_REGION_SLACK_NUM 1
+#define BMQ_REGION_SLACK_NUM 6
 #endif
 
 namespace bmq {
@@ -75,6 +79,7 @@ public:
     std::string error;
     bool built = false, broken = false;
     uint64_t generation = 0; // bumped by every rebuild: ids of different generations are unrelated
+    uint32_t slack_num = BMQ_REGION_SLACK_NUM; // region size = nodes * (1 + slack_num / 4) buckets (bmq_config.region_slack)
     bool tiny = false;       // test knob (tools/host_fuzz.cpp): minimal initial capacities, so that every growth path runs all the time
 
     // ---- arrays in exec memory ----
@@ -787,7 +792,7 @@ private:
         trie_used += slots;
         return true;
     }
-    uint32_t buckets_for(uint64_t nodes) const { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nodes + (tiny ? 0 : nodes * BMQ_REGION_SLACK_NUM / 4 + 2), tiny ? 1 : 8), 0x7FFFFFF0ull); }
+    uint32_t buckets_for(uint64_t nodes) const { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nodes + (tiny ? 0 : nodes * slack_num / 4 + 2), tiny ? 1 : 8), 0x7FFFFFF0ull); }
     // new tenant with room for `nodes` nodes; written to the host mirror (flush_directory uploads)
     bool create_tenant(const std::string& name, uint64_t nodes, uint32_t n_routes) {
         if (tenant_slot.count(name)) return true;

@@ -813,6 +813,7 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
     if (const char* v = bmq_env("BMQ_QCAP")) c.wave_queue_cap = (uint32_t)atoi(v); // profiling experiments
     if (const char* v = bmq_env("BMQ_PCAP")) c.wave_pair_cap = (uint32_t)atoi(v);
     if ((c.wave_queue_cap != 0 && c.wave_queue_cap != 128) || (c.wave_pair_cap != 0 && c.wave_pair_cap != 128)) return BMQ_E_INVAL;
+    if (c.region_slack > 64) return BMQ_E_INVAL;
     const bool smallest = c.wave_queue_cap == 128 || c.wave_pair_cap == 128;
     c.wave_queue_cap = smallest ? WALK_QC_SMALLEST : WALK_QC_DEFAULT; // (what bmq_config reports back / BatchArgs carries: the geometry in use)
     c.wave_pair_cap = smallest ? WALK_PC_SMALLEST : WALK_PC_DEFAULT;
@@ -853,9 +854,11 @@ int bmq_engine_create(const bmq_config* cfg, bmq_engine** out) {
         e->dx.device = e->dxi[0].device = e->dxi[1].device = c.device;
         e->dx.stream = e->dxi[0].stream = e->stream;
         e->dix = std::make_unique<DistIndex<DevExec>>(e->dxi[0]);
+        if (c.region_slack) e->dix->slack_num = c.region_slack;
         e->drt = std::make_unique<RetainDyn<DevExec>>(e->dx);
     } else {
         e->hix = std::make_unique<DistIndex<HostExec>>(e->hx);
+        if (c.region_slack) e->hix->slack_num = c.region_slack;
         e->hrt = std::make_unique<RetainDyn<HostExec>>(e->hx);
     }
     *out = e.release();
@@ -1049,9 +1052,11 @@ int bmq_compact_begin(bmq_engine* e) {
         bx->upload_stream = nullptr;
         e->cmp.bx = bx;
         e->cmp.next_d = std::make_unique<DistIndex<DevExec>>(*bx);
+        e->cmp.next_d->slack_num = e->dix->slack_num;
         // the sizes below are read through the serving generation's executor: behind what the engine stream holds
     } else {
         e->cmp.next_h = std::make_unique<DistIndex<HostExec>>(e->hx);
+        e->cmp.next_h->slack_num = e->hix->slack_num;
     }
     std::string msg;
     if (!with_generations(e, [&](auto& cur, auto& next) {

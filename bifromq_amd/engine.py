@@ -184,7 +184,7 @@ class Engine:
     """One engine per KV range replica (cf. DistWorkerCoProc's SubscriptionCache)."""
 
     def __init__(self, device: int = 0, wave_queue_cap: int = 0, wave_pair_cap: int = 0, slow_scratch_mb: int = 0, kernel_timing: bool = False,
-                 dedup_min_topics: int = 0, dedup_sorted: bool = False):
+                 dedup_min_topics: int = 0, dedup_sorted: bool = False, region_slack: int = 0):
         L = _lib.lib()
         cfg = _lib.Config()
         cfg.struct_size = C.sizeof(_lib.Config)
@@ -195,6 +195,7 @@ class Engine:
         cfg.kernel_timing = 1 if kernel_timing else 0
         cfg.dedup_min_topics = dedup_min_topics  # 0: default = never; n: batches of >= n topics are de-duplicated on the device first
         cfg.dedup_sorted = 1 if dedup_sorted else 0  # ... by comparing neighbours: the batches arrive ordered by (tenant index, topic)
+        cfg.region_slack = region_slack  # 0: default (6: trie regions at load factor 0.2); 1: 0.4 (less memory, more second probes)
         h = C.c_void_p()
         rc = L.bmq_engine_create(C.byref(cfg), C.byref(h))
         if rc:

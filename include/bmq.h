@@ -78,7 +78,11 @@ typedef struct bmq_config {
                                /* speed depends on the order: a row that equals no neighbour is matched on its own.  0 = hash.          */
                                /* Measured on the survey's 1 M-publish batch (profiles/r05b/): 56 us of de-duplication (hash: 125 us)  */
                                /* for 31 us less walking -- a loss there; a caller that sends every topic ONCE gains 17 %              */
-    uint32_t reserved[5];
+    uint32_t region_slack;     /* a tenant's region of the filter trie holds nodes x (1 + region_slack / 4) buckets of two 32-byte slots:    */
+                               /* 0 = default = 6 (load factor 0.2, 160 bytes of region per trie node); 1 = load factor 0.4 (64 + 16 bytes  */
+                               /* per node: the layout of rounds 2-5; k_walk is 8 % slower on the survey's workload -- more second probes), */
+                               /* up to 64.  A memory / speed trade, nothing else depends on it                                            */
+    uint32_t reserved[4];
 } bmq_config;
 
 /* Counters of the last completed match batch (for roofline accounting). */

@@ -1,0 +1,79 @@
+"""Experiment (GPU box): does the ORDER of the filters in a C4 batch matter to k_retain_walk?  The kernel hands the batch out in quads of consecutive
+filters, dynamically; its tail was read as "single heavy filters walked alone at the end" (DESIGN 7.4).  This runs bench.py's C4 batch 0 as generated,
+sorted heaviest first (by the number of topics a filter matched in a first run: the best cost estimate there is), and heaviest last.
+    python tools/c4_order_probe.py > gpurun_out/c4_order.txt"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bifromq_amd as B  # noqa: E402
+
+dev = torch.device("cuda", 0)
+seed = 0xB1F20004
+w = B.Workload(seed, 1, 1, 0)
+n_topics, n = 1_000_000, 100_000
+data, off, tt = w.retain(seed, n_topics, filters=False)
+eng = B.Engine(device=0, kernel_timing=True)
+eng.retain_rebuild(w.tenants(), tt, packed_topics=(data, off))
+tdata, toff = w.tenants_packed()
+d_tenants = torch.from_numpy(tdata.copy()).to(dev)
+d_tenant_off = torch.from_numpy(toff.astype(np.int32)).to(dev)
+fdata, foff, ft = w.retain(seed + 1, n, filters=True)
+foff = foff.astype(np.int64)
+cap = 64 * n
+d_row = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+
+
+def upload(order):
+    lens = (foff[1:] - foff[:-1])[order]
+    noff = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=noff[1:])
+    out = np.zeros(int(noff[-1]) + 32, dtype=np.uint8)
+    # gather the filters' bytes in the new order
+    src = np.repeat(foff[:-1][order], lens) + (np.arange(int(noff[-1])) - np.repeat(noff[:-1], lens))
+    out[:int(noff[-1])] = fdata[src]
+    return (torch.from_numpy(out).to(dev), torch.from_numpy(noff.astype(np.int32)).to(dev), torch.from_numpy(ft[order].astype(np.int32)).to(dev))
+
+
+def run(bt, k=8):
+    global d_ids, cap
+    ms = []
+    for _ in range(k):
+        while True:
+            eng.retain_match_batch_device(d_tenants.data_ptr(), d_tenant_off.data_ptr(), 1, bt[2].data_ptr(), bt[0].data_ptr(), bt[1].data_ptr(), n,
+                                          d_row.data_ptr(), d_ids.data_ptr(), cap, d_total.data_ptr())
+            try:
+                eng.finish()
+                break
+            except B.BmqError as ex:
+                if ex.code != -3:
+                    raise
+                cap = int(d_total.item()) * 2
+                d_ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+        st = eng.stats()
+        ms.append((st.ms_walk, st.ms_expand))
+    a = np.array(ms[2:])
+    return a.mean(axis=0), a.min(axis=0)
+
+
+ident = np.arange(n)
+base = upload(ident)
+m, mn = run(base)
+rows = d_row.cpu().numpy().astype(np.int64)
+cnt = rows[1:] - rows[:-1]
+levels = np.array([bytes(fdata[foff[i]:foff[i + 1]]).count(b"/") + 1 for i in range(n)])
+plus = np.array([bytes(fdata[foff[i]:foff[i + 1]]).split(b"/").count(b"+") for i in range(n)])
+print("as generated:        walk %.4f ms (min %.4f)  expand %.4f" % (m[0], mn[0], m[1]))
+print("matches per filter: mean %.0f p50 %.0f p99 %.0f max %d; levels mean %.2f; '+' levels mean %.2f max %d" % (cnt.mean(), np.median(cnt), np.percentile(cnt, 99), cnt.max(), levels.mean(), plus.mean(), plus.max()))
+for name, order in (("heaviest first (by matches)", np.argsort(-cnt, kind="stable")), ("heaviest last", np.argsort(cnt, kind="stable")),
+                    ("most '+' levels first", np.argsort(-plus, kind="stable")), ("shuffled", np.random.default_rng(1).permutation(n))):
+    m, mn = run(upload(order))
+    print("%-28s walk %.4f ms (min %.4f)  expand %.4f" % (name + ":", m[0], mn[0], m[1]))
+m, mn = run(base)
+print("as generated again:  walk %.4f ms (min %.4f)  expand %.4f" % (m[0], mn[0], m[1]))
