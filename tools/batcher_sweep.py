@@ -14,9 +14,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps({"threads": threads, "calls_per_s": len(tt) / sec, "topics_per_launch": st.n_topics / max(st.n_batches, 1)}))
     bt.close(); eng.close()
 else:
-    for threads in (64, 256):
-        for infl in (1, 2, 3):
-            for fan in (2, 4, 8):
+    # python tools/batcher_sweep.py [threads,...] [inflight,...] [fanout,...]   (BMQ_LIB = a -DBMQ_EXPERIMENTS=1 build: the two knobs are environment switches there only)
+    arg = lambda i, d: tuple(int(x) for x in sys.argv[i].split(",")) if len(sys.argv) > i else d
+    for threads in arg(1, (64, 256)):
+        for infl in arg(2, (1, 2, 3)):
+            for fan in arg(3, (2, 4, 8)):
                 env = dict(os.environ, BMQ_BATCHER_INFLIGHT=str(infl), BMQ_BATCHER_FANOUT=str(fan), PYTHONPATH=".")
                 r = subprocess.run([sys.executable, __file__, "child", str(threads)], env=env, capture_output=True, text=True, timeout=120)
                 print("inflight", infl, "fanout", fan, (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
