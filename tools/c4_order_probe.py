@@ -67,6 +67,9 @@ base = upload(ident)
 m, mn = run(base)
 rows = d_row.cpu().numpy().astype(np.int64)
 cnt = rows[1:] - rows[:-1]
+with open("gpurun_out/c4_block_ids.txt", "w") as fh:  # ids per 64-row block, for tools/ubench_write_skew.hip
+    pad = np.concatenate([cnt, np.zeros((-n) % 64, dtype=cnt.dtype)])
+    fh.write("\n".join(str(int(x)) for x in pad.reshape(-1, 64).sum(axis=1)) + "\n")
 levels = np.array([bytes(fdata[foff[i]:foff[i + 1]]).count(b"/") + 1 for i in range(n)])
 plus = np.array([bytes(fdata[foff[i]:foff[i + 1]]).split(b"/").count(b"+") for i in range(n)])
 print("as generated:        walk %.4f ms (min %.4f)  expand %.4f" % (m[0], mn[0], m[1]))
