@@ -942,12 +942,15 @@ def compaction_leg(args, eng, step, torch, np, fetch_csr=None):
 
     from tests import util as U
 
+    stamps = []  # (start of a clocked batch, its duration in ms): where the slowest batch of the compaction fell
+
     def clocked(k, base=0):
         out = []
         for i in range(k):
             t0 = time.perf_counter()
             step(base + i)
             out.append((time.perf_counter() - t0) * 1e3)
+            stamps.append((t0, out[-1]))
         return out
 
     def pct(v):
@@ -963,7 +966,7 @@ def compaction_leg(args, eng, step, torch, np, fetch_csr=None):
     t_begin = time.perf_counter()
     eng.compact_begin()
     begin_ms = (time.perf_counter() - t_begin) * 1e3
-    poll_ms, failure = [], []
+    poll_ms, poll_t0, failure = [], [], []
 
     def compactor():
         try:
@@ -975,12 +978,14 @@ def compaction_leg(args, eng, step, torch, np, fetch_csr=None):
                 done = eng.compact_poll(args.compact_chunk)
                 dt = time.perf_counter() - t0
                 poll_ms.append(dt * 1e3)
+                poll_t0.append(t0)
                 time.sleep(dt * (1.0 - args.compact_duty) / max(args.compact_duty, 1e-3))
         except Exception as ex:  # noqa: BLE001
             failure.append(repr(ex))
 
     th = threading.Thread(target=compactor)
     t0 = time.perf_counter()
+    del stamps[:]
     th.start()
     during, i = [], 0
     while th.is_alive():
@@ -991,6 +996,13 @@ def compaction_leg(args, eng, step, torch, np, fetch_csr=None):
     if failure:
         eng.compact_abort()
         return {"error": failure[0]}
+    # the slowest batch of the compaction: when it ran, and which bmq_compact_poll was in progress then (the three slowest, for the pattern)
+    slowest = []
+    for ts, ms in sorted(stamps, key=lambda x: -x[1])[:3]:
+        k = int(np.searchsorted(np.asarray(poll_t0), ts, side="right")) - 1
+        inside = k >= 0 and ts < poll_t0[k] + poll_ms[k] * 1e-3
+        slowest.append({"ms": float(ms), "s_after_the_first_poll": float(ts - poll_t0[0]) if poll_t0 else None, "poll_no": k,
+                        "inside_that_poll": bool(inside), "that_poll_ms": float(poll_ms[k]) if k >= 0 else None})
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     carried, replayed = eng.compact_swap()
@@ -1000,7 +1012,7 @@ def compaction_leg(args, eng, step, torch, np, fetch_csr=None):
     out = {"what": "bmq_compact_begin / _poll(%d ids) / _swap while 1 M-publish batches are matched back to back by another thread" % args.compact_chunk,
            "batch_ms_idle": pct(idle), "batch_ms_while_compacting": pct(during), "batch_ms_after_swap": pct(after_idle),
            "p99_ratio": pct(during)["p99"] / pct(idle)["p99"], "poll_ms": pct(poll_ms), "polls": len(poll_ms), "duty": args.compact_duty,
-           "begin_ms": begin_ms, "build_s": build_s, "swap_ms": swap_ms, "keys_carried": int(carried), "ops_replayed": int(replayed),
+           "slowest_batches_while_compacting": slowest, "begin_ms": begin_ms, "build_s": build_s, "swap_ms": swap_ms, "keys_carried": int(carried), "ops_replayed": int(replayed),
            "before": {"n_routes": int(info0.n_routes), "next_route_id": int(info0.next_route_id), "garbage_bytes": int(info0.garbage_bytes),
                       "device_bytes": int(info0.device_bytes), "generation": int(info0.generation)},
            "after": {"n_routes": int(info1.n_routes), "next_route_id": int(info1.next_route_id), "garbage_bytes": int(info1.garbage_bytes),
