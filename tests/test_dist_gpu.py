@@ -301,7 +301,7 @@ def test_in_batch_dedup_changes_nothing_but_the_work():
             o = sorted(range(len(topics)), key=lambda i: tt[i])
             topics, tt, exp = [topics[i] for i in o], [tt[i] for i in o], [exp[i] for i in o]
         stats = []
-        for dd, geom in ((1, {}), (0xFFFFFFFF, {}), (1, dict(wave_queue_cap=128, wave_pair_cap=128, slow_scratch_mb=1))):
+        for dd, geom in ((1, {}), (0xFFFFFFFF, dict(region_slack=1)), (1, dict(wave_queue_cap=128, wave_pair_cap=128, slow_scratch_mb=1))):  # (region_slack = 1: the regions of rounds 2-5, load factor 0.4)
             e = B.Engine(device=0, dedup_min_topics=dd, **geom).rebuild(keys)
             row, ids = e.match_batch(tnames, tt, topics)
             assert U.csr_rows(row, ids) == exp

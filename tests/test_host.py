@@ -416,6 +416,26 @@ def test_walk_geometry_caps_are_a_selector():
         assert ei.value.code == -1  # BMQ_E_INVAL
 
 
+def test_region_slack_sizes_the_trie_regions():
+    """bmq_config.region_slack: a tenant's region holds nodes x (1 + slack / 4) two-slot buckets -- 0 = the default (6: load factor 0.2), 1 = the layout of
+    rounds 2-5 (0.4); more than 64 is refused.  Only the table size depends on it (the walk's results are compared on the GPU: tests/test_dist_gpu.py)."""
+    keys = sorted(B.route_key("t%d" % (i % 3), "a/%d/+/x%d" % (i % 50, i), 1, "0\0r%d\0d" % i) for i in range(3000))
+    slots = {}
+    for slack in (0, 1, 6, 12):
+        e = B.Engine(device=-1, region_slack=slack).rebuild(keys)
+        info = e.info()
+        slots[slack] = (int(info.trie_slots), int(info.n_nodes), int(info.n_routes))
+        e.close()
+    assert slots[0] == slots[6] and slots[1][1:] == slots[6][1:] == slots[12][1:]
+    n_nodes = slots[6][1]
+    assert slots[1][0] < slots[6][0] < slots[12][0]
+    assert 2 * 1.2 * n_nodes <= slots[1][0] <= 2 * 1.3 * n_nodes + 64   # nodes x 1.25 buckets of two slots (+ a few buckets per tenant)
+    assert 2 * 2.4 * n_nodes <= slots[6][0] <= 2 * 2.6 * n_nodes + 64   # nodes x 2.5
+    with pytest.raises(B.BmqError) as ei:
+        B.Engine(device=-1, region_slack=65)
+    assert ei.value.code == -1  # BMQ_E_INVAL
+
+
 def test_ops_of_one_batch_apply_in_order_also_when_the_filter_is_new():
     """tests/test_dist_gpu.py's test of the same name over the host executor (its par() runs the ops of a large batch on several threads)."""
     import bifromq_amd as B
