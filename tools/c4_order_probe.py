@@ -78,5 +78,20 @@ for name, order in (("heaviest first (by matches)", np.argsort(-cnt, kind="stabl
                     ("most '+' levels first", np.argsort(-plus, kind="stable")), ("shuffled", np.random.default_rng(1).permutation(n))):
     m, mn = run(upload(order))
     print("%-28s walk %.4f ms (min %.4f)  expand %.4f" % (name + ":", m[0], mn[0], m[1]))
+# the floor a single wave sets: the heaviest filters alone (a batch of k filters: the kernel's time is its slowest wave's)
+for k in (1, 8, 64, 1024):
+    order = np.argsort(-cnt, kind="stable")[:k]
+    lens = (foff[1:] - foff[:-1])[order]
+    noff = np.zeros(k + 1, dtype=np.int64)
+    np.cumsum(lens, out=noff[1:])
+    out = np.zeros(int(noff[-1]) + 32, dtype=np.uint8)
+    src = np.repeat(foff[:-1][order], lens) + (np.arange(int(noff[-1])) - np.repeat(noff[:-1], lens))
+    out[:int(noff[-1])] = fdata[src]
+    bt = (torch.from_numpy(out).to(dev), torch.from_numpy(noff.astype(np.int32)).to(dev), torch.from_numpy(ft[order].astype(np.int32)).to(dev))
+    n_save = n
+    n = k
+    m, mn = run(bt)
+    n = n_save
+    print("the %4d heaviest filters alone (%.0f matches each on average): walk %.4f ms (min %.4f)  expand %.4f" % (k, cnt[order].mean(), m[0], mn[0], m[1]))
 m, mn = run(base)
 print("as generated again:  walk %.4f ms (min %.4f)  expand %.4f" % (m[0], mn[0], m[1]))
