@@ -93,5 +93,44 @@ for k in (1, 8, 64, 1024):
     m, mn = run(bt)
     n = n_save
     print("the %4d heaviest filters alone (%.0f matches each on average): walk %.4f ms (min %.4f)  expand %.4f" % (k, cnt[order].mean(), m[0], mn[0], m[1]))
+# which SHAPE of filter carries the walk's time: batches of one class each (the level of the '+', '#' at the end or not).  Two batch sizes: 100 k filters drawn from the
+# class (throughput) and 2048 (one quad per wave at most: the time is the class's slowest filters')
+split = [bytes(fdata[foff[i]:foff[i + 1]]).split(b"/") for i in range(n)]
+ppos = np.array([lv.index(b"+") if b"+" in lv else -1 for lv in split])
+hashed = np.array([lv[-1] == b"#" for lv in split])
+rng = np.random.default_rng(7)
+
+
+def run_subset(order):
+    global n
+    k = len(order)
+    lens = (foff[1:] - foff[:-1])[order]
+    noff = np.zeros(k + 1, dtype=np.int64)
+    np.cumsum(lens, out=noff[1:])
+    out = np.zeros(int(noff[-1]) + 32, dtype=np.uint8)
+    src = np.repeat(foff[:-1][order], lens) + (np.arange(int(noff[-1])) - np.repeat(noff[:-1], lens))
+    out[:int(noff[-1])] = fdata[src]
+    bt = (torch.from_numpy(out).to(dev), torch.from_numpy(noff.astype(np.int32)).to(dev), torch.from_numpy(ft[order].astype(np.int32)).to(dev))
+    n_save, n = n, k
+    try:
+        return run(bt, k=5)
+    except B.BmqError as ex:
+        if ex.code != -6:
+            raise
+        return (np.array([float("nan"), float("nan")]), None)
+    finally:
+        n = n_save
+
+
+print("class: '+' at level, '#' at the end | share of the batch | mean matches | walk ms: 100 k filters of the class / 2048 of them / the 2048 with the most matches | ")
+for pp in range(-1, 8):
+    for hh in (False, True):
+        idx = np.nonzero((ppos == pp) & (hashed == hh))[0]
+        if len(idx) < 200:
+            continue
+        big = run_subset(rng.choice(idx, 100_000 if not hh or pp < 0 else 20_000, replace=True))[0]
+        small = run_subset(rng.choice(idx, 2048, replace=False if len(idx) >= 2048 else True))[0]
+        top = run_subset(idx[np.argsort(-cnt[idx], kind="stable")[:2048]])[0]
+        print("  '+' at %2d  '#' %-5s  %5.1f %%  matches %9.0f   walk %.4f (%s filters) / %.4f / %.4f ms" % (pp, hh, 100.0 * len(idx) / n, cnt[idx].mean(), big[0], "100 k" if not hh or pp < 0 else "20 k", small[0], top[0]))
 m, mn = run(base)
 print("as generated again:  walk %.4f ms (min %.4f)  expand %.4f" % (m[0], mn[0], m[1]))
