@@ -25,6 +25,10 @@ final class NativeMatcher {
      *  device by comparing neighbours (every row keeps its own row in the result).  matchAll(Set) callers need none of it: a set has no repeats. */
     static native long createOrdered(int device, int dedupMinTopics);
 
+    /** bmq_config.region_slack: the filter trie's regions hold nodes x (1 + regionSlack / 4) buckets -- 0: the default (6, load factor 0.2),
+     *  1: half the region memory for about 8 % more time in the match kernel (INTEGRATION.md, "Memory against speed"). */
+    static native long createCompact(int device, int regionSlack);
+
     static native void destroy(long engine);
 
     /** IKVRangeCoProc.reset(): all route keys of the range (a KV scan: ascending; route id = rank).  Built on the GPU. */

@@ -72,6 +72,22 @@ JNIEXPORT jlong JNICALL NM(createOrdered)(JNIEnv* env, jclass c, jint device, ji
     }
     return (jlong)(intptr_t)e;
 }
+/* long createCompact(int device, int regionSlack)   -- bmq_config.region_slack: memory against speed.  The filter trie's per-tenant regions hold
+ * nodes x (1 + regionSlack / 4) buckets; 0 = the default (6: load factor 0.2), 1 = half the region memory for ~8 % more time in the match kernel */
+JNIEXPORT jlong JNICALL NM(createCompact)(JNIEnv* env, jclass c, jint device, jint regionSlack) {
+    (void)c;
+    bmq_config cfg = {0};
+    cfg.struct_size = sizeof cfg;
+    cfg.device = device;
+    cfg.region_slack = regionSlack > 0 ? (uint32_t)regionSlack : 0u;
+    bmq_engine* e = NULL;
+    const int rc = bmq_engine_create(&cfg, &e);
+    if (rc != BMQ_OK) {
+        throw_state(env, NULL, "bmq_engine_create (a gfx950 device is required; regionSlack <= 64)", rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)e;
+}
 /* void destroy(long engine) */
 JNIEXPORT void JNICALL NM(destroy)(JNIEnv* env, jclass c, jlong h) {
     (void)env, (void)c;
