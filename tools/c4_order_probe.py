@@ -132,5 +132,26 @@ for pp in range(-1, 8):
         small = run_subset(rng.choice(idx, 2048, replace=False if len(idx) >= 2048 else True))[0]
         top = run_subset(idx[np.argsort(-cnt[idx], kind="stable")[:2048]])[0]
         print("  '+' at %2d  '#' %-5s  %5.1f %%  matches %9.0f   walk %.4f (%s filters) / %.4f / %.4f ms" % (pp, hh, 100.0 * len(idx) / n, cnt[idx].mean(), big[0], "100 k" if not hh or pp < 0 else "20 k", small[0], top[0]))
+# longest-job-first with the cost a pre-pass could know: the size of the frontier behind the filter's '+' (distinct children of its literal prefix among the
+# retained topics) x the levels that follow it -- computed here on the host from the topics
+t0 = time.time()
+kids = {}
+tb = bytes(data)
+for i in range(n_topics):
+    lv = tb[off[i]:off[i + 1]].split(b"/")
+    for k in range(len(lv)):
+        kids.setdefault(b"/".join(lv[:k]), set()).add(lv[k])
+cost = np.zeros(n)
+for i, lv in enumerate(split):
+    if b"+" in lv:
+        pp = lv.index(b"+")
+        tail = len(lv) - 1 - pp - (1 if lv[-1] == b"#" else 0)
+        cost[i] = len(kids.get(b"/".join(lv[:pp]), ())) * max(tail, 0)
+print("cost estimate (frontier behind the '+' x literal levels behind it): mean %.1f p99 %.0f max %.0f; %d filters above 256, %d above 1024  (%.0f s on the host)" % (cost.mean(), np.percentile(cost, 99), cost.max(), int((cost > 256).sum()), int((cost > 1024).sum()), time.time() - t0))
+for name, order in (("costliest first (all sorted)", np.argsort(-cost, kind="stable")),
+                    ("the filters above 256 first, the rest as generated", np.concatenate([np.nonzero(cost > 256)[0][np.argsort(-cost[cost > 256], kind="stable")], np.nonzero(cost <= 256)[0]])),
+                    ("costliest last", np.argsort(cost, kind="stable"))):
+    m, mn = run(upload(order))
+    print("%-52s walk %.4f ms (min %.4f)  expand %.4f" % (name + ":", m[0], mn[0], m[1]))
 m, mn = run(base)
 print("as generated again:  walk %.4f ms (min %.4f)  expand %.4f" % (m[0], mn[0], m[1]))
