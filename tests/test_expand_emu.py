@@ -78,3 +78,23 @@ def test_the_match_kernels_of_the_dist_direction_under_the_wave_emulator(tmp_pat
     r = subprocess.run([exe, "16", str(seed)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.startswith("walk emu ok:"), r.stdout
+
+
+def test_the_work_list_simulator_reproduces_the_kernel_and_ranks_the_orders(tmp_path):
+    """tools/sched_sim.cpp (planning tool of round 6): replays the drain of k_walk's work list on an index the product's builder makes and counts rounds per wave
+    for different orders of taking the items.  Kept honest here: the kernel's own order (one stack, depth first, 176 slots with parking) must come out at the
+    14-16 rounds per wave the GPU measures (15.5-15.7), the two-stack order and the full order by levels behind an item below it, in that order."""
+    exe = str(tmp_path / "sched_sim")
+    csrc = os.path.join(ROOT, "bifromq_amd", "csrc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", csrc, os.path.join(ROOT, "tools", "sched_sim.cpp"), os.path.join(csrc, "bmq_gen.cpp"),
+                    os.path.join(csrc, "bmq_codec.cpp"), "-o", exe], check=True, capture_output=True, text=True)
+    r = subprocess.run([exe, "4", "8000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rounds = {}
+    for line in r.stdout.splitlines():
+        name, _, rest = line.partition("waves ")
+        if "rounds/wave" in rest:
+            rounds[name.strip()] = float(rest.split("rounds/wave")[1].split()[0])
+    assert 14.0 <= rounds["lifo QC176 park"] <= 16.5, rounds
+    assert rounds["rem"] < rounds["two stacks rem>=3"] < rounds["lifo"], rounds
+    assert rounds["rem"] < 12.0, rounds
