@@ -153,5 +153,27 @@ for name, order in (("costliest first (all sorted)", np.argsort(-cost, kind="sta
                     ("costliest last", np.argsort(cost, kind="stable"))):
     m, mn = run(upload(order))
     print("%-52s walk %.4f ms (min %.4f)  expand %.4f" % (name + ":", m[0], mn[0], m[1]))
+# is it CLUMPING -- waves that happen to hold two or three costly filters at once?  The costly filters (estimate above 1024) dealt out evenly instead of where chance puts them
+hv = np.nonzero(cost > 1024)[0]
+hv = hv[np.argsort(-cost[hv], kind="stable")]
+lt = np.nonzero(cost <= 1024)[0]
+def interleave(step, lead):  # one costly filter at the head of every `step`-th quad from quad `lead` on, light filters everywhere else
+    out, li, hi = [], 0, 0
+    q = 0
+    while li < len(lt) or hi < len(hv):
+        quad = []
+        if hi < len(hv) and q >= lead and (q - lead) % step == 0:
+            quad.append(hv[hi]); hi += 1
+        while len(quad) < 4 and li < len(lt):
+            quad.append(lt[li]); li += 1
+        if not quad:
+            quad = list(hv[hi:hi + 4]); hi += len(quad)
+        out.extend(quad); q += 1
+    return np.array(out)
+for name, order in (("one costly filter per quad, from the first quad on", interleave(1, 0)), ("one per 2nd quad", interleave(2, 0)), ("one per 4th quad (spread over the whole batch)", interleave(4, 0)),
+                    ("one per quad, behind 8192 quads of light filters", interleave(1, 8192))):
+    assert len(order) == n and len(set(order.tolist())) == n
+    m, mn = run(upload(order))
+    print("%-62s walk %.4f ms (min %.4f)  expand %.4f" % (name + ":", m[0], mn[0], m[1]))
 m, mn = run(base)
 print("as generated again:  walk %.4f ms (min %.4f)  expand %.4f" % (m[0], mn[0], m[1]))
