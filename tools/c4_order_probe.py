@@ -175,5 +175,9 @@ for name, order in (("one costly filter per quad, from the first quad on", inter
     assert len(order) == n and len(set(order.tolist())) == n
     m, mn = run(upload(order))
     print("%-62s walk %.4f ms (min %.4f)  expand %.4f" % (name + ":", m[0], mn[0], m[1]))
+# floor or slope?  prefixes of the batch as generated
+for k in (1563, 3125, 6250, 12500, 25000, 50000, 100000):
+    m = run_subset(np.arange(k))[0]
+    print("the first %6d filters of the batch: walk %.4f ms  expand %.4f" % (k, m[0], m[1]))
 m, mn = run(base)
 print("as generated again:  walk %.4f ms (min %.4f)  expand %.4f" % (m[0], mn[0], m[1]))
